@@ -1,0 +1,104 @@
+// Common device/host utilities for the gfx950 (MI355X, CDNA4) kernels.  wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/emo_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define EMO_WAVE 64
+
+// ---------------------------------------------------------------- error handling (thread-local message)
+void emo_set_error(const char* fmt, ...);
+#define EMO_CHECK(cond, ...)                       \
+    do {                                           \
+        if (!(cond)) {                             \
+            emo_set_error(__VA_ARGS__);            \
+            return EMO_ERR_INVALID;                \
+        }                                          \
+    } while (0)
+#define EMO_LAUNCH_CHECK()                                                   \
+    do {                                                                     \
+        hipError_t e__ = hipGetLastError();                                  \
+        if (e__ != hipSuccess) {                                             \
+            emo_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,     \
+                          hipGetErrorString(e__));                           \
+            return EMO_ERR_LAUNCH;                                           \
+        }                                                                    \
+    } while (0)
+
+// ---------------------------------------------------------------- scalar conversion helpers
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// ---------------------------------------------------------------- counter-based dropout RNG
+// One 32-bit hash per PAIR of elements (16 random bits each).  keep iff bits >= thr16,
+// thr16 = round(p * 65536).  Forward and backward regenerate the same mask from
+// (seed, offset, linear element index) — nothing is stored.
+__host__ __device__ __forceinline__ uint32_t emo_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+struct DropCtx {
+    uint32_t key;    // mixed (seed, offset)
+    uint32_t thr16;  // 0 => dropout disabled
+    float scale;     // 1/(1-p)
+};
+__host__ __device__ __forceinline__ DropCtx make_drop(float p, uint64_t seed, uint64_t offset) {
+    DropCtx d;
+    d.thr16 = p > 0.f ? (uint32_t)(p * 65536.f + 0.5f) : 0u;
+    d.scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    uint32_t k = emo_hash32((uint32_t)seed ^ 0x9E3779B9u);
+    k = emo_hash32(k ^ (uint32_t)(seed >> 32));
+    k = emo_hash32(k ^ (uint32_t)offset * 0x85EBCA6Bu ^ (uint32_t)(offset >> 32));
+    d.key = k;
+    return d;
+}
+// multiplier (0 or scale) for linear element index idx
+__host__ __device__ __forceinline__ float drop_mult(const DropCtx& d, uint64_t idx) {
+    if (d.thr16 == 0u) return 1.f;
+    uint32_t pair = (uint32_t)(idx >> 1) ^ (uint32_t)(idx >> 33) * 0x9E3779B1u;
+    uint32_t h = emo_hash32(pair * 0x9E3779B1u + d.key);
+    uint32_t bits = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
+    return bits >= d.thr16 ? d.scale : 0.f;
+}
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_new_f(float x) {
+    const float c = 0.7978845608028654f;  // sqrt(2/pi)
+    return 0.5f * x * (1.f + tanhf(c * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float dgelu_new_f(float x) {
+    const float c = 0.7978845608028654f;
+    float u = c * (x + 0.044715f * x * x * x);
+    float t = tanhf(u);
+    return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * c * (1.f + 3.f * 0.044715f * x * x);
+}
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

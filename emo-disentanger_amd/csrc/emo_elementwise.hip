@@ -1,0 +1,622 @@
+// HBM-bound kernels of the path: K1 embedding prologue (fwd/bwd), K6 LayerNorm (fwd/bwd),
+// dropout re-application, K9 cross-entropy (fwd/bwd), K12 accuracy counts, optimizer plumbing
+// (sum of squares, clip coefficient, Adam, dtype cast).  All are one-pass, 16-B-per-lane
+// coalesced streams with wave64 shuffle reductions; none is reshaped into a GEMM.
+#include <stdarg.h>
+
+#include "emo_common.h"
+
+// ------------------------------------------------------------------------------------------------ errors / misc
+static thread_local char g_err[512] = "";
+void emo_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* emo_last_error(void) { return g_err; }
+extern "C" int emo_version(void) { return 100; }
+extern "C" int emo_device_cus(void) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    return n;
+}
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { f32x4 t = *(const f32x4*)p; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]}; }
+};
+template <> struct Vec4<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) { bf16x4 t = *(const bf16x4*)p; v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3]; }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) { bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; *(bf16x4*)p = t; }
+};
+
+// ================================================================================================ K1 embedding
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ seg,
+                                                        const float* __restrict__ E, const float* __restrict__ S,
+                                                        const float* __restrict__ pe, T* __restrict__ out, int64_t M, int64_t T_len,
+                                                        int64_t D, int64_t pos0, float scale, DropCtx drop) {
+    const int64_t d4 = D >> 2, total = M * d4;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = it / d4, c = (it - row * d4) << 2;
+        const int64_t t = row % T_len;
+        float e[4], s[4] = {0, 0, 0, 0}, p[4], o[4];
+        Vec4<float>::load(E + tok[row] * D + c, e);
+        if (seg) Vec4<float>::load(S + seg[row] * D + c, s);
+        Vec4<float>::load(pe + (pos0 + t) * D + c, p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // reference order: emb.mul_(scale); emb += seg.mul_(scale); + pe
+            float v = e[i] * scale;
+            v += s[i] * scale;
+            v += p[i];
+            o[i] = v * drop_mult(drop, (uint64_t)(row * D + c + i));
+        }
+        Vec4<T>::store(out + row * D + c, o);
+    }
+}
+
+extern "C" int emo_embed_fwd(const int64_t* tok, const int64_t* seg, const float* E, const float* S, const float* pe,
+                             void* out, int dtype, int64_t B, int64_t T, int64_t D, int64_t V, int64_t n_seg, int64_t pos0,
+                             float scale, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
+    (void)V; (void)n_seg;
+    EMO_CHECK(tok && E && pe && out, "emo_embed_fwd: null pointer");
+    EMO_CHECK((D & 3) == 0, "emo_embed_fwd: D must be a multiple of 4");
+    EMO_CHECK(!(seg && !S), "emo_embed_fwd: seg ids without a segment table");
+    const int64_t M = B * T, total = M * (D >> 2);
+    int64_t blocks = cdiv64(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    DropCtx drop = make_drop(p_drop, seed, offset);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EMO_F32) hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, tok, seg, E, S, pe, (float*)out, M, T, D, pos0, scale, drop);
+    else hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, tok, seg, E, S, pe, (bf16_t*)out, M, T, D, pos0, scale, drop);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
+// backward: block = (64-column slice) x (token chunk); per-block LDS table [(V+n_seg) x 64] fp32
+// accumulated with ds_add_f32, flushed once with global atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ seg,
+                                                        const T* __restrict__ dout, float* __restrict__ dE, float* __restrict__ dS,
+                                                        int64_t M, int64_t D, int64_t V, int64_t n_seg, int64_t rows_per_block,
+                                                        float scale, DropCtx drop) {
+    extern __shared__ float tab[];  // (V + n_seg) * 64
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t rows_tab = V + n_seg;
+    for (int64_t i = threadIdx.x; i < rows_tab * 64; i += 256) tab[i] = 0.f;
+    __syncthreads();
+    const int64_t mbeg = (int64_t)blockIdx.y * rows_per_block;
+    int64_t mend = mbeg + rows_per_block;
+    if (mend > M) mend = M;
+    if (col < D) {
+        for (int64_t m = mbeg + wave; m < mend; m += 4) {
+            float g = to_f32<T>(dout[m * D + col]) * drop_mult(drop, (uint64_t)(m * D + col)) * scale;
+            atomicAdd(&tab[tok[m] * 64 + lane], g);
+            if (seg) atomicAdd(&tab[(V + seg[m]) * 64 + lane], g);
+        }
+    }
+    __syncthreads();
+    if (col < D) {
+        for (int64_t r = wave; r < rows_tab; r += 4) {
+            float v = tab[r * 64 + lane];
+            if (v != 0.f) {
+                if (r < V) atomicAdd(dE + r * D + col, v);
+                else atomicAdd(dS + (r - V) * D + col, v);
+            }
+        }
+    }
+}
+
+extern "C" int emo_embed_bwd(const int64_t* tok, const int64_t* seg, const void* dout, int dtype, float* dE, float* dS,
+                             int64_t B, int64_t T, int64_t D, int64_t V, int64_t n_seg, float scale, float p_drop,
+                             uint64_t seed, uint64_t offset, emo_stream_t stream) {
+    EMO_CHECK(tok && dout && dE, "emo_embed_bwd: null pointer");
+    if (!seg) n_seg = 0;
+    EMO_CHECK(!(seg && !dS), "emo_embed_bwd: seg ids without dS");
+    const size_t lds = (size_t)(V + n_seg) * 64 * sizeof(float);
+    EMO_CHECK(lds <= 160 * 1024, "emo_embed_bwd: vocabulary of %lld rows does not fit the LDS table", (long long)(V + n_seg));
+    const int64_t M = B * T;
+    int64_t rpb = 2048;
+    if (rpb > M) rpb = M;
+    dim3 grid((unsigned)cdiv64(D, 64), (unsigned)cdiv64(M, rpb));
+    DropCtx drop = make_drop(p_drop, seed, offset);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EMO_F32) {
+        static bool a = false;
+        if (!a) { (void)hipFuncSetAttribute((const void*)embed_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a = true; }
+        hipLaunchKernelGGL(embed_bwd_kernel<float>, grid, dim3(256), lds, st, tok, seg, (const float*)dout, dE, dS, M, D, V, n_seg, rpb, scale, drop);
+    } else {
+        static bool a = false;
+        if (!a) { (void)hipFuncSetAttribute((const void*)embed_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a = true; }
+        hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, grid, dim3(256), lds, st, tok, seg, (const bf16_t*)dout, dE, dS, M, D, V, n_seg, rpb, scale, drop);
+    }
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
+// ================================================================================================ K6 LayerNorm
+// one wave per row; lane owns columns {lane*4 + 256*j}, j < NV (D <= 256*NV), kept in registers.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int64_t M,
+                                                            int64_t D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float v[NV][4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int64_t c = lane * 4 + 256 * j;
+        if (c < D) Vec4<T>::load(x + row * D + c, v[j]);
+        else v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
+        s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int64_t c = lane * 4 + 256 * j;
+        if (c < D) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { float d = v[j][i] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int64_t c = lane * 4 + 256 * j;
+        if (c < D) {
+            float g[4], b[4], o[4];
+            Vec4<float>::load(gamma + c, g);
+            Vec4<float>::load(beta + c, b);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (v[j][i] - mu) * rs * g[i] + b[i];
+            Vec4<T>::store(y + row * D + c, o);
+        }
+    }
+}
+
+extern "C" int emo_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                 int dtype, int64_t M, int64_t D, float eps, emo_stream_t stream) {
+    EMO_CHECK(x && gamma && beta && y && mean && rstd, "emo_layernorm_fwd: null pointer");
+    EMO_CHECK((D & 3) == 0 && D <= 1024, "emo_layernorm_fwd: D must be a multiple of 4 and <= 1024 (got %lld)", (long long)D);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)cdiv64(M, 4));
+#define LN_FWD(TT, NVV) hipLaunchKernelGGL((layernorm_fwd_kernel<TT, NVV>), grid, dim3(256), 0, st, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, M, D, eps)
+    const int nv = (int)cdiv64(D, 256);
+    if (dtype == EMO_F32) { if (nv <= 1) LN_FWD(float, 1); else if (nv == 2) LN_FWD(float, 2); else LN_FWD(float, 4); }
+    else { if (nv <= 1) LN_FWD(bf16_t, 1); else if (nv == 2) LN_FWD(bf16_t, 2); else LN_FWD(bf16_t, 4); }
+#undef LN_FWD
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
+// backward: wave per row (grid-stride over rows), per-lane dgamma/dbeta partials kept in registers
+// over all rows of the block, reduced across the block's 4 waves in LDS, one atomic per column.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                            T* __restrict__ dx, T* __restrict__ dx_drop, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int64_t M, int64_t D, DropCtx drop) {
+    __shared__ float red[2][4][256 * NV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[NV][4], dg[NV][4], db[NV][4];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int64_t c = lane * 4 + 256 * j;
+        if (c < D) Vec4<float>::load(gamma + c, g[j]);
+        else g[j][0] = g[j][1] = g[j][2] = g[j][3] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dg[j][i] = db[j][i] = 0.f;
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float gy[NV][4], xh[NV][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int64_t c = lane * 4 + 256 * j;
+            if (c < D) {
+                float a[4], b[4];
+                Vec4<T>::load(dy + row * D + c, a);
+                Vec4<T>::load(x + row * D + c, b);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xh[j][i] = (b[i] - mu) * rs;
+                    dg[j][i] += a[i] * xh[j][i];
+                    db[j][i] += a[i];
+                    gy[j][i] = a[i] * g[j][i];
+                    s1 += gy[j][i];
+                    s2 += gy[j][i] * xh[j][i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gy[j][i] = xh[j][i] = 0.f;
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int64_t c = lane * 4 + 256 * j;
+            if (c < D) {
+                float o[4], r[4] = {0, 0, 0, 0};
+                if (dres) Vec4<T>::load(dres + row * D + c, r);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = rs * (gy[j][i] - s1 - xh[j][i] * s2) + r[i];
+                Vec4<T>::store(dx + row * D + c, o);
+                if (dx_drop) {
+                    // the consumer re-reads dx in storage precision: mask the ROUNDED value
+                    float od[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) od[i] = to_f32<T>(from_f32<T>(o[i])) * drop_mult(drop, (uint64_t)(row * D + c + i));
+                    Vec4<T>::store(dx_drop + row * D + c, od);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            red[0][wave][j * 256 + lane * 4 + i] = dg[j][i];
+            red[1][wave][j * 256 + lane * 4 + i] = db[j][i];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 256 * NV; c += 256) {
+        if (c < D) {
+            atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+            atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        }
+    }
+}
+
+extern "C" int emo_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                 const void* dres, void* dx, void* dx_drop, float* dgamma, float* dbeta, int dtype, int64_t M,
+                                 int64_t D, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
+    EMO_CHECK(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "emo_layernorm_bwd: null pointer");
+    EMO_CHECK((D & 3) == 0 && D <= 1024, "emo_layernorm_bwd: D must be a multiple of 4 and <= 1024 (got %lld)", (long long)D);
+    hipStream_t st = (hipStream_t)stream;
+    int64_t blocks = cdiv64(M, 4);
+    if (blocks > 1024) blocks = 1024;
+    dim3 grid((unsigned)blocks);
+    DropCtx drop = make_drop(p_drop, seed, offset);
+#define LN_BWD(TT, NVV) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NVV>), grid, dim3(256), 0, st, (const TT*)dy, (const TT*)x, gamma, mean, rstd, (const TT*)dres, (TT*)dx, (TT*)dx_drop, dgamma, dbeta, M, D, drop)
+    const int nv = (int)cdiv64(D, 256);
+    if (dtype == EMO_F32) { if (nv <= 1) LN_BWD(float, 1); else if (nv == 2) LN_BWD(float, 2); else LN_BWD(float, 4); }
+    else { if (nv <= 1) LN_BWD(bf16_t, 1); else if (nv == 2) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4); }
+#undef LN_BWD
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ dropout re-apply
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t n, DropCtx drop) {
+    const int64_t n4 = n >> 2;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < n4; it += (int64_t)gridDim.x * blockDim.x) {
+        float v[4];
+        Vec4<T>::load(x + it * 4, v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] *= drop_mult(drop, (uint64_t)(it * 4 + i));
+        Vec4<T>::store(out + it * 4, v);
+    }
+}
+extern "C" int emo_dropout_apply(const void* x, void* out, int dtype, int64_t n, float p_drop, uint64_t seed, uint64_t offset,
+                                 emo_stream_t stream) {
+    EMO_CHECK(x && out && (n & 3) == 0, "emo_dropout_apply: bad args (n must be a multiple of 4)");
+    int64_t blocks = cdiv64(n >> 2, 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    DropCtx drop = make_drop(p_drop, seed, offset);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EMO_F32) hipLaunchKernelGGL(dropout_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (float*)out, n, drop);
+    else hipLaunchKernelGGL(dropout_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, n, drop);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
+// ================================================================================================ K9 cross-entropy
+__global__ __launch_bounds__(256) void xent_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ tgt, int64_t M,
+                                                       int64_t V, int64_t ignore, float* __restrict__ row_lse, float* __restrict__ acc) {
+    __shared__ float part[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float lsum = 0.f, lcnt = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+        const float* l = logits + row * V;
+        float mx = -INFINITY;
+        for (int64_t c = lane; c < V; c += 64) mx = fmaxf(mx, l[c]);
+        mx = wave_max(mx);
+        float s = 0.f;
+        for (int64_t c = lane; c < V; c += 64) s += expf(l[c] - mx);
+        s = wave_sum(s);
+        const float lse = mx + logf(s);
+        if (lane == 0) {
+            row_lse[row] = lse;
+            const int64_t t = tgt[row];
+            if (t != ignore) { lsum += lse - l[t]; lcnt += 1.f; }
+        }
+    }
+    if (lane == 0) { part[0][wave] = lsum; part[1][wave] = lcnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(acc, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
+        atomicAdd(acc + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+    }
+}
+extern "C" int emo_xent_fwd(const float* logits, const int64_t* tgt, int64_t M, int64_t V, int64_t ignore_index, float* row_lse,
+                            float* acc, emo_stream_t stream) {
+    EMO_CHECK(logits && tgt && row_lse && acc, "emo_xent_fwd: null pointer");
+    int64_t blocks = cdiv64(M, 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(xent_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, tgt, M, V, ignore_index, row_lse, acc);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void xent_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ tgt,
+                                                       const float* __restrict__ row_lse, const float* __restrict__ gscale,
+                                                       T* __restrict__ dl, int64_t ld, int64_t M, int64_t V, int64_t ignore) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float gs = gscale[0];
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+        const int64_t t = tgt[row];
+        const float lse = row_lse[row];
+        const float keep = (t != ignore) ? gs : 0.f;
+        for (int64_t c = lane; c < ld; c += 64) {
+            float v = 0.f;
+            if (c < V) v = (expf(logits[row * V + c] - lse) - (c == t ? 1.f : 0.f)) * keep;
+            dl[row * ld + c] = from_f32<T>(v);
+        }
+    }
+}
+extern "C" int emo_xent_bwd(const float* logits, const int64_t* tgt, const float* row_lse, const float* gscale, void* dlogits,
+                            int64_t ld_out, int dtype_out, int64_t M, int64_t V, int64_t ignore_index, emo_stream_t stream) {
+    EMO_CHECK(logits && tgt && row_lse && gscale && dlogits && ld_out >= V, "emo_xent_bwd: bad args");
+    int64_t blocks = cdiv64(M, 4);
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype_out == EMO_F32) hipLaunchKernelGGL(xent_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, logits, tgt, row_lse, gscale, (float*)dlogits, ld_out, M, V, ignore_index);
+    else hipLaunchKernelGGL(xent_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, logits, tgt, row_lse, gscale, (bf16_t*)dlogits, ld_out, M, V, ignore_index);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
+// ================================================================================================ argmax / accuracy
+__device__ __forceinline__ void wave_argmax(float& v, int64_t& idx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(v, o, 64);
+        int64_t oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+__device__ __forceinline__ int64_t row_argmax(const float* l, int64_t V, int lane) {
+    float best = -INFINITY;
+    int64_t bi = INT64_MAX;
+    for (int64_t c = lane; c < V; c += 64) {
+        float x = l[c];
+        if (x > best || (x != x && bi == INT64_MAX)) { best = x; bi = c; }  // first max wins inside a lane (ascending c)
+    }
+    wave_argmax(best, bi);
+    return bi;
+}
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int64_t rows, int64_t V, int64_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int64_t bi = row_argmax(logits + row * V, V, lane);
+    if (lane == 0) out[row] = bi;
+}
+extern "C" int emo_argmax(const float* logits, int64_t rows, int64_t V, int64_t* out, emo_stream_t stream) {
+    EMO_CHECK(logits && out && rows > 0 && V > 0, "emo_argmax: bad args");
+    hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, rows, V, out);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
+__global__ __launch_bounds__(256) void accuracy_kernel(const float* __restrict__ logits, const int64_t* __restrict__ tgt,
+                                                       const int64_t* __restrict__ chord, const int64_t* __restrict__ melody, int64_t M,
+                                                       int64_t V, int64_t pad, unsigned long long* __restrict__ counts) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long c[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+        int64_t bi = row_argmax(logits + row * V, V, lane);
+        if (lane == 0) {
+            const int64_t t = tgt[row];
+            const unsigned long long ok = (bi == t);
+            if (t != pad) { c[0]++; c[1] += ok; }
+            if (chord && chord[row] == 1) { c[2]++; c[3] += ok; }
+            if (melody && melody[row] == 1) { c[4]++; c[5] += ok; }
+        }
+    }
+    if (lane == 0)
+        for (int i = 0; i < 6; ++i)
+            if (c[i]) atomicAdd(counts + i, c[i]);
+}
+extern "C" int emo_accuracy_counts(const float* logits, const int64_t* tgt, const int64_t* chord, const int64_t* melody, int64_t M,
+                                   int64_t V, int64_t pad, int64_t* counts, emo_stream_t stream) {
+    EMO_CHECK(logits && tgt && counts, "emo_accuracy_counts: null pointer");
+    int64_t blocks = cdiv64(M, 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(accuracy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, tgt, chord, melody, M, V, pad, (unsigned long long*)counts);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
+// ================================================================================================ K10 nucleus sampling
+// One 256-thread block per stream.  probs = softmax(l/temp) (fp32, as NumPy on fp32 logits),
+// bitonic sort (descending, ties by ascending index) of <=1024 entries in LDS, inclusive cumsum,
+// last_index = SECOND position whose cumsum exceeds top_p (reference inference.py:93-94 keeps the
+// crossing token — SURVEY F12); where the reference would raise IndexError (single crossing) all
+// sorted tokens are kept.  Draw: cdf over the renormalised (f64) candidates, searchsorted(u, right).
+__global__ __launch_bounds__(256) void nucleus_kernel(const float* __restrict__ logits, int64_t V, float temp, float top_p,
+                                                      const float* __restrict__ u, int64_t* __restrict__ out) {
+    __shared__ float sp[1024];
+    __shared__ int si[1024];
+    __shared__ float red[4];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* l = logits + (int64_t)blockIdx.x * V;
+    int n2 = 1;
+    while (n2 < V) n2 <<= 1;
+    float mx = -INFINITY;
+    for (int c = tid; c < V; c += 256) mx = fmaxf(mx, l[c] / temp);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = tid; c < n2; c += 256) {
+        float e = (c < V) ? expf(l[c] / temp - mx) : -1.f;
+        sp[c] = e;
+        si[c] = c;
+        if (c < V) s += e;
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    for (int c = tid; c < V; c += 256) sp[c] = sp[c] / tot;
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += 256) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    float a = sp[i], b = sp[ixj];
+                    int ia = si[i], ib = si[ixj];
+                    bool a_first = (a > b) || (a == b && ia < ib);  // descending order wanted
+                    bool up = ((i & k) == 0);
+                    if (up ? !a_first : a_first) { sp[i] = b; sp[ixj] = a; si[i] = ib; si[ixj] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        float cum = 0.f;
+        int crossings = 0, last = -1;
+        for (int i = 0; i < V; ++i) {
+            cum += sp[i];
+            if (cum > top_p) {
+                if (++crossings == 2) { last = i; break; }
+            }
+        }
+        if (crossings == 0) last = V < 3 ? (int)V : 3;
+        else if (crossings == 1) last = (int)V;
+        double csum = 0.0;
+        for (int i = 0; i < last; ++i) csum += (double)sp[i];
+        const double target = (double)u[blockIdx.x] * csum;
+        double run = 0.0;
+        int pick = last - 1;
+        for (int i = 0; i < last; ++i) {
+            run += (double)sp[i];
+            if (run > target) { pick = i; break; }
+        }
+        s_last = si[pick];
+        out[blockIdx.x] = (int64_t)s_last;
+    }
+}
+extern "C" int emo_sample_nucleus(const float* logits, int64_t rows, int64_t V, float temperature, float top_p, const float* u,
+                                  int64_t* out, emo_stream_t stream) {
+    EMO_CHECK(logits && u && out && rows > 0, "emo_sample_nucleus: bad args");
+    EMO_CHECK(V > 0 && V <= 1024, "emo_sample_nucleus: V must be <= 1024 (got %lld)", (long long)V);
+    EMO_CHECK(temperature > 0.f, "emo_sample_nucleus: temperature must be > 0");
+    hipLaunchKernelGGL(nucleus_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, V, temperature, top_p, u, out);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
+// ================================================================================================ optimizer plumbing
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ acc) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const int64_t n4 = n >> 2;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < n4; it += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 v = *(const f32x4*)(x + it * 4);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = n4 * 4; i < n; ++i) s += x[i] * x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+}
+extern "C" int emo_sumsq(const float* x, int64_t n, float* acc, emo_stream_t stream) {
+    EMO_CHECK(x && acc && n > 0 && ((uintptr_t)x & 15) == 0, "emo_sumsq: bad args (x must be 16-B aligned)");
+    int64_t blocks = cdiv64(cdiv64(n, 4), 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, acc);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float pre, float* coef) {
+    const float total = sqrtf(sumsq[0]) * pre;            // norm of the (pre-scaled) gradient
+    float c = max_norm / (total + 1e-6f);                 // torch.nn.utils.clip_grad_norm_
+    coef[0] = (c < 1.f ? c : 1.f) * pre;
+}
+extern "C" int emo_clip_coef(const float* sumsq, float max_norm, float pre, float* coef, emo_stream_t stream) {
+    EMO_CHECK(sumsq && coef, "emo_clip_coef: null pointer");
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, pre, coef);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, bf16_t* __restrict__ pb, int64_t n, float lr, float b1, float b2,
+                                                   float eps, float bc1, float bc2_sqrt, const float* __restrict__ gscale) {
+    const float gs = gscale ? gscale[0] : 1.f;
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gs;
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);       // torch: exp_avg.lerp_(grad, 1-beta1)
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;      // exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        const float pi = p[i] - step_size * (mi / denom);
+        m[i] = mi; v[i] = vi; p[i] = pi;
+        if (pb) pb[i] = (bf16_t)pi;
+    }
+}
+extern "C" int emo_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
+                             float beta2, float eps, int64_t step, const float* gscale, emo_stream_t stream) {
+    EMO_CHECK(p && g && m && v && n > 0 && step > 0, "emo_adam_step: bad args");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    int64_t blocks = cdiv64(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
+                       (float)bc1, (float)sqrt(bc2), gscale);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
+template <typename S, typename Dd>
+__global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ s, Dd* __restrict__ d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        d[i] = from_f32<Dd>(to_f32<S>(s[i]));
+}
+extern "C" int emo_cast(const void* src, int sd, void* dst, int dd, int64_t n, emo_stream_t stream) {
+    EMO_CHECK(src && dst && n > 0, "emo_cast: bad args");
+    int64_t blocks = cdiv64(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (sd == EMO_F32 && dd == EMO_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
+    else if (sd == EMO_BF16 && dd == EMO_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
+    else if (sd == EMO_F32 && dd == EMO_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+    else hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}

@@ -1,0 +1,780 @@
+// K3+K4 — FAVOR+ feature map fused with causal linear attention (Performer), forward + backward.
+//
+// Math per (batch b, head h), F = n_feat features, m = F/2, c = dh^-1/4:
+//   phi(x)  = [exp(u - off), exp(-u - off)],  u = (c x) W  (W = omega [dh,m]),  off = |c x|^2/2 + ln(F)/2
+//   S_t = sum_{j<=t} phi(k_j) (x) v_j   z_t = sum_{j<=t} phi(k_j)
+//   out_t = phi(q_t)^T S_t / den_t,   den_t = phi(q_t).z_t + eps
+// Chunked prefix-sum evaluation (chunk C tokens): the intra-chunk part is a masked C x C product,
+// the inter-chunk part goes through the running state, which lives in MFMA accumulators (fp32
+// registers) for the whole scan and is mirrored to LDS once per chunk as an MFMA operand.
+// One workgroup (4 waves) per (b,h); every contraction is an "NT" product of two LDS images
+// whose reduction index is contiguous, so fragments are single ds_read_b128 (bf16) / ds_read_b32
+// (exact-f32 mode on v_mfma_f32_16x16x4_f32).  Image row strides are padded (+16 B) so that the
+// 16 rows of a fragment read hit distinct bank groups.
+// Backward = two independent scans: a forward sweep producing dq and a reverse sweep producing
+// dk, dv (state R_t = sum_{s>t} phi(q_s) (x) [dN_s, dD_s]); the feature-map Jacobian is fused.
+//   dN_t = dout_t/den_t,  dD_t = -(dout_t.out_t)/den_t
+#include "emo_common.h"
+
+#include "emo_lds_mma.h"
+
+// per-row feature offset: off[t] = 0.5*c^2*|x_t|^2 + 0.5*ln(F); TPR threads per row, shuffle reduce
+template <typename CT, int DH, int C>
+__device__ __forceinline__ void row_offsets(const CT* X, int ld, float* off, float c2, float half_ln_f, int tid) {
+    constexpr int TPR = 256 / C;           // threads per row (C in {16,32,64} -> 16,8,4)
+    constexpr int EPT = CMax<DH / TPR, 1>::v;
+    const int r = tid / TPR, part = tid % TPR;
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int d = part * EPT + e;
+        if (d < DH) { float x = to_f32<CT>(X[r * ld + d]); s += x * x; }
+    }
+#pragma unroll
+    for (int o = TPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (part == 0) off[r] = 0.5f * c2 * s + half_ln_f;
+}
+
+// feature images.  WT image [MF][LDX] holds omega^T (k = d).  X image [C][LDX].
+// row-major:  Ff[t][f]  (rows<->m via R=WT, col<->t via C=X)
+template <typename CT, int DHP, int MF, int C>
+__device__ __forceinline__ void features_rowmajor(CT* Ff, int ldf, const CT* WT, const CT* X, int ldx, const float* off, float cs,
+                                                  int valid_rows, int wave, int lane) {
+    constexpr int NT = (MF / 16) * (C / 16);
+    for (int tile = wave; tile < NT; tile += 4) {
+        const int rt = tile / (C / 16), ct = tile % (C / 16);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        mm16<CT>(acc, WT, ldx, rt * 16, X, ldx, ct * 16, DHP, lane);
+        const int t = ct * 16 + (lane & 15), m0 = rt * 16 + (lane >> 4) * 4;
+        const float o = off[t];
+        const float ok = t < valid_rows ? 1.f : 0.f;
+        float p[4], n[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float u = cs * acc[r]; p[r] = Img<CT>::ex(u - o) * ok; n[r] = Img<CT>::ex(-u - o) * ok; }
+        Img<CT>::store4(Ff + t * ldf + m0, p[0], p[1], p[2], p[3]);
+        Img<CT>::store4(Ff + t * ldf + MF + m0, n[0], n[1], n[2], n[3]);
+    }
+}
+// transposed: FT[f][t]  (rows<->t via R=X, col<->m via C=WT)
+template <typename CT, int DHP, int MF, int C>
+__device__ __forceinline__ void features_transposed(CT* FT, int ldt, const CT* WT, const CT* X, int ldx, const float* off, float cs,
+                                                    int valid_rows, int wave, int lane) {
+    constexpr int NT = (MF / 16) * (C / 16);
+    for (int tile = wave; tile < NT; tile += 4) {
+        const int rt = tile / (MF / 16), ct = tile % (MF / 16);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        mm16<CT>(acc, X, ldx, rt * 16, WT, ldx, ct * 16, DHP, lane);
+        const int t0 = rt * 16 + (lane >> 4) * 4, m = ct * 16 + (lane & 15);
+        float p[4], n[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float o = off[t0 + r];
+            const float ok = (t0 + r) < valid_rows ? 1.f : 0.f;
+            float u = cs * acc[r];
+            p[r] = Img<CT>::ex(u - o) * ok;
+            n[r] = Img<CT>::ex(-u - o) * ok;
+        }
+        Img<CT>::store4(FT + m * ldt + t0, p[0], p[1], p[2], p[3]);
+        Img<CT>::store4(FT + (MF + m) * ldt + t0, n[0], n[1], n[2], n[3]);
+    }
+}
+
+template <typename CT, int DH, int MF, int C> struct FavorDims {
+    static constexpr int F = 2 * MF;
+    static constexpr int KMIN = Img<CT>::KMIN, PAD = Img<CT>::PAD;
+    static constexpr int DHP = CMax<DH, KMIN>::v;
+    static constexpr int MFP = CMax<MF, KMIN>::v;
+    static constexpr int CP = CMax<C, KMIN>::v;
+    static constexpr int LDX = DHP + PAD;  // k = d
+    static constexpr int LDM = MFP + PAD;  // k = m
+    static constexpr int LDC = CP + PAD;   // k = j / t (chunk index)
+    static constexpr int LDF = F + PAD;    // k = f
+};
+
+template <typename CT>
+__device__ __forceinline__ void zero_img(CT* img, int n, int tid) {
+    for (int i = tid; i < n; i += 256) img[i] = from_f32<CT>(0.f);
+}
+
+// =============================================================================================== forward
+template <typename CT, int DH, int MF, int C>
+__global__ __launch_bounds__(256) void favor_fwd_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+                                                        const float* __restrict__ omega, CT* __restrict__ out, int64_t ld_out,
+                                                        float* __restrict__ den_g, float* __restrict__ state_S, float* __restrict__ state_z,
+                                                        int64_t T, int64_t H, float eps) {
+    typedef FavorDims<CT, DH, MF, C> D;
+    constexpr int F = D::F, LDX = D::LDX, LDC = D::LDC, LDF = D::LDF, DHP = D::DHP, CP = D::CP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    CT* WT = (CT*)smem;                 // [MF][LDX]
+    CT* Xq = WT + MF * LDX;             // [C][LDX]
+    CT* Xk = Xq + C * LDX;              // [C][LDX]
+    CT* VT = Xk + C * LDX;              // [DH][LDC]
+    CT* Qf = VT + DH * LDC;             // [C][LDF]
+    CT* Kf = Qf + C * LDF;              // [C][LDF]
+    CT* KfT = Kf + C * LDF;             // [F][LDC]
+    CT* Am = KfT + F * LDC;             // [C][LDC]
+    CT* ST = Am + C * LDC;              // [DH][LDF]   S^T mirror (k = f)
+    float* offq = (float*)(ST + DH * LDF);
+    float* offk = offq + C;
+    float* dens = offk + C;
+    float* zz = dens + C;               // [F]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;
+    const CT* qb = q + (b * T) * ld + h * DH;
+    const CT* kb = k + (b * T) * ld + h * DH;
+    const CT* vb = v + (b * T) * ld + h * DH;
+    CT* ob = out + (b * T) * ld_out + h * DH;
+    float* dg = den_g + bh * T;
+    const float cs = rsqrtf(sqrtf((float)DH));   // dh^-1/4
+    const float half_ln_f = 0.5f * logf((float)F);
+
+    // omega^T image, zero state
+    zero_img(WT, MF * LDX, tid);
+    zero_img(ST, DH * LDF, tid);
+    zero_img(VT, DH * LDC, tid);
+    zero_img(KfT, F * LDC, tid);
+    zero_img(Am, C * LDC, tid);
+    for (int i = tid; i < F; i += 256) zz[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < DH * MF; i += 256) { const int d = i / MF, m = i % MF; WT[m * LDX + d] = from_f32<CT>(omega[i]); }
+
+    constexpr int NTS = (F / 16) * (DH / 16);          // state tiles: rows<->f (R=KfT), col<->d (C=VT)
+    constexpr int NTS_W = (NTS + 3) / 4;
+    f32x4 sacc[NTS_W];
+#pragma unroll
+    for (int i = 0; i < NTS_W; ++i) sacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t t0 = 0; t0 < T; t0 += C) {
+        const int valid = (int)((T - t0) < C ? (T - t0) : C);
+        __syncthreads();
+        load_rows<CT, DH, DHP>(Xq, LDX, qb + t0 * ld, ld, C, valid, tid);
+        load_rows<CT, DH, DHP>(Xk, LDX, kb + t0 * ld, ld, C, valid, tid);
+        load_rows_T<CT, DH>(VT, LDC, vb + t0 * ld, ld, C, valid, tid);
+        __syncthreads();
+        row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
+        row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
+        __syncthreads();
+        features_rowmajor<CT, DHP, MF, C>(Qf, LDF, WT, Xq, LDX, offq, cs, C, wave, lane);
+        features_rowmajor<CT, DHP, MF, C>(Kf, LDF, WT, Xk, LDX, offk, cs, valid, wave, lane);
+        features_transposed<CT, DHP, MF, C>(KfT, LDC, WT, Xk, LDX, offk, cs, valid, wave, lane);
+        __syncthreads();
+        // A[t][j] = Qf[t].Kf[j] masked j<=t : rows<->j (R=Kf), col<->t (C=Qf)
+        {
+            constexpr int NT = (C / 16) * (C / 16);
+            for (int tile = wave; tile < NT; tile += 4) {
+                const int jt = tile / (C / 16), tt = tile % (C / 16);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (jt <= tt) mm16<CT>(acc, Kf, LDF, jt * 16, Qf, LDF, tt * 16, F, lane);
+                const int t = tt * 16 + (lane & 15), j0 = jt * 16 + (lane >> 4) * 4;
+                Img<CT>::store4(Am + t * LDC + j0, j0 <= t ? acc[0] : 0.f, j0 + 1 <= t ? acc[1] : 0.f, j0 + 2 <= t ? acc[2] : 0.f,
+                                j0 + 3 <= t ? acc[3] : 0.f);
+            }
+        }
+        __syncthreads();
+        // den[t] = rowsum(A[t]) + Qf[t].z_prev + eps
+        {
+            constexpr int TPR = 256 / C;
+            const int r = tid / TPR, part = tid % TPR;
+            float s = 0.f;
+            for (int j = part; j < C; j += TPR) s += to_f32<CT>(Am[r * LDC + j]);
+            for (int f = part; f < F; f += TPR) s += to_f32<CT>(Qf[r * LDF + f]) * zz[f];
+#pragma unroll
+            for (int o = TPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (part == 0) {
+                dens[r] = s + eps;
+                if (r < valid) dg[t0 + r] = s + eps;
+            }
+        }
+        __syncthreads();
+        // out^T: rows<->d, col<->t : VT.Am^T (K=C) + ST.Qf^T (K=F)
+        {
+            constexpr int NT = (DH / 16) * (C / 16);
+            for (int tile = wave; tile < NT; tile += 4) {
+                const int dt = tile / (C / 16), tt = tile % (C / 16);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                mm16<CT>(acc, VT, LDC, dt * 16, Am, LDC, tt * 16, CP, lane);
+                mm16<CT>(acc, ST, LDF, dt * 16, Qf, LDF, tt * 16, F, lane);
+                const int t = tt * 16 + (lane & 15), d0 = dt * 16 + (lane >> 4) * 4;
+                if (t < valid) {
+                    const float inv = 1.f / dens[t];
+                    Img<CT>::store4(ob + (t0 + t) * ld_out + d0, acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+                }
+            }
+        }
+        __syncthreads();
+        // state: S[f][d] += sum_j KfT[f][j] VT[d][j]; mirror ST[d][f]; z += colsum
+#pragma unroll
+        for (int i = 0; i < NTS_W; ++i) {
+            const int tile = wave + 4 * i;
+            if (tile < NTS) {
+                const int ft = tile / (DH / 16), dt = tile % (DH / 16);
+                mm16<CT>(sacc[i], KfT, LDC, ft * 16, VT, LDC, dt * 16, CP, lane);
+                const int d = dt * 16 + (lane & 15), f0 = ft * 16 + (lane >> 4) * 4;
+                Img<CT>::store4(ST + d * LDF + f0, sacc[i][0], sacc[i][1], sacc[i][2], sacc[i][3]);
+            }
+        }
+        for (int f = tid; f < F; f += 256) {
+            float s = 0.f;
+            for (int j = 0; j < C; ++j) s += to_f32<CT>(KfT[f * LDC + j]);
+            zz[f] += s;
+        }
+    }
+    __syncthreads();
+    if (state_S) {
+#pragma unroll
+        for (int i = 0; i < NTS_W; ++i) {
+            const int tile = wave + 4 * i;
+            if (tile < NTS) {
+                const int ft = tile / (DH / 16), dt = tile % (DH / 16);
+                const int d = dt * 16 + (lane & 15), f0 = ft * 16 + (lane >> 4) * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) state_S[(bh * F + f0 + r) * DH + d] = sacc[i][r];
+            }
+        }
+        for (int f = tid; f < F; f += 256) state_z[bh * F + f] = zz[f];
+    }
+}
+
+// =============================================================================================== backward, shared pieces
+// load dout/out rows -> G image (dN = dout/den) [C][LDX] (+ optional transposed GT [DH][LDC]) and dD[t]
+template <typename CT, int DH, int DHP, int C>
+__device__ __forceinline__ void load_grads(CT* G, int ldg, CT* GT, int ldgt, float* dD, const CT* __restrict__ dout, const CT* __restrict__ outp,
+                                           int64_t ld_out, const float* __restrict__ den, int valid, int tid) {
+    constexpr int TPR = 256 / C;
+    constexpr int EPT = CMax<DHP / TPR, 1>::v;
+    const int r = tid / TPR, part = tid % TPR;
+    const float inv = r < valid ? 1.f / den[r] : 0.f;
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int d = part * EPT + e;
+        if (d < DHP) {
+            float g = 0.f, o = 0.f;
+            if (r < valid && d < DH) { g = to_f32<CT>(dout[(int64_t)r * ld_out + d]); o = to_f32<CT>(outp[(int64_t)r * ld_out + d]); }
+            dot += g * o;
+            const CT gn = from_f32<CT>(g * inv);
+            G[r * ldg + d] = gn;
+            if (GT && d < DH) GT[d * ldgt + r] = gn;
+        }
+    }
+#pragma unroll
+    for (int o = TPR >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    if (part == 0) dD[r] = -dot * inv;
+}
+
+// a = dPhi * Phi ; Adiff[t][m] = a+ - a- ; sumA[t] += a+ + a-   (lane owns f0..f0+3 (plus) and MF+f0.. (minus) of column t)
+template <typename CT, int MF>
+__device__ __forceinline__ void jac_epilogue(const f32x4& accP, const f32x4& accM, const CT* Ff, int ldf, CT* Adiff, int lda, float* sumA,
+                                             const float* extra_vec /* z or r, [F] */, float extra_scale, int t, int m0, int lane) {
+    float ad[4], s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float ap = (accP[r] + extra_vec[m0 + r] * extra_scale) * to_f32<CT>(Ff[t * ldf + m0 + r]);
+        const float am = (accM[r] + extra_vec[MF + m0 + r] * extra_scale) * to_f32<CT>(Ff[t * ldf + MF + m0 + r]);
+        ad[r] = ap - am;
+        s += ap + am;
+    }
+    Img<CT>::store4(Adiff + t * lda + m0, ad[0], ad[1], ad[2], ad[3]);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if ((lane >> 4) == 0) atomicAdd(&sumA[t], s);
+}
+
+// pad columns m in [MF, MFP) of the (aliased) Adiff image must be finite zeros
+template <typename CT, int MF, int MFP, int C>
+__device__ __forceinline__ void zero_adiff_pad(CT* Adiff, int lda, int tid) {
+    if constexpr (MFP > MF) {
+        for (int i = tid; i < C * (MFP - MF); i += 256) Adiff[(i / (MFP - MF)) * lda + MF + i % (MFP - MF)] = from_f32<CT>(0.f);
+    }
+}
+
+// dx[t][d] = c * ( sum_m W[d][m] Adiff[t][m] - (c x[t][d]) sumA[t] ) : rows<->d (R=W), col<->t (C=Adiff)
+template <typename CT, int DH, int MFP, int C>
+__device__ __forceinline__ void dx_from_adiff(const CT* W, int ldw, const CT* Adiff, int lda, const float* sumA, const CT* __restrict__ xg,
+                                              int64_t ld, CT* __restrict__ dxg, int64_t ld_d, float cs, int valid, int wave, int lane) {
+    constexpr int NT = (DH / 16) * (C / 16);
+    for (int tile = wave; tile < NT; tile += 4) {
+        const int dt = tile / (C / 16), tt = tile % (C / 16);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        mm16<CT>(acc, W, ldw, dt * 16, Adiff, lda, tt * 16, MFP, lane);
+        const int t = tt * 16 + (lane & 15), d0 = dt * 16 + (lane >> 4) * 4;
+        if (t < valid) {
+            const float sa = sumA[t];
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = cs * (acc[r] - cs * to_f32<CT>(xg[(int64_t)t * ld + d0 + r]) * sa);
+            Img<CT>::store4(dxg + (int64_t)t * ld_d + d0, o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// =============================================================================================== backward: dq (forward sweep)
+template <typename CT, int DH, int MF, int C>
+__global__ __launch_bounds__(256) void favor_bwd_dq_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+                                                           const float* __restrict__ omega, const CT* __restrict__ out, const CT* __restrict__ dout,
+                                                           int64_t ld_out, const float* __restrict__ den_g, CT* __restrict__ dq, int64_t ld_d,
+                                                           int64_t T, int64_t H) {
+    typedef FavorDims<CT, DH, MF, C> D;
+    constexpr int F = D::F, LDX = D::LDX, LDC = D::LDC, LDF = D::LDF, LDM = D::LDM, DHP = D::DHP, CP = D::CP, MFP = D::MFP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    CT* WT = (CT*)smem;            // [MF][LDX]  omega^T (k=d)
+    CT* W = WT + MF * LDX;         // [DH][LDM]  omega   (k=m)
+    CT* Xq = W + DH * LDM;         // [C][LDX]
+    CT* Xk = Xq + C * LDX;         // [C][LDX]   (aliased by Adiff [C][LDM] after the feature step)
+    constexpr int XKSZ = C * CMax<LDX, LDM>::v;
+    CT* Adiff = Xk;
+    CT* Vr = Xk + XKSZ;            // [C][LDX]   v rows (k=d)
+    CT* VT = Vr + C * LDX;         // [DH][LDC]
+    CT* G = VT + DH * LDC;         // [C][LDX]   dN rows (k=d)
+    CT* Qf = G + C * LDX;          // [C][LDF]
+    CT* KfT = Qf + C * LDF;        // [F][LDC]
+    CT* Pm = KfT + F * LDC;        // [C][LDC]
+    CT* SF = Pm + C * LDC;         // [F][LDX]   S mirror (k=d)
+    float* offq = (float*)(SF + F * LDX);
+    float* offk = offq + C;
+    float* dD = offk + C;
+    float* sumA = dD + C;
+    float* zz = sumA + C;          // [F]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;
+    const CT* qb = q + (b * T) * ld + h * DH;
+    const CT* kb = k + (b * T) * ld + h * DH;
+    const CT* vb = v + (b * T) * ld + h * DH;
+    const CT* ob = out + (b * T) * ld_out + h * DH;
+    const CT* gb = dout + (b * T) * ld_out + h * DH;
+    CT* dqb = dq + (b * T) * ld_d + h * DH;
+    const float* dg = den_g + bh * T;
+    const float cs = rsqrtf(sqrtf((float)DH));
+    const float half_ln_f = 0.5f * logf((float)F);
+
+    zero_img(WT, MF * LDX, tid);
+    zero_img(W, DH * LDM, tid);
+    zero_img(SF, F * LDX, tid);
+    zero_img(VT, DH * LDC, tid);
+    zero_img(KfT, F * LDC, tid);
+    zero_img(Pm, C * LDC, tid);
+    for (int i = tid; i < F; i += 256) zz[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < DH * MF; i += 256) {
+        const int d = i / MF, m = i % MF;
+        const CT w = from_f32<CT>(omega[i]);
+        WT[m * LDX + d] = w;
+        W[d * LDM + m] = w;
+    }
+    constexpr int NTS = (DH / 16) * (F / 16);   // state tiles: rows<->d (R=VT), col<->f (C=KfT) -> SF[f][d0..]
+    constexpr int NTS_W = (NTS + 3) / 4;
+    f32x4 sacc[NTS_W];
+#pragma unroll
+    for (int i = 0; i < NTS_W; ++i) sacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t t0 = 0; t0 < T; t0 += C) {
+        const int valid = (int)((T - t0) < C ? (T - t0) : C);
+        __syncthreads();
+        load_rows<CT, DH, DHP>(Xq, LDX, qb + t0 * ld, ld, C, valid, tid);
+        load_rows<CT, DH, DHP>(Xk, LDX, kb + t0 * ld, ld, C, valid, tid);
+        load_rows<CT, DH, DHP>(Vr, LDX, vb + t0 * ld, ld, C, valid, tid);
+        load_rows_T<CT, DH>(VT, LDC, vb + t0 * ld, ld, C, valid, tid);
+        load_grads<CT, DH, DHP, C>(G, LDX, (CT*)nullptr, 0, dD, gb + t0 * ld_out, ob + t0 * ld_out, ld_out, dg + t0, valid, tid);
+        for (int i = tid; i < C; i += 256) sumA[i] = 0.f;
+        __syncthreads();
+        row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
+        row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
+        __syncthreads();
+        features_rowmajor<CT, DHP, MF, C>(Qf, LDF, WT, Xq, LDX, offq, cs, C, wave, lane);
+        features_transposed<CT, DHP, MF, C>(KfT, LDC, WT, Xk, LDX, offk, cs, valid, wave, lane);
+        // P[t][j] = dN_t.v_j + dD_t, masked j<=t : rows<->j (R=Vr), col<->t (C=G)
+        {
+            constexpr int NT = (C / 16) * (C / 16);
+            for (int tile = wave; tile < NT; tile += 4) {
+                const int jt = tile / (C / 16), tt = tile % (C / 16);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (jt <= tt) mm16<CT>(acc, Vr, LDX, jt * 16, G, LDX, tt * 16, DHP, lane);
+                const int t = tt * 16 + (lane & 15), j0 = jt * 16 + (lane >> 4) * 4;
+                const float dd = dD[t];
+                Img<CT>::store4(Pm + t * LDC + j0, j0 <= t ? acc[0] + dd : 0.f, j0 + 1 <= t ? acc[1] + dd : 0.f,
+                                j0 + 2 <= t ? acc[2] + dd : 0.f, j0 + 3 <= t ? acc[3] + dd : 0.f);
+            }
+        }
+        __syncthreads();
+        // dPhi_q^T: rows<->f, col<->t : KfT.Pm^T (K=C) + SF.G^T (K=DHP) + z[f] dD[t]; fused Jacobian -> Adiff, sumA
+        zero_adiff_pad<CT, MF, MFP, C>(Adiff, LDM, tid);
+        {
+            constexpr int NP = (MF / 16) * (C / 16);
+            for (int pr = wave; pr < NP; pr += 4) {
+                const int ft = pr / (C / 16), tt = pr % (C / 16);
+                f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f};
+                mm16<CT>(aP, KfT, LDC, ft * 16, Pm, LDC, tt * 16, CP, lane);
+                mm16<CT>(aP, SF, LDX, ft * 16, G, LDX, tt * 16, DHP, lane);
+                mm16<CT>(aM, KfT, LDC, MF + ft * 16, Pm, LDC, tt * 16, CP, lane);
+                mm16<CT>(aM, SF, LDX, MF + ft * 16, G, LDX, tt * 16, DHP, lane);
+                const int t = tt * 16 + (lane & 15), m0 = ft * 16 + (lane >> 4) * 4;
+                jac_epilogue<CT, MF>(aP, aM, Qf, LDF, Adiff, LDM, sumA, zz, dD[t], t, m0, lane);
+            }
+        }
+        __syncthreads();
+        dx_from_adiff<CT, DH, MFP, C>(W, LDM, Adiff, LDM, sumA, qb + t0 * ld, ld, dqb + t0 * ld_d, ld_d, cs, valid, wave, lane);
+        // state S[f][d] (+)= ; mirror SF[f][d0..] ; z += colsum(KfT)
+#pragma unroll
+        for (int i = 0; i < NTS_W; ++i) {
+            const int tile = wave + 4 * i;
+            if (tile < NTS) {
+                const int dt = tile / (F / 16), ft = tile % (F / 16);
+                mm16<CT>(sacc[i], VT, LDC, dt * 16, KfT, LDC, ft * 16, CP, lane);
+            }
+        }
+        __syncthreads();   // all reads of SF / zz for this chunk are done
+#pragma unroll
+        for (int i = 0; i < NTS_W; ++i) {
+            const int tile = wave + 4 * i;
+            if (tile < NTS) {
+                const int dt = tile / (F / 16), ft = tile % (F / 16);
+                const int f = ft * 16 + (lane & 15), d0 = dt * 16 + (lane >> 4) * 4;
+                Img<CT>::store4(SF + f * LDX + d0, sacc[i][0], sacc[i][1], sacc[i][2], sacc[i][3]);
+            }
+        }
+        for (int f = tid; f < F; f += 256) {
+            float s = 0.f;
+            for (int j = 0; j < C; ++j) s += to_f32<CT>(KfT[f * LDC + j]);
+            zz[f] += s;
+        }
+    }
+}
+
+// =============================================================================================== backward: dk, dv (reverse sweep)
+template <typename CT, int DH, int MF, int C>
+__global__ __launch_bounds__(256) void favor_bwd_dkv_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+                                                            const float* __restrict__ omega, const CT* __restrict__ out, const CT* __restrict__ dout,
+                                                            int64_t ld_out, const float* __restrict__ den_g, CT* __restrict__ dk, CT* __restrict__ dv,
+                                                            int64_t ld_d, int64_t T, int64_t H) {
+    typedef FavorDims<CT, DH, MF, C> D;
+    constexpr int F = D::F, LDX = D::LDX, LDC = D::LDC, LDF = D::LDF, LDM = D::LDM, DHP = D::DHP, CP = D::CP, MFP = D::MFP;
+    constexpr int LXC = CMax<LDX, LDC>::v, LXM = CMax<LDX, LDM>::v;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    CT* WT = (CT*)smem;             // [MF][LDX]
+    CT* W = WT + MF * LDX;          // [DH][LDM]
+    CT* Xq = W + DH * LDM;          // [C][LDX] -> aliased by PmT [C][LDC] after the feature step
+    CT* PmT = Xq;
+    CT* Xk = Xq + C * LXC;          // [C][LDX] -> aliased by AmT [C][LDC]
+    CT* AmT = Xk;
+    CT* Vr = Xk + C * LXC;          // [C][LDX]
+    CT* G = Vr + C * LDX;           // [C][LDX] -> aliased by Adiff [C][LDM] after P is formed
+    CT* Adiff = G;
+    CT* GT = G + C * LXM;           // [DH][LDC]
+    CT* Qf = GT + DH * LDC;         // [C][LDF]
+    CT* Kf = Qf + C * LDF;          // [C][LDF]
+    CT* QfT = Kf + C * LDF;         // [F][LDC]
+    CT* RF = QfT + F * LDC;         // [F][LDX]  R mirror (k=d)
+    CT* RT = RF + F * LDX;          // [DH][LDF] R^T mirror (k=f)
+    float* offq = (float*)(RT + DH * LDF);
+    float* offk = offq + C;
+    float* dD = offk + C;
+    float* sumA = dD + C;
+    float* rr = sumA + C;           // [F]  r[f] = sum_{t>chunk} Qf_t[f] dD_t
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;
+    const CT* qb = q + (b * T) * ld + h * DH;
+    const CT* kb = k + (b * T) * ld + h * DH;
+    const CT* vb = v + (b * T) * ld + h * DH;
+    const CT* ob = out + (b * T) * ld_out + h * DH;
+    const CT* gb = dout + (b * T) * ld_out + h * DH;
+    CT* dkb = dk + (b * T) * ld_d + h * DH;
+    CT* dvb = dv + (b * T) * ld_d + h * DH;
+    const float* dg = den_g + bh * T;
+    const float cs = rsqrtf(sqrtf((float)DH));
+    const float half_ln_f = 0.5f * logf((float)F);
+
+    zero_img(WT, MF * LDX, tid);
+    zero_img(W, DH * LDM, tid);
+    zero_img(RF, F * LDX, tid);
+    zero_img(RT, DH * LDF, tid);
+    zero_img(GT, DH * LDC, tid);
+    zero_img(QfT, F * LDC, tid);
+    for (int i = tid; i < F; i += 256) rr[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < DH * MF; i += 256) {
+        const int d = i / MF, m = i % MF;
+        const CT w = from_f32<CT>(omega[i]);
+        WT[m * LDX + d] = w;
+        W[d * LDM + m] = w;
+    }
+    constexpr int NTS = (DH / 16) * (F / 16);   // rows<->d (R=GT), col<->f (C=QfT)
+    constexpr int NTS_W = (NTS + 3) / 4;
+    f32x4 racc[NTS_W];
+#pragma unroll
+    for (int i = 0; i < NTS_W; ++i) racc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int64_t nchunks = (T + C - 1) / C;
+    for (int64_t ci = nchunks - 1; ci >= 0; --ci) {
+        const int64_t t0 = ci * C;
+        const int valid = (int)((T - t0) < C ? (T - t0) : C);
+        __syncthreads();
+        load_rows<CT, DH, DHP>(Xq, LDX, qb + t0 * ld, ld, C, valid, tid);
+        load_rows<CT, DH, DHP>(Xk, LDX, kb + t0 * ld, ld, C, valid, tid);
+        load_rows<CT, DH, DHP>(Vr, LDX, vb + t0 * ld, ld, C, valid, tid);
+        load_grads<CT, DH, DHP, C>(G, LDX, GT, LDC, dD, gb + t0 * ld_out, ob + t0 * ld_out, ld_out, dg + t0, valid, tid);
+        for (int i = tid; i < C; i += 256) sumA[i] = 0.f;
+        __syncthreads();
+        row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
+        row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
+        __syncthreads();
+        features_rowmajor<CT, DHP, MF, C>(Qf, LDF, WT, Xq, LDX, offq, cs, valid, wave, lane);
+        features_rowmajor<CT, DHP, MF, C>(Kf, LDF, WT, Xk, LDX, offk, cs, valid, wave, lane);
+        features_transposed<CT, DHP, MF, C>(QfT, LDC, WT, Xq, LDX, offq, cs, valid, wave, lane);
+        __syncthreads();   // Xq / Xk dead from here: PmT / AmT may overwrite them
+        // PmT[j][t] = dN_t.v_j + dD_t (t>=j) : rows<->t (R=G), col<->j (C=Vr)
+        // AmT[j][t] = Qf_t.Kf_j       (t>=j) : rows<->t (R=Qf), col<->j (C=Kf)
+        {
+            constexpr int NT = (C / 16) * (C / 16);
+            for (int tile = wave; tile < NT; tile += 4) {
+                const int tt = tile / (C / 16), jt = tile % (C / 16);
+                f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aA = {0.f, 0.f, 0.f, 0.f};
+                if (tt >= jt) {
+                    mm16<CT>(aP, G, LDX, tt * 16, Vr, LDX, jt * 16, DHP, lane);
+                    mm16<CT>(aA, Qf, LDF, tt * 16, Kf, LDF, jt * 16, F, lane);
+                }
+                const int j = jt * 16 + (lane & 15), tb = tt * 16 + (lane >> 4) * 4;
+                float p[4], a[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool keep = (tb + r) >= j && (tb + r) < valid;
+                    p[r] = keep ? aP[r] + dD[tb + r] : 0.f;
+                    a[r] = keep ? aA[r] : 0.f;
+                }
+                // stores go to the aliased Xq/Xk storage: wait until every wave finished reading G/Vr/Qf/Kf? (G,Vr,Qf,Kf are
+                // distinct buffers; Xq/Xk are dead) -> safe without an extra barrier
+                Img<CT>::store4(PmT + j * LDC + tb, p[0], p[1], p[2], p[3]);
+                Img<CT>::store4(AmT + j * LDC + tb, a[0], a[1], a[2], a[3]);
+            }
+        }
+        __syncthreads();   // G dead from here: Adiff may overwrite it
+        // dPhi_k^T: rows<->f, col<->j : QfT.PmT^T (K=C) + RF.Vr^T (K=DHP) + r[f]; fused Jacobian (uses Kf)
+        zero_adiff_pad<CT, MF, MFP, C>(Adiff, LDM, tid);
+        {
+            constexpr int NP = (MF / 16) * (C / 16);
+            for (int pr = wave; pr < NP; pr += 4) {
+                const int ft = pr / (C / 16), jt = pr % (C / 16);
+                f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f};
+                mm16<CT>(aP, QfT, LDC, ft * 16, PmT, LDC, jt * 16, CP, lane);
+                mm16<CT>(aP, RF, LDX, ft * 16, Vr, LDX, jt * 16, DHP, lane);
+                mm16<CT>(aM, QfT, LDC, MF + ft * 16, PmT, LDC, jt * 16, CP, lane);
+                mm16<CT>(aM, RF, LDX, MF + ft * 16, Vr, LDX, jt * 16, DHP, lane);
+                const int j = jt * 16 + (lane & 15), m0 = ft * 16 + (lane >> 4) * 4;
+                jac_epilogue<CT, MF>(aP, aM, Kf, LDF, Adiff, LDM, sumA, rr, 1.f, j, m0, lane);
+            }
+        }
+        // dV^T: rows<->d, col<->j : GT.AmT^T (K=C) + RT.Kf^T (K=F)
+        {
+            constexpr int NT = (DH / 16) * (C / 16);
+            for (int tile = wave; tile < NT; tile += 4) {
+                const int dt = tile / (C / 16), jt = tile % (C / 16);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                mm16<CT>(acc, GT, LDC, dt * 16, AmT, LDC, jt * 16, CP, lane);
+                mm16<CT>(acc, RT, LDF, dt * 16, Kf, LDF, jt * 16, F, lane);
+                const int j = jt * 16 + (lane & 15), d0 = dt * 16 + (lane >> 4) * 4;
+                if (j < valid) Img<CT>::store4(dvb + (t0 + j) * ld_d + d0, acc[0], acc[1], acc[2], acc[3]);
+            }
+        }
+        __syncthreads();
+        dx_from_adiff<CT, DH, MFP, C>(W, LDM, Adiff, LDM, sumA, kb + t0 * ld, ld, dkb + t0 * ld_d, ld_d, cs, valid, wave, lane);
+        // state R[f][d] += sum_t QfT[f][t] GT[d][t]
+#pragma unroll
+        for (int i = 0; i < NTS_W; ++i) {
+            const int tile = wave + 4 * i;
+            if (tile < NTS) {
+                const int dt = tile / (F / 16), ft = tile % (F / 16);
+                mm16<CT>(racc[i], GT, LDC, dt * 16, QfT, LDC, ft * 16, CP, lane);
+            }
+        }
+        __syncthreads();   // all reads of RF / RT / rr for this chunk are done
+#pragma unroll
+        for (int i = 0; i < NTS_W; ++i) {
+            const int tile = wave + 4 * i;
+            if (tile < NTS) {
+                const int dt = tile / (F / 16), ft = tile % (F / 16);
+                const int f = ft * 16 + (lane & 15), d0 = dt * 16 + (lane >> 4) * 4;
+                Img<CT>::store4(RF + f * LDX + d0, racc[i][0], racc[i][1], racc[i][2], racc[i][3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) RT[(d0 + r) * LDF + f] = from_f32<CT>(racc[i][r]);
+            }
+        }
+        for (int f = tid; f < F; f += 256) {
+            float s = 0.f;
+            for (int t = 0; t < C; ++t) s += to_f32<CT>(QfT[f * LDC + t]) * dD[t];
+            rr[f] += s;
+        }
+    }
+}
+
+// =============================================================================================== decode step (recurrent form)
+// One workgroup per (stream, head); thread f (< F) owns row f of the state.
+template <typename CT>
+__global__ __launch_bounds__(128) void favor_decode_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+                                                           const float* __restrict__ omega, float* __restrict__ state_S, float* __restrict__ state_z,
+                                                           CT* __restrict__ out, int64_t ld_out, int64_t H, int dh, int mf, float eps) {
+    __shared__ float xq[64], xk[64], xv[64], fq[128], num[2][64], dpart[2];
+    const int tid = threadIdx.x, F = 2 * mf;
+    const int64_t sh = blockIdx.x, s = sh / H, h = sh % H;
+    if (tid < dh) {
+        xq[tid] = to_f32<CT>(q[s * ld + h * dh + tid]);
+        xk[tid] = to_f32<CT>(k[s * ld + h * dh + tid]);
+        xv[tid] = to_f32<CT>(v[s * ld + h * dh + tid]);
+    }
+    __syncthreads();
+    const float cs = rsqrtf(sqrtf((float)dh)), half_ln_f = 0.5f * logf((float)F);
+    float pq = 0.f, pk = 0.f;
+    if (tid < F) {
+        const int m = tid % mf;
+        const float sgn = tid < mf ? 1.f : -1.f;
+        float uq = 0.f, uk = 0.f, nq = 0.f, nk = 0.f;
+        for (int d = 0; d < dh; ++d) {
+            const float w = omega[d * mf + m];
+            uq += xq[d] * w; uk += xk[d] * w;
+            nq += xq[d] * xq[d]; nk += xk[d] * xk[d];
+        }
+        pq = __expf(sgn * cs * uq - (0.5f * cs * cs * nq + half_ln_f));
+        pk = __expf(sgn * cs * uk - (0.5f * cs * cs * nk + half_ln_f));
+        fq[tid] = pq;
+        float* Srow = state_S + (sh * F + tid) * dh;
+        for (int d = 0; d < dh; ++d) Srow[d] += pk * xv[d];
+        const float z = state_z[sh * F + tid] + pk;
+        state_z[sh * F + tid] = z;
+    }
+    __syncthreads();
+    // out[d] = sum_f fq[f] S[f][d] / (sum_f fq[f] z[f] + eps): thread (half = tid/64, d = tid%64)
+    const int d = tid & 63, half = tid >> 6;
+    float acc = 0.f, dn = 0.f;
+    if (d < dh)
+        for (int f = half; f < F; f += 2) acc += fq[f] * state_S[(sh * F + f) * dh + d];
+    if (d == 0)
+        for (int f = half; f < F; f += 2) dn += fq[f] * state_z[sh * F + f];
+    num[half][d] = acc;
+    if (d == 0) dpart[half] = dn;
+    __syncthreads();
+    if (tid < dh) out[s * ld_out + h * dh + tid] = from_f32<CT>((num[0][tid] + num[1][tid]) / (dpart[0] + dpart[1] + eps));
+}
+
+// =============================================================================================== host
+template <typename CT, int DH, int MF, int C> static size_t fwd_lds() {
+    typedef FavorDims<CT, DH, MF, C> D;
+    return sizeof(CT) * (size_t)(MF * D::LDX + 2 * C * D::LDX + DH * D::LDC + 2 * C * D::LDF + D::F * D::LDC + C * D::LDC + DH * D::LDF) +
+           sizeof(float) * (size_t)(3 * C + D::F);
+}
+template <typename CT, int DH, int MF, int C> static size_t dq_lds() {
+    typedef FavorDims<CT, DH, MF, C> D;
+    return sizeof(CT) * (size_t)(MF * D::LDX + DH * D::LDM + C * D::LDX + C * CMax<D::LDX, D::LDM>::v + C * D::LDX + DH * D::LDC + C * D::LDX +
+                                 C * D::LDF + D::F * D::LDC + C * D::LDC + D::F * D::LDX) +
+           sizeof(float) * (size_t)(4 * C + D::F);
+}
+template <typename CT, int DH, int MF, int C> static size_t dkv_lds() {
+    typedef FavorDims<CT, DH, MF, C> D;
+    return sizeof(CT) * (size_t)(MF * D::LDX + DH * D::LDM + 2 * C * CMax<D::LDX, D::LDC>::v + C * D::LDX + C * CMax<D::LDX, D::LDM>::v + DH * D::LDC +
+                                 2 * C * D::LDF + D::F * D::LDC + D::F * D::LDX + DH * D::LDF) +
+           sizeof(float) * (size_t)(4 * C + D::F);
+}
+
+#define EMO_MAX_LDS (160 * 1024)
+
+template <typename CT, int DH, int MF, int CF, int CQ, int CK>
+static int run_favor(int which, const void* q, const void* k, const void* v, int64_t ld, const float* omega, void* out, int64_t ld_out, float* den,
+                     float* sS, float* sz, const void* dout, void* dq, void* dk, void* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, float eps,
+                     hipStream_t st) {
+    dim3 grid((unsigned)(B * H));
+    if (which == 0) {
+        const size_t lds = fwd_lds<CT, DH, MF, CF>();
+        EMO_CHECK(lds <= EMO_MAX_LDS, "favor fwd: LDS %zu too large", lds);
+        auto kf = favor_fwd_kernel<CT, DH, MF, CF>;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        hipLaunchKernelGGL(kf, grid, dim3(256), lds, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (CT*)out, ld_out, den, sS, sz, T, H, eps);
+    } else {
+        const size_t l1 = dq_lds<CT, DH, MF, CQ>(), l2 = dkv_lds<CT, DH, MF, CK>();
+        EMO_CHECK(l1 <= EMO_MAX_LDS && l2 <= EMO_MAX_LDS, "favor bwd: LDS %zu / %zu too large", l1, l2);
+        auto k1 = favor_bwd_dq_kernel<CT, DH, MF, CQ>;
+        auto k2 = favor_bwd_dkv_kernel<CT, DH, MF, CK>;
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
+            (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+            attr = true;
+        }
+        hipLaunchKernelGGL(k1, grid, dim3(256), l1, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
+                           (CT*)dq, ld_d, T, H);
+        hipLaunchKernelGGL(k2, grid, dim3(256), l2, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
+                           (CT*)dk, (CT*)dv, ld_d, T, H);
+    }
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
+static int dispatch_favor(int which, int dtype, int64_t dh, int64_t mf, const void* q, const void* k, const void* v, int64_t ld, const float* omega,
+                          void* out, int64_t ld_out, float* den, float* sS, float* sz, const void* dout, void* dq, void* dk, void* dv, int64_t ld_d,
+                          int64_t B, int64_t T, int64_t H, float eps, hipStream_t st) {
+#define FAVOR_CASE(DHv, MFv, CFb, CQb, CKb, CFf, CQf, CKf)                                                                                   \
+    if (dh == DHv && mf == MFv) {                                                                                                            \
+        if (dtype == EMO_BF16)                                                                                                               \
+            return run_favor<bf16_t, DHv, MFv, CFb, CQb, CKb>(which, q, k, v, ld, omega, out, ld_out, den, sS, sz, dout, dq, dk, dv, ld_d, B, T, H, eps, st); \
+        return run_favor<float, DHv, MFv, CFf, CQf, CKf>(which, q, k, v, ld, omega, out, ld_out, den, sS, sz, dout, dq, dk, dv, ld_d, B, T, H, eps, st);     \
+    }
+    FAVOR_CASE(64, 64, 64, 64, 64, 32, 32, 16)
+    FAVOR_CASE(32, 64, 64, 64, 64, 32, 32, 32)
+    FAVOR_CASE(32, 32, 64, 64, 64, 32, 32, 32)
+    FAVOR_CASE(16, 16, 64, 64, 64, 32, 32, 32)
+    FAVOR_CASE(16, 32, 64, 64, 64, 32, 32, 32)
+#undef FAVOR_CASE
+    emo_set_error("favor attention: unsupported (d_head=%lld, n_feat=%lld); built: (64,128) (32,128) (32,64) (16,32) (16,64)", (long long)dh,
+                  (long long)(2 * mf));
+    return EMO_ERR_UNSUPPORTED;
+}
+
+static int favor_check(const void* q, const void* k, const void* v, int64_t ld, int64_t ld_out, int dtype, int64_t dh, int64_t n_feat) {
+    EMO_CHECK(q && k && v, "favor attention: null pointer");
+    EMO_CHECK(dtype == EMO_F32 || dtype == EMO_BF16, "favor attention: bad dtype");
+    const int64_t ve = dtype == EMO_BF16 ? 8 : 4;
+    EMO_CHECK(ld % ve == 0 && ld_out % 4 == 0 && dh % ve == 0, "favor attention: ld/dh must keep rows 16-B aligned");
+    EMO_CHECK(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0, "favor attention: q/k/v must be 16-B aligned");
+    EMO_CHECK(n_feat % 2 == 0, "favor attention: n_feat must be even");
+    return EMO_OK;
+}
+
+extern "C" int emo_favor_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const float* omega, void* out, int64_t ld_out, float* den,
+                                  float* state_S, float* state_z, int dtype, int64_t B, int64_t T, int64_t H, int64_t dh, int64_t n_feat, float eps,
+                                  emo_stream_t stream) {
+    int rc = favor_check(q, k, v, ld, ld_out, dtype, dh, n_feat);
+    if (rc) return rc;
+    EMO_CHECK(omega && out && den, "emo_favor_attn_fwd: null pointer");
+    EMO_CHECK(((uintptr_t)out & 15) == 0, "emo_favor_attn_fwd: out must be 16-B aligned");
+    EMO_CHECK(!(state_S && !state_z), "emo_favor_attn_fwd: state_S without state_z");
+    return dispatch_favor(0, dtype, dh, n_feat / 2, q, k, v, ld, omega, out, ld_out, den, state_S, state_z, nullptr, nullptr, nullptr, nullptr, 0, B, T, H,
+                          eps, (hipStream_t)stream);
+}
+
+extern "C" int emo_favor_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const float* omega, const void* out, const void* dout,
+                                  int64_t ld_out, const float* den, void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H,
+                                  int64_t dh, int64_t n_feat, float eps, emo_stream_t stream) {
+    int rc = favor_check(q, k, v, ld, ld_out, dtype, dh, n_feat);
+    if (rc) return rc;
+    EMO_CHECK(omega && out && dout && den && dq && dk && dv, "emo_favor_attn_bwd: null pointer");
+    EMO_CHECK(ld_d % 4 == 0, "emo_favor_attn_bwd: ld_d must be a multiple of 4");
+    EMO_CHECK((((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)out | (uintptr_t)dout) & 15) == 0, "emo_favor_attn_bwd: pointers must be 16-B aligned");
+    return dispatch_favor(1, dtype, dh, n_feat / 2, q, k, v, ld, omega, (void*)out, ld_out, (float*)den, nullptr, nullptr, dout, dq, dk, dv, ld_d, B, T, H,
+                          eps, (hipStream_t)stream);
+}
+
+extern "C" int emo_favor_decode_step(const void* q, const void* k, const void* v, int64_t ld, const float* omega, float* state_S, float* state_z, void* out,
+                                     int64_t ld_out, int dtype, int64_t n_streams, int64_t H, int64_t dh, int64_t n_feat, float eps, emo_stream_t stream) {
+    EMO_CHECK(q && k && v && omega && state_S && state_z && out, "emo_favor_decode_step: null pointer");
+    EMO_CHECK(dh <= 64 && n_feat <= 128 && n_feat % 2 == 0, "emo_favor_decode_step: needs d_head<=64, n_feat<=128");
+    dim3 grid((unsigned)(n_streams * H));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EMO_F32)
+        hipLaunchKernelGGL(favor_decode_kernel<float>, grid, dim3(128), 0, st, (const float*)q, (const float*)k, (const float*)v, ld, omega, state_S, state_z,
+                           (float*)out, ld_out, H, (int)dh, (int)(n_feat / 2), eps);
+    else
+        hipLaunchKernelGGL(favor_decode_kernel<bf16_t>, grid, dim3(128), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, omega, state_S,
+                           state_z, (bf16_t*)out, ld_out, H, (int)dh, (int)(n_feat / 2), eps);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}

@@ -1,0 +1,89 @@
+// LDS-image MFMA helpers shared by the attention kernels (emo_favor.hip, emo_softmax_attn.hip).
+// An "image" is an LDS matrix [rows][ld] whose reduction index k is contiguous; every contraction
+// is acc(16x16) += R . C^T over two images (bf16: ds_read_b128 + v_mfma_f32_16x16x32_bf16;
+// exact-f32 mode: ds_read_b32 + v_mfma_f32_16x16x4_f32).
+#pragma once
+#include "emo_common.h"
+
+template <typename CT> struct Img;
+template <> struct Img<bf16_t> {
+    static constexpr int KMIN = 32, PAD = 8, KSTEP = 32;
+    typedef bf16x8 V;
+    static __device__ __forceinline__ V load(const bf16_t* img, int ld, int row0, int k, int lane) {
+        return *(const bf16x8*)(img + (row0 + (lane & 15)) * ld + k + (lane >> 4) * 8);
+    }
+    static __device__ __forceinline__ f32x4 mma(V r, V c, f32x4 acc) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(r, c, acc, 0, 0, 0); }
+    static __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
+        bf16x4 t = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+        *(bf16x4*)p = t;
+    }
+    static __device__ __forceinline__ float ex(float x) { return __expf(x); }
+};
+template <> struct Img<float> {
+    static constexpr int KMIN = 4, PAD = 2, KSTEP = 4;
+    typedef float V;
+    static __device__ __forceinline__ V load(const float* img, int ld, int row0, int k, int lane) {
+        return img[(row0 + (lane & 15)) * ld + k + (lane >> 4)];
+    }
+    static __device__ __forceinline__ f32x4 mma(V r, V c, f32x4 acc) { return __builtin_amdgcn_mfma_f32_16x16x4f32(r, c, acc, 0, 0, 0); }
+    static __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
+    static __device__ __forceinline__ float ex(float x) { return expf(x); }
+};
+
+// acc(16x16) += R[rrow0.., :K] . Cc[crow0.., :K]^T.  Lane l, reg r owns (R-row = rrow0 + (l>>4)*4 + r, C-row = crow0 + (l&15)).
+template <typename CT>
+__device__ __forceinline__ void mm16(f32x4& acc, const CT* R, int ldr, int rrow0, const CT* Cc, int ldc, int crow0, int K, int lane) {
+    for (int k = 0; k < K; k += Img<CT>::KSTEP) {
+        typename Img<CT>::V a = Img<CT>::load(R, ldr, rrow0, k, lane);
+        typename Img<CT>::V b = Img<CT>::load(Cc, ldc, crow0, k, lane);
+        acc = Img<CT>::mma(a, b, acc);
+    }
+}
+
+template <int A, int B> struct CMax { static constexpr int v = A > B ? A : B; };
+
+// ---- global row tile [rows x NC] -> LDS image [rows][ld] (zero-fill invalid rows and pad columns up to NCP)
+template <typename CT, int NC, int NCP>
+__device__ __forceinline__ void load_rows(CT* img, int ld, const CT* __restrict__ src, int64_t ld_src, int rows, int valid_rows, int tid) {
+    constexpr int VE = 16 / sizeof(CT);  // elements per 16-B vector
+    constexpr int CH = NCP / VE;
+    for (int it = tid; it < rows * CH; it += 256) {
+        const int r = it / CH, c = (it % CH) * VE;
+        CT tmp[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) tmp[e] = from_f32<CT>(0.f);
+        if (r < valid_rows && c < NC) {
+            if constexpr (sizeof(CT) == 2) *(bf16x8*)tmp = *(const bf16x8*)(src + (int64_t)r * ld_src + c);
+            else *(f32x4*)tmp = *(const f32x4*)(src + (int64_t)r * ld_src + c);
+        }
+#pragma unroll
+        for (int e = 0; e < VE; ++e) img[r * ld + c + e] = tmp[e];
+    }
+}
+// ---- global row tile [rows x NC] -> transposed LDS image [NC][ld] (k = row index contiguous); rows even
+template <typename CT, int NC>
+__device__ __forceinline__ void load_rows_T(CT* img, int ld, const CT* __restrict__ src, int64_t ld_src, int rows, int valid_rows, int tid) {
+    constexpr int VE = 16 / sizeof(CT);
+    constexpr int CH = NC / VE;
+    const int pairs = rows >> 1;
+    for (int it = tid; it < pairs * CH; it += 256) {
+        const int p = it % pairs, c = (it / pairs) * VE;
+        CT a[VE], b[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) a[e] = b[e] = from_f32<CT>(0.f);
+        if (2 * p < valid_rows) {
+            if constexpr (sizeof(CT) == 2) *(bf16x8*)a = *(const bf16x8*)(src + (int64_t)(2 * p) * ld_src + c);
+            else *(f32x4*)a = *(const f32x4*)(src + (int64_t)(2 * p) * ld_src + c);
+        }
+        if (2 * p + 1 < valid_rows) {
+            if constexpr (sizeof(CT) == 2) *(bf16x8*)b = *(const bf16x8*)(src + (int64_t)(2 * p + 1) * ld_src + c);
+            else *(f32x4*)b = *(const f32x4*)(src + (int64_t)(2 * p + 1) * ld_src + c);
+        }
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            img[(c + e) * ld + 2 * p] = a[e];
+            img[(c + e) * ld + 2 * p + 1] = b[e];
+        }
+    }
+}
+

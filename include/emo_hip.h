@@ -1,0 +1,172 @@
+/*
+ * emo_hip.h — C-ABI of libemo_hip.so: the MI355X (gfx950) kernels behind the
+ * stage-2 causal-LM hot path of EMO-Disentanger (Performer / GPT-2 backbones).
+ *
+ * The reference has NO FFI: its seam is the Python object contract of
+ * MusicPerformer / MusicGPT2.  Each entry point below cites
+ * the reference lines (relative to /root/reference/stage2_accompaniment) whose
+ * arithmetic it replaces; the Python classes in emo-disentanger_amd/model/
+ * bind them through ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer owned by the caller (torch tensors);
+ *     the library never allocates or frees tensor memory; scratch is caller-provided
+ *     after the matching *_workspace_bytes() query;
+ *   - every launch takes an explicit hipStream_t (as void*) and is asynchronous;
+ *   - return value: 0 = ok, <0 = error (emo_last_error() gives a thread-local message);
+ *   - dims are int64_t, row-major; "ld" = row stride in ELEMENTS;
+ *   - dtype: EMO_F32 (parity mode: exact-f32 MFMA/VALU math) or EMO_BF16 (speed mode:
+ *     bf16 storage + bf16 MFMA, fp32 accumulation / statistics / scan state).
+ *   - dropout masks are never stored: forward and backward regenerate them from
+ *     (seed, offset, linear element index).
+ */
+#ifndef EMO_HIP_H
+#define EMO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* emo_stream_t; /* hipStream_t */
+
+enum { EMO_OK = 0, EMO_ERR_INVALID = -1, EMO_ERR_LAUNCH = -2, EMO_ERR_UNSUPPORTED = -3 };
+enum { EMO_F32 = 0, EMO_BF16 = 1 };
+enum { EMO_ACT_NONE = 0, EMO_ACT_RELU = 1, EMO_ACT_GELU_NEW = 2 };
+enum { EMO_MUL_NONE = 0, EMO_MUL_NONZERO = 1, EMO_MUL_DGELU_NEW = 2 };
+
+int emo_version(void);
+const char* emo_last_error(void);
+/* number of CUs of the current device (for grid sizing on the host side) */
+int emo_device_cus(void);
+
+/* ------------------------------------------------------------------ K2/K7/K8: dense GEMM on MFMA
+ * C[M,N] = epilogue( A·B )   with
+ *   a_trans=0: A stored [M,K] (k contiguous)      a_trans=1: A stored [K,M]
+ *   b_trans=0: B stored [N,K] (nn.Linear weight)  b_trans=1: B stored [K,N] (HF Conv1D weight)
+ * epilogue order: +bias[n] -> (aux_out = value) -> act -> *mul(mul_aux) -> dropout -> +residual
+ * Replaces: F.linear in fast-transformers AttentionLayer / TransformerEncoderLayer
+ * (called from model/fast_transformer_decoder.py:28-51), HF Conv1D addmm in GPT2Attention /
+ * GPT2MLP (model/music_gpt2.py:42-51,86), dec_out_proj (music_performer.py:27,65), and their
+ * autograd backward (dgrad / wgrad).
+ */
+typedef struct {
+    const float* bias;    /* [N] fp32 or NULL */
+    int act;              /* EMO_ACT_* */
+    void* aux_out;        /* NULL or [M,N] (dtype_out, ld=ldc): value before the activation */
+    const void* mul_aux;  /* NULL or [M,N] (dtype_out, ld=ldc), see mul_mode */
+    int mul_mode;         /* EMO_MUL_NONZERO: *= (mul_aux!=0)*mul_scale ; EMO_MUL_DGELU_NEW: *= gelu_new'(mul_aux) */
+    float mul_scale;
+    float p_drop;         /* dropout after the activation; element index = m*N+n */
+    uint64_t seed, offset;
+    const void* residual; /* NULL or [M,N] (dtype_out, ld=ldc) added last */
+} emo_epilogue_t;
+
+int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, int b_trans, int64_t ldb,
+             void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+             int dtype_in, int dtype_out, int accumulate /* C += result; fp32 out only */,
+             const emo_epilogue_t* epi /* may be NULL */, emo_stream_t stream);
+
+/* out[n] (+)= sum_m X[m,n] — bias gradients */
+int emo_colsum(const void* X, int dtype, int64_t M, int64_t N, int64_t ld, float* out,
+               int accumulate, emo_stream_t stream);
+
+/* ------------------------------------------------------------------ K1: embedding prologue
+ * out[b,t,:] = dropout( (E[tok[b,t]] + S[seg[b,t]]) * scale + pe[pos0 + t] )
+ * Replaces TokenEmbedding.forward x2 + PositionalEncoding + emb_dropout
+ * (model/transformer_helpers.py:81-87,57-63; model/music_performer.py:51-62).
+ * pe: fp32 rows of length D (the `pe.pe` buffer [max_pos,1,D] is exactly that). */
+int emo_embed_fwd(const int64_t* tok, const int64_t* seg, const float* E, const float* S,
+                  const float* pe, void* out, int dtype, int64_t B, int64_t T, int64_t D,
+                  int64_t V, int64_t n_seg, int64_t pos0, float scale, float p_drop,
+                  uint64_t seed, uint64_t offset, emo_stream_t stream);
+/* dE[tok] += dout*mask*scale ; dS[seg] += ...  (fp32 accumulate, caller zeroes) */
+int emo_embed_bwd(const int64_t* tok, const int64_t* seg, const void* dout, int dtype, float* dE,
+                  float* dS, int64_t B, int64_t T, int64_t D, int64_t V, int64_t n_seg,
+                  float scale, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream);
+
+/* ------------------------------------------------------------------ K6: LayerNorm (eps inside sqrt, biased var)
+ * Replaces nn.LayerNorm norm1/norm2 (fast-transformers TransformerEncoderLayer) and ln_1/ln_2 (HF GPT2Block). */
+int emo_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                      float* rstd, int dtype, int64_t M, int64_t D, float eps, emo_stream_t stream);
+/* dx = LN'(dy) (+ dres);  dx_drop (optional) = dx * dropmask(p,seed,offset);  dgamma/dbeta += (atomic) */
+int emo_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                      const float* rstd, const void* dres, void* dx, void* dx_drop, float* dgamma,
+                      float* dbeta, int dtype, int64_t M, int64_t D, float p_drop, uint64_t seed,
+                      uint64_t offset, emo_stream_t stream);
+/* out = x * dropmask  (backward of a dropout whose forward was fused in a GEMM epilogue) */
+int emo_dropout_apply(const void* x, void* out, int dtype, int64_t n, float p_drop, uint64_t seed,
+                      uint64_t offset, emo_stream_t stream);
+
+/* ------------------------------------------------------------------ K3+K4: FAVOR+ causal linear attention
+ * q,k,v: [B*T, H*dh] views with row stride ld (a fused [B*T,3*H*dh] projection works);
+ * omega [dh, n_feat/2] fp32; out [B*T, H*dh] (ld_out); den [B,H,T] fp32 (saved for backward).
+ * state_S [B,H,n_feat,dh] / state_z [B,H,n_feat] fp32: optional final scan state (decode prefill).
+ * Replaces fast-transformers Favor.forward + CausalLinearAttention.forward + native
+ * causal_product (called via model/fast_transformer_decoder.py:28-40) and their backward. */
+int emo_favor_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const float* omega,
+                       void* out, int64_t ld_out, float* den, float* state_S, float* state_z,
+                       int dtype, int64_t B, int64_t T, int64_t H, int64_t dh, int64_t n_feat,
+                       float eps, emo_stream_t stream);
+int emo_favor_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const float* omega,
+                       const void* out, const void* dout, int64_t ld_out, const float* den,
+                       void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T,
+                       int64_t H, int64_t dh, int64_t n_feat, float eps, emo_stream_t stream);
+/* one recurrent step per stream: state += phi(k) (x) v ; out = phi(q)^T S / (phi(q).z + eps) */
+int emo_favor_decode_step(const void* q, const void* k, const void* v, int64_t ld, const float* omega,
+                          float* state_S, float* state_z, void* out, int64_t ld_out, int dtype,
+                          int64_t n_streams, int64_t H, int64_t dh, int64_t n_feat, float eps,
+                          emo_stream_t stream);
+
+/* ------------------------------------------------------------------ K5: causal softmax attention (GPT-2)
+ * Replaces HF GPT2Attention._attn (model/music_gpt2.py:86): softmax(q k^T/sqrt(dh) + causal) [dropout] v.
+ * lse [B,H,T] fp32 saved for backward.  Dropout index = ((b*H+h)*T + i)*T + j. */
+int emo_softmax_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, void* out,
+                         int64_t ld_out, float* lse, int dtype, int64_t B, int64_t T, int64_t H,
+                         int64_t dh, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream);
+int emo_softmax_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* out,
+                         const void* dout, int64_t ld_out, const float* lse, void* dq, void* dk,
+                         void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H,
+                         int64_t dh, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream);
+/* decode: one query row per stream against a KV cache [n_streams, T_max, H*dh]; lens[s] = valid keys */
+int emo_softmax_attn_decode(const void* q, int64_t ld_q, const void* kcache, const void* vcache,
+                            int64_t T_max, const int64_t* lens, void* out, int64_t ld_out, int dtype,
+                            int64_t n_streams, int64_t H, int64_t dh, emo_stream_t stream);
+
+/* ------------------------------------------------------------------ K9: cross-entropy with ignore_index
+ * Replaces F.cross_entropy in compute_loss (model/music_performer.py:72-81).
+ * fwd: row_lse[m]; acc[0] += sum of -logp over kept rows, acc[1] += #kept rows (caller zeroes acc).
+ * bwd: dlogits[m,v] = (exp(l - lse) - [v==tgt]) * (tgt!=ignore) * gscale[0]   (gscale: device scalar) */
+int emo_xent_fwd(const float* logits, const int64_t* tgt, int64_t M, int64_t V, int64_t ignore_index,
+                 float* row_lse, float* acc, emo_stream_t stream);
+int emo_xent_bwd(const float* logits, const int64_t* tgt, const float* row_lse, const float* gscale,
+                 void* dlogits, int64_t ld_out /* >= V; columns V..ld_out-1 are zero-filled */,
+                 int dtype_out, int64_t M, int64_t V, int64_t ignore_index, emo_stream_t stream);
+
+/* ------------------------------------------------------------------ K10/K12: sampling + accuracy
+ * argmax over V per row (greedy / parity mode; first max wins like np.argmax / torch.argmax).
+ * nucleus: softmax(l/temp) -> sort desc -> keep through the token that crosses top_p
+ * (inference.py:71-100 semantics incl. F12) -> renormalise -> draw from u[row] in [0,1). */
+int emo_argmax(const float* logits, int64_t rows, int64_t V, int64_t* out, emo_stream_t stream);
+int emo_sample_nucleus(const float* logits, int64_t rows, int64_t V, float temperature, float top_p,
+                       const float* u, int64_t* out, emo_stream_t stream);
+/* counts[0..5] += {nonpad, nonpad&correct, chord, chord&correct, melody, melody&correct} (train.py:184-193) */
+int emo_accuracy_counts(const float* logits, const int64_t* tgt, const int64_t* chord,
+                        const int64_t* melody, int64_t M, int64_t V, int64_t pad, int64_t* counts,
+                        emo_stream_t stream);
+
+/* ------------------------------------------------------------------ optimizer plumbing (K11, SURVEY f-3)
+ * sumsq: acc[0] += sum x^2.  clip_coef: coef[0] = min(1, max_norm/(sqrt(sumsq*pre*pre)+1e-6)) * pre
+ * (pre = 1/world for DP-averaged grads).  adam: torch.optim.Adam semantics (no amsgrad, wd=0),
+ * grads scaled by gscale[0]; optionally refreshes the bf16 compute copy of the weights. */
+int emo_sumsq(const float* x, int64_t n, float* acc, emo_stream_t stream);
+int emo_clip_coef(const float* sumsq, float max_norm, float pre, float* coef, emo_stream_t stream);
+int emo_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                  float beta1, float beta2, float eps, int64_t step, const float* gscale,
+                  emo_stream_t stream);
+int emo_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, emo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMO_HIP_H */
