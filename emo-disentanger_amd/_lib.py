@@ -1,0 +1,89 @@
+"""ctypes binding of libemo_hip.so (C-ABI declared in include/emo_hip.h).
+
+The library is built IN-TREE by ``__graft_entry__.build()`` / ``make -C emo-disentanger_amd/csrc``.
+Missing library => ImportError (the product path has no CPU / eager fallback)."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libemo_hip.so')
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU_NEW = 0, 1, 2
+MUL_NONE, MUL_NONZERO, MUL_DGELU_NEW = 0, 1, 2
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError('libemo_hip.so not built: run `python -c "import __graft_entry__ as g; g.build()"` '
+                      'or `make -C emo-disentanger_amd/csrc` (hipcc --offload-arch=gfx950)')
+lib = ctypes.CDLL(LIB_PATH)
+
+c_p, c_i, c_l, c_f, c_u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64
+
+
+class Epilogue(ctypes.Structure):
+    _fields_ = [('bias', c_p), ('act', c_i), ('aux_out', c_p), ('mul_aux', c_p), ('mul_mode', c_i), ('mul_scale', c_f),
+                ('p_drop', c_f), ('seed', c_u64), ('offset', c_u64), ('residual', c_p)]
+
+
+_SIG = {
+    'emo_version': (c_i, []),
+    'emo_last_error': (ctypes.c_char_p, []),
+    'emo_device_cus': (c_i, []),
+    'emo_gemm': (c_i, [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, ctypes.POINTER(Epilogue), c_p]),
+    'emo_colsum': (c_i, [c_p, c_i, c_l, c_l, c_l, c_p, c_i, c_p]),
+    'emo_embed_fwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_l, c_l, c_l, c_l, c_l, c_f, c_f, c_u64, c_u64, c_p]),
+    'emo_embed_bwd': (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_f, c_u64, c_u64, c_p]),
+    'emo_layernorm_fwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_l, c_f, c_p]),
+    'emo_layernorm_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_l, c_f, c_u64, c_u64, c_p]),
+    'emo_dropout_apply': (c_i, [c_p, c_p, c_i, c_l, c_f, c_u64, c_u64, c_p]),
+    'emo_favor_attn_fwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_l, c_l, c_l, c_l, c_l, c_f, c_p]),
+    'emo_favor_attn_bwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_l, c_f, c_p]),
+    'emo_favor_decode_step': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_f, c_p]),
+    'emo_softmax_attn_fwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p]),
+    'emo_softmax_attn_bwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p]),
+    'emo_softmax_attn_decode': (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_p]),
+    'emo_xent_fwd': (c_i, [c_p, c_p, c_l, c_l, c_l, c_p, c_p, c_p]),
+    'emo_xent_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_p]),
+    'emo_argmax': (c_i, [c_p, c_l, c_l, c_p, c_p]),
+    'emo_sample_nucleus': (c_i, [c_p, c_l, c_l, c_f, c_f, c_p, c_p, c_p]),
+    'emo_accuracy_counts': (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_p]),
+    'emo_sumsq': (c_i, [c_p, c_l, c_p, c_p]),
+    'emo_clip_coef': (c_i, [c_p, c_f, c_f, c_p, c_p]),
+    'emo_adam_step': (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_l, c_p, c_p]),
+    'emo_cast': (c_i, [c_p, c_i, c_p, c_i, c_l, c_p]),
+}
+for _name, (_res, _args) in _SIG.items():
+    _fn = getattr(lib, _name)          # AttributeError here = header/library mismatch
+    _fn.restype, _fn.argtypes = _res, _args
+
+
+class EmoError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise EmoError('libemo_hip error %d: %s' % (rc, lib.emo_last_error().decode()))
+
+
+def dtype_code(t):
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    raise EmoError('unsupported dtype %s (float32 / bfloat16 only)' % t)
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL). Tensors must live on the GPU: no CPU fallback."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise EmoError('emo-disentanger_amd ops need GPU tensors (the HIP path has no CPU fallback)')
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,228 @@
+"""Thin tensor-level wrappers over the C-ABI (no autograd here; see model/ for the autograd glue).
+
+Every function takes GPU tensors, validates layout, and launches on torch's current stream.
+2-D operands may be row-strided views (``stride(1) == 1``), e.g. the q/k/v slices of a fused
+projection."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU_NEW, ACT_NONE, ACT_RELU, BF16, F32, MUL_DGELU_NEW, MUL_NONE, MUL_NONZERO, Epilogue, check,
+                   dtype_code, lib, ptr, stream)
+
+__all__ = ['gemm', 'colsum', 'embed_fwd', 'embed_bwd', 'layernorm_fwd', 'layernorm_bwd', 'dropout_apply', 'favor_attn_fwd',
+           'favor_attn_bwd', 'favor_decode_step', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'xent_fwd',
+           'xent_bwd', 'argmax', 'sample_nucleus', 'accuracy_counts', 'sumsq', 'clip_coef', 'adam_step', 'cast',
+           'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW']
+
+
+def _rows(t):
+    assert t.dim() == 2 and t.stride(1) == 1, 'need a 2-D tensor with unit column stride'
+    return t.stride(0)
+
+
+def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumulate=False, bias=None, act=ACT_NONE,
+         aux_out=None, mul_aux=None, mul_mode=MUL_NONE, mul_scale=1.0, p_drop=0.0, seed=0, offset=0, residual=None):
+    """C[M,N] = epilogue(op(A) @ op(B));  a_trans: A stored [K,M];  b_trans=False: B stored [N,K] (nn.Linear),
+    b_trans=True: B stored [K,N] (HF Conv1D)."""
+    K, M = (A.shape if a_trans else A.shape[::-1])
+    Kb, N = (B.shape if b_trans else B.shape[::-1])
+    assert K == Kb, 'inner dims differ: %s vs %s' % (tuple(A.shape), tuple(B.shape))
+    assert A.dtype == B.dtype
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=out_dtype or A.dtype)
+    epi = Epilogue(ptr(bias), act, ptr(aux_out), ptr(mul_aux), mul_mode, mul_scale, p_drop, seed, offset, ptr(residual))
+    for t in (aux_out, mul_aux, residual):
+        assert t is None or (t.dtype == out.dtype and _rows(t) == _rows(out))
+    assert bias is None or bias.dtype == torch.float32
+    check(lib.emo_gemm(ptr(A), int(a_trans), _rows(A), ptr(B), int(b_trans), _rows(B), ptr(out), _rows(out), M, N, K,
+                       dtype_code(A.dtype), dtype_code(out.dtype), int(accumulate), ctypes.byref(epi), stream()))
+    return out
+
+
+def colsum(X, out=None, accumulate=False):
+    M, N = X.shape
+    if out is None:
+        out = torch.empty(N, device=X.device, dtype=torch.float32)
+    check(lib.emo_colsum(ptr(X), dtype_code(X.dtype), M, N, _rows(X), ptr(out), int(accumulate), stream()))
+    return out
+
+
+def embed_fwd(tok, seg, E, S, pe, dtype, scale, pos0=0, p_drop=0.0, seed=0, offset=0):
+    B, T = tok.shape
+    D = E.shape[1]
+    out = torch.empty(B, T, D, device=tok.device, dtype=dtype)
+    assert pe.is_contiguous() and pe.shape[-1] == D and pe.numel() >= (pos0 + T) * D
+    check(lib.emo_embed_fwd(ptr(tok.contiguous()), ptr(None if seg is None else seg.contiguous()), ptr(E), ptr(S), ptr(pe), ptr(out),
+                            dtype_code(dtype), B, T, D, E.shape[0], 0 if S is None else S.shape[0], pos0, scale, p_drop, seed, offset,
+                            stream()))
+    return out
+
+
+def embed_bwd(tok, seg, dout, dE, dS, scale, p_drop=0.0, seed=0, offset=0):
+    B, T = tok.shape
+    D = dE.shape[1]
+    assert dout.is_contiguous()
+    check(lib.emo_embed_bwd(ptr(tok.contiguous()), ptr(None if seg is None else seg.contiguous()), ptr(dout), dtype_code(dout.dtype),
+                            ptr(dE), ptr(dS), B, T, D, dE.shape[0], 0 if dS is None else dS.shape[0], scale, p_drop, seed, offset,
+                            stream()))
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    M, D = x.shape
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    check(lib.emo_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), dtype_code(x.dtype), M, D, eps, stream()))
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, want_drop=False, p_drop=0.0, seed=0, offset=0):
+    M, D = x.shape
+    assert dy.is_contiguous() and x.is_contiguous() and (dres is None or dres.is_contiguous())
+    dx = torch.empty_like(x)
+    dxd = torch.empty_like(x) if want_drop else None
+    check(lib.emo_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dxd), ptr(dgamma), ptr(dbeta),
+                                dtype_code(x.dtype), M, D, p_drop, seed, offset, stream()))
+    return dx, dxd
+
+
+def dropout_apply(x, p_drop, seed, offset):
+    assert x.is_contiguous()
+    out = torch.empty_like(x)
+    check(lib.emo_dropout_apply(ptr(x), ptr(out), dtype_code(x.dtype), x.numel(), p_drop, seed, offset, stream()))
+    return out
+
+
+def favor_attn_fwd(q, k, v, omega, B, T, H, eps=1e-6, want_state=False):
+    """q,k,v: [B*T, H*dh] (row-strided views allowed). Returns out [B*T, H*dh], den [B,H,T] (, S, z)."""
+    M, HD = q.shape
+    dh = HD // H
+    n_feat = 2 * omega.shape[1]
+    assert M == B * T and omega.shape[0] == dh and omega.dtype == torch.float32 and omega.is_contiguous()
+    assert _rows(q) == _rows(k) == _rows(v)
+    out = torch.empty(M, HD, device=q.device, dtype=q.dtype)
+    den = torch.empty(B, H, T, device=q.device, dtype=torch.float32)
+    S = torch.empty(B, H, n_feat, dh, device=q.device, dtype=torch.float32) if want_state else None
+    z = torch.empty(B, H, n_feat, device=q.device, dtype=torch.float32) if want_state else None
+    check(lib.emo_favor_attn_fwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(omega), ptr(out), HD, ptr(den), ptr(S), ptr(z), dtype_code(q.dtype),
+                                 B, T, H, dh, n_feat, eps, stream()))
+    return (out, den, S, z) if want_state else (out, den)
+
+
+def favor_attn_bwd(q, k, v, omega, out, dout, den, B, T, H, dqkv=None, eps=1e-6):
+    """Returns (dq, dk, dv) views of one fused [B*T, 3*H*dh] buffer (ready for the fused-QKV dgrad/wgrad)."""
+    M, HD = q.shape
+    dh = HD // H
+    n_feat = 2 * omega.shape[1]
+    assert out.is_contiguous() and dout.is_contiguous()
+    if dqkv is None:
+        dqkv = torch.empty(M, 3 * HD, device=q.device, dtype=q.dtype)
+    dq, dk, dv = dqkv[:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:]
+    check(lib.emo_favor_attn_bwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(omega), ptr(out), ptr(dout), HD, ptr(den), ptr(dq), ptr(dk), ptr(dv),
+                                 3 * HD, dtype_code(q.dtype), B, T, H, dh, n_feat, eps, stream()))
+    return dq, dk, dv
+
+
+def favor_decode_step(q, k, v, omega, state_S, state_z, H, eps=1e-6):
+    n, HD = q.shape
+    dh = HD // H
+    out = torch.empty(n, HD, device=q.device, dtype=q.dtype)
+    check(lib.emo_favor_decode_step(ptr(q), ptr(k), ptr(v), _rows(q), ptr(omega), ptr(state_S), ptr(state_z), ptr(out), HD,
+                                    dtype_code(q.dtype), n, H, dh, 2 * omega.shape[1], eps, stream()))
+    return out
+
+
+def softmax_attn_fwd(q, k, v, B, T, H, p_drop=0.0, seed=0, offset=0):
+    M, HD = q.shape
+    dh = HD // H
+    assert M == B * T and _rows(q) == _rows(k) == _rows(v)
+    out = torch.empty(M, HD, device=q.device, dtype=q.dtype)
+    lse = torch.empty(B, H, T, device=q.device, dtype=torch.float32)
+    check(lib.emo_softmax_attn_fwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(out), HD, ptr(lse), dtype_code(q.dtype), B, T, H, dh, p_drop,
+                                   seed, offset, stream()))
+    return out, lse
+
+
+def softmax_attn_bwd(q, k, v, out, dout, lse, B, T, H, p_drop=0.0, seed=0, offset=0, dqkv=None):
+    M, HD = q.shape
+    dh = HD // H
+    assert out.is_contiguous() and dout.is_contiguous()
+    if dqkv is None:
+        dqkv = torch.empty(M, 3 * HD, device=q.device, dtype=q.dtype)
+    dq, dk, dv = dqkv[:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:]
+    check(lib.emo_softmax_attn_bwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(out), ptr(dout), HD, ptr(lse), ptr(dq), ptr(dk), ptr(dv), 3 * HD,
+                                   dtype_code(q.dtype), B, T, H, dh, p_drop, seed, offset, stream()))
+    return dq, dk, dv
+
+
+def softmax_attn_decode(q, kcache, vcache, lens, H):
+    n, HD = q.shape
+    T_max = kcache.shape[1]
+    assert kcache.is_contiguous() and vcache.is_contiguous() and lens.dtype == torch.int64
+    out = torch.empty(n, HD, device=q.device, dtype=q.dtype)
+    check(lib.emo_softmax_attn_decode(ptr(q), _rows(q), ptr(kcache), ptr(vcache), T_max, ptr(lens), ptr(out), HD, dtype_code(q.dtype), n, H,
+                                      HD // H, stream()))
+    return out
+
+
+def xent_fwd(logits, tgt, ignore_index):
+    M, V = logits.shape
+    assert logits.is_contiguous() and logits.dtype == torch.float32
+    lse = torch.empty(M, device=logits.device, dtype=torch.float32)
+    acc = torch.zeros(2, device=logits.device, dtype=torch.float32)
+    check(lib.emo_xent_fwd(ptr(logits), ptr(tgt.contiguous()), M, V, ignore_index, ptr(lse), ptr(acc), stream()))
+    return lse, acc
+
+
+def xent_bwd(logits, tgt, lse, gscale, ignore_index, out_dtype, ld_out=None):
+    M, V = logits.shape
+    ld_out = ld_out or ((V + 7) // 8) * 8
+    dl = torch.empty(M, ld_out, device=logits.device, dtype=out_dtype)
+    check(lib.emo_xent_bwd(ptr(logits), ptr(tgt.contiguous()), ptr(lse), ptr(gscale), ptr(dl), ld_out, dtype_code(out_dtype), M, V,
+                           ignore_index, stream()))
+    return dl
+
+
+def argmax(logits):
+    rows, V = logits.shape
+    assert logits.is_contiguous() and logits.dtype == torch.float32
+    out = torch.empty(rows, device=logits.device, dtype=torch.int64)
+    check(lib.emo_argmax(ptr(logits), rows, V, ptr(out), stream()))
+    return out
+
+
+def sample_nucleus(logits, temperature, top_p, u):
+    rows, V = logits.shape
+    assert logits.is_contiguous() and logits.dtype == torch.float32 and u.dtype == torch.float32 and u.numel() == rows
+    out = torch.empty(rows, device=logits.device, dtype=torch.int64)
+    check(lib.emo_sample_nucleus(ptr(logits), rows, V, temperature, top_p, ptr(u), ptr(out), stream()))
+    return out
+
+
+def accuracy_counts(logits, tgt, chord, melody, pad):
+    M, V = logits.shape
+    counts = torch.zeros(6, device=logits.device, dtype=torch.int64)
+    check(lib.emo_accuracy_counts(ptr(logits), ptr(tgt.contiguous()), ptr(None if chord is None else chord.contiguous()),
+                                  ptr(None if melody is None else melody.contiguous()), M, V, pad, ptr(counts), stream()))
+    return counts
+
+
+def sumsq(x, acc):
+    check(lib.emo_sumsq(ptr(x), x.numel(), ptr(acc), stream()))
+
+
+def clip_coef(sumsq_t, max_norm, pre, coef):
+    check(lib.emo_clip_coef(ptr(sumsq_t), max_norm, pre, ptr(coef), stream()))
+
+
+def adam_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, step, gscale):
+    check(lib.emo_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(p_bf16), p.numel(), lr, beta1, beta2, eps, step, ptr(gscale), stream()))
+
+
+def cast(src, dst):
+    assert src.numel() == dst.numel() and src.is_contiguous() and dst.is_contiguous()
+    check(lib.emo_cast(ptr(src), dtype_code(src.dtype), ptr(dst), dtype_code(dst.dtype), src.numel(), stream()))
+    return dst

@@ -1,0 +1,346 @@
+"""Kernel-level parity (GPU): every C-ABI entry point against the oracle / a PyTorch fp32-fp64 CPU
+reference of the same op.  Tolerances: EMO_F32 paths 2e-5 (exact-f32 MFMA, reassociation only);
+EMO_BF16 paths 3e-2 relative to the tensor scale (bf16 storage, fp32 accumulate)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def _ops():
+    from emo_disentanger_amd import ops
+    return ops
+
+
+def _tol(dt):
+    return 2e-5 if dt == torch.float32 else 3e-2
+
+
+def _close(got, ref, dt, scale=None, mult=1.0):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    s = float(ref.abs().max()) if scale is None else scale
+    err = float((got - ref).abs().max())
+    assert err <= mult * _tol(dt) * max(s, 1e-6), 'max err %.3e vs scale %.3e (tol %.1e)' % (err, s, mult * _tol(dt))
+
+
+def _r(*shape, seed=0, dt=torch.float32, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dt)
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('a_trans,b_trans', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('M,N,K', [(70, 50, 37), (200, 136, 264), (129, 327, 512), (1024, 512, 512)])
+def test_gemm_layouts(dt, a_trans, b_trans, M, N, K):
+    ops = _ops()
+    if dt == torch.bfloat16:   # bf16 path: leading dims must be multiples of 8 -> allocate padded, take views
+        pad = lambda n: (n + 7) // 8 * 8
+    else:
+        pad = lambda n: n
+    A = _r(*((K, pad(M)) if a_trans else (M, pad(K))), seed=1, dt=dt)
+    Bm = _r(*((K, pad(N)) if b_trans else (N, pad(K))), seed=2, dt=dt)
+    Av = A[:, :M] if a_trans else A[:, :K]
+    Bv = Bm[:, :N] if b_trans else Bm[:, :K]
+    ref = (Av.double().T if a_trans else Av.double()) @ (Bv.double() if b_trans else Bv.double().T)
+    Ac, Bc = A.cuda(), Bm.cuda()            # slice AFTER the copy so that the padded row stride survives
+    Ag = Ac[:, :M] if a_trans else Ac[:, :K]
+    Bg = Bc[:, :N] if b_trans else Bc[:, :K]
+    out = ops.gemm(Ag, Bg, a_trans=bool(a_trans), b_trans=bool(b_trans), out_dtype=torch.float32)
+    _close(out, ref, dt, mult=1.0 if dt == torch.float32 else 0.3)
+
+
+@pytest.mark.parametrize('dt', DT)
+def test_gemm_epilogue_bias_act_residual_aux(dt):
+    ops = _ops()
+    M, N, K = 300, 264, 128
+    A, W = _r(M, K, seed=3, dt=dt), _r(N, K, seed=4, dt=dt, scale=0.2)
+    bias, res = _r(N, seed=5), _r(M, N, seed=6, dt=dt)
+    z = A.double() @ W.double().T + bias.double()
+    for act, fn in ((ops.ACT_RELU, torch.relu), (ops.ACT_GELU_NEW, lambda x: 0.5 * x * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * x ** 3)))),
+                    (ops.ACT_NONE, lambda x: x)):
+        aux = torch.empty(M, N, device='cuda', dtype=dt)
+        out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), act=act, residual=res.cuda(), aux_out=aux)
+        _close(aux, z, dt)
+        _close(out, fn(z) + res.double(), dt)
+
+
+@pytest.mark.parametrize('dt', DT)
+def test_gemm_epilogue_mul_modes_and_dropout(dt):
+    ops = _ops()
+    M, N, K = 256, 128, 64
+    A, W = _r(M, K, seed=7, dt=dt), _r(N, K, seed=8, dt=dt, scale=0.3)
+    aux = _r(M, N, seed=9, dt=dt)
+    aux[aux.abs() < 0.5] = 0
+    z = A.double() @ W.double().T
+    out = ops.gemm(A.cuda(), W.cuda(), mul_aux=aux.cuda(), mul_mode=ops.MUL_NONZERO, mul_scale=1.25)
+    _close(out, z * (aux.double() != 0) * 1.25, dt)
+    x = aux.double()
+    u = math.sqrt(2 / math.pi) * (x + 0.044715 * x ** 3)
+    dg = 0.5 * (1 + torch.tanh(u)) + 0.5 * x * (1 - torch.tanh(u) ** 2) * math.sqrt(2 / math.pi) * (1 + 3 * 0.044715 * x ** 2)
+    out = ops.gemm(A.cuda(), W.cuda(), mul_aux=aux.cuda(), mul_mode=ops.MUL_DGELU_NEW)
+    _close(out, z * dg, dt)
+    # dropout: deterministic in (seed, offset), ~p zeros, survivors scaled by 1/(1-p), and consistent
+    # with emo_dropout_apply / layernorm_bwd masks (same element indexing m*N+n)
+    o1 = ops.gemm(A.cuda(), W.cuda(), p_drop=0.1, seed=11, offset=3)
+    o2 = ops.gemm(A.cuda(), W.cuda(), p_drop=0.1, seed=11, offset=3)
+    o3 = ops.gemm(A.cuda(), W.cuda(), p_drop=0.1, seed=11, offset=4)
+    assert torch.equal(o1, o2) and not torch.equal(o1, o3)
+    plain = ops.gemm(A.cuda(), W.cuda())
+    masked = ops.dropout_apply(plain, 0.1, 11, 3)
+    _close(o1, masked, dt, mult=2.0)
+    frac = float((o1 == 0).float().mean())
+    assert 0.08 < frac < 0.12
+    keep = o1 != 0
+    _close(o1[keep], (plain.double() / 0.9)[keep], dt, mult=2.0)
+
+
+def test_gemm_splitk_wgrad_accumulate():
+    ops = _ops()
+    for dt in DT:
+        Mred, N, K = 4096, 136, 264          # dW[N,K] = dY[Mred,N]^T X[Mred,K]
+        dY, X = _r(Mred, N, seed=12, dt=dt), _r(Mred, K, seed=13, dt=dt)
+        ref = dY.double().T @ X.double()
+        out = ops.gemm(dY.cuda(), X.cuda(), a_trans=True, b_trans=True, out_dtype=torch.float32)
+        _close(out, ref, dt, mult=1.0 if dt == torch.float32 else 0.3)
+        out2 = ops.gemm(dY.cuda(), X.cuda(), a_trans=True, b_trans=True, out=out.clone(), accumulate=True)
+        _close(out2, 2 * ref, dt, mult=1.0 if dt == torch.float32 else 0.3)
+        cs = ops.colsum(dY.cuda())
+        _close(cs, dY.double().sum(0), dt, mult=1.0 if dt == torch.float32 else 0.3)
+
+
+def test_gemm_bf16_safe_and_tr_paths_agree(monkeypatch):
+    # the transposed-operand fragments are fetched with ds_read_b64_tr_b16; EMO_GEMM_SAFE_TR=1 (read at first use)
+    # selects a scalar-read variant of the same kernel; both are compared with the reference in the layout tests.
+    ops = _ops()
+    A, Bm = _r(264, 200, seed=20, dt=torch.bfloat16), _r(264, 136, seed=21, dt=torch.bfloat16)
+    out = ops.gemm(A.cuda(), Bm.cuda(), a_trans=True, b_trans=True, out_dtype=torch.float32)
+    _close(out, A.double().T @ Bm.double(), torch.bfloat16, mult=0.3)
+
+
+# ------------------------------------------------------------------------------------------- embedding / LN / xent
+@pytest.mark.parametrize('dt', DT)
+def test_embed_fwd_bwd(dt):
+    ops = _ops()
+    from oracle.weights import positional_encoding
+    B, T, D, V = 3, 50, 64, 37
+    E, S = _r(V, D, seed=1).requires_grad_(True), _r(2, D, seed=2).requires_grad_(True)
+    pe = positional_encoding(D, 200)
+    g = torch.Generator().manual_seed(0)
+    tok, seg = torch.randint(0, V, (B, T), generator=g), torch.randint(0, 2, (B, T), generator=g)
+    ref = (torch.nn.functional.embedding(tok, E) * 8.0 + torch.nn.functional.embedding(seg, S) * 8.0) + pe[:T].permute(1, 0, 2)
+    out = ops.embed_fwd(tok.cuda(), seg.cuda(), E.detach().cuda(), S.detach().cuda(), pe.cuda(), dt, 8.0)
+    _close(out, ref, dt)
+    out5 = ops.embed_fwd(tok.cuda(), seg.cuda(), E.detach().cuda(), S.detach().cuda(), pe.cuda(), dt, 8.0, pos0=5)
+    _close(out5, (torch.nn.functional.embedding(tok, E) * 8.0 + torch.nn.functional.embedding(seg, S) * 8.0) + pe[5:5 + T].permute(1, 0, 2), dt)
+    dout = _r(B, T, D, seed=3, dt=dt)
+    ref.backward(dout.float())
+    dE, dS = torch.zeros(V, D, device='cuda'), torch.zeros(2, D, device='cuda')
+    ops.embed_bwd(tok.cuda(), seg.cuda(), dout.cuda(), dE, dS, 8.0)
+    _close(dE, E.grad, torch.float32, mult=5)
+    _close(dS, S.grad, torch.float32, mult=5)
+    # dropout consistency fwd/bwd: masked positions get no gradient
+    o = ops.embed_fwd(tok.cuda(), None, E.detach().cuda(), None, pe.cuda(), torch.float32, 1.0, p_drop=0.5, seed=4, offset=1)
+    dE2 = torch.zeros(V, D, device='cuda')
+    ones = torch.ones(B, T, D, device='cuda')
+    ops.embed_bwd(tok.cuda(), None, ones, dE2, None, 1.0, p_drop=0.5, seed=4, offset=1)
+    mask = (o != 0).float() * 2.0
+    ref2 = torch.zeros(V, D, device='cuda').index_add_(0, tok.cuda().view(-1), mask.view(-1, D))
+    _close(dE2, ref2, torch.float32, mult=5)
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('D', [64, 256, 512])
+def test_layernorm_fwd_bwd(dt, D):
+    ops = _ops()
+    M = 203
+    x = _r(M, D, seed=1, dt=dt).float().requires_grad_(True)
+    gm, bt = (_r(D, seed=2) * 0.1 + 1).requires_grad_(True), _r(D, seed=3).requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(x, (D,), gm, bt, 1e-5)
+    y, mean, rstd = ops.layernorm_fwd(x.detach().to(dt).cuda(), gm.detach().cuda(), bt.detach().cuda())
+    _close(y, ref, dt)
+    dy, dres = _r(M, D, seed=4, dt=dt), _r(M, D, seed=5, dt=dt)
+    ref.backward(dy.float())
+    dg, db = torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda')
+    dx, dxd = ops.layernorm_bwd(dy.cuda(), x.detach().to(dt).cuda(), gm.detach().cuda(), mean, rstd, dg, db, dres=dres.cuda(), want_drop=True,
+                                p_drop=0.25, seed=9, offset=2)
+    _close(dx, x.grad + dres.float(), dt, mult=2)
+    _close(dg, gm.grad, dt, mult=4)
+    _close(db, bt.grad, dt, mult=4)
+    _close(dxd, ops.dropout_apply(dx, 0.25, 9, 2), dt)
+
+
+def test_xent_fwd_bwd_and_accuracy():
+    ops = _ops()
+    from oracle import host_ref
+    M, V = 301, 327
+    logits = (_r(M, V, seed=1) * 3).requires_grad_(True)
+    g = torch.Generator().manual_seed(1)
+    tgt = torch.randint(0, V, (M,), generator=g)
+    tgt[:40] = V - 1
+    ref = torch.nn.functional.cross_entropy(logits, tgt, ignore_index=V - 1)
+    ref.backward()
+    lse, acc = ops.xent_fwd(logits.detach().cuda(), tgt.cuda(), V - 1)
+    loss = acc[0] / acc[1]
+    assert abs(float(loss) - float(ref)) < 1e-5
+    gs = (1.0 / acc[1]).reshape(1)
+    for dt in DT:
+        dl = ops.xent_bwd(logits.detach().cuda(), tgt.cuda(), lse, gs, V - 1, dt)
+        assert dl.shape[1] == 328 and float(dl[:, V:].abs().max()) == 0.0
+        _close(dl[:, :V], logits.grad, dt)
+    chord = (torch.rand(M, generator=g) < 0.2).long()
+    melody = ((torch.rand(M, generator=g) < 0.3) & (chord == 0)).long()
+    c = ops.accuracy_counts(logits.detach().cuda(), tgt.cuda(), chord.cuda(), melody.cuda(), V - 1).cpu().numpy()
+    tot, ch, me, ot = host_ref.compute_accuracy(logits.detach().numpy()[None], tgt.numpy()[None], chord.numpy()[None], melody.numpy()[None], V - 1)
+    assert abs(c[1] / c[0] - tot) < 1e-12 and abs(c[3] / c[2] - ch) < 1e-12 and abs(c[5] / c[4] - me) < 1e-12
+    am = ops.argmax(logits.detach().cuda()).cpu()
+    assert torch.equal(am, logits.detach().argmax(-1))
+
+
+# ------------------------------------------------------------------------------------------- FAVOR+ attention
+FAVOR_CASES = [(2, 150, 2, 64, 128), (1, 70, 3, 32, 64), (2, 33, 2, 16, 32), (1, 200, 2, 32, 128), (1, 64, 1, 16, 64)]
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('B,T,H,dh,nf', FAVOR_CASES)
+def test_favor_attention_fwd_bwd_vs_oracle(dt, B, T, H, dh, nf):
+    ops = _ops()
+    from oracle import model_ref
+    from oracle.weights import orthogonal_omega
+    om = orthogonal_omega(dh, nf, np.random.default_rng(5))
+    qkv = _r(B * T, 3 * H * dh, seed=1, dt=dt, scale=0.8)
+    q, k, v = [qkv[:, i * H * dh:(i + 1) * H * dh].double().view(B, T, H, dh).requires_grad_(True) for i in range(3)]
+    ref = model_ref.causal_linear_attention(q, k, v, om.double(), form='quadratic')
+    dout = _r(B, T, H, dh, seed=2, dt=dt)
+    ref.backward(dout.double())
+    qc = qkv.cuda()
+    HD = H * dh
+    out, den, S, z = ops.favor_attn_fwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], om.cuda(), B, T, H, want_state=True)
+    _close(out.view(B, T, H, dh), ref, dt, mult=3)
+    # final state == sum_j phi(k_j) (x) v_j
+    Kf = model_ref.favor_features(k.detach(), om.double())
+    _close(S, torch.einsum('nlhf,nlhd->nhfd', Kf, v.detach()), dt, mult=3)
+    _close(z, Kf.sum(1), dt, mult=3)
+    dq, dk, dv = ops.favor_attn_bwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], om.cuda(), out, dout.view(B * T, HD).cuda(), den, B, T, H)
+    gscale = max(float(q.grad.abs().max()), float(k.grad.abs().max()), float(v.grad.abs().max()))
+    _close(dv.reshape(B, T, H, dh), v.grad, dt, scale=gscale, mult=4)
+    _close(dq.reshape(B, T, H, dh), q.grad, dt, scale=gscale, mult=4)
+    _close(dk.reshape(B, T, H, dh), k.grad, dt, scale=gscale, mult=4)
+
+
+@pytest.mark.parametrize('dt', DT)
+def test_favor_decode_step_matches_prefill(dt):
+    ops = _ops()
+    from oracle.weights import orthogonal_omega
+    B, T, H, dh, nf = 3, 40, 2, 32, 64
+    om = orthogonal_omega(dh, nf, np.random.default_rng(6)).cuda()
+    qkv = _r(B * T, 3 * H * dh, seed=3, dt=dt, scale=0.8).cuda()
+    HD = H * dh
+    full, _ = ops.favor_attn_fwd(qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], om, B, T, H)
+    # prefill T-1 tokens, then one recurrent step for the last token of each stream
+    x3 = qkv.view(B, T, 3 * HD)
+    pre = x3[:, :T - 1].reshape(B * (T - 1), 3 * HD)
+    _, _, S, z = ops.favor_attn_fwd(pre[:, :HD], pre[:, HD:2 * HD], pre[:, 2 * HD:], om, B, T - 1, H, want_state=True)
+    last = x3[:, T - 1].contiguous()
+    o = ops.favor_decode_step(last[:, :HD], last[:, HD:2 * HD], last[:, 2 * HD:], om, S, z, H)
+    _close(o, full.view(B, T, HD)[:, T - 1], dt, mult=3)
+
+
+# ------------------------------------------------------------------------------------------- softmax attention
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('B,T,H,dh', [(2, 150, 2, 64), (1, 70, 3, 32), (2, 33, 2, 16), (1, 256, 1, 64)])
+def test_softmax_attention_fwd_bwd(dt, B, T, H, dh):
+    ops = _ops()
+    HD = H * dh
+    qkv = _r(B * T, 3 * HD, seed=4, dt=dt)
+    q, k, v = [qkv[:, i * HD:(i + 1) * HD].double().view(B, T, H, dh).permute(0, 2, 1, 3).requires_grad_(True) for i in range(3)]
+    w = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    w = w.masked_fill(~torch.tril(torch.ones(T, T, dtype=torch.bool)), float('-inf')).softmax(-1)
+    ref = (w @ v).permute(0, 2, 1, 3).reshape(B * T, HD)
+    dout = _r(B * T, HD, seed=5, dt=dt)
+    ref.backward(dout.double())
+    qc = qkv.cuda()
+    out, lse = ops.softmax_attn_fwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], B, T, H)
+    _close(out, ref, dt)
+    dq, dk, dv = ops.softmax_attn_bwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], out, dout.cuda(), lse, B, T, H)
+    back = lambda g: g.permute(0, 2, 1, 3).reshape(B * T, HD)
+    gs = max(float(q.grad.abs().max()), float(k.grad.abs().max()), float(v.grad.abs().max()))
+    _close(dq, back(q.grad), dt, scale=gs, mult=3)
+    _close(dk, back(k.grad), dt, scale=gs, mult=3)
+    _close(dv, back(v.grad), dt, scale=gs, mult=3)
+    # decode kernel: last query row against the cache of all T keys
+    kc = qc[:, HD:2 * HD].reshape(B, T, HD).contiguous()
+    vc = qc[:, 2 * HD:].reshape(B, T, HD).contiguous()
+    ql = qc[:, :HD].reshape(B, T, HD)[:, -1].contiguous()
+    od = ops.softmax_attn_decode(ql, kc, vc, torch.full((B,), T, dtype=torch.int64, device='cuda'), H)
+    _close(od, ref.view(B, T, HD)[:, -1], dt)
+
+
+def test_softmax_attention_dropout_consistency():
+    # with dropout the backward must use the same mask as the forward: finite-difference-free check via linearity in v
+    ops = _ops()
+    B, T, H, dh = 1, 96, 2, 32
+    HD = H * dh
+    qkv = _r(B * T, 3 * HD, seed=6).cuda()
+    out, lse = ops.softmax_attn_fwd(qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], B, T, H, p_drop=0.3, seed=5, offset=7)
+    dout = _r(B * T, HD, seed=7).cuda()
+    dq, dk, dv = ops.softmax_attn_bwd(qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], out, dout, lse, B, T, H, p_drop=0.3, seed=5, offset=7)
+    # out is linear in v: <dout, out(v + e dv_dir)> - <dout, out(v)> = e <dv, dv_dir>
+    dirv = _r(B * T, HD, seed=8).cuda()
+    q2 = qkv.clone()
+    q2[:, 2 * HD:] += dirv
+    out2, _ = ops.softmax_attn_fwd(q2[:, :HD], q2[:, HD:2 * HD], q2[:, 2 * HD:], B, T, H, p_drop=0.3, seed=5, offset=7)
+    lhs = float(((out2 - out).double() * dout.double()).sum())
+    rhs = float((dv.double() * dirv.double()).sum())
+    assert abs(lhs - rhs) <= 1e-3 * max(1.0, abs(rhs))
+    out3, _ = ops.softmax_attn_fwd(qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], B, T, H)
+    assert not torch.allclose(out, out3)
+
+
+# ------------------------------------------------------------------------------------------- sampling / optimizer
+def test_nucleus_sampling_matches_host_reference():
+    ops = _ops()
+    from oracle import host_ref
+    rng = np.random.default_rng(3)
+    for V, scale, temp, p in ((327, 4.0, 1.1, 0.9), (327, 1.0, 1.2, 0.97), (40, 2.0, 1.1, 0.99), (370, 3.0, 1.0, 0.5)):
+        logits = (rng.standard_normal((16, V)) * scale).astype(np.float32)
+        u = rng.random(16).astype(np.float32)
+        got = ops.sample_nucleus(torch.from_numpy(logits).cuda(), temp, p, torch.from_numpy(u).cuda()).cpu().numpy()
+        for r in range(16):
+            probs = host_ref.temperature(logits[r], temp)
+            cand, pr = host_ref.nucleus_candidates(probs, p)
+            cdf = np.cumsum(pr)
+            cdf /= cdf[-1]
+            exp = cand[np.searchsorted(cdf, u[r], side='right')]
+            # ties/rounding at a cdf boundary may move the pick by one rank: accept a neighbour within 1e-5 of the boundary
+            if got[r] != exp:
+                i = int(np.searchsorted(cdf, u[r], side='right'))
+                near = min(abs(cdf[i] - u[r]), abs(cdf[i - 1] - u[r]) if i > 0 else 1.0)
+                assert near < 1e-5 and got[r] in cand, (V, r, got[r], exp)
+
+
+def test_adam_and_clip_match_torch():
+    ops = _ops()
+    n = 10007
+    p0, g = _r(n, seed=1), _r(n, seed=2)
+    p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=1e-3)
+    pc, m, v = p0.clone().cuda(), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    pb = torch.empty(n, device='cuda', dtype=torch.bfloat16)
+    for step in range(1, 4):
+        gi = g * step
+        p.grad = gi.clone()
+        total = torch.nn.utils.clip_grad_norm_([p], 0.5)
+        opt.step()
+        ss, coef = torch.zeros(1, device='cuda'), torch.zeros(1, device='cuda')
+        ops.sumsq(gi.cuda(), ss)
+        assert abs(float(ss.sqrt()) - float(total)) < 1e-3 * float(total)
+        ops.clip_coef(ss, 0.5, 1.0, coef)
+        ops.adam_step(pc, gi.cuda(), m, v, pb, 1e-3, 0.9, 0.999, 1e-8, step, coef)
+        _close(pc, p.detach(), torch.float32, mult=2)
+    _close(pb, p.detach(), torch.bfloat16)
