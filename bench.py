@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py — training tokens/s of the stage-2 Performer (d512, L12, H8, F128, seq 2048, bf16) on
+synthetic EMOPIA-shaped batches: BASELINE.json configs[1] at N=1, configs[2] (DP over RCCL) at N>1.
+
+One "step" = zero_grad + forward + CE loss + backward + grad all-reduce (N>1) + clip(0.5) + Adam +
+LR schedule + device-side accuracy counts, with dropout 0.1 active and omega redrawn every forward
+(reference-faithful).  Prints ONE JSON line on rank 0 (contract in the task statement) with
+`roofline` (dominant kernel, HIP-event timed on the launch stream) and `cpu_baseline` (the oracle's
+CPU training step timed on this box's host cores; N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch  # noqa: E402
+
+CFG = dict(n_token=327, n_layer=12, n_head=8, d_model=512, d_ff=2048, n_feat=128, seq=2048)
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def gemm_flops_per_token():
+    d, f, L, V = CFG['d_model'], CFG['d_ff'], CFG['n_layer'], CFG['n_token']
+    return 3 * (L * 2 * (4 * d * d + 2 * d * f) + 2 * d * V)      # fwd + dgrad + wgrad = 227.5 MFLOP
+
+
+def time_kernel(fn, iters=10, warm=3):
+    """Average duration (ms) of `fn` (launches on torch's current stream) measured with HIP events on that stream."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def dominant_kernel_roofline(B, T):
+    """The forward/dgrad GEMMs all run the same kernel template (gemm_bf16_kernel, K-contiguous A); time
+    the per-layer launch mix of the NT instance [QKV, out-proj, FFN1, FFN2] and report FLOP/s over the mix."""
+    from emo_disentanger_amd import ops
+    M, d, f = B * T, CFG['d_model'], CFG['d_ff']
+    dev = 'cuda'
+    shapes = [(M, 3 * d, d), (M, d, d), (M, f, d), (M, d, f)]
+    tot_ms, tot_flop, per = 0.0, 0.0, []
+    for (m, n, k) in shapes:
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = (torch.randn(n, k, device=dev) * 0.02).to(torch.bfloat16)
+        out = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+        ms = time_kernel(lambda: ops.gemm(a, w, out=out))
+        fl = 2.0 * m * n * k
+        per.append({'M': m, 'N': n, 'K': k, 'ms': round(ms, 4), 'tflops': round(fl / ms / 1e9, 1)})
+        tot_ms += ms
+        tot_flop += fl
+        del a, w, out
+    achieved = tot_flop / tot_ms / 1e9
+    return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+            'kernel': 'gemm_bf16_kernel<A_KC=1,B_KC=1> (fwd Linear GEMMs: QKV, out-proj, FFN1, FFN2)',
+            'avg_launch_ms': round(tot_ms / len(shapes), 4), 'per_shape': per}
+
+
+def cpu_baseline(T, steps=2):
+    """Oracle (CPU restatement of the reference path: torch fp32 eager + the C causal-product) timed on the host cores."""
+    from oracle import model_ref
+    from oracle.weights import make_state_dict, synthetic_batch
+    sd = make_state_dict('performer', CFG['n_token'], CFG['n_layer'], CFG['n_head'], CFG['d_model'], CFG['d_ff'], favor_feature_dims=CFG['n_feat'], seed=0)
+    b = synthetic_batch(CFG['n_token'], 1, T, seed=1234)
+    cores = torch.get_num_threads()
+    args = ('performer', sd, b, CFG['n_token'], CFG['n_layer'], CFG['n_head'], CFG['d_model'])
+    model_ref.loss_and_grads(*args, p_drop=0.1, training=True)        # warm-up (also builds the C kernel)
+    t0 = time.time()
+    for _ in range(steps):
+        model_ref.loss_and_grads(*args, p_drop=0.1, training=True)
+    dt = (time.time() - t0) / steps
+    return {'value': round(T / dt, 1), 'unit': 'tokens/s', 'cores': cores, 'kind': 'port',
+            'sample': 'oracle Performer L12 d512 fwd+bwd (no optimizer), B=1 x T=%d, %d timed steps, torch fp32 eager + C causal product' % (T, steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64, help='sequences per GPU (BASELINE.md: B=64)')
+    ap.add_argument('--seq', type=int, default=CFG['seq'])
+    ap.add_argument('--redraw', default='every_forward')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    from emo_disentanger_amd import dp, ops
+    from emo_disentanger_amd.data import synthetic_batch
+    from emo_disentanger_amd.model.music_performer import MusicPerformer
+    from emo_disentanger_amd.optim import FusedAdam
+    rank, local_rank, world = dp.init_distributed()
+    assert world == max(args.gpus, 1) or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    torch.manual_seed(0)
+    B, T = args.batch, args.seq
+    model = MusicPerformer(CFG['n_token'], CFG['n_layer'], CFG['n_head'], CFG['d_model'], CFG['d_ff'], CFG['d_model'],
+                           favor_feature_dims=CFG['n_feat'], use_segment_emb=True, n_segment_types=2, dropout=0.1,
+                           compute_dtype='bf16', redraw=args.redraw).to(dev)
+    model.train()
+    if world > 1:
+        dp.sync_model_from_rank0(model)
+    max_lr, eta_min, warmup_steps, T_max = 1e-4, 1e-5, 200, 500000      # pop1k7_pretrain.yaml
+    opt = FusedAdam(model, lr=max_lr, max_grad_norm=0.5, world_size=world)
+    batches = [synthetic_batch(CFG['n_token'], B, T, seed=dp.shard_seed(1234, rank) + 100 * i, device=dev) for i in range(2)]
+    ps = model._ensure_store()
+    counts = torch.zeros(6, device=dev, dtype=torch.int64)
+    loss_acc = torch.zeros((), device=dev)
+    state = {'step': 0}
+
+    def step():
+        state['step'] += 1
+        b = batches[state['step'] % len(batches)]
+        opt.zero_grad()
+        logits = model(b['dec_input'], seg_inp=b['track_mask'], attn_kwargs={'omit_feature_map_draw': False})
+        losses = model.compute_loss(logits, b['dec_target'])
+        losses['total_loss'].backward()
+        dp.allreduce_sum_(ps.flat_grad)
+        opt.step()
+        loss_acc.add_(losses['recons_loss'].detach())
+        counts.add_(ops.accuracy_counts(logits.detach().view(-1, logits.shape[-1]), b['dec_target'].view(-1), b['chord_idx'].view(-1),
+                                        b['melody_idx'].view(-1), CFG['n_token'] - 1))
+        s = state['step']
+        opt.param_groups[0]['lr'] = max_lr * s / warmup_steps if s < warmup_steps else \
+            eta_min + (max_lr - eta_min) * (1 + math.cos(math.pi * (s - warmup_steps) / T_max)) / 2
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    loss_acc.zero_()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = dp.max_over_ranks(time.perf_counter() - t0, dev)
+    mean_loss = float(loss_acc) / max(args.steps, 1)
+    tokens = world * B * T * args.steps
+    value = tokens / elapsed
+    out = {'metric': 'train tokens/sec, stage2 Performer d512 L12 seq%d' % T, 'value': round(value, 1), 'unit': 'tokens/s', 'n_gpus': world,
+           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * elapsed / args.steps, 3), 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+           'config': {'workload': 'BASELINE configs[%d]: stage2 Performer d_model=512 n_layer=12 n_head=8 favor_dims=128 seq=%d, B=%d/GPU, '
+                                  'dropout 0.1, omega redraw %s, fwd+bwd+allreduce+clip+Adam' % (1 if world == 1 else 2, T, B, args.redraw),
+                      'global_batch': world * B, 'seq_len': T, 'parallelism': 'dp%d' % world, 'n_token': CFG['n_token']},
+           'mean_loss': round(mean_loss, 4), 'gemm_tflops_model': round(value * gemm_flops_per_token() / 1e12, 1)}
+    if rank == 0:
+        if not args.no_roofline:
+            out['roofline'] = dominant_kernel_roofline(B, T)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(min(T, 2048))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

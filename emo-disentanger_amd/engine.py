@@ -1,0 +1,343 @@
+"""Execution engine under MusicPerformer / MusicGPT2: flat parameter storage, per-layer forward /
+backward schedules over the C-ABI ops, and the single autograd node that wraps the whole decoder
+stack (one Python-level node => ~10 kernel launches per layer, no per-op autograd bookkeeping).
+
+Storage layout (HBM): all trainable parameters live in ONE fp32 buffer (``flat32``) with a matching
+``flat_grad`` (one RCCL all-reduce, one fused Adam launch) and, in bf16 mode, a bf16 mirror
+(``flat16``) that the MFMA GEMMs read.  The three Performer projections q/k/v are adjacent in the
+buffer so that one [3D, D] view feeds a fused QKV GEMM; ``nn.Parameter`` objects are views into the
+flat buffers, so ``state_dict()`` keys / shapes / registration order stay the reference's.
+Activations are [B*T, D] row-major in the compute dtype; LayerNorm statistics, softmax / FAVOR
+normalisers, logits and all gradients of parameters are fp32.
+"""
+import math
+
+import torch
+
+from . import ops
+from ._lib import EmoError
+
+ALIGN = 8  # elements; keeps every parameter 16-B aligned in the bf16 mirror
+
+
+def _dt(name):
+    if name in ('bf16', 'bfloat16', torch.bfloat16):
+        return torch.bfloat16
+    if name in ('fp32', 'f32', 'float32', torch.float32):
+        return torch.float32
+    raise ValueError('compute dtype must be bf16 or fp32, got %r' % (name,))
+
+
+class ParamStore:
+    """Flat fp32 master / grad / (bf16 mirror) buffers; parameters are re-pointed to views."""
+
+    def __init__(self, module, compute_dtype, fused_groups):
+        named = list(module.named_parameters())
+        dev = named[0][1].device
+        if dev.type != 'cuda':
+            raise EmoError('emo-disentanger_amd models run on the GPU only (no CPU fallback): call .cuda() first')
+        byname = dict(named)
+        order, seen = [], set()
+        for n, _ in named:
+            if n in seen:
+                continue
+            grp = next((g for g in fused_groups if n == g[0]), None)
+            for m in (grp if grp else [n]):
+                order.append(m)
+                seen.add(m)
+        self.offsets, off = {}, 0
+        fused = {g[0]: g for g in fused_groups}
+        for n in order:
+            self.offsets[n] = off
+            sz = byname[n].numel()
+            in_group = any(n in g for g in fused_groups)
+            off += sz if in_group else (sz + ALIGN - 1) // ALIGN * ALIGN
+        total = (off + ALIGN - 1) // ALIGN * ALIGN
+        self.device, self.total, self.compute_dtype = dev, total, compute_dtype
+        self.flat32 = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.flat16 = torch.zeros(total, device=dev, dtype=torch.bfloat16) if compute_dtype == torch.bfloat16 else None
+        self.params = byname
+        self.shapes = {n: tuple(p.shape) for n, p in named}
+        with torch.no_grad():
+            for n, p in named:
+                o = self.offsets[n]
+                view = self.flat32[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+        self._fused = fused
+        self._mirror_version = -1
+        self._first, self._last = named[0][1], named[-1][1]
+
+    # -- consistency ---------------------------------------------------------------------------
+    def intact(self):
+        """False after module._apply (.cuda()/.to()/.float()) replaced the parameter storage."""
+        lo, hi = self.flat32.data_ptr(), self.flat32.data_ptr() + 4 * self.total
+        return all(p.device == self.device and lo <= p.data_ptr() < hi for p in (self._first, self._last))
+
+    def sync_mirror(self):
+        """Refresh the bf16 mirror if anything wrote the fp32 master through torch (optimizer.step,
+        load_state_dict, init): views share the base's version counter."""
+        if self.flat16 is not None and self.flat32._version != self._mirror_version:
+            ops.cast(self.flat32, self.flat16)
+            self._mirror_version = self.flat32._version
+
+    def mark_mirror_fresh(self):
+        self._mirror_version = self.flat32._version
+
+    def ensure_grads(self):
+        """Re-attach .grad views (zero_grad(set_to_none=True) drops them)."""
+        missing = [n for n, p in self.params.items() if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * self.offsets[n]]
+        if not missing:
+            return
+        if len(missing) == len(self.params):
+            self.flat_grad.zero_()
+        for n in missing:
+            p, o = self.params[n], self.offsets[n]
+            g = self.flat_grad[o:o + p.numel()].view(p.shape)
+            if len(missing) != len(self.params):
+                if p.grad is not None:
+                    g.copy_(p.grad)
+                else:
+                    g.zero_()
+            p.grad = g
+
+    # -- views ------------------------------------------------------------------------------------
+    def _view(self, buf, name, rows=None):
+        o, shp = self.offsets[name], self.shapes[name]
+        if name in self._fused and rows is not None:
+            n = sum(self.params[m].numel() for m in self._fused[name])
+            return buf[o:o + n].view(rows, -1) if len(shp) == 2 else buf[o:o + n]
+        return buf[o:o + self.params[name].numel()].view(shp)
+
+    def w(self, name, fused_rows=None):
+        """GEMM operand view (compute dtype)."""
+        return self._view(self.flat16 if self.flat16 is not None else self.flat32, name, fused_rows)
+
+    def f32(self, name, fused_rows=None):
+        return self._view(self.flat32, name, fused_rows)
+
+    def g(self, name, fused_rows=None):
+        return self._view(self.flat_grad, name, fused_rows)
+
+
+# =================================================================================================== layer schedules
+class LayerCtx:
+    __slots__ = ('t',)
+
+    def __init__(self):
+        self.t = {}
+
+
+def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save):
+    """Post-LN encoder layer with FAVOR+ causal attention.  x: [M, D]."""
+    D = x.shape[1]
+    q = pfx + 'attention.query_projection.'
+    qkv = ops.gemm(x, ps.w(q + 'weight', 3 * D), bias=ps.f32(q + 'bias', 3 * D))
+    attn, den = ops.favor_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], omega, B, T, H)
+    x1 = ops.gemm(attn, ps.w(pfx + 'attention.out_projection.weight'), bias=ps.f32(pfx + 'attention.out_projection.bias'),
+                  p_drop=p, seed=seed, offset=off + 1, residual=x)
+    h1, m1, r1 = ops.layernorm_fwd(x1, ps.f32(pfx + 'norm1.weight'), ps.f32(pfx + 'norm1.bias'))
+    f = ops.gemm(h1, ps.w(pfx + 'linear1.weight'), bias=ps.f32(pfx + 'linear1.bias'), act=ops.ACT_RELU, p_drop=p, seed=seed, offset=off + 2)
+    x2 = ops.gemm(f, ps.w(pfx + 'linear2.weight'), bias=ps.f32(pfx + 'linear2.bias'), p_drop=p, seed=seed, offset=off + 3, residual=h1)
+    out, m2, r2 = ops.layernorm_fwd(x2, ps.f32(pfx + 'norm2.weight'), ps.f32(pfx + 'norm2.bias'))
+    if save is not None:
+        save.t = dict(x=x, qkv=qkv, attn=attn, den=den, x1=x1, m1=m1, r1=r1, h1=h1, f=f, x2=x2, m2=m2, r2=r2, omega=omega)
+    return out
+
+
+def _wgrad(ps, wname, bname, dy, xin, fused_rows=None):
+    """dW[N,K] += dy[M,N]^T xin[M,K] ; db[N] += colsum(dy)   (nn.Linear layout)."""
+    ops.gemm(dy, xin, a_trans=True, b_trans=True, out=ps.g(wname, fused_rows), accumulate=True)
+    ops.colsum(dy, out=ps.g(bname, fused_rows), accumulate=True)
+
+
+def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
+    s = save.t
+    D = dout.shape[1]
+    inv = 1.0 / (1.0 - p) if p > 0 else 1.0
+    g2, dyd = ops.layernorm_bwd(dout, s['x2'], ps.f32(pfx + 'norm2.weight'), s['m2'], s['r2'], ps.g(pfx + 'norm2.weight'), ps.g(pfx + 'norm2.bias'),
+                                want_drop=p > 0, p_drop=p, seed=seed, offset=off + 3)
+    if dyd is None:
+        dyd = g2
+    _wgrad(ps, pfx + 'linear2.weight', pfx + 'linear2.bias', dyd, s['f'])
+    df = ops.gemm(dyd, ps.w(pfx + 'linear2.weight'), b_trans=True, mul_aux=s['f'], mul_mode=ops.MUL_NONZERO, mul_scale=inv)
+    _wgrad(ps, pfx + 'linear1.weight', pfx + 'linear1.bias', df, s['h1'])
+    dh1 = ops.gemm(df, ps.w(pfx + 'linear1.weight'), b_trans=True, residual=g2)
+    g1, da = ops.layernorm_bwd(dh1, s['x1'], ps.f32(pfx + 'norm1.weight'), s['m1'], s['r1'], ps.g(pfx + 'norm1.weight'), ps.g(pfx + 'norm1.bias'),
+                               want_drop=p > 0, p_drop=p, seed=seed, offset=off + 1)
+    if da is None:
+        da = g1
+    _wgrad(ps, pfx + 'attention.out_projection.weight', pfx + 'attention.out_projection.bias', da, s['attn'])
+    dattn = ops.gemm(da, ps.w(pfx + 'attention.out_projection.weight'), b_trans=True)
+    qkv = s['qkv']
+    dq, dk, dv = ops.favor_attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], s['omega'], s['attn'], dattn, s['den'], B, T, H)
+    dqkv = dq._base if dq._base is not None else torch.cat([dq, dk, dv], 1)
+    q = pfx + 'attention.query_projection.'
+    _wgrad(ps, q + 'weight', q + 'bias', dqkv, s['x'], fused_rows=3 * D)
+    return ops.gemm(dqkv, ps.w(q + 'weight', 3 * D), b_trans=True, residual=g1)
+
+
+def gpt2_block_fwd(ps, pfx, x, B, T, H, p, seed, off, save):
+    """HF GPT2Block (pre-LN, Conv1D weights [in,out], gelu_new, no final ln_f) — SURVEY App. B/C."""
+    D = x.shape[1]
+    n1, m1, r1 = ops.layernorm_fwd(x, ps.f32(pfx + 'ln_1.weight'), ps.f32(pfx + 'ln_1.bias'))
+    qkv = ops.gemm(n1, ps.w(pfx + 'attn.c_attn.weight'), b_trans=True, bias=ps.f32(pfx + 'attn.c_attn.bias'))
+    a, lse = ops.softmax_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, T, H, p_drop=p, seed=seed, offset=off + 1)
+    h = ops.gemm(a, ps.w(pfx + 'attn.c_proj.weight'), b_trans=True, bias=ps.f32(pfx + 'attn.c_proj.bias'), p_drop=p, seed=seed, offset=off + 2, residual=x)
+    n2, m2, r2 = ops.layernorm_fwd(h, ps.f32(pfx + 'ln_2.weight'), ps.f32(pfx + 'ln_2.bias'))
+    z = torch.empty(x.shape[0], ps.shapes[pfx + 'mlp.c_fc.weight'][1], device=x.device, dtype=x.dtype) if save is not None else None
+    f = ops.gemm(n2, ps.w(pfx + 'mlp.c_fc.weight'), b_trans=True, bias=ps.f32(pfx + 'mlp.c_fc.bias'), act=ops.ACT_GELU_NEW, aux_out=z)
+    out = ops.gemm(f, ps.w(pfx + 'mlp.c_proj.weight'), b_trans=True, bias=ps.f32(pfx + 'mlp.c_proj.bias'), p_drop=p, seed=seed, offset=off + 3, residual=h)
+    if save is not None:
+        save.t = dict(x=x, m1=m1, r1=r1, n1=n1, qkv=qkv, a=a, lse=lse, h=h, m2=m2, r2=r2, n2=n2, z=z, f=f)
+    return out
+
+
+def _wgrad_conv1d(ps, wname, bname, xin, dy):
+    """dW[K,N] += xin[M,K]^T dy[M,N] ; db[N] += colsum(dy)   (HF Conv1D layout)."""
+    ops.gemm(xin, dy, a_trans=True, b_trans=True, out=ps.g(wname), accumulate=True)
+    ops.colsum(dy, out=ps.g(bname), accumulate=True)
+
+
+def gpt2_block_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
+    s = save.t
+    D = dout.shape[1]
+    dyd = ops.dropout_apply(dout, p, seed, off + 3) if p > 0 else dout
+    _wgrad_conv1d(ps, pfx + 'mlp.c_proj.weight', pfx + 'mlp.c_proj.bias', s['f'], dyd)
+    dz = ops.gemm(dyd, ps.w(pfx + 'mlp.c_proj.weight'), mul_aux=s['z'], mul_mode=ops.MUL_DGELU_NEW)
+    _wgrad_conv1d(ps, pfx + 'mlp.c_fc.weight', pfx + 'mlp.c_fc.bias', s['n2'], dz)
+    dn2 = ops.gemm(dz, ps.w(pfx + 'mlp.c_fc.weight'))
+    dh, _ = ops.layernorm_bwd(dn2, s['h'], ps.f32(pfx + 'ln_2.weight'), s['m2'], s['r2'], ps.g(pfx + 'ln_2.weight'), ps.g(pfx + 'ln_2.bias'), dres=dout)
+    dad = ops.dropout_apply(dh, p, seed, off + 2) if p > 0 else dh
+    _wgrad_conv1d(ps, pfx + 'attn.c_proj.weight', pfx + 'attn.c_proj.bias', s['a'], dad)
+    da = ops.gemm(dad, ps.w(pfx + 'attn.c_proj.weight'))
+    qkv = s['qkv']
+    dq, dk, dv = ops.softmax_attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], s['a'], da, s['lse'], B, T, H, p_drop=p, seed=seed, offset=off + 1)
+    dqkv = dq._base
+    _wgrad_conv1d(ps, pfx + 'attn.c_attn.weight', pfx + 'attn.c_attn.bias', s['n1'], dqkv)
+    dn1 = ops.gemm(dqkv, ps.w(pfx + 'attn.c_attn.weight'))
+    dx, _ = ops.layernorm_bwd(dn1, s['x'], ps.f32(pfx + 'ln_1.weight'), s['m1'], s['r1'], ps.g(pfx + 'ln_1.weight'), ps.g(pfx + 'ln_1.bias'), dres=dh)
+    return dx
+
+
+# =================================================================================================== autograd nodes
+class DecoderStackFn(torch.autograd.Function):
+    """tokens -> final hidden states [B,T,D].  Parameter gradients are accumulated straight into the
+    flat grad buffer (the ``.grad`` views); the node returns None for them."""
+
+    @staticmethod
+    def forward(ctx, model, tok, seg, anchor, need_bwd):
+        ps = model._store
+        B, T = tok.shape
+        D, H, L = model.d_model, model.n_head, model.n_layer
+        p = model.dropout if model.training else 0.0
+        seed, base = model._next_dropout_base()
+        E = ps.f32('token_emb.emb_lookup.weight')
+        S = ps.f32('segemb.emb_lookup.weight') if (seg is not None and model.use_segment_emb) else None
+        seg = seg if S is not None else None
+        pe = model.pe.pe if model.use_pe else model._zero_pe(T, D)
+        x = ops.embed_fwd(tok, seg, E, S, pe, ps.compute_dtype, float(model.token_emb.emb_scale), p_drop=p, seed=seed, offset=base).view(B * T, D)
+        saves = []
+        omegas = model._omegas() if model.kind == 'performer' else None
+        for l in range(L):
+            sv = LayerCtx() if need_bwd else None
+            if model.kind == 'performer':
+                x = performer_layer_fwd(ps, model._layer_prefix(l), x, omegas[l], B, T, H, p, seed, base + 8 * (l + 1), sv)
+            else:
+                x = gpt2_block_fwd(ps, model._layer_prefix(l), x, B, T, H, p, seed, base + 8 * (l + 1), sv)
+            saves.append(sv)
+        ctx.model, ctx.saves, ctx.tok, ctx.seg = model, saves, tok, seg
+        ctx.cfg = (B, T, D, H, L, p, seed, base)
+        return x.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, ps = ctx.model, ctx.model._store
+        B, T, D, H, L, p, seed, base = ctx.cfg
+        ps.ensure_grads()
+        dx = dout.reshape(B * T, D)
+        if dx.dtype != ps.compute_dtype or not dx.is_contiguous():
+            dx = dx.to(ps.compute_dtype).contiguous()
+        for l in reversed(range(L)):
+            if model.kind == 'performer':
+                dx = performer_layer_bwd(ps, model._layer_prefix(l), dx, B, T, H, p, seed, base + 8 * (l + 1), ctx.saves[l])
+            else:
+                dx = gpt2_block_bwd(ps, model._layer_prefix(l), dx, B, T, H, p, seed, base + 8 * (l + 1), ctx.saves[l])
+            ctx.saves[l] = None
+        dS = ps.g('segemb.emb_lookup.weight') if ctx.seg is not None else None
+        ops.embed_bwd(ctx.tok, ctx.seg, dx, ps.g('token_emb.emb_lookup.weight'), dS, float(model.token_emb.emb_scale), p_drop=p, seed=seed, offset=base)
+        return None, None, None, None, None
+
+
+class LogitsFn(torch.autograd.Function):
+    """dec_out_proj: fp32 logits = h W^T + b (untied nn.Linear, music_performer.py:27,65)."""
+
+    @staticmethod
+    def forward(ctx, model, h):
+        ps = model._store
+        shp = h.shape
+        h2 = h.reshape(-1, shp[-1])
+        logits = ops.gemm(h2, ps.w('dec_out_proj.weight'), bias=ps.f32('dec_out_proj.bias'), out_dtype=torch.float32)
+        ctx.model, ctx.h2, ctx.shp = model, h2, shp
+        return logits.view(*shp[:-1], -1)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ps = ctx.model._store
+        ps.ensure_grads()
+        M, V = ctx.h2.shape[0], dlogits.shape[-1]
+        dl = dlogits.reshape(M, V)
+        Vp = (V + 7) // 8 * 8
+        base = dl._base
+        if base is not None and base.dim() == 2 and base.shape == (M, Vp) and base.dtype == torch.float32 and dl.data_ptr() == base.data_ptr():
+            padded = base                                         # produced by XentFn: already padded, pad columns are zero
+        else:
+            padded = torch.zeros(M, Vp, device=dl.device, dtype=torch.float32)
+            padded[:, :V].copy_(dl)
+        if ps.compute_dtype == torch.bfloat16:
+            p16 = torch.empty(M, Vp, device=dl.device, dtype=torch.bfloat16)
+            ops.cast(padded, p16)
+            padded = p16
+        g = padded[:, :V]
+        ops.gemm(g, ctx.h2, a_trans=True, b_trans=True, out=ps.g('dec_out_proj.weight'), accumulate=True)
+        ops.colsum(g, out=ps.g('dec_out_proj.bias'), accumulate=True)
+        dh = ops.gemm(g, ps.w('dec_out_proj.weight'), b_trans=True)
+        return None, dh.view(ctx.shp)
+
+
+class XentFn(torch.autograd.Function):
+    """F.cross_entropy(ignore_index, reduction='mean') on fp32 logits (music_performer.py:72-81)."""
+
+    @staticmethod
+    def forward(ctx, logits, tgt, ignore_index):
+        V = logits.shape[-1]
+        l2 = logits.reshape(-1, V)
+        if not l2.is_contiguous():
+            l2 = l2.contiguous()
+        t = tgt.reshape(-1)
+        lse, acc = ops.xent_fwd(l2, t, ignore_index)
+        ctx.save_for_backward(l2, t, lse, acc)
+        ctx.ignore, ctx.shape = ignore_index, logits.shape
+        return acc[0] / acc[1]
+
+    @staticmethod
+    def backward(ctx, gout):
+        l2, t, lse, acc = ctx.saved_tensors
+        gscale = (gout.float() / acc[1]).reshape(1)
+        V = l2.shape[1]
+        dl = ops.xent_bwd(l2, t, lse, gscale, ctx.ignore, torch.float32)
+        g = dl.view(ctx.shape) if dl.shape[1] == V else _as_view(dl, V, ctx.shape)
+        return g, None, None
+
+
+def _as_view(dl, V, shape):
+    """[M, Vp] padded buffer -> [..., V] strided VIEW (no copy) so LogitsFn.backward can reuse the buffer."""
+    M, Vp = dl.shape
+    lead = shape[:-1]
+    strides, s = [], Vp
+    for d in reversed(lead):
+        strides.append(s)
+        s *= d
+    return dl.as_strided(tuple(lead) + (V,), tuple(reversed(strides)) + (1,))

@@ -1,0 +1,72 @@
+"""MusicPerformer — drop-in for /root/reference/stage2_accompaniment/model/music_performer.py:9-81
+(same constructor signature, forward / compute_loss contract, state_dict keys and parameter order),
+executed by hand-written gfx950 kernels through libemo_hip.so.
+
+FAVOR+ omega handling: stock fast-transformers redraws omega on EVERY forward of
+every layer (train and eval) and the reference's ``attn_kwargs`` are inert.  ``redraw`` selects
+  'every_forward' (default, reference-faithful; one batched randn+QR per forward),
+  'honor_kwarg'   (redraw unless attn_kwargs['omit_feature_map_draw'] is true — the authors' intent),
+  'fixed'         (use the `...feature_map.omega` buffers as they are; parity tests / decode engine).
+"""
+import torch
+
+from .fast_transformer_decoder import FastTransformerDecoder
+from .transformer_helpers import weights_init
+from ._base import MusicLMBase
+
+
+class MusicPerformer(MusicLMBase):
+    kind = 'performer'
+
+    def __init__(self, n_token, n_layer, n_head, d_model, d_ff, d_embed,
+                 activation='relu', dropout=0.1, use_pe=True, favor_feature_dims=None,
+                 use_segment_emb=False, n_segment_types=None, use_chord_mhot_emb=False,
+                 compute_dtype=None, redraw='every_forward'):
+        super().__init__()
+        self._init_common(n_token, n_layer, n_head, d_model, d_ff, d_embed, activation, dropout, use_pe, use_segment_emb,
+                          n_segment_types, use_chord_mhot_emb, compute_dtype)
+        self.favor_feature_dims = favor_feature_dims
+        self.transformer_decoder = FastTransformerDecoder(n_layer, n_head, d_model, d_ff, dropout, activation, favor_feature_dims)
+        self._init_tail(use_segment_emb, n_segment_types)
+        self.redraw = redraw
+        self.apply(weights_init)
+        self.draw_feature_maps()
+        print('[info] model init completed')
+
+    def _layer_prefix(self, l):
+        return 'transformer_decoder.decoder_layers.%d.' % l
+
+    def _fused_groups(self):
+        g = []
+        for l in range(self.n_layer):
+            a = self._layer_prefix(l) + 'attention.'
+            g.append([a + 'query_projection.weight', a + 'key_projection.weight', a + 'value_projection.weight'])
+            g.append([a + 'query_projection.bias', a + 'key_projection.bias', a + 'value_projection.bias'])
+        return g
+
+    @torch.no_grad()
+    def draw_feature_maps(self):
+        """fast_transformers orthogonal_random_matrix_: per block of d_head columns G~N(0,1), Q=qr(G), columns
+        rescaled by the row norms of G.  One batched draw for all layers (torch RNG, like the reference)."""
+        bufs = [lyr.attention.inner_attention.feature_map.omega for lyr in self.transformer_decoder.decoder_layers]
+        dh, cols = bufs[0].shape
+        dev = bufs[0].device
+        start = 0
+        while start < cols:
+            end = min(start + dh, cols)
+            block = torch.randn(len(bufs), dh, dh, device=dev)
+            norms = block.pow(2).sum(-1).sqrt()
+            qmat, _ = torch.linalg.qr(block)
+            for i, b in enumerate(bufs):
+                b[:, start:end] = qmat[i, :, :end - start] * norms[i, None, :end - start]
+            start += dh
+
+    def _omegas(self):
+        if self.redraw == 'every_forward' or (self.redraw == 'honor_kwarg' and not self._attn_kwargs.get('omit_feature_map_draw', False)):
+            self.draw_feature_maps()
+        elif self.redraw not in ('fixed', 'honor_kwarg'):
+            raise ValueError('redraw must be every_forward | honor_kwarg | fixed')
+        # the backward pass must see the omega of ITS forward: hand out private copies when redrawing
+        keep = self.redraw != 'fixed'
+        return [(lyr.attention.inner_attention.feature_map.omega.clone() if keep else lyr.attention.inner_attention.feature_map.omega)
+                for lyr in self.transformer_decoder.decoder_layers]
