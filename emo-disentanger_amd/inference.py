@@ -1,0 +1,312 @@
+"""Autoregressive generation — the sampling loop of
+/root/reference/stage2_accompaniment/inference.py (temperature :71-83, nucleus :86-100,
+generate_conditional :231-327) on top of a recurrent-state / KV-cache decode engine.
+
+The reference re-runs the full model over the whole (<=2048-token) prefix for every sampled token
+(SURVEY F7).  Here the Performer keeps its FAVOR+ scan state (S [F x dh], z [F] per layer/head) and
+GPT-2 keeps a KV cache in HBM, so a step costs one token of work; results equal full recompute
+(tests/test_gpu_generate.py).  Rejected samples (Beat going backwards, PAD, early EOS) re-sample from
+the SAME logits without touching the state.  Once the window slides (len >= 2048) absolute positions
+restart at 0 every step, which invalidates any cache: the engine then falls back to the reference's
+full-window forward.  Host-side sampling helpers keep the reference's NumPy semantics (global RNG,
+F12 nucleus indexing); `sample_on_device` is the batched on-GPU path (emo_sample_nucleus).
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import engine, ops
+
+max_dec_inp_len = 2048
+
+
+# ------------------------------------------------------------------------------------------------ host sampling (reference semantics)
+def temperature(logits, temperature, inadmissibles=None):
+    if inadmissibles is not None:
+        logits[inadmissibles] -= np.inf
+    try:
+        with np.errstate(over='ignore', invalid='ignore'):
+            probs = np.exp(logits / temperature) / np.sum(np.exp(logits / temperature))
+        assert np.count_nonzero(np.isnan(probs)) == 0
+    except AssertionError:
+        print('overflow detected, use 128-bit')
+        logits = logits.astype(np.float128)
+        probs = np.exp(logits / temperature) / np.sum(np.exp(logits / temperature))
+        probs = probs.astype(float)
+    return probs
+
+
+def nucleus(probs, p):
+    probs /= sum(probs)
+    sorted_probs = np.sort(probs)[::-1]
+    sorted_index = np.argsort(probs)[::-1]
+    cusum_sorted_probs = np.cumsum(sorted_probs)
+    after_threshold = cusum_sorted_probs > p
+    if sum(after_threshold) > 0:
+        last_index = np.where(after_threshold)[0][1]      # reference indexing: keeps the crossing token
+        candi_index = sorted_index[:last_index]
+    else:
+        candi_index = sorted_index[:3]
+    candi_probs = np.array([probs[i] for i in candi_index], dtype=np.float64)
+    candi_probs /= sum(candi_probs)
+    return np.random.choice(candi_index, size=1, p=candi_probs)[0]
+
+
+def sample_on_device(logits, temp, top_p, u=None, greedy=False):
+    """logits fp32 [n, V] on the GPU -> int64 [n] (no host round trip)."""
+    if greedy:
+        return ops.argmax(logits.contiguous())
+    if u is None:
+        u = torch.rand(logits.shape[0], device=logits.device)
+    return ops.sample_nucleus(logits.contiguous(), temp, top_p, u)
+
+
+def get_position_idx(event):
+    return int(event.split('_')[-1])
+
+
+# ------------------------------------------------------------------------------------------------ decode engines
+class _EngineBase:
+    def __init__(self, model, n_streams, max_len=max_dec_inp_len):
+        self.model, self.n, self.max_len = model, n_streams, max_len
+        self.ps = model._ensure_store()
+        self.dev, self.dt = self.ps.device, self.ps.compute_dtype
+        self.pos = 0
+
+    def _embed(self, tok, seg, pos0):
+        m, ps = self.model, self.ps
+        S = ps.f32('segemb.emb_lookup.weight') if (seg is not None and m.use_segment_emb) else None
+        pe = m.pe.pe if m.use_pe else m._zero_pe(pos0 + tok.shape[1], m.d_model)
+        return ops.embed_fwd(tok, seg if S is not None else None, ps.f32('token_emb.emb_lookup.weight'), S, pe, self.dt, float(m.token_emb.emb_scale),
+                             pos0=pos0).view(-1, m.d_model)
+
+    def _logits(self, h):
+        return ops.gemm(h, self.ps.w('dec_out_proj.weight'), bias=self.ps.f32('dec_out_proj.bias'), out_dtype=torch.float32)
+
+    @torch.no_grad()
+    def append(self, tok, seg):
+        """tok, seg: int64 [n, k]; consumes k tokens per stream, returns logits [n, V] after the last one."""
+        if self.pos == 0:
+            return self.prefill(tok, seg)
+        out = None
+        for i in range(tok.shape[1]):
+            out = self.step(tok[:, i], seg[:, i])
+        return out
+
+
+class PerformerDecodeEngine(_EngineBase):
+    """FAVOR+ recurrent state per layer: S [n,H,F,dh], z [n,H,F] fp32 (6.4 MB / stream at the perf config).
+    omega is fixed for the lifetime of the engine (the state is only meaningful under one feature map)."""
+
+    def __init__(self, model, n_streams, redraw=True):
+        super().__init__(model, n_streams)
+        if redraw and model.redraw != 'fixed':
+            model.draw_feature_maps()
+        self.omegas = [lyr.attention.inner_attention.feature_map.omega.clone() for lyr in model.transformer_decoder.decoder_layers]
+        self.S, self.z = [None] * model.n_layer, [None] * model.n_layer
+
+    @torch.no_grad()
+    def prefill(self, tok, seg):
+        m, ps = self.model, self.ps
+        B, T = tok.shape
+        D, H = m.d_model, m.n_head
+        x = self._embed(tok, seg, 0)
+        for l in range(m.n_layer):
+            pfx = m._layer_prefix(l)
+            q = pfx + 'attention.query_projection.'
+            qkv = ops.gemm(x, ps.w(q + 'weight', 3 * D), bias=ps.f32(q + 'bias', 3 * D))
+            attn, _, self.S[l], self.z[l] = ops.favor_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], self.omegas[l], B, T, H, want_state=True)
+            x = self._tail(pfx, x, attn)
+        self.pos = T
+        return self._logits(x.view(B, T, D)[:, -1].contiguous())
+
+    def _tail(self, pfx, x, attn):
+        ps = self.ps
+        x1 = ops.gemm(attn, ps.w(pfx + 'attention.out_projection.weight'), bias=ps.f32(pfx + 'attention.out_projection.bias'), residual=x)
+        h1, _, _ = ops.layernorm_fwd(x1, ps.f32(pfx + 'norm1.weight'), ps.f32(pfx + 'norm1.bias'))
+        f = ops.gemm(h1, ps.w(pfx + 'linear1.weight'), bias=ps.f32(pfx + 'linear1.bias'), act=ops.ACT_RELU)
+        x2 = ops.gemm(f, ps.w(pfx + 'linear2.weight'), bias=ps.f32(pfx + 'linear2.bias'), residual=h1)
+        out, _, _ = ops.layernorm_fwd(x2, ps.f32(pfx + 'norm2.weight'), ps.f32(pfx + 'norm2.bias'))
+        return out
+
+    @torch.no_grad()
+    def step(self, tok, seg):
+        m, ps = self.model, self.ps
+        D, H = m.d_model, m.n_head
+        x = self._embed(tok.view(-1, 1), None if seg is None else seg.view(-1, 1), self.pos)
+        for l in range(m.n_layer):
+            pfx = m._layer_prefix(l)
+            q = pfx + 'attention.query_projection.'
+            qkv = ops.gemm(x, ps.w(q + 'weight', 3 * D), bias=ps.f32(q + 'bias', 3 * D))
+            attn = ops.favor_decode_step(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], self.omegas[l], self.S[l], self.z[l], H)
+            x = self._tail(pfx, x, attn)
+        self.pos += 1
+        return self._logits(x)
+
+
+class GPT2DecodeEngine(_EngineBase):
+    """KV cache in HBM: per layer k,v [n, max_len, D] in the compute dtype (1.6 GB for 32 streams x 2048 x 12 layers, bf16)."""
+
+    def __init__(self, model, n_streams, max_len=max_dec_inp_len):
+        super().__init__(model, n_streams, max_len)
+        D = model.d_model
+        self.kc = [torch.zeros(n_streams, max_len, D, device=self.dev, dtype=self.dt) for _ in range(model.n_layer)]
+        self.vc = [torch.zeros(n_streams, max_len, D, device=self.dev, dtype=self.dt) for _ in range(model.n_layer)]
+        self.lens = torch.zeros(n_streams, device=self.dev, dtype=torch.int64)
+
+    def _block_tail(self, pfx, x, a):
+        ps = self.ps
+        h = ops.gemm(a, ps.w(pfx + 'attn.c_proj.weight'), b_trans=True, bias=ps.f32(pfx + 'attn.c_proj.bias'), residual=x)
+        n2, _, _ = ops.layernorm_fwd(h, ps.f32(pfx + 'ln_2.weight'), ps.f32(pfx + 'ln_2.bias'))
+        f = ops.gemm(n2, ps.w(pfx + 'mlp.c_fc.weight'), b_trans=True, bias=ps.f32(pfx + 'mlp.c_fc.bias'), act=ops.ACT_GELU_NEW)
+        return ops.gemm(f, ps.w(pfx + 'mlp.c_proj.weight'), b_trans=True, bias=ps.f32(pfx + 'mlp.c_proj.bias'), residual=h)
+
+    @torch.no_grad()
+    def prefill(self, tok, seg):
+        m, ps = self.model, self.ps
+        B, T = tok.shape
+        D, H = m.d_model, m.n_head
+        x = self._embed(tok, seg, 0)
+        for l in range(m.n_layer):
+            pfx = m._layer_prefix(l)
+            n1, _, _ = ops.layernorm_fwd(x, ps.f32(pfx + 'ln_1.weight'), ps.f32(pfx + 'ln_1.bias'))
+            qkv = ops.gemm(n1, ps.w(pfx + 'attn.c_attn.weight'), b_trans=True, bias=ps.f32(pfx + 'attn.c_attn.bias'))
+            self.kc[l][:, :T].copy_(qkv[:, D:2 * D].view(B, T, D))
+            self.vc[l][:, :T].copy_(qkv[:, 2 * D:].view(B, T, D))
+            a, _ = ops.softmax_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, T, H)
+            x = self._block_tail(pfx, x, a)
+        self.pos = T
+        self.lens.fill_(T)
+        return self._logits(x.view(B, T, D)[:, -1].contiguous())
+
+    @torch.no_grad()
+    def step(self, tok, seg):
+        m, ps = self.model, self.ps
+        D, H = m.d_model, m.n_head
+        x = self._embed(tok.view(-1, 1), None if seg is None else seg.view(-1, 1), self.pos)
+        self.lens.add_(1)
+        for l in range(m.n_layer):
+            pfx = m._layer_prefix(l)
+            n1, _, _ = ops.layernorm_fwd(x, ps.f32(pfx + 'ln_1.weight'), ps.f32(pfx + 'ln_1.bias'))
+            qkv = ops.gemm(n1, ps.w(pfx + 'attn.c_attn.weight'), b_trans=True, bias=ps.f32(pfx + 'attn.c_attn.bias'))
+            self.kc[l][:, self.pos].copy_(qkv[:, D:2 * D])
+            self.vc[l][:, self.pos].copy_(qkv[:, 2 * D:])
+            a = ops.softmax_attn_decode(qkv[:, :D], self.kc[l], self.vc[l], self.lens, H)
+            x = self._block_tail(pfx, x, a)
+        self.pos += 1
+        return self._logits(x)
+
+
+def make_engine(model, n_streams, **kw):
+    return PerformerDecodeEngine(model, n_streams, **kw) if model.kind == 'performer' else GPT2DecodeEngine(model, n_streams, **kw)
+
+
+# ------------------------------------------------------------------------------------------------ reference loop
+def generate_conditional(model, event2idx, idx2event, lead_sheet_events, primer,
+                         max_events=10000, skip_check=False, max_bars=None,
+                         temp=1.2, top_p=0.9, inadmissibles=None,
+                         model_type="performer", use_cache=True, sampler=None, verbose=False):
+    """Same control flow, arguments and return value as inference.py:231-327.  `sampler(probs)` defaults to
+    nucleus(probs, top_p) with NumPy's global RNG, exactly like the reference."""
+    say = print if verbose else (lambda *a, **k: None)
+    dev = next(model.parameters()).device
+    generated = primer + [event2idx['Track_LeadSheet']] + lead_sheet_events[0] + [event2idx['Track_Full']]
+    seg_inp = [0 for _ in range(len(generated))]
+    seg_inp[-1] = 1
+    target_bars, generated_bars = len(lead_sheet_events), 0
+    if max_bars is not None:
+        target_bars = min(max_bars, target_bars)
+    steps, cur_pos, failed_cnt = 0, 0, 0
+    time_st = time.time()
+    eng = make_engine(model, 1) if use_cache else None
+    consumed = 0                 # tokens already folded into the engine state
+    cached_logits = None
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            while generated_bars < target_bars:
+                assert len(generated) == len(seg_inp)
+                if eng is not None and len(generated) < max_dec_inp_len:
+                    if consumed < len(generated):
+                        tok = torch.tensor([generated[consumed:]], dtype=torch.long, device=dev)
+                        seg = torch.tensor([seg_inp[consumed:]], dtype=torch.long, device=dev)
+                        cached_logits = eng.append(tok, seg)
+                        consumed = len(generated)
+                    logits = cached_logits                       # rejected samples re-use the same logits
+                else:
+                    dec_input = torch.tensor([generated[-max_dec_inp_len:]], dtype=torch.long, device=dev)
+                    dec_seg_inp = torch.tensor([seg_inp[-max_dec_inp_len:]], dtype=torch.long, device=dev)
+                    kw = {'attn_kwargs': {'omit_feature_map_draw': steps > 0}} if model_type == 'performer' else {}
+                    logits = model(dec_input, seg_inp=dec_seg_inp, keep_last_only=True, **kw)
+                logits_np = (logits[0]).cpu().detach().numpy().copy()
+                probs = temperature(logits_np, temp, inadmissibles=inadmissibles)
+                word = int(sampler(probs) if sampler is not None else nucleus(probs, top_p))
+                word_event = idx2event[word]
+                if not skip_check:
+                    if 'Beat' in word_event:
+                        event_pos = get_position_idx(word_event)
+                        if not event_pos >= cur_pos:
+                            failed_cnt += 1
+                            say('[info] position not increasing, failed cnt:', failed_cnt)
+                            if failed_cnt >= 256:
+                                say('[FATAL] model stuck, exiting with generated events ...')
+                                return generated
+                            continue
+                        else:
+                            cur_pos = event_pos
+                            failed_cnt = 0
+                if word_event == 'Track_LeadSheet':
+                    steps += 1
+                    generated.append(word)
+                    seg_inp.append(0)
+                    generated_bars += 1
+                    say('[info] generated {} bars, #events = {}'.format(generated_bars, len(generated)))
+                    if generated_bars < target_bars:
+                        generated.extend(lead_sheet_events[generated_bars])
+                        seg_inp.extend([0 for _ in range(len(lead_sheet_events[generated_bars]))])
+                        generated.append(event2idx['Track_Full'])
+                        seg_inp.append(1)
+                        cur_pos = 0
+                    continue
+                if word_event == 'PAD_None' or (word_event == 'EOS_None' and generated_bars < target_bars - 1):
+                    continue
+                elif word_event == 'EOS_None' and generated_bars == target_bars - 1:
+                    say('[info] gotten eos')
+                    generated.append(word)
+                    break
+                generated.append(word)
+                seg_inp.append(1)
+                steps += 1
+                if len(generated) > max_events:
+                    say('[info] max events reached')
+                    break
+    finally:
+        model.train(was_training)
+    say('-- generated events:', len(generated))
+    say('-- time elapsed  : {:.2f} secs'.format(time.time() - time_st))
+    say('-- time per event: {:.2f} secs'.format((time.time() - time_st) / len(generated)))
+    return generated[:-1]
+
+
+@torch.no_grad()
+def generate_streams(model, prompt_tok, prompt_seg, n_new, temp=1.1, top_p=0.9, greedy=False, seed=0, seg_value=1):
+    """BASELINE configs[3]: n parallel streams in lock-step (grammar checks off => fixed token count).  Everything stays
+    on the GPU: recurrent/KV state, sampling, token buffer.  Returns int64 [n, T0 + n_new]."""
+    n, T0 = prompt_tok.shape
+    dev = prompt_tok.device
+    eng = make_engine(model, n)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    out = torch.empty(n, T0 + n_new, dtype=torch.long, device=dev)
+    out[:, :T0] = prompt_tok
+    seg_col = torch.full((n,), seg_value, dtype=torch.long, device=dev)
+    logits = eng.prefill(prompt_tok, prompt_seg)
+    for i in range(n_new):
+        u = torch.rand(n, device=dev, generator=gen)
+        nxt = sample_on_device(logits, temp, top_p, u, greedy)
+        out[:, T0 + i] = nxt
+        if i + 1 < n_new:
+            logits = eng.step(nxt, seg_col)
+    return out

@@ -17,6 +17,15 @@ __all__ = ['gemm', 'colsum', 'embed_fwd', 'embed_bwd', 'layernorm_fwd', 'layerno
            'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW']
 
 
+def _c(t):
+    """contiguous int64 tensor (or None).  NEVER call .contiguous() inside a ptr(...) argument: the temporary dies before
+    the launch and the caching allocator hands its block to the next temporary."""
+    if t is None:
+        return None
+    assert t.dtype == torch.int64
+    return t if t.is_contiguous() else t.contiguous()
+
+
 def _rows(t):
     assert t.dim() == 2 and t.stride(1) == 1, 'need a 2-D tensor with unit column stride'
     return t.stride(0)
@@ -54,7 +63,8 @@ def embed_fwd(tok, seg, E, S, pe, dtype, scale, pos0=0, p_drop=0.0, seed=0, offs
     D = E.shape[1]
     out = torch.empty(B, T, D, device=tok.device, dtype=dtype)
     assert pe.is_contiguous() and pe.shape[-1] == D and pe.numel() >= (pos0 + T) * D
-    check(lib.emo_embed_fwd(ptr(tok.contiguous()), ptr(None if seg is None else seg.contiguous()), ptr(E), ptr(S), ptr(pe), ptr(out),
+    tok, seg = _c(tok), _c(seg)       # keep the contiguous copies alive until the launch is queued
+    check(lib.emo_embed_fwd(ptr(tok), ptr(seg), ptr(E), ptr(S), ptr(pe), ptr(out),
                             dtype_code(dtype), B, T, D, E.shape[0], 0 if S is None else S.shape[0], pos0, scale, p_drop, seed, offset,
                             stream()))
     return out
@@ -64,7 +74,8 @@ def embed_bwd(tok, seg, dout, dE, dS, scale, p_drop=0.0, seed=0, offset=0):
     B, T = tok.shape
     D = dE.shape[1]
     assert dout.is_contiguous()
-    check(lib.emo_embed_bwd(ptr(tok.contiguous()), ptr(None if seg is None else seg.contiguous()), ptr(dout), dtype_code(dout.dtype),
+    tok, seg = _c(tok), _c(seg)
+    check(lib.emo_embed_bwd(ptr(tok), ptr(seg), ptr(dout), dtype_code(dout.dtype),
                             ptr(dE), ptr(dS), B, T, D, dE.shape[0], 0 if dS is None else dS.shape[0], scale, p_drop, seed, offset,
                             stream()))
 
@@ -173,7 +184,8 @@ def xent_fwd(logits, tgt, ignore_index):
     assert logits.is_contiguous() and logits.dtype == torch.float32
     lse = torch.empty(M, device=logits.device, dtype=torch.float32)
     acc = torch.zeros(2, device=logits.device, dtype=torch.float32)
-    check(lib.emo_xent_fwd(ptr(logits), ptr(tgt.contiguous()), M, V, ignore_index, ptr(lse), ptr(acc), stream()))
+    tgt = _c(tgt)
+    check(lib.emo_xent_fwd(ptr(logits), ptr(tgt), M, V, ignore_index, ptr(lse), ptr(acc), stream()))
     return lse, acc
 
 
@@ -181,7 +193,8 @@ def xent_bwd(logits, tgt, lse, gscale, ignore_index, out_dtype, ld_out=None):
     M, V = logits.shape
     ld_out = ld_out or ((V + 7) // 8) * 8
     dl = torch.empty(M, ld_out, device=logits.device, dtype=out_dtype)
-    check(lib.emo_xent_bwd(ptr(logits), ptr(tgt.contiguous()), ptr(lse), ptr(gscale), ptr(dl), ld_out, dtype_code(out_dtype), M, V,
+    tgt = _c(tgt)
+    check(lib.emo_xent_bwd(ptr(logits), ptr(tgt), ptr(lse), ptr(gscale), ptr(dl), ld_out, dtype_code(out_dtype), M, V,
                            ignore_index, stream()))
     return dl
 
@@ -205,8 +218,9 @@ def sample_nucleus(logits, temperature, top_p, u):
 def accuracy_counts(logits, tgt, chord, melody, pad):
     M, V = logits.shape
     counts = torch.zeros(6, device=logits.device, dtype=torch.int64)
-    check(lib.emo_accuracy_counts(ptr(logits), ptr(tgt.contiguous()), ptr(None if chord is None else chord.contiguous()),
-                                  ptr(None if melody is None else melody.contiguous()), M, V, pad, ptr(counts), stream()))
+    assert logits.is_contiguous() and logits.dtype == torch.float32
+    tgt, chord, melody = _c(tgt), _c(chord), _c(melody)
+    check(lib.emo_accuracy_counts(ptr(logits), ptr(tgt), ptr(chord), ptr(melody), M, V, pad, ptr(counts), stream()))
     return counts
 
 
