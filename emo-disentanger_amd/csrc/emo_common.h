@@ -78,6 +78,24 @@ __host__ __device__ __forceinline__ float drop_mult(const DropCtx& d, uint64_t i
     return bits >= d.thr16 ? d.scale : 0.f;
 }
 
+// 4 consecutive elements starting at an EVEN index: two hashes instead of four; bit-identical to drop_mult()
+__device__ __forceinline__ void drop_mult4(const DropCtx& d, uint64_t idx0, float (&m)[4]) {
+    if (d.thr16 == 0u) { m[0] = m[1] = m[2] = m[3] = 1.f; return; }
+    if (idx0 & 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m[i] = drop_mult(d, idx0 + i);
+        return;
+    }
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        const uint64_t idx = idx0 + 2 * h2;
+        const uint32_t pair = (uint32_t)(idx >> 1) ^ (uint32_t)(idx >> 33) * 0x9E3779B1u;
+        const uint32_t h = emo_hash32(pair * 0x9E3779B1u + d.key);
+        m[2 * h2] = (h & 0xFFFFu) >= d.thr16 ? d.scale : 0.f;
+        m[2 * h2 + 1] = (h >> 16) >= d.thr16 ? d.scale : 0.f;
+    }
+}
+
 // ---------------------------------------------------------------- wave / block reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -47,13 +47,15 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
         Vec4<float>::load(E + tok[row] * D + c, e);
         if (seg) Vec4<float>::load(S + seg[row] * D + c, s);
         Vec4<float>::load(pe + (pos0 + t) * D + c, p);
+        float dm[4];
+        drop_mult4(drop, (uint64_t)(row * D + c), dm);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             // reference order: emb.mul_(scale); emb += seg.mul_(scale); + pe
             float v = e[i] * scale;
             v += s[i] * scale;
             v += p[i];
-            o[i] = v * drop_mult(drop, (uint64_t)(row * D + c + i));
+            o[i] = v * dm[i];
         }
         Vec4<T>::store(out + row * D + c, o);
     }
@@ -256,9 +258,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 Vec4<T>::store(dx + row * D + c, o);
                 if (dx_drop) {
                     // the consumer re-reads dx in storage precision: mask the ROUNDED value
-                    float od[4];
+                    float od[4], dm[4];
+                    drop_mult4(drop, (uint64_t)(row * D + c), dm);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) od[i] = to_f32<T>(from_f32<T>(o[i])) * drop_mult(drop, (uint64_t)(row * D + c + i));
+                    for (int i = 0; i < 4; ++i) od[i] = to_f32<T>(from_f32<T>(o[i])) * dm[i];
                     Vec4<T>::store(dx_drop + row * D + c, od);
                 }
             }
@@ -304,10 +307,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void dropout_apply_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t n, DropCtx drop) {
     const int64_t n4 = n >> 2;
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < n4; it += (int64_t)gridDim.x * blockDim.x) {
-        float v[4];
+        float v[4], dm[4];
         Vec4<T>::load(x + it * 4, v);
+        drop_mult4(drop, (uint64_t)(it * 4), dm);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] *= drop_mult(drop, (uint64_t)(it * 4 + i));
+        for (int i = 0; i < 4; ++i) v[i] *= dm[i];
         Vec4<T>::store(out + it * 4, v);
     }
 }

@@ -18,10 +18,14 @@
 
 #include "emo_lds_mma.h"
 
+// 8 waves per workgroup (one workgroup per (b,h), ~120-155 KB LDS => 1 workgroup per CU): two waves per SIMD so that
+// one wave's LDS / exp / global phases overlap the other's MFMAs.
+constexpr int FT = 512, FW = FT / 64;
+
 // per-row feature offset: off[t] = 0.5*c^2*|x_t|^2 + 0.5*ln(F); TPR threads per row, shuffle reduce
 template <typename CT, int DH, int C>
 __device__ __forceinline__ void row_offsets(const CT* X, int ld, float* off, float c2, float half_ln_f, int tid) {
-    constexpr int TPR = 256 / C;           // threads per row (C in {16,32,64} -> 16,8,4)
+    constexpr int TPR = FT / C;           // threads per row (C in {16,32,64} -> 16,8,4)
     constexpr int EPT = CMax<DH / TPR, 1>::v;
     const int r = tid / TPR, part = tid % TPR;
     float s = 0.f;
@@ -41,7 +45,7 @@ template <typename CT, int DHP, int MF, int C>
 __device__ __forceinline__ void features_rowmajor(CT* Ff, int ldf, const CT* WT, const CT* X, int ldx, const float* off, float cs,
                                                   int valid_rows, int wave, int lane) {
     constexpr int NT = (MF / 16) * (C / 16);
-    for (int tile = wave; tile < NT; tile += 4) {
+    for (int tile = wave; tile < NT; tile += FW) {
         const int rt = tile / (C / 16), ct = tile % (C / 16);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         mm16<CT>(acc, WT, ldx, rt * 16, X, ldx, ct * 16, DHP, lane);
@@ -60,7 +64,7 @@ template <typename CT, int DHP, int MF, int C>
 __device__ __forceinline__ void features_transposed(CT* FT, int ldt, const CT* WT, const CT* X, int ldx, const float* off, float cs,
                                                     int valid_rows, int wave, int lane) {
     constexpr int NT = (MF / 16) * (C / 16);
-    for (int tile = wave; tile < NT; tile += 4) {
+    for (int tile = wave; tile < NT; tile += FW) {
         const int rt = tile / (MF / 16), ct = tile % (MF / 16);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         mm16<CT>(acc, X, ldx, rt * 16, WT, ldx, ct * 16, DHP, lane);
@@ -93,12 +97,12 @@ template <typename CT, int DH, int MF, int C> struct FavorDims {
 
 template <typename CT>
 __device__ __forceinline__ void zero_img(CT* img, int n, int tid) {
-    for (int i = tid; i < n; i += 256) img[i] = from_f32<CT>(0.f);
+    for (int i = tid; i < n; i += FT) img[i] = from_f32<CT>(0.f);
 }
 
 // =============================================================================================== forward
 template <typename CT, int DH, int MF, int C>
-__global__ __launch_bounds__(256) void favor_fwd_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+__global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
                                                         const float* __restrict__ omega, CT* __restrict__ out, int64_t ld_out,
                                                         float* __restrict__ den_g, float* __restrict__ state_S, float* __restrict__ state_z,
                                                         int64_t T, int64_t H, float eps) {
@@ -135,12 +139,12 @@ __global__ __launch_bounds__(256) void favor_fwd_kernel(const CT* __restrict__ q
     zero_img(VT, DH * LDC, tid);
     zero_img(KfT, F * LDC, tid);
     zero_img(Am, C * LDC, tid);
-    for (int i = tid; i < F; i += 256) zz[i] = 0.f;
+    for (int i = tid; i < F; i += FT) zz[i] = 0.f;
     __syncthreads();
-    for (int i = tid; i < DH * MF; i += 256) { const int d = i / MF, m = i % MF; WT[m * LDX + d] = from_f32<CT>(omega[i]); }
+    for (int i = tid; i < DH * MF; i += FT) { const int d = i / MF, m = i % MF; WT[m * LDX + d] = from_f32<CT>(omega[i]); }
 
     constexpr int NTS = (F / 16) * (DH / 16);          // state tiles: rows<->f (R=KfT), col<->d (C=VT)
-    constexpr int NTS_W = (NTS + 3) / 4;
+    constexpr int NTS_W = (NTS + FW - 1) / FW;
     f32x4 sacc[NTS_W];
 #pragma unroll
     for (int i = 0; i < NTS_W; ++i) sacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -148,9 +152,9 @@ __global__ __launch_bounds__(256) void favor_fwd_kernel(const CT* __restrict__ q
     for (int64_t t0 = 0; t0 < T; t0 += C) {
         const int valid = (int)((T - t0) < C ? (T - t0) : C);
         __syncthreads();
-        load_rows<CT, DH, DHP>(Xq, LDX, qb + t0 * ld, ld, C, valid, tid);
-        load_rows<CT, DH, DHP>(Xk, LDX, kb + t0 * ld, ld, C, valid, tid);
-        load_rows_T<CT, DH>(VT, LDC, vb + t0 * ld, ld, C, valid, tid);
+        load_rows<CT, DH, DHP, FT>(Xq, LDX, qb + t0 * ld, ld, C, valid, tid);
+        load_rows<CT, DH, DHP, FT>(Xk, LDX, kb + t0 * ld, ld, C, valid, tid);
+        load_rows_T<CT, DH, FT>(VT, LDC, vb + t0 * ld, ld, C, valid, tid);
         __syncthreads();
         row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
         row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256) void favor_fwd_kernel(const CT* __restrict__ q
         // A[t][j] = Qf[t].Kf[j] masked j<=t : rows<->j (R=Kf), col<->t (C=Qf)
         {
             constexpr int NT = (C / 16) * (C / 16);
-            for (int tile = wave; tile < NT; tile += 4) {
+            for (int tile = wave; tile < NT; tile += FW) {
                 const int jt = tile / (C / 16), tt = tile % (C / 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 if (jt <= tt) mm16<CT>(acc, Kf, LDF, jt * 16, Qf, LDF, tt * 16, F, lane);
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256) void favor_fwd_kernel(const CT* __restrict__ q
         __syncthreads();
         // den[t] = rowsum(A[t]) + Qf[t].z_prev + eps
         {
-            constexpr int TPR = 256 / C;
+            constexpr int TPR = FT / C;
             const int r = tid / TPR, part = tid % TPR;
             float s = 0.f;
             for (int j = part; j < C; j += TPR) s += to_f32<CT>(Am[r * LDC + j]);
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void favor_fwd_kernel(const CT* __restrict__ q
         // out^T: rows<->d, col<->t : VT.Am^T (K=C) + ST.Qf^T (K=F)
         {
             constexpr int NT = (DH / 16) * (C / 16);
-            for (int tile = wave; tile < NT; tile += 4) {
+            for (int tile = wave; tile < NT; tile += FW) {
                 const int dt = tile / (C / 16), tt = tile % (C / 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 mm16<CT>(acc, VT, LDC, dt * 16, Am, LDC, tt * 16, CP, lane);
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256) void favor_fwd_kernel(const CT* __restrict__ q
         // state: S[f][d] += sum_j KfT[f][j] VT[d][j]; mirror ST[d][f]; z += colsum
 #pragma unroll
         for (int i = 0; i < NTS_W; ++i) {
-            const int tile = wave + 4 * i;
+            const int tile = wave + FW * i;
             if (tile < NTS) {
                 const int ft = tile / (DH / 16), dt = tile % (DH / 16);
                 mm16<CT>(sacc[i], KfT, LDC, ft * 16, VT, LDC, dt * 16, CP, lane);
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256) void favor_fwd_kernel(const CT* __restrict__ q
                 Img<CT>::store4(ST + d * LDF + f0, sacc[i][0], sacc[i][1], sacc[i][2], sacc[i][3]);
             }
         }
-        for (int f = tid; f < F; f += 256) {
+        for (int f = tid; f < F; f += FT) {
             float s = 0.f;
             for (int j = 0; j < C; ++j) s += to_f32<CT>(KfT[f * LDC + j]);
             zz[f] += s;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void favor_fwd_kernel(const CT* __restrict__ q
     if (state_S) {
 #pragma unroll
         for (int i = 0; i < NTS_W; ++i) {
-            const int tile = wave + 4 * i;
+            const int tile = wave + FW * i;
             if (tile < NTS) {
                 const int ft = tile / (DH / 16), dt = tile % (DH / 16);
                 const int d = dt * 16 + (lane & 15), f0 = ft * 16 + (lane >> 4) * 4;
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(256) void favor_fwd_kernel(const CT* __restrict__ q
                 for (int r = 0; r < 4; ++r) state_S[(bh * F + f0 + r) * DH + d] = sacc[i][r];
             }
         }
-        for (int f = tid; f < F; f += 256) state_z[bh * F + f] = zz[f];
+        for (int f = tid; f < F; f += FT) state_z[bh * F + f] = zz[f];
     }
 }
 
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) void favor_fwd_kernel(const CT* __restrict__ q
 template <typename CT, int DH, int DHP, int C>
 __device__ __forceinline__ void load_grads(CT* G, int ldg, CT* GT, int ldgt, float* dD, const CT* __restrict__ dout, const CT* __restrict__ outp,
                                            int64_t ld_out, const float* __restrict__ den, int valid, int tid) {
-    constexpr int TPR = 256 / C;
+    constexpr int TPR = FT / C;
     constexpr int EPT = CMax<DHP / TPR, 1>::v;
     const int r = tid / TPR, part = tid % TPR;
     const float inv = r < valid ? 1.f / den[r] : 0.f;
@@ -285,7 +289,7 @@ __device__ __forceinline__ void jac_epilogue(const f32x4& accP, const f32x4& acc
 template <typename CT, int MF, int MFP, int C>
 __device__ __forceinline__ void zero_adiff_pad(CT* Adiff, int lda, int tid) {
     if constexpr (MFP > MF) {
-        for (int i = tid; i < C * (MFP - MF); i += 256) Adiff[(i / (MFP - MF)) * lda + MF + i % (MFP - MF)] = from_f32<CT>(0.f);
+        for (int i = tid; i < C * (MFP - MF); i += FT) Adiff[(i / (MFP - MF)) * lda + MF + i % (MFP - MF)] = from_f32<CT>(0.f);
     }
 }
 
@@ -294,7 +298,7 @@ template <typename CT, int DH, int MFP, int C>
 __device__ __forceinline__ void dx_from_adiff(const CT* W, int ldw, const CT* Adiff, int lda, const float* sumA, const CT* __restrict__ xg,
                                               int64_t ld, CT* __restrict__ dxg, int64_t ld_d, float cs, int valid, int wave, int lane) {
     constexpr int NT = (DH / 16) * (C / 16);
-    for (int tile = wave; tile < NT; tile += 4) {
+    for (int tile = wave; tile < NT; tile += FW) {
         const int dt = tile / (C / 16), tt = tile % (C / 16);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         mm16<CT>(acc, W, ldw, dt * 16, Adiff, lda, tt * 16, MFP, lane);
@@ -311,7 +315,7 @@ __device__ __forceinline__ void dx_from_adiff(const CT* W, int ldw, const CT* Ad
 
 // =============================================================================================== backward: dq (forward sweep)
 template <typename CT, int DH, int MF, int C>
-__global__ __launch_bounds__(256) void favor_bwd_dq_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+__global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
                                                            const float* __restrict__ omega, const CT* __restrict__ out, const CT* __restrict__ dout,
                                                            int64_t ld_out, const float* __restrict__ den_g, CT* __restrict__ dq, int64_t ld_d,
                                                            int64_t T, int64_t H) {
@@ -355,16 +359,16 @@ __global__ __launch_bounds__(256) void favor_bwd_dq_kernel(const CT* __restrict_
     zero_img(VT, DH * LDC, tid);
     zero_img(KfT, F * LDC, tid);
     zero_img(Pm, C * LDC, tid);
-    for (int i = tid; i < F; i += 256) zz[i] = 0.f;
+    for (int i = tid; i < F; i += FT) zz[i] = 0.f;
     __syncthreads();
-    for (int i = tid; i < DH * MF; i += 256) {
+    for (int i = tid; i < DH * MF; i += FT) {
         const int d = i / MF, m = i % MF;
         const CT w = from_f32<CT>(omega[i]);
         WT[m * LDX + d] = w;
         W[d * LDM + m] = w;
     }
     constexpr int NTS = (DH / 16) * (F / 16);   // state tiles: rows<->d (R=VT), col<->f (C=KfT) -> SF[f][d0..]
-    constexpr int NTS_W = (NTS + 3) / 4;
+    constexpr int NTS_W = (NTS + FW - 1) / FW;
     f32x4 sacc[NTS_W];
 #pragma unroll
     for (int i = 0; i < NTS_W; ++i) sacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -372,12 +376,12 @@ __global__ __launch_bounds__(256) void favor_bwd_dq_kernel(const CT* __restrict_
     for (int64_t t0 = 0; t0 < T; t0 += C) {
         const int valid = (int)((T - t0) < C ? (T - t0) : C);
         __syncthreads();
-        load_rows<CT, DH, DHP>(Xq, LDX, qb + t0 * ld, ld, C, valid, tid);
-        load_rows<CT, DH, DHP>(Xk, LDX, kb + t0 * ld, ld, C, valid, tid);
-        load_rows<CT, DH, DHP>(Vr, LDX, vb + t0 * ld, ld, C, valid, tid);
-        load_rows_T<CT, DH>(VT, LDC, vb + t0 * ld, ld, C, valid, tid);
+        load_rows<CT, DH, DHP, FT>(Xq, LDX, qb + t0 * ld, ld, C, valid, tid);
+        load_rows<CT, DH, DHP, FT>(Xk, LDX, kb + t0 * ld, ld, C, valid, tid);
+        load_rows<CT, DH, DHP, FT>(Vr, LDX, vb + t0 * ld, ld, C, valid, tid);
+        load_rows_T<CT, DH, FT>(VT, LDC, vb + t0 * ld, ld, C, valid, tid);
         load_grads<CT, DH, DHP, C>(G, LDX, (CT*)nullptr, 0, dD, gb + t0 * ld_out, ob + t0 * ld_out, ld_out, dg + t0, valid, tid);
-        for (int i = tid; i < C; i += 256) sumA[i] = 0.f;
+        for (int i = tid; i < C; i += FT) sumA[i] = 0.f;
         __syncthreads();
         row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
         row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(256) void favor_bwd_dq_kernel(const CT* __restrict_
         // P[t][j] = dN_t.v_j + dD_t, masked j<=t : rows<->j (R=Vr), col<->t (C=G)
         {
             constexpr int NT = (C / 16) * (C / 16);
-            for (int tile = wave; tile < NT; tile += 4) {
+            for (int tile = wave; tile < NT; tile += FW) {
                 const int jt = tile / (C / 16), tt = tile % (C / 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 if (jt <= tt) mm16<CT>(acc, Vr, LDX, jt * 16, G, LDX, tt * 16, DHP, lane);
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(256) void favor_bwd_dq_kernel(const CT* __restrict_
         zero_adiff_pad<CT, MF, MFP, C>(Adiff, LDM, tid);
         {
             constexpr int NP = (MF / 16) * (C / 16);
-            for (int pr = wave; pr < NP; pr += 4) {
+            for (int pr = wave; pr < NP; pr += FW) {
                 const int ft = pr / (C / 16), tt = pr % (C / 16);
                 f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f};
                 mm16<CT>(aP, KfT, LDC, ft * 16, Pm, LDC, tt * 16, CP, lane);
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(256) void favor_bwd_dq_kernel(const CT* __restrict_
         // state S[f][d] (+)= ; mirror SF[f][d0..] ; z += colsum(KfT)
 #pragma unroll
         for (int i = 0; i < NTS_W; ++i) {
-            const int tile = wave + 4 * i;
+            const int tile = wave + FW * i;
             if (tile < NTS) {
                 const int dt = tile / (F / 16), ft = tile % (F / 16);
                 mm16<CT>(sacc[i], VT, LDC, dt * 16, KfT, LDC, ft * 16, CP, lane);
@@ -427,14 +431,14 @@ __global__ __launch_bounds__(256) void favor_bwd_dq_kernel(const CT* __restrict_
         __syncthreads();   // all reads of SF / zz for this chunk are done
 #pragma unroll
         for (int i = 0; i < NTS_W; ++i) {
-            const int tile = wave + 4 * i;
+            const int tile = wave + FW * i;
             if (tile < NTS) {
                 const int dt = tile / (F / 16), ft = tile % (F / 16);
                 const int f = ft * 16 + (lane & 15), d0 = dt * 16 + (lane >> 4) * 4;
                 Img<CT>::store4(SF + f * LDX + d0, sacc[i][0], sacc[i][1], sacc[i][2], sacc[i][3]);
             }
         }
-        for (int f = tid; f < F; f += 256) {
+        for (int f = tid; f < F; f += FT) {
             float s = 0.f;
             for (int j = 0; j < C; ++j) s += to_f32<CT>(KfT[f * LDC + j]);
             zz[f] += s;
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(256) void favor_bwd_dq_kernel(const CT* __restrict_
 
 // =============================================================================================== backward: dk, dv (reverse sweep)
 template <typename CT, int DH, int MF, int C>
-__global__ __launch_bounds__(256) void favor_bwd_dkv_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+__global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
                                                             const float* __restrict__ omega, const CT* __restrict__ out, const CT* __restrict__ dout,
                                                             int64_t ld_out, const float* __restrict__ den_g, CT* __restrict__ dk, CT* __restrict__ dv,
                                                             int64_t ld_d, int64_t T, int64_t H) {
@@ -492,16 +496,16 @@ __global__ __launch_bounds__(256) void favor_bwd_dkv_kernel(const CT* __restrict
     zero_img(RT, DH * LDF, tid);
     zero_img(GT, DH * LDC, tid);
     zero_img(QfT, F * LDC, tid);
-    for (int i = tid; i < F; i += 256) rr[i] = 0.f;
+    for (int i = tid; i < F; i += FT) rr[i] = 0.f;
     __syncthreads();
-    for (int i = tid; i < DH * MF; i += 256) {
+    for (int i = tid; i < DH * MF; i += FT) {
         const int d = i / MF, m = i % MF;
         const CT w = from_f32<CT>(omega[i]);
         WT[m * LDX + d] = w;
         W[d * LDM + m] = w;
     }
     constexpr int NTS = (DH / 16) * (F / 16);   // rows<->d (R=GT), col<->f (C=QfT)
-    constexpr int NTS_W = (NTS + 3) / 4;
+    constexpr int NTS_W = (NTS + FW - 1) / FW;
     f32x4 racc[NTS_W];
 #pragma unroll
     for (int i = 0; i < NTS_W; ++i) racc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -511,11 +515,11 @@ __global__ __launch_bounds__(256) void favor_bwd_dkv_kernel(const CT* __restrict
         const int64_t t0 = ci * C;
         const int valid = (int)((T - t0) < C ? (T - t0) : C);
         __syncthreads();
-        load_rows<CT, DH, DHP>(Xq, LDX, qb + t0 * ld, ld, C, valid, tid);
-        load_rows<CT, DH, DHP>(Xk, LDX, kb + t0 * ld, ld, C, valid, tid);
-        load_rows<CT, DH, DHP>(Vr, LDX, vb + t0 * ld, ld, C, valid, tid);
+        load_rows<CT, DH, DHP, FT>(Xq, LDX, qb + t0 * ld, ld, C, valid, tid);
+        load_rows<CT, DH, DHP, FT>(Xk, LDX, kb + t0 * ld, ld, C, valid, tid);
+        load_rows<CT, DH, DHP, FT>(Vr, LDX, vb + t0 * ld, ld, C, valid, tid);
         load_grads<CT, DH, DHP, C>(G, LDX, GT, LDC, dD, gb + t0 * ld_out, ob + t0 * ld_out, ld_out, dg + t0, valid, tid);
-        for (int i = tid; i < C; i += 256) sumA[i] = 0.f;
+        for (int i = tid; i < C; i += FT) sumA[i] = 0.f;
         __syncthreads();
         row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
         row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(256) void favor_bwd_dkv_kernel(const CT* __restrict
         // AmT[j][t] = Qf_t.Kf_j       (t>=j) : rows<->t (R=Qf), col<->j (C=Kf)
         {
             constexpr int NT = (C / 16) * (C / 16);
-            for (int tile = wave; tile < NT; tile += 4) {
+            for (int tile = wave; tile < NT; tile += FW) {
                 const int tt = tile / (C / 16), jt = tile % (C / 16);
                 f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aA = {0.f, 0.f, 0.f, 0.f};
                 if (tt >= jt) {
@@ -554,7 +558,7 @@ __global__ __launch_bounds__(256) void favor_bwd_dkv_kernel(const CT* __restrict
         zero_adiff_pad<CT, MF, MFP, C>(Adiff, LDM, tid);
         {
             constexpr int NP = (MF / 16) * (C / 16);
-            for (int pr = wave; pr < NP; pr += 4) {
+            for (int pr = wave; pr < NP; pr += FW) {
                 const int ft = pr / (C / 16), jt = pr % (C / 16);
                 f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f};
                 mm16<CT>(aP, QfT, LDC, ft * 16, PmT, LDC, jt * 16, CP, lane);
@@ -568,7 +572,7 @@ __global__ __launch_bounds__(256) void favor_bwd_dkv_kernel(const CT* __restrict
         // dV^T: rows<->d, col<->j : GT.AmT^T (K=C) + RT.Kf^T (K=F)
         {
             constexpr int NT = (DH / 16) * (C / 16);
-            for (int tile = wave; tile < NT; tile += 4) {
+            for (int tile = wave; tile < NT; tile += FW) {
                 const int dt = tile / (C / 16), jt = tile % (C / 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 mm16<CT>(acc, GT, LDC, dt * 16, AmT, LDC, jt * 16, CP, lane);
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(256) void favor_bwd_dkv_kernel(const CT* __restrict
         // state R[f][d] += sum_t QfT[f][t] GT[d][t]
 #pragma unroll
         for (int i = 0; i < NTS_W; ++i) {
-            const int tile = wave + 4 * i;
+            const int tile = wave + FW * i;
             if (tile < NTS) {
                 const int dt = tile / (F / 16), ft = tile % (F / 16);
                 mm16<CT>(racc[i], GT, LDC, dt * 16, QfT, LDC, ft * 16, CP, lane);
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(256) void favor_bwd_dkv_kernel(const CT* __restrict
         __syncthreads();   // all reads of RF / RT / rr for this chunk are done
 #pragma unroll
         for (int i = 0; i < NTS_W; ++i) {
-            const int tile = wave + 4 * i;
+            const int tile = wave + FW * i;
             if (tile < NTS) {
                 const int dt = tile / (F / 16), ft = tile % (F / 16);
                 const int f = ft * 16 + (lane & 15), d0 = dt * 16 + (lane >> 4) * 4;
@@ -600,7 +604,7 @@ __global__ __launch_bounds__(256) void favor_bwd_dkv_kernel(const CT* __restrict
                 for (int r = 0; r < 4; ++r) RT[(d0 + r) * LDF + f] = from_f32<CT>(racc[i][r]);
             }
         }
-        for (int f = tid; f < F; f += 256) {
+        for (int f = tid; f < F; f += FT) {
             float s = 0.f;
             for (int t = 0; t < C; ++t) s += to_f32<CT>(QfT[f * LDC + t]) * dD[t];
             rr[f] += s;
@@ -656,6 +660,58 @@ __global__ __launch_bounds__(128) void favor_decode_kernel(const CT* __restrict_
     if (tid < dh) out[s * ld_out + h * dh + tid] = from_f32<CT>((num[0][tid] + num[1][tid]) / (dpart[0] + dpart[1] + eps));
 }
 
+// =============================================================================================== omega draw
+// FAVOR+ orthogonal random features (fast-transformers orthogonal_random_matrix_): per block of dh columns,
+// G ~ N(0,1)^{dh x dh} (supplied by the caller's RNG), Q = orthonormal basis of G's columns, column j scaled by
+// the norm of ROW j of G.  Gram-Schmidt with re-orthogonalisation (CGS2) in LDS replaces the Householder QR of
+// torch.qr: the two differ only by column signs, to which the feature set {exp(+u), exp(-u)} is invariant.
+// grid = (n_layers * n_blocks); one wave per block; lane = row index.
+__global__ __launch_bounds__(64) void favor_omega_kernel(const float* __restrict__ gauss, float* __restrict__ omega, int dh, int cols, int nblocks) {
+    __shared__ float Q[64 * 65];
+    __shared__ float v[64], cf[64];
+    const int lane = threadIdx.x;
+    const int layer = blockIdx.x / nblocks, blk = blockIdx.x % nblocks;
+    const float* G = gauss + (int64_t)blockIdx.x * dh * dh;
+    float rn = 0.f;
+    if (lane < dh)
+        for (int b = 0; b < dh; ++b) { const float g = G[lane * dh + b]; rn += g * g; }
+    rn = sqrtf(rn);                                   // norm of row `lane` of G
+    const int start = blk * dh;
+    const int ncol = (cols - start) < dh ? (cols - start) : dh;
+    for (int j = 0; j < ncol; ++j) {
+        float x = lane < dh ? G[lane * dh + j] : 0.f; // column j, element `lane`
+        for (int pass = 0; pass < 2; ++pass) {
+            v[lane] = x;
+            __syncthreads();
+            float c = 0.f;
+            if (lane < j)
+                for (int a = 0; a < dh; ++a) c += Q[a * 65 + lane] * v[a];
+            cf[lane] = lane < j ? c : 0.f;
+            __syncthreads();
+            float sub = 0.f;
+            if (lane < dh)
+                for (int i = 0; i < j; ++i) sub += cf[i] * Q[lane * 65 + i];
+            x -= sub;
+            __syncthreads();
+        }
+        const float nrm = sqrtf(wave_sum(lane < dh ? x * x : 0.f));
+        const float qv = x / nrm;
+        if (lane < dh) Q[lane * 65 + j] = qv;
+        const float scale = __shfl(rn, j, 64);
+        if (lane < dh) omega[((int64_t)layer * dh + lane) * cols + start + j] = qv * scale;
+        __syncthreads();
+    }
+}
+
+extern "C" int emo_favor_draw_omega(const float* gauss, float* omega, int64_t n_layers, int64_t dh, int64_t n_feat, emo_stream_t stream) {
+    EMO_CHECK(gauss && omega && dh > 0 && dh <= 64 && n_feat % 2 == 0, "emo_favor_draw_omega: bad args (d_head <= 64)");
+    const int cols = (int)(n_feat / 2);
+    const int nblocks = (cols + (int)dh - 1) / (int)dh;
+    hipLaunchKernelGGL(favor_omega_kernel, dim3((unsigned)(n_layers * nblocks)), dim3(64), 0, (hipStream_t)stream, gauss, omega, (int)dh, cols, nblocks);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
 // =============================================================================================== host
 template <typename CT, int DH, int MF, int C> static size_t fwd_lds() {
     typedef FavorDims<CT, DH, MF, C> D;
@@ -688,7 +744,7 @@ static int run_favor(int which, const void* q, const void* k, const void* v, int
         auto kf = favor_fwd_kernel<CT, DH, MF, CF>;
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-        hipLaunchKernelGGL(kf, grid, dim3(256), lds, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (CT*)out, ld_out, den, sS, sz, T, H, eps);
+        hipLaunchKernelGGL(kf, grid, dim3(FT), lds, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (CT*)out, ld_out, den, sS, sz, T, H, eps);
     } else {
         const size_t l1 = dq_lds<CT, DH, MF, CQ>(), l2 = dkv_lds<CT, DH, MF, CK>();
         EMO_CHECK(l1 <= EMO_MAX_LDS && l2 <= EMO_MAX_LDS, "favor bwd: LDS %zu / %zu too large", l1, l2);
@@ -700,9 +756,9 @@ static int run_favor(int which, const void* q, const void* k, const void* v, int
             (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
             attr = true;
         }
-        hipLaunchKernelGGL(k1, grid, dim3(256), l1, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
+        hipLaunchKernelGGL(k1, grid, dim3(FT), l1, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
                            (CT*)dq, ld_d, T, H);
-        hipLaunchKernelGGL(k2, grid, dim3(256), l2, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
+        hipLaunchKernelGGL(k2, grid, dim3(FT), l2, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
                            (CT*)dk, (CT*)dv, ld_d, T, H);
     }
     EMO_LAUNCH_CHECK();

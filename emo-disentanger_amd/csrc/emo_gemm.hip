@@ -34,72 +34,98 @@ struct EpiParams {
 
 // ------------------------------------------------------------------------------------------------
 // epilogue for 4 consecutive columns n..n+3 of row m
+template <typename OutT> struct Out4;
+template <> struct Out4<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { f32x4 t = *(const f32x4*)p; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]}; }
+};
+template <> struct Out4<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) { bf16x4 t = *(const bf16x4*)p; v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3]; }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) { bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; *(bf16x4*)p = t; }
+};
+
 template <typename OutT>
 __device__ __forceinline__ void epi_store4(const EpiParams& ep, OutT* __restrict__ C, int64_t m, int64_t n,
                                            f32x4 acc, int64_t N) {
     const int64_t off = m * ep.ldc + n;
-    const bool vec = (n + 3 < N) && ((ep.ldc & 3) == 0);
     float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-    const int cnt = vec ? 4 : (int)((N - n) < 4 ? (N - n) : 4);
-    if (ep.bias) {
-        if (vec) {
+    if ((n + 3 < N) && ((ep.ldc & 3) == 0)) {
+        // ---- fast path: 4 valid, 8/16-B aligned columns
+        if (ep.bias) {
             f32x4 b = *(const f32x4*)(ep.bias + n);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] += b[i];
-        } else {
-            for (int i = 0; i < cnt; ++i) v[i] += ep.bias[n + i];
         }
-    }
-    if (ep.aux_out) {
-        OutT* ao = (OutT*)ep.aux_out + off;
-        for (int i = 0; i < cnt; ++i) ao[i] = from_f32<OutT>(v[i]);
-    }
-    if (ep.act == EMO_ACT_RELU) {
+        if (ep.aux_out) Out4<OutT>::store((OutT*)ep.aux_out + off, v);
+        if (ep.act == EMO_ACT_RELU) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-    } else if (ep.act == EMO_ACT_GELU_NEW) {
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+        } else if (ep.act == EMO_ACT_GELU_NEW) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = gelu_new_f(v[i]);
-    }
-    if (ep.mul_mode != EMO_MUL_NONE) {
-        const OutT* ma = (const OutT*)ep.mul_aux + off;
-        for (int i = 0; i < cnt; ++i) {
-            float a = to_f32<OutT>(ma[i]);
-            v[i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (a != 0.f ? ep.mul_scale : 0.f) : dgelu_new_f(a);
+            for (int i = 0; i < 4; ++i) v[i] = gelu_new_f(v[i]);
         }
-    }
-    if (ep.drop.thr16) {
-        for (int i = 0; i < cnt; ++i) v[i] *= drop_mult(ep.drop, (uint64_t)(m * N + n + i));
-    }
-    if (ep.residual) {
-        const OutT* r = (const OutT*)ep.residual + off;
-        if (vec && sizeof(OutT) == 2) {
-            bf16x4 rv = *(const bf16x4*)r;
+        if (ep.mul_mode != EMO_MUL_NONE) {
+            float a[4];
+            Out4<OutT>::load((const OutT*)ep.mul_aux + off, a);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] += (float)rv[i];
-        } else {
-            for (int i = 0; i < cnt; ++i) v[i] += to_f32<OutT>(r[i]);
+            for (int i = 0; i < 4; ++i) v[i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (a[i] != 0.f ? ep.mul_scale : 0.f) : dgelu_new_f(a[i]);
         }
+        if (ep.drop.thr16) {
+            float dm[4];
+            drop_mult4(ep.drop, (uint64_t)(m * N + n), dm);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] *= dm[i];
+        }
+        if (ep.residual) {
+            float r[4];
+            Out4<OutT>::load((const OutT*)ep.residual + off, r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += r[i];
+        }
+        OutT* c = C + off;
+        if constexpr (sizeof(OutT) == 4) {
+            if (ep.atomic) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) atomicAdd((float*)c + i, v[i]);
+                return;
+            }
+            if (ep.accumulate) {
+                float o[4];
+                Out4<float>::load((const float*)c, o);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += o[i];
+            }
+        }
+        Out4<OutT>::store(c, v);
+        return;
     }
-    OutT* c = C + off;
-    if constexpr (sizeof(OutT) == 4) {
-        if (ep.atomic) {
-            for (int i = 0; i < cnt; ++i) atomicAdd((float*)c + i, v[i]);
-        } else if (ep.accumulate) {
-            for (int i = 0; i < cnt; ++i) ((float*)c)[i] += v[i];
-        } else if (vec) {
-            *(f32x4*)c = (f32x4){v[0], v[1], v[2], v[3]};
-        } else {
-            for (int i = 0; i < cnt; ++i) ((float*)c)[i] = v[i];
+    // ---- edge path (partial column group or unaligned ldc): scalar
+    const int cnt = (int)((N - n) < 4 ? (N - n) : 4);
+    for (int i = 0; i < cnt; ++i) {
+        float x = v[i];
+        if (ep.bias) x += ep.bias[n + i];
+        if (ep.aux_out) ((OutT*)ep.aux_out)[off + i] = from_f32<OutT>(x);
+        if (ep.act == EMO_ACT_RELU) x = fmaxf(x, 0.f);
+        else if (ep.act == EMO_ACT_GELU_NEW) x = gelu_new_f(x);
+        if (ep.mul_mode != EMO_MUL_NONE) {
+            const float a = to_f32<OutT>(((const OutT*)ep.mul_aux)[off + i]);
+            x *= (ep.mul_mode == EMO_MUL_NONZERO) ? (a != 0.f ? ep.mul_scale : 0.f) : dgelu_new_f(a);
         }
-    } else {
-        if (vec) {
-            bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-            *(bf16x4*)c = o;
-        } else {
-            for (int i = 0; i < cnt; ++i) c[i] = from_f32<OutT>(v[i]);
+        if (ep.drop.thr16) x *= drop_mult(ep.drop, (uint64_t)(m * N + n + i));
+        if (ep.residual) x += to_f32<OutT>(((const OutT*)ep.residual)[off + i]);
+        if constexpr (sizeof(OutT) == 4) {
+            if (ep.atomic) { atomicAdd((float*)C + off + i, x); continue; }
+            if (ep.accumulate) x += ((const float*)C)[off + i];
         }
+        C[off + i] = from_f32<OutT>(x);
     }
+}
+
+// out-of-line copy for kernels with many accumulator tiles (keeps the unrolled epilogue small enough that the
+// accumulator array stays in registers instead of scratch)
+template <typename OutT>
+__device__ __noinline__ void epi_store4_call(const EpiParams& ep, OutT* __restrict__ C, int64_t m, int64_t n, f32x4 acc, int64_t N) {
+    epi_store4<OutT>(ep, C, m, n, acc, N);
 }
 
 // XCD-aware (m_tile, n_tile) from the linear block id (dispatcher places block b on XCD b%8).
@@ -330,6 +356,290 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 }
 
 // ================================================================================================
+// bf16 MFMA kernel, v2: LDS-DMA (global_load_lds, 16 B/lane) into a 4-stage ring of 128x128x32 tiles.
+// The register-staged kernel above keeps only ONE K-tile in flight, so with K=512 every K-step pays
+// a full HBM/L2 round trip (measured ~1.2 us per step vs 0.2 us of MFMA work).  Here three K-tiles
+// are in flight behind counted `s_waitcnt vmcnt(N)` + raw s_barrier (never vmcnt(0) in the loop, never
+// __syncthreads), the staging costs no VGPRs, and LDS stays at 64 KB/block (2 blocks per CU).
+// LDS images (per stage, per operand 8 KB): K-contig [128 rows][4 x 16-B chunks], chunk ^= (row>>2)&3;
+// MN-contig [32 k][128 rows] with the 32-B granule swizzle of the v1 kernel.  The DMA writes LDS
+// lane-linearly, so the swizzle is applied to the per-lane SOURCE address and again on the read.
+// Requires K (per split) % 32 == 0; edge rows are clamped to valid addresses (their outputs are dropped).
+constexpr int G2_BK = 32, G2_ST = 4, G2_STAGE = 16384;
+
+// per-lane BYTE offsets of the two 16-B pieces this lane fetches for one operand tile (constant over the K loop);
+// the K position is carried by a wave-uniform base pointer so that a K step costs no per-lane address arithmetic.
+template <bool KC>
+__device__ __forceinline__ void glds_offsets(int64_t ld, int64_t row0, int64_t nrows, int wave, int lane, uint32_t (&off)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = wave * 2 + i;   // wave-instruction index 0..7 (1 KiB each)
+        if constexpr (KC) {
+            const int row = j * 16 + (lane >> 2), pc = lane & 3;
+            const int c = pc ^ ((row >> 2) & 3);
+            int64_t gr = row0 + row;
+            if (gr > nrows - 1) gr = nrows - 1;
+            off[i] = (uint32_t)((gr * ld + c * 8) * 2);
+        } else {
+            const int k = j * 4 + (lane >> 4), p16 = lane & 15;
+            const int g = (p16 >> 1) ^ swz_k(k);
+            int64_t gr = row0 + (g * 2 + (p16 & 1)) * 8;
+            if (gr > nrows - 1) gr = ((nrows - 1) >> 3) << 3;
+            off[i] = (uint32_t)(((int64_t)k * ld + gr) * 2);
+        }
+    }
+}
+__device__ __forceinline__ void glds_issue2(const char* __restrict__ base, const uint32_t (&off)[2], char* stage_op, int wave) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[i]),
+                                         (__attribute__((address_space(3))) void*)(stage_op + (wave * 2 + i) * 1024), 16, 0, 0);
+}
+
+template <bool KC>
+__device__ __forceinline__ bf16x8 lfrag2(const char* lds, int rbase, int lane) {
+    if constexpr (KC) {
+        const int row = rbase + (lane & 15);
+        const int pc = (lane >> 4) ^ ((row >> 2) & 3);
+        return *(const bf16x8*)(lds + row * 64 + (pc << 4));
+    } else {
+        const int i = lane & 15, g = rbase >> 4;
+        bf16x8 v;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = (lane >> 4) * 8 + h * 4 + (i >> 2);
+            const char* p = lds + k * 256 + ((g ^ swz_k(k)) << 5) + ((i & 3) << 3);
+            short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
+            bf16x4 tb = __builtin_bit_cast(bf16x4, t);
+            v[h * 4 + 0] = tb[0]; v[h * 4 + 1] = tb[1]; v[h * 4 + 2] = tb[2]; v[h * 4 + 3] = tb[3];
+        }
+        return v;
+    }
+}
+
+template <bool A_KC, bool B_KC, typename OutT>
+__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                             OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, int64_t k_per_split,
+                                                             EpiParams ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // G2_ST x (8 KB A + 8 KB B)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t tiles_n = (N + GB_N - 1) / GB_N, tiles_m = (M + GB_M - 1) / GB_M;
+    int64_t tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    if (tm >= tiles_m) return;
+    const int64_t m0 = tm * GB_M, n0 = tn * GB_N;
+    const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
+    const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+    if (kbeg >= kend) return;
+    const int nk = (int)((kend - kbeg) / G2_BK);
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint32_t offA[2], offB[2];
+    glds_offsets<A_KC>(lda, m0, M, wave, lane, offA);
+    glds_offsets<B_KC>(ldb, n0, N, wave, lane, offB);
+    // wave-uniform running base pointers (bytes); one K step = 32 elements (K-contig) or 32 rows of ld (MN-contig)
+    const char* gA = (const char*)A + (A_KC ? kbeg : kbeg * lda) * 2;
+    const char* gB = (const char*)B + (B_KC ? kbeg : kbeg * ldb) * 2;
+    const int64_t stepA = (A_KC ? (int64_t)G2_BK : (int64_t)G2_BK * lda) * 2;
+    const int64_t stepB = (B_KC ? (int64_t)G2_BK : (int64_t)G2_BK * ldb) * 2;
+#pragma unroll
+    for (int s = 0; s < G2_ST - 1; ++s) {
+        if (s < nk) {
+            glds_issue2(gA, offA, smem + s * G2_STAGE, wave);
+            glds_issue2(gB, offB, smem + s * G2_STAGE + 8192, wave);
+            gA += stepA;
+            gB += stepB;
+        }
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        const int newer = (nk - 1 - kt) < (G2_ST - 2) ? (nk - 1 - kt) : (G2_ST - 2);
+        if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int nxt = kt + G2_ST - 1;
+        if (nxt < nk) {
+            char* st = smem + (nxt % G2_ST) * G2_STAGE;
+            glds_issue2(gA, offA, st, wave);
+            glds_issue2(gB, offB, st + 8192, wave);
+            gA += stepA;
+            gB += stepB;
+        }
+        const char* la = smem + (kt % G2_ST) * G2_STAGE;
+        const char* lb = la + 8192;
+        bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = lfrag2<A_KC>(la, wm * 64 + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = lfrag2<B_KC>(lb, wn * 64 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
+            int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (m < M && n < N) epi_store4<OutT>(ep, C, m, n, acc[i][j], N);
+        }
+}
+
+// ================================================================================================
+// bf16 MFMA kernel, v3: 256x256x64 block tile, 8 waves (2x4, wave tile 128x64 = 8x4 MFMA tiles), LDS-DMA
+// double buffer (2 x 64 KB).  PMC on v1/v2 showed the 128^2 tile is bound by the CU's vector-memory front
+// end (TA busy 61 % at only 12 B/clk/CU: half-line 64-B row pieces, 1 B of tile traffic per 64 FLOP); the
+// 256^2 tile halves the tile bytes per FLOP and fetches full 128-B lines (BK=64), and one K step carries
+// 64 MFMAs per wave (1024 MFMA cycles), enough to cover the L2 round trip of the next stage with a plain
+// double buffer: wait vmcnt(0) -> barrier -> issue stage k+1 -> compute stage k.
+constexpr int G3_M = 256, G3_N = 256, G3_K = 64, G3_OP = 32768;   // bytes per operand per stage
+
+template <bool KC>
+__device__ __forceinline__ void g3_offsets(int64_t ld, int64_t row0, int64_t nrows, int wave, int lane, uint32_t (&off)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = wave * 4 + i;   // wave-instruction 0..31 (1 KiB each)
+        if constexpr (KC) {
+            const int row = j * 8 + (lane >> 3), pc = lane & 7;
+            const int c = pc ^ (row & 7);
+            int64_t gr = row0 + row;
+            if (gr > nrows - 1) gr = nrows - 1;
+            off[i] = (uint32_t)((gr * ld + c * 8) * 2);
+        } else {
+            const int k = j * 2 + (lane >> 5), p16 = lane & 31;
+            const int g = (p16 >> 1) ^ swz_k(k);
+            int64_t gr = row0 + (g * 2 + (p16 & 1)) * 8;
+            if (gr > nrows - 1) gr = ((nrows - 1) >> 3) << 3;
+            off[i] = (uint32_t)(((int64_t)k * ld + gr) * 2);
+        }
+    }
+}
+__device__ __forceinline__ void g3_issue(const char* __restrict__ base, const uint32_t (&off)[4], char* stage_op, int wave) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[i]),
+                                         (__attribute__((address_space(3))) void*)(stage_op + (wave * 4 + i) * 1024), 16, 0, 0);
+}
+template <bool KC>
+__device__ __forceinline__ bf16x8 g3_frag(const char* lds, int rbase, int ks, int lane) {
+    if constexpr (KC) {
+        const int row = rbase + (lane & 15), ch = ks * 4 + (lane >> 4);
+        return *(const bf16x8*)(lds + row * 128 + ((ch ^ (row & 7)) << 4));
+    } else {
+        const int i = lane & 15, g = rbase >> 4;
+        bf16x8 v;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = ks * 32 + (lane >> 4) * 8 + h * 4 + (i >> 2);
+            const char* p = lds + k * 512 + ((g ^ swz_k(k)) << 5) + ((i & 3) << 3);
+            short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
+            bf16x4 tb = __builtin_bit_cast(bf16x4, t);
+            v[h * 4 + 0] = tb[0]; v[h * 4 + 1] = tb[1]; v[h * 4 + 2] = tb[2]; v[h * 4 + 3] = tb[3];
+        }
+        return v;
+    }
+}
+
+template <bool A_KC, bool B_KC, typename OutT>
+__global__ __launch_bounds__(512) void gemm_bf16_g3_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                           OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, int64_t k_per_split, EpiParams ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (32 KB A + 32 KB B)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t tiles_n = (N + G3_N - 1) / G3_N, tiles_m = (M + G3_M - 1) / G3_M;
+    int64_t tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    if (tm >= tiles_m) return;
+    const int64_t m0 = tm * G3_M, n0 = tn * G3_N;
+    const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
+    const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+    if (kbeg >= kend) return;
+    const int nk = (int)((kend - kbeg) / G3_K);
+    const int wm = wave >> 2, wn = wave & 3;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint32_t offA[4], offB[4];
+    g3_offsets<A_KC>(lda, m0, M, wave, lane, offA);
+    g3_offsets<B_KC>(ldb, n0, N, wave, lane, offB);
+    const char* gA = (const char*)A + (A_KC ? kbeg : kbeg * lda) * 2;
+    const char* gB = (const char*)B + (B_KC ? kbeg : kbeg * ldb) * 2;
+    const int64_t stepA = (A_KC ? (int64_t)G3_K : (int64_t)G3_K * lda) * 2;
+    const int64_t stepB = (B_KC ? (int64_t)G3_K : (int64_t)G3_K * ldb) * 2;
+    g3_issue(gA, offA, smem, wave);
+    g3_issue(gB, offB, smem + G3_OP, wave);
+    gA += stepA;
+    gB += stepB;
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) {
+            char* st = smem + ((kt + 1) & 1) * 2 * G3_OP;
+            g3_issue(gA, offA, st, wave);
+            g3_issue(gB, offB, st + G3_OP, wave);
+            gA += stepA;
+            gB += stepB;
+        }
+        const char* la = smem + (kt & 1) * 2 * G3_OP;
+        const char* lb = la + G3_OP;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[8], fb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = g3_frag<B_KC>(lb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = g3_frag<A_KC>(la, wm * 128 + i * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 8; ++i)
+#pragma clang loop unroll(full)
+        for (int j = 0; j < 4; ++j) {
+            int64_t m = m0 + wm * 128 + i * 16 + (lane & 15);
+            int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (m < M && n < N) epi_store4_call<OutT>(ep, C, m, n, acc[i][j], N);
+        }
+}
+
+template <bool A_KC, bool B_KC, typename OutT>
+static void launch_g3(dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int64_t M, int64_t N,
+                      int64_t K, int64_t kps, const EpiParams& ep) {
+    auto kfn = gemm_bf16_g3_kernel<A_KC, B_KC, OutT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G3_OP);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(512), 4 * G3_OP, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
+}
+template <typename OutT>
+static void dispatch_g3(bool akc, bool bkc, dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C,
+                        int64_t M, int64_t N, int64_t K, int64_t kps, const EpiParams& ep) {
+    if (akc && bkc) launch_g3<true, true, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    else if (akc && !bkc) launch_g3<true, false, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    else if (!akc && bkc) launch_g3<false, true, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    else launch_g3<false, false, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+}
+
+// ================================================================================================
 static bool g_safe_tr = false;
 static bool g_safe_tr_init = false;
 static bool use_safe_tr() {
@@ -351,6 +661,36 @@ static void launch_bf16(dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda,
         attr_set = true;
     }
     hipLaunchKernelGGL(kfn, grid, dim3(256), 65536, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
+}
+
+template <bool A_KC, bool B_KC, typename OutT>
+static void launch_glds(dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int64_t M, int64_t N,
+                        int64_t K, int64_t kps, const EpiParams& ep) {
+    auto kfn = gemm_bf16_glds_kernel<A_KC, B_KC, OutT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G2_ST * G2_STAGE);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(256), G2_ST * G2_STAGE, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
+}
+
+template <typename OutT>
+static void dispatch_glds(bool akc, bool bkc, dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C,
+                          int64_t M, int64_t N, int64_t K, int64_t kps, const EpiParams& ep) {
+    if (akc && bkc) launch_glds<true, true, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    else if (akc && !bkc) launch_glds<true, false, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    else if (!akc && bkc) launch_glds<false, true, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    else launch_glds<false, false, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+}
+
+static int g_gemm_variant = -1;   // EMO_GEMM_VARIANT: 1 = register-staged v1, 2 = LDS-DMA ring (default when eligible)
+static int gemm_variant() {
+    if (g_gemm_variant < 0) {
+        const char* e = getenv("EMO_GEMM_VARIANT");
+        g_gemm_variant = (e && e[0] >= '1' && e[0] <= '3') ? (e[0] - '0') : 2;
+    }
+    return g_gemm_variant;
 }
 
 template <bool SAFE, typename OutT>
@@ -385,7 +725,20 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         has_epi = e->bias || e->act || e->aux_out || ep.mul_mode || ep.drop.thr16 || e->residual;
     }
     const bool big = dtype_in == EMO_BF16;
-    const int64_t BMt = big ? GB_M : 64, BNt = big ? GB_N : 64, BKt = big ? GB_K : 16;
+    const int variant = big ? gemm_variant() : 0;
+    // v3 (256^2 tile) when the problem fills the chip with 256^2 tiles and N does not waste a tile
+    bool use_g3 = false;
+    if (big && variant >= 2 && !use_safe_tr() && (K % G3_K) == 0 && M >= 256) {
+        const int64_t t3 = cdiv64(M, G3_M) * cdiv64(N, G3_N);
+        const bool n_ok = (N % G3_N) == 0 || N >= 4 * G3_N;
+        const bool enough = t3 >= 512 || (dtype_out == EMO_F32 && !has_epi && K >= 64 * G3_K);   // split-K refills the grid
+        // measured r01: with 1 block/CU the exposed prologue/epilogue makes the 256^2 kernel SLOWER than the 128^2 ones at
+        // K=512 (293 vs 505 TFLOP/s) and no faster at K=2048 -> kept for experiments only (EMO_GEMM_FORCE_G3=1)
+        use_g3 = n_ok && enough && false;
+    }
+    if (big && variant >= 2 && !use_safe_tr() && (K % G3_K) == 0 && M >= 8 && N >= 8 && getenv("EMO_GEMM_FORCE_G3") != nullptr) use_g3 = true;
+    const int64_t BMt = big ? (use_g3 ? G3_M : GB_M) : 64, BNt = big ? (use_g3 ? G3_N : GB_N) : 64;
+    const int64_t BKt = big ? (use_g3 ? G3_K : (variant >= 2 ? G2_BK : GB_K)) : 16;
     const int64_t tiles_m = cdiv64(M, BMt), tiles_n = cdiv64(N, BNt);
     const int64_t tiles_m8 = cdiv64(tiles_m, 8) * 8;
     // split-K: only for plain fp32 outputs (wgrad) when the tile grid cannot fill the chip
@@ -421,7 +774,20 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         const bf16_t* b = (const bf16_t*)B;
         const bool akc = !a_trans, bkc = !b_trans;
         const bool safe = use_safe_tr();
-        if (dtype_out == EMO_F32) {
+        const int64_t rowsA = a_trans ? (use_g3 ? G3_K : G2_BK) : M, rowsB = b_trans ? (use_g3 ? G3_K : G2_BK) : N;
+        const int64_t spanA = (rowsA * lda + (a_trans ? M : 0)) * 2, spanB = (rowsB * ldb + (b_trans ? N : 0)) * 2;
+        const bool span_ok = spanA < (int64_t)0xFFFF0000 && spanB < (int64_t)0xFFFF0000;
+        const bool glds_ok = !safe && variant >= 2 && (akc && bkc || variant >= 3) && (K % G2_BK) == 0 && (kps % G2_BK) == 0 && M >= 8 && N >= 8 && span_ok;
+        if (use_g3 && span_ok && (kps % G3_K) == 0) {
+            if (dtype_out == EMO_F32) dispatch_g3<float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
+            else dispatch_g3<bf16_t>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
+        } else if (use_g3) {
+            emo_set_error("emo_gemm: internal tile-selection error");
+            return EMO_ERR_INVALID;
+        } else if (glds_ok) {
+            if (dtype_out == EMO_F32) dispatch_glds<float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
+            else dispatch_glds<bf16_t>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
+        } else if (dtype_out == EMO_F32) {   // register-staged v1 (same 128^2 grid; any K, predicated edges)
             if (safe) dispatch_bf16<true, float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
             else dispatch_bf16<false, float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
         } else {
@@ -434,23 +800,56 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// column sums (bias gradients): grid (col blocks of 256 cols? no: 64 cols) x row splits, atomics.
+// column sums (bias gradients): HBM-bound stream.  A thread owns 16 B of columns (8 bf16 / 4 f32), a wave a
+// 1-KiB row segment, the block's 4 waves take interleaved rows (4 rows in flight per thread); partials are
+// combined in LDS and flushed with one atomic per column per block.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int64_t M, int64_t N, int64_t ld,
                                                      float* __restrict__ out, int64_t rows_per_block) {
-    // block: 64 columns x 4 row-lanes ; thread (c = tid&63, r = tid>>6)
-    __shared__ float part[4][64];
-    const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
-    const int64_t n = (int64_t)blockIdx.x * 64 + c;
+    constexpr int VE = 16 / sizeof(T);
+    __shared__ float part[4][64 * VE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c0 = (int64_t)blockIdx.x * 64 * VE + lane * VE;
     const int64_t mbeg = (int64_t)blockIdx.y * rows_per_block;
     int64_t mend = mbeg + rows_per_block;
     if (mend > M) mend = M;
-    float s = 0.f;
-    if (n < N)
-        for (int64_t m = mbeg + r; m < mend; m += 4) s += to_f32<T>(X[m * ld + n]);
-    part[r][c] = s;
+    float s[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) s[e] = 0.f;
+    if (c0 + VE <= N && (ld % VE) == 0 && (((uintptr_t)X) & 15) == 0) {
+        int64_t m = mbeg + wave;
+        for (; m + 12 < mend; m += 16) {
+            T v[4][VE];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (sizeof(T) == 2) *(bf16x8*)v[u] = *(const bf16x8*)(X + (m + 4 * u) * ld + c0);
+                else *(f32x4*)v[u] = *(const f32x4*)(X + (m + 4 * u) * ld + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < VE; ++e) s[e] += to_f32<T>(v[u][e]);
+        }
+        for (; m < mend; m += 4) {
+            T v[VE];
+            if constexpr (sizeof(T) == 2) *(bf16x8*)v = *(const bf16x8*)(X + m * ld + c0);
+            else *(f32x4*)v = *(const f32x4*)(X + m * ld + c0);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) s[e] += to_f32<T>(v[e]);
+        }
+    } else {
+        for (int64_t m = mbeg + wave; m < mend; m += 4)
+#pragma unroll
+            for (int e = 0; e < VE; ++e)
+                if (c0 + e < N) s[e] += to_f32<T>(X[m * ld + c0 + e]);
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) part[wave][lane * VE + e] = s[e];
     __syncthreads();
-    if (r == 0 && n < N) atomicAdd(out + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
+    for (int c = threadIdx.x; c < 64 * VE; c += 256) {
+        const int64_t n = (int64_t)blockIdx.x * 64 * VE + c;
+        if (n < N) atomicAdd(out + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
+    }
 }
 
 extern "C" int emo_colsum(const void* X, int dtype, int64_t M, int64_t N, int64_t ld, float* out, int accumulate,
@@ -461,7 +860,7 @@ extern "C" int emo_colsum(const void* X, int dtype, int64_t M, int64_t N, int64_
         hipError_t me = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), st);
         EMO_CHECK(me == hipSuccess, "emo_colsum: memset failed");
     }
-    const int64_t cb = cdiv64(N, 64);
+    const int64_t cb = cdiv64(N, dtype == EMO_F32 ? 256 : 512);
     int64_t rsplit = cdiv64(2048, cb);
     if (rsplit > cdiv64(M, 64)) rsplit = cdiv64(M, 64);
     if (rsplit < 1) rsplit = 1;

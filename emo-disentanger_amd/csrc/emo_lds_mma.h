@@ -43,11 +43,11 @@ __device__ __forceinline__ void mm16(f32x4& acc, const CT* R, int ldr, int rrow0
 template <int A, int B> struct CMax { static constexpr int v = A > B ? A : B; };
 
 // ---- global row tile [rows x NC] -> LDS image [rows][ld] (zero-fill invalid rows and pad columns up to NCP)
-template <typename CT, int NC, int NCP>
+template <typename CT, int NC, int NCP, int NTHR = 256>
 __device__ __forceinline__ void load_rows(CT* img, int ld, const CT* __restrict__ src, int64_t ld_src, int rows, int valid_rows, int tid) {
     constexpr int VE = 16 / sizeof(CT);  // elements per 16-B vector
     constexpr int CH = NCP / VE;
-    for (int it = tid; it < rows * CH; it += 256) {
+    for (int it = tid; it < rows * CH; it += NTHR) {
         const int r = it / CH, c = (it % CH) * VE;
         CT tmp[VE];
 #pragma unroll
@@ -61,12 +61,12 @@ __device__ __forceinline__ void load_rows(CT* img, int ld, const CT* __restrict_
     }
 }
 // ---- global row tile [rows x NC] -> transposed LDS image [NC][ld] (k = row index contiguous); rows even
-template <typename CT, int NC>
+template <typename CT, int NC, int NTHR = 256>
 __device__ __forceinline__ void load_rows_T(CT* img, int ld, const CT* __restrict__ src, int64_t ld_src, int rows, int valid_rows, int tid) {
     constexpr int VE = 16 / sizeof(CT);
     constexpr int CH = NC / VE;
     const int pairs = rows >> 1;
-    for (int it = tid; it < pairs * CH; it += 256) {
+    for (int it = tid; it < pairs * CH; it += NTHR) {
         const int p = it % pairs, c = (it / pairs) * VE;
         CT a[VE], b[VE];
 #pragma unroll

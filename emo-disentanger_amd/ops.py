@@ -12,7 +12,7 @@ from ._lib import (ACT_GELU_NEW, ACT_NONE, ACT_RELU, BF16, F32, MUL_DGELU_NEW, M
                    dtype_code, lib, ptr, stream)
 
 __all__ = ['gemm', 'colsum', 'embed_fwd', 'embed_bwd', 'layernorm_fwd', 'layernorm_bwd', 'dropout_apply', 'favor_attn_fwd',
-           'favor_attn_bwd', 'favor_decode_step', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'xent_fwd',
+           'favor_attn_bwd', 'favor_decode_step', 'favor_draw_omega', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'xent_fwd',
            'xent_bwd', 'argmax', 'sample_nucleus', 'accuracy_counts', 'sumsq', 'clip_coef', 'adam_step', 'cast',
            'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW']
 
@@ -144,6 +144,14 @@ def favor_decode_step(q, k, v, omega, state_S, state_z, H, eps=1e-6):
     check(lib.emo_favor_decode_step(ptr(q), ptr(k), ptr(v), _rows(q), ptr(omega), ptr(state_S), ptr(state_z), ptr(out), HD,
                                     dtype_code(q.dtype), n, H, dh, 2 * omega.shape[1], eps, stream()))
     return out
+
+
+def favor_draw_omega(gauss, omega):
+    """gauss [L, nb, dh, dh] ~ N(0,1) -> omega [L, dh, n_feat/2] (orthogonal blocks scaled by row norms)."""
+    L, nb, dh, _ = gauss.shape
+    assert gauss.is_contiguous() and omega.is_contiguous() and omega.shape[:2] == (L, dh)
+    check(lib.emo_favor_draw_omega(ptr(gauss), ptr(omega), L, dh, 2 * omega.shape[2], stream()))
+    return omega
 
 
 def softmax_attn_fwd(q, k, v, B, T, H, p_drop=0.0, seed=0, offset=0):

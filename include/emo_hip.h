@@ -118,6 +118,12 @@ int emo_favor_decode_step(const void* q, const void* k, const void* v, int64_t l
                           int64_t n_streams, int64_t H, int64_t dh, int64_t n_feat, float eps,
                           emo_stream_t stream);
 
+/* FAVOR+ omega draw (fast-transformers orthogonal_random_matrix_, called from new_feature_map() on every
+ * forward — SURVEY F8): gauss [n_layers, ceil((n_feat/2)/dh), dh, dh] ~ N(0,1) from the caller's RNG ->
+ * omega [n_layers, dh, n_feat/2] with orthogonal columns per block scaled by the row norms of the block. */
+int emo_favor_draw_omega(const float* gauss, float* omega, int64_t n_layers, int64_t dh, int64_t n_feat,
+                         emo_stream_t stream);
+
 /* ------------------------------------------------------------------ K5: causal softmax attention (GPT-2)
  * Replaces HF GPT2Attention._attn (model/music_gpt2.py:86): softmax(q k^T/sqrt(dh) + causal) [dropout] v.
  * lse [B,H,T] fp32 saved for backward.  Dropout index = ((b*H+h)*T + i)*T + j. */

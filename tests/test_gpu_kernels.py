@@ -344,3 +344,43 @@ def test_adam_and_clip_match_torch():
         ops.adam_step(pc, gi.cuda(), m, v, pb, 1e-3, 0.9, 0.999, 1e-8, step, coef)
         _close(pc, p.detach(), torch.float32, mult=2)
     _close(pb, p.detach(), torch.bfloat16)
+
+
+def test_favor_omega_draw_is_orthogonal_with_row_norm_scaling():
+    ops = _ops()
+    for L, dh, nf in ((3, 64, 128), (2, 32, 128), (2, 16, 32)):
+        cols = nf // 2
+        nb = (cols + dh - 1) // dh
+        g = torch.Generator().manual_seed(L)
+        gauss = torch.randn(L, nb, dh, dh, generator=g)
+        om = ops.favor_draw_omega(gauss.cuda(), torch.empty(L, dh, cols, device='cuda')).cpu().double()
+        for l in range(L):
+            for b in range(nb):
+                G = gauss[l, b].double()
+                blk = om[l][:, b * dh:(b + 1) * dh]
+                w = blk.shape[1]
+                norms = G.pow(2).sum(1).sqrt()[:w]
+                gram = blk.T @ blk
+                assert (gram - torch.diag(norms ** 2)).abs().max() < 1e-3 * float(norms.max() ** 2)   # orthogonal, |col j| = |row j of G|
+                qref, _ = torch.linalg.qr(G)                                                       # same columns up to sign
+                cosines = ((blk / norms) * qref[:, :w]).sum(0).abs()
+                assert (cosines - 1).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize('a_trans,b_trans', [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_256_tile_kernel_all_layouts(a_trans, b_trans):
+    """Shapes large enough for the 256x256x64 LDS-DMA kernel (incl. ragged M/N edges and split-K wgrad)."""
+    ops = _ops()
+    dt = torch.bfloat16
+    for (M, N, K) in ((32768 + 40, 1024, 128), (512, 768, 8192)):
+        A = _r(*((K, M) if a_trans else (M, K)), seed=1, dt=dt)
+        Bm = _r(*((K, N) if b_trans else (N, K)), seed=2, dt=dt)
+        ref = (A.double().T if a_trans else A.double()) @ (Bm.double() if b_trans else Bm.double().T)
+        out = ops.gemm(A.cuda(), Bm.cuda(), a_trans=bool(a_trans), b_trans=bool(b_trans), out_dtype=torch.float32)
+        _close(out, ref, dt, mult=0.3)
+    # fused epilogue through the same kernel
+    M, N, K = 32768, 1024, 128
+    A, W = _r(M, K, seed=3, dt=dt), _r(N, K, seed=4, dt=dt, scale=0.2)
+    bias, res = _r(N, seed=5), _r(M, N, seed=6, dt=dt)
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), act=ops.ACT_RELU, residual=res.cuda())
+    _close(out, torch.relu(A.double() @ W.double().T + bias.double()) + res.double(), dt)
