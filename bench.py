@@ -45,28 +45,80 @@ def time_kernel(fn, iters=10, warm=3):
 
 
 def dominant_kernel_roofline(B, T):
-    """The forward/dgrad GEMMs all run the same kernel template (gemm_bf16_kernel, K-contiguous A); time
-    the per-layer launch mix of the NT instance [QKV, out-proj, FFN1, FFN2] and report FLOP/s over the mix."""
+    """Dominant kernel by total time (rocprofv3, profiles/): the wgrad instance gemm_bf16_kernel<A_KC=0,B_KC=0,fp32 out>
+    (dW = dY^T X, reduction over the B*T tokens, both operands read through ds_read_b64_tr_b16, split-K fp32 atomics).
+    Time its per-layer launch mix [QKV, out-proj, FFN1, FFN2] with HIP events on the launch stream; algorithmic
+    FLOPs per launch = 2*M*N*K.  The forward (LDS-DMA ring) and dgrad instances are reported alongside."""
     from emo_disentanger_amd import ops
     M, d, f = B * T, CFG['d_model'], CFG['d_ff']
     dev = 'cuda'
-    shapes = [(M, 3 * d, d), (M, d, d), (M, f, d), (M, d, f)]
-    tot_ms, tot_flop, per = 0.0, 0.0, []
-    for (m, n, k) in shapes:
-        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+    shapes = [('qkv', 3 * d, d), ('out', d, d), ('ffn1', f, d), ('ffn2', d, f)]
+    agg = {'wgrad': [0.0, 0.0], 'fwd': [0.0, 0.0], 'dgrad': [0.0, 0.0]}
+    per = []
+    for name, n, k in shapes:
+        x = torch.randn(M, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * 0.02).to(torch.bfloat16)
-        out = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
-        ms = time_kernel(lambda: ops.gemm(a, w, out=out))
-        fl = 2.0 * m * n * k
-        per.append({'M': m, 'N': n, 'K': k, 'ms': round(ms, 4), 'tflops': round(fl / ms / 1e9, 1)})
-        tot_ms += ms
-        tot_flop += fl
-        del a, w, out
-    achieved = tot_flop / tot_ms / 1e9
+        dy = torch.randn(M, n, device=dev).to(torch.bfloat16)
+        y = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
+        dx = torch.empty(M, k, device=dev, dtype=torch.bfloat16)
+        dw = torch.zeros(n, k, device=dev)
+        fl = 2.0 * M * n * k
+        t_w = time_kernel(lambda: ops.gemm(dy, x, a_trans=True, b_trans=True, out=dw, accumulate=True))
+        t_f = time_kernel(lambda: ops.gemm(x, w, out=y))
+        t_d = time_kernel(lambda: ops.gemm(dy, w, b_trans=True, out=dx))
+        for key, t in (('wgrad', t_w), ('fwd', t_f), ('dgrad', t_d)):
+            agg[key][0] += t
+            agg[key][1] += fl
+        per.append({'gemm': name, 'M': M, 'N': n, 'K': k, 'wgrad_ms': round(t_w, 4), 'fwd_ms': round(t_f, 4), 'dgrad_ms': round(t_d, 4),
+                    'wgrad_tflops': round(fl / t_w / 1e9, 1), 'fwd_tflops': round(fl / t_f / 1e9, 1), 'dgrad_tflops': round(fl / t_d / 1e9, 1)})
+        del x, w, dy, y, dx, dw
+    achieved = agg['wgrad'][1] / agg['wgrad'][0] / 1e9
     return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
-            'kernel': 'gemm_bf16_kernel<A_KC=1,B_KC=1> (fwd Linear GEMMs: QKV, out-proj, FFN1, FFN2)',
-            'avg_launch_ms': round(tot_ms / len(shapes), 4), 'per_shape': per}
+            'kernel': 'gemm_bf16_kernel<false,false,false,float> (wgrad dW = dY^T X over B*T tokens; per-layer mix QKV/out/FFN1/FFN2)',
+            'avg_launch_ms': round(agg['wgrad'][0] / len(shapes), 4),
+            'other_instances_tflops': {'fwd_lds_dma_ring': round(agg['fwd'][1] / agg['fwd'][0] / 1e9, 1),
+                                       'dgrad': round(agg['dgrad'][1] / agg['dgrad'][0] / 1e9, 1)},
+            'per_shape': per}
+
+
+def generation_bench(model, n_streams=32, prompt=64, n_new=256, top_p=0.9, temp=1.1):
+    """BASELINE configs[3] (bounded): 32 parallel streams, nucleus p=0.9, recurrent FAVOR+ state in HBM, hipGraph-replayed
+    decode step; tokens/s = streams * new tokens / wall time (prefill of the 64-token prompt included)."""
+    from emo_disentanger_amd import inference as inf
+    dev = next(model.parameters()).device
+    g = torch.Generator().manual_seed(7)
+    ptok = torch.randint(0, CFG['n_token'] - 1, (n_streams, prompt), generator=g).to(dev)
+    pseg = torch.ones(n_streams, prompt, dtype=torch.long, device=dev)
+    model.eval()
+    inf.generate_streams(model, ptok, pseg, 8, temp=temp, top_p=top_p, seed=1)          # warm-up (kernels, graph machinery)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = inf.generate_streams(model, ptok, pseg, n_new, temp=temp, top_p=top_p, seed=2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    model.train()
+    assert out.shape == (n_streams, prompt + n_new) and int(out.max()) < CFG['n_token']
+    return {'metric': 'AR gen tokens/sec, stage2 Performer d512 L12, %d streams, nucleus p=%.2f' % (n_streams, top_p),
+            'value': round(n_streams * n_new / dt, 1), 'unit': 'tokens/s', 'streams': n_streams, 'prompt': prompt, 'new_tokens': n_new,
+            'ms_per_token_step': round(1000 * dt / n_new, 3), 'engine': 'FAVOR+ recurrent state in HBM + hipGraph replay of the decode step'}
+
+
+def cpu_generation_baseline(ctx=256, n_tok=4):
+    """Reference-style AR step on the CPU oracle: full-prefix recompute per token (inference.py:252-272), 1 stream."""
+    from oracle import model_ref
+    from oracle.weights import make_state_dict
+    sd = make_state_dict('performer', CFG['n_token'], CFG['n_layer'], CFG['n_head'], CFG['d_model'], CFG['d_ff'], favor_feature_dims=CFG['n_feat'], seed=0)
+    x = torch.randint(0, CFG['n_token'] - 1, (1, ctx))
+    seg = torch.ones(1, ctx, dtype=torch.long)
+    with torch.no_grad():
+        model_ref.forward('performer', sd, x, seg, CFG['n_layer'], CFG['n_head'], CFG['d_model'], keep_last_only=True)
+        t0 = time.time()
+        for _ in range(n_tok):
+            model_ref.forward('performer', sd, x, seg, CFG['n_layer'], CFG['n_head'], CFG['d_model'], keep_last_only=True)
+        dt = (time.time() - t0) / n_tok
+    return {'value': round(1.0 / dt, 2), 'unit': 'tokens/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'oracle full-prefix recompute at context %d, 1 stream, %d tokens' % (ctx, n_tok)}
 
 
 def cpu_baseline(T, steps=2):
@@ -96,6 +148,7 @@ def main():
     ap.add_argument('--redraw', default='every_forward')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-gen', action='store_true')
     args = ap.parse_args()
 
     from emo_disentanger_amd import dp, ops
@@ -154,7 +207,7 @@ def main():
     mean_loss = float(loss_acc) / max(args.steps, 1)
     tokens = world * B * T * args.steps
     value = tokens / elapsed
-    out = {'metric': 'train tokens/sec, stage2 Performer d512 L12 seq%d' % T, 'value': round(value, 1), 'unit': 'tokens/s', 'n_gpus': world,
+    out = {'metric': 'train tokens/sec (+ AR gen tokens/sec in "gen"), stage2 Performer d512 L12 seq%d' % T, 'value': round(value, 1), 'unit': 'tokens/s', 'n_gpus': world,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * elapsed / args.steps, 3), 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
            'config': {'workload': 'BASELINE configs[%d]: stage2 Performer d_model=512 n_layer=12 n_head=8 favor_dims=128 seq=%d, B=%d/GPU, '
@@ -162,7 +215,15 @@ def main():
                       'global_batch': world * B, 'seq_len': T, 'parallelism': 'dp%d' % world, 'n_token': CFG['n_token']},
            'mean_loss': round(mean_loss, 4), 'gemm_tflops_model': round(value * gemm_flops_per_token() / 1e12, 1)}
     if rank == 0:
+        if world == 1 and not args.no_gen:
+            del batches
+            out['gen'] = generation_bench(model)
+            if not args.no_cpu_baseline:
+                out['gen']['cpu_baseline'] = cpu_generation_baseline()
         if not args.no_roofline:
+            del opt
+            model._store = None
+            torch.cuda.empty_cache()
             out['roofline'] = dominant_kernel_roofline(B, T)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(min(T, 2048))

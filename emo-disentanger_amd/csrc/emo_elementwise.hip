@@ -38,15 +38,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ seg,
                                                         const float* __restrict__ E, const float* __restrict__ S,
                                                         const float* __restrict__ pe, T* __restrict__ out, int64_t M, int64_t T_len,
-                                                        int64_t D, int64_t pos0, float scale, DropCtx drop) {
+                                                        int64_t D, int64_t pos0, const int64_t* __restrict__ pos_ids, float scale, DropCtx drop) {
     const int64_t d4 = D >> 2, total = M * d4;
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = it / d4, c = (it - row * d4) << 2;
         const int64_t t = row % T_len;
+        const int64_t pbase = pos_ids ? pos_ids[row / T_len] : pos0;
         float e[4], s[4] = {0, 0, 0, 0}, p[4], o[4];
         Vec4<float>::load(E + tok[row] * D + c, e);
         if (seg) Vec4<float>::load(S + seg[row] * D + c, s);
-        Vec4<float>::load(pe + (pos0 + t) * D + c, p);
+        Vec4<float>::load(pe + (pbase + t) * D + c, p);
         float dm[4];
         drop_mult4(drop, (uint64_t)(row * D + c), dm);
 #pragma unroll
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 
 extern "C" int emo_embed_fwd(const int64_t* tok, const int64_t* seg, const float* E, const float* S, const float* pe,
                              void* out, int dtype, int64_t B, int64_t T, int64_t D, int64_t V, int64_t n_seg, int64_t pos0,
-                             float scale, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
+                             const int64_t* pos_ids, float scale, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
     (void)V; (void)n_seg;
     EMO_CHECK(tok && E && pe && out, "emo_embed_fwd: null pointer");
     EMO_CHECK((D & 3) == 0, "emo_embed_fwd: D must be a multiple of 4");
@@ -73,8 +74,8 @@ extern "C" int emo_embed_fwd(const int64_t* tok, const int64_t* seg, const float
     if (blocks > 4096) blocks = 4096;
     DropCtx drop = make_drop(p_drop, seed, offset);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == EMO_F32) hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, tok, seg, E, S, pe, (float*)out, M, T, D, pos0, scale, drop);
-    else hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, tok, seg, E, S, pe, (bf16_t*)out, M, T, D, pos0, scale, drop);
+    if (dtype == EMO_F32) hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, tok, seg, E, S, pe, (float*)out, M, T, D, pos0, pos_ids, scale, drop);
+    else hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, tok, seg, E, S, pe, (bf16_t*)out, M, T, D, pos0, pos_ids, scale, drop);
     EMO_LAUNCH_CHECK();
     return EMO_OK;
 }

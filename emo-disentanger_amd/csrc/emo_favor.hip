@@ -179,10 +179,16 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
         // den[t] = rowsum(A[t]) + Qf[t].z_prev + eps
         {
             constexpr int TPR = FT / C;
+            constexpr int VE = 16 / sizeof(CT);
             const int r = tid / TPR, part = tid % TPR;
             float s = 0.f;
-            for (int j = part; j < C; j += TPR) s += to_f32<CT>(Am[r * LDC + j]);
-            for (int f = part; f < F; f += TPR) s += to_f32<CT>(Qf[r * LDF + f]) * zz[f];
+            if constexpr ((C / TPR) % VE == 0 && (F / TPR) % VE == 0 && sizeof(CT) == 2) {
+                s = sum_contig<CT, C / TPR>(Am + r * LDC + part * (C / TPR)) +
+                    dot_contig<CT, F / TPR>(Qf + r * LDF + part * (F / TPR), zz + part * (F / TPR));
+            } else {
+                for (int j = part; j < C; j += TPR) s += to_f32<CT>(Am[r * LDC + j]);
+                for (int f = part; f < F; f += TPR) s += to_f32<CT>(Qf[r * LDF + f]) * zz[f];
+            }
 #pragma unroll
             for (int o = TPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
             if (part == 0) {
@@ -218,10 +224,20 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
                 Img<CT>::store4(ST + d * LDF + f0, sacc[i][0], sacc[i][1], sacc[i][2], sacc[i][3]);
             }
         }
-        for (int f = tid; f < F; f += FT) {
-            float s = 0.f;
-            for (int j = 0; j < C; ++j) s += to_f32<CT>(KfT[f * LDC + j]);
-            zz[f] += s;
+        if constexpr (sizeof(CT) == 2 && C == 64 && 4 * F <= FT) {
+            const int f = tid >> 2, part = tid & 3;
+            if (f < F) {
+                float s = sum_contig<CT, 16>(KfT + f * LDC + part * 16);
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                if (part == 0) zz[f] += s;
+            }
+        } else {
+            for (int f = tid; f < F; f += FT) {
+                float s = 0.f;
+                for (int j = 0; j < C; ++j) s += to_f32<CT>(KfT[f * LDC + j]);
+                zz[f] += s;
+            }
         }
     }
     __syncthreads();
@@ -438,10 +454,20 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
                 Img<CT>::store4(SF + f * LDX + d0, sacc[i][0], sacc[i][1], sacc[i][2], sacc[i][3]);
             }
         }
-        for (int f = tid; f < F; f += FT) {
-            float s = 0.f;
-            for (int j = 0; j < C; ++j) s += to_f32<CT>(KfT[f * LDC + j]);
-            zz[f] += s;
+        if constexpr (sizeof(CT) == 2 && C == 64 && 4 * F <= FT) {
+            const int f = tid >> 2, part = tid & 3;
+            if (f < F) {
+                float s = sum_contig<CT, 16>(KfT + f * LDC + part * 16);
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                if (part == 0) zz[f] += s;
+            }
+        } else {
+            for (int f = tid; f < F; f += FT) {
+                float s = 0.f;
+                for (int j = 0; j < C; ++j) s += to_f32<CT>(KfT[f * LDC + j]);
+                zz[f] += s;
+            }
         }
     }
 }
@@ -604,21 +630,33 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
                 for (int r = 0; r < 4; ++r) RT[(d0 + r) * LDF + f] = from_f32<CT>(racc[i][r]);
             }
         }
-        for (int f = tid; f < F; f += FT) {
-            float s = 0.f;
-            for (int t = 0; t < C; ++t) s += to_f32<CT>(QfT[f * LDC + t]) * dD[t];
-            rr[f] += s;
+        if constexpr (sizeof(CT) == 2 && C == 64 && 4 * F <= FT) {
+            const int f = tid >> 2, part = tid & 3;
+            if (f < F) {
+                float s = dot_contig<CT, 16>(QfT + f * LDC + part * 16, dD + part * 16);
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                if (part == 0) rr[f] += s;
+            }
+        } else {
+            for (int f = tid; f < F; f += FT) {
+                float s = 0.f;
+                for (int t = 0; t < C; ++t) s += to_f32<CT>(QfT[f * LDC + t]) * dD[t];
+                rr[f] += s;
+            }
         }
     }
 }
 
 // =============================================================================================== decode step (recurrent form)
-// One workgroup per (stream, head); thread f (< F) owns row f of the state.
+// One workgroup (256 threads) per (stream, head).  Phase 1: phi(q), phi(k) (thread f < F).  Phase 2: ONE coalesced pass
+// over the fp32 state S [F x dh]: thread (d = tid % dh, g = tid / dh) walks rows f = g, g+G, ... : S[f][d] += phi_k[f] v[d],
+// num[d] += phi_q[f] S[f][d] — the state is read once and written once per token (6.4 MB per stream-step over 12 layers).
 template <typename CT>
-__global__ __launch_bounds__(128) void favor_decode_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+__global__ __launch_bounds__(256) void favor_decode_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
                                                            const float* __restrict__ omega, float* __restrict__ state_S, float* __restrict__ state_z,
                                                            CT* __restrict__ out, int64_t ld_out, int64_t H, int dh, int mf, float eps) {
-    __shared__ float xq[64], xk[64], xv[64], fq[128], num[2][64], dpart[2];
+    __shared__ float xq[64], xk[64], xv[64], fq[128], fk[128], num[16][64], dpart[4];
     const int tid = threadIdx.x, F = 2 * mf;
     const int64_t sh = blockIdx.x, s = sh / H, h = sh % H;
     if (tid < dh) {
@@ -628,7 +666,7 @@ __global__ __launch_bounds__(128) void favor_decode_kernel(const CT* __restrict_
     }
     __syncthreads();
     const float cs = rsqrtf(sqrtf((float)dh)), half_ln_f = 0.5f * logf((float)F);
-    float pq = 0.f, pk = 0.f;
+    float dn = 0.f;
     if (tid < F) {
         const int m = tid % mf;
         const float sgn = tid < mf ? 1.f : -1.f;
@@ -638,26 +676,33 @@ __global__ __launch_bounds__(128) void favor_decode_kernel(const CT* __restrict_
             uq += xq[d] * w; uk += xk[d] * w;
             nq += xq[d] * xq[d]; nk += xk[d] * xk[d];
         }
-        pq = __expf(sgn * cs * uq - (0.5f * cs * cs * nq + half_ln_f));
-        pk = __expf(sgn * cs * uk - (0.5f * cs * cs * nk + half_ln_f));
+        const float pq = __expf(sgn * cs * uq - (0.5f * cs * cs * nq + half_ln_f));
+        const float pk = __expf(sgn * cs * uk - (0.5f * cs * cs * nk + half_ln_f));
         fq[tid] = pq;
-        float* Srow = state_S + (sh * F + tid) * dh;
-        for (int d = 0; d < dh; ++d) Srow[d] += pk * xv[d];
+        fk[tid] = pk;
         const float z = state_z[sh * F + tid] + pk;
         state_z[sh * F + tid] = z;
+        dn = pq * z;
     }
+    dn = wave_sum(dn);
+    if ((tid & 63) == 0) dpart[tid >> 6] = dn;
     __syncthreads();
-    // out[d] = sum_f fq[f] S[f][d] / (sum_f fq[f] z[f] + eps): thread (half = tid/64, d = tid%64)
-    const int d = tid & 63, half = tid >> 6;
-    float acc = 0.f, dn = 0.f;
-    if (d < dh)
-        for (int f = half; f < F; f += 2) acc += fq[f] * state_S[(sh * F + f) * dh + d];
-    if (d == 0)
-        for (int f = half; f < F; f += 2) dn += fq[f] * state_z[sh * F + f];
-    num[half][d] = acc;
-    if (d == 0) dpart[half] = dn;
+    const int G = 256 / dh, d = tid % dh, g = tid / dh;
+    float acc = 0.f;
+    float* Sb = state_S + sh * F * dh;
+    const float vd = xv[d];
+    for (int f = g; f < F; f += G) {
+        const float sv = Sb[f * dh + d] + fk[f] * vd;
+        Sb[f * dh + d] = sv;
+        acc += fq[f] * sv;
+    }
+    num[g][d] = acc;
     __syncthreads();
-    if (tid < dh) out[s * ld_out + h * dh + tid] = from_f32<CT>((num[0][tid] + num[1][tid]) / (dpart[0] + dpart[1] + eps));
+    if (tid < dh) {
+        float a = 0.f;
+        for (int p = 0; p < G; ++p) a += num[p][tid];
+        out[s * ld_out + h * dh + tid] = from_f32<CT>(a / (dpart[0] + dpart[1] + dpart[2] + dpart[3] + eps));
+    }
 }
 
 // =============================================================================================== omega draw
@@ -822,14 +867,14 @@ extern "C" int emo_favor_attn_bwd(const void* q, const void* k, const void* v, i
 extern "C" int emo_favor_decode_step(const void* q, const void* k, const void* v, int64_t ld, const float* omega, float* state_S, float* state_z, void* out,
                                      int64_t ld_out, int dtype, int64_t n_streams, int64_t H, int64_t dh, int64_t n_feat, float eps, emo_stream_t stream) {
     EMO_CHECK(q && k && v && omega && state_S && state_z && out, "emo_favor_decode_step: null pointer");
-    EMO_CHECK(dh <= 64 && n_feat <= 128 && n_feat % 2 == 0, "emo_favor_decode_step: needs d_head<=64, n_feat<=128");
+    EMO_CHECK(dh <= 64 && dh >= 16 && 256 % dh == 0 && n_feat <= 128 && n_feat % 2 == 0, "emo_favor_decode_step: needs 16<=d_head<=64 dividing 256, n_feat<=128");
     dim3 grid((unsigned)(n_streams * H));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == EMO_F32)
-        hipLaunchKernelGGL(favor_decode_kernel<float>, grid, dim3(128), 0, st, (const float*)q, (const float*)k, (const float*)v, ld, omega, state_S, state_z,
+        hipLaunchKernelGGL(favor_decode_kernel<float>, grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, ld, omega, state_S, state_z,
                            (float*)out, ld_out, H, (int)dh, (int)(n_feat / 2), eps);
     else
-        hipLaunchKernelGGL(favor_decode_kernel<bf16_t>, grid, dim3(128), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, omega, state_S,
+        hipLaunchKernelGGL(favor_decode_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, omega, state_S,
                            state_z, (bf16_t*)out, ld_out, H, (int)dh, (int)(n_feat / 2), eps);
     EMO_LAUNCH_CHECK();
     return EMO_OK;

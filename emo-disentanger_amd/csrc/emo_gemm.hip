@@ -30,6 +30,7 @@ struct EpiParams {
     int64_t ldc;
     int accumulate;
     int atomic;
+    int ablate;   // diagnostics only (EMO_GEMM_ABLATE): 1 = skip tile loads, 2 = skip MFMAs
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -365,18 +366,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 // MN-contig [32 k][128 rows] with the 32-B granule swizzle of the v1 kernel.  The DMA writes LDS
 // lane-linearly, so the swizzle is applied to the per-lane SOURCE address and again on the read.
 // Requires K (per split) % 32 == 0; edge rows are clamped to valid addresses (their outputs are dropped).
-constexpr int G2_BK = 32, G2_ST = 4, G2_STAGE = 16384;
+constexpr int G2_BK = 32;   // K granularity the host guarantees for this kernel family
 
-// per-lane BYTE offsets of the two 16-B pieces this lane fetches for one operand tile (constant over the K loop);
+// per-lane BYTE offsets of the 16-B pieces this lane fetches for one operand tile (constant over the K loop);
 // the K position is carried by a wave-uniform base pointer so that a K step costs no per-lane address arithmetic.
-template <bool KC>
-__device__ __forceinline__ void glds_offsets(int64_t ld, int64_t row0, int64_t nrows, int wave, int lane, uint32_t (&off)[2]) {
+template <bool KC, int BK>
+__device__ __forceinline__ void glds_offsets(int64_t ld, int64_t row0, int64_t nrows, int wave, int lane, uint32_t (&off)[BK / 16]) {
+    constexpr int NI = BK / 16;               // wave-instructions per wave per operand tile (1 KiB each)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int j = wave * 2 + i;   // wave-instruction index 0..7 (1 KiB each)
+    for (int i = 0; i < NI; ++i) {
+        const int j = wave * NI + i;
         if constexpr (KC) {
-            const int row = j * 16 + (lane >> 2), pc = lane & 3;
-            const int c = pc ^ ((row >> 2) & 3);
+            int row, c;
+            if constexpr (BK == 32) { row = j * 16 + (lane >> 2); c = (lane & 3) ^ ((row >> 2) & 3); }
+            else { row = j * 8 + (lane >> 3); c = (lane & 7) ^ (row & 7); }
             int64_t gr = row0 + row;
             if (gr > nrows - 1) gr = nrows - 1;
             off[i] = (uint32_t)((gr * ld + c * 8) * 2);
@@ -389,25 +392,31 @@ __device__ __forceinline__ void glds_offsets(int64_t ld, int64_t row0, int64_t n
         }
     }
 }
-__device__ __forceinline__ void glds_issue2(const char* __restrict__ base, const uint32_t (&off)[2], char* stage_op, int wave) {
+template <int NI>
+__device__ __forceinline__ void glds_issue2(const char* __restrict__ base, const uint32_t (&off)[NI], char* stage_op, int wave) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[i]),
-                                         (__attribute__((address_space(3))) void*)(stage_op + (wave * 2 + i) * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(stage_op + (wave * NI + i) * 1024), 16, 0, 0);
 }
 
-template <bool KC>
-__device__ __forceinline__ bf16x8 lfrag2(const char* lds, int rbase, int lane) {
+template <bool KC, int BK>
+__device__ __forceinline__ bf16x8 lfrag2(const char* lds, int rbase, int ks, int lane) {
     if constexpr (KC) {
         const int row = rbase + (lane & 15);
-        const int pc = (lane >> 4) ^ ((row >> 2) & 3);
-        return *(const bf16x8*)(lds + row * 64 + (pc << 4));
+        if constexpr (BK == 32) {
+            const int pc = (lane >> 4) ^ ((row >> 2) & 3);
+            return *(const bf16x8*)(lds + row * 64 + (pc << 4));
+        } else {
+            const int ch = ks * 4 + (lane >> 4);
+            return *(const bf16x8*)(lds + row * 128 + ((ch ^ (row & 7)) << 4));
+        }
     } else {
         const int i = lane & 15, g = rbase >> 4;
         bf16x8 v;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int k = (lane >> 4) * 8 + h * 4 + (i >> 2);
+            const int k = ks * 32 + (lane >> 4) * 8 + h * 4 + (i >> 2);
             const char* p = lds + k * 256 + ((g ^ swz_k(k)) << 5) + ((i & 3) << 3);
             short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
             bf16x4 tb = __builtin_bit_cast(bf16x4, t);
@@ -417,11 +426,19 @@ __device__ __forceinline__ bf16x8 lfrag2(const char* lds, int rbase, int lane) {
     }
 }
 
-template <bool A_KC, bool B_KC, typename OutT>
+template <int N> __device__ __forceinline__ void wait_vmcnt();
+template <> __device__ __forceinline__ void wait_vmcnt<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<16>() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+
+// BK = 32, ST = 4 : 64 KB ring, three 32-deep tiles in flight;  BK = 64, ST = 2 : 64 KB double buffer of full 128-B lines.
+template <bool A_KC, bool B_KC, typename OutT, int BK, int ST>
 __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                              OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, int64_t k_per_split,
                                                              EpiParams ep) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // G2_ST x (8 KB A + 8 KB B)
+    constexpr int OPB = 128 * BK * 2, STAGE = 2 * OPB, NI = BK / 16, LPT = 2 * NI;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // ST x (A tile + B tile)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t tiles_n = (N + GB_N - 1) / GB_N, tiles_m = (M + GB_M - 1) / GB_M;
@@ -432,7 +449,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
     const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
     const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
     if (kbeg >= kend) return;
-    const int nk = (int)((kend - kbeg) / G2_BK);
+    const int nk = (int)((kend - kbeg) / BK);
     const int wm = wave >> 1, wn = wave & 1;
     f32x4 acc[4][4];
 #pragma unroll
@@ -440,50 +457,57 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    uint32_t offA[2], offB[2];
-    glds_offsets<A_KC>(lda, m0, M, wave, lane, offA);
-    glds_offsets<B_KC>(ldb, n0, N, wave, lane, offB);
-    // wave-uniform running base pointers (bytes); one K step = 32 elements (K-contig) or 32 rows of ld (MN-contig)
+    uint32_t offA[NI], offB[NI];
+    glds_offsets<A_KC, BK>(lda, m0, M, wave, lane, offA);
+    glds_offsets<B_KC, BK>(ldb, n0, N, wave, lane, offB);
+    // wave-uniform running base pointers (bytes)
     const char* gA = (const char*)A + (A_KC ? kbeg : kbeg * lda) * 2;
     const char* gB = (const char*)B + (B_KC ? kbeg : kbeg * ldb) * 2;
-    const int64_t stepA = (A_KC ? (int64_t)G2_BK : (int64_t)G2_BK * lda) * 2;
-    const int64_t stepB = (B_KC ? (int64_t)G2_BK : (int64_t)G2_BK * ldb) * 2;
+    const int64_t stepA = (A_KC ? (int64_t)BK : (int64_t)BK * lda) * 2;
+    const int64_t stepB = (B_KC ? (int64_t)BK : (int64_t)BK * ldb) * 2;
 #pragma unroll
-    for (int s = 0; s < G2_ST - 1; ++s) {
+    for (int s = 0; s < ST - 1; ++s) {
         if (s < nk) {
-            glds_issue2(gA, offA, smem + s * G2_STAGE, wave);
-            glds_issue2(gB, offB, smem + s * G2_STAGE + 8192, wave);
+            glds_issue2<NI>(gA, offA, smem + s * STAGE, wave);
+            glds_issue2<NI>(gB, offB, smem + s * STAGE + OPB, wave);
             gA += stepA;
             gB += stepB;
         }
     }
     for (int kt = 0; kt < nk; ++kt) {
-        const int newer = (nk - 1 - kt) < (G2_ST - 2) ? (nk - 1 - kt) : (G2_ST - 2);
-        if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int newer = (nk - 1 - kt) < (ST - 2) ? (nk - 1 - kt) : (ST - 2);
+        if (newer >= 2) wait_vmcnt<2 * LPT>();
+        else if (newer == 1) wait_vmcnt<LPT>();
+        else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const int nxt = kt + G2_ST - 1;
-        if (nxt < nk) {
-            char* st = smem + (nxt % G2_ST) * G2_STAGE;
-            glds_issue2(gA, offA, st, wave);
-            glds_issue2(gB, offB, st + 8192, wave);
+        const int nxt = kt + ST - 1;
+        if (nxt < nk && ep.ablate != 1) {
+            char* st = smem + (nxt % ST) * STAGE;
+            glds_issue2<NI>(gA, offA, st, wave);
+            glds_issue2<NI>(gB, offB, st + OPB, wave);
             gA += stepA;
             gB += stepB;
         }
-        const char* la = smem + (kt % G2_ST) * G2_STAGE;
-        const char* lb = la + 8192;
-        bf16x8 fa[4], fb[4];
+        const char* la = smem + (kt % ST) * STAGE;
+        const char* lb = la + OPB;
+        if (ep.ablate == 2) continue;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = lfrag2<A_KC>(la, wm * 64 + i * 16, lane);
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 fa[4], fb[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = lfrag2<B_KC>(lb, wn * 64 + j * 16, lane);
+            for (int i = 0; i < 4; ++i) fa[i] = lfrag2<A_KC, BK>(la, wm * 64 + i * 16, ks, lane);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) fb[j] = lfrag2<B_KC, BK>(lb, wn * 64 + j * 16, ks, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        if constexpr (ST == 2) {   // double buffer: the stage just computed is overwritten by the NEXT iteration's issue
+            asm volatile("" ::: "memory");
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -640,6 +664,65 @@ static void dispatch_g3(bool akc, bool bkc, dim3 grid, hipStream_t st, const bf1
 }
 
 // ================================================================================================
+// skinny GEMM for the decode step (M <= 32 rows: n streams x 1 token): weight-bandwidth / launch bound.
+// One wave per 16 output columns, the whole K loop in registers: weight rows (nn.Linear [N,K]) and the M
+// activation rows are fetched as MFMA fragments straight from global memory (16 B per lane, no LDS —
+// the guide's rule for M <= 16 GEMV-like shapes), 4 K-steps of loads in flight.
+template <typename OutT>
+__global__ __launch_bounds__(256) void gemm_bf16_skinny_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                               OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, EpiParams ep) {
+    // block = 16 output columns; its 4 waves split the K range (shorter dependent chains, 4x the loads in flight) and
+    // combine through LDS; wave 0 runs the fused epilogue.
+    __shared__ f32x4 red[3][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n0 = (int64_t)blockIdx.x * 16;
+    int64_t nb = n0 + (lane & 15);
+    if (nb > N - 1) nb = N - 1;
+    int64_t m_lo = lane & 15, m_hi = 16 + (lane & 15);
+    if (m_lo > M - 1) m_lo = M - 1;
+    if (m_hi > M - 1) m_hi = M - 1;
+    const int64_t kq = ((K / 32 + 3) / 4) * 32;            // K slice per wave (multiple of 32)
+    const int64_t kb = wave * kq;
+    int64_t ke = kb + kq;
+    if (ke > K) ke = K;
+    const bf16_t* pb = B + nb * ldb + (lane >> 4) * 8;
+    const bf16_t* pa0 = A + m_lo * lda + (lane >> 4) * 8;
+    const bf16_t* pa1 = A + m_hi * lda + (lane >> 4) * 8;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    int64_t k = kb;
+    for (; k + 128 <= ke; k += 128) {
+        bf16x8 fb[4], fa0[4], fa1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            fb[u] = *(const bf16x8*)(pb + k + u * 32);
+            fa0[u] = *(const bf16x8*)(pa0 + k + u * 32);
+            fa1[u] = *(const bf16x8*)(pa1 + k + u * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[u], fa0[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[u], fa1[u], acc1, 0, 0, 0);
+        }
+    }
+    for (; k < ke; k += 32) {
+        bf16x8 fb = *(const bf16x8*)(pb + k), fa0 = *(const bf16x8*)(pa0 + k), fa1 = *(const bf16x8*)(pa1 + k);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa1, acc1, 0, 0, 0);
+    }
+    if (wave > 0) { red[wave - 1][0][lane] = acc0; red[wave - 1][1][lane] = acc1; }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) { acc0 += red[w][0][lane]; acc1 += red[w][1][lane]; }
+    const int64_t n = n0 + (lane >> 4) * 4;
+    const int64_t m0 = lane & 15;
+    if (n < N) {
+        if (m0 < M) epi_store4<OutT>(ep, C, m0, n, acc0, N);
+        if (m0 + 16 < M) epi_store4<OutT>(ep, C, m0 + 16, n, acc1, N);
+    }
+}
+
+// ================================================================================================
 static bool g_safe_tr = false;
 static bool g_safe_tr_init = false;
 static bool use_safe_tr() {
@@ -663,25 +746,46 @@ static void launch_bf16(dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda,
     hipLaunchKernelGGL(kfn, grid, dim3(256), 65536, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
 }
 
-template <bool A_KC, bool B_KC, typename OutT>
+static int g_glds_bk = -1;   // EMO_GEMM_BK=32|64 forces one LDS-DMA geometry (default: per-shape heuristic)
+static int glds_bk() {
+    if (g_glds_bk < 0) {
+        const char* e = getenv("EMO_GEMM_BK");
+        g_glds_bk = !e ? 0 : ((e[0] == '6') ? 64 : 32);
+    }
+    return g_glds_bk;
+}
+static bool g_glds_bk_forced() { return glds_bk() != 0; }
+
+template <bool A_KC, bool B_KC, typename OutT, int BK, int ST>
 static void launch_glds(dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int64_t M, int64_t N,
                         int64_t K, int64_t kps, const EpiParams& ep) {
-    auto kfn = gemm_bf16_glds_kernel<A_KC, B_KC, OutT>;
+    auto kfn = gemm_bf16_glds_kernel<A_KC, B_KC, OutT, BK, ST>;
+    constexpr int LDS = ST * 2 * 128 * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G2_ST * G2_STAGE);
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kfn, grid, dim3(256), G2_ST * G2_STAGE, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), LDS, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
 }
 
+template <typename OutT, int BK, int ST>
+static void dispatch_glds2(bool akc, bool bkc, dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C,
+                           int64_t M, int64_t N, int64_t K, int64_t kps, const EpiParams& ep) {
+    if (akc && bkc) launch_glds<true, true, OutT, BK, ST>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    else if (akc && !bkc) launch_glds<true, false, OutT, BK, ST>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    else if (!akc && bkc) launch_glds<false, true, OutT, BK, ST>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    else launch_glds<false, false, OutT, BK, ST>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+}
 template <typename OutT>
 static void dispatch_glds(bool akc, bool bkc, dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C,
                           int64_t M, int64_t N, int64_t K, int64_t kps, const EpiParams& ep) {
-    if (akc && bkc) launch_glds<true, true, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-    else if (akc && !bkc) launch_glds<true, false, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-    else if (!akc && bkc) launch_glds<false, true, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-    else launch_glds<false, false, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    // measured r01 (tools/bench_gemm.py): the 4-stage ring of 32-deep tiles wins for short reductions (K=512: 494 vs 459
+    // TFLOP/s), the double buffer of full 128-B lines for long ones (K=2048: 770 vs 700) and for MN-contiguous B (dgrad).
+    const bool can64 = (kps % 64) == 0 && (K % 64) == 0;
+    const int bk = g_glds_bk_forced() ? glds_bk() : ((K > 1024 || !bkc) ? 64 : 32);
+    if (bk == 64 && can64) dispatch_glds2<OutT, 64, 2>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    else dispatch_glds2<OutT, 32, 4>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
 }
 
 static int g_gemm_variant = -1;   // EMO_GEMM_VARIANT: 1 = register-staged v1, 2 = LDS-DMA ring (default when eligible)
@@ -717,6 +821,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     ep.ldc = ldc;
     ep.accumulate = accumulate;
     ep.drop = make_drop(0.f, 0, 0);
+    { const char* ab = getenv("EMO_GEMM_ABLATE"); ep.ablate = ab ? atoi(ab) : 0; }
     bool has_epi = false;
     if (e) {
         ep.bias = e->bias; ep.act = e->act; ep.aux_out = e->aux_out; ep.mul_aux = e->mul_aux;
@@ -726,6 +831,16 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     }
     const bool big = dtype_in == EMO_BF16;
     const int variant = big ? gemm_variant() : 0;
+    if (big && M <= 32 && !a_trans && !b_trans && (K % 32) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0 &&
+        !accumulate && getenv("EMO_GEMM_NO_SKINNY") == nullptr) {
+        dim3 g((unsigned)cdiv64(N, 16));
+        if (dtype_out == EMO_F32)
+            hipLaunchKernelGGL(gemm_bf16_skinny_kernel<float>, g, dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (float*)C, M, N, K, ep);
+        else
+            hipLaunchKernelGGL(gemm_bf16_skinny_kernel<bf16_t>, g, dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, M, N, K, ep);
+        EMO_LAUNCH_CHECK();
+        return EMO_OK;
+    }
     // v3 (256^2 tile) when the problem fills the chip with 256^2 tiles and N does not waste a tile
     bool use_g3 = false;
     if (big && variant >= 2 && !use_safe_tr() && (K % G3_K) == 0 && M >= 256) {
@@ -777,7 +892,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         const int64_t rowsA = a_trans ? (use_g3 ? G3_K : G2_BK) : M, rowsB = b_trans ? (use_g3 ? G3_K : G2_BK) : N;
         const int64_t spanA = (rowsA * lda + (a_trans ? M : 0)) * 2, spanB = (rowsB * ldb + (b_trans ? N : 0)) * 2;
         const bool span_ok = spanA < (int64_t)0xFFFF0000 && spanB < (int64_t)0xFFFF0000;
-        const bool glds_ok = !safe && variant >= 2 && (akc && bkc || variant >= 3) && (K % G2_BK) == 0 && (kps % G2_BK) == 0 && M >= 8 && N >= 8 && span_ok;
+        const bool glds_ok = !safe && variant >= 2 && (akc || variant >= 3) && (K % G2_BK) == 0 && (kps % G2_BK) == 0 && M >= 8 && N >= 8 && span_ok;
         if (use_g3 && span_ok && (kps % G3_K) == 0) {
             if (dtype_out == EMO_F32) dispatch_g3<float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
             else dispatch_g3<bf16_t>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);

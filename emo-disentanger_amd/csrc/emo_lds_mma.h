@@ -81,9 +81,44 @@ __device__ __forceinline__ void load_rows_T(CT* img, int ld, const CT* __restric
         }
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
-            img[(c + e) * ld + 2 * p] = a[e];
-            img[(c + e) * ld + 2 * p + 1] = b[e];
+            if constexpr (sizeof(CT) == 2) {      // rows 2p, 2p+1 of column c+e are adjacent in the image: one 4-B store
+                bf16x2 pr = {a[e], b[e]};
+                *(bf16x2*)(img + (c + e) * ld + 2 * p) = pr;
+            } else {
+                img[(c + e) * ld + 2 * p] = a[e];
+                img[(c + e) * ld + 2 * p + 1] = b[e];
+            }
         }
     }
 }
 
+
+// sum / dot over N contiguous image elements starting at p (16-B aligned, N multiple of the 16-B vector width)
+template <typename CT, int N>
+__device__ __forceinline__ float sum_contig(const CT* p) {
+    constexpr int VE = 16 / sizeof(CT);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < N / VE; ++i) {
+        if constexpr (sizeof(CT) == 2) { bf16x8 v = *(const bf16x8*)(p + i * VE);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)v[e]; }
+        else { f32x4 v = *(const f32x4*)(p + i * VE); s += v[0] + v[1] + v[2] + v[3]; }
+    }
+    return s;
+}
+template <typename CT, int N>
+__device__ __forceinline__ float dot_contig(const CT* p, const float* w) {
+    constexpr int VE = 16 / sizeof(CT);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < N / VE; ++i) {
+        if constexpr (sizeof(CT) == 2) { bf16x8 v = *(const bf16x8*)(p + i * VE);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)v[e] * w[i * VE + e]; }
+        else { f32x4 v = *(const f32x4*)(p + i * VE);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += v[e] * w[i * VE + e]; }
+    }
+    return s;
+}

@@ -73,13 +73,14 @@ class _EngineBase:
         self.ps = model._ensure_store()
         self.dev, self.dt = self.ps.device, self.ps.compute_dtype
         self.pos = 0
+        self.pos_dev = torch.zeros(n_streams, device=self.dev, dtype=torch.int64)   # device-side positions (hipGraph replay)
 
-    def _embed(self, tok, seg, pos0):
+    def _embed(self, tok, seg, pos0, dev_pos=False):
         m, ps = self.model, self.ps
         S = ps.f32('segemb.emb_lookup.weight') if (seg is not None and m.use_segment_emb) else None
-        pe = m.pe.pe if m.use_pe else m._zero_pe(pos0 + tok.shape[1], m.d_model)
+        pe = m.pe.pe if m.use_pe else m._zero_pe(self.max_len, m.d_model)
         return ops.embed_fwd(tok, seg if S is not None else None, ps.f32('token_emb.emb_lookup.weight'), S, pe, self.dt, float(m.token_emb.emb_scale),
-                             pos0=pos0).view(-1, m.d_model)
+                             pos0=pos0, pos_ids=self.pos_dev if dev_pos else None).view(-1, m.d_model)
 
     def _logits(self, h):
         return ops.gemm(h, self.ps.w('dec_out_proj.weight'), bias=self.ps.f32('dec_out_proj.bias'), out_dtype=torch.float32)
@@ -119,6 +120,7 @@ class PerformerDecodeEngine(_EngineBase):
             attn, _, self.S[l], self.z[l] = ops.favor_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], self.omegas[l], B, T, H, want_state=True)
             x = self._tail(pfx, x, attn)
         self.pos = T
+        self.pos_dev.fill_(T)
         return self._logits(x.view(B, T, D)[:, -1].contiguous())
 
     def _tail(self, pfx, x, attn):
@@ -131,17 +133,22 @@ class PerformerDecodeEngine(_EngineBase):
         return out
 
     @torch.no_grad()
-    def step(self, tok, seg):
+    def step(self, tok, seg, dev_pos=False):
+        """dev_pos=True: positions come from the device array `pos_dev` (and are advanced on the device), so the whole step is
+        capturable in a hipGraph and replayable."""
         m, ps = self.model, self.ps
         D, H = m.d_model, m.n_head
-        x = self._embed(tok.view(-1, 1), None if seg is None else seg.view(-1, 1), self.pos)
+        x = self._embed(tok.view(-1, 1), None if seg is None else seg.view(-1, 1), self.pos, dev_pos)
         for l in range(m.n_layer):
             pfx = m._layer_prefix(l)
             q = pfx + 'attention.query_projection.'
             qkv = ops.gemm(x, ps.w(q + 'weight', 3 * D), bias=ps.f32(q + 'bias', 3 * D))
             attn = ops.favor_decode_step(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], self.omegas[l], self.S[l], self.z[l], H)
             x = self._tail(pfx, x, attn)
-        self.pos += 1
+        if dev_pos:
+            self.pos_dev.add_(1)
+        else:
+            self.pos += 1
         return self._logits(x)
 
 
@@ -177,24 +184,34 @@ class GPT2DecodeEngine(_EngineBase):
             a, _ = ops.softmax_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, T, H)
             x = self._block_tail(pfx, x, a)
         self.pos = T
+        self.pos_dev.fill_(T)
         self.lens.fill_(T)
         return self._logits(x.view(B, T, D)[:, -1].contiguous())
 
     @torch.no_grad()
-    def step(self, tok, seg):
+    def step(self, tok, seg, dev_pos=False):
         m, ps = self.model, self.ps
         D, H = m.d_model, m.n_head
-        x = self._embed(tok.view(-1, 1), None if seg is None else seg.view(-1, 1), self.pos)
+        x = self._embed(tok.view(-1, 1), None if seg is None else seg.view(-1, 1), self.pos, dev_pos)
+        if dev_pos:
+            slot = torch.arange(self.n, device=self.dev) * self.max_len + self.pos_dev      # flat cache row of each stream's new token
         self.lens.add_(1)
         for l in range(m.n_layer):
             pfx = m._layer_prefix(l)
             n1, _, _ = ops.layernorm_fwd(x, ps.f32(pfx + 'ln_1.weight'), ps.f32(pfx + 'ln_1.bias'))
             qkv = ops.gemm(n1, ps.w(pfx + 'attn.c_attn.weight'), b_trans=True, bias=ps.f32(pfx + 'attn.c_attn.bias'))
-            self.kc[l][:, self.pos].copy_(qkv[:, D:2 * D])
-            self.vc[l][:, self.pos].copy_(qkv[:, 2 * D:])
+            if dev_pos:
+                self.kc[l].view(-1, D).index_copy_(0, slot, qkv[:, D:2 * D])
+                self.vc[l].view(-1, D).index_copy_(0, slot, qkv[:, 2 * D:])
+            else:
+                self.kc[l][:, self.pos].copy_(qkv[:, D:2 * D])
+                self.vc[l][:, self.pos].copy_(qkv[:, 2 * D:])
             a = ops.softmax_attn_decode(qkv[:, :D], self.kc[l], self.vc[l], self.lens, H)
             x = self._block_tail(pfx, x, a)
-        self.pos += 1
+        if dev_pos:
+            self.pos_dev.add_(1)
+        else:
+            self.pos += 1
         return self._logits(x)
 
 
@@ -291,22 +308,47 @@ def generate_conditional(model, event2idx, idx2event, lead_sheet_events, primer,
 
 
 @torch.no_grad()
-def generate_streams(model, prompt_tok, prompt_seg, n_new, temp=1.1, top_p=0.9, greedy=False, seed=0, seg_value=1):
+def generate_streams(model, prompt_tok, prompt_seg, n_new, temp=1.1, top_p=0.9, greedy=False, seed=0, seg_value=1, use_graph=True):
     """BASELINE configs[3]: n parallel streams in lock-step (grammar checks off => fixed token count).  Everything stays
-    on the GPU: recurrent/KV state, sampling, token buffer.  Returns int64 [n, T0 + n_new]."""
+    on the GPU: recurrent/KV state, positions, sampling, token buffer.  One decode step is ~110 small launches, so the
+    step (sample -> append -> embed -> 12 layers -> logits) is captured ONCE in a hipGraph and replayed per token.
+    Returns int64 [n, T0 + n_new]."""
     n, T0 = prompt_tok.shape
     dev = prompt_tok.device
     eng = make_engine(model, n)
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
+    U = torch.rand(max(n_new, 1), n, device=dev, generator=gen)
     out = torch.empty(n, T0 + n_new, dtype=torch.long, device=dev)
     out[:, :T0] = prompt_tok
     seg_col = torch.full((n,), seg_value, dtype=torch.long, device=dev)
-    logits = eng.prefill(prompt_tok, prompt_seg)
-    for i in range(n_new):
-        u = torch.rand(n, device=dev, generator=gen)
-        nxt = sample_on_device(logits, temp, top_p, u, greedy)
-        out[:, T0 + i] = nxt
-        if i + 1 < n_new:
-            logits = eng.step(nxt, seg_col)
+    logits_buf = eng.prefill(prompt_tok, prompt_seg).clone()
+    step_idx = torch.zeros(1, dtype=torch.long, device=dev)
+
+    def one_step():
+        u = U.index_select(0, step_idx).view(n)
+        nxt = sample_on_device(logits_buf, temp, top_p, u, greedy)
+        out.scatter_(1, (step_idx + T0).expand(n, 1), nxt.view(n, 1))
+        logits_buf.copy_(eng.step(nxt, seg_col, dev_pos=True))
+        step_idx.add_(1)
+
+    if n_new <= 0:
+        return out
+    one_step()                                   # eager first step (also warms every kernel / attribute cache)
+    if n_new == 1:
+        return out
+    if not use_graph:
+        for _ in range(n_new - 1):
+            one_step()
+        return out
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            one_step()
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(n_new - 1):
+        graph.replay()
     return out

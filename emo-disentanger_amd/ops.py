@@ -58,15 +58,15 @@ def colsum(X, out=None, accumulate=False):
     return out
 
 
-def embed_fwd(tok, seg, E, S, pe, dtype, scale, pos0=0, p_drop=0.0, seed=0, offset=0):
+def embed_fwd(tok, seg, E, S, pe, dtype, scale, pos0=0, p_drop=0.0, seed=0, offset=0, pos_ids=None):
     B, T = tok.shape
     D = E.shape[1]
     out = torch.empty(B, T, D, device=tok.device, dtype=dtype)
     assert pe.is_contiguous() and pe.shape[-1] == D and pe.numel() >= (pos0 + T) * D
-    tok, seg = _c(tok), _c(seg)       # keep the contiguous copies alive until the launch is queued
+    tok, seg, pos_ids = _c(tok), _c(seg), _c(pos_ids)       # keep the contiguous copies alive until the launch is queued
     check(lib.emo_embed_fwd(ptr(tok), ptr(seg), ptr(E), ptr(S), ptr(pe), ptr(out),
-                            dtype_code(dtype), B, T, D, E.shape[0], 0 if S is None else S.shape[0], pos0, scale, p_drop, seed, offset,
-                            stream()))
+                            dtype_code(dtype), B, T, D, E.shape[0], 0 if S is None else S.shape[0], pos0, ptr(pos_ids), scale, p_drop, seed,
+                            offset, stream()))
     return out
 
 

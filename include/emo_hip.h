@@ -75,11 +75,13 @@ int emo_colsum(const void* X, int dtype, int64_t M, int64_t N, int64_t ld, float
  * out[b,t,:] = dropout( (E[tok[b,t]] + S[seg[b,t]]) * scale + pe[pos0 + t] )
  * Replaces TokenEmbedding.forward x2 + PositionalEncoding + emb_dropout
  * (model/transformer_helpers.py:81-87,57-63; model/music_performer.py:51-62).
- * pe: fp32 rows of length D (the `pe.pe` buffer [max_pos,1,D] is exactly that). */
+ * pe: fp32 rows of length D (the `pe.pe` buffer [max_pos,1,D] is exactly that).
+ * pos_ids (nullable, device int64 [B]): per-sequence position of its first token, replacing pos0 —
+ * decode streams of different lengths, and hipGraph replay (no host-side position baked in). */
 int emo_embed_fwd(const int64_t* tok, const int64_t* seg, const float* E, const float* S,
                   const float* pe, void* out, int dtype, int64_t B, int64_t T, int64_t D,
-                  int64_t V, int64_t n_seg, int64_t pos0, float scale, float p_drop,
-                  uint64_t seed, uint64_t offset, emo_stream_t stream);
+                  int64_t V, int64_t n_seg, int64_t pos0, const int64_t* pos_ids, float scale,
+                  float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream);
 /* dE[tok] += dout*mask*scale ; dS[seg] += ...  (fp32 accumulate, caller zeroes) */
 int emo_embed_bwd(const int64_t* tok, const int64_t* seg, const void* dout, int dtype, float* dE,
                   float* dS, int64_t B, int64_t T, int64_t D, int64_t V, int64_t n_seg,

@@ -98,10 +98,29 @@ def test_generate_streams_lockstep_greedy_and_nucleus():
     top2 = full[:, T0 - 1:-1].topk(2, -1).values
     safe = (top2[..., 0] - top2[..., 1]) > 1e-3
     assert torch.equal(out[:, T0:][safe], full[:, T0 - 1:-1].argmax(-1)[safe])     # every greedy token is the argmax of its prefix
+    eager = inf.generate_streams(m, ptok, pseg, Tn, greedy=True, use_graph=False)
+    assert torch.equal(out, eager)                                                 # hipGraph replay == eager launches
     a = inf.generate_streams(m, ptok, pseg, Tn, temp=1.1, top_p=0.9, seed=3)
-    b = inf.generate_streams(m, ptok, pseg, Tn, temp=1.1, top_p=0.9, seed=3)
+    b = inf.generate_streams(m, ptok, pseg, Tn, temp=1.1, top_p=0.9, seed=3, use_graph=False)
     c = inf.generate_streams(m, ptok, pseg, Tn, temp=1.1, top_p=0.9, seed=4)
     assert torch.equal(a, b) and not torch.equal(a, c) and int(a.max()) < V
+
+
+def test_generate_streams_gpt2_kv_cache_graph():
+    from emo_disentanger_amd import inference as inf
+    g = json.load(open(os.path.join(G, 'generate.json')))
+    m = _tiny_gpt2(g['model'])
+    gen = torch.Generator().manual_seed(2)
+    ptok = torch.randint(0, g['model']['V'] - 1, (3, 9), generator=gen).cuda()
+    pseg = torch.ones(3, 9, dtype=torch.long).cuda()
+    a = inf.generate_streams(m, ptok, pseg, 20, greedy=True)
+    b = inf.generate_streams(m, ptok, pseg, 20, greedy=True, use_graph=False)
+    assert torch.equal(a, b)
+    with torch.no_grad():
+        full = m(a, seg_inp=torch.ones_like(a))
+    top2 = full[:, 8:-1].topk(2, -1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-3
+    assert torch.equal(a[:, 9:][safe], full[:, 8:-1].argmax(-1)[safe])
 
 
 @pytest.mark.parametrize('accum', [1, 2])

@@ -384,3 +384,17 @@ def test_gemm_256_tile_kernel_all_layouts(a_trans, b_trans):
     bias, res = _r(N, seed=5), _r(M, N, seed=6, dt=dt)
     out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), act=ops.ACT_RELU, residual=res.cuda())
     _close(out, torch.relu(A.double() @ W.double().T + bias.double()) + res.double(), dt)
+
+
+@pytest.mark.parametrize('M', [1, 7, 16, 32])
+def test_gemm_skinny_decode_shapes(M):
+    """M <= 32 (decode: n streams x 1 token) takes the register-only skinny kernel."""
+    ops = _ops()
+    dt = torch.bfloat16
+    for N, K in ((512, 512), (1536, 512), (2048, 512), (512, 2048), (327, 512)):
+        A, W = _r(M, K, seed=1, dt=dt), _r(N, K, seed=2, dt=dt, scale=0.1)
+        bias, res = _r(N, seed=3), _r(M, N, seed=4, dt=dt)
+        out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), act=ops.ACT_RELU, residual=res.cuda())
+        _close(out, torch.relu(A.double() @ W.double().T + bias.double()) + res.double(), dt)
+        out32 = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), out_dtype=torch.float32)
+        _close(out32, A.double() @ W.double().T + bias.double(), dt, mult=0.3)
