@@ -122,6 +122,126 @@ __device__ __forceinline__ void epi_store4(const EpiParams& ep, OutT* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tile epilogue through LDS.  Measured (EMO_GEMM_ABLATE, K=512 vs K=2048): the per-tile FIXED cost was ~7 us, most of it
+// the store tail of the fragment-layout epilogue (16 x 8-B row-strided stores per lane = the store-issue-bound pattern
+// of the guide's T21).  The 128x128 fp32 accumulator tile is staged in the (now idle) 64 KB of LDS with a 16-B-chunk
+// XOR swizzle, then every thread owns 8 CONSECUTIVE columns of a row: bias / residual / mask loads and the output
+// store are 16-B, fully coalesced (16 lanes per 256-B row), and the dropout hash count halves.
+template <typename OutT>
+__device__ __forceinline__ void epi_row8(const EpiParams& ep, OutT* __restrict__ C, int64_t m, int64_t n, float (&v)[8], int64_t N) {
+    const int64_t off = m * ep.ldc + n;
+    if ((n + 7 < N) && ((ep.ldc & 7) == 0)) {
+        if (ep.bias) {
+            f32x4 b0 = *(const f32x4*)(ep.bias + n), b1 = *(const f32x4*)(ep.bias + n + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] += b0[i]; v[4 + i] += b1[i]; }
+        }
+        if (ep.aux_out) {
+            float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
+            Out4<OutT>::store((OutT*)ep.aux_out + off, lo);
+            Out4<OutT>::store((OutT*)ep.aux_out + off + 4, hi);
+        }
+        if (ep.act == EMO_ACT_RELU) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        } else if (ep.act == EMO_ACT_GELU_NEW) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = gelu_new_f(v[i]);
+        }
+        if (ep.mul_mode != EMO_MUL_NONE) {
+            float a[8];
+            { float t0[4], t1[4]; Out4<OutT>::load((const OutT*)ep.mul_aux + off, t0); Out4<OutT>::load((const OutT*)ep.mul_aux + off + 4, t1);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) { a[i] = t0[i]; a[4 + i] = t1[i]; } }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (a[i] != 0.f ? ep.mul_scale : 0.f) : dgelu_new_f(a[i]);
+        }
+        if (ep.drop.thr16) {
+            float d0[4], d1[4];
+            drop_mult4(ep.drop, (uint64_t)(m * N + n), d0);
+            drop_mult4(ep.drop, (uint64_t)(m * N + n + 4), d1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] *= d0[i]; v[4 + i] *= d1[i]; }
+        }
+        if (ep.residual) {
+            float t0[4], t1[4];
+            Out4<OutT>::load((const OutT*)ep.residual + off, t0);
+            Out4<OutT>::load((const OutT*)ep.residual + off + 4, t1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] += t0[i]; v[4 + i] += t1[i]; }
+        }
+        OutT* c = C + off;
+        if constexpr (sizeof(OutT) == 4) {
+            if (ep.atomic) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) atomicAdd((float*)c + i, v[i]);
+                return;
+            }
+            if (ep.accumulate) {
+                float t0[4], t1[4];
+                Out4<float>::load((const float*)c, t0);
+                Out4<float>::load((const float*)c + 4, t1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v[i] += t0[i]; v[4 + i] += t1[i]; }
+            }
+            float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
+            Out4<float>::store((float*)c, lo);
+            Out4<float>::store((float*)c + 4, hi);
+        } else {
+            bf16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+            *(bf16x8*)c = o;
+        }
+        return;
+    }
+    // edge: reuse the 4-wide path (which itself falls back to scalars)
+    if (n < N) epi_store4<OutT>(ep, C, m, n, (f32x4){v[0], v[1], v[2], v[3]}, N);
+    if (n + 4 < N) epi_store4<OutT>(ep, C, m, n + 4, (f32x4){v[4], v[5], v[6], v[7]}, N);
+}
+
+// acc[i][j]: lane owns row (wm*64 + i*16 + (lane&15)), columns (wn*64 + j*16 + (lane>>4)*4 .. +3) of the 128x128 tile
+template <typename OutT>
+__device__ __forceinline__ void epilogue_tile128(const EpiParams& ep, OutT* __restrict__ C, int64_t m0, int64_t n0, int64_t M, int64_t N,
+                                                 const f32x4 (&acc)[4][4], char* lds, int tid, int wm, int wn, int lane) {
+    if (ep.atomic) {
+        // split-K partial sums: fp32 atomics straight from the fragment layout (row-contiguous atomics measured 20-40 % slower:
+        // 16 lanes of one instruction then hit the same 128-B lines)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
+                const int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+                if (m < M && n < N) epi_store4<OutT>(ep, C, m, n, acc[i][j], N);
+            }
+        return;
+    }
+    __syncthreads();                      // every wave is done reading operand tiles from this LDS
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = wm * 64 + i * 16 + (lane & 15);
+            const int chunk = (wn * 64 + j * 16 + (lane >> 4) * 4) >> 2;          // 16-B chunk index 0..31
+            *(f32x4*)(lds + row * 512 + ((chunk ^ (row & 7)) << 4)) = acc[i][j];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = tid + 256 * it;   // 0..2047 : row = idx >> 4, 8-column group = idx & 15
+        const int row = idx >> 4, grp = idx & 15;
+        const int64_t m = m0 + row, n = n0 + grp * 8;
+        if (m < M && n < N) {
+            const f32x4 lo = *(const f32x4*)(lds + row * 512 + (((2 * grp) ^ (row & 7)) << 4));
+            const f32x4 hi = *(const f32x4*)(lds + row * 512 + (((2 * grp + 1) ^ (row & 7)) << 4));
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            epi_row8<OutT>(ep, C, m, n, v, N);
+        }
+    }
+}
+
 // out-of-line copy for kernels with many accumulator tiles (keeps the unrolled epilogue small enough that the
 // accumulator array stays in registers instead of scratch)
 template <typename OutT>
@@ -346,14 +466,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
         __syncthreads();
         cur ^= 1;
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
-            int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-            if (m < M && n < N) epi_store4<OutT>(ep, C, m, n, acc[i][j], N);
-        }
+    epilogue_tile128<OutT>(ep, C, m0, n0, M, N, acc, smem, tid, wm, wn, lane);
 }
 
 // ================================================================================================
@@ -509,14 +622,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
             asm volatile("" ::: "memory");
         }
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
-            int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-            if (m < M && n < N) epi_store4<OutT>(ep, C, m, n, acc[i][j], N);
-        }
+    epilogue_tile128<OutT>(ep, C, m0, n0, M, N, acc, smem, tid, wm, wn, lane);
 }
 
 // ================================================================================================
@@ -746,6 +852,102 @@ static void launch_bf16(dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda,
     hipLaunchKernelGGL(kfn, grid, dim3(256), 65536, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
 }
 
+// v2p: the BK=32 / 4-stage ring with SOFTWARE-PIPELINED fragments.  Ablation (EMO_GEMM_ABLATE=1: no tile loads) showed
+// the plain ring's inner loop alone reaches only ~43 % MFMA utilisation: every K step does barrier -> 8 ds_read_b128 ->
+// lgkmcnt(0) -> 16 MFMA, so the LDS latency is exposed once per step.  Here the fragments of stage k+1 are read into a
+// second register set while the MFMAs of stage k run (the ring guarantees stage k+1 has landed one step earlier), at
+// the price of one tile less in flight (2 instead of 3).
+template <bool A_KC, bool B_KC, typename OutT>
+__global__ __launch_bounds__(256) void gemm_bf16_glds_pf_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                                OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, int64_t k_per_split,
+                                                                EpiParams ep) {
+    constexpr int BK = 32, ST = 4, OPB = 128 * BK * 2, STAGE = 2 * OPB, NI = BK / 16, LPT = 2 * NI;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t tiles_n = (N + GB_N - 1) / GB_N, tiles_m = (M + GB_M - 1) / GB_M;
+    int64_t tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    if (tm >= tiles_m) return;
+    const int64_t m0 = tm * GB_M, n0 = tn * GB_N;
+    const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
+    const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+    if (kbeg >= kend) return;
+    const int nk = (int)((kend - kbeg) / BK);
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint32_t offA[NI], offB[NI];
+    glds_offsets<A_KC, BK>(lda, m0, M, wave, lane, offA);
+    glds_offsets<B_KC, BK>(ldb, n0, N, wave, lane, offB);
+    const char* gA = (const char*)A + (A_KC ? kbeg : kbeg * lda) * 2;
+    const char* gB = (const char*)B + (B_KC ? kbeg : kbeg * ldb) * 2;
+    const int64_t stepA = (A_KC ? (int64_t)BK : (int64_t)BK * lda) * 2;
+    const int64_t stepB = (B_KC ? (int64_t)BK : (int64_t)BK * ldb) * 2;
+    int issued = 0;
+    auto issue_next = [&]() {
+        if (issued < nk) {
+            char* st = smem + (issued % ST) * STAGE;
+            glds_issue2<NI>(gA, offA, st, wave);
+            glds_issue2<NI>(gB, offB, st + OPB, wave);
+            gA += stepA;
+            gB += stepB;
+            ++issued;
+        }
+    };
+    issue_next(); issue_next(); issue_next();
+    // stage 0 must have landed before the first fragment read: at most (issued-1) younger tiles may stay in flight
+    if (issued >= 3) wait_vmcnt<2 * LPT>(); else if (issued == 2) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa0[i] = lfrag2<A_KC, BK>(smem, wm * 64 + i * 16, 0, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb0[j] = lfrag2<B_KC, BK>(smem + OPB, wn * 64 + j * 16, 0, lane);
+
+#define EMO_PF_STEP(CURA, CURB, NXTA, NXTB, KT)                                                                                   \
+    {                                                                                                                             \
+        const int kt_ = (KT);                                                                                                     \
+        if (kt_ + 1 < nk) {                                                                                                       \
+            /* stage kt+1 must have landed; only stage kt+2 may still be in flight */                                             \
+            if (issued > kt_ + 2) wait_vmcnt<LPT>(); else wait_vmcnt<0>();                                                        \
+            __builtin_amdgcn_s_barrier();                                                                                         \
+            asm volatile("" ::: "memory");                                                                                        \
+            issue_next();                                                                                                         \
+            const char* la_ = smem + ((kt_ + 1) % ST) * STAGE;                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) NXTA[i] = lfrag2<A_KC, BK>(la_, wm * 64 + i * 16, 0, lane);             \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) NXTB[j] = lfrag2<B_KC, BK>(la_ + OPB, wn * 64 + j * 16, 0, lane);       \
+        }                                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                             \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                         \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CURB[j], CURA[i], acc[i][j], 0, 0, 0);                        \
+    }
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        EMO_PF_STEP(fa0, fb0, fa1, fb1, kt)
+        EMO_PF_STEP(fa1, fb1, fa0, fb0, kt + 1)
+    }
+    if (kt < nk) EMO_PF_STEP(fa0, fb0, fa1, fb1, kt)
+#undef EMO_PF_STEP
+    epilogue_tile128<OutT>(ep, C, m0, n0, M, N, acc, smem, tid, wm, wn, lane);
+}
+
+template <bool A_KC, bool B_KC, typename OutT>
+static void launch_glds_pf(dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int64_t M, int64_t N,
+                           int64_t K, int64_t kps, const EpiParams& ep) {
+    auto kfn = gemm_bf16_glds_pf_kernel<A_KC, B_KC, OutT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(256), 65536, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
+}
+
 static int g_glds_bk = -1;   // EMO_GEMM_BK=32|64 forces one LDS-DMA geometry (default: per-shape heuristic)
 static int glds_bk() {
     if (g_glds_bk < 0) {
@@ -784,7 +986,10 @@ static void dispatch_glds(bool akc, bool bkc, dim3 grid, hipStream_t st, const b
     // TFLOP/s), the double buffer of full 128-B lines for long ones (K=2048: 770 vs 700) and for MN-contiguous B (dgrad).
     const bool can64 = (kps % 64) == 0 && (K % 64) == 0;
     const int bk = g_glds_bk_forced() ? glds_bk() : ((K > 1024 || !bkc) ? 64 : 32);
+    static const bool use_pf = getenv("EMO_GEMM_NO_PF") == nullptr;
     if (bk == 64 && can64) dispatch_glds2<OutT, 64, 2>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    else if (use_pf && akc && bkc) launch_glds_pf<true, true, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    else if (use_pf && akc && !bkc) launch_glds_pf<true, false, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
     else dispatch_glds2<OutT, 32, 4>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
 }
 
