@@ -202,7 +202,7 @@ __device__ __forceinline__ void epi_row8(const EpiParams& ep, OutT* __restrict__
 }
 
 // acc[i][j]: lane owns row (wm*64 + i*16 + (lane&15)), columns (wn*64 + j*16 + (lane>>4)*4 .. +3) of the 128x128 tile
-template <typename OutT>
+template <typename OutT, int PASSES = 1>
 __device__ __forceinline__ void epilogue_tile128(const EpiParams& ep, OutT* __restrict__ C, int64_t m0, int64_t n0, int64_t M, int64_t N,
                                                  const f32x4 (&acc)[4][4], char* lds, int tid, int wm, int wn, int lane) {
     if (ep.atomic) {
@@ -218,26 +218,34 @@ __device__ __forceinline__ void epilogue_tile128(const EpiParams& ep, OutT* __re
             }
         return;
     }
-    __syncthreads();                      // every wave is done reading operand tiles from this LDS
+    // PASSES = 2: the tile goes through LDS in two 64-row halves (32 KB) so that kernels with a 48 KB operand ring
+    // (3 blocks per CU) can use the same epilogue.
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int pass = 0; pass < PASSES; ++pass) {
+        constexpr int ROWS = 128 / PASSES;
+        __syncthreads();                  // every wave is done reading operand tiles (or the previous half) from this LDS
+        if (PASSES == 1 || wm == pass) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = wm * 64 + i * 16 + (lane & 15);
-            const int chunk = (wn * 64 + j * 16 + (lane >> 4) * 4) >> 2;          // 16-B chunk index 0..31
-            *(f32x4*)(lds + row * 512 + ((chunk ^ (row & 7)) << 4)) = acc[i][j];
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = (PASSES == 1 ? wm * 64 : 0) + i * 16 + (lane & 15);
+                    const int chunk = (wn * 64 + j * 16 + (lane >> 4) * 4) >> 2;          // 16-B chunk index 0..31
+                    *(f32x4*)(lds + row * 512 + ((chunk ^ (row & 7)) << 4)) = acc[i][j];
+                }
         }
-    __syncthreads();
+        __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int idx = tid + 256 * it;   // 0..2047 : row = idx >> 4, 8-column group = idx & 15
-        const int row = idx >> 4, grp = idx & 15;
-        const int64_t m = m0 + row, n = n0 + grp * 8;
-        if (m < M && n < N) {
-            const f32x4 lo = *(const f32x4*)(lds + row * 512 + (((2 * grp) ^ (row & 7)) << 4));
-            const f32x4 hi = *(const f32x4*)(lds + row * 512 + (((2 * grp + 1) ^ (row & 7)) << 4));
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            epi_row8<OutT>(ep, C, m, n, v, N);
+        for (int it = 0; it < 8 / PASSES; ++it) {
+            const int idx = tid + 256 * it;   // row = idx >> 4, 8-column group = idx & 15
+            const int row = idx >> 4, grp = idx & 15;
+            const int64_t m = m0 + pass * ROWS + row, n = n0 + grp * 8;
+            if (m < M && n < N) {
+                const f32x4 lo = *(const f32x4*)(lds + row * 512 + (((2 * grp) ^ (row & 7)) << 4));
+                const f32x4 hi = *(const f32x4*)(lds + row * 512 + (((2 * grp + 1) ^ (row & 7)) << 4));
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                epi_row8<OutT>(ep, C, m, n, v, N);
+            }
         }
     }
 }
@@ -637,7 +645,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __res
             asm volatile("" ::: "memory");
         }
     }
-    epilogue_tile128<OutT>(ep, C, m0, n0, M, N, acc, smem, tid, wm, wn, lane);
+    epilogue_tile128<OutT, (ST * STAGE >= 65536 ? 1 : 2)>(ep, C, m0, n0, M, N, acc, smem, tid, wm, wn, lane);
 }
 
 // ================================================================================================
@@ -965,6 +973,154 @@ static void launch_glds_pf(dim3 grid, hipStream_t st, const bf16_t* A, int64_t l
     hipLaunchKernelGGL(kfn, grid, dim3(256), 65536, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
 }
 
+// v4: 128 x 256 block tile, 8 waves (2 x 4, wave tile 64 x 64 as in v2), BK = 32, 4-stage LDS-DMA ring (96 KB, one block
+// = 2 waves per SIMD).  The K=512 forward GEMMs are bound by the CU's vector-memory front end (ablation: tile loads alone
+// take 80 % of the kernel time at ~12-16 B/clk/CU); doubling BN cuts the tile bytes per FLOP by 25 % at unchanged
+// MFMA / LDS-read structure.  Both operands K-contiguous or B MN-contiguous (same images as v2).
+constexpr int G4_N = 256, G4_STAGE = 24576;   // per stage: 8 KB A + 16 KB B
+
+template <bool B_KC, typename OutT>
+__global__ __launch_bounds__(512) void gemm_bf16_g4_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                           OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, EpiParams ep) {
+    constexpr int BK = 32, ST = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t tiles_n = (N + G4_N - 1) / G4_N, tiles_m = (M + GB_M - 1) / GB_M;
+    int64_t tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    if (tm >= tiles_m) return;
+    const int64_t m0 = tm * GB_M, n0 = tn * G4_N;
+    const int nk = (int)(K / BK);
+    const int wm = wave >> 2, wn = wave & 3;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // A tile: 8 wave-instructions (1 per wave); B tile: 16 (2 per wave)
+    uint32_t offA, offB[2];
+    {
+        const int row = wave * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        int64_t gr = m0 + row;
+        if (gr > M - 1) gr = M - 1;
+        offA = (uint32_t)((gr * lda + c * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = wave * 2 + i;
+        if constexpr (B_KC) {
+            const int row = j * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+            int64_t gr = n0 + row;
+            if (gr > N - 1) gr = N - 1;
+            offB[i] = (uint32_t)((gr * ldb + c * 8) * 2);
+        } else {
+            // [32 k][256 rows] = 512 B per k-row: wave-instruction j covers k-rows 2j, 2j+1
+            const int k = j * 2 + (lane >> 5), p16 = lane & 31;
+            const int g = (p16 >> 1) ^ swz_k(k);
+            int64_t gr = n0 + (g * 2 + (p16 & 1)) * 8;
+            if (gr > N - 1) gr = ((N - 1) >> 3) << 3;
+            offB[i] = (uint32_t)(((int64_t)k * ldb + gr) * 2);
+        }
+    }
+    const char* gA = (const char*)A;
+    const char* gB = (const char*)B;
+    const int64_t stepA = (int64_t)BK * 2, stepB = (B_KC ? (int64_t)BK : (int64_t)BK * ldb) * 2;
+    int issued = 0;
+    auto issue_next = [&]() {
+        if (issued < nk) {
+            char* st = smem + (issued % ST) * G4_STAGE;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + offA),
+                                             (__attribute__((address_space(3))) void*)(st + wave * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + offB[i]),
+                                                 (__attribute__((address_space(3))) void*)(st + 8192 + (wave * 2 + i) * 1024), 16, 0, 0);
+            gA += stepA;
+            gB += stepB;
+            ++issued;
+        }
+    };
+    issue_next(); issue_next(); issue_next();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int newer = issued - 1 - kt;          // tiles issued after kt
+        if (newer >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (newer == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_next();
+        const char* la = smem + (kt % ST) * G4_STAGE;
+        const char* lb = la + 8192;
+        bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = lfrag2<true, BK>(la, wm * 64 + i * 16, 0, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (B_KC) fb[j] = lfrag2<true, BK>(lb, wn * 64 + j * 16, 0, lane);
+            else {
+                const int rbase = wn * 64 + j * 16, i2 = lane & 15, g = rbase >> 4;
+                bf16x8 v;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k = (lane >> 4) * 8 + h * 4 + (i2 >> 2);
+                    const char* p = lb + k * 512 + ((g ^ swz_k(k)) << 5) + ((i2 & 3) << 3);
+                    short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
+                    bf16x4 tb = __builtin_bit_cast(bf16x4, t);
+                    v[h * 4 + 0] = tb[0]; v[h * 4 + 1] = tb[1]; v[h * 4 + 2] = tb[2]; v[h * 4 + 3] = tb[3];
+                }
+                fb[j] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    // epilogue: two 128x128 halves (columns [0,128) = waves wn<2, [128,256) = wn>=2) through 64 KB of LDS each
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        if ((wn >> 1) == half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = wm * 64 + i * 16 + (lane & 15);
+                    const int chunk = ((wn & 1) * 64 + j * 16 + (lane >> 4) * 4) >> 2;
+                    *(f32x4*)(smem + row * 512 + ((chunk ^ (row & 7)) << 4)) = acc[i][j];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + 512 * it;   // 0..2047 : row = idx >> 4, 8-column group = idx & 15
+            const int row = idx >> 4, grp = idx & 15;
+            const int64_t m = m0 + row, n = n0 + half * 128 + grp * 8;
+            if (m < M && n < N) {
+                const f32x4 lo = *(const f32x4*)(smem + row * 512 + (((2 * grp) ^ (row & 7)) << 4));
+                const f32x4 hi = *(const f32x4*)(smem + row * 512 + (((2 * grp + 1) ^ (row & 7)) << 4));
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                epi_row8<OutT>(ep, C, m, n, v, N);
+            }
+        }
+    }
+}
+
+template <bool B_KC, typename OutT>
+static void launch_g4(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int64_t M, int64_t N, int64_t K,
+                      const EpiParams& ep) {
+    auto kfn = gemm_bf16_g4_kernel<B_KC, OutT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G4_STAGE);
+        attr_set = true;
+    }
+    const int64_t tiles_m8 = cdiv64(cdiv64(M, GB_M), 8) * 8, tiles_n = cdiv64(N, G4_N);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(tiles_m8 * tiles_n)), dim3(512), 4 * G4_STAGE, st, A, lda, B, ldb, (OutT*)C, M, N, K, ep);
+}
+
 static int g_glds_bk = -1;   // EMO_GEMM_BK=32|64 forces one LDS-DMA geometry (default: per-shape heuristic)
 static int glds_bk() {
     if (g_glds_bk < 0) {
@@ -999,15 +1155,27 @@ static void dispatch_glds2(bool akc, bool bkc, dim3 grid, hipStream_t st, const 
 template <typename OutT>
 static void dispatch_glds(bool akc, bool bkc, dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C,
                           int64_t M, int64_t N, int64_t K, int64_t kps, const EpiParams& ep) {
-    // measured r01 (tools/bench_gemm.py): the 4-stage ring of 32-deep tiles wins for short reductions (K=512: 494 vs 459
-    // TFLOP/s), the double buffer of full 128-B lines for long ones (K=2048: 770 vs 700) and for MN-contiguous B (dgrad).
+    // measured r01 (tools/bench_gemm.py, MI355X): the per-tile fixed cost (prologue latency + epilogue, ~4-5 us) is what
+    // limits the K=512 GEMMs, so OCCUPANCY wins over prefetch depth: a 3-stage ring of 32-deep tiles (48 KB LDS, 3 blocks
+    // per CU) beats the 4-stage ring (64 KB, 2 blocks) by 13-16 % (qkv 575 vs 509, ffn1 659 vs 568 TFLOP/s); for the
+    // long reduction (K=2048) the double buffer of full 128-B lines is best (842 vs 796); for MN-contiguous B (dgrad)
+    // the 2-stage ring of 32-deep tiles (32 KB) is best.  EMO_GEMM_ST / EMO_GEMM_BK / EMO_GEMM_PF force one geometry.
     const bool can64 = (kps % 64) == 0 && (K % 64) == 0;
-    const int bk = g_glds_bk_forced() ? glds_bk() : ((K > 1024 || !bkc) ? 64 : 32);
-    static const bool use_pf = getenv("EMO_GEMM_NO_PF") == nullptr;
-    if (bk == 64 && can64) dispatch_glds2<OutT, 64, 2>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-    else if (use_pf && akc && bkc) launch_glds_pf<true, true, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-    else if (use_pf && akc && !bkc) launch_glds_pf<true, false, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-    else dispatch_glds2<OutT, 32, 4>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    static const int st_env = getenv("EMO_GEMM_ST") ? atoi(getenv("EMO_GEMM_ST")) : 0;
+    static const bool use_pf = getenv("EMO_GEMM_PF") != nullptr;
+    if (st_env == 4 || g_glds_bk_forced() || use_pf) {
+        const int bk = g_glds_bk_forced() ? glds_bk() : 32;
+        if (bk == 64 && can64) dispatch_glds2<OutT, 64, 2>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+        else if (use_pf && akc && bkc) launch_glds_pf<true, true, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+        else if (use_pf && akc && !bkc) launch_glds_pf<true, false, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+        else dispatch_glds2<OutT, 32, 4>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+        return;
+    }
+    if (st_env == 3) { dispatch_glds2<OutT, 32, 3>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep); return; }
+    if (st_env == 2) { dispatch_glds2<OutT, 32, 2>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep); return; }
+    if (bkc && K > 1024 && can64) dispatch_glds2<OutT, 64, 2>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    else if (bkc) dispatch_glds2<OutT, 32, 3>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    else dispatch_glds2<OutT, 32, 2>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
 }
 
 static int g_gemm_variant = -1;   // EMO_GEMM_VARIANT: 1 = register-staged v1, 2 = LDS-DMA ring (default when eligible)
@@ -1120,7 +1288,13 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         const int64_t spanA = (rowsA * lda + (a_trans ? M : 0)) * 2, spanB = (rowsB * ldb + (b_trans ? N : 0)) * 2;
         const bool span_ok = spanA < (int64_t)0xFFFF0000 && spanB < (int64_t)0xFFFF0000;
         const bool glds_ok = !safe && variant >= 2 && (akc || variant >= 3) && (K % G2_BK) == 0 && (kps % G2_BK) == 0 && M >= 8 && N >= 8 && span_ok;
-        if (use_g3 && span_ok && (kps % G3_K) == 0) {
+        static const bool g4_on = getenv("EMO_GEMM_G4") != nullptr;   // 128x256 tile: measured no faster than 128x128 (r01) -> opt-in
+        const bool use_g4 = g4_on && !safe && variant >= 2 && akc && splits == 1 && !accumulate && (K % G2_BK) == 0 && (N % G4_N) == 0 && span_ok &&
+                            cdiv64(M, GB_M) * (N / G4_N) >= 512 && K <= 1024;
+        if (use_g4) {
+            if (dtype_out == EMO_F32) { if (bkc) launch_g4<true, float>(st, a, lda, b, ldb, C, M, N, K, ep); else launch_g4<false, float>(st, a, lda, b, ldb, C, M, N, K, ep); }
+            else { if (bkc) launch_g4<true, bf16_t>(st, a, lda, b, ldb, C, M, N, K, ep); else launch_g4<false, bf16_t>(st, a, lda, b, ldb, C, M, N, K, ep); }
+        } else if (use_g3 && span_ok && (kps % G3_K) == 0) {
             if (dtype_out == EMO_F32) dispatch_g3<float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
             else dispatch_g3<bf16_t>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
         } else if (use_g3) {
