@@ -149,12 +149,25 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
 #pragma unroll
     for (int i = 0; i < NTS_W; ++i) sacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    RowPrefetch<CT, DH, DHP, C, FT> pq, pk, pv;
+    {
+        const int v0 = (int)(T < C ? T : C);
+        pq.load(qb, ld, v0, tid);
+        pk.load(kb, ld, v0, tid);
+        pv.load(vb, ld, v0, tid);
+    }
     for (int64_t t0 = 0; t0 < T; t0 += C) {
         const int valid = (int)((T - t0) < C ? (T - t0) : C);
         __syncthreads();
-        load_rows<CT, DH, DHP, FT>(Xq, LDX, qb + t0 * ld, ld, C, valid, tid);
-        load_rows<CT, DH, DHP, FT>(Xk, LDX, kb + t0 * ld, ld, C, valid, tid);
-        load_rows_T<CT, DH, FT>(VT, LDC, vb + t0 * ld, ld, C, valid, tid);
+        pq.store_rows(Xq, LDX, tid);
+        pk.store_rows(Xk, LDX, tid);
+        pv.store_T(VT, LDC, tid);
+        if (t0 + C < T) {                          // next chunk's q/k/v stay in flight during this chunk's compute
+            const int vn = (int)((T - t0 - C) < C ? (T - t0 - C) : C);
+            pq.load(qb + (t0 + C) * ld, ld, vn, tid);
+            pk.load(kb + (t0 + C) * ld, ld, vn, tid);
+            pv.load(vb + (t0 + C) * ld, ld, vn, tid);
+        }
         __syncthreads();
         row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
         row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
@@ -283,6 +296,47 @@ __device__ __forceinline__ void load_grads(CT* G, int ldg, CT* GT, int ldgt, flo
     if (part == 0) dD[r] = -dot * inv;
 }
 
+// prefetched variant of load_grads: dout / out rows arrive through RowPrefetch registers, den through `dn`
+template <typename CT, int DH, int DHP, int C, int NI_>
+__device__ __forceinline__ void store_grads(const RowPrefetch<CT, DH, DHP, C, FT>& pg, const RowPrefetch<CT, DH, DHP, C, FT>& po,
+                                            const float (&dn)[NI_], int valid, CT* G, int ldg, CT* GT, int ldgt, float* dD, int tid) {
+    typedef RowPrefetch<CT, DH, DHP, C, FT> P;
+#pragma unroll
+    for (int i = 0; i < P::NI; ++i) {
+        const int it = tid + FT * i;
+        const bool act = it < C * P::CH;
+        const int row = act ? it / P::CH : 0, c = (it % P::CH) * P::VE;
+        const float inv = (act && row < valid) ? 1.f / dn[i] : 0.f;
+        float dot = 0.f, g[P::VE];
+#pragma unroll
+        for (int e = 0; e < P::VE; ++e) { g[e] = to_f32<CT>(pg.r[i][e]); dot += g[e] * to_f32<CT>(po.r[i][e]); }
+#pragma unroll
+        for (int o = P::CH >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        if (act) {
+            if (c == 0) dD[row] = -dot * inv;
+#pragma unroll
+            for (int e = 0; e < P::VE; ++e) {
+                const CT gn = from_f32<CT>(g[e] * inv);
+                G[row * ldg + c + e] = gn;
+                if (GT) GT[(c + e) * ldgt + row] = gn;
+            }
+        }
+    }
+    if constexpr (DHP > DH) {
+        for (int it = tid; it < C * (DHP - DH); it += FT) G[(it / (DHP - DH)) * ldg + DH + it % (DHP - DH)] = from_f32<CT>(0.f);
+    }
+}
+template <typename CT, int DH, int DHP, int C, int NI_>
+__device__ __forceinline__ void load_den(float (&dn)[NI_], const float* __restrict__ den, int valid, int tid) {
+    typedef RowPrefetch<CT, DH, DHP, C, FT> P;
+#pragma unroll
+    for (int i = 0; i < P::NI; ++i) {
+        const int it = tid + FT * i;
+        const int row = it / P::CH;
+        dn[i] = (it < C * P::CH && row < valid) ? den[row] : 1.f;
+    }
+}
+
 // a = dPhi * Phi ; Adiff[t][m] = a+ - a- ; sumA[t] += a+ + a-   (lane owns f0..f0+3 (plus) and MF+f0.. (minus) of column t)
 template <typename CT, int MF>
 __device__ __forceinline__ void jac_epilogue(const f32x4& accP, const f32x4& accM, const CT* Ff, int ldf, CT* Adiff, int lda, float* sumA,
@@ -389,15 +443,31 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
 #pragma unroll
     for (int i = 0; i < NTS_W; ++i) sacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    typedef RowPrefetch<CT, DH, DHP, C, FT> PF;
+    PF pq, pk, pv, pg, po;
+    float dn[PF::NI];
+    {
+        const int v0 = (int)(T < C ? T : C);
+        pq.load(qb, ld, v0, tid); pk.load(kb, ld, v0, tid); pv.load(vb, ld, v0, tid);
+        pg.load(gb, ld_out, v0, tid); po.load(ob, ld_out, v0, tid);
+        load_den<CT, DH, DHP, C>(dn, dg, v0, tid);
+    }
     for (int64_t t0 = 0; t0 < T; t0 += C) {
         const int valid = (int)((T - t0) < C ? (T - t0) : C);
         __syncthreads();
-        load_rows<CT, DH, DHP, FT>(Xq, LDX, qb + t0 * ld, ld, C, valid, tid);
-        load_rows<CT, DH, DHP, FT>(Xk, LDX, kb + t0 * ld, ld, C, valid, tid);
-        load_rows<CT, DH, DHP, FT>(Vr, LDX, vb + t0 * ld, ld, C, valid, tid);
-        load_rows_T<CT, DH, FT>(VT, LDC, vb + t0 * ld, ld, C, valid, tid);
-        load_grads<CT, DH, DHP, C>(G, LDX, (CT*)nullptr, 0, dD, gb + t0 * ld_out, ob + t0 * ld_out, ld_out, dg + t0, valid, tid);
+        pq.store_rows(Xq, LDX, tid);
+        pk.store_rows(Xk, LDX, tid);
+        pv.store_rows(Vr, LDX, tid);
+        pv.store_T(VT, LDC, tid);
+        store_grads<CT, DH, DHP, C>(pg, po, dn, valid, G, LDX, (CT*)nullptr, 0, dD, tid);
         for (int i = tid; i < C; i += FT) sumA[i] = 0.f;
+        if (t0 + C < T) {
+            const int64_t tn_ = t0 + C;
+            const int vn = (int)((T - tn_) < C ? (T - tn_) : C);
+            pq.load(qb + tn_ * ld, ld, vn, tid); pk.load(kb + tn_ * ld, ld, vn, tid); pv.load(vb + tn_ * ld, ld, vn, tid);
+            pg.load(gb + tn_ * ld_out, ld_out, vn, tid); po.load(ob + tn_ * ld_out, ld_out, vn, tid);
+            load_den<CT, DH, DHP, C>(dn, dg + tn_, vn, tid);
+        }
         __syncthreads();
         row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
         row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
@@ -537,15 +607,31 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
     for (int i = 0; i < NTS_W; ++i) racc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int64_t nchunks = (T + C - 1) / C;
+    typedef RowPrefetch<CT, DH, DHP, C, FT> PF;
+    PF pq, pk, pv, pg, po;
+    float dn[PF::NI];
+    {
+        const int64_t tl_ = (nchunks - 1) * C;
+        const int v0 = (int)(T - tl_);
+        pq.load(qb + tl_ * ld, ld, v0, tid); pk.load(kb + tl_ * ld, ld, v0, tid); pv.load(vb + tl_ * ld, ld, v0, tid);
+        pg.load(gb + tl_ * ld_out, ld_out, v0, tid); po.load(ob + tl_ * ld_out, ld_out, v0, tid);
+        load_den<CT, DH, DHP, C>(dn, dg + tl_, v0, tid);
+    }
     for (int64_t ci = nchunks - 1; ci >= 0; --ci) {
         const int64_t t0 = ci * C;
         const int valid = (int)((T - t0) < C ? (T - t0) : C);
         __syncthreads();
-        load_rows<CT, DH, DHP, FT>(Xq, LDX, qb + t0 * ld, ld, C, valid, tid);
-        load_rows<CT, DH, DHP, FT>(Xk, LDX, kb + t0 * ld, ld, C, valid, tid);
-        load_rows<CT, DH, DHP, FT>(Vr, LDX, vb + t0 * ld, ld, C, valid, tid);
-        load_grads<CT, DH, DHP, C>(G, LDX, GT, LDC, dD, gb + t0 * ld_out, ob + t0 * ld_out, ld_out, dg + t0, valid, tid);
+        pq.store_rows(Xq, LDX, tid);
+        pk.store_rows(Xk, LDX, tid);
+        pv.store_rows(Vr, LDX, tid);
+        store_grads<CT, DH, DHP, C>(pg, po, dn, valid, G, LDX, GT, LDC, dD, tid);
         for (int i = tid; i < C; i += FT) sumA[i] = 0.f;
+        if (ci > 0) {                                  // previous (earlier) chunk: full, stays in flight during this chunk's compute
+            const int64_t tn_ = t0 - C;
+            pq.load(qb + tn_ * ld, ld, C, tid); pk.load(kb + tn_ * ld, ld, C, tid); pv.load(vb + tn_ * ld, ld, C, tid);
+            pg.load(gb + tn_ * ld_out, ld_out, C, tid); po.load(ob + tn_ * ld_out, ld_out, C, tid);
+            load_den<CT, DH, DHP, C>(dn, dg + tn_, C, tid);
+        }
         __syncthreads();
         row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
         row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);

@@ -122,3 +122,54 @@ __device__ __forceinline__ float dot_contig(const CT* p, const float* w) {
     }
     return s;
 }
+
+// Register prefetch of one [ROWS x NC] row tile (one 16-B vector per item, item -> thread round-robin): the global
+// loads of chunk c+1 are issued right after chunk c's images are written and stay in flight during chunk c's compute.
+template <typename CT, int NC, int NCP, int ROWS, int NTHR>
+struct RowPrefetch {
+    static constexpr int VE = 16 / sizeof(CT), CH = NC / VE, NI = (ROWS * CH + NTHR - 1) / NTHR;
+    CT r[NI][VE];
+    __device__ __forceinline__ void load(const CT* __restrict__ src, int64_t ld_src, int valid, int tid) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int it = tid + NTHR * i;
+            const int row = it / CH, c = (it % CH) * VE;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) r[i][e] = from_f32<CT>(0.f);
+            if (it < ROWS * CH && row < valid) {
+                if constexpr (sizeof(CT) == 2) *(bf16x8*)r[i] = *(const bf16x8*)(src + (int64_t)row * ld_src + c);
+                else *(f32x4*)r[i] = *(const f32x4*)(src + (int64_t)row * ld_src + c);
+            }
+        }
+    }
+    // row-major image [ROWS][ld] (k = column); pad columns NC..NCP are (re)zeroed
+    __device__ __forceinline__ void store_rows(CT* img, int ld, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int it = tid + NTHR * i;
+            if (it < ROWS * CH) {
+                const int row = it / CH, c = (it % CH) * VE;
+                if constexpr (sizeof(CT) == 2) *(bf16x8*)(img + row * ld + c) = *(const bf16x8*)r[i];
+                else {
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) img[row * ld + c + e] = r[i][e];
+                }
+            }
+        }
+        if constexpr (NCP > NC) {
+            for (int it = tid; it < ROWS * (NCP - NC); it += NTHR) img[(it / (NCP - NC)) * ld + NC + it % (NCP - NC)] = from_f32<CT>(0.f);
+        }
+    }
+    // transposed image [NC][ld] (k = row index)
+    __device__ __forceinline__ void store_T(CT* img, int ld, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int it = tid + NTHR * i;
+            if (it < ROWS * CH) {
+                const int row = it / CH, c = (it % CH) * VE;
+#pragma unroll
+                for (int e = 0; e < VE; ++e) img[(c + e) * ld + row] = r[i][e];
+            }
+        }
+    }
+};
