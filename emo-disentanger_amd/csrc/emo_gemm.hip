@@ -354,11 +354,12 @@ __device__ __forceinline__ int swz_k(int k) { return (k & 3) | (((k >> 3) & 1) <
 
 // ---- global -> registers: 4 x 16 B per thread per operand
 // K-contig operand: tile [128 rows][64 k]; chunk c = 8 k's.  idx = tid + 256*i : row = idx>>3, chunk = idx&7
-template <bool KC>
+template <bool KC, int BKT = GB_K>
 __device__ __forceinline__ void gload_tile(const bf16_t* __restrict__ P, int64_t ld, int64_t row0, int64_t nrows,
-                                           int64_t k0, int64_t kend, int tid, bf16x8 (&r)[4]) {
+                                           int64_t k0, int64_t kend, int tid, bf16x8 (&r)[BKT / 16]) {
+    static_assert(BKT == 64 || !KC, "the 32-deep register-staged tile is only built for MN-contiguous operands");
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BKT / 16; ++i) {
         const int idx = tid + 256 * i;
         bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
         if constexpr (KC) {
@@ -382,10 +383,10 @@ __device__ __forceinline__ void gload_tile(const bf16_t* __restrict__ P, int64_t
     }
 }
 
-template <bool KC>
-__device__ __forceinline__ void lstore_tile(char* lds, int tid, const bf16x8 (&r)[4]) {
+template <bool KC, int BKT = GB_K>
+__device__ __forceinline__ void lstore_tile(char* lds, int tid, const bf16x8 (&r)[BKT / 16]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BKT / 16; ++i) {
         const int idx = tid + 256 * i;
         if constexpr (KC) {
             const int row = idx >> 3, ch = idx & 7;
@@ -429,12 +430,13 @@ __device__ __forceinline__ bf16x8 lfrag(const char* lds, int rbase, int ks, int 
     }
 }
 
-template <bool A_KC, bool B_KC, bool SAFE, typename OutT>
+template <bool A_KC, bool B_KC, bool SAFE, typename OutT, int BKT = GB_K>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                         const bf16_t* __restrict__ B, int64_t ldb,
                                                         OutT* __restrict__ C, int64_t M, int64_t N, int64_t K,
                                                         int64_t k_per_split, EpiParams ep) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (16 KB A + 16 KB B)
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (A tile + B tile), 128 x BKT bf16 each
+    constexpr int OPB = 128 * BKT * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t tiles_n = (N + GB_N - 1) / GB_N, tiles_m = (M + GB_M - 1) / GB_M;
     int64_t tm, tn, split = 0;
@@ -452,23 +454,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    bf16x8 ra[4], rb[4];
-    gload_tile<A_KC>(A, lda, m0, M, kbeg, kend, tid, ra);
-    gload_tile<B_KC>(B, ldb, n0, N, kbeg, kend, tid, rb);
-    lstore_tile<A_KC>(smem, tid, ra);
-    lstore_tile<B_KC>(smem + 16384, tid, rb);
+    bf16x8 ra[BKT / 16], rb[BKT / 16];
+    gload_tile<A_KC, BKT>(A, lda, m0, M, kbeg, kend, tid, ra);
+    gload_tile<B_KC, BKT>(B, ldb, n0, N, kbeg, kend, tid, rb);
+    lstore_tile<A_KC, BKT>(smem, tid, ra);
+    lstore_tile<B_KC, BKT>(smem + OPB, tid, rb);
     __syncthreads();
     int cur = 0;
-    for (int64_t k0 = kbeg; k0 < kend; k0 += GB_K) {
-        const bool more = (k0 + GB_K) < kend;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BKT) {
+        const bool more = (k0 + BKT) < kend;
         if (more) {
-            gload_tile<A_KC>(A, lda, m0, M, k0 + GB_K, kend, tid, ra);
-            gload_tile<B_KC>(B, ldb, n0, N, k0 + GB_K, kend, tid, rb);
+            gload_tile<A_KC, BKT>(A, lda, m0, M, k0 + BKT, kend, tid, ra);
+            gload_tile<B_KC, BKT>(B, ldb, n0, N, k0 + BKT, kend, tid, rb);
         }
-        const char* la = smem + cur * 32768;
-        const char* lb = la + 16384;
+        const char* la = smem + cur * 2 * OPB;
+        const char* lb = la + OPB;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BKT / 32; ++ks) {
             bf16x8 fa[4], fb[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[i] = lfrag<A_KC, SAFE>(la, wm * 64 + i * 16, ks, lane);
@@ -481,14 +483,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            char* na = smem + (cur ^ 1) * 32768;
-            lstore_tile<A_KC>(na, tid, ra);
-            lstore_tile<B_KC>(na + 16384, tid, rb);
+            char* na = smem + (cur ^ 1) * 2 * OPB;
+            lstore_tile<A_KC, BKT>(na, tid, ra);
+            lstore_tile<B_KC, BKT>(na + OPB, tid, rb);
         }
         __syncthreads();
         cur ^= 1;
     }
-    epilogue_tile128<OutT>(ep, C, m0, n0, M, N, acc, smem, tid, wm, wn, lane);
+    epilogue_tile128<OutT, (BKT == 64 ? 1 : 2)>(ep, C, m0, n0, M, N, acc, smem, tid, wm, wn, lane);
 }
 
 // ================================================================================================
@@ -1187,6 +1189,13 @@ static int gemm_variant() {
     return g_gemm_variant;
 }
 
+template <typename OutT>
+static void launch_bf16_tn32(dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int64_t M, int64_t N,
+                             int64_t K, int64_t kps, const EpiParams& ep) {
+    auto kfn = gemm_bf16_kernel<false, false, false, OutT, 32>;
+    hipLaunchKernelGGL(kfn, grid, dim3(256), 32768, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
+}
+
 template <bool SAFE, typename OutT>
 static void dispatch_bf16(bool akc, bool bkc, dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B,
                           int64_t ldb, void* C, int64_t M, int64_t N, int64_t K, int64_t kps, const EpiParams& ep) {
@@ -1253,8 +1262,8 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         const int64_t max_splits = K / (4 * BKt);
         if (splits > max_splits) splits = max_splits;
         if (splits >= 4) {                       // one K-split per XCD round (splitk_coords): keep the 8 XCDs evenly loaded
-            const int64_t r8 = cdiv64(splits, 8) * 8;
-            splits = r8 <= max_splits ? r8 : (splits / 8) * 8 > 0 ? (splits / 8) * 8 : splits;
+            const int64_t r8 = cdiv64(splits, 8) * 8;   // (a rounds x steps cost model that preferred 32 splits measured slower: atomics)
+            splits = r8 <= max_splits ? r8 : ((splits / 8) * 8 > 0 ? (splits / 8) * 8 : splits);
         }
         if (splits < 1) splits = 1;
     }
@@ -1303,6 +1312,8 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         } else if (glds_ok) {
             if (dtype_out == EMO_F32) dispatch_glds<float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
             else dispatch_glds<bf16_t>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
+        } else if (!akc && !bkc && !safe && getenv("EMO_GEMM_TN32") != nullptr && dtype_out == EMO_F32) {
+            launch_bf16_tn32<float>(grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
         } else if (dtype_out == EMO_F32) {   // register-staged v1 (same 128^2 grid; any K, predicated edges)
             if (safe) dispatch_bf16<true, float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
             else dispatch_bf16<false, float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
