@@ -209,17 +209,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const T* __restrict__ dres,
                                                             T* __restrict__ dx, T* __restrict__ dx_drop, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int64_t M, int64_t D, DropCtx drop) {
-    __shared__ float red[2][4][256 * NV];
+                                                            float* __restrict__ dbeta, float* __restrict__ dcol, int64_t M, int64_t D, DropCtx drop) {
+    __shared__ float red[3][4][256 * NV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float g[NV][4], dg[NV][4], db[NV][4];
+    float g[NV][4], dg[NV][4], db[NV][4], dc[NV][4];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int64_t c = lane * 4 + 256 * j;
         if (c < D) Vec4<float>::load(gamma + c, g[j]);
         else g[j][0] = g[j][1] = g[j][2] = g[j][3] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dg[j][i] = db[j][i] = 0.f;
+        for (int i = 0; i < 4; ++i) dg[j][i] = db[j][i] = dc[j][i] = 0.f;
     }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
@@ -257,12 +257,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = rs * (gy[j][i] - s1 - xh[j][i] * s2) + r[i];
                 Vec4<T>::store(dx + row * D + c, o);
+                if (dcol && !dx_drop) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dc[j][i] += to_f32<T>(from_f32<T>(o[i]));
+                }
                 if (dx_drop) {
                     // the consumer re-reads dx in storage precision: mask the ROUNDED value
                     float od[4], dm[4];
                     drop_mult4(drop, (uint64_t)(row * D + c), dm);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) od[i] = to_f32<T>(from_f32<T>(o[i])) * dm[i];
+                    for (int i = 0; i < 4; ++i) { od[i] = to_f32<T>(from_f32<T>(o[i])) * dm[i]; dc[j][i] += to_f32<T>(from_f32<T>(od[i])); }
                     Vec4<T>::store(dx_drop + row * D + c, od);
                 }
             }
@@ -274,19 +278,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         for (int i = 0; i < 4; ++i) {
             red[0][wave][j * 256 + lane * 4 + i] = dg[j][i];
             red[1][wave][j * 256 + lane * 4 + i] = db[j][i];
+            red[2][wave][j * 256 + lane * 4 + i] = dc[j][i];
         }
     __syncthreads();
     for (int c = threadIdx.x; c < 256 * NV; c += 256) {
         if (c < D) {
             atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
             atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+            if (dcol) atomicAdd(dcol + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
         }
     }
 }
 
 extern "C" int emo_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                                 const void* dres, void* dx, void* dx_drop, float* dgamma, float* dbeta, int dtype, int64_t M,
-                                 int64_t D, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
+                                 const void* dres, void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dcol, int dtype,
+                                 int64_t M, int64_t D, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
     EMO_CHECK(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "emo_layernorm_bwd: null pointer");
     EMO_CHECK((D & 3) == 0 && D <= 1024, "emo_layernorm_bwd: D must be a multiple of 4 and <= 1024 (got %lld)", (long long)D);
     hipStream_t st = (hipStream_t)stream;
@@ -294,7 +300,7 @@ extern "C" int emo_layernorm_bwd(const void* dy, const void* x, const float* gam
     if (blocks > 1024) blocks = 1024;
     dim3 grid((unsigned)blocks);
     DropCtx drop = make_drop(p_drop, seed, offset);
-#define LN_BWD(TT, NVV) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NVV>), grid, dim3(256), 0, st, (const TT*)dy, (const TT*)x, gamma, mean, rstd, (const TT*)dres, (TT*)dx, (TT*)dx_drop, dgamma, dbeta, M, D, drop)
+#define LN_BWD(TT, NVV) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NVV>), grid, dim3(256), 0, st, (const TT*)dy, (const TT*)x, gamma, mean, rstd, (const TT*)dres, (TT*)dx, (TT*)dx_drop, dgamma, dbeta, dcol, M, D, drop)
     const int nv = (int)cdiv64(D, 256);
     if (dtype == EMO_F32) { if (nv <= 1) LN_BWD(float, 1); else if (nv == 2) LN_BWD(float, 2); else LN_BWD(float, 4); }
     else { if (nv <= 1) LN_BWD(bf16_t, 1); else if (nv == 2) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4); }

@@ -147,10 +147,12 @@ def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save):
     return out
 
 
-def _wgrad(ps, wname, bname, dy, xin, fused_rows=None):
-    """dW[N,K] += dy[M,N]^T xin[M,K] ; db[N] += colsum(dy)   (nn.Linear layout)."""
+def _wgrad(ps, wname, bname, dy, xin, fused_rows=None, bias_done=False):
+    """dW[N,K] += dy[M,N]^T xin[M,K] ; db[N] += colsum(dy)   (nn.Linear layout).  bias_done: the column sums were already
+    accumulated by the LayerNorm-backward kernel that produced dy."""
     ops.gemm(dy, xin, a_trans=True, b_trans=True, out=ps.g(wname, fused_rows), accumulate=True)
-    ops.colsum(dy, out=ps.g(bname, fused_rows), accumulate=True)
+    if not bias_done:
+        ops.colsum(dy, out=ps.g(bname, fused_rows), accumulate=True)
 
 
 def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
@@ -158,18 +160,18 @@ def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
     D = dout.shape[1]
     inv = 1.0 / (1.0 - p) if p > 0 else 1.0
     g2, dyd = ops.layernorm_bwd(dout, s['x2'], ps.f32(pfx + 'norm2.weight'), s['m2'], s['r2'], ps.g(pfx + 'norm2.weight'), ps.g(pfx + 'norm2.bias'),
-                                want_drop=p > 0, p_drop=p, seed=seed, offset=off + 3)
+                                want_drop=p > 0, p_drop=p, seed=seed, offset=off + 3, dcol=ps.g(pfx + 'linear2.bias'))
     if dyd is None:
         dyd = g2
-    _wgrad(ps, pfx + 'linear2.weight', pfx + 'linear2.bias', dyd, s['f'])
+    _wgrad(ps, pfx + 'linear2.weight', pfx + 'linear2.bias', dyd, s['f'], bias_done=True)
     df = ops.gemm(dyd, ps.w(pfx + 'linear2.weight'), b_trans=True, mul_aux=s['f'], mul_mode=ops.MUL_NONZERO, mul_scale=inv)
     _wgrad(ps, pfx + 'linear1.weight', pfx + 'linear1.bias', df, s['h1'])
     dh1 = ops.gemm(df, ps.w(pfx + 'linear1.weight'), b_trans=True, residual=g2)
     g1, da = ops.layernorm_bwd(dh1, s['x1'], ps.f32(pfx + 'norm1.weight'), s['m1'], s['r1'], ps.g(pfx + 'norm1.weight'), ps.g(pfx + 'norm1.bias'),
-                               want_drop=p > 0, p_drop=p, seed=seed, offset=off + 1)
+                               want_drop=p > 0, p_drop=p, seed=seed, offset=off + 1, dcol=ps.g(pfx + 'attention.out_projection.bias'))
     if da is None:
         da = g1
-    _wgrad(ps, pfx + 'attention.out_projection.weight', pfx + 'attention.out_projection.bias', da, s['attn'])
+    _wgrad(ps, pfx + 'attention.out_projection.weight', pfx + 'attention.out_projection.bias', da, s['attn'], bias_done=True)
     dattn = ops.gemm(da, ps.w(pfx + 'attention.out_projection.weight'), b_trans=True)
     qkv = s['qkv']
     dq, dk, dv = ops.favor_attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], s['omega'], s['attn'], dattn, s['den'], B, T, H)

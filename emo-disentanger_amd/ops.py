@@ -90,13 +90,13 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, want_drop=False, p_drop=0.0, seed=0, offset=0):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, want_drop=False, p_drop=0.0, seed=0, offset=0, dcol=None):
     M, D = x.shape
     assert dy.is_contiguous() and x.is_contiguous() and (dres is None or dres.is_contiguous())
     dx = torch.empty_like(x)
     dxd = torch.empty_like(x) if want_drop else None
     check(lib.emo_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dxd), ptr(dgamma), ptr(dbeta),
-                                dtype_code(x.dtype), M, D, p_drop, seed, offset, stream()))
+                                ptr(dcol), dtype_code(x.dtype), M, D, p_drop, seed, offset, stream()))
     return dx, dxd
 
 

@@ -91,11 +91,13 @@ int emo_embed_bwd(const int64_t* tok, const int64_t* seg, const void* dout, int 
  * Replaces nn.LayerNorm norm1/norm2 (fast-transformers TransformerEncoderLayer) and ln_1/ln_2 (HF GPT2Block). */
 int emo_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                       float* rstd, int dtype, int64_t M, int64_t D, float eps, emo_stream_t stream);
-/* dx = LN'(dy) (+ dres);  dx_drop (optional) = dx * dropmask(p,seed,offset);  dgamma/dbeta += (atomic) */
+/* dx = LN'(dy) (+ dres);  dx_drop (optional) = dx * dropmask(p,seed,offset);  dgamma/dbeta += (atomic);
+ * dcol (optional, fp32 [D]) += column sums of dx_drop (of dx when dx_drop is NULL) — the bias gradient of the Linear
+ * whose output fed this LayerNorm's residual branch, fused here to save one pass over the tensor. */
 int emo_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                       const float* rstd, const void* dres, void* dx, void* dx_drop, float* dgamma,
-                      float* dbeta, int dtype, int64_t M, int64_t D, float p_drop, uint64_t seed,
-                      uint64_t offset, emo_stream_t stream);
+                      float* dbeta, float* dcol, int dtype, int64_t M, int64_t D, float p_drop,
+                      uint64_t seed, uint64_t offset, emo_stream_t stream);
 /* out = x * dropmask  (backward of a dropout whose forward was fused in a GEMM epilogue) */
 int emo_dropout_apply(const void* x, void* out, int dtype, int64_t n, float p_drop, uint64_t seed,
                       uint64_t offset, emo_stream_t stream);

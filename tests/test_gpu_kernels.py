@@ -167,8 +167,10 @@ def test_layernorm_fwd_bwd(dt, D):
     dy, dres = _r(M, D, seed=4, dt=dt), _r(M, D, seed=5, dt=dt)
     ref.backward(dy.float())
     dg, db = torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda')
+    dcol = torch.zeros(D, device='cuda')
     dx, dxd = ops.layernorm_bwd(dy.cuda(), x.detach().to(dt).cuda(), gm.detach().cuda(), mean, rstd, dg, db, dres=dres.cuda(), want_drop=True,
-                                p_drop=0.25, seed=9, offset=2)
+                                p_drop=0.25, seed=9, offset=2, dcol=dcol)
+    _close(dcol, dxd.double().sum(0), dt, mult=4)
     _close(dx, x.grad + dres.float(), dt, mult=2)
     _close(dg, gm.grad, dt, mult=4)
     _close(db, bt.grad, dt, mult=4)
