@@ -44,42 +44,33 @@ def time_kernel(fn, iters=10, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
-def dominant_kernel_roofline(B, T):
-    """Dominant kernel by total time (rocprofv3, profiles/): the wgrad instance gemm_bf16_kernel<A_KC=0,B_KC=0,fp32 out>
-    (dW = dY^T X, reduction over the B*T tokens, both operands read through ds_read_b64_tr_b16, split-K fp32 atomics).
-    Time its per-layer launch mix [QKV, out-proj, FFN1, FFN2] with HIP events on the launch stream; algorithmic
-    FLOPs per launch = 2*M*N*K.  The forward (LDS-DMA ring) and dgrad instances are reported alongside."""
-    from emo_disentanger_amd import ops
-    M, d, f = B * T, CFG['d_model'], CFG['d_ff']
-    dev = 'cuda'
-    shapes = [('qkv', 3 * d, d), ('out', d, d), ('ffn1', f, d), ('ffn2', d, f)]
-    agg = {'wgrad': [0.0, 0.0], 'fwd': [0.0, 0.0], 'dgrad': [0.0, 0.0]}
-    per = []
-    for name, n, k in shapes:
-        x = torch.randn(M, k, device=dev).to(torch.bfloat16)
-        w = (torch.randn(n, k, device=dev) * 0.02).to(torch.bfloat16)
-        dy = torch.randn(M, n, device=dev).to(torch.bfloat16)
-        y = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
-        dx = torch.empty(M, k, device=dev, dtype=torch.bfloat16)
-        dw = torch.zeros(n, k, device=dev)
-        fl = 2.0 * M * n * k
-        t_w = time_kernel(lambda: ops.gemm(dy, x, a_trans=True, b_trans=True, out=dw, accumulate=True))
-        t_f = time_kernel(lambda: ops.gemm(x, w, out=y))
-        t_d = time_kernel(lambda: ops.gemm(dy, w, b_trans=True, out=dx))
-        for key, t in (('wgrad', t_w), ('fwd', t_f), ('dgrad', t_d)):
-            agg[key][0] += t
-            agg[key][1] += fl
-        per.append({'gemm': name, 'M': M, 'N': n, 'K': k, 'wgrad_ms': round(t_w, 4), 'fwd_ms': round(t_f, 4), 'dgrad_ms': round(t_d, 4),
-                    'wgrad_tflops': round(fl / t_w / 1e9, 1), 'fwd_tflops': round(fl / t_f / 1e9, 1), 'dgrad_tflops': round(fl / t_d / 1e9, 1)})
-        del x, w, dy, y, dx, dw
-    achieved = agg['wgrad'][1] / agg['wgrad'][0] / 1e9
+def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
+    """Dominant kernel by total time (rocprofv3 --kernel-trace --stats, profiles/): the wgrad instance
+    gemm_bf16_kernel<A_KC=0,B_KC=0,fp32 out,BK=64> (dW = dY^T X, reduction over the B*T tokens, both operands read through
+    ds_read_b64_tr_b16, split-K fp32 atomics placed per XCD).  Every launch of it inside `n_steps` real training steps is
+    bracketed by HIP events on the launch stream (in situ: same data, same cache state as the timed region);
+    achieved = sum(algorithmic FLOPs = 2*M*N*K) / sum(durations)."""
+    from emo_disentanger_amd import engine
+    engine.KERNEL_TIMING = []
+    for _ in range(n_steps):
+        step_fn()
+    torch.cuda.synchronize()
+    rec, engine.KERNEL_TIMING = engine.KERNEL_TIMING, None
+    ms = [e0.elapsed_time(e1) for e0, e1, _, _ in rec]
+    flops = sum(r[2] for r in rec)
+    abytes = sum(r[3] for r in rec)
+    tot = sum(ms)
+    achieved = flops / tot / 1e9
+    traffic = None          # HBM bytes per launch from rocprofv3 PMC passes (collected offline, committed under profiles/)
+    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_wgrad.json')
+    if os.path.exists(pmc) and B * T == 131072:
+        traffic = json.load(open(pmc)).get('traffic_bytes_per_launch')
     return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
-            'kernel': 'gemm_bf16_kernel<false,false,false,float> (wgrad dW = dY^T X over B*T tokens; per-layer mix QKV/out/FFN1/FFN2)',
-            'avg_launch_ms': round(agg['wgrad'][0] / len(shapes), 4),
-            'other_instances_tflops': {'fwd_lds_dma_ring': round(agg['fwd'][1] / agg['fwd'][0] / 1e9, 1),
-                                       'dgrad': round(agg['dgrad'][1] / agg['dgrad'][0] / 1e9, 1)},
-            'per_shape': per}
+            'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+            'kernel': 'gemm_bf16_kernel<false,false,false,float,64> (wgrad dW = dY^T X over B*T tokens)',
+            'launches_timed': len(rec), 'avg_launch_ms': round(tot / len(rec), 4),
+            'algorithmic_flops_per_launch': round(flops / len(rec)), 'algorithmic_bytes_per_launch': round(abytes / len(rec)),
+            'timing': 'HIP events around every launch of this kernel in %d real training steps (launch stream = torch current stream)' % n_steps}
 
 
 def generation_bench(model, n_streams=32, prompt=64, n_new=256, top_p=0.9, temp=1.1):
@@ -214,17 +205,15 @@ def main():
                                   'dropout 0.1, omega redraw %s, fwd+bwd+allreduce+clip+Adam' % (1 if world == 1 else 2, T, B, args.redraw),
                       'global_batch': world * B, 'seq_len': T, 'parallelism': 'dp%d' % world, 'n_token': CFG['n_token']},
            'mean_loss': round(mean_loss, 4), 'gemm_tflops_model': round(value * gemm_flops_per_token() / 1e12, 1)}
+    if not args.no_roofline:                 # every rank runs the instrumented steps (they contain the all-reduce)
+        roof = dominant_kernel_roofline(step, B, T)
+        if rank == 0:
+            out['roofline'] = roof
     if rank == 0:
         if world == 1 and not args.no_gen:
-            del batches
             out['gen'] = generation_bench(model)
             if not args.no_cpu_baseline:
                 out['gen']['cpu_baseline'] = cpu_generation_baseline()
-        if not args.no_roofline:
-            del opt
-            model._store = None
-            torch.cuda.empty_cache()
-            out['roofline'] = dominant_kernel_roofline(B, T)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(min(T, 2048))
         print(json.dumps(out), flush=True)

@@ -571,7 +571,7 @@ template <> __device__ __forceinline__ void wait_vmcnt<16>() { asm volatile("s_w
 
 // BK = 32, ST = 4 : 64 KB ring, three 32-deep tiles in flight;  BK = 64, ST = 2 : 64 KB double buffer of full 128-B lines.
 template <bool A_KC, bool B_KC, typename OutT, int BK, int ST>
-__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+__global__ __launch_bounds__(256, (ST == 2 && BK == 32) ? 4 : 2) void gemm_bf16_glds_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                              OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, int64_t k_per_split,
                                                              EpiParams ep) {
     constexpr int OPB = 128 * BK * 2, STAGE = 2 * OPB, NI = BK / 16, LPT = 2 * NI;

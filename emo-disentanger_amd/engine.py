@@ -147,10 +147,24 @@ def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save):
     return out
 
 
+KERNEL_TIMING = None   # bench.py sets this to a list to HIP-event-time every wgrad launch in situ (same stream as the launch)
+
+
+def _timed_wgrad(a, b, out):
+    if KERNEL_TIMING is None:
+        ops.gemm(a, b, a_trans=True, b_trans=True, out=out, accumulate=True)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.gemm(a, b, a_trans=True, b_trans=True, out=out, accumulate=True)
+    e1.record()
+    KERNEL_TIMING.append((e0, e1, 2.0 * a.shape[0] * a.shape[1] * b.shape[1], (a.shape[0] * (a.shape[1] + b.shape[1])) * a.element_size()))
+
+
 def _wgrad(ps, wname, bname, dy, xin, fused_rows=None, bias_done=False):
     """dW[N,K] += dy[M,N]^T xin[M,K] ; db[N] += colsum(dy)   (nn.Linear layout).  bias_done: the column sums were already
     accumulated by the LayerNorm-backward kernel that produced dy."""
-    ops.gemm(dy, xin, a_trans=True, b_trans=True, out=ps.g(wname, fused_rows), accumulate=True)
+    _timed_wgrad(dy, xin, ps.g(wname, fused_rows))
     if not bias_done:
         ops.colsum(dy, out=ps.g(bname, fused_rows), accumulate=True)
 
@@ -199,7 +213,7 @@ def gpt2_block_fwd(ps, pfx, x, B, T, H, p, seed, off, save):
 
 def _wgrad_conv1d(ps, wname, bname, xin, dy):
     """dW[K,N] += xin[M,K]^T dy[M,N] ; db[N] += colsum(dy)   (HF Conv1D layout)."""
-    ops.gemm(xin, dy, a_trans=True, b_trans=True, out=ps.g(wname), accumulate=True)
+    _timed_wgrad(xin, dy, ps.g(wname))
     ops.colsum(dy, out=ps.g(bname), accumulate=True)
 
 
@@ -303,7 +317,7 @@ class LogitsFn(torch.autograd.Function):
             ops.cast(padded, p16)
             padded = p16
         g = padded[:, :V]
-        ops.gemm(g, ctx.h2, a_trans=True, b_trans=True, out=ps.g('dec_out_proj.weight'), accumulate=True)
+        _timed_wgrad(g, ctx.h2, ps.g('dec_out_proj.weight'))
         ops.colsum(g, out=ps.g('dec_out_proj.bias'), accumulate=True)
         dh = ops.gemm(g, ps.w('dec_out_proj.weight'), b_trans=True)
         return None, dh.view(ctx.shp)
