@@ -148,8 +148,9 @@ def main():
     from emo_disentanger_amd.optim import FusedAdam
     rank, local_rank, world = dp.init_distributed()
     assert world == max(args.gpus, 1) or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    local_dev = local_rank % torch.cuda.device_count()     # (== local_rank on a real multi-GPU node)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
     torch.manual_seed(0)
     B, T = args.batch, args.seq
     model = MusicPerformer(CFG['n_token'], CFG['n_layer'], CFG['n_head'], CFG['d_model'], CFG['d_ff'], CFG['d_model'],

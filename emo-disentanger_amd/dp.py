@@ -20,9 +20,9 @@ def init_distributed(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
-        if backend == 'nccl':
-            torch.cuda.set_device(local_rank)
+        backend = backend or os.environ.get('EMO_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
