@@ -351,6 +351,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 constexpr int GB_M = 128, GB_N = 128, GB_K = 64;
 
 __device__ __forceinline__ int swz_k(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+// chunk swizzle of the 64-B-row (BK=32) K-contiguous image: f(row>>2) = {0,3,2,1}.  ds_read_b128 is serviced in the lane
+// groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...; with this map the 16 lanes of every group hit 16 distinct 16-B slots
+// of the 256-B bank row (the plain (row>>2)&3 map measured 2-way: SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE).
+__device__ __forceinline__ int swz32(int row) { return (0 - (row >> 2)) & 3; }
 
 // ---- global -> registers: 4 x 16 B per thread per operand
 // K-contig operand: tile [128 rows][64 k]; chunk c = 8 k's.  idx = tid + 256*i : row = idx>>3, chunk = idx&7
@@ -515,7 +519,7 @@ __device__ __forceinline__ void glds_offsets(int64_t ld, int64_t row0, int64_t n
         const int j = wave * NI + i;
         if constexpr (KC) {
             int row, c;
-            if constexpr (BK == 32) { row = j * 16 + (lane >> 2); c = (lane & 3) ^ ((row >> 2) & 3); }
+            if constexpr (BK == 32) { row = j * 16 + (lane >> 2); c = (lane & 3) ^ swz32(row); }
             else { row = j * 8 + (lane >> 3); c = (lane & 7) ^ (row & 7); }
             int64_t gr = row0 + row;
             if (gr > nrows - 1) gr = nrows - 1;
@@ -542,7 +546,7 @@ __device__ __forceinline__ bf16x8 lfrag2(const char* lds, int rbase, int ks, int
     if constexpr (KC) {
         const int row = rbase + (lane & 15);
         if constexpr (BK == 32) {
-            const int pc = (lane >> 4) ^ ((row >> 2) & 3);
+            const int pc = (lane >> 4) ^ swz32(row);
             return *(const bf16x8*)(lds + row * 64 + (pc << 4));
         } else {
             const int ch = ks * 4 + (lane >> 4);
@@ -1003,7 +1007,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_g4_kernel(const bf16_t* __restr
     // A tile: 8 wave-instructions (1 per wave); B tile: 16 (2 per wave)
     uint32_t offA, offB[2];
     {
-        const int row = wave * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        const int row = wave * 16 + (lane >> 2), c = (lane & 3) ^ swz32(row);
         int64_t gr = m0 + row;
         if (gr > M - 1) gr = M - 1;
         offA = (uint32_t)((gr * lda + c * 8) * 2);
@@ -1012,7 +1016,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_g4_kernel(const bf16_t* __restr
     for (int i = 0; i < 2; ++i) {
         const int j = wave * 2 + i;
         if constexpr (B_KC) {
-            const int row = j * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+            const int row = j * 16 + (lane >> 2), c = (lane & 3) ^ swz32(row);
             int64_t gr = n0 + row;
             if (gr > N - 1) gr = N - 1;
             offB[i] = (uint32_t)((gr * ldb + c * 8) * 2);
