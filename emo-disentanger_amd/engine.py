@@ -149,6 +149,45 @@ def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save):
 
 KERNEL_TIMING = None   # bench.py sets this to a list to HIP-event-time every wgrad launch in situ (same stream as the launch)
 
+# Weight-gradient GEMMs (and the remaining bias column sums) only feed the optimizer, so they run on a SECOND HIP stream
+# next to the dgrad / attention-backward chain of the main stream: the two kernels' prologue / epilogue / tail phases
+# overlap on the CUs.  EMO_WGRAD_STREAM=0 disables it.
+import os as _os
+_SIDE = {'stream': None, 'on': _os.environ.get('EMO_WGRAD_STREAM', '1') != '0'}
+
+
+class _side_stream:
+    """with _side_stream(t1, t2, ...): launches go to the side stream after everything queued so far on the main stream;
+    the tensors are marked as used by the side stream so the caching allocator does not recycle them early."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+
+    def __enter__(self):
+        if not _SIDE['on']:
+            return self
+        main = torch.cuda.current_stream()
+        if _SIDE['stream'] is None or _SIDE['stream'].device != main.device:
+            _SIDE['stream'] = torch.cuda.Stream(device=main.device)
+        side = _SIDE['stream']
+        side.wait_stream(main)
+        for t in self.tensors:
+            if t is not None:
+                t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if _SIDE['on']:
+            self.ctx.__exit__(*a)
+        return False
+
+
+def join_side_stream():
+    if _SIDE['on'] and _SIDE['stream'] is not None:
+        torch.cuda.current_stream().wait_stream(_SIDE['stream'])
+
 
 def _timed_wgrad(a, b, out):
     if KERNEL_TIMING is None:
@@ -164,9 +203,10 @@ def _timed_wgrad(a, b, out):
 def _wgrad(ps, wname, bname, dy, xin, fused_rows=None, bias_done=False):
     """dW[N,K] += dy[M,N]^T xin[M,K] ; db[N] += colsum(dy)   (nn.Linear layout).  bias_done: the column sums were already
     accumulated by the LayerNorm-backward kernel that produced dy."""
-    _timed_wgrad(dy, xin, ps.g(wname, fused_rows))
-    if not bias_done:
-        ops.colsum(dy, out=ps.g(bname, fused_rows), accumulate=True)
+    with _side_stream(dy, xin):
+        _timed_wgrad(dy, xin, ps.g(wname, fused_rows))
+        if not bias_done:
+            ops.colsum(dy, out=ps.g(bname, fused_rows), accumulate=True)
 
 
 def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
@@ -213,8 +253,9 @@ def gpt2_block_fwd(ps, pfx, x, B, T, H, p, seed, off, save):
 
 def _wgrad_conv1d(ps, wname, bname, xin, dy):
     """dW[K,N] += xin[M,K]^T dy[M,N] ; db[N] += colsum(dy)   (HF Conv1D layout)."""
-    _timed_wgrad(xin, dy, ps.g(wname))
-    ops.colsum(dy, out=ps.g(bname), accumulate=True)
+    with _side_stream(dy, xin):
+        _timed_wgrad(xin, dy, ps.g(wname))
+        ops.colsum(dy, out=ps.g(bname), accumulate=True)
 
 
 def gpt2_block_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
@@ -284,6 +325,7 @@ class DecoderStackFn(torch.autograd.Function):
             ctx.saves[l] = None
         dS = ps.g('segemb.emb_lookup.weight') if ctx.seg is not None else None
         ops.embed_bwd(ctx.tok, ctx.seg, dx, ps.g('token_emb.emb_lookup.weight'), dS, float(model.token_emb.emb_scale), p_drop=p, seed=seed, offset=base)
+        join_side_stream()          # all weight gradients are complete before anything downstream (all-reduce, optimizer) runs
         return None, None, None, None, None
 
 
@@ -317,9 +359,11 @@ class LogitsFn(torch.autograd.Function):
             ops.cast(padded, p16)
             padded = p16
         g = padded[:, :V]
-        _timed_wgrad(g, ctx.h2, ps.g('dec_out_proj.weight'))
-        ops.colsum(g, out=ps.g('dec_out_proj.bias'), accumulate=True)
+        with _side_stream(padded, ctx.h2):
+            _timed_wgrad(g, ctx.h2, ps.g('dec_out_proj.weight'))
+            ops.colsum(g, out=ps.g('dec_out_proj.bias'), accumulate=True)
         dh = ops.gemm(g, ps.w('dec_out_proj.weight'), b_trans=True)
+        join_side_stream()
         return None, dh.view(ctx.shp)
 
 

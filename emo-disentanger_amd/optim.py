@@ -34,6 +34,8 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         ps = self._buffers()
         ps.ensure_grads()
+        from .engine import join_side_stream
+        join_side_stream()
         g = self.param_groups[0]
         pre = 1.0 / self.world_size
         self._ss.zero_()
