@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256, (ST == 2 && BK == 32) ? 4 : 2) void gemm_bf16_
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const int nxt = kt + ST - 1;
-        if (nxt < nk && ep.ablate != 1) {
+        if (nxt < nk && ep.ablate != 1 && ep.ablate != 3) {
             char* st = smem + (nxt % ST) * STAGE;
             glds_issue2<NI>(gA, offA, st, wave);
             glds_issue2<NI>(gB, offB, st + OPB, wave);
@@ -637,10 +637,15 @@ __global__ __launch_bounds__(256, (ST == 2 && BK == 32) ? 4 : 2) void gemm_bf16_
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 fa[4], fb[4];
+            if (ep.ablate == 3) {          // diagnostics: no LDS fragment reads either (MFMA + barrier + epilogue only)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { fa[i] = (bf16x8){1, 1, 1, 1, 1, 1, 1, 1}; fb[i] = (bf16x8){1, 1, 1, 1, 1, 1, 1, 1}; }
+            } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[i] = lfrag2<A_KC, BK>(la, wm * 64 + i * 16, ks, lane);
 #pragma unroll
             for (int j = 0; j < 4; ++j) fb[j] = lfrag2<B_KC, BK>(lb, wn * 64 + j * 16, ks, lane);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1127,6 +1132,141 @@ static void launch_g4(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t
     hipLaunchKernelGGL(kfn, dim3((unsigned)(tiles_m8 * tiles_n)), dim3(512), 4 * G4_STAGE, st, A, lda, B, ldb, (OutT*)C, M, N, K, ep);
 }
 
+// v5: 256 x 128 block tile, FOUR waves (2 x 2, wave tile 128 x 64 = 8 x 4 MFMA tiles), BK = 32, 3-stage LDS-DMA ring
+// (72 KB => 2 blocks per CU).  Ablation of the 128^2 kernel at K=512 (EMO_GEMM_ABLATE) showed four ADDITIVE costs of
+// similar size — MFMA, fragment reads, tile DMA, and the per-tile fixed part (prologue + epilogue + C store burst);
+// the bigger wave tile cuts fragment reads per MFMA by 25 %, the bigger block tile cuts DMA bytes per FLOP by 25 % and
+// halves the number of per-tile fixed costs per FLOP.  A operand K-contiguous; B K-contiguous or MN-contiguous.
+constexpr int G5_M = 256, G5_STAGE = 24576;   // per stage: 16 KB A + 8 KB B
+
+template <bool B_KC, typename OutT>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_g5_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                              OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, EpiParams ep) {
+    constexpr int BK = 32, ST = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t tiles_n = (N + GB_N - 1) / GB_N, tiles_m = (M + G5_M - 1) / G5_M;
+    int64_t tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    if (tm >= tiles_m) return;
+    const int64_t m0 = tm * G5_M, n0 = tn * GB_N;
+    const int nk = (int)(K / BK);
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // A tile [256 rows][32 k]: 16 wave-instructions (4 per wave); B tile [128][32]: 8 (2 per wave)
+    uint32_t offA[4], offB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 16 + (lane >> 2), c = (lane & 3) ^ swz32(row);
+        int64_t gr = m0 + row;
+        if (gr > M - 1) gr = M - 1;
+        offA[i] = (uint32_t)((gr * lda + c * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = wave * 2 + i;
+        if constexpr (B_KC) {
+            const int row = j * 16 + (lane >> 2), c = (lane & 3) ^ swz32(row);
+            int64_t gr = n0 + row;
+            if (gr > N - 1) gr = N - 1;
+            offB[i] = (uint32_t)((gr * ldb + c * 8) * 2);
+        } else {
+            const int k = j * 4 + (lane >> 4), p16 = lane & 15;
+            const int g = (p16 >> 1) ^ swz_k(k);
+            int64_t gr = n0 + (g * 2 + (p16 & 1)) * 8;
+            if (gr > N - 1) gr = ((N - 1) >> 3) << 3;
+            offB[i] = (uint32_t)(((int64_t)k * ldb + gr) * 2);
+        }
+    }
+    const char* gA = (const char*)A;
+    const char* gB = (const char*)B;
+    const int64_t stepA = (int64_t)BK * 2, stepB = (B_KC ? (int64_t)BK : (int64_t)BK * ldb) * 2;
+    int issued = 0;
+    auto issue_next = [&]() {
+        if (issued < nk) {
+            char* st = smem + (issued % ST) * G5_STAGE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + offA[i]),
+                                                 (__attribute__((address_space(3))) void*)(st + (wave * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + offB[i]),
+                                                 (__attribute__((address_space(3))) void*)(st + 16384 + (wave * 2 + i) * 1024), 16, 0, 0);
+            gA += stepA;
+            gB += stepB;
+            ++issued;
+        }
+    };
+    issue_next(); issue_next();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int newer = issued - 1 - kt;          // tiles issued after kt (6 DMA instructions per tile per thread)
+        if (newer >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_next();
+        const char* la = smem + (kt % ST) * G5_STAGE;
+        const char* lb = la + 16384;
+        bf16x8 fa[8], fb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = lfrag2<B_KC, BK>(lb, wn * 64 + j * 16, 0, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = lfrag2<true, BK>(la, wm * 128 + i * 16, 0, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    // epilogue: four 64-row slabs through 32 KB of LDS (the ring is idle now)
+#pragma clang loop unroll(full)
+    for (int pass = 0; pass < 4; ++pass) {
+        __syncthreads();
+        if (wm == (pass >> 1)) {
+#pragma clang loop unroll(full)
+            for (int ii = 0; ii < 4; ++ii)
+#pragma clang loop unroll(full)
+                for (int j = 0; j < 4; ++j) {
+                    const int row = ii * 16 + (lane & 15);
+                    const int chunk = (wn * 64 + j * 16 + (lane >> 4) * 4) >> 2;
+                    *(f32x4*)(smem + row * 512 + ((chunk ^ (row & 7)) << 4)) = acc[(pass & 1) * 4 + ii][j];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + 256 * it;   // 0..1023 : row = idx >> 4 (64 rows), 8-column group = idx & 15
+            const int row = idx >> 4, grp = idx & 15;
+            const int64_t m = m0 + pass * 64 + row, n = n0 + grp * 8;
+            if (m < M && n < N) {
+                const f32x4 lo = *(const f32x4*)(smem + row * 512 + (((2 * grp) ^ (row & 7)) << 4));
+                const f32x4 hi = *(const f32x4*)(smem + row * 512 + (((2 * grp + 1) ^ (row & 7)) << 4));
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                epi_row8<OutT>(ep, C, m, n, v, N);
+            }
+        }
+    }
+}
+
+template <bool B_KC, typename OutT>
+static void launch_g5(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int64_t M, int64_t N, int64_t K,
+                      const EpiParams& ep) {
+    auto kfn = gemm_bf16_g5_kernel<B_KC, OutT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * G5_STAGE);
+        attr_set = true;
+    }
+    const int64_t tiles_m8 = cdiv64(cdiv64(M, G5_M), 8) * 8, tiles_n = cdiv64(N, GB_N);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(tiles_m8 * tiles_n)), dim3(256), 3 * G5_STAGE, st, A, lda, B, ldb, (OutT*)C, M, N, K, ep);
+}
+
 static int g_glds_bk = -1;   // EMO_GEMM_BK=32|64 forces one LDS-DMA geometry (default: per-shape heuristic)
 static int glds_bk() {
     if (g_glds_bk < 0) {
@@ -1304,7 +1444,13 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         static const bool g4_on = getenv("EMO_GEMM_G4") != nullptr;   // 128x256 tile: measured no faster than 128x128 (r01) -> opt-in
         const bool use_g4 = g4_on && !safe && variant >= 2 && akc && splits == 1 && !accumulate && (K % G2_BK) == 0 && (N % G4_N) == 0 && span_ok &&
                             cdiv64(M, GB_M) * (N / G4_N) >= 512 && K <= 1024;
-        if (use_g4) {
+        static const bool g5_on = getenv("EMO_GEMM_G5") != nullptr;
+        const bool use_g5 = g5_on && !safe && variant >= 2 && akc && splits == 1 && !accumulate && (K % G2_BK) == 0 && span_ok &&
+                            cdiv64(M, G5_M) * cdiv64(N, GB_N) >= 512;
+        if (use_g5) {
+            if (dtype_out == EMO_F32) { if (bkc) launch_g5<true, float>(st, a, lda, b, ldb, C, M, N, K, ep); else launch_g5<false, float>(st, a, lda, b, ldb, C, M, N, K, ep); }
+            else { if (bkc) launch_g5<true, bf16_t>(st, a, lda, b, ldb, C, M, N, K, ep); else launch_g5<false, bf16_t>(st, a, lda, b, ldb, C, M, N, K, ep); }
+        } else if (use_g4) {
             if (dtype_out == EMO_F32) { if (bkc) launch_g4<true, float>(st, a, lda, b, ldb, C, M, N, K, ep); else launch_g4<false, float>(st, a, lda, b, ldb, C, M, N, K, ep); }
             else { if (bkc) launch_g4<true, bf16_t>(st, a, lda, b, ldb, C, M, N, K, ep); else launch_g4<false, bf16_t>(st, a, lda, b, ldb, C, M, N, K, ep); }
         } else if (use_g3 && span_ok && (kps % G3_K) == 0) {
