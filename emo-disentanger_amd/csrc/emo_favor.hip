@@ -101,11 +101,23 @@ __device__ __forceinline__ void zero_img(CT* img, int n, int tid) {
 }
 
 // =============================================================================================== forward
-template <typename CT, int DH, int MF, int C>
+// sum over segments [p_lo, p_hi) of one element of the per-segment state increments (workspace [.., P, stride])
+__device__ __forceinline__ float seg_sum(const float* __restrict__ ws, int64_t stride, int p_lo, int p_hi, int64_t idx) {
+    float s = 0.f;
+    for (int p = p_lo; p < p_hi; ++p) s += ws[p * stride + idx];
+    return s;
+}
+
+// Segment-parallel scan (P > 1): the T axis is cut into P segments of Ts tokens (Ts a multiple of the chunk size).  A first
+// "state only" launch (SO = true) computes every segment's state increment into S_ws [B*H, P, F, DH] / z_ws [B*H, P, F]; the main
+// launch then starts each segment from the sum of the increments before it.  P = 1 is the plain single-pass scan.
+// SO = true: "state only" pass of the segment-parallel scan (writes the segment's state increment to S_ws / z_ws).
+template <typename CT, int DH, int MF, int C, bool SO>
 __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
                                                         const float* __restrict__ omega, CT* __restrict__ out, int64_t ld_out,
                                                         float* __restrict__ den_g, float* __restrict__ state_S, float* __restrict__ state_z,
-                                                        int64_t T, int64_t H, float eps) {
+                                                        int64_t T, int64_t H, float eps, float* __restrict__ S_ws, float* __restrict__ z_ws,
+                                                        int P, int64_t Ts) {
     typedef FavorDims<CT, DH, MF, C> D;
     constexpr int F = D::F, LDX = D::LDX, LDC = D::LDC, LDF = D::LDF, DHP = D::DHP, CP = D::CP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -124,7 +136,12 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
     float* zz = dens + C;               // [F]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;
+    // segment-parallel scan: block = (b, h, segment p); the segment covers tokens [tbeg, tend)
+    const int64_t bh = blockIdx.x / P, b = bh / H, h = bh % H;
+    const int p_seg = (int)(blockIdx.x % P);
+    const int64_t tbeg = (int64_t)p_seg * Ts;
+    const int64_t tend = (tbeg + Ts < T) ? tbeg + Ts : T;
+    if (SO && p_seg == P - 1) return;               // nobody consumes the last segment's increment
     const CT* qb = q + (b * T) * ld + h * DH;
     const CT* kb = k + (b * T) * ld + h * DH;
     const CT* vb = v + (b * T) * ld + h * DH;
@@ -149,33 +166,51 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
 #pragma unroll
     for (int i = 0; i < NTS_W; ++i) sacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    RowPrefetch<CT, DH, DHP, C, FT> pq, pk, pv;
-    {
-        const int v0 = (int)(T < C ? T : C);
-        pq.load(qb, ld, v0, tid);
-        pk.load(kb, ld, v0, tid);
-        pv.load(vb, ld, v0, tid);
+    if (!SO && p_seg > 0) {                         // state carried in = sum of the increments of segments 0..p-1
+        const float* Si = S_ws + bh * P * (int64_t)F * DH;
+#pragma unroll
+        for (int i = 0; i < NTS_W; ++i) {
+            const int tile = wave + FW * i;
+            if (tile < NTS) {
+                const int ft = tile / (DH / 16), dt = tile % (DH / 16);
+                const int d = dt * 16 + (lane & 15), f0 = ft * 16 + (lane >> 4) * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sacc[i][r] = seg_sum(Si, (int64_t)F * DH, 0, p_seg, (f0 + r) * DH + d);
+                Img<CT>::store4(ST + d * LDF + f0, sacc[i][0], sacc[i][1], sacc[i][2], sacc[i][3]);
+            }
+        }
+        for (int f = tid; f < F; f += FT) zz[f] = seg_sum(z_ws + bh * P * (int64_t)F, F, 0, p_seg, f);
     }
-    for (int64_t t0 = 0; t0 < T; t0 += C) {
-        const int valid = (int)((T - t0) < C ? (T - t0) : C);
+    RowPrefetch<CT, DH, DHP, C, FT> pq, pk, pv;
+    if (tbeg < tend) {
+        const int v0 = (int)((tend - tbeg) < C ? (tend - tbeg) : C);
+        if constexpr (!SO) pq.load(qb + tbeg * ld, ld, v0, tid);
+        pk.load(kb + tbeg * ld, ld, v0, tid);
+        pv.load(vb + tbeg * ld, ld, v0, tid);
+    }
+    for (int64_t t0 = tbeg; t0 < tend; t0 += C) {
+        const int valid = (int)((tend - t0) < C ? (tend - t0) : C);
         __syncthreads();
-        pq.store_rows(Xq, LDX, tid);
+        if constexpr (!SO) pq.store_rows(Xq, LDX, tid);
         pk.store_rows(Xk, LDX, tid);
         pv.store_T(VT, LDC, tid);
-        if (t0 + C < T) {                          // next chunk's q/k/v stay in flight during this chunk's compute
-            const int vn = (int)((T - t0 - C) < C ? (T - t0 - C) : C);
-            pq.load(qb + (t0 + C) * ld, ld, vn, tid);
+        if (t0 + C < tend) {                       // next chunk's q/k/v stay in flight during this chunk's compute
+            const int vn = (int)((tend - t0 - C) < C ? (tend - t0 - C) : C);
+            if constexpr (!SO) pq.load(qb + (t0 + C) * ld, ld, vn, tid);
             pk.load(kb + (t0 + C) * ld, ld, vn, tid);
             pv.load(vb + (t0 + C) * ld, ld, vn, tid);
         }
         __syncthreads();
-        row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
+        if constexpr (!SO) row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
         row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
         __syncthreads();
-        features_rowmajor<CT, DHP, MF, C>(Qf, LDF, WT, Xq, LDX, offq, cs, C, wave, lane);
-        features_rowmajor<CT, DHP, MF, C>(Kf, LDF, WT, Xk, LDX, offk, cs, valid, wave, lane);
+        if constexpr (!SO) {
+            features_rowmajor<CT, DHP, MF, C>(Qf, LDF, WT, Xq, LDX, offq, cs, C, wave, lane);
+            features_rowmajor<CT, DHP, MF, C>(Kf, LDF, WT, Xk, LDX, offk, cs, valid, wave, lane);
+        }
         features_transposed<CT, DHP, MF, C>(KfT, LDC, WT, Xk, LDX, offk, cs, valid, wave, lane);
         __syncthreads();
+        if constexpr (!SO) {
         // A[t][j] = Qf[t].Kf[j] masked j<=t : rows<->j (R=Kf), col<->t (C=Qf)
         {
             constexpr int NT = (C / 16) * (C / 16);
@@ -226,6 +261,7 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
             }
         }
         __syncthreads();
+        }   // !SO
         // state: S[f][d] += sum_j KfT[f][j] VT[d][j]; mirror ST[d][f]; z += colsum
 #pragma unroll
         for (int i = 0; i < NTS_W; ++i) {
@@ -233,8 +269,10 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
             if (tile < NTS) {
                 const int ft = tile / (DH / 16), dt = tile % (DH / 16);
                 mm16<CT>(sacc[i], KfT, LDC, ft * 16, VT, LDC, dt * 16, CP, lane);
-                const int d = dt * 16 + (lane & 15), f0 = ft * 16 + (lane >> 4) * 4;
-                Img<CT>::store4(ST + d * LDF + f0, sacc[i][0], sacc[i][1], sacc[i][2], sacc[i][3]);
+                if constexpr (!SO) {
+                    const int d = dt * 16 + (lane & 15), f0 = ft * 16 + (lane >> 4) * 4;
+                    Img<CT>::store4(ST + d * LDF + f0, sacc[i][0], sacc[i][1], sacc[i][2], sacc[i][3]);
+                }
             }
         }
         if constexpr (sizeof(CT) == 2 && C == 64 && 4 * F <= FT) {
@@ -254,7 +292,9 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
         }
     }
     __syncthreads();
-    if (state_S) {
+    float* So = SO ? S_ws + (bh * P + p_seg) * (int64_t)F * DH : ((state_S && p_seg == P - 1) ? state_S + bh * (int64_t)F * DH : nullptr);
+    float* zo = SO ? z_ws + (bh * P + p_seg) * (int64_t)F : ((state_S && p_seg == P - 1) ? state_z + bh * (int64_t)F : nullptr);
+    if (So) {
 #pragma unroll
         for (int i = 0; i < NTS_W; ++i) {
             const int tile = wave + FW * i;
@@ -262,10 +302,10 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
                 const int ft = tile / (DH / 16), dt = tile % (DH / 16);
                 const int d = dt * 16 + (lane & 15), f0 = ft * 16 + (lane >> 4) * 4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) state_S[(bh * F + f0 + r) * DH + d] = sacc[i][r];
+                for (int r = 0; r < 4; ++r) So[(f0 + r) * DH + d] = sacc[i][r];
             }
         }
-        for (int f = tid; f < F; f += FT) state_z[bh * F + f] = zz[f];
+        for (int f = tid; f < F; f += FT) zo[f] = zz[f];
     }
 }
 
@@ -388,7 +428,8 @@ template <typename CT, int DH, int MF, int C>
 __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
                                                            const float* __restrict__ omega, const CT* __restrict__ out, const CT* __restrict__ dout,
                                                            int64_t ld_out, const float* __restrict__ den_g, CT* __restrict__ dq, int64_t ld_d,
-                                                           int64_t T, int64_t H) {
+                                                           int64_t T, int64_t H, const float* __restrict__ S_ws, const float* __restrict__ z_ws,
+                                                           int P, int64_t Ts) {
     typedef FavorDims<CT, DH, MF, C> D;
     constexpr int F = D::F, LDX = D::LDX, LDC = D::LDC, LDF = D::LDF, LDM = D::LDM, DHP = D::DHP, CP = D::CP, MFP = D::MFP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -412,7 +453,10 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
     float* zz = sumA + C;          // [F]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int64_t bh = blockIdx.x / P, b = bh / H, h = bh % H;
+    const int p_seg = (int)(blockIdx.x % P);
+    const int64_t tbeg = (int64_t)p_seg * Ts;
+    const int64_t tend = (tbeg + Ts < T) ? tbeg + Ts : T;
     const CT* qb = q + (b * T) * ld + h * DH;
     const CT* kb = k + (b * T) * ld + h * DH;
     const CT* vb = v + (b * T) * ld + h * DH;
@@ -443,17 +487,32 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
 #pragma unroll
     for (int i = 0; i < NTS_W; ++i) sacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    if (p_seg > 0) {                                // K-state carried in from segments 0..p-1
+        const float* Si = S_ws + bh * P * (int64_t)F * DH;
+#pragma unroll
+        for (int i = 0; i < NTS_W; ++i) {
+            const int tile = wave + FW * i;
+            if (tile < NTS) {
+                const int dt = tile / (F / 16), ft = tile % (F / 16);
+                const int f = ft * 16 + (lane & 15), d0 = dt * 16 + (lane >> 4) * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sacc[i][r] = seg_sum(Si, (int64_t)F * DH, 0, p_seg, f * DH + d0 + r);
+                Img<CT>::store4(SF + f * LDX + d0, sacc[i][0], sacc[i][1], sacc[i][2], sacc[i][3]);
+            }
+        }
+        for (int f = tid; f < F; f += FT) zz[f] = seg_sum(z_ws + bh * P * (int64_t)F, F, 0, p_seg, f);
+    }
     typedef RowPrefetch<CT, DH, DHP, C, FT> PF;
     PF pq, pk, pv, pg, po;
     float dn[PF::NI];
-    {
-        const int v0 = (int)(T < C ? T : C);
-        pq.load(qb, ld, v0, tid); pk.load(kb, ld, v0, tid); pv.load(vb, ld, v0, tid);
-        pg.load(gb, ld_out, v0, tid); po.load(ob, ld_out, v0, tid);
-        load_den<CT, DH, DHP, C>(dn, dg, v0, tid);
+    if (tbeg < tend) {
+        const int v0 = (int)((tend - tbeg) < C ? (tend - tbeg) : C);
+        pq.load(qb + tbeg * ld, ld, v0, tid); pk.load(kb + tbeg * ld, ld, v0, tid); pv.load(vb + tbeg * ld, ld, v0, tid);
+        pg.load(gb + tbeg * ld_out, ld_out, v0, tid); po.load(ob + tbeg * ld_out, ld_out, v0, tid);
+        load_den<CT, DH, DHP, C>(dn, dg + tbeg, v0, tid);
     }
-    for (int64_t t0 = 0; t0 < T; t0 += C) {
-        const int valid = (int)((T - t0) < C ? (T - t0) : C);
+    for (int64_t t0 = tbeg; t0 < tend; t0 += C) {
+        const int valid = (int)((tend - t0) < C ? (tend - t0) : C);
         __syncthreads();
         pq.store_rows(Xq, LDX, tid);
         pk.store_rows(Xk, LDX, tid);
@@ -461,9 +520,9 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
         pv.store_T(VT, LDC, tid);
         store_grads<CT, DH, DHP, C>(pg, po, dn, valid, G, LDX, (CT*)nullptr, 0, dD, tid);
         for (int i = tid; i < C; i += FT) sumA[i] = 0.f;
-        if (t0 + C < T) {
+        if (t0 + C < tend) {
             const int64_t tn_ = t0 + C;
-            const int vn = (int)((T - tn_) < C ? (T - tn_) : C);
+            const int vn = (int)((tend - tn_) < C ? (tend - tn_) : C);
             pq.load(qb + tn_ * ld, ld, vn, tid); pk.load(kb + tn_ * ld, ld, vn, tid); pv.load(vb + tn_ * ld, ld, vn, tid);
             pg.load(gb + tn_ * ld_out, ld_out, vn, tid); po.load(ob + tn_ * ld_out, ld_out, vn, tid);
             load_den<CT, DH, DHP, C>(dn, dg + tn_, vn, tid);
@@ -543,11 +602,13 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
 }
 
 // =============================================================================================== backward: dk, dv (reverse sweep)
-template <typename CT, int DH, int MF, int C>
+// SO = true: "state only" pass of the reverse segment scan: the segment's increments of R [F, DH] and r [F] go to R_ws / r_ws.
+template <typename CT, int DH, int MF, int C, bool SO>
 __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
                                                             const float* __restrict__ omega, const CT* __restrict__ out, const CT* __restrict__ dout,
                                                             int64_t ld_out, const float* __restrict__ den_g, CT* __restrict__ dk, CT* __restrict__ dv,
-                                                            int64_t ld_d, int64_t T, int64_t H) {
+                                                            int64_t ld_d, int64_t T, int64_t H, float* __restrict__ R_ws, float* __restrict__ r_ws, int P,
+                                                            int64_t Ts) {
     typedef FavorDims<CT, DH, MF, C> D;
     constexpr int F = D::F, LDX = D::LDX, LDC = D::LDC, LDF = D::LDF, LDM = D::LDM, DHP = D::DHP, CP = D::CP, MFP = D::MFP;
     constexpr int LXC = CMax<LDX, LDC>::v, LXM = CMax<LDX, LDM>::v;
@@ -574,7 +635,11 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
     float* rr = sumA + C;           // [F]  r[f] = sum_{t>chunk} Qf_t[f] dD_t
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int64_t bh = blockIdx.x / P, b = bh / H, h = bh % H;
+    const int p_seg = (int)(blockIdx.x % P);
+    const int64_t tbeg = (int64_t)p_seg * Ts;
+    const int64_t tend = (tbeg + Ts < T) ? tbeg + Ts : T;
+    if (SO && p_seg == 0) return;                   // nobody consumes the first segment's increment
     const CT* qb = q + (b * T) * ld + h * DH;
     const CT* kb = k + (b * T) * ld + h * DH;
     const CT* vb = v + (b * T) * ld + h * DH;
@@ -606,40 +671,64 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
 #pragma unroll
     for (int i = 0; i < NTS_W; ++i) racc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int64_t nchunks = (T + C - 1) / C;
+    if (!SO && p_seg < P - 1) {                     // R-state carried in from segments p+1..P-1
+        const float* Ri = R_ws + bh * P * (int64_t)F * DH;
+#pragma unroll
+        for (int i = 0; i < NTS_W; ++i) {
+            const int tile = wave + FW * i;
+            if (tile < NTS) {
+                const int dt = tile / (F / 16), ft = tile % (F / 16);
+                const int f = ft * 16 + (lane & 15), d0 = dt * 16 + (lane >> 4) * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) racc[i][r] = seg_sum(Ri, (int64_t)F * DH, p_seg + 1, P, f * DH + d0 + r);
+                Img<CT>::store4(RF + f * LDX + d0, racc[i][0], racc[i][1], racc[i][2], racc[i][3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) RT[(d0 + r) * LDF + f] = from_f32<CT>(racc[i][r]);
+            }
+        }
+        for (int f = tid; f < F; f += FT) rr[f] = seg_sum(r_ws + bh * P * (int64_t)F, F, p_seg + 1, P, f);
+    }
+    const int64_t nchunks = (tend > tbeg) ? (tend - tbeg + C - 1) / C : 0;
     typedef RowPrefetch<CT, DH, DHP, C, FT> PF;
     PF pq, pk, pv, pg, po;
     float dn[PF::NI];
-    {
-        const int64_t tl_ = (nchunks - 1) * C;
-        const int v0 = (int)(T - tl_);
-        pq.load(qb + tl_ * ld, ld, v0, tid); pk.load(kb + tl_ * ld, ld, v0, tid); pv.load(vb + tl_ * ld, ld, v0, tid);
+    if (nchunks > 0) {
+        const int64_t tl_ = tbeg + (nchunks - 1) * C;
+        const int v0 = (int)(tend - tl_);
+        pq.load(qb + tl_ * ld, ld, v0, tid);
+        if constexpr (!SO) { pk.load(kb + tl_ * ld, ld, v0, tid); pv.load(vb + tl_ * ld, ld, v0, tid); }
         pg.load(gb + tl_ * ld_out, ld_out, v0, tid); po.load(ob + tl_ * ld_out, ld_out, v0, tid);
         load_den<CT, DH, DHP, C>(dn, dg + tl_, v0, tid);
     }
     for (int64_t ci = nchunks - 1; ci >= 0; --ci) {
-        const int64_t t0 = ci * C;
-        const int valid = (int)((T - t0) < C ? (T - t0) : C);
+        const int64_t t0 = tbeg + ci * C;
+        const int valid = (int)((tend - t0) < C ? (tend - t0) : C);
         __syncthreads();
         pq.store_rows(Xq, LDX, tid);
-        pk.store_rows(Xk, LDX, tid);
-        pv.store_rows(Vr, LDX, tid);
+        if constexpr (!SO) {
+            pk.store_rows(Xk, LDX, tid);
+            pv.store_rows(Vr, LDX, tid);
+        }
         store_grads<CT, DH, DHP, C>(pg, po, dn, valid, G, LDX, GT, LDC, dD, tid);
         for (int i = tid; i < C; i += FT) sumA[i] = 0.f;
         if (ci > 0) {                                  // previous (earlier) chunk: full, stays in flight during this chunk's compute
             const int64_t tn_ = t0 - C;
-            pq.load(qb + tn_ * ld, ld, C, tid); pk.load(kb + tn_ * ld, ld, C, tid); pv.load(vb + tn_ * ld, ld, C, tid);
+            pq.load(qb + tn_ * ld, ld, C, tid);
+            if constexpr (!SO) { pk.load(kb + tn_ * ld, ld, C, tid); pv.load(vb + tn_ * ld, ld, C, tid); }
             pg.load(gb + tn_ * ld_out, ld_out, C, tid); po.load(ob + tn_ * ld_out, ld_out, C, tid);
             load_den<CT, DH, DHP, C>(dn, dg + tn_, C, tid);
         }
         __syncthreads();
         row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
-        row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
+        if constexpr (!SO) row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
         __syncthreads();
-        features_rowmajor<CT, DHP, MF, C>(Qf, LDF, WT, Xq, LDX, offq, cs, valid, wave, lane);
-        features_rowmajor<CT, DHP, MF, C>(Kf, LDF, WT, Xk, LDX, offk, cs, valid, wave, lane);
+        if constexpr (!SO) {
+            features_rowmajor<CT, DHP, MF, C>(Qf, LDF, WT, Xq, LDX, offq, cs, valid, wave, lane);
+            features_rowmajor<CT, DHP, MF, C>(Kf, LDF, WT, Xk, LDX, offk, cs, valid, wave, lane);
+        }
         features_transposed<CT, DHP, MF, C>(QfT, LDC, WT, Xq, LDX, offq, cs, valid, wave, lane);
         __syncthreads();   // Xq / Xk dead from here: PmT / AmT may overwrite them
+        if constexpr (!SO) {
         // PmT[j][t] = dN_t.v_j + dD_t (t>=j) : rows<->t (R=G), col<->j (C=Vr)
         // AmT[j][t] = Qf_t.Kf_j       (t>=j) : rows<->t (R=Qf), col<->j (C=Kf)
         {
@@ -695,6 +784,7 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
         }
         __syncthreads();
         dx_from_adiff<CT, DH, MFP, C>(W, LDM, Adiff, LDM, sumA, kb + t0 * ld, ld, dkb + t0 * ld_d, ld_d, cs, valid, wave, lane);
+        }   // !SO
         // state R[f][d] += sum_t QfT[f][t] GT[d][t]
 #pragma unroll
         for (int i = 0; i < NTS_W; ++i) {
@@ -704,6 +794,7 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
                 mm16<CT>(racc[i], GT, LDC, dt * 16, QfT, LDC, ft * 16, CP, lane);
             }
         }
+        if constexpr (!SO) {
         __syncthreads();   // all reads of RF / RT / rr for this chunk are done
 #pragma unroll
         for (int i = 0; i < NTS_W; ++i) {
@@ -715,6 +806,7 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) RT[(d0 + r) * LDF + f] = from_f32<CT>(racc[i][r]);
             }
+        }
         }
         if constexpr (sizeof(CT) == 2 && C == 64 && 4 * F <= FT) {
             const int f = tid >> 2, part = tid & 3;
@@ -731,6 +823,20 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
                 rr[f] += s;
             }
         }
+    }
+    if constexpr (SO) {
+        __syncthreads();
+        float* Ro = R_ws + (bh * P + p_seg) * (int64_t)F * DH;
+#pragma unroll
+        for (int i = 0; i < NTS_W; ++i) {
+            const int tile = wave + FW * i;
+            if (tile < NTS) {
+                const int dt = tile / (F / 16), ft = tile % (F / 16);
+                const int f = ft * 16 + (lane & 15), d0 = dt * 16 + (lane >> 4) * 4;
+                *(f32x4*)(Ro + f * DH + d0) = racc[i];
+            }
+        }
+        for (int f = tid; f < F; f += FT) r_ws[(bh * P + p_seg) * (int64_t)F + f] = rr[f];
     }
 }
 
@@ -864,33 +970,93 @@ template <typename CT, int DH, int MF, int C> static size_t dkv_lds() {
 
 #define EMO_MAX_LDS (160 * 1024)
 
+// ---- segment-parallel scan geometry (see favor_fwd_kernel).  One workgroup per (b, h, segment); segments only when B*H alone cannot
+// fill the 256 CUs.  Ts is a multiple of 64 (every chunk size divides it) and at least 2 chunks long.
+#define EMO_FAVOR_SEG_ALIGN 64
+#define EMO_FAVOR_MAX_SEGMENTS 16
+static void favor_segments(int64_t B, int64_t T, int64_t H, int* P_out, int64_t* Ts_out) {
+    int64_t want = 1;
+    const char* e = getenv("EMO_FAVOR_SEGMENTS");
+    if (e && atoi(e) > 0) want = atoi(e);
+    else if (B * H < 256) want = (256 + B * H - 1) / (B * H);
+    if (want > EMO_FAVOR_MAX_SEGMENTS) want = EMO_FAVOR_MAX_SEGMENTS;
+    const int64_t max_p = T / (2 * EMO_FAVOR_SEG_ALIGN);
+    if (want > max_p) want = max_p;
+    if (want < 1) want = 1;
+    int64_t Ts = (T + want - 1) / want;
+    Ts = (Ts + EMO_FAVOR_SEG_ALIGN - 1) / EMO_FAVOR_SEG_ALIGN * EMO_FAVOR_SEG_ALIGN;
+    if (Ts < EMO_FAVOR_SEG_ALIGN) Ts = EMO_FAVOR_SEG_ALIGN;
+    const int64_t P = T > 0 ? (T + Ts - 1) / Ts : 1;
+    *P_out = (int)(P < 1 ? 1 : P);
+    *Ts_out = Ts;
+}
+
+extern "C" int64_t emo_favor_attn_workspace_bytes(int64_t B, int64_t T, int64_t H, int64_t dh, int64_t n_feat) {
+    int P; int64_t Ts;
+    favor_segments(B, T, H, &P, &Ts);
+    if (P <= 1) return 0;
+    return B * H * P * (n_feat * dh + n_feat) * (int64_t)sizeof(float);
+}
+
 template <typename CT, int DH, int MF, int CF, int CQ, int CK>
 static int run_favor(int which, const void* q, const void* k, const void* v, int64_t ld, const float* omega, void* out, int64_t ld_out, float* den,
                      float* sS, float* sz, const void* dout, void* dq, void* dk, void* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, float eps,
-                     hipStream_t st) {
-    dim3 grid((unsigned)(B * H));
+                     void* workspace, int64_t workspace_bytes, hipStream_t st) {
+    constexpr int F = 2 * MF;
+    int P = 1; int64_t Ts = T > 0 ? T : 1;
+    if (workspace) {
+        favor_segments(B, T, H, &P, &Ts);
+        const int64_t need = P > 1 ? B * H * P * (int64_t)(F * DH + F) * (int64_t)sizeof(float) : 0;
+        EMO_CHECK(workspace_bytes >= need, "favor attention: workspace %lld B < %lld B (emo_favor_attn_workspace_bytes)", (long long)workspace_bytes,
+                  (long long)need);
+        EMO_CHECK(((uintptr_t)workspace & 15) == 0, "favor attention: workspace must be 16-B aligned");
+    }
+    if (P <= 1) { P = 1; Ts = T > 0 ? T : 1; }
+    float* wsS = (float*)workspace;
+    float* wsz = wsS ? wsS + B * H * P * (int64_t)F * DH : nullptr;
+    dim3 grid((unsigned)(B * H * P));
     if (which == 0) {
         const size_t lds = fwd_lds<CT, DH, MF, CF>();
         EMO_CHECK(lds <= EMO_MAX_LDS, "favor fwd: LDS %zu too large", lds);
-        auto kf = favor_fwd_kernel<CT, DH, MF, CF>;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-        hipLaunchKernelGGL(kf, grid, dim3(FT), lds, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (CT*)out, ld_out, den, sS, sz, T, H, eps);
-    } else {
-        const size_t l1 = dq_lds<CT, DH, MF, CQ>(), l2 = dkv_lds<CT, DH, MF, CK>();
-        EMO_CHECK(l1 <= EMO_MAX_LDS && l2 <= EMO_MAX_LDS, "favor bwd: LDS %zu / %zu too large", l1, l2);
-        auto k1 = favor_bwd_dq_kernel<CT, DH, MF, CQ>;
-        auto k2 = favor_bwd_dkv_kernel<CT, DH, MF, CK>;
+        auto kf = favor_fwd_kernel<CT, DH, MF, CF, false>;
+        auto ks = favor_fwd_kernel<CT, DH, MF, CF, true>;
         static bool attr = false;
         if (!attr) {
-            (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
-            (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+            (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
         }
+        if (P > 1)
+            hipLaunchKernelGGL(ks, grid, dim3(FT), lds, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (CT*)out, ld_out, den, sS, sz, T, H, eps, wsS,
+                               wsz, P, Ts);
+        hipLaunchKernelGGL(kf, grid, dim3(FT), lds, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (CT*)out, ld_out, den, sS, sz, T, H, eps, wsS, wsz,
+                           P, Ts);
+    } else {
+        const size_t l0 = fwd_lds<CT, DH, MF, CF>(), l1 = dq_lds<CT, DH, MF, CQ>(), l2 = dkv_lds<CT, DH, MF, CK>();
+        EMO_CHECK(l0 <= EMO_MAX_LDS && l1 <= EMO_MAX_LDS && l2 <= EMO_MAX_LDS, "favor bwd: LDS %zu / %zu / %zu too large", l0, l1, l2);
+        auto k0 = favor_fwd_kernel<CT, DH, MF, CF, true>;
+        auto k1 = favor_bwd_dq_kernel<CT, DH, MF, CQ>;
+        auto k2 = favor_bwd_dkv_kernel<CT, DH, MF, CK, false>;
+        auto k2s = favor_bwd_dkv_kernel<CT, DH, MF, CK, true>;
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l0);
+            (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
+            (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+            (void)hipFuncSetAttribute((const void*)k2s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+            attr = true;
+        }
+        // P > 1: the K-state increments are recomputed (state-only forward pass), then the workspace is reused for the R-state increments
+        if (P > 1)
+            hipLaunchKernelGGL(k0, grid, dim3(FT), l0, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (CT*)nullptr, ld_out, (float*)nullptr,
+                               (float*)nullptr, (float*)nullptr, T, H, eps, wsS, wsz, P, Ts);
         hipLaunchKernelGGL(k1, grid, dim3(FT), l1, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
-                           (CT*)dq, ld_d, T, H);
+                           (CT*)dq, ld_d, T, H, (const float*)wsS, (const float*)wsz, P, Ts);
+        if (P > 1)
+            hipLaunchKernelGGL(k2s, grid, dim3(FT), l2, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
+                               (CT*)dk, (CT*)dv, ld_d, T, H, wsS, wsz, P, Ts);
         hipLaunchKernelGGL(k2, grid, dim3(FT), l2, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
-                           (CT*)dk, (CT*)dv, ld_d, T, H);
+                           (CT*)dk, (CT*)dv, ld_d, T, H, wsS, wsz, P, Ts);
     }
     EMO_LAUNCH_CHECK();
     return EMO_OK;
@@ -898,12 +1064,14 @@ static int run_favor(int which, const void* q, const void* k, const void* v, int
 
 static int dispatch_favor(int which, int dtype, int64_t dh, int64_t mf, const void* q, const void* k, const void* v, int64_t ld, const float* omega,
                           void* out, int64_t ld_out, float* den, float* sS, float* sz, const void* dout, void* dq, void* dk, void* dv, int64_t ld_d,
-                          int64_t B, int64_t T, int64_t H, float eps, hipStream_t st) {
+                          int64_t B, int64_t T, int64_t H, float eps, void* ws, int64_t ws_bytes, hipStream_t st) {
 #define FAVOR_CASE(DHv, MFv, CFb, CQb, CKb, CFf, CQf, CKf)                                                                                   \
     if (dh == DHv && mf == MFv) {                                                                                                            \
         if (dtype == EMO_BF16)                                                                                                               \
-            return run_favor<bf16_t, DHv, MFv, CFb, CQb, CKb>(which, q, k, v, ld, omega, out, ld_out, den, sS, sz, dout, dq, dk, dv, ld_d, B, T, H, eps, st); \
-        return run_favor<float, DHv, MFv, CFf, CQf, CKf>(which, q, k, v, ld, omega, out, ld_out, den, sS, sz, dout, dq, dk, dv, ld_d, B, T, H, eps, st);     \
+            return run_favor<bf16_t, DHv, MFv, CFb, CQb, CKb>(which, q, k, v, ld, omega, out, ld_out, den, sS, sz, dout, dq, dk, dv, ld_d, B, T, H, eps, ws, \
+                                                              ws_bytes, st);                                                                 \
+        return run_favor<float, DHv, MFv, CFf, CQf, CKf>(which, q, k, v, ld, omega, out, ld_out, den, sS, sz, dout, dq, dk, dv, ld_d, B, T, H, eps, ws,      \
+                                                         ws_bytes, st);                                                                      \
     }
     FAVOR_CASE(64, 64, 64, 64, 64, 32, 32, 16)
     FAVOR_CASE(32, 64, 64, 64, 64, 32, 32, 32)
@@ -928,26 +1096,26 @@ static int favor_check(const void* q, const void* k, const void* v, int64_t ld, 
 
 extern "C" int emo_favor_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const float* omega, void* out, int64_t ld_out, float* den,
                                   float* state_S, float* state_z, int dtype, int64_t B, int64_t T, int64_t H, int64_t dh, int64_t n_feat, float eps,
-                                  emo_stream_t stream) {
+                                  void* workspace, int64_t workspace_bytes, emo_stream_t stream) {
     int rc = favor_check(q, k, v, ld, ld_out, dtype, dh, n_feat);
     if (rc) return rc;
     EMO_CHECK(omega && out && den, "emo_favor_attn_fwd: null pointer");
     EMO_CHECK(((uintptr_t)out & 15) == 0, "emo_favor_attn_fwd: out must be 16-B aligned");
     EMO_CHECK(!(state_S && !state_z), "emo_favor_attn_fwd: state_S without state_z");
     return dispatch_favor(0, dtype, dh, n_feat / 2, q, k, v, ld, omega, out, ld_out, den, state_S, state_z, nullptr, nullptr, nullptr, nullptr, 0, B, T, H,
-                          eps, (hipStream_t)stream);
+                          eps, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int emo_favor_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const float* omega, const void* out, const void* dout,
                                   int64_t ld_out, const float* den, void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H,
-                                  int64_t dh, int64_t n_feat, float eps, emo_stream_t stream) {
+                                  int64_t dh, int64_t n_feat, float eps, void* workspace, int64_t workspace_bytes, emo_stream_t stream) {
     int rc = favor_check(q, k, v, ld, ld_out, dtype, dh, n_feat);
     if (rc) return rc;
     EMO_CHECK(omega && out && dout && den && dq && dk && dv, "emo_favor_attn_bwd: null pointer");
     EMO_CHECK(ld_d % 4 == 0, "emo_favor_attn_bwd: ld_d must be a multiple of 4");
     EMO_CHECK((((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)out | (uintptr_t)dout) & 15) == 0, "emo_favor_attn_bwd: pointers must be 16-B aligned");
     return dispatch_favor(1, dtype, dh, n_feat / 2, q, k, v, ld, omega, (void*)out, ld_out, (float*)den, nullptr, nullptr, dout, dq, dk, dv, ld_d, B, T, H,
-                          eps, (hipStream_t)stream);
+                          eps, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int emo_favor_decode_step(const void* q, const void* k, const void* v, int64_t ld, const float* omega, float* state_S, float* state_z, void* out,

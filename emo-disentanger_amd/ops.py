@@ -107,6 +107,23 @@ def dropout_apply(x, p_drop, seed, offset):
     return out
 
 
+_favor_ws = {}
+
+
+def _favor_workspace(device, B, T, H, dh, n_feat):
+    """Scratch for the segment-parallel scan (see include/emo_hip.h); one buffer per (device, stream), grown on demand.  Consumers on
+    one stream run in launch order, so fwd/bwd of all layers can share it."""
+    need = lib.emo_favor_attn_workspace_bytes(B, T, H, dh, n_feat)
+    if need == 0:
+        return None, 0
+    key = (device, stream())
+    buf = _favor_ws.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(need, device=device, dtype=torch.uint8)
+        _favor_ws[key] = buf
+    return buf, need
+
+
 def favor_attn_fwd(q, k, v, omega, B, T, H, eps=1e-6, want_state=False):
     """q,k,v: [B*T, H*dh] (row-strided views allowed). Returns out [B*T, H*dh], den [B,H,T] (, S, z)."""
     M, HD = q.shape
@@ -118,8 +135,9 @@ def favor_attn_fwd(q, k, v, omega, B, T, H, eps=1e-6, want_state=False):
     den = torch.empty(B, H, T, device=q.device, dtype=torch.float32)
     S = torch.empty(B, H, n_feat, dh, device=q.device, dtype=torch.float32) if want_state else None
     z = torch.empty(B, H, n_feat, device=q.device, dtype=torch.float32) if want_state else None
+    ws, ws_bytes = _favor_workspace(q.device, B, T, H, dh, n_feat)
     check(lib.emo_favor_attn_fwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(omega), ptr(out), HD, ptr(den), ptr(S), ptr(z), dtype_code(q.dtype),
-                                 B, T, H, dh, n_feat, eps, stream()))
+                                 B, T, H, dh, n_feat, eps, ptr(ws), ws_bytes, stream()))
     return (out, den, S, z) if want_state else (out, den)
 
 
@@ -132,8 +150,9 @@ def favor_attn_bwd(q, k, v, omega, out, dout, den, B, T, H, dqkv=None, eps=1e-6)
     if dqkv is None:
         dqkv = torch.empty(M, 3 * HD, device=q.device, dtype=q.dtype)
     dq, dk, dv = dqkv[:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:]
+    ws, ws_bytes = _favor_workspace(q.device, B, T, H, dh, n_feat)
     check(lib.emo_favor_attn_bwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(omega), ptr(out), ptr(dout), HD, ptr(den), ptr(dq), ptr(dk), ptr(dv),
-                                 3 * HD, dtype_code(q.dtype), B, T, H, dh, n_feat, eps, stream()))
+                                 3 * HD, dtype_code(q.dtype), B, T, H, dh, n_feat, eps, ptr(ws), ws_bytes, stream()))
     return dq, dk, dv
 
 

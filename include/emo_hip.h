@@ -107,15 +107,24 @@ int emo_dropout_apply(const void* x, void* out, int dtype, int64_t n, float p_dr
  * omega [dh, n_feat/2] fp32; out [B*T, H*dh] (ld_out); den [B,H,T] fp32 (saved for backward).
  * state_S [B,H,n_feat,dh] / state_z [B,H,n_feat] fp32: optional final scan state (decode prefill).
  * Replaces fast-transformers Favor.forward + CausalLinearAttention.forward + native
- * causal_product (called via model/fast_transformer_decoder.py:28-40) and their backward. */
+ * causal_product (called via model/fast_transformer_decoder.py:28-40) and their backward.
+ *
+ * workspace: when B*H workgroups cannot fill the GPU (the reference's default batch_size 4 x 8 heads
+ * = 32), the scan is cut into P time segments that run in parallel: a state-only pass writes each
+ * segment's state increment to the workspace and the main pass starts every segment from the sum
+ * of the increments before it (behind it, for the reverse sweep of dk/dv).  The caller owns the
+ * scratch: emo_favor_attn_workspace_bytes() gives its size (0 = single segment; same value for
+ * fwd and bwd, contents need not survive between calls).  workspace = NULL forces P = 1. */
+int64_t emo_favor_attn_workspace_bytes(int64_t B, int64_t T, int64_t H, int64_t dh, int64_t n_feat);
 int emo_favor_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const float* omega,
                        void* out, int64_t ld_out, float* den, float* state_S, float* state_z,
                        int dtype, int64_t B, int64_t T, int64_t H, int64_t dh, int64_t n_feat,
-                       float eps, emo_stream_t stream);
+                       float eps, void* workspace, int64_t workspace_bytes, emo_stream_t stream);
 int emo_favor_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const float* omega,
                        const void* out, const void* dout, int64_t ld_out, const float* den,
                        void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T,
-                       int64_t H, int64_t dh, int64_t n_feat, float eps, emo_stream_t stream);
+                       int64_t H, int64_t dh, int64_t n_feat, float eps, void* workspace,
+                       int64_t workspace_bytes, emo_stream_t stream);
 /* one recurrent step per stream: state += phi(k) (x) v ; out = phi(q)^T S / (phi(q).z + eps) */
 int emo_favor_decode_step(const void* q, const void* k, const void* v, int64_t ld, const float* omega,
                           float* state_S, float* state_z, void* out, int64_t ld_out, int dtype,

@@ -235,6 +235,69 @@ def test_favor_attention_fwd_bwd_vs_oracle(dt, B, T, H, dh, nf):
     _close(dk.reshape(B, T, H, dh), k.grad, dt, scale=gscale, mult=4)
 
 
+# segment-parallel scan (B*H < 256 workgroups): automatic segment count, forced counts, ragged last segment, empty tail segments
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('B,T,H,dh,nf,segs', [(1, 700, 2, 64, 128, None), (1, 512, 2, 32, 64, 4), (2, 330, 1, 16, 32, 3), (1, 1000, 1, 32, 128, 16),
+                                              (1, 257, 2, 64, 128, 2)])
+def test_favor_attention_segmented_scan(dt, B, T, H, dh, nf, segs, monkeypatch):
+    ops = _ops()
+    from oracle import model_ref
+    from oracle.weights import orthogonal_omega
+    from emo_disentanger_amd._lib import lib
+    if segs is not None:
+        monkeypatch.setenv('EMO_FAVOR_SEGMENTS', str(segs))
+    assert lib.emo_favor_attn_workspace_bytes(B, T, H, dh, nf) > 0          # these shapes do take the segmented path
+    om = orthogonal_omega(dh, nf, np.random.default_rng(8))
+    qkv = _r(B * T, 3 * H * dh, seed=11, dt=dt, scale=0.8)
+    q, k, v = [qkv[:, i * H * dh:(i + 1) * H * dh].double().view(B, T, H, dh).requires_grad_(True) for i in range(3)]
+    ref = model_ref.causal_linear_attention(q, k, v, om.double(), form='quadratic')
+    dout = _r(B, T, H, dh, seed=12, dt=dt)
+    ref.backward(dout.double())
+    qc = qkv.cuda()
+    HD = H * dh
+    out, den, S, z = ops.favor_attn_fwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], om.cuda(), B, T, H, want_state=True)
+    _close(out.view(B, T, H, dh), ref, dt, mult=3)
+    Kf = model_ref.favor_features(k.detach(), om.double())
+    _close(S, torch.einsum('nlhf,nlhd->nhfd', Kf, v.detach()), dt, mult=3)
+    _close(z, Kf.sum(1), dt, mult=3)
+    dq, dk, dv = ops.favor_attn_bwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], om.cuda(), out, dout.view(B * T, HD).cuda(), den, B, T, H)
+    gscale = max(float(q.grad.abs().max()), float(k.grad.abs().max()), float(v.grad.abs().max()))
+    _close(dv.reshape(B, T, H, dh), v.grad, dt, scale=gscale, mult=4)
+    _close(dq.reshape(B, T, H, dh), q.grad, dt, scale=gscale, mult=4)
+    _close(dk.reshape(B, T, H, dh), k.grad, dt, scale=gscale, mult=4)
+    # and against the single-segment scan of the same kernels (fp32: only the summation order of the carried state differs)
+    monkeypatch.setenv('EMO_FAVOR_SEGMENTS', '1')
+    assert lib.emo_favor_attn_workspace_bytes(B, T, H, dh, nf) == 0
+    out1, den1 = ops.favor_attn_fwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], om.cuda(), B, T, H)
+    _close(out, out1, dt, mult=3)
+    _close(den, den1, dt, scale=float(den1.abs().max()), mult=3)
+
+
+def test_favor_workspace_contract():
+    ops = _ops()
+    from emo_disentanger_amd._lib import lib, ptr, EmoError, check
+    from oracle.weights import orthogonal_omega
+    B, T, H, dh, nf = 1, 512, 2, 32, 64
+    need = lib.emo_favor_attn_workspace_bytes(B, T, H, dh, nf)
+    assert need > 0 and need % (4 * (nf * dh + nf)) == 0
+    assert lib.emo_favor_attn_workspace_bytes(64, 2048, 8, 64, 128) == 0     # B*H >= 256: one segment, no scratch
+    assert lib.emo_favor_attn_workspace_bytes(1, 100, 1, 64, 128) == 0       # too short to cut
+    om = orthogonal_omega(dh, nf, np.random.default_rng(8)).cuda()
+    qkv = _r(B * T, 3 * H * dh, seed=11, dt=torch.float32).cuda()
+    HD = H * dh
+    out = torch.empty(B * T, HD, device='cuda')
+    den = torch.empty(B, H, T, device='cuda')
+    small = torch.empty(need - 16, dtype=torch.uint8, device='cuda')
+    with pytest.raises(EmoError, match='workspace'):
+        check(lib.emo_favor_attn_fwd(ptr(qkv[:, :HD]), ptr(qkv[:, HD:2 * HD]), ptr(qkv[:, 2 * HD:]), 3 * HD, ptr(om), ptr(out), HD, ptr(den), None, None,
+                                     0, B, T, H, dh, nf, 1e-6, ptr(small), small.numel(), torch.cuda.current_stream().cuda_stream))
+    # NULL workspace = single-segment scan, same result as the wrapper's segmented call
+    check(lib.emo_favor_attn_fwd(ptr(qkv[:, :HD]), ptr(qkv[:, HD:2 * HD]), ptr(qkv[:, 2 * HD:]), 3 * HD, ptr(om), ptr(out), HD, ptr(den), None, None,
+                                 0, B, T, H, dh, nf, 1e-6, None, 0, torch.cuda.current_stream().cuda_stream))
+    out2, den2 = ops.favor_attn_fwd(qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], om, B, T, H)
+    _close(out2, out, torch.float32, mult=3)
+
+
 @pytest.mark.parametrize('dt', DT)
 def test_favor_decode_step_matches_prefill(dt):
     ops = _ops()
