@@ -29,7 +29,7 @@ struct EpiParams {
     const void* residual;
     int64_t ldc;
     int accumulate;
-    int atomic;
+    int atomic;   // 0 = plain store; > 0 = split-K partial sums via fp32 atomics, value = XCDs per split (splitk_coords)
     int ablate;   // diagnostics only (EMO_GEMM_ABLATE): 1 = skip tile loads, 2 = skip MFMAs
 };
 
@@ -269,11 +269,18 @@ __device__ __forceinline__ void tile_coords(int64_t tiles_m, int64_t tiles_n, in
 // ONE XCD (split = xcd + 8*round) and run back-to-back there: the range is fetched from HBM once into that XCD's L2
 // instead of once per XCD (measured: wgrad of the 512x512 projection was HBM-bound at 253 TFLOP/s with x-fastest order).
 // grid.x = tiles_m*tiles_n * roundup(splits, 8), grid.z = 1.
-__device__ __forceinline__ void splitk_coords(int64_t tiles_m, int64_t tiles_n, int64_t& tm, int64_t& tn, int64_t& split) {
+__device__ __forceinline__ void splitk_coords(int64_t tiles_m, int64_t tiles_n, int g, int64_t& tm, int64_t& tn, int64_t& split) {
     const int64_t bid = blockIdx.x, ntile = tiles_m * tiles_n;
     const int64_t xcd = bid & 7, q = bid >> 3;
-    split = xcd + 8 * (q / ntile);
-    const int64_t t = q % ntile;
+    int64_t t;
+    if (g <= 1) {                     // >= 8 splits: one split per XCD per round
+        split = xcd + 8 * (q / ntile);
+        t = q % ntile;
+    } else {                          // 8/g splits (g = 2, 4): a split owns g XCDs, its tiles alternate between them
+        split = xcd / g;
+        t = q * g + (xcd % g);
+        if (t >= ntile) { tm = tiles_m; tn = 0; return; }   // caller returns on tm >= tiles_m
+    }
     tm = t / tiles_n;
     tn = t % tiles_n;
 }
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
     int64_t tm, tn, split = 0;
-    if (ep.atomic) splitk_coords(tiles_m, tiles_n, tm, tn, split);
+    if (ep.atomic) splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
     else tile_coords(tiles_m, tiles_n, tm, tn);
     if (tm >= tiles_m) return;
     const int64_t m0 = tm * BM, n0 = tn * BN;
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t tiles_n = (N + GB_N - 1) / GB_N, tiles_m = (M + GB_M - 1) / GB_M;
     int64_t tm, tn, split = 0;
-    if (ep.atomic) splitk_coords(tiles_m, tiles_n, tm, tn, split);
+    if (ep.atomic) splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
     else tile_coords(tiles_m, tiles_n, tm, tn);
     if (tm >= tiles_m) return;
     const int64_t m0 = tm * GB_M, n0 = tn * GB_N;
@@ -584,7 +591,7 @@ __global__ __launch_bounds__(256, (ST == 2 && BK == 32) ? 4 : 2) void gemm_bf16_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t tiles_n = (N + GB_N - 1) / GB_N, tiles_m = (M + GB_M - 1) / GB_M;
     int64_t tm, tn, split = 0;
-    if (ep.atomic) splitk_coords(tiles_m, tiles_n, tm, tn, split);
+    if (ep.atomic) splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
     else tile_coords(tiles_m, tiles_n, tm, tn);
     if (tm >= tiles_m) return;
     const int64_t m0 = tm * GB_M, n0 = tn * GB_N;
@@ -722,7 +729,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_g3_kernel(const bf16_t* __restr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t tiles_n = (N + G3_N - 1) / G3_N, tiles_m = (M + G3_M - 1) / G3_M;
     int64_t tm, tn, split = 0;
-    if (ep.atomic) splitk_coords(tiles_m, tiles_n, tm, tn, split);
+    if (ep.atomic) splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
     else tile_coords(tiles_m, tiles_n, tm, tn);
     if (tm >= tiles_m) return;
     const int64_t m0 = tm * G3_M, n0 = tn * G3_N;
@@ -902,7 +909,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_pf_kernel(const bf16_t* __
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t tiles_n = (N + GB_N - 1) / GB_N, tiles_m = (M + GB_M - 1) / GB_M;
     int64_t tm, tn, split = 0;
-    if (ep.atomic) splitk_coords(tiles_m, tiles_n, tm, tn, split);
+    if (ep.atomic) splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
     else tile_coords(tiles_m, tiles_n, tm, tn);
     if (tm >= tiles_m) return;
     const int64_t m0 = tm * GB_M, n0 = tn * GB_N;
@@ -1402,14 +1409,30 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     // split-K: only for plain fp32 outputs (wgrad) when the tile grid cannot fill the chip
     int64_t splits = 1;
     if (dtype_out == EMO_F32 && !has_epi && tiles_m * tiles_n < 256 && K >= 8 * BKt) {
-        splits = cdiv64(512, tiles_m * tiles_n);
         const int64_t max_splits = K / (4 * BKt);
-        if (splits > max_splits) splits = max_splits;
-        if (splits >= 4) {                       // one K-split per XCD round (splitk_coords): keep the 8 XCDs evenly loaded
-            const int64_t r8 = cdiv64(splits, 8) * 8;   // (a rounds x steps cost model that preferred 32 splits measured slower: atomics)
-            splits = r8 <= max_splits ? r8 : ((splits / 8) * 8 > 0 ? (splits / 8) * 8 : splits);
+        if (big) {
+            // Cost model fitted to the r01 sweep (tools/bench_wgrad_splits.py, M = 8k/32k/131k tokens): a 128^2 x 64 K-step takes ~1.1 us
+            // with one block per CU and ~1.4 us with two; blocks run in rounds of 512 (2 per CU); every split pays ~0.18 us per output
+            // tile for its fp32 atomics.  (The old "fill 512 blocks" rule over-split small token counts: 162 vs 77 us at M = 8192.)
+            static const int cand[] = {1, 2, 4, 8, 16, 24, 32};
+            const double tiles = (double)(tiles_m * tiles_n), ksteps = (double)cdiv64(K, BKt);
+            double best = 1e30;
+            for (int c : cand) {
+                if (c > max_splits && c > 1) break;
+                const double blocks = tiles * c, rounds = (double)cdiv64((int64_t)blocks, 512);
+                const double t = rounds * (double)cdiv64((int64_t)ksteps, c) * (blocks > 256 ? 1.4 : 1.1) + c * tiles * 0.18;
+                if (t < best) { best = t; splits = c; }
+            }
+        } else {
+            splits = cdiv64(512, tiles_m * tiles_n);
+            if (splits > max_splits) splits = max_splits;
+            if (splits >= 4) {                       // one K-split per XCD round (splitk_coords): keep the 8 XCDs evenly loaded
+                const int64_t r8 = cdiv64(splits, 8) * 8;
+                splits = r8 <= max_splits ? r8 : ((splits / 8) * 8 > 0 ? (splits / 8) * 8 : splits);
+            }
         }
         if (splits < 1) splits = 1;
+        { const char* fs = getenv("EMO_GEMM_SPLITS"); if (fs && atoi(fs) > 0) splits = atoi(fs) <= max_splits ? atoi(fs) : max_splits; }   // tuning sweeps
     }
     int64_t kps = cdiv64(cdiv64(K, splits), BKt) * BKt;
     splits = cdiv64(K, kps);
@@ -1419,10 +1442,11 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
             hipError_t me = hipMemsetAsync(C, 0, (size_t)(M * N) * sizeof(float), st);
             EMO_CHECK(me == hipSuccess, "emo_gemm: memset failed");
         }
-        ep.atomic = 1;
+        ep.atomic = (splits == 2 || splits == 4) ? (int)(8 / splits) : 1;
     }
     dim3 grid((unsigned)(tiles_m8 * tiles_n), 1, 1);
-    if (splits > 1) grid.x = (unsigned)(tiles_m * tiles_n * (cdiv64(splits, 8) * 8));   // see splitk_coords()
+    if (splits > 1)   // see splitk_coords()
+        grid.x = ep.atomic > 1 ? (unsigned)(8 * cdiv64(tiles_m * tiles_n, ep.atomic)) : (unsigned)(tiles_m * tiles_n * (cdiv64(splits, 8) * 8));
     if (dtype_in == EMO_F32) {
         const float* a = (const float*)A;
         const float* b = (const float*)B;
