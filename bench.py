@@ -44,33 +44,64 @@ def time_kernel(fn, iters=10, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
+GEMM_KERNELS = {   # layout class of ops.gemm -> the kernel instance it launches at the bench shapes (names as in the rocprofv3 summary)
+    'TN': ('gemm_bf16_kernel<false,false,false,float,64> + splitk_reduce_kernel', 'wgrad dW = dY^T X, reduction over the B*T tokens'),
+    'NN': ('gemm_bf16_glds_kernel<true,false,bf16,32,2>', 'dgrad dX = dY W'),
+    'NT': ('gemm_bf16_glds_kernel<true,true,bf16,32,3>', 'forward Y = X W^T + fused epilogue, K = 512'),
+    'NT/K>1024': ('gemm_bf16_glds_kernel<true,true,bf16,64,2>', 'forward Y = X W^T + fused epilogue, K = 2048'),
+}
+
+
 def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
-    """Dominant kernel by total time (rocprofv3 --kernel-trace --stats, profiles/): the wgrad instance
-    gemm_bf16_kernel<A_KC=0,B_KC=0,fp32 out,BK=64> (dW = dY^T X, reduction over the B*T tokens, both operands read through
-    ds_read_b64_tr_b16, split-K fp32 atomics placed per XCD).  Every launch of it inside `n_steps` real training steps is
-    bracketed by HIP events on the launch stream (in situ: same data, same cache state as the timed region);
-    achieved = sum(algorithmic FLOPs = 2*M*N*K) / sum(durations)."""
-    from emo_disentanger_amd import engine
-    engine.KERNEL_TIMING = []
-    for _ in range(n_steps):
-        step_fn()
-    torch.cuda.synchronize()
-    rec, engine.KERNEL_TIMING = engine.KERNEL_TIMING, None
-    ms = [e0.elapsed_time(e1) for e0, e1, _, _ in rec]
-    flops = sum(r[2] for r in rec)
-    abytes = sum(r[3] for r in rec)
-    tot = sum(ms)
-    achieved = flops / tot / 1e9
-    traffic = None          # HBM bytes per launch from rocprofv3 PMC passes (collected offline, committed under profiles/)
+    """Every GEMM launch inside `n_steps` real training steps is bracketed by HIP events on its launch stream (in situ: same data,
+    same cache state as the timed region).  The four GEMM kernel instances (wgrad TN, dgrad NN, forward NT at K=512 and K=2048) take ~65 % of the
+    step; `roofline` is the class with the largest total time (the dominant kernel of the rocprofv3 summary under profiles/),
+    the others are listed in `roofline_others`.  achieved = sum(algorithmic FLOPs = 2*M*N*K) / sum(durations).
+
+    Kernel durations only mean something when kernels do not share the CUs: the optional second HIP stream for wgrad
+    (EMO_WGRAD_STREAM=1, off by default) is forced off for the instrumented steps; when it is enabled for the timed region the
+    stretched in-step average is reported next to the serialized one."""
+    from emo_disentanger_amd import engine, ops
+
+    def instrumented(side_on):
+        was = engine._SIDE['on']
+        engine._SIDE['on'] = side_on and was
+        ops.GEMM_TIMING = []
+        try:
+            for _ in range(n_steps):
+                step_fn()
+            torch.cuda.synchronize()
+        finally:
+            rec, ops.GEMM_TIMING = ops.GEMM_TIMING, None
+            engine._SIDE['on'] = was
+        by = {}
+        for kind, e0, e1, fl, by_ in rec:
+            d = by.setdefault(kind, {'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'n': 0})
+            d['ms'] += e0.elapsed_time(e1); d['flops'] += fl; d['bytes'] += by_; d['n'] += 1
+        return by
+
+    serial = instrumented(False)
+    overlapped = instrumented(True) if engine._SIDE['on'] else {}
     pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_wgrad.json')
-    if os.path.exists(pmc) and B * T == 131072:
-        traffic = json.load(open(pmc)).get('traffic_bytes_per_launch')
-    return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
-            'kernel': 'gemm_bf16_kernel<false,false,false,float,64> (wgrad dW = dY^T X over B*T tokens)',
-            'launches_timed': len(rec), 'avg_launch_ms': round(tot / len(rec), 4),
-            'algorithmic_flops_per_launch': round(flops / len(rec)), 'algorithmic_bytes_per_launch': round(abytes / len(rec)),
-            'timing': 'HIP events around every launch of this kernel in %d real training steps (launch stream = torch current stream)' % n_steps}
+
+    def entry(kind):
+        d = serial[kind]
+        achieved = d['flops'] / d['ms'] / 1e9
+        traffic = None      # HBM bytes per launch from rocprofv3 PMC passes (collected offline, committed under profiles/)
+        if kind == 'TN' and os.path.exists(pmc) and B * T == 131072:
+            traffic = json.load(open(pmc)).get('traffic_bytes_per_launch')
+        return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+                'kernel': '%s (%s)' % GEMM_KERNELS.get(kind, (kind, 'other GEMM')), 'launches_timed': d['n'], 'avg_launch_ms': round(d['ms'] / d['n'], 4),
+                'total_ms_per_step': round(d['ms'] / n_steps, 2),
+                'avg_launch_ms_overlapped_in_step': round(overlapped[kind]['ms'] / overlapped[kind]['n'], 4) if kind in overlapped else None,
+                'algorithmic_flops_per_launch': round(d['flops'] / d['n']), 'algorithmic_bytes_per_launch': round(d['bytes'] / d['n'])}
+
+    order = sorted(serial, key=lambda k: -serial[k]['ms'])
+    roof = entry(order[0])
+    roof['timing'] = 'HIP events on the launch stream around every GEMM launch in %d real training steps (kernels serialized on one stream)' % n_steps
+    roof['roofline_others'] = [entry(k) for k in order[1:]]
+    return roof
 
 
 def generation_bench(model, n_streams=32, prompt=64, n_new=256, top_p=0.9, temp=1.1):

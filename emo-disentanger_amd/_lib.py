@@ -24,7 +24,7 @@ c_p, c_i, c_l, c_f, c_u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctype
 
 class Epilogue(ctypes.Structure):
     _fields_ = [('bias', c_p), ('act', c_i), ('aux_out', c_p), ('mul_aux', c_p), ('mul_mode', c_i), ('mul_scale', c_f),
-                ('p_drop', c_f), ('seed', c_u64), ('offset', c_u64), ('residual', c_p)]
+                ('p_drop', c_f), ('seed', c_u64), ('offset', c_u64), ('residual', c_p), ('workspace', c_p), ('workspace_bytes', c_l)]
 
 
 _SIG = {
@@ -32,6 +32,7 @@ _SIG = {
     'emo_last_error': (ctypes.c_char_p, []),
     'emo_device_cus': (c_i, []),
     'emo_gemm': (c_i, [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, ctypes.POINTER(Epilogue), c_p]),
+    'emo_gemm_workspace_bytes': (c_l, [c_l, c_l, c_l, c_i, c_i]),
     'emo_colsum': (c_i, [c_p, c_i, c_l, c_l, c_l, c_p, c_i, c_p]),
     'emo_embed_fwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_l, c_l, c_l, c_l, c_l, c_p, c_f, c_f, c_u64, c_u64, c_p]),
     'emo_embed_bwd': (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_f, c_u64, c_u64, c_p]),

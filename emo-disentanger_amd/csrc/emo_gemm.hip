@@ -30,6 +30,7 @@ struct EpiParams {
     int64_t ldc;
     int accumulate;
     int atomic;   // 0 = plain store; > 0 = split-K partial sums via fp32 atomics, value = XCDs per split (splitk_coords)
+    int64_t ws_stride;   // > 0: split-K partials go to C + split * ws_stride with plain stores (splitk_reduce_kernel sums them)
     int ablate;   // diagnostics only (EMO_GEMM_ABLATE): 1 = skip tile loads, 2 = skip MFMAs
 };
 
@@ -299,7 +300,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
     int64_t tm, tn, split = 0;
-    if (ep.atomic) splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
+    if (ep.atomic) {
+        splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
+        if (ep.ws_stride) { C += split * ep.ws_stride; ep.atomic = 0; }
+    }
     else tile_coords(tiles_m, tiles_n, tm, tn);
     if (tm >= tiles_m) return;
     const int64_t m0 = tm * BM, n0 = tn * BN;
@@ -451,7 +455,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t tiles_n = (N + GB_N - 1) / GB_N, tiles_m = (M + GB_M - 1) / GB_M;
     int64_t tm, tn, split = 0;
-    if (ep.atomic) splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
+    if (ep.atomic) {
+        splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
+        if (ep.ws_stride) { C += split * ep.ws_stride; ep.atomic = 0; }
+    }
     else tile_coords(tiles_m, tiles_n, tm, tn);
     if (tm >= tiles_m) return;
     const int64_t m0 = tm * GB_M, n0 = tn * GB_N;
@@ -591,7 +598,10 @@ __global__ __launch_bounds__(256, (ST == 2 && BK == 32) ? 4 : 2) void gemm_bf16_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t tiles_n = (N + GB_N - 1) / GB_N, tiles_m = (M + GB_M - 1) / GB_M;
     int64_t tm, tn, split = 0;
-    if (ep.atomic) splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
+    if (ep.atomic) {
+        splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
+        if (ep.ws_stride) { C += split * ep.ws_stride; ep.atomic = 0; }
+    }
     else tile_coords(tiles_m, tiles_n, tm, tn);
     if (tm >= tiles_m) return;
     const int64_t m0 = tm * GB_M, n0 = tn * GB_N;
@@ -729,7 +739,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_g3_kernel(const bf16_t* __restr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t tiles_n = (N + G3_N - 1) / G3_N, tiles_m = (M + G3_M - 1) / G3_M;
     int64_t tm, tn, split = 0;
-    if (ep.atomic) splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
+    if (ep.atomic) {
+        splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
+        if (ep.ws_stride) { C += split * ep.ws_stride; ep.atomic = 0; }
+    }
     else tile_coords(tiles_m, tiles_n, tm, tn);
     if (tm >= tiles_m) return;
     const int64_t m0 = tm * G3_M, n0 = tn * G3_N;
@@ -909,7 +922,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_pf_kernel(const bf16_t* __
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t tiles_n = (N + GB_N - 1) / GB_N, tiles_m = (M + GB_M - 1) / GB_M;
     int64_t tm, tn, split = 0;
-    if (ep.atomic) splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
+    if (ep.atomic) {
+        splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
+        if (ep.ws_stride) { C += split * ep.ws_stride; ep.atomic = 0; }
+    }
     else tile_coords(tiles_m, tiles_n, tm, tn);
     if (tm >= tiles_m) return;
     const int64_t m0 = tm * GB_M, n0 = tn * GB_N;
@@ -1356,6 +1372,64 @@ static void dispatch_bf16(bool akc, bool bkc, dim3 grid, hipStream_t st, const b
     else launch_bf16<false, false, SAFE, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
 }
 
+// ------------------------------------------------------------------------------------------------ split-K
+// out (+)= sum over splits of the partial results written by the GEMM (deterministic: fixed summation order, no atomics)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int64_t stride, int splits, float* __restrict__ out, int64_t n4,
+                                                            int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 a = accumulate ? ((const f32x4*)out)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splits; ++s) a += *(const f32x4*)(ws + s * stride + 4 * i);
+    ((f32x4*)out)[i] = a;
+}
+
+// number of K-splits for a plain fp32-output GEMM (wgrad).  max_ws_splits > 0: partials go to a caller workspace (plain stores +
+// splitk_reduce_kernel); 0: fp32 atomics into C.
+static int64_t choose_splits(int64_t M, int64_t N, int64_t K, bool big, bool has_epi, int dtype_out, int64_t BMt, int64_t BNt, int64_t BKt,
+                             int64_t max_ws_splits) {
+    const int64_t tiles_m = cdiv64(M, BMt), tiles_n = cdiv64(N, BNt);
+    int64_t splits = 1;
+    if (dtype_out == EMO_F32 && !has_epi && tiles_m * tiles_n < 256 && K >= 8 * BKt) {
+        const int64_t max_splits = K / (4 * BKt);
+        if (big) {
+            // Cost model fitted to the r01 sweep (tools/bench_wgrad_splits.py, M = 8k/32k/131k tokens): a 128^2 x 64 K-step takes ~1.1 us
+            // with one block per CU and ~1.4 us with two; blocks run in rounds of 512 (2 per CU); every split pays ~0.18 us per output
+            // tile for its fp32 atomics (device-scope atomics from 8 XCDs resolve beyond the L2s: ~0.3 TB/s), or ~0.03 us per tile for
+            // plain stores + its share of the reduce pass when a workspace is available.
+            static const int cand[] = {1, 2, 4, 8, 16, 24, 32};
+            const double tiles = (double)(tiles_m * tiles_n), ksteps = (double)cdiv64(K, BKt);
+            const double per_split = max_ws_splits > 0 ? 0.03 : 0.18;
+            double best = 1e30;
+            for (int c : cand) {
+                if (c > 1 && (c > max_splits || (max_ws_splits > 0 && c > max_ws_splits))) break;
+                const double blocks = tiles * c, rounds = (double)cdiv64((int64_t)blocks, 512);
+                const double t = rounds * (double)cdiv64((int64_t)ksteps, c) * (blocks > 256 ? 1.4 : 1.1) + c * tiles * per_split;
+                if (t < best) { best = t; splits = c; }
+            }
+        } else {
+            splits = cdiv64(512, tiles_m * tiles_n);
+            if (splits > max_splits) splits = max_splits;
+            if (splits >= 4) {                       // one K-split per XCD round (splitk_coords): keep the 8 XCDs evenly loaded
+                const int64_t r8 = cdiv64(splits, 8) * 8;
+                splits = r8 <= max_splits ? r8 : ((splits / 8) * 8 > 0 ? (splits / 8) * 8 : splits);
+            }
+            if (max_ws_splits > 0 && splits > max_ws_splits) splits = max_ws_splits;
+        }
+        if (splits < 1) splits = 1;
+        { const char* fs = getenv("EMO_GEMM_SPLITS"); if (fs && atoi(fs) > 0) splits = atoi(fs) <= max_splits ? atoi(fs) : max_splits; }   // tuning sweeps
+    }
+    return splits;
+}
+
+#define EMO_GEMM_MAX_SPLITS 32
+extern "C" int64_t emo_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype_in, int dtype_out) {
+    if (dtype_out != EMO_F32 || M <= 0 || N <= 0 || K <= 0) return 0;
+    const bool big = dtype_in == EMO_BF16;
+    const int64_t BMt = big ? GB_M : 64, BNt = big ? GB_N : 64, BKt = big ? (gemm_variant() >= 2 ? G2_BK : GB_K) : 16;
+    const int64_t splits = choose_splits(M, N, K, big, false, dtype_out, BMt, BNt, BKt, EMO_GEMM_MAX_SPLITS);
+    return splits > 1 ? splits * M * N * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, int b_trans, int64_t ldb, void* C,
                         int64_t ldc, int64_t M, int64_t N, int64_t K, int dtype_in, int dtype_out, int accumulate,
                         const emo_epilogue_t* e, emo_stream_t stream) {
@@ -1407,43 +1481,28 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     const int64_t tiles_m = cdiv64(M, BMt), tiles_n = cdiv64(N, BNt);
     const int64_t tiles_m8 = cdiv64(tiles_m, 8) * 8;
     // split-K: only for plain fp32 outputs (wgrad) when the tile grid cannot fill the chip
-    int64_t splits = 1;
-    if (dtype_out == EMO_F32 && !has_epi && tiles_m * tiles_n < 256 && K >= 8 * BKt) {
-        const int64_t max_splits = K / (4 * BKt);
-        if (big) {
-            // Cost model fitted to the r01 sweep (tools/bench_wgrad_splits.py, M = 8k/32k/131k tokens): a 128^2 x 64 K-step takes ~1.1 us
-            // with one block per CU and ~1.4 us with two; blocks run in rounds of 512 (2 per CU); every split pays ~0.18 us per output
-            // tile for its fp32 atomics.  (The old "fill 512 blocks" rule over-split small token counts: 162 vs 77 us at M = 8192.)
-            static const int cand[] = {1, 2, 4, 8, 16, 24, 32};
-            const double tiles = (double)(tiles_m * tiles_n), ksteps = (double)cdiv64(K, BKt);
-            double best = 1e30;
-            for (int c : cand) {
-                if (c > max_splits && c > 1) break;
-                const double blocks = tiles * c, rounds = (double)cdiv64((int64_t)blocks, 512);
-                const double t = rounds * (double)cdiv64((int64_t)ksteps, c) * (blocks > 256 ? 1.4 : 1.1) + c * tiles * 0.18;
-                if (t < best) { best = t; splits = c; }
-            }
-        } else {
-            splits = cdiv64(512, tiles_m * tiles_n);
-            if (splits > max_splits) splits = max_splits;
-            if (splits >= 4) {                       // one K-split per XCD round (splitk_coords): keep the 8 XCDs evenly loaded
-                const int64_t r8 = cdiv64(splits, 8) * 8;
-                splits = r8 <= max_splits ? r8 : ((splits / 8) * 8 > 0 ? (splits / 8) * 8 : splits);
-            }
-        }
-        if (splits < 1) splits = 1;
-        { const char* fs = getenv("EMO_GEMM_SPLITS"); if (fs && atoi(fs) > 0) splits = atoi(fs) <= max_splits ? atoi(fs) : max_splits; }   // tuning sweeps
-    }
+    void* ws = e ? e->workspace : nullptr;
+    const int64_t ws_bytes = e ? e->workspace_bytes : 0;
+    const bool ws_ok = ws && ldc == N && ((M * N) & 3) == 0 && ((uintptr_t)ws & 15) == 0 && getenv("EMO_GEMM_SPLIT_ATOMIC") == nullptr;
+    int64_t max_ws_splits = ws_ok ? ws_bytes / (M * N * (int64_t)sizeof(float)) : 0;
+    int64_t splits = choose_splits(M, N, K, big, has_epi, dtype_out, BMt, BNt, BKt, max_ws_splits >= 2 ? max_ws_splits : 0);
     int64_t kps = cdiv64(cdiv64(K, splits), BKt) * BKt;
     splits = cdiv64(K, kps);
+    const bool use_ws = splits > 1 && max_ws_splits >= splits;
+    const int accumulate_final = accumulate;
     if (splits > 1) {
         EMO_CHECK(ldc == N, "emo_gemm: split-K needs contiguous C");
-        if (!accumulate) {
+        if (use_ws) {
+            ep.ws_stride = M * N;
+            ep.accumulate = 0;
+        } else if (!accumulate) {
             hipError_t me = hipMemsetAsync(C, 0, (size_t)(M * N) * sizeof(float), st);
             EMO_CHECK(me == hipSuccess, "emo_gemm: memset failed");
         }
         ep.atomic = (splits == 2 || splits == 4) ? (int)(8 / splits) : 1;
     }
+    void* const C_final = C;
+    if (use_ws) C = ws;
     dim3 grid((unsigned)(tiles_m8 * tiles_n), 1, 1);
     if (splits > 1)   // see splitk_coords()
         grid.x = ep.atomic > 1 ? (unsigned)(8 * cdiv64(tiles_m * tiles_n, ep.atomic)) : (unsigned)(tiles_m * tiles_n * (cdiv64(splits, 8) * 8));
@@ -1497,6 +1556,12 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         }
     }
     EMO_LAUNCH_CHECK();
+    if (use_ws) {
+        const int64_t n4 = (M * N) >> 2;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, st, (const float*)ws, M * N, (int)splits, (float*)C_final, n4,
+                           accumulate_final);
+        EMO_LAUNCH_CHECK();
+    }
     return EMO_OK;
 }
 

@@ -147,13 +147,12 @@ def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save):
     return out
 
 
-KERNEL_TIMING = None   # bench.py sets this to a list to HIP-event-time every wgrad launch in situ (same stream as the launch)
-
-# Weight-gradient GEMMs (and the remaining bias column sums) only feed the optimizer, so they run on a SECOND HIP stream
-# next to the dgrad / attention-backward chain of the main stream: the two kernels' prologue / epilogue / tail phases
-# overlap on the CUs.  EMO_WGRAD_STREAM=0 disables it.
+# Weight-gradient GEMMs (and the remaining bias column sums) only feed the optimizer, so they CAN run on a second HIP stream
+# next to the dgrad / attention-backward chain of the main stream (EMO_WGRAD_STREAM=1).  Measured r01: worth 3.5 % while the
+# wgrad kernel still paid for split-K atomics (79.9 -> 77.1 ms/step); with the workspace split-K the kernels no longer leave
+# gaps to fill and sharing the CUs costs more than it hides (72.9 ms with, 70.8 ms without) -> off by default.
 import os as _os
-_SIDE = {'stream': None, 'on': _os.environ.get('EMO_WGRAD_STREAM', '1') != '0'}
+_SIDE = {'stream': None, 'on': _os.environ.get('EMO_WGRAD_STREAM', '0') == '1'}
 
 
 class _side_stream:
@@ -190,14 +189,7 @@ def join_side_stream():
 
 
 def _timed_wgrad(a, b, out):
-    if KERNEL_TIMING is None:
-        ops.gemm(a, b, a_trans=True, b_trans=True, out=out, accumulate=True)
-        return
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
     ops.gemm(a, b, a_trans=True, b_trans=True, out=out, accumulate=True)
-    e1.record()
-    KERNEL_TIMING.append((e0, e1, 2.0 * a.shape[0] * a.shape[1] * b.shape[1], (a.shape[0] * (a.shape[1] + b.shape[1])) * a.element_size()))
 
 
 def _wgrad(ps, wname, bname, dy, xin, fused_rows=None, bias_done=False):

@@ -31,6 +31,23 @@ def _rows(t):
     return t.stride(0)
 
 
+_ws_cache = {}
+GEMM_TIMING = None   # bench.py sets this to a list: every GEMM launch is then bracketed by HIP events on its launch stream (in situ)
+
+
+def _workspace(kind, device, need):
+    """Caller-owned kernel scratch (the library never allocates): one buffer per (kind, device, stream), grown on demand.  Consumers on one
+    stream run in launch order, so consecutive launches can share it."""
+    if need == 0:
+        return None, 0
+    key = (kind, device, stream())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(need, device=device, dtype=torch.uint8)
+        _ws_cache[key] = buf
+    return buf, buf.numel()
+
+
 def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumulate=False, bias=None, act=ACT_NONE,
          aux_out=None, mul_aux=None, mul_mode=MUL_NONE, mul_scale=1.0, p_drop=0.0, seed=0, offset=0, residual=None):
     """C[M,N] = epilogue(op(A) @ op(B));  a_trans: A stored [K,M];  b_trans=False: B stored [N,K] (nn.Linear),
@@ -41,12 +58,22 @@ def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumu
     assert A.dtype == B.dtype
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=out_dtype or A.dtype)
-    epi = Epilogue(ptr(bias), act, ptr(aux_out), ptr(mul_aux), mul_mode, mul_scale, p_drop, seed, offset, ptr(residual))
+    ws, ws_bytes = None, 0
+    if out.dtype == torch.float32 and bias is None and residual is None and aux_out is None and mul_aux is None and act == ACT_NONE and p_drop == 0.0:
+        ws, ws_bytes = _workspace('gemm', A.device, lib.emo_gemm_workspace_bytes(M, N, K, dtype_code(A.dtype), dtype_code(out.dtype)))
+    epi = Epilogue(ptr(bias), act, ptr(aux_out), ptr(mul_aux), mul_mode, mul_scale, p_drop, seed, offset, ptr(residual), ptr(ws), ws_bytes)
     for t in (aux_out, mul_aux, residual):
         assert t is None or (t.dtype == out.dtype and _rows(t) == _rows(out))
     assert bias is None or bias.dtype == torch.float32
+    if GEMM_TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib.emo_gemm(ptr(A), int(a_trans), _rows(A), ptr(B), int(b_trans), _rows(B), ptr(out), _rows(out), M, N, K,
                        dtype_code(A.dtype), dtype_code(out.dtype), int(accumulate), ctypes.byref(epi), stream()))
+    if GEMM_TIMING is not None:
+        e1.record()
+        GEMM_TIMING.append((('T' if a_trans else 'N') + ('N' if b_trans else 'T') + ('/K>1024' if K > 1024 and not a_trans and not b_trans else ''), e0, e1, 2.0 * M * N * K,
+                            (M * K + N * K) * A.element_size() + M * N * out.element_size()))
     return out
 
 
@@ -107,21 +134,9 @@ def dropout_apply(x, p_drop, seed, offset):
     return out
 
 
-_favor_ws = {}
-
-
 def _favor_workspace(device, B, T, H, dh, n_feat):
-    """Scratch for the segment-parallel scan (see include/emo_hip.h); one buffer per (device, stream), grown on demand.  Consumers on
-    one stream run in launch order, so fwd/bwd of all layers can share it."""
-    need = lib.emo_favor_attn_workspace_bytes(B, T, H, dh, n_feat)
-    if need == 0:
-        return None, 0
-    key = (device, stream())
-    buf = _favor_ws.get(key)
-    if buf is None or buf.numel() < need:
-        buf = torch.empty(need, device=device, dtype=torch.uint8)
-        _favor_ws[key] = buf
-    return buf, need
+    """Scratch for the segment-parallel scan (see include/emo_hip.h)."""
+    return _workspace('favor', device, lib.emo_favor_attn_workspace_bytes(B, T, H, dh, n_feat))
 
 
 def favor_attn_fwd(q, k, v, omega, B, T, H, eps=1e-6, want_state=False):

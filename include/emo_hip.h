@@ -60,7 +60,13 @@ typedef struct {
     float p_drop;         /* dropout after the activation; element index = m*N+n */
     uint64_t seed, offset;
     const void* residual; /* NULL or [M,N] (dtype_out, ld=ldc) added last */
+    void* workspace;      /* NULL or caller scratch for split-K partial sums (plain fp32-output GEMMs = weight gradients): */
+    int64_t workspace_bytes; /* with it the splits are summed in a fixed order by a reduce kernel (deterministic, no atomics);
+                              * without it they are fp32 atomics into C.  Size: emo_gemm_workspace_bytes(). */
 } emo_epilogue_t;
+
+/* scratch that lets emo_gemm() run its split-K without atomics (0 = this problem is not split) */
+int64_t emo_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype_in, int dtype_out);
 
 int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, int b_trans, int64_t ldb,
              void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,

@@ -114,6 +114,32 @@ def test_gemm_splitk_wgrad_accumulate():
         _close(cs, dY.double().sum(0), dt, mult=1.0 if dt == torch.float32 else 0.3)
 
 
+@pytest.mark.parametrize('splits', [None, 2, 4, 8, 24])
+def test_gemm_splitk_workspace_is_deterministic_and_matches_atomics(splits, monkeypatch):
+    # wgrad shapes: with the caller workspace the K-splits are summed in a fixed order (bitwise reproducible); without it they are
+    # fp32 atomics into C.  Both must agree with the reference; odd sizes exercise tile edges and the ragged last split.
+    ops = _ops()
+    from emo_disentanger_amd._lib import lib
+    if splits is not None:
+        monkeypatch.setenv('EMO_GEMM_SPLITS', str(splits))
+    for dt in DT:
+        Mred, N, K = 8192 + 64, 264, 200
+        assert lib.emo_gemm_workspace_bytes(N, K, Mred, 0 if dt == torch.float32 else 1, 0) > 0
+        dY, X = _r(Mred, N, seed=12, dt=dt).cuda(), _r(Mred, K, seed=13, dt=dt).cuda()
+        ref = dY.double().T @ X.double()
+        base = _r(N, K, seed=14).cuda()
+        o1 = ops.gemm(dY, X, a_trans=True, b_trans=True, out=base.clone(), accumulate=True)
+        o2 = ops.gemm(dY, X, a_trans=True, b_trans=True, out=base.clone(), accumulate=True)
+        assert torch.equal(o1, o2)
+        _close(o1 - base, ref, dt, mult=1.0 if dt == torch.float32 else 0.3)
+        o3 = ops.gemm(dY, X, a_trans=True, b_trans=True, out_dtype=torch.float32)
+        _close(o3, ref, dt, mult=1.0 if dt == torch.float32 else 0.3)
+        monkeypatch.setenv('EMO_GEMM_SPLIT_ATOMIC', '1')
+        o4 = ops.gemm(dY, X, a_trans=True, b_trans=True, out_dtype=torch.float32)
+        monkeypatch.delenv('EMO_GEMM_SPLIT_ATOMIC')
+        _close(o4, o3, dt, scale=float(ref.abs().max()), mult=0.05)
+
+
 def test_gemm_bf16_safe_and_tr_paths_agree(monkeypatch):
     # the transposed-operand fragments are fetched with ds_read_b64_tr_b16; EMO_GEMM_SAFE_TR=1 (read at first use)
     # selects a scalar-read variant of the same kernel; both are compared with the reference in the layout tests.
