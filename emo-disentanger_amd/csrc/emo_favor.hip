@@ -21,6 +21,9 @@
 // 8 waves per workgroup (one workgroup per (b,h), ~120-155 KB LDS => 1 workgroup per CU): two waves per SIMD so that
 // one wave's LDS / exp / global phases overlap the other's MFMAs.
 constexpr int FT = 512, FW = FT / 64;
+#ifndef FAVOR_PAD16
+#define FAVOR_PAD16 0
+#endif
 
 // per-row feature offset: off[t] = 0.5*c^2*|x_t|^2 + 0.5*ln(F); TPR threads per row, shuffle reduce
 template <typename CT, int DH, int C>
@@ -29,10 +32,16 @@ __device__ __forceinline__ void row_offsets(const CT* X, int ld, float* off, flo
     constexpr int EPT = CMax<DH / TPR, 1>::v;
     const int r = tid / TPR, part = tid % TPR;
     float s = 0.f;
+    if constexpr (sizeof(CT) == 2 && EPT == 8 && DH % 8 == 0) {       // one 16-B read instead of 8 scalar ones
+        const bf16x8 v = *(const bf16x8*)(X + r * ld + part * 8);
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int d = part * EPT + e;
-        if (d < DH) { float x = to_f32<CT>(X[r * ld + d]); s += x * x; }
+        for (int e = 0; e < 8; ++e) { const float x = (float)v[e]; s += x * x; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int d = part * EPT + e;
+            if (d < DH) { float x = to_f32<CT>(X[r * ld + d]); s += x * x; }
+        }
     }
 #pragma unroll
     for (int o = TPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -45,7 +54,9 @@ template <typename CT, int DHP, int MF, int C>
 __device__ __forceinline__ void features_rowmajor(CT* Ff, int ldf, const CT* WT, const CT* X, int ldx, const float* off, float cs,
                                                   int valid_rows, int wave, int lane) {
     constexpr int NT = (MF / 16) * (C / 16);
-    for (int tile = wave; tile < NT; tile += FW) {
+    _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
+            const int tile = wave + FW * tile_i;
+            if (NT % FW != 0 && tile >= NT) break;
         const int rt = tile / (C / 16), ct = tile % (C / 16);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         mm16<CT>(acc, WT, ldx, rt * 16, X, ldx, ct * 16, DHP, lane);
@@ -59,12 +70,43 @@ __device__ __forceinline__ void features_rowmajor(CT* Ff, int ldf, const CT* WT,
         Img<CT>::store4(Ff + t * ldf + MF + m0, n[0], n[1], n[2], n[3]);
     }
 }
+// both layouts of the same features from ONE product + ONE set of exps: Ff[t][f] (8-B stores) and FTt[f][t] (2-B stores, 16 lanes = 32
+// contiguous bytes).  r01 ablation: the feature phase (MFMA -> 8 quarter-rate v_exp per lane -> store, all dependent) was 35 % of the
+// forward kernel; the second orientation cost a full second pass.
+template <typename CT, int DHP, int MF, int C>
+__device__ __forceinline__ void features_both(CT* Ff, int ldf, CT* FTt, int ldt, const CT* WT, const CT* X, int ldx, const float* off, float cs,
+                                              int valid_rows, int wave, int lane) {
+    constexpr int NT = (MF / 16) * (C / 16);
+#pragma unroll
+    for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
+        const int tile = wave + FW * tile_i;
+        if (NT % FW != 0 && tile >= NT) break;
+        const int rt = tile / (C / 16), ct = tile % (C / 16);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        mm16<CT>(acc, WT, ldx, rt * 16, X, ldx, ct * 16, DHP, lane);
+        const int t = ct * 16 + (lane & 15), m0 = rt * 16 + (lane >> 4) * 4;
+        const float o = off[t];
+        const float ok = t < valid_rows ? 1.f : 0.f;
+        float p[4], n[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float u = cs * acc[r]; p[r] = Img<CT>::ex(u - o) * ok; n[r] = Img<CT>::ex(-u - o) * ok; }
+        Img<CT>::store4(Ff + t * ldf + m0, p[0], p[1], p[2], p[3]);
+        Img<CT>::store4(Ff + t * ldf + MF + m0, n[0], n[1], n[2], n[3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            FTt[(m0 + r) * ldt + t] = from_f32<CT>(p[r]);
+            FTt[(MF + m0 + r) * ldt + t] = from_f32<CT>(n[r]);
+        }
+    }
+}
 // transposed: FT[f][t]  (rows<->t via R=X, col<->m via C=WT)
 template <typename CT, int DHP, int MF, int C>
 __device__ __forceinline__ void features_transposed(CT* FT, int ldt, const CT* WT, const CT* X, int ldx, const float* off, float cs,
                                                     int valid_rows, int wave, int lane) {
     constexpr int NT = (MF / 16) * (C / 16);
-    for (int tile = wave; tile < NT; tile += FW) {
+    _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
+            const int tile = wave + FW * tile_i;
+            if (NT % FW != 0 && tile >= NT) break;
         const int rt = tile / (MF / 16), ct = tile % (MF / 16);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         mm16<CT>(acc, X, ldx, rt * 16, WT, ldx, ct * 16, DHP, lane);
@@ -83,9 +125,13 @@ __device__ __forceinline__ void features_transposed(CT* FT, int ldt, const CT* W
     }
 }
 
-template <typename CT, int DH, int MF, int C> struct FavorDims {
+// KIND: 0 = forward, 1 = dq, 2 = dk/dv kernel.  bf16 row pads: ds_read_b128 operand reads (lane -> row l&15, 16-B chunk l>>4) are
+// bank-conflict-free only for row strides = 8 (mod 16) dwords, i.e. a pad of 16 bf16 on the 64- / 128-wide rows (PMC r01: with the 8-element
+// pad 41-45 % of all LDS cycles were bank conflicts and the LDS array was busy 64-86 % of the kernel time).  The dk/dv kernel's images do
+// not fit 160 KB with that pad and keep 8.
+template <typename CT, int DH, int MF, int C, int KIND> struct FavorDims {
     static constexpr int F = 2 * MF;
-    static constexpr int KMIN = Img<CT>::KMIN, PAD = Img<CT>::PAD;
+    static constexpr int KMIN = Img<CT>::KMIN, PAD = (sizeof(CT) == 2 && KIND != 2 && FAVOR_PAD16) ? 16 : Img<CT>::PAD;
     static constexpr int DHP = CMax<DH, KMIN>::v;
     static constexpr int MFP = CMax<MF, KMIN>::v;
     static constexpr int CP = CMax<C, KMIN>::v;
@@ -118,7 +164,7 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
                                                         float* __restrict__ den_g, float* __restrict__ state_S, float* __restrict__ state_z,
                                                         int64_t T, int64_t H, float eps, float* __restrict__ S_ws, float* __restrict__ z_ws,
                                                         int P, int64_t Ts) {
-    typedef FavorDims<CT, DH, MF, C> D;
+    typedef FavorDims<CT, DH, MF, C, 0> D;
     constexpr int F = D::F, LDX = D::LDX, LDC = D::LDC, LDF = D::LDF, DHP = D::DHP, CP = D::CP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     CT* WT = (CT*)smem;                 // [MF][LDX]
@@ -135,6 +181,8 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
     float* dens = offk + C;
     float* zz = dens + C;               // [F]
 
+    const int abl = P >> 8;   // diagnostics (EMO_FAVOR_ABLATE): skip phases, results are garbage
+    P &= 0xFF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // segment-parallel scan: block = (b, h, segment p); the segment covers tokens [tbeg, tend)
     const int64_t bh = blockIdx.x / P, b = bh / H, h = bh % H;
@@ -181,7 +229,8 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
         }
         for (int f = tid; f < F; f += FT) zz[f] = seg_sum(z_ws + bh * P * (int64_t)F, F, 0, p_seg, f);
     }
-    RowPrefetch<CT, DH, DHP, C, FT> pq, pk, pv;
+    RowPrefetch<CT, DH, DHP, C, FT> pq, pk;
+    RowPrefetch<CT, DH, DHP, C, FT, true> pv;   // only ever stored transposed
     if (tbeg < tend) {
         const int v0 = (int)((tend - tbeg) < C ? (tend - tbeg) : C);
         if constexpr (!SO) pq.load(qb + tbeg * ld, ld, v0, tid);
@@ -191,9 +240,11 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
     for (int64_t t0 = tbeg; t0 < tend; t0 += C) {
         const int valid = (int)((tend - t0) < C ? (tend - t0) : C);
         __syncthreads();
+        if (!(abl & 1)) {
         if constexpr (!SO) pq.store_rows(Xq, LDX, tid);
         pk.store_rows(Xk, LDX, tid);
-        pv.store_T(VT, LDC, tid);
+        }
+        if (!(abl & 2)) pv.store_T(VT, LDC, tid);
         if (t0 + C < tend) {                       // next chunk's q/k/v stay in flight during this chunk's compute
             const int vn = (int)((tend - t0 - C) < C ? (tend - t0 - C) : C);
             if constexpr (!SO) pq.load(qb + (t0 + C) * ld, ld, vn, tid);
@@ -201,20 +252,27 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
             pv.load(vb + (t0 + C) * ld, ld, vn, tid);
         }
         __syncthreads();
+        if (!(abl & 4)) {
         if constexpr (!SO) row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
         row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
+        }
         __syncthreads();
+        if (!(abl & 8)) {
         if constexpr (!SO) {
             features_rowmajor<CT, DHP, MF, C>(Qf, LDF, WT, Xq, LDX, offq, cs, C, wave, lane);
-            features_rowmajor<CT, DHP, MF, C>(Kf, LDF, WT, Xk, LDX, offk, cs, valid, wave, lane);
+            features_both<CT, DHP, MF, C>(Kf, LDF, KfT, LDC, WT, Xk, LDX, offk, cs, valid, wave, lane);
+        } else {
+            features_transposed<CT, DHP, MF, C>(KfT, LDC, WT, Xk, LDX, offk, cs, valid, wave, lane);
         }
-        features_transposed<CT, DHP, MF, C>(KfT, LDC, WT, Xk, LDX, offk, cs, valid, wave, lane);
+        }
         __syncthreads();
         if constexpr (!SO) {
         // A[t][j] = Qf[t].Kf[j] masked j<=t : rows<->j (R=Kf), col<->t (C=Qf)
-        {
+        if (!(abl & 16)) {
             constexpr int NT = (C / 16) * (C / 16);
-            for (int tile = wave; tile < NT; tile += FW) {
+            _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
+            const int tile = wave + FW * tile_i;
+            if (NT % FW != 0 && tile >= NT) break;
                 const int jt = tile / (C / 16), tt = tile % (C / 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 if (jt <= tt) mm16<CT>(acc, Kf, LDF, jt * 16, Qf, LDF, tt * 16, F, lane);
@@ -225,7 +283,7 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
         }
         __syncthreads();
         // den[t] = rowsum(A[t]) + Qf[t].z_prev + eps
-        {
+        if (!(abl & 32)) {
             constexpr int TPR = FT / C;
             constexpr int VE = 16 / sizeof(CT);
             const int r = tid / TPR, part = tid % TPR;
@@ -246,9 +304,11 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
         }
         __syncthreads();
         // out^T: rows<->d, col<->t : VT.Am^T (K=C) + ST.Qf^T (K=F)
-        {
+        if (!(abl & 64)) {
             constexpr int NT = (DH / 16) * (C / 16);
-            for (int tile = wave; tile < NT; tile += FW) {
+            _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
+            const int tile = wave + FW * tile_i;
+            if (NT % FW != 0 && tile >= NT) break;
                 const int dt = tile / (C / 16), tt = tile % (C / 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 mm16<CT>(acc, VT, LDC, dt * 16, Am, LDC, tt * 16, CP, lane);
@@ -263,6 +323,7 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
         __syncthreads();
         }   // !SO
         // state: S[f][d] += sum_j KfT[f][j] VT[d][j]; mirror ST[d][f]; z += colsum
+        if (!(abl & 128))
 #pragma unroll
         for (int i = 0; i < NTS_W; ++i) {
             const int tile = wave + FW * i;
@@ -408,7 +469,9 @@ template <typename CT, int DH, int MFP, int C>
 __device__ __forceinline__ void dx_from_adiff(const CT* W, int ldw, const CT* Adiff, int lda, const float* sumA, const CT* __restrict__ xg,
                                               int64_t ld, CT* __restrict__ dxg, int64_t ld_d, float cs, int valid, int wave, int lane) {
     constexpr int NT = (DH / 16) * (C / 16);
-    for (int tile = wave; tile < NT; tile += FW) {
+    _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
+            const int tile = wave + FW * tile_i;
+            if (NT % FW != 0 && tile >= NT) break;
         const int dt = tile / (C / 16), tt = tile % (C / 16);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         mm16<CT>(acc, W, ldw, dt * 16, Adiff, lda, tt * 16, MFP, lane);
@@ -430,7 +493,7 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
                                                            int64_t ld_out, const float* __restrict__ den_g, CT* __restrict__ dq, int64_t ld_d,
                                                            int64_t T, int64_t H, const float* __restrict__ S_ws, const float* __restrict__ z_ws,
                                                            int P, int64_t Ts) {
-    typedef FavorDims<CT, DH, MF, C> D;
+    typedef FavorDims<CT, DH, MF, C, 1> D;
     constexpr int F = D::F, LDX = D::LDX, LDC = D::LDC, LDF = D::LDF, LDM = D::LDM, DHP = D::DHP, CP = D::CP, MFP = D::MFP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     CT* WT = (CT*)smem;            // [MF][LDX]  omega^T (k=d)
@@ -536,7 +599,9 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
         // P[t][j] = dN_t.v_j + dD_t, masked j<=t : rows<->j (R=Vr), col<->t (C=G)
         {
             constexpr int NT = (C / 16) * (C / 16);
-            for (int tile = wave; tile < NT; tile += FW) {
+            _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
+            const int tile = wave + FW * tile_i;
+            if (NT % FW != 0 && tile >= NT) break;
                 const int jt = tile / (C / 16), tt = tile % (C / 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 if (jt <= tt) mm16<CT>(acc, Vr, LDX, jt * 16, G, LDX, tt * 16, DHP, lane);
@@ -551,7 +616,9 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
         zero_adiff_pad<CT, MF, MFP, C>(Adiff, LDM, tid);
         {
             constexpr int NP = (MF / 16) * (C / 16);
-            for (int pr = wave; pr < NP; pr += FW) {
+            _Pragma("unroll") for (int pr_i = 0; pr_i < (NP + FW - 1) / FW; ++pr_i) {
+            const int pr = wave + FW * pr_i;
+            if (NP % FW != 0 && pr >= NP) break;
                 const int ft = pr / (C / 16), tt = pr % (C / 16);
                 f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f};
                 mm16<CT>(aP, KfT, LDC, ft * 16, Pm, LDC, tt * 16, CP, lane);
@@ -609,7 +676,7 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
                                                             int64_t ld_out, const float* __restrict__ den_g, CT* __restrict__ dk, CT* __restrict__ dv,
                                                             int64_t ld_d, int64_t T, int64_t H, float* __restrict__ R_ws, float* __restrict__ r_ws, int P,
                                                             int64_t Ts) {
-    typedef FavorDims<CT, DH, MF, C> D;
+    typedef FavorDims<CT, DH, MF, C, 2> D;
     constexpr int F = D::F, LDX = D::LDX, LDC = D::LDC, LDF = D::LDF, LDM = D::LDM, DHP = D::DHP, CP = D::CP, MFP = D::MFP;
     constexpr int LXC = CMax<LDX, LDC>::v, LXM = CMax<LDX, LDM>::v;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -723,17 +790,20 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
         if constexpr (!SO) row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
         __syncthreads();
         if constexpr (!SO) {
-            features_rowmajor<CT, DHP, MF, C>(Qf, LDF, WT, Xq, LDX, offq, cs, valid, wave, lane);
+            features_both<CT, DHP, MF, C>(Qf, LDF, QfT, LDC, WT, Xq, LDX, offq, cs, valid, wave, lane);
             features_rowmajor<CT, DHP, MF, C>(Kf, LDF, WT, Xk, LDX, offk, cs, valid, wave, lane);
+        } else {
+            features_transposed<CT, DHP, MF, C>(QfT, LDC, WT, Xq, LDX, offq, cs, valid, wave, lane);
         }
-        features_transposed<CT, DHP, MF, C>(QfT, LDC, WT, Xq, LDX, offq, cs, valid, wave, lane);
         __syncthreads();   // Xq / Xk dead from here: PmT / AmT may overwrite them
         if constexpr (!SO) {
         // PmT[j][t] = dN_t.v_j + dD_t (t>=j) : rows<->t (R=G), col<->j (C=Vr)
         // AmT[j][t] = Qf_t.Kf_j       (t>=j) : rows<->t (R=Qf), col<->j (C=Kf)
         {
             constexpr int NT = (C / 16) * (C / 16);
-            for (int tile = wave; tile < NT; tile += FW) {
+            _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
+            const int tile = wave + FW * tile_i;
+            if (NT % FW != 0 && tile >= NT) break;
                 const int tt = tile / (C / 16), jt = tile % (C / 16);
                 f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aA = {0.f, 0.f, 0.f, 0.f};
                 if (tt >= jt) {
@@ -759,7 +829,9 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
         zero_adiff_pad<CT, MF, MFP, C>(Adiff, LDM, tid);
         {
             constexpr int NP = (MF / 16) * (C / 16);
-            for (int pr = wave; pr < NP; pr += FW) {
+            _Pragma("unroll") for (int pr_i = 0; pr_i < (NP + FW - 1) / FW; ++pr_i) {
+            const int pr = wave + FW * pr_i;
+            if (NP % FW != 0 && pr >= NP) break;
                 const int ft = pr / (C / 16), jt = pr % (C / 16);
                 f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f};
                 mm16<CT>(aP, QfT, LDC, ft * 16, PmT, LDC, jt * 16, CP, lane);
@@ -773,7 +845,9 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
         // dV^T: rows<->d, col<->j : GT.AmT^T (K=C) + RT.Kf^T (K=F)
         {
             constexpr int NT = (DH / 16) * (C / 16);
-            for (int tile = wave; tile < NT; tile += FW) {
+            _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
+            const int tile = wave + FW * tile_i;
+            if (NT % FW != 0 && tile >= NT) break;
                 const int dt = tile / (C / 16), jt = tile % (C / 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 mm16<CT>(acc, GT, LDC, dt * 16, AmT, LDC, jt * 16, CP, lane);
@@ -951,18 +1025,18 @@ extern "C" int emo_favor_draw_omega(const float* gauss, float* omega, int64_t n_
 
 // =============================================================================================== host
 template <typename CT, int DH, int MF, int C> static size_t fwd_lds() {
-    typedef FavorDims<CT, DH, MF, C> D;
+    typedef FavorDims<CT, DH, MF, C, 0> D;
     return sizeof(CT) * (size_t)(MF * D::LDX + 2 * C * D::LDX + DH * D::LDC + 2 * C * D::LDF + D::F * D::LDC + C * D::LDC + DH * D::LDF) +
            sizeof(float) * (size_t)(3 * C + D::F);
 }
 template <typename CT, int DH, int MF, int C> static size_t dq_lds() {
-    typedef FavorDims<CT, DH, MF, C> D;
+    typedef FavorDims<CT, DH, MF, C, 1> D;
     return sizeof(CT) * (size_t)(MF * D::LDX + DH * D::LDM + C * D::LDX + C * CMax<D::LDX, D::LDM>::v + C * D::LDX + DH * D::LDC + C * D::LDX +
                                  C * D::LDF + D::F * D::LDC + C * D::LDC + D::F * D::LDX) +
            sizeof(float) * (size_t)(4 * C + D::F);
 }
 template <typename CT, int DH, int MF, int C> static size_t dkv_lds() {
-    typedef FavorDims<CT, DH, MF, C> D;
+    typedef FavorDims<CT, DH, MF, C, 2> D;
     return sizeof(CT) * (size_t)(MF * D::LDX + DH * D::LDM + 2 * C * CMax<D::LDX, D::LDC>::v + C * D::LDX + C * CMax<D::LDX, D::LDM>::v + DH * D::LDC +
                                  2 * C * D::LDF + D::F * D::LDC + D::F * D::LDX + DH * D::LDF) +
            sizeof(float) * (size_t)(4 * C + D::F);
@@ -1029,8 +1103,9 @@ static int run_favor(int which, const void* q, const void* k, const void* v, int
         if (P > 1)
             hipLaunchKernelGGL(ks, grid, dim3(FT), lds, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (CT*)out, ld_out, den, sS, sz, T, H, eps, wsS,
                                wsz, P, Ts);
+        const char* ab = getenv("EMO_FAVOR_ABLATE");   // diagnostics only
         hipLaunchKernelGGL(kf, grid, dim3(FT), lds, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (CT*)out, ld_out, den, sS, sz, T, H, eps, wsS, wsz,
-                           P, Ts);
+                           P | (ab ? atoi(ab) << 8 : 0), Ts);
     } else {
         const size_t l0 = fwd_lds<CT, DH, MF, CF>(), l1 = dq_lds<CT, DH, MF, CQ>(), l2 = dkv_lds<CT, DH, MF, CK>();
         EMO_CHECK(l0 <= EMO_MAX_LDS && l1 <= EMO_MAX_LDS && l2 <= EMO_MAX_LDS, "favor bwd: LDS %zu / %zu / %zu too large", l0, l1, l2);

@@ -125,7 +125,10 @@ __device__ __forceinline__ float dot_contig(const CT* p, const float* w) {
 
 // Register prefetch of one [ROWS x NC] row tile (one 16-B vector per item, item -> thread round-robin): the global
 // loads of chunk c+1 are issued right after chunk c's images are written and stay in flight during chunk c's compute.
-template <typename CT, int NC, int NCP, int ROWS, int NTHR>
+// ROWFAST: item -> (row = it % ROWS, chunk = it / ROWS): the lanes of a wave hold 64 different rows of one 16-B column chunk, so the
+// transposed image store (store_T) writes 64 consecutive k positions per instruction (conflict-free; the row-major mapping makes the 8 lanes
+// of a row hit one bank: 8-way conflict).  Costs less coalesced global loads (prefetched a chunk ahead, latency hidden).
+template <typename CT, int NC, int NCP, int ROWS, int NTHR, bool ROWFAST = false>
 struct RowPrefetch {
     static constexpr int VE = 16 / sizeof(CT), CH = NC / VE, NI = (ROWS * CH + NTHR - 1) / NTHR;
     CT r[NI][VE];
@@ -133,7 +136,7 @@ struct RowPrefetch {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int it = tid + NTHR * i;
-            const int row = it / CH, c = (it % CH) * VE;
+            const int row = ROWFAST ? it % ROWS : it / CH, c = (ROWFAST ? it / ROWS : it % CH) * VE;
 #pragma unroll
             for (int e = 0; e < VE; ++e) r[i][e] = from_f32<CT>(0.f);
             if (it < ROWS * CH && row < valid) {
@@ -148,7 +151,7 @@ struct RowPrefetch {
         for (int i = 0; i < NI; ++i) {
             const int it = tid + NTHR * i;
             if (it < ROWS * CH) {
-                const int row = it / CH, c = (it % CH) * VE;
+                const int row = ROWFAST ? it % ROWS : it / CH, c = (ROWFAST ? it / ROWS : it % CH) * VE;
                 if constexpr (sizeof(CT) == 2) *(bf16x8*)(img + row * ld + c) = *(const bf16x8*)r[i];
                 else {
 #pragma unroll
@@ -166,7 +169,7 @@ struct RowPrefetch {
         for (int i = 0; i < NI; ++i) {
             const int it = tid + NTHR * i;
             if (it < ROWS * CH) {
-                const int row = it / CH, c = (it % CH) * VE;
+                const int row = ROWFAST ? it % ROWS : it / CH, c = (ROWFAST ? it / ROWS : it % CH) * VE;
 #pragma unroll
                 for (int e = 0; e < VE; ++e) img[(c + e) * ld + row] = r[i][e];
             }
