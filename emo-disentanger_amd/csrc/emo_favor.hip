@@ -515,6 +515,8 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
     float* sumA = dD + C;
     float* zz = sumA + C;          // [F]
 
+    const int abl = P >> 8;   // diagnostics (EMO_FAVOR_ABLATE_DQ)
+    P &= 0xFF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t bh = blockIdx.x / P, b = bh / H, h = bh % H;
     const int p_seg = (int)(blockIdx.x % P);
@@ -577,11 +579,13 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
     for (int64_t t0 = tbeg; t0 < tend; t0 += C) {
         const int valid = (int)((tend - t0) < C ? (tend - t0) : C);
         __syncthreads();
+        if (!(abl & 1)) {
         pq.store_rows(Xq, LDX, tid);
         pk.store_rows(Xk, LDX, tid);
         pv.store_rows(Vr, LDX, tid);
-        pv.store_T(VT, LDC, tid);
-        store_grads<CT, DH, DHP, C>(pg, po, dn, valid, G, LDX, (CT*)nullptr, 0, dD, tid);
+        }
+        if (!(abl & 2)) pv.store_T(VT, LDC, tid);
+        if (!(abl & 4)) store_grads<CT, DH, DHP, C>(pg, po, dn, valid, G, LDX, (CT*)nullptr, 0, dD, tid);
         for (int i = tid; i < C; i += FT) sumA[i] = 0.f;
         if (t0 + C < tend) {
             const int64_t tn_ = t0 + C;
@@ -594,10 +598,12 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
         row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
         row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
         __syncthreads();
+        if (!(abl & 8)) {
         features_rowmajor<CT, DHP, MF, C>(Qf, LDF, WT, Xq, LDX, offq, cs, C, wave, lane);
         features_transposed<CT, DHP, MF, C>(KfT, LDC, WT, Xk, LDX, offk, cs, valid, wave, lane);
+        }
         // P[t][j] = dN_t.v_j + dD_t, masked j<=t : rows<->j (R=Vr), col<->t (C=G)
-        {
+        if (!(abl & 16)) {
             constexpr int NT = (C / 16) * (C / 16);
             _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
             const int tile = wave + FW * tile_i;
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
         __syncthreads();
         // dPhi_q^T: rows<->f, col<->t : KfT.Pm^T (K=C) + SF.G^T (K=DHP) + z[f] dD[t]; fused Jacobian -> Adiff, sumA
         zero_adiff_pad<CT, MF, MFP, C>(Adiff, LDM, tid);
-        {
+        if (!(abl & 32)) {
             constexpr int NP = (MF / 16) * (C / 16);
             _Pragma("unroll") for (int pr_i = 0; pr_i < (NP + FW - 1) / FW; ++pr_i) {
             const int pr = wave + FW * pr_i;
@@ -630,8 +636,9 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
             }
         }
         __syncthreads();
-        dx_from_adiff<CT, DH, MFP, C>(W, LDM, Adiff, LDM, sumA, qb + t0 * ld, ld, dqb + t0 * ld_d, ld_d, cs, valid, wave, lane);
+        if (!(abl & 64)) dx_from_adiff<CT, DH, MFP, C>(W, LDM, Adiff, LDM, sumA, qb + t0 * ld, ld, dqb + t0 * ld_d, ld_d, cs, valid, wave, lane);
         // state S[f][d] (+)= ; mirror SF[f][d0..] ; z += colsum(KfT)
+        if (!(abl & 128))
 #pragma unroll
         for (int i = 0; i < NTS_W; ++i) {
             const int tile = wave + FW * i;
@@ -701,6 +708,8 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
     float* sumA = dD + C;
     float* rr = sumA + C;           // [F]  r[f] = sum_{t>chunk} Qf_t[f] dD_t
 
+    const int abl = P >> 8;   // diagnostics (EMO_FAVOR_ABLATE_DKV)
+    P &= 0xFF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t bh = blockIdx.x / P, b = bh / H, h = bh % H;
     const int p_seg = (int)(blockIdx.x % P);
@@ -771,12 +780,14 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
         const int64_t t0 = tbeg + ci * C;
         const int valid = (int)((tend - t0) < C ? (tend - t0) : C);
         __syncthreads();
+        if (!(abl & 1)) {
         pq.store_rows(Xq, LDX, tid);
         if constexpr (!SO) {
             pk.store_rows(Xk, LDX, tid);
             pv.store_rows(Vr, LDX, tid);
         }
-        store_grads<CT, DH, DHP, C>(pg, po, dn, valid, G, LDX, GT, LDC, dD, tid);
+        }
+        if (!(abl & 4)) store_grads<CT, DH, DHP, C>(pg, po, dn, valid, G, LDX, GT, LDC, dD, tid);
         for (int i = tid; i < C; i += FT) sumA[i] = 0.f;
         if (ci > 0) {                                  // previous (earlier) chunk: full, stays in flight during this chunk's compute
             const int64_t tn_ = t0 - C;
@@ -789,17 +800,19 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
         row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
         if constexpr (!SO) row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
         __syncthreads();
+        if (!(abl & 8)) {
         if constexpr (!SO) {
             features_both<CT, DHP, MF, C>(Qf, LDF, QfT, LDC, WT, Xq, LDX, offq, cs, valid, wave, lane);
             features_rowmajor<CT, DHP, MF, C>(Kf, LDF, WT, Xk, LDX, offk, cs, valid, wave, lane);
         } else {
             features_transposed<CT, DHP, MF, C>(QfT, LDC, WT, Xq, LDX, offq, cs, valid, wave, lane);
         }
+        }
         __syncthreads();   // Xq / Xk dead from here: PmT / AmT may overwrite them
         if constexpr (!SO) {
         // PmT[j][t] = dN_t.v_j + dD_t (t>=j) : rows<->t (R=G), col<->j (C=Vr)
         // AmT[j][t] = Qf_t.Kf_j       (t>=j) : rows<->t (R=Qf), col<->j (C=Kf)
-        {
+        if (!(abl & 16)) {
             constexpr int NT = (C / 16) * (C / 16);
             _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
             const int tile = wave + FW * tile_i;
@@ -827,7 +840,7 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
         __syncthreads();   // G dead from here: Adiff may overwrite it
         // dPhi_k^T: rows<->f, col<->j : QfT.PmT^T (K=C) + RF.Vr^T (K=DHP) + r[f]; fused Jacobian (uses Kf)
         zero_adiff_pad<CT, MF, MFP, C>(Adiff, LDM, tid);
-        {
+        if (!(abl & 32)) {
             constexpr int NP = (MF / 16) * (C / 16);
             _Pragma("unroll") for (int pr_i = 0; pr_i < (NP + FW - 1) / FW; ++pr_i) {
             const int pr = wave + FW * pr_i;
@@ -843,7 +856,7 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
             }
         }
         // dV^T: rows<->d, col<->j : GT.AmT^T (K=C) + RT.Kf^T (K=F)
-        {
+        if (!(abl & 2)) {
             constexpr int NT = (DH / 16) * (C / 16);
             _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
             const int tile = wave + FW * tile_i;
@@ -857,9 +870,10 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
             }
         }
         __syncthreads();
-        dx_from_adiff<CT, DH, MFP, C>(W, LDM, Adiff, LDM, sumA, kb + t0 * ld, ld, dkb + t0 * ld_d, ld_d, cs, valid, wave, lane);
+        if (!(abl & 64)) dx_from_adiff<CT, DH, MFP, C>(W, LDM, Adiff, LDM, sumA, kb + t0 * ld, ld, dkb + t0 * ld_d, ld_d, cs, valid, wave, lane);
         }   // !SO
         // state R[f][d] += sum_t QfT[f][t] GT[d][t]
+        if (!(abl & 128))
 #pragma unroll
         for (int i = 0; i < NTS_W; ++i) {
             const int tile = wave + FW * i;
@@ -1126,12 +1140,12 @@ static int run_favor(int which, const void* q, const void* k, const void* v, int
             hipLaunchKernelGGL(k0, grid, dim3(FT), l0, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (CT*)nullptr, ld_out, (float*)nullptr,
                                (float*)nullptr, (float*)nullptr, T, H, eps, wsS, wsz, P, Ts);
         hipLaunchKernelGGL(k1, grid, dim3(FT), l1, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
-                           (CT*)dq, ld_d, T, H, (const float*)wsS, (const float*)wsz, P, Ts);
+                           (CT*)dq, ld_d, T, H, (const float*)wsS, (const float*)wsz, P | (getenv("EMO_FAVOR_ABLATE_DQ") ? atoi(getenv("EMO_FAVOR_ABLATE_DQ")) << 8 : 0), Ts);
         if (P > 1)
             hipLaunchKernelGGL(k2s, grid, dim3(FT), l2, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
                                (CT*)dk, (CT*)dv, ld_d, T, H, wsS, wsz, P, Ts);
         hipLaunchKernelGGL(k2, grid, dim3(FT), l2, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
-                           (CT*)dk, (CT*)dv, ld_d, T, H, wsS, wsz, P, Ts);
+                           (CT*)dk, (CT*)dv, ld_d, T, H, wsS, wsz, P | (getenv("EMO_FAVOR_ABLATE_DKV") ? atoi(getenv("EMO_FAVOR_ABLATE_DKV")) << 8 : 0), Ts);
     }
     EMO_LAUNCH_CHECK();
     return EMO_OK;
