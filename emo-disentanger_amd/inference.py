@@ -307,6 +307,160 @@ def generate_conditional(model, event2idx, idx2event, lead_sheet_events, primer,
     return generated[:-1]
 
 
+# ------------------------------------------------------------------------------------------------ batched reference loop (SURVEY f-4)
+def nucleus_rs(probs, p, rs):
+    """nucleus() with an explicit np.random.RandomState instead of the global one (one independent RNG per stream)."""
+    probs = probs / sum(probs)
+    sorted_probs = np.sort(probs)[::-1]
+    sorted_index = np.argsort(probs)[::-1]
+    after_threshold = np.cumsum(sorted_probs) > p
+    if sum(after_threshold) > 0:
+        candi_index = sorted_index[:np.where(after_threshold)[0][1]]
+    else:
+        candi_index = sorted_index[:3]
+    candi_probs = np.array([probs[i] for i in candi_index], dtype=np.float64)
+    candi_probs /= sum(candi_probs)
+    return rs.choice(candi_index, size=1, p=candi_probs)[0]
+
+
+class _Stream:
+    """Per-stream state of generate_conditional's loop (inference.py:233-250)."""
+
+    def __init__(self, event2idx, lead_sheet_events, primer, max_bars):
+        self.lead = lead_sheet_events
+        self.generated = list(primer) + [event2idx['Track_LeadSheet']] + list(lead_sheet_events[0]) + [event2idx['Track_Full']]
+        self.seg = [0] * len(self.generated)
+        self.seg[-1] = 1
+        self.target_bars = len(lead_sheet_events) if max_bars is None else min(max_bars, len(lead_sheet_events))
+        self.generated_bars, self.cur_pos, self.failed_cnt = 0, 0, 0
+        self.consumed = 0            # tokens already folded into the engine state
+        self.done, self.stuck = self.target_bars <= 0, False
+
+    def offer(self, word, event2idx, idx2event, skip_check, max_events):
+        """One sampled word through the grammar of inference.py:276-318.  Returns False when the sample is rejected (the caller
+        re-samples from the SAME distribution, like the reference's `continue`), True when the stream advanced or ended."""
+        ev = idx2event[word]
+        if not skip_check and 'Beat' in ev:
+            pos = get_position_idx(ev)
+            if not pos >= self.cur_pos:
+                self.failed_cnt += 1
+                if self.failed_cnt >= 256:          # reference: returns `generated` as is (no [:-1])
+                    self.done = self.stuck = True
+                    return True
+                return False
+            self.cur_pos, self.failed_cnt = pos, 0
+        if ev == 'Track_LeadSheet':
+            self.generated.append(word)
+            self.seg.append(0)
+            self.generated_bars += 1
+            if self.generated_bars < self.target_bars:
+                nxt = self.lead[self.generated_bars]
+                self.generated.extend(nxt)
+                self.seg.extend([0] * len(nxt))
+                self.generated.append(event2idx['Track_Full'])
+                self.seg.append(1)
+                self.cur_pos = 0
+            else:
+                self.done = True
+            return True
+        if ev == 'PAD_None' or (ev == 'EOS_None' and self.generated_bars < self.target_bars - 1):
+            return False
+        if ev == 'EOS_None' and self.generated_bars == self.target_bars - 1:
+            self.generated.append(word)
+            self.done = True
+            return True
+        self.generated.append(word)
+        self.seg.append(1)
+        if len(self.generated) > max_events:
+            self.done = True
+        return True
+
+    def result(self):
+        return self.generated if self.stuck else self.generated[:-1]
+
+
+def generate_conditional_batch(model, event2idx, idx2event, lead_sheets, primers, max_events=10000, skip_check=False, max_bars=None,
+                               temp=1.2, top_p=0.9, inadmissibles=None, samplers=None, seeds=None):
+    """n independent generate_conditional() runs (one lead sheet + primer each) in lock-step on ONE decode engine: per-stream bar
+    counter, Beat position, rejection counter and RNG; every engine step feeds each unfinished stream its next pending token (a
+    sampled word, or the next token of an injected lead-sheet bar), so streams of different lengths stay aligned in position.
+    `samplers[i](probs)` defaults to nucleus_rs(probs, top_p, RandomState(seeds[i])).  Stream i returns exactly what
+    generate_conditional(..., sampler=samplers[i]) returns for it alone (tests/test_gpu_generate.py), as long as it stays inside
+    the 2048-token window (max_dec_inp_len); a stream that reaches the window is finished by the single-stream windowed path."""
+    n = len(lead_sheets)
+    assert n == len(primers) and n > 0
+    if samplers is None:
+        rss = [np.random.RandomState((seeds[i] if seeds is not None else i)) for i in range(n)]
+        samplers = [(lambda probs, rs=rs: nucleus_rs(probs, top_p, rs)) for rs in rss]
+    dev = next(model.parameters()).device
+    st = [_Stream(event2idx, lead_sheets[i], primers[i], max_bars) for i in range(n)]
+    pad = event2idx.get('PAD_None', 0)
+    was_training = model.training
+    model.eval()
+    overflow = []
+    try:
+        with torch.no_grad():
+            eng = make_engine(model, n)
+            L0 = min(len(s.generated) for s in st)
+            tok = torch.tensor([s.generated[:L0] for s in st], dtype=torch.long, device=dev)
+            seg = torch.tensor([s.seg[:L0] for s in st], dtype=torch.long, device=dev)
+            logits = eng.prefill(tok, seg)
+            for s in st:
+                s.consumed = L0
+            while True:
+                logits_np = None
+                for i, s in enumerate(st):
+                    if s.done:
+                        continue
+                    if len(s.generated) >= max_dec_inp_len:      # window slides: positions restart, the recurrent state is void
+                        s.done = True
+                        overflow.append(i)
+                        continue
+                    if s.consumed < len(s.generated):
+                        continue
+                    if logits_np is None:
+                        logits_np = logits.cpu().numpy()
+                    while True:                                  # a rejected sample re-derives probs from the same logits (reference: `continue`)
+                        probs = temperature(logits_np[i].copy(), temp, inadmissibles=inadmissibles)
+                        if s.offer(int(samplers[i](probs)), event2idx, idx2event, skip_check, max_events):
+                            break
+                if all(s.done for s in st):
+                    break
+                nxt_tok = [s.generated[s.consumed] if s.consumed < len(s.generated) else pad for s in st]
+                nxt_seg = [s.seg[s.consumed] if s.consumed < len(s.seg) else 1 for s in st]
+                for s in st:
+                    if s.consumed < len(s.generated):
+                        s.consumed += 1
+                logits = eng.step(torch.tensor(nxt_tok, dtype=torch.long, device=dev), torch.tensor(nxt_seg, dtype=torch.long, device=dev))
+    finally:
+        model.train(was_training)
+    out = [s.result() for s in st]
+    for i in overflow:       # rare: hand the stream to the reference-shaped single-stream loop (full-window forward per token)
+        out[i] = _resume_windowed(model, event2idx, idx2event, st[i], max_events, skip_check, temp, inadmissibles, samplers[i])
+    return out
+
+
+def _resume_windowed(model, event2idx, idx2event, s, max_events, skip_check, temp, inadmissibles, sampler):
+    dev = next(model.parameters()).device
+    s.done = False
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            while not s.done:
+                dec_input = torch.tensor([s.generated[-max_dec_inp_len:]], dtype=torch.long, device=dev)
+                dec_seg = torch.tensor([s.seg[-max_dec_inp_len:]], dtype=torch.long, device=dev)
+                kw = {'attn_kwargs': {'omit_feature_map_draw': True}} if model.kind == 'performer' else {}
+                logits_np = model(dec_input, seg_inp=dec_seg, keep_last_only=True, **kw)[0].cpu().numpy().copy()
+                while True:
+                    probs = temperature(logits_np.copy(), temp, inadmissibles=inadmissibles)
+                    if s.offer(int(sampler(probs)), event2idx, idx2event, skip_check, max_events):
+                        break
+    finally:
+        model.train(was_training)
+    return s.result()
+
+
 @torch.no_grad()
 def generate_streams(model, prompt_tok, prompt_seg, n_new, temp=1.1, top_p=0.9, greedy=False, seed=0, seg_value=1, use_graph=True):
     """BASELINE configs[3]: n parallel streams in lock-step (grammar checks off => fixed token count).  Everything stays

@@ -47,6 +47,39 @@ def test_generate_conditional_reproduces_reference_traces(use_cache):
         assert out == run['generated']
 
 
+@pytest.mark.parametrize('kind', ['gpt2', 'performer'])
+@pytest.mark.parametrize('skip_check', [False, True])
+def test_generate_conditional_batch_equals_single_stream_runs(kind, skip_check):
+    # SURVEY f-4: streams with DIFFERENT lead sheets / primers / RNGs in lock-step on one engine; every stream must reproduce
+    # what the single-stream reference-shaped loop produces for it alone with the same sampler.
+    from emo_disentanger_amd import inference as inf
+    from emo_disentanger_amd.model.music_performer import MusicPerformer
+    from oracle.weights import make_state_dict
+    g = json.load(open(os.path.join(G, 'generate.json')))
+    e2i = {e: i for i, e in enumerate(g['events'])}
+    i2e = {i: e for e, i in e2i.items()}
+    if kind == 'gpt2':
+        model = _tiny_gpt2(g['model'])
+    else:
+        m = g['model']
+        sd = make_state_dict('performer', m['V'], m['L'], m['H'], m['d'], m['dff'], favor_feature_dims=32, seed=m['seed'], scale=m['scale'])
+        model = MusicPerformer(m['V'], m['L'], m['H'], m['d'], m['dff'], m['d'], favor_feature_dims=32, use_segment_emb=True, n_segment_types=2,
+                               compute_dtype='fp32', redraw='fixed')
+        model.load_state_dict(sd)
+        model = model.cuda().eval()
+    lead = [list(b) for b in g['lead']]
+    leads = [lead, lead[::-1], lead[:2], [lead[1]] * 4, lead + lead]
+    primers = [list(g['primer']), [1, 5, 6], list(g['primer']), [2, 4], [3, 5, 6]]
+    seeds = [11, 12, 13, 14, 15]
+    batch = inf.generate_conditional_batch(model, e2i, i2e, leads, primers, max_events=150, skip_check=skip_check, temp=1.2, top_p=0.97, seeds=seeds)
+    assert len({tuple(b) for b in batch}) == len(leads)          # five different sequences (prompts of 4 different lengths)
+    for i in range(len(leads)):
+        rs = np.random.RandomState(seeds[i])
+        single = inf.generate_conditional(model, e2i, i2e, leads[i], primers[i], max_events=150, skip_check=skip_check, temp=1.2, top_p=0.97,
+                                          model_type=kind, sampler=lambda p, rs=rs: inf.nucleus_rs(p, 0.97, rs))
+        assert batch[i] == single, i
+
+
 @pytest.mark.parametrize('kind,dtype', [('performer', 'fp32'), ('performer', 'bf16'), ('gpt2', 'fp32'), ('gpt2', 'bf16')])
 def test_decode_engine_equals_full_recompute(kind, dtype):
     from emo_disentanger_amd import inference as inf
