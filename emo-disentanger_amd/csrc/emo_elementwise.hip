@@ -473,7 +473,7 @@ extern "C" int emo_accuracy_counts(const float* logits, const int64_t* tgt, cons
 // sorted tokens are kept.  Draw: cdf over the renormalised (f64) candidates, searchsorted(u, right).
 __global__ __launch_bounds__(256) void nucleus_kernel(const float* __restrict__ logits, int64_t V, float temp, float top_p,
                                                       const float* __restrict__ u, int64_t* __restrict__ out) {
-    __shared__ float sp[1024];
+    __shared__ __attribute__((aligned(16))) float sp[1024 + 8];
     __shared__ int si[1024];
     __shared__ float red[4];
     __shared__ int s_last;
@@ -517,25 +517,45 @@ __global__ __launch_bounds__(256) void nucleus_kernel(const float* __restrict__ 
         }
     }
     if (tid == 0) {
+        // sequential fp32 cumsum (np.cumsum order), but fed by 16-B LDS reads: the dependent chain is the adds, not 327 LDS round trips
         float cum = 0.f;
         int crossings = 0, last = -1;
-        for (int i = 0; i < V; ++i) {
-            cum += sp[i];
-            if (cum > top_p) {
-                if (++crossings == 2) { last = i; break; }
+        for (int i0 = 0; i0 < V && last < 0; i0 += 8) {
+            const f32x4 a = *(const f32x4*)(sp + i0), b = *(const f32x4*)(sp + i0 + 4);
+            const float c8[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (i0 + e < V && last < 0) {
+                    cum += c8[e];
+                    if (cum > top_p && ++crossings == 2) last = i0 + e;
+                }
             }
         }
         if (crossings == 0) last = V < 3 ? (int)V : 3;
         else if (crossings == 1) last = (int)V;
         double csum = 0.0;
-        for (int i = 0; i < last; ++i) csum += (double)sp[i];
+        for (int i0 = 0; i0 < last; i0 += 8) {
+            const f32x4 a = *(const f32x4*)(sp + i0), b = *(const f32x4*)(sp + i0 + 4);
+            const float c8[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (i0 + e < last) csum += (double)c8[e];
+        }
         const double target = (double)u[blockIdx.x] * csum;
         double run = 0.0;
-        int pick = last - 1;
-        for (int i = 0; i < last; ++i) {
-            run += (double)sp[i];
-            if (run > target) { pick = i; break; }
+        int pick = -1;
+        for (int i0 = 0; i0 < last && pick < 0; i0 += 8) {
+            const f32x4 a = *(const f32x4*)(sp + i0), b = *(const f32x4*)(sp + i0 + 4);
+            const float c8[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (i0 + e < last && pick < 0) {
+                    run += (double)c8[e];
+                    if (run > target) pick = i0 + e;
+                }
+            }
         }
+        if (pick < 0) pick = last - 1;
         s_last = si[pick];
         out[blockIdx.x] = (int64_t)s_last;
     }

@@ -985,6 +985,76 @@ __global__ __launch_bounds__(256) void favor_decode_kernel(const CT* __restrict_
     }
 }
 
+// Compile-time (dh, mf) variant of the decode step: the whole state slice of the block (F x dh fp32 = 32 KB at 128 x 64) is requested
+// with 16-B loads BEFORE the feature phase, so the HBM round trip overlaps the phi(q), phi(k) computation; everything is unrolled
+// (r01: the generic kernel took 18 us per layer for 16.8 MB of state traffic = 0.9 TB/s, latency-bound on 32 dependent 4-B accesses).
+template <typename CT, int DH, int MF>
+__global__ __launch_bounds__(256) void favor_decode_fast_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+                                                                const float* __restrict__ omega, float* __restrict__ state_S,
+                                                                float* __restrict__ state_z, CT* __restrict__ out, int64_t ld_out, int64_t H, float eps) {
+    constexpr int F = 2 * MF, TPRW = DH / 4, R = 256 / TPRW, NP = (F + R - 1) / R;   // threads per state row, rows per pass, passes
+    __shared__ float xq[DH], xk[DH], xv[DH], fq[F], fk[F], dpart[4];
+    __shared__ f32x4 num[R][TPRW];
+    const int tid = threadIdx.x;
+    const int64_t sh = blockIdx.x, s = sh / H, h = sh % H;
+    const int d4 = (tid % TPRW) * 4, g = tid / TPRW;
+    float* Sb = state_S + sh * F * DH;
+    f32x4 st[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int f = g + R * i;
+        st[i] = f < F ? *(const f32x4*)(Sb + f * DH + d4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (tid < DH) {
+        xq[tid] = to_f32<CT>(q[s * ld + h * DH + tid]);
+        xk[tid] = to_f32<CT>(k[s * ld + h * DH + tid]);
+        xv[tid] = to_f32<CT>(v[s * ld + h * DH + tid]);
+    }
+    __syncthreads();
+    const float cs = rsqrtf(sqrtf((float)DH)), half_ln_f = 0.5f * logf((float)F);
+    float dn = 0.f;
+    if (tid < F) {
+        const int m = tid % MF;
+        const float sgn = tid < MF ? 1.f : -1.f;
+        float uq = 0.f, uk = 0.f, nq = 0.f, nk = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) {
+            const float w = omega[d * MF + m];
+            uq += xq[d] * w; uk += xk[d] * w;
+            nq += xq[d] * xq[d]; nk += xk[d] * xk[d];
+        }
+        const float pq = __expf(sgn * cs * uq - (0.5f * cs * cs * nq + half_ln_f));
+        const float pk = __expf(sgn * cs * uk - (0.5f * cs * cs * nk + half_ln_f));
+        fq[tid] = pq;
+        fk[tid] = pk;
+        const float z = state_z[sh * F + tid] + pk;
+        state_z[sh * F + tid] = z;
+        dn = pq * z;
+    }
+    dn = wave_sum(dn);
+    if ((tid & 63) == 0) dpart[tid >> 6] = dn;
+    __syncthreads();
+    const f32x4 vd = {xv[d4], xv[d4 + 1], xv[d4 + 2], xv[d4 + 3]};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int f = g + R * i;
+        if (f < F) {
+            const f32x4 sv = st[i] + fk[f] * vd;
+            *(f32x4*)(Sb + f * DH + d4) = sv;
+            acc += fq[f] * sv;
+        }
+    }
+    num[g][tid % TPRW] = acc;
+    __syncthreads();
+    if (tid < DH) {
+        float a = 0.f;
+#pragma unroll
+        for (int p = 0; p < R; ++p) a += num[p][tid >> 2][tid & 3];
+        out[s * ld_out + h * DH + tid] = from_f32<CT>(a / (dpart[0] + dpart[1] + dpart[2] + dpart[3] + eps));
+    }
+}
+
 // =============================================================================================== omega draw
 // FAVOR+ orthogonal random features (fast-transformers orthogonal_random_matrix_): per block of dh columns,
 // G ~ N(0,1)^{dh x dh} (supplied by the caller's RNG), Q = orthonormal basis of G's columns, column j scaled by
@@ -1213,6 +1283,25 @@ extern "C" int emo_favor_decode_step(const void* q, const void* k, const void* v
     EMO_CHECK(dh <= 64 && dh >= 16 && 256 % dh == 0 && n_feat <= 128 && n_feat % 2 == 0, "emo_favor_decode_step: needs 16<=d_head<=64 dividing 256, n_feat<=128");
     dim3 grid((unsigned)(n_streams * H));
     hipStream_t st = (hipStream_t)stream;
+#define DECODE_CASE(DHv, MFv)                                                                                                                   \
+    if (dh == DHv && n_feat == 2 * MFv) {                                                                                                       \
+        if (dtype == EMO_F32)                                                                                                                   \
+            hipLaunchKernelGGL((favor_decode_fast_kernel<float, DHv, MFv>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, ld,   \
+                               omega, state_S, state_z, (float*)out, ld_out, H, eps);                                                           \
+        else                                                                                                                                    \
+            hipLaunchKernelGGL((favor_decode_fast_kernel<bf16_t, DHv, MFv>), grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, \
+                               ld, omega, state_S, state_z, (bf16_t*)out, ld_out, H, eps);                                                      \
+        EMO_LAUNCH_CHECK();                                                                                                                     \
+        return EMO_OK;                                                                                                                          \
+    }
+    if (getenv("EMO_FAVOR_DECODE_GENERIC") == nullptr && (((uintptr_t)state_S) & 15) == 0) {
+        DECODE_CASE(64, 64)
+        DECODE_CASE(32, 64)
+        DECODE_CASE(32, 32)
+        DECODE_CASE(16, 16)
+        DECODE_CASE(16, 32)
+    }
+#undef DECODE_CASE
     if (dtype == EMO_F32)
         hipLaunchKernelGGL(favor_decode_kernel<float>, grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, ld, omega, state_S, state_z,
                            (float*)out, ld_out, H, (int)dh, (int)(n_feat / 2), eps);

@@ -309,6 +309,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int64_t m0 = tm * BM, n0 = tn * BN;
     const int64_t kbeg = split * k_per_split;
     const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+    if (kbeg >= kend) return;                 // surplus split of the rounded-up grid: no K range, and no workspace slice either
     const int wm = wave >> 1, wn = wave & 1;  // 2x2 waves, 32x32 each
     f32x4 acc[2][2];
 #pragma unroll

@@ -140,6 +140,30 @@ def test_gemm_splitk_workspace_is_deterministic_and_matches_atomics(splits, monk
         _close(o4, o3, dt, scale=float(ref.abs().max()), mult=0.05)
 
 
+@pytest.mark.parametrize('splits', [None, 3, 5, 13])
+def test_gemm_splitk_workspace_stays_inside_its_bounds(splits, monkeypatch):
+    # the split grid is rounded up to whole XCD rounds; surplus splits own no K range and must not touch the workspace
+    # (regression: the fp32 kernel wrote zero tiles past an exactly-sized workspace)
+    _ops()
+    import ctypes
+    from emo_disentanger_amd._lib import lib, ptr, check, Epilogue
+    if splits is not None:
+        monkeypatch.setenv('EMO_GEMM_SPLITS', str(splits))
+    for dt, code in ((torch.float32, 0), (torch.bfloat16, 1)):
+        Mred, N, K = 4096 + 128, 136, 72
+        need = lib.emo_gemm_workspace_bytes(N, K, Mred, code, 0)
+        assert need > 0
+        dY, X = _r(Mred, N, seed=1, dt=dt).cuda(), _r(Mred, K, seed=2, dt=dt).cuda()
+        guard = 1 << 20
+        buf = torch.full((need + guard,), 0x5A, dtype=torch.uint8, device='cuda')
+        out = torch.zeros(N, K, device='cuda')
+        epi = Epilogue(None, 0, None, None, 0, 1.0, 0.0, 0, 0, None, ptr(buf), need)
+        check(lib.emo_gemm(ptr(dY), 1, N, ptr(X), 1, K, ptr(out), K, N, K, Mred, code, 0, 0, ctypes.byref(epi), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert bool((buf[need:] == 0x5A).all()), 'workspace overrun'
+        _close(out, dY.double().T @ X.double(), dt, mult=1.0 if dt == torch.float32 else 0.3)
+
+
 def test_gemm_bf16_safe_and_tr_paths_agree(monkeypatch):
     # the transposed-operand fragments are fetched with ds_read_b64_tr_b16; EMO_GEMM_SAFE_TR=1 (read at first use)
     # selects a scalar-read variant of the same kernel; both are compared with the reference in the layout tests.
