@@ -51,6 +51,7 @@ _SIG = {
     'emo_xent_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_p]),
     'emo_argmax': (c_i, [c_p, c_l, c_l, c_p, c_p]),
     'emo_sample_nucleus': (c_i, [c_p, c_l, c_l, c_f, c_f, c_p, c_p, c_p]),
+    'emo_sample_nucleus_step': (c_i, [c_p, c_l, c_l, c_f, c_f, c_p, c_p, c_p, c_l, c_l, c_p, c_p]),
     'emo_accuracy_counts': (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_p]),
     'emo_sumsq': (c_i, [c_p, c_l, c_p, c_p]),
     'emo_clip_coef': (c_i, [c_p, c_f, c_f, c_p, c_p]),

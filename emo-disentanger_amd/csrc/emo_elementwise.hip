@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = it / d4, c = (it - row * d4) << 2;
         const int64_t t = row % T_len;
-        const int64_t pbase = pos_ids ? pos_ids[row / T_len] : pos0;
+        const int64_t pbase = pos0 + (pos_ids ? pos_ids[row / T_len] : 0);
         float e[4], s[4] = {0, 0, 0, 0}, p[4], o[4];
         Vec4<float>::load(E + tok[row] * D + c, e);
         if (seg) Vec4<float>::load(S + seg[row] * D + c, s);
@@ -466,21 +466,24 @@ extern "C" int emo_accuracy_counts(const float* logits, const int64_t* tgt, cons
 }
 
 // ================================================================================================ K10 nucleus sampling
-// One 256-thread block per stream.  probs = softmax(l/temp) (fp32, as NumPy on fp32 logits),
-// bitonic sort (descending, ties by ascending index) of <=1024 entries in LDS, inclusive cumsum,
-// last_index = SECOND position whose cumsum exceeds top_p (reference inference.py:93-94 keeps the
-// crossing token — SURVEY F12); where the reference would raise IndexError (single crossing) all
-// sorted tokens are kept.  Draw: cdf over the renormalised (f64) candidates, searchsorted(u, right).
+// One 256-thread block per stream.  probs = softmax(l/temp) (fp32, as NumPy on fp32 logits); rank sort (descending, ties by
+// ascending index) of <= 1024 entries in LDS; inclusive cumsum in np.cumsum's sequential fp32 order; last_index = SECOND position
+// whose cumsum exceeds top_p (reference inference.py:93-94 keeps the crossing token — SURVEY F12); where the reference would raise
+// IndexError (single crossing) all sorted tokens are kept.  Draw: cdf over the renormalised (f64) candidates, searchsorted(u, right).
+// Serial work is two tight prefix scans (fp32 by wave 0, f64 by wave 1, concurrently); because both prefixes are monotone the
+// crossing positions are COUNTS (#{cum <= top_p}, #{run <= target}) taken by all threads.  r01: 62 us (bitonic network + three
+// branchy single-thread loops) -> see profiles.
 __global__ __launch_bounds__(256) void nucleus_kernel(const float* __restrict__ logits, int64_t V, float temp, float top_p,
-                                                      const float* __restrict__ u, int64_t* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float sp[1024 + 8];
+                                                      const float* __restrict__ u, int64_t* __restrict__ out, int64_t* __restrict__ step,
+                                                      int64_t* __restrict__ seq, int64_t ld_seq, int64_t col0) {
+    __shared__ __attribute__((aligned(16))) float sp[1024 + 8], sq[1024 + 8], cumf[1024 + 8];
+    __shared__ __attribute__((aligned(16))) double cumd[1024 + 8];
     __shared__ int si[1024];
     __shared__ float red[4];
-    __shared__ int s_last;
+    __shared__ int cnt[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* l = logits + (int64_t)blockIdx.x * V;
-    int n2 = 1;
-    while (n2 < V) n2 <<= 1;
+    const int Vp = ((int)V + 7) & ~7;
     float mx = -INFINITY;
     for (int c = tid; c < V; c += 256) mx = fmaxf(mx, l[c] / temp);
     mx = wave_max(mx);
@@ -489,75 +492,80 @@ __global__ __launch_bounds__(256) void nucleus_kernel(const float* __restrict__ 
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     float s = 0.f;
-    for (int c = tid; c < n2; c += 256) {
-        float e = (c < V) ? expf(l[c] / temp - mx) : -1.f;
+    for (int c = tid; c < V; c += 256) {
+        const float e = expf(l[c] / temp - mx);
         sp[c] = e;
-        si[c] = c;
-        if (c < V) s += e;
+        s += e;
     }
     s = wave_sum(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
     const float tot = red[0] + red[1] + red[2] + red[3];
-    for (int c = tid; c < V; c += 256) sp[c] = sp[c] / tot;
+    for (int c = tid; c < V; c += 256) sq[c] = sp[c] / tot;
+    for (int c = (int)V + tid; c < Vp + 8; c += 256) sq[c] = -1.f;        // never greater than or equal to a probability
     __syncthreads();
-    for (int k = 2; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n2; i += 256) {
-                int ixj = i ^ j;
-                if (ixj > i) {
-                    float a = sp[i], b = sp[ixj];
-                    int ia = si[i], ib = si[ixj];
-                    bool a_first = (a > b) || (a == b && ia < ib);  // descending order wanted
-                    bool up = ((i & k) == 0);
-                    if (up ? !a_first : a_first) { sp[i] = b; sp[ixj] = a; si[i] = ib; si[ixj] = ia; }
-                }
+    for (int c = tid; c < Vp; c += 256) {
+        if (c < V) {
+            const float pc = sq[c];
+            int rank = 0;
+            for (int j0 = 0; j0 < Vp; j0 += 4) {
+                const f32x4 q4 = *(const f32x4*)(sq + j0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rank += (int)(q4[e] > pc) | ((int)(q4[e] == pc) & (int)(j0 + e < c));
             }
-            __syncthreads();
+            sp[rank] = pc;
+            si[rank] = c;
+        } else {
+            sp[c] = 0.f;                                                   // sorted tail pad: adds nothing to either prefix
         }
     }
-    if (tid == 0) {
-        // sequential fp32 cumsum (np.cumsum order), but fed by 16-B LDS reads: the dependent chain is the adds, not 327 LDS round trips
+    __syncthreads();
+    if (tid == 0) {                        // np.cumsum order, fp32
         float cum = 0.f;
-        int crossings = 0, last = -1;
-        for (int i0 = 0; i0 < V && last < 0; i0 += 8) {
+        for (int i0 = 0; i0 < Vp; i0 += 8) {
             const f32x4 a = *(const f32x4*)(sp + i0), b = *(const f32x4*)(sp + i0 + 4);
-            const float c8[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (i0 + e < V && last < 0) {
-                    cum += c8[e];
-                    if (cum > top_p && ++crossings == 2) last = i0 + e;
-                }
-            }
+            f32x4 ca, cb;
+            ca[0] = cum += a[0]; ca[1] = cum += a[1]; ca[2] = cum += a[2]; ca[3] = cum += a[3];
+            cb[0] = cum += b[0]; cb[1] = cum += b[1]; cb[2] = cum += b[2]; cb[3] = cum += b[3];
+            *(f32x4*)(cumf + i0) = ca;
+            *(f32x4*)(cumf + i0 + 4) = cb;
         }
-        if (crossings == 0) last = V < 3 ? (int)V : 3;
-        else if (crossings == 1) last = (int)V;
-        double csum = 0.0;
-        for (int i0 = 0; i0 < last; i0 += 8) {
-            const f32x4 a = *(const f32x4*)(sp + i0), b = *(const f32x4*)(sp + i0 + 4);
-            const float c8[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (i0 + e < last) csum += (double)c8[e];
-        }
-        const double target = (double)u[blockIdx.x] * csum;
+    } else if (tid == 64) {                // sequential f64 prefix of the same sorted probabilities (candidate renormalisation + draw)
         double run = 0.0;
-        int pick = -1;
-        for (int i0 = 0; i0 < last && pick < 0; i0 += 8) {
-            const f32x4 a = *(const f32x4*)(sp + i0), b = *(const f32x4*)(sp + i0 + 4);
-            const float c8[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (i0 + e < last && pick < 0) {
-                    run += (double)c8[e];
-                    if (run > target) pick = i0 + e;
-                }
-            }
+        for (int i0 = 0; i0 < Vp; i0 += 4) {
+            const f32x4 a = *(const f32x4*)(sp + i0);
+            cumd[i0] = run += (double)a[0];
+            cumd[i0 + 1] = run += (double)a[1];
+            cumd[i0 + 2] = run += (double)a[2];
+            cumd[i0 + 3] = run += (double)a[3];
         }
-        if (pick < 0) pick = last - 1;
-        s_last = si[pick];
-        out[blockIdx.x] = (int64_t)s_last;
+    }
+    __syncthreads();
+    // first crossing i1 = #{i < V : cum_i <= top_p}; cum is non-decreasing, so the second crossing is i1 + 1
+    int c1 = 0;
+    for (int i = tid; i < V; i += 256) c1 += (cumf[i] <= top_p) ? 1 : 0;
+    c1 = (int)wave_sum((float)c1);
+    if (lane == 0) cnt[wave] = c1;
+    __syncthreads();
+    const int i1 = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    int last;
+    if (i1 >= V) last = V < 3 ? (int)V : 3;       // no crossing
+    else if (i1 + 1 >= V) last = (int)V;          // single crossing (reference: IndexError)
+    else last = i1 + 1;
+    const int64_t kstep = step ? step[blockIdx.x] : 0;            // device-side step counter of this stream (hipGraph replay)
+    const double target = (double)u[kstep * gridDim.x + blockIdx.x] * cumd[last - 1];
+    __syncthreads();
+    int c2 = 0;
+    for (int i = tid; i < last; i += 256) c2 += (cumd[i] <= target) ? 1 : 0;
+    c2 = (int)wave_sum((float)c2);
+    if (lane == 0) cnt[wave] = c2;
+    __syncthreads();
+    if (tid == 0) {
+        int pick = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        if (pick >= last) pick = last - 1;
+        out[blockIdx.x] = (int64_t)si[pick];
+        if (seq) seq[(int64_t)blockIdx.x * ld_seq + col0 + kstep] = (int64_t)si[pick];
+        if (step) step[blockIdx.x] = kstep + 1;
     }
 }
 extern "C" int emo_sample_nucleus(const float* logits, int64_t rows, int64_t V, float temperature, float top_p, const float* u,
@@ -565,7 +573,18 @@ extern "C" int emo_sample_nucleus(const float* logits, int64_t rows, int64_t V, 
     EMO_CHECK(logits && u && out && rows > 0, "emo_sample_nucleus: bad args");
     EMO_CHECK(V > 0 && V <= 1024, "emo_sample_nucleus: V must be <= 1024 (got %lld)", (long long)V);
     EMO_CHECK(temperature > 0.f, "emo_sample_nucleus: temperature must be > 0");
-    hipLaunchKernelGGL(nucleus_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, V, temperature, top_p, u, out);
+    hipLaunchKernelGGL(nucleus_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, V, temperature, top_p, u, out, (int64_t*)nullptr,
+                       (int64_t*)nullptr, (int64_t)0, (int64_t)0);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+extern "C" int emo_sample_nucleus_step(const float* logits, int64_t rows, int64_t V, float temperature, float top_p, const float* u_steps,
+                                       int64_t* step, int64_t* seq, int64_t ld_seq, int64_t col0, int64_t* out, emo_stream_t stream) {
+    EMO_CHECK(logits && u_steps && out && step && rows > 0, "emo_sample_nucleus_step: bad args");
+    EMO_CHECK(V > 0 && V <= 1024, "emo_sample_nucleus_step: V must be <= 1024 (got %lld)", (long long)V);
+    EMO_CHECK(temperature > 0.f, "emo_sample_nucleus_step: temperature must be > 0");
+    hipLaunchKernelGGL(nucleus_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, V, temperature, top_p, u_steps, out, step, seq,
+                       ld_seq, col0);
     EMO_LAUNCH_CHECK();
     return EMO_OK;
 }

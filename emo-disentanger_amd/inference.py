@@ -74,16 +74,17 @@ class _EngineBase:
         self.dev, self.dt = self.ps.device, self.ps.compute_dtype
         self.pos = 0
         self.pos_dev = torch.zeros(n_streams, device=self.dev, dtype=torch.int64)   # device-side positions (hipGraph replay)
+        self.dev_pos0, self.pos_auto = 0, True   # position = dev_pos0 + pos_dev[stream]; pos_auto: the engine advances pos_dev itself
 
     def _embed(self, tok, seg, pos0, dev_pos=False):
         m, ps = self.model, self.ps
         S = ps.f32('segemb.emb_lookup.weight') if (seg is not None and m.use_segment_emb) else None
         pe = m.pe.pe if m.use_pe else m._zero_pe(self.max_len, m.d_model)
         return ops.embed_fwd(tok, seg if S is not None else None, ps.f32('token_emb.emb_lookup.weight'), S, pe, self.dt, float(m.token_emb.emb_scale),
-                             pos0=pos0, pos_ids=self.pos_dev if dev_pos else None).view(-1, m.d_model)
+                             pos0=self.dev_pos0 if dev_pos else pos0, pos_ids=self.pos_dev if dev_pos else None).view(-1, m.d_model)
 
-    def _logits(self, h):
-        return ops.gemm(h, self.ps.w('dec_out_proj.weight'), bias=self.ps.f32('dec_out_proj.bias'), out_dtype=torch.float32)
+    def _logits(self, h, out=None):
+        return ops.gemm(h, self.ps.w('dec_out_proj.weight'), bias=self.ps.f32('dec_out_proj.bias'), out=out, out_dtype=torch.float32)
 
     @torch.no_grad()
     def append(self, tok, seg):
@@ -133,9 +134,9 @@ class PerformerDecodeEngine(_EngineBase):
         return out
 
     @torch.no_grad()
-    def step(self, tok, seg, dev_pos=False):
+    def step(self, tok, seg, dev_pos=False, logits_out=None):
         """dev_pos=True: positions come from the device array `pos_dev` (and are advanced on the device), so the whole step is
-        capturable in a hipGraph and replayable."""
+        capturable in a hipGraph and replayable.  logits_out: write the logits into this static buffer (no copy kernel)."""
         m, ps = self.model, self.ps
         D, H = m.d_model, m.n_head
         x = self._embed(tok.view(-1, 1), None if seg is None else seg.view(-1, 1), self.pos, dev_pos)
@@ -146,10 +147,11 @@ class PerformerDecodeEngine(_EngineBase):
             attn = ops.favor_decode_step(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], self.omegas[l], self.S[l], self.z[l], H)
             x = self._tail(pfx, x, attn)
         if dev_pos:
-            self.pos_dev.add_(1)
+            if self.pos_auto:
+                self.pos_dev.add_(1)
         else:
             self.pos += 1
-        return self._logits(x)
+        return self._logits(x, logits_out)
 
 
 class GPT2DecodeEngine(_EngineBase):
@@ -479,12 +481,25 @@ def generate_streams(model, prompt_tok, prompt_seg, n_new, temp=1.1, top_p=0.9, 
     logits_buf = eng.prefill(prompt_tok, prompt_seg).clone()
     step_idx = torch.zeros(1, dtype=torch.long, device=dev)
 
-    def one_step():
-        u = U.index_select(0, step_idx).view(n)
-        nxt = sample_on_device(logits_buf, temp, top_p, u, greedy)
-        out.scatter_(1, (step_idx + T0).expand(n, 1), nxt.view(n, 1))
-        logits_buf.copy_(eng.step(nxt, seg_col, dev_pos=True))
-        step_idx.add_(1)
+    fused = (not greedy) and model.kind == 'performer'
+    if fused:
+        # all loop state on the device inside OUR kernels: the sampler reads u[step[r], r], writes the token into out[r, T0 + step[r]] and
+        # advances step[r]; the embedding takes position (T0 - 1) + step[r]; the logits GEMM writes straight into logits_buf
+        # (5 fewer launches per token than the torch index_select / scatter_ / add_ / copy_ version below).
+        step_ctr = torch.zeros(n, dtype=torch.long, device=dev)
+        eng.pos_dev, eng.dev_pos0, eng.pos_auto = step_ctr, T0 - 1, False
+        nxt_buf = torch.empty(n, dtype=torch.long, device=dev)
+
+        def one_step():
+            ops.sample_nucleus_step(logits_buf, temp, top_p, U, step_ctr, seq=out, col0=T0, out=nxt_buf)
+            eng.step(nxt_buf, seg_col, dev_pos=True, logits_out=logits_buf)
+    else:
+        def one_step():
+            u = U.index_select(0, step_idx).view(n)
+            nxt = sample_on_device(logits_buf, temp, top_p, u, greedy)
+            out.scatter_(1, (step_idx + T0).expand(n, 1), nxt.view(n, 1))
+            logits_buf.copy_(eng.step(nxt, seg_col, dev_pos=True))
+            step_idx.add_(1)
 
     if n_new <= 0:
         return out

@@ -13,7 +13,7 @@ from ._lib import (ACT_GELU_NEW, ACT_NONE, ACT_RELU, BF16, F32, MUL_DGELU_NEW, M
 
 __all__ = ['gemm', 'colsum', 'embed_fwd', 'embed_bwd', 'layernorm_fwd', 'layernorm_bwd', 'dropout_apply', 'favor_attn_fwd',
            'favor_attn_bwd', 'favor_decode_step', 'favor_draw_omega', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'xent_fwd',
-           'xent_bwd', 'argmax', 'sample_nucleus', 'accuracy_counts', 'sumsq', 'clip_coef', 'adam_step', 'cast',
+           'xent_bwd', 'argmax', 'sample_nucleus', 'sample_nucleus_step', 'accuracy_counts', 'sumsq', 'clip_coef', 'adam_step', 'cast',
            'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW']
 
 
@@ -254,6 +254,20 @@ def sample_nucleus(logits, temperature, top_p, u):
     assert logits.is_contiguous() and logits.dtype == torch.float32 and u.dtype == torch.float32 and u.numel() == rows
     out = torch.empty(rows, device=logits.device, dtype=torch.int64)
     check(lib.emo_sample_nucleus(ptr(logits), rows, V, temperature, top_p, ptr(u), ptr(out), stream()))
+    return out
+
+
+def sample_nucleus_step(logits, temperature, top_p, u_steps, step, seq=None, col0=0, out=None):
+    """One lock-step sampling step with device-side loop state (see include/emo_hip.h): uses u_steps[step[r], r], writes the id to out[r]
+    and seq[r, col0 + step[r]], increments step[r].  Allocation-free when `out` is given (hipGraph capture)."""
+    rows, V = logits.shape
+    assert logits.is_contiguous() and logits.dtype == torch.float32 and u_steps.dtype == torch.float32 and u_steps.is_contiguous()
+    assert u_steps.shape[-1] == rows and step.dtype == torch.int64 and step.numel() == rows
+    assert seq is None or (seq.dtype == torch.int64 and seq.stride(1) == 1 and seq.shape[0] == rows)
+    if out is None:
+        out = torch.empty(rows, device=logits.device, dtype=torch.int64)
+    check(lib.emo_sample_nucleus_step(ptr(logits), rows, V, temperature, top_p, ptr(u_steps), ptr(step), ptr(seq), 0 if seq is None else seq.stride(0),
+                                      col0, ptr(out), stream()))
     return out
 
 

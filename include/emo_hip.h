@@ -78,7 +78,7 @@ int emo_colsum(const void* X, int dtype, int64_t M, int64_t N, int64_t ld, float
                int accumulate, emo_stream_t stream);
 
 /* ------------------------------------------------------------------ K1: embedding prologue
- * out[b,t,:] = dropout( (E[tok[b,t]] + S[seg[b,t]]) * scale + pe[pos0 + t] )
+ * out[b,t,:] = dropout( (E[tok[b,t]] + S[seg[b,t]]) * scale + pe[pos0 + pos_ids[b] + t] )   (pos_ids NULL = zeros)
  * Replaces TokenEmbedding.forward x2 + PositionalEncoding + emb_dropout
  * (model/transformer_helpers.py:81-87,57-63; model/music_performer.py:51-62).
  * pe: fp32 rows of length D (the `pe.pe` buffer [max_pos,1,D] is exactly that).
@@ -175,6 +175,12 @@ int emo_xent_bwd(const float* logits, const int64_t* tgt, const float* row_lse, 
 int emo_argmax(const float* logits, int64_t rows, int64_t V, int64_t* out, emo_stream_t stream);
 int emo_sample_nucleus(const float* logits, int64_t rows, int64_t V, float temperature, float top_p,
                        const float* u, int64_t* out, emo_stream_t stream);
+/* One step of the lock-step generation loop (inference.py:252-327 with grammar checks off) with all loop state on the device, so
+ * the step can be captured once in a hipGraph and replayed: stream r draws with u_steps[step[r], r] (u_steps: [n_steps, rows]),
+ * the sampled id goes to out[r] and to seq[r, col0 + step[r]] (seq may be NULL), then step[r] += 1. */
+int emo_sample_nucleus_step(const float* logits, int64_t rows, int64_t V, float temperature,
+                            float top_p, const float* u_steps, int64_t* step, int64_t* seq,
+                            int64_t ld_seq, int64_t col0, int64_t* out, emo_stream_t stream);
 /* counts[0..5] += {nonpad, nonpad&correct, chord, chord&correct, melody, melody&correct} (train.py:184-193) */
 int emo_accuracy_counts(const float* logits, const int64_t* tgt, const int64_t* chord,
                         const int64_t* melody, int64_t M, int64_t V, int64_t pad, int64_t* counts,

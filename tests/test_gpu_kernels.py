@@ -439,6 +439,26 @@ def test_nucleus_sampling_matches_host_reference():
                 assert near < 1e-5 and got[r] in cand, (V, r, got[r], exp)
 
 
+def test_nucleus_step_keeps_loop_state_on_device():
+    # emo_sample_nucleus_step: u[step[r], r], token -> out[r] and seq[r, col0 + step[r]], step[r] += 1; identical picks to emo_sample_nucleus
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    n, V, K, col0 = 5, 327, 4, 3
+    U = torch.rand(K, n, generator=g).cuda()
+    step = torch.tensor([0, 1, 0, 2, 1], dtype=torch.long).cuda()
+    seq = torch.full((n, col0 + K + 2), -1, dtype=torch.long).cuda()
+    exp_seq, exp_step = seq.clone(), step.clone()
+    for it in range(2):
+        logits = (torch.randn(n, V, generator=g) * 2.0).cuda()
+        tok = ops.sample_nucleus_step(logits, 1.1, 0.9, U, step, seq=seq, col0=col0)
+        u_rows = U[exp_step, torch.arange(n).cuda()].contiguous()
+        ref = ops.sample_nucleus(logits, 1.1, 0.9, u_rows)
+        assert torch.equal(tok, ref)
+        exp_seq[torch.arange(n).cuda(), col0 + exp_step] = ref
+        exp_step += 1
+        assert torch.equal(step, exp_step) and torch.equal(seq, exp_seq)
+
+
 def test_adam_and_clip_match_torch():
     ops = _ops()
     n = 10007
