@@ -30,6 +30,14 @@ struct EpiParams {
     int64_t ldc;
     int accumulate;
     int atomic;   // 0 = plain store; > 0 = split-K partial sums via fp32 atomics, value = XCDs per split (splitk_coords)
+    // LayerNorm folded around a skinny (M <= 32) GEMM — decode path, see gemm_bf16_skinny_kernel
+    const float* ln_c1;        // [N]: C = rstd[m] * (A.B^T - mean[m] * ln_c1[n]) (+ bias ...); row statistics of A computed in-kernel
+    float* ln_stats_out;       // optional [M][2] (mean, rstd) of the A rows, written by block 0
+    const void* rln_x;         // residual = LayerNorm(rln_x[m][n]) from rln_stats [M][2], rln_gamma / rln_beta [N]
+    const float* rln_stats;
+    const float* rln_gamma;
+    const float* rln_beta;
+    float ln_eps;
     int64_t ws_stride;   // > 0: split-K partials go to C + split * ws_stride with plain stores (splitk_reduce_kernel sums them)
     int ablate;   // diagnostics only (EMO_GEMM_ABLATE): 1 = skip tile loads, 2 = skip MFMAs
 };
@@ -835,7 +843,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_skinny_kernel(const bf16_t* __r
                                                                OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, EpiParams ep) {
     // block = 16 output columns; its 4 waves split the K range (shorter dependent chains, 4x the loads in flight) and
     // combine through LDS; wave 0 runs the fused epilogue.
+    //
+    // LayerNorm folding (decode step: a standalone LN launch on 32 rows costs as much as this whole GEMM).  For A' = LN(A) * gamma + beta:
+    //   A'.W^T [m][n] = rstd[m] * ( (A.(gamma*W)^T)[m][n] - mean[m] * c1[n] ) + (beta.W^T)[n],   c1[n] = sum_k gamma_k W[n][k]
+    // so the kernel multiplies the RAW rows by the gamma-scaled weights (prepared once by the caller, like c1 and the folded bias), gets
+    // mean / rstd of its A rows from the fragments it loads anyway, and applies them in the epilogue (ep.ln_c1).  A residual that is itself
+    // a LayerNorm output is rebuilt from the raw tensor and the statistics an earlier kernel exported (ep.rln_*, ep.ln_stats_out).
     __shared__ f32x4 red[3][2][64];
+    __shared__ float st[4][2][16][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n0 = (int64_t)blockIdx.x * 16;
     int64_t nb = n0 + (lane & 15);
@@ -851,6 +866,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_skinny_kernel(const bf16_t* __r
     const bf16_t* pa0 = A + m_lo * lda + (lane >> 4) * 8;
     const bf16_t* pa1 = A + m_hi * lda + (lane >> 4) * 8;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const bool ln = ep.ln_c1 != nullptr;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;        // sum / sum of squares of this lane's slices of rows m_lo / m_hi
     int64_t k = kb;
     for (; k + 128 <= ke; k += 128) {
         bf16x8 fb[4], fa0[4], fa1[4];
@@ -860,6 +877,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_skinny_kernel(const bf16_t* __r
             fa0[u] = *(const bf16x8*)(pa0 + k + u * 32);
             fa1[u] = *(const bf16x8*)(pa1 + k + u * 32);
         }
+        if (ln) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = (float)fa0[u][e], b = (float)fa1[u][e];
+                    s0 += a; q0 += a * a; s1 += b; q1 += b * b;
+                }
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[u], fa0[u], acc0, 0, 0, 0);
@@ -868,8 +894,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_skinny_kernel(const bf16_t* __r
     }
     for (; k < ke; k += 32) {
         bf16x8 fb = *(const bf16x8*)(pb + k), fa0 = *(const bf16x8*)(pa0 + k), fa1 = *(const bf16x8*)(pa1 + k);
+        if (ln) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = (float)fa0[e], b = (float)fa1[e];
+                s0 += a; q0 += a * a; s1 += b; q1 += b * b;
+            }
+        }
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa0, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa1, acc1, 0, 0, 0);
+    }
+    if (ln) {                                                // the 4 lane groups hold different k slices of the same row
+        s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
+        q0 += __shfl_xor(q0, 16, 64); q0 += __shfl_xor(q0, 32, 64);
+        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+        q1 += __shfl_xor(q1, 16, 64); q1 += __shfl_xor(q1, 32, 64);
+        if (lane < 16) { st[wave][0][lane][0] = s0; st[wave][0][lane][1] = q0; st[wave][1][lane][0] = s1; st[wave][1][lane][1] = q1; }
     }
     if (wave > 0) { red[wave - 1][0][lane] = acc0; red[wave - 1][1][lane] = acc1; }
     __syncthreads();
@@ -878,6 +918,42 @@ __global__ __launch_bounds__(256) void gemm_bf16_skinny_kernel(const bf16_t* __r
     for (int w = 0; w < 3; ++w) { acc0 += red[w][0][lane]; acc1 += red[w][1][lane]; }
     const int64_t n = n0 + (lane >> 4) * 4;
     const int64_t m0 = lane & 15;
+    if (ln) {
+        const int r = lane & 15;
+        const float invK = 1.f / (float)K;
+        float su = 0.f, sq = 0.f, tu = 0.f, tq = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { su += st[w][0][r][0]; sq += st[w][0][r][1]; tu += st[w][1][r][0]; tq += st[w][1][r][1]; }
+        const float mean0 = su * invK, mean1 = tu * invK;
+        const float rstd0 = rsqrtf(fmaxf(sq * invK - mean0 * mean0, 0.f) + ep.ln_eps), rstd1 = rsqrtf(fmaxf(tq * invK - mean1 * mean1, 0.f) + ep.ln_eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float c1 = (n + i < N) ? ep.ln_c1[n + i] : 0.f;
+            acc0[i] = rstd0 * (acc0[i] - mean0 * c1);
+            acc1[i] = rstd1 * (acc1[i] - mean1 * c1);
+        }
+        if (ep.ln_stats_out && blockIdx.x == 0 && lane < 16) {
+            if (m0 < M) { ep.ln_stats_out[m0 * 2] = mean0; ep.ln_stats_out[m0 * 2 + 1] = rstd0; }
+            if (m0 + 16 < M) { ep.ln_stats_out[(m0 + 16) * 2] = mean1; ep.ln_stats_out[(m0 + 16) * 2 + 1] = rstd1; }
+        }
+    }
+    if (ep.rln_x) {                                          // residual = LayerNorm(rln_x) rebuilt from exported statistics
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t m = m0 + 16 * h;
+            if (m < M) {
+                const float mean = ep.rln_stats[m * 2], rstd = ep.rln_stats[m * 2 + 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (n + i < N) {
+                        const float x = to_f32<OutT>(((const OutT*)ep.rln_x)[m * ep.ldc + n + i]);
+                        const float rv = (x - mean) * rstd * ep.rln_gamma[n + i] + ep.rln_beta[n + i];
+                        if (h == 0) acc0[i] += rv; else acc1[i] += rv;
+                    }
+                }
+            }
+        }
+    }
     if (n < N) {
         if (m0 < M) epi_store4<OutT>(ep, C, m0, n, acc0, N);
         if (m0 + 16 < M) epi_store4<OutT>(ep, C, m0 + 16, n, acc1, N);
@@ -1453,7 +1529,13 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         ep.mul_mode = e->mul_aux ? e->mul_mode : EMO_MUL_NONE; ep.mul_scale = e->mul_scale;
         ep.drop = make_drop(e->p_drop, e->seed, e->offset); ep.residual = e->residual;
         has_epi = e->bias || e->act || e->aux_out || ep.mul_mode || ep.drop.thr16 || e->residual;
+        ep.ln_c1 = e->ln_c1; ep.ln_stats_out = e->ln_stats_out; ep.ln_eps = e->ln_eps;
+        ep.rln_x = e->rln_x; ep.rln_stats = e->rln_stats; ep.rln_gamma = e->rln_gamma; ep.rln_beta = e->rln_beta;
+        EMO_CHECK(!e->rln_x || (e->rln_stats && e->rln_gamma && e->rln_beta && !e->act && !ep.drop.thr16 && !ep.mul_mode),
+                  "emo_gemm: rln_x needs rln_stats/gamma/beta and no activation / dropout / mul epilogue");
+        EMO_CHECK(!e->ln_stats_out || e->ln_c1, "emo_gemm: ln_stats_out needs ln_c1");
     }
+    const bool ln_fused = e && (e->ln_c1 || e->rln_x);
     const bool big = dtype_in == EMO_BF16;
     const int variant = big ? gemm_variant() : 0;
     if (big && M <= 32 && !a_trans && !b_trans && (K % 32) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0 &&
@@ -1466,6 +1548,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         EMO_LAUNCH_CHECK();
         return EMO_OK;
     }
+    EMO_CHECK(!ln_fused, "emo_gemm: the LayerNorm-folded epilogue (ln_c1 / rln_x) exists only on the skinny path (bf16, M <= 32, NT, K %% 32 == 0)");
     // v3 (256^2 tile) when the problem fills the chip with 256^2 tiles and N does not waste a tile
     bool use_g3 = false;
     if (big && variant >= 2 && !use_safe_tr() && (K % G3_K) == 0 && M >= 256) {

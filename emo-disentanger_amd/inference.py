@@ -11,6 +11,7 @@ restart at 0 every step, which invalidates any cache: the engine then falls back
 full-window forward.  Host-side sampling helpers keep the reference's NumPy semantics (global RNG,
 F12 nucleus indexing); `sample_on_device` is the batched on-GPU path (emo_sample_nucleus).
 """
+import os
 import time
 
 import numpy as np
@@ -107,6 +108,56 @@ class PerformerDecodeEngine(_EngineBase):
             model.draw_feature_maps()
         self.omegas = [lyr.attention.inner_attention.feature_map.omega.clone() for lyr in model.transformer_decoder.decoder_layers]
         self.S, self.z = [None] * model.n_layer, [None] * model.n_layer
+        # bf16 one-token steps: norm1 / norm2 are folded into the GEMMs around them (2 launches fewer per layer, see emo_hip.h: ln_c1 / rln_*)
+        self.fold = None
+        if self.dt == torch.bfloat16 and n_streams <= 32 and os.environ.get('EMO_DECODE_LN_FOLD', '1') != '0':
+            self._prepare_folds()
+
+    def _prepare_folds(self):
+        """gamma-scaled weights, c1[n] = sum_k gamma_k W[n,k] (of the ROUNDED bf16 product, the one the MFMA sees) and bias + W.beta for every
+        GEMM whose input is a LayerNorm output: linear1 (norm1), the next layer's q/k/v projection and the final logits (norm2).  Built once
+        per engine from the fp32 masters: the engine is a snapshot of the weights, like its omegas."""
+        m, ps = self.model, self.ps
+        D = m.d_model
+
+        def fold(wname, bname, rows, gamma, beta):
+            W = ps.f32(wname, rows)
+            Wg = (W * gamma[None, :]).to(torch.bfloat16).contiguous()
+            return Wg, Wg.float().sum(1).contiguous(), (ps.f32(bname, rows) + W @ beta).contiguous()
+
+        L = m.n_layer
+        pf = [m._layer_prefix(l) for l in range(L)]
+        self.fold = {'ffn1': [fold(pf[l] + 'linear1.weight', pf[l] + 'linear1.bias', None, ps.f32(pf[l] + 'norm1.weight'), ps.f32(pf[l] + 'norm1.bias'))
+                              for l in range(L)],
+                     'qkv': [None] + [fold(pf[l] + 'attention.query_projection.weight', pf[l] + 'attention.query_projection.bias', 3 * D,
+                                           ps.f32(pf[l - 1] + 'norm2.weight'), ps.f32(pf[l - 1] + 'norm2.bias')) for l in range(1, L)],
+                     'out': fold('dec_out_proj.weight', 'dec_out_proj.bias', None, ps.f32(pf[L - 1] + 'norm2.weight'), ps.f32(pf[L - 1] + 'norm2.bias'))}
+        self.stats1 = torch.empty(self.n, 2, device=self.dev, dtype=torch.float32)
+        self.stats2 = torch.empty(self.n, 2, device=self.dev, dtype=torch.float32)
+
+    def _step_folded(self, x, logits_out):
+        """One token per stream, LayerNorms folded: per layer q/k/v GEMM, state update, out-projection, linear1, linear2 (5 launches)."""
+        m, ps, fd = self.model, self.ps, self.fold
+        D, H = m.d_model, m.n_head
+        res = None                                   # (raw tensor, stats, gamma, beta) whose LayerNorm is the current hidden state
+        for l in range(m.n_layer):
+            pfx = m._layer_prefix(l)
+            q = pfx + 'attention.query_projection.'
+            if res is None:
+                qkv = ops.gemm(x, ps.w(q + 'weight', 3 * D), bias=ps.f32(q + 'bias', 3 * D))
+            else:
+                Wg, c1, bb = fd['qkv'][l]
+                qkv = ops.gemm(res[0], Wg, bias=bb, ln_c1=c1, ln_stats_out=self.stats2)
+            attn = ops.favor_decode_step(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], self.omegas[l], self.S[l], self.z[l], H)
+            ow, ob = ps.w(pfx + 'attention.out_projection.weight'), ps.f32(pfx + 'attention.out_projection.bias')
+            x1 = ops.gemm(attn, ow, bias=ob, residual=x) if res is None else ops.gemm(attn, ow, bias=ob, rln=res)
+            Wg, c1, bb = fd['ffn1'][l]
+            f = ops.gemm(x1, Wg, bias=bb, act=ops.ACT_RELU, ln_c1=c1, ln_stats_out=self.stats1)
+            x2 = ops.gemm(f, ps.w(pfx + 'linear2.weight'), bias=ps.f32(pfx + 'linear2.bias'),
+                          rln=(x1, self.stats1, ps.f32(pfx + 'norm1.weight'), ps.f32(pfx + 'norm1.bias')))
+            res = (x2, self.stats2, ps.f32(pfx + 'norm2.weight'), ps.f32(pfx + 'norm2.bias'))
+        Wg, c1, bb = fd['out']
+        return ops.gemm(res[0], Wg, bias=bb, ln_c1=c1, out=logits_out, out_dtype=torch.float32)
 
     @torch.no_grad()
     def prefill(self, tok, seg):
@@ -140,6 +191,14 @@ class PerformerDecodeEngine(_EngineBase):
         m, ps = self.model, self.ps
         D, H = m.d_model, m.n_head
         x = self._embed(tok.view(-1, 1), None if seg is None else seg.view(-1, 1), self.pos, dev_pos)
+        if self.fold is not None:
+            out = self._step_folded(x, logits_out)
+            if dev_pos:
+                if self.pos_auto:
+                    self.pos_dev.add_(1)
+            else:
+                self.pos += 1
+            return out
         for l in range(m.n_layer):
             pfx = m._layer_prefix(l)
             q = pfx + 'attention.query_projection.'

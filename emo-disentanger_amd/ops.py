@@ -49,9 +49,10 @@ def _workspace(kind, device, need):
 
 
 def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumulate=False, bias=None, act=ACT_NONE,
-         aux_out=None, mul_aux=None, mul_mode=MUL_NONE, mul_scale=1.0, p_drop=0.0, seed=0, offset=0, residual=None):
+         aux_out=None, mul_aux=None, mul_mode=MUL_NONE, mul_scale=1.0, p_drop=0.0, seed=0, offset=0, residual=None,
+         ln_c1=None, ln_eps=1e-5, ln_stats_out=None, rln=None):
     """C[M,N] = epilogue(op(A) @ op(B));  a_trans: A stored [K,M];  b_trans=False: B stored [N,K] (nn.Linear),
-    b_trans=True: B stored [K,N] (HF Conv1D)."""
+    b_trans=True: B stored [K,N] (HF Conv1D).  ln_c1 / ln_stats_out / rln: LayerNorm folded around a decode-step GEMM (include/emo_hip.h)."""
     K, M = (A.shape if a_trans else A.shape[::-1])
     Kb, N = (B.shape if b_trans else B.shape[::-1])
     assert K == Kb, 'inner dims differ: %s vs %s' % (tuple(A.shape), tuple(B.shape))
@@ -61,7 +62,10 @@ def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumu
     ws, ws_bytes = None, 0
     if out.dtype == torch.float32 and bias is None and residual is None and aux_out is None and mul_aux is None and act == ACT_NONE and p_drop == 0.0:
         ws, ws_bytes = _workspace('gemm', A.device, lib.emo_gemm_workspace_bytes(M, N, K, dtype_code(A.dtype), dtype_code(out.dtype)))
-    epi = Epilogue(ptr(bias), act, ptr(aux_out), ptr(mul_aux), mul_mode, mul_scale, p_drop, seed, offset, ptr(residual), ptr(ws), ws_bytes)
+    rx, rstats, rgamma, rbeta = rln if rln is not None else (None, None, None, None)     # residual = LayerNorm(rx) from exported statistics
+    assert rx is None or (rx.dtype == out.dtype and _rows(rx) == _rows(out))
+    epi = Epilogue(ptr(bias), act, ptr(aux_out), ptr(mul_aux), mul_mode, mul_scale, p_drop, seed, offset, ptr(residual),
+                   ptr(ln_c1), ln_eps, ptr(ln_stats_out), ptr(rx), ptr(rstats), ptr(rgamma), ptr(rbeta), ptr(ws), ws_bytes)
     for t in (aux_out, mul_aux, residual):
         assert t is None or (t.dtype == out.dtype and _rows(t) == _rows(out))
     assert bias is None or bias.dtype == torch.float32

@@ -60,6 +60,19 @@ typedef struct {
     float p_drop;         /* dropout after the activation; element index = m*N+n */
     uint64_t seed, offset;
     const void* residual; /* NULL or [M,N] (dtype_out, ld=ldc) added last */
+    /* LayerNorm folded around a decode-step GEMM (bf16, M <= 32, NT; any other shape is refused).  With A' = LN(A)*gamma + beta:
+     *   A'.W^T [m][n] = rstd[m] * ((A.(gamma*W)^T)[m][n] - mean[m]*c1[n]) + (beta.W^T)[n],   c1[n] = sum_k gamma[k] W[n][k]
+     * the caller passes B = gamma*W, ln_c1 = c1 and folds beta.W^T into `bias`; mean/rstd of the A rows are computed in-kernel
+     * (biased variance, ln_eps inside the sqrt: nn.LayerNorm) and optionally exported.  rln_*: the residual is LayerNorm(rln_x)
+     * rebuilt from exported statistics (added before bias; needs act = none, no dropout).  Replaces the standalone norm1 / norm2
+     * launches of fast-transformers' TransformerEncoderLayer on the one-token decode path. */
+    const float* ln_c1;       /* NULL or [N] */
+    float ln_eps;
+    float* ln_stats_out;      /* NULL or [M,2] (mean, rstd) of the A rows */
+    const void* rln_x;        /* NULL or [M,N] (dtype_out, ld=ldc): raw tensor whose LayerNorm is the residual */
+    const float* rln_stats;   /* [M,2] (mean, rstd) of the rln_x rows */
+    const float* rln_gamma;   /* [N] */
+    const float* rln_beta;    /* [N] */
     void* workspace;      /* NULL or caller scratch for split-K partial sums (plain fp32-output GEMMs = weight gradients): */
     int64_t workspace_bytes; /* with it the splits are summed in a fixed order by a reduce kernel (deterministic, no atomics);
                               * without it they are fp32 atomics into C.  Size: emo_gemm_workspace_bytes(). */

@@ -157,11 +157,42 @@ def test_gemm_splitk_workspace_stays_inside_its_bounds(splits, monkeypatch):
         guard = 1 << 20
         buf = torch.full((need + guard,), 0x5A, dtype=torch.uint8, device='cuda')
         out = torch.zeros(N, K, device='cuda')
-        epi = Epilogue(None, 0, None, None, 0, 1.0, 0.0, 0, 0, None, ptr(buf), need)
+        epi = Epilogue(mul_scale=1.0, workspace=ptr(buf), workspace_bytes=need)
         check(lib.emo_gemm(ptr(dY), 1, N, ptr(X), 1, K, ptr(out), K, N, K, Mred, code, 0, 0, ctypes.byref(epi), torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         assert bool((buf[need:] == 0x5A).all()), 'workspace overrun'
         _close(out, dY.double().T @ X.double(), dt, mult=1.0 if dt == torch.float32 else 0.3)
+
+
+@pytest.mark.parametrize('M', [1, 7, 32])
+def test_gemm_skinny_layernorm_folding(M):
+    # decode path: y = LN(x) W^T + b and y2 = f W2^T + b2 + LN(x) computed WITHOUT a LayerNorm launch (statistics in-kernel / exported)
+    ops = _ops()
+    K, N = 512, 224
+    x = (_r(M, K, seed=1) * 2.0 + 0.3).to(torch.bfloat16)
+    W = _r(N, K, seed=2, scale=0.05)
+    b, gamma, beta = _r(N, seed=3, scale=0.1), 1.0 + _r(K, seed=4, scale=0.1), _r(K, seed=5, scale=0.1)
+    xd = x.double()
+    mean, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    ln = (xd - mean) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()
+    ref = torch.relu(ln @ W.double().T + b.double())
+    Wg = (W * gamma[None, :]).to(torch.bfloat16).cuda()
+    c1 = Wg.float().sum(1).contiguous()
+    bias = (b + W @ beta).cuda()
+    stats = torch.empty(M, 2, device='cuda')
+    y = ops.gemm(x.cuda(), Wg, bias=bias, act=ops.ACT_RELU, ln_c1=c1, ln_stats_out=stats)
+    _close(y, ref, torch.bfloat16, mult=2)
+    _close(stats[:, 0], mean[:, 0], torch.float32, scale=1.0, mult=10)
+    _close(stats[:, 1], 1.0 / torch.sqrt(var[:, 0] + 1e-5), torch.float32, scale=1.0, mult=10)
+    # second GEMM (K2 = N): residual = LN(x)[:, :N2] rebuilt from the exported statistics (N2 = K so that x has the output's shape)
+    f = _r(M, N, seed=6).to(torch.bfloat16)
+    W2 = _r(K, N, seed=7, scale=0.05).to(torch.bfloat16)
+    b2 = _r(K, seed=8, scale=0.1)
+    ref2 = f.double() @ W2.double().T + b2.double() + ln
+    y2 = ops.gemm(f.cuda(), W2.cuda(), bias=b2.cuda(), rln=(x.cuda(), stats, gamma.cuda(), beta.cuda()))
+    _close(y2, ref2, torch.bfloat16, mult=2)
+    with pytest.raises(Exception, match='skinny'):
+        ops.gemm(_r(64, K, seed=1).to(torch.bfloat16).cuda(), Wg, ln_c1=c1)
 
 
 def test_gemm_bf16_safe_and_tr_paths_agree(monkeypatch):
