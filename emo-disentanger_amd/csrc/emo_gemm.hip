@@ -838,71 +838,90 @@ static void dispatch_g3(bool akc, bool bkc, dim3 grid, hipStream_t st, const bf1
 // One wave per 16 output columns, the whole K loop in registers: weight rows (nn.Linear [N,K]) and the M
 // activation rows are fetched as MFMA fragments straight from global memory (16 B per lane, no LDS —
 // the guide's rule for M <= 16 GEMV-like shapes), 4 K-steps of loads in flight.
-template <typename OutT>
-__global__ __launch_bounds__(256) void gemm_bf16_skinny_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+template <typename OutT, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_bf16_skinny_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                                OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, EpiParams ep) {
-    // block = 16 output columns; its 4 waves split the K range (shorter dependent chains, 4x the loads in flight) and
+    // block = 16 output columns; its NW waves split the K range (shorter dependent chains, NW x the loads in flight) and
     // combine through LDS; wave 0 runs the fused epilogue.
+    //
+    // Operand path: an MFMA fragment wants lane -> (row l&15, 16-B k-chunk l>>4), i.e. the 16 lanes of a quarter wave in 16 DIFFERENT rows;
+    // read straight from global that is 16 cache-line tag look-ups per quarter wave and the texture path delivers ~16 B/clk: the kernel
+    // time was linear in K (r01: 3.8 / 5.1 / 8.1 / 13.6 us at K = 512 / 1024 / 2048 / 4096, whatever N).  Each wave therefore streams its
+    // [32 + 16 rows] x 128-k chunk with row-contiguous 16-B loads (a quarter wave = one 256-B row), parks it in a private LDS tile (row
+    // stride 144 bf16 = 8 mod 16 dwords: conflict-free ds_read_b128) and takes the fragments from there; the next chunk's loads are in
+    // flight during the MFMAs.
     //
     // LayerNorm folding (decode step: a standalone LN launch on 32 rows costs as much as this whole GEMM).  For A' = LN(A) * gamma + beta:
     //   A'.W^T [m][n] = rstd[m] * ( (A.(gamma*W)^T)[m][n] - mean[m] * c1[n] ) + (beta.W^T)[n],   c1[n] = sum_k gamma_k W[n][k]
     // so the kernel multiplies the RAW rows by the gamma-scaled weights (prepared once by the caller, like c1 and the folded bias), gets
     // mean / rstd of its A rows from the fragments it loads anyway, and applies them in the epilogue (ep.ln_c1).  A residual that is itself
     // a LayerNorm output is rebuilt from the raw tensor and the statistics an earlier kernel exported (ep.rln_*, ep.ln_stats_out).
-    __shared__ f32x4 red[3][2][64];
-    __shared__ float st[4][2][16][2];
+    constexpr int LDT = 144, TROWS = 48;                    // tile rows 0..31: A, 32..47: B
+    extern __shared__ __attribute__((aligned(16))) char skinny_smem[];
+    bf16_t* tile = (bf16_t*)skinny_smem + (threadIdx.x >> 6) * (TROWS * LDT);
+    f32x4 (*red)[2][64] = (f32x4 (*)[2][64])(skinny_smem + (size_t)NW * TROWS * LDT * sizeof(bf16_t));
+    float (*st)[2][16][2] = (float (*)[2][16][2])((char*)red + sizeof(f32x4) * (NW - 1) * 2 * 64);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n0 = (int64_t)blockIdx.x * 16;
-    int64_t nb = n0 + (lane & 15);
-    if (nb > N - 1) nb = N - 1;
-    int64_t m_lo = lane & 15, m_hi = 16 + (lane & 15);
-    if (m_lo > M - 1) m_lo = M - 1;
-    if (m_hi > M - 1) m_hi = M - 1;
-    const int64_t kq = ((K / 32 + 3) / 4) * 32;            // K slice per wave (multiple of 32)
+    const int64_t kq = ((K / 32 + NW - 1) / NW) * 32;      // K slice per wave (multiple of 32)
     const int64_t kb = wave * kq;
     int64_t ke = kb + kq;
     if (ke > K) ke = K;
-    const bf16_t* pb = B + nb * ldb + (lane >> 4) * 8;
-    const bf16_t* pa0 = A + m_lo * lda + (lane >> 4) * 8;
-    const bf16_t* pa1 = A + m_hi * lda + (lane >> 4) * 8;
+    // loader mapping: item = lane + 64 j -> (row = item / 16, 16-B chunk = item % 16); A: j < 8 (32 rows), B: j < 4 (16 rows)
+    const int lrow = lane >> 4, lch = lane & 15;
+    const bf16_t* ga[8];
+    const bf16_t* gb[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int64_t m = lrow + 4 * j;
+        if (m > M - 1) m = M - 1;
+        ga[j] = A + m * lda + lch * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int64_t nn = n0 + lrow + 4 * j;
+        if (nn > N - 1) nn = N - 1;
+        gb[j] = B + nn * ldb + lch * 8;
+    }
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const bool ln = ep.ln_c1 != nullptr;
-    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;        // sum / sum of squares of this lane's slices of rows m_lo / m_hi
-    int64_t k = kb;
-    for (; k + 128 <= ke; k += 128) {
-        bf16x8 fb[4], fa0[4], fa1[4];
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;        // sum / sum of squares of this lane's slices of rows (lane&15) / 16 + (lane&15)
+    bf16x8 ra[8], rb[4];
+    const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    auto fetch = [&](int64_t k) {
+        const bool ok = k + lch * 8 < ke;                   // chunk tail (ke - k < 128): the missing k columns read as zeros
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ra[j] = ok ? *(const bf16x8*)(ga[j] + k) : zero8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rb[j] = ok ? *(const bf16x8*)(gb[j] + k) : zero8;
+    };
+    if (kb < ke) fetch(kb);
+    for (int64_t k = kb; k < ke; k += 128) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *(bf16x8*)(tile + (lrow + 4 * j) * LDT + lch * 8) = ra[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(bf16x8*)(tile + (32 + lrow + 4 * j) * LDT + lch * 8) = rb[j];
+        if (k + 128 < ke) fetch(k + 128);                   // in flight during this chunk's MFMAs
+        __builtin_amdgcn_wave_barrier();                    // wave-private tile: LDS operations of one wave complete in program order
+        const int steps = (int)(((ke - k) < 128 ? (ke - k) : 128) / 32);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            fb[u] = *(const bf16x8*)(pb + k + u * 32);
-            fa0[u] = *(const bf16x8*)(pa0 + k + u * 32);
-            fa1[u] = *(const bf16x8*)(pa1 + k + u * 32);
-        }
-        if (ln) {
+            if (u < steps) {
+                const bf16x8 fb = *(const bf16x8*)(tile + (32 + (lane & 15)) * LDT + u * 32 + (lane >> 4) * 8);
+                const bf16x8 fa0 = *(const bf16x8*)(tile + (lane & 15) * LDT + u * 32 + (lane >> 4) * 8);
+                const bf16x8 fa1 = *(const bf16x8*)(tile + (16 + (lane & 15)) * LDT + u * 32 + (lane >> 4) * 8);
+                if (ln) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float a = (float)fa0[u][e], b = (float)fa1[u][e];
-                    s0 += a; q0 += a * a; s1 += b; q1 += b * b;
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = (float)fa0[e], y = (float)fa1[e];
+                        s0 += x; q0 += x * x; s1 += y; q1 += y * y;
+                    }
                 }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[u], fa0[u], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[u], fa1[u], acc1, 0, 0, 0);
-        }
-    }
-    for (; k < ke; k += 32) {
-        bf16x8 fb = *(const bf16x8*)(pb + k), fa0 = *(const bf16x8*)(pa0 + k), fa1 = *(const bf16x8*)(pa1 + k);
-        if (ln) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float a = (float)fa0[e], b = (float)fa1[e];
-                s0 += a; q0 += a * a; s1 += b; q1 += b * b;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa1, acc1, 0, 0, 0);
             }
         }
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa1, acc1, 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();
     }
     if (ln) {                                                // the 4 lane groups hold different k slices of the same row
         s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
@@ -915,7 +934,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_skinny_kernel(const bf16_t* __r
     __syncthreads();
     if (wave > 0) return;
 #pragma unroll
-    for (int w = 0; w < 3; ++w) { acc0 += red[w][0][lane]; acc1 += red[w][1][lane]; }
+    for (int w = 0; w < NW - 1; ++w) { acc0 += red[w][0][lane]; acc1 += red[w][1][lane]; }
     const int64_t n = n0 + (lane >> 4) * 4;
     const int64_t m0 = lane & 15;
     if (ln) {
@@ -923,7 +942,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_skinny_kernel(const bf16_t* __r
         const float invK = 1.f / (float)K;
         float su = 0.f, sq = 0.f, tu = 0.f, tq = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { su += st[w][0][r][0]; sq += st[w][0][r][1]; tu += st[w][1][r][0]; tq += st[w][1][r][1]; }
+        for (int w = 0; w < NW; ++w) { su += st[w][0][r][0]; sq += st[w][0][r][1]; tu += st[w][1][r][0]; tq += st[w][1][r][1]; }
         const float mean0 = su * invK, mean1 = tu * invK;
         const float rstd0 = rsqrtf(fmaxf(sq * invK - mean0 * mean0, 0.f) + ep.ln_eps), rstd1 = rsqrtf(fmaxf(tq * invK - mean1 * mean1, 0.f) + ep.ln_eps);
 #pragma unroll
@@ -1541,10 +1560,18 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     if (big && M <= 32 && !a_trans && !b_trans && (K % 32) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0 &&
         !accumulate && getenv("EMO_GEMM_NO_SKINNY") == nullptr) {
         dim3 g((unsigned)cdiv64(N, 16));
-        if (dtype_out == EMO_F32)
-            hipLaunchKernelGGL(gemm_bf16_skinny_kernel<float>, g, dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (float*)C, M, N, K, ep);
-        else
-            hipLaunchKernelGGL(gemm_bf16_skinny_kernel<bf16_t>, g, dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, M, N, K, ep);
+        const int nw = K >= 1024 ? 8 : 4;
+#define SKINNY_LAUNCH(OutT, NWv)                                                                                                            \
+    do {                                                                                                                                    \
+        constexpr size_t lds_ = (size_t)NWv * 48 * 144 * 2 + sizeof(f32x4) * (NWv - 1) * 2 * 64 + sizeof(float) * NWv * 2 * 16 * 2;          \
+        auto kfn = gemm_bf16_skinny_kernel<OutT, NWv>;                                                                                      \
+        static bool attr_ = false;                                                                                                          \
+        if (!attr_) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); attr_ = true; }   \
+        hipLaunchKernelGGL(kfn, g, dim3(64 * NWv), lds_, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (OutT*)C, M, N, K, ep);          \
+    } while (0)
+        if (dtype_out == EMO_F32) { if (nw == 8) SKINNY_LAUNCH(float, 8); else SKINNY_LAUNCH(float, 4); }
+        else { if (nw == 8) SKINNY_LAUNCH(bf16_t, 8); else SKINNY_LAUNCH(bf16_t, 4); }
+#undef SKINNY_LAUNCH
         EMO_LAUNCH_CHECK();
         return EMO_OK;
     }
