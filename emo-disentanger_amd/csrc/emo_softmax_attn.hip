@@ -26,17 +26,43 @@ __device__ __forceinline__ void rows_dot(float* Dv, const CT* __restrict__ a, co
 }
 
 // =============================================================================================== forward
+// fragment of an LDS image [rows][ld] (k contiguous) in the PERMUTED k order of the score registers: a lane that owns S[j][t] for
+// j = jt*16 + (l>>4)*4 + r (r = 0..3) feeds P straight from registers into the next MFMA if the other operand is read as
+//   bf16: step s (32 k):  e = 0..7  <->  k = (2s + e/4)*16 + (l>>4)*4 + e%4          (two 8-B reads)
+//   f32 : step (jt, r)    <->  k = jt*16 + (l>>4)*4 + r                              (one 4-B read)
+// (the contraction index order is free as long as both operands agree), so the probabilities never go through LDS.
+template <typename CT>
+__device__ __forceinline__ typename Img<CT>::V load_perm(const CT* img, int ld, int row0, int step, int lane) {
+    const CT* p = img + (row0 + (lane & 15)) * ld + (lane >> 4) * 4;
+    if constexpr (sizeof(CT) == 2) {
+        const bf16x4 lo = *(const bf16x4*)(p + (2 * step) * 16), hi = *(const bf16x4*)(p + (2 * step + 1) * 16);
+        return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    } else {
+        return p[(step >> 2) * 16 + (step & 3)];
+    }
+}
+// the matching register operand built from s[jt][r]
+template <typename CT>
+__device__ __forceinline__ typename Img<CT>::V reg_perm(const float (&s)[4][4], int step) {
+    if constexpr (sizeof(CT) == 2) {
+        return (bf16x8){(bf16_t)s[2 * step][0], (bf16_t)s[2 * step][1], (bf16_t)s[2 * step][2], (bf16_t)s[2 * step][3],
+                        (bf16_t)s[2 * step + 1][0], (bf16_t)s[2 * step + 1][1], (bf16_t)s[2 * step + 1][2], (bf16_t)s[2 * step + 1][3]};
+    } else {
+        return s[step >> 2][step & 3];
+    }
+}
+template <typename CT> struct SaK { static constexpr int NS64 = 64 / Img<CT>::KSTEP; };   // MFMA steps over a 64-wide k range
+
 template <typename CT, int DH>
 __global__ __launch_bounds__(256) void sattn_fwd_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
                                                         CT* __restrict__ out, int64_t ld_out, float* __restrict__ lse_g, int64_t T, int64_t H,
                                                         DropCtx drop) {
     typedef SaDims<CT, DH> D;
-    constexpr int LDX = D::LDX, LDC = D::LDC, DHP = D::DHP, ND = DH / 16;
+    constexpr int LDX = D::LDX, LDC = D::LDC, DHP = D::DHP, ND = DH / 16, NQ = DHP / Img<CT>::KSTEP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     CT* Qi = (CT*)smem;          // [64][LDX]
     CT* Ki = Qi + 64 * LDX;      // [64][LDX]
     CT* VT = Ki + 64 * LDX;      // [DH][LDC]
-    CT* Pi = VT + DH * LDC;      // [64][LDC]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t qt = (int64_t)gridDim.x - 1 - blockIdx.x;   // longest tiles first
     const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
@@ -45,8 +71,19 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const CT* __restrict__ q
     const CT* kb = k + (b * T) * ld + h * DH;
     const CT* vb = v + (b * T) * ld + h * DH;
     const int qvalid = (int)((T - q0) < 64 ? (T - q0) : 64);
+    RowPrefetch<CT, DH, DHP, 64, 256> pk;
+    RowPrefetch<CT, DH, DHP, 64, 256, true> pv;              // only stored transposed
+    {
+        const int kv0 = (int)(T < 64 ? T : 64);
+        pk.load(kb, ld, kv0, tid);
+        pv.load(vb, ld, kv0, tid);
+    }
     load_rows<CT, DH, DHP>(Qi, LDX, qb + q0 * ld, ld, 64, qvalid, tid);
-    const float sqrt_dh = sqrtf((float)DH);
+    __syncthreads();
+    typename Img<CT>::V qf[NQ];                              // this wave's 16 query rows stay in registers for the whole sweep
+#pragma unroll
+    for (int kk = 0; kk < NQ; ++kk) qf[kk] = Img<CT>::load(Qi, LDX, wave * 16, kk * Img<CT>::KSTEP, lane);
+    const float sqrt_dh = sqrtf((float)DH), rsqrt_dh = 1.f / sqrt_dh;
     const int tl = wave * 16 + (lane & 15);        // local query row
     const int64_t tg = q0 + tl;                    // global query index
     float m_run = -INFINITY, l_run = 0.f;
@@ -56,21 +93,30 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const CT* __restrict__ q
 
     for (int64_t kt = 0; kt <= qt; ++kt) {
         const int64_t k0 = kt * 64;
-        const int kvalid = (int)((T - k0) < 64 ? (T - k0) : 64);
-        __syncthreads();
-        load_rows<CT, DH, DHP>(Ki, LDX, kb + k0 * ld, ld, 64, kvalid, tid);
-        load_rows_T<CT, DH>(VT, LDC, vb + k0 * ld, ld, 64, kvalid, tid);
+        __syncthreads();                                     // every wave is done with the previous K / V images
+        pk.store_rows(Ki, LDX, tid);
+        pv.store_T(VT, LDC, tid);
+        if (kt < qt) {                                       // next key tile stays in flight during this tile's math
+            const int64_t kn = k0 + 64;
+            const int nv = (int)((T - kn) < 64 ? (T - kn) : 64);
+            pk.load(kb + kn * ld, ld, nv, tid);
+            pv.load(vb + kn * ld, ld, nv, tid);
+        }
         __syncthreads();
         float s[4][4];
         float mx = -INFINITY;
+        const bool diag = kt == qt;
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            mm16<CT>(acc, Ki, LDX, jt * 16, Qi, LDX, wave * 16, DHP, lane);
+            if (!(diag && jt > wave)) {                      // key sub-tile entirely above this wave's rows: masked anyway
+#pragma unroll
+                for (int kk = 0; kk < NQ; ++kk) acc = Img<CT>::mma(Img<CT>::load(Ki, LDX, jt * 16, kk * Img<CT>::KSTEP, lane), qf[kk], acc);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t jg = k0 + jt * 16 + (lane >> 4) * 4 + r;
-                float val = acc[r] / sqrt_dh;
+                float val = sizeof(CT) == 2 ? acc[r] * rsqrt_dh : acc[r] / sqrt_dh;     // parity mode keeps the reference's division
                 if (jg > tg || jg >= T) val = -INFINITY;
                 s[jt][r] = val;
                 mx = fmaxf(mx, val);
@@ -84,17 +130,14 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const CT* __restrict__ q
         float psum = 0.f;
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
-            float p[4];
+            float dm[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop.thr16) drop_mult4(drop, (uint64_t)((bh * T + tg) * T + k0 + jt * 16 + (lane >> 4) * 4), dm);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                p[r] = expf(s[jt][r] - m_new);
-                psum += p[r];
-                if (drop.thr16) {
-                    const int64_t jg = k0 + jt * 16 + (lane >> 4) * 4 + r;
-                    p[r] *= drop_mult(drop, (uint64_t)((bh * T + tg) * T + jg));
-                }
+                const float p = Img<CT>::ex(s[jt][r] - m_new);
+                psum += p;
+                s[jt][r] = p * dm[r];
             }
-            Img<CT>::store4(Pi + tl * LDC + jt * 16 + (lane >> 4) * 4, p[0], p[1], p[2], p[3]);
         }
         psum += __shfl_xor(psum, 16, 64);
         psum += __shfl_xor(psum, 32, 64);
@@ -102,9 +145,13 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const CT* __restrict__ q
         m_run = m_new;
 #pragma unroll
         for (int i = 0; i < ND; ++i) oacc[i] *= alpha;
-        __syncthreads();
+        // O^T[d][t] += sum_j V^T[d][j] P[t][j] : P from registers, V^T read in the same permuted k order
 #pragma unroll
-        for (int i = 0; i < ND; ++i) mm16<CT>(oacc[i], VT, LDC, i * 16, Pi, LDC, wave * 16, 64, lane);
+        for (int st = 0; st < SaK<CT>::NS64; ++st) {
+            const typename Img<CT>::V pf = reg_perm<CT>(s, st);
+#pragma unroll
+            for (int i = 0; i < ND; ++i) oacc[i] = Img<CT>::mma(load_perm<CT>(VT, LDC, i * 16, st, lane), pf, oacc[i]);
+        }
     }
     if (tg < T) {
         const float inv = 1.f / l_run;
@@ -119,21 +166,21 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const CT* __restrict__ q
 }
 
 // =============================================================================================== backward: dQ (per query tile)
+// Also exports delta[t] = dO[t].O[t] (one value per query row) for the dK/dV pass, which used to recompute it for every (key tile, query tile) pair.
 template <typename CT, int DH>
 __global__ __launch_bounds__(256) void sattn_bwd_dq_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
                                                            const CT* __restrict__ out, const CT* __restrict__ dout, int64_t ld_out,
-                                                           const float* __restrict__ lse_g, CT* __restrict__ dq, int64_t ld_d, int64_t T, int64_t H,
-                                                           DropCtx drop) {
+                                                           const float* __restrict__ lse_g, float* __restrict__ delta_g, CT* __restrict__ dq, int64_t ld_d,
+                                                           int64_t T, int64_t H, DropCtx drop) {
     typedef SaDims<CT, DH> D;
-    constexpr int LDX = D::LDX, LDC = D::LDC, DHP = D::DHP, ND = DH / 16;
+    constexpr int LDX = D::LDX, LDC = D::LDC, DHP = D::DHP, ND = DH / 16, NQ = DHP / Img<CT>::KSTEP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    CT* Qi = (CT*)smem;           // [64][LDX]
+    CT* Qi = (CT*)smem;           // [64][LDX]  (only to build the register fragments)
     CT* dOi = Qi + 64 * LDX;      // [64][LDX]
     CT* Ki = dOi + 64 * LDX;      // [64][LDX]
     CT* Vi = Ki + 64 * LDX;       // [64][LDX]
     CT* KT = Vi + 64 * LDX;       // [DH][LDC]
-    CT* dSi = KT + DH * LDC;      // [64][LDC]
-    float* Dv = (float*)(dSi + 64 * LDC);   // [64]
+    float* Dv = (float*)(KT + DH * LDC);   // [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t qt = (int64_t)gridDim.x - 1 - blockIdx.x;
     const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
@@ -144,45 +191,72 @@ __global__ __launch_bounds__(256) void sattn_bwd_dq_kernel(const CT* __restrict_
     const CT* ob = out + (b * T) * ld_out + h * DH;
     const CT* gb = dout + (b * T) * ld_out + h * DH;
     const int qvalid = (int)((T - q0) < 64 ? (T - q0) : 64);
+    RowPrefetch<CT, DH, DHP, 64, 256> pk, pv;
+    RowPrefetch<CT, DH, DHP, 64, 256, true> pkT;
+    {
+        const int kv0 = (int)(T < 64 ? T : 64);
+        pk.load(kb, ld, kv0, tid); pv.load(vb, ld, kv0, tid); pkT.load(kb, ld, kv0, tid);
+    }
     load_rows<CT, DH, DHP>(Qi, LDX, qb + q0 * ld, ld, 64, qvalid, tid);
     load_rows<CT, DH, DHP>(dOi, LDX, gb + q0 * ld_out, ld_out, 64, qvalid, tid);
     rows_dot<CT, DH>(Dv, gb + q0 * ld_out, ob + q0 * ld_out, ld_out, qvalid, tid);
     __syncthreads();
-    const float sqrt_dh = sqrtf((float)DH);
+    typename Img<CT>::V qf[NQ], gf[NQ];
+#pragma unroll
+    for (int kk = 0; kk < NQ; ++kk) {
+        qf[kk] = Img<CT>::load(Qi, LDX, wave * 16, kk * Img<CT>::KSTEP, lane);
+        gf[kk] = Img<CT>::load(dOi, LDX, wave * 16, kk * Img<CT>::KSTEP, lane);
+    }
+    const float sqrt_dh = sqrtf((float)DH), rsqrt_dh = 1.f / sqrt_dh;
     const int tl = wave * 16 + (lane & 15);
     const int64_t tg = q0 + tl;
     const float lse = tg < T ? lse_g[bh * T + tg] : 0.f;
     const float Dt = Dv[tl];
+    if (delta_g && tid < qvalid) delta_g[bh * T + q0 + tid] = Dv[tid];
     f32x4 dqacc[ND];
 #pragma unroll
     for (int i = 0; i < ND; ++i) dqacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int64_t kt = 0; kt <= qt; ++kt) {
         const int64_t k0 = kt * 64;
-        const int kvalid = (int)((T - k0) < 64 ? (T - k0) : 64);
         __syncthreads();
-        load_rows<CT, DH, DHP>(Ki, LDX, kb + k0 * ld, ld, 64, kvalid, tid);
-        load_rows<CT, DH, DHP>(Vi, LDX, vb + k0 * ld, ld, 64, kvalid, tid);
-        load_rows_T<CT, DH>(KT, LDC, kb + k0 * ld, ld, 64, kvalid, tid);
+        pk.store_rows(Ki, LDX, tid);
+        pv.store_rows(Vi, LDX, tid);
+        pkT.store_T(KT, LDC, tid);
+        if (kt < qt) {
+            const int64_t kn = k0 + 64;
+            const int nv = (int)((T - kn) < 64 ? (T - kn) : 64);
+            pk.load(kb + kn * ld, ld, nv, tid); pv.load(vb + kn * ld, ld, nv, tid); pkT.load(kb + kn * ld, ld, nv, tid);
+        }
         __syncthreads();
+        const bool diag = kt == qt;
+        float ds[4][4];
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
             f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            mm16<CT>(sa, Ki, LDX, jt * 16, Qi, LDX, wave * 16, DHP, lane);
-            mm16<CT>(dp, Vi, LDX, jt * 16, dOi, LDX, wave * 16, DHP, lane);
-            float ds[4];
+            if (!(diag && jt > wave)) {
+#pragma unroll
+                for (int kk = 0; kk < NQ; ++kk) {
+                    sa = Img<CT>::mma(Img<CT>::load(Ki, LDX, jt * 16, kk * Img<CT>::KSTEP, lane), qf[kk], sa);
+                    dp = Img<CT>::mma(Img<CT>::load(Vi, LDX, jt * 16, kk * Img<CT>::KSTEP, lane), gf[kk], dp);
+                }
+            }
+            float dm[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop.thr16) drop_mult4(drop, (uint64_t)((bh * T + tg) * T + k0 + jt * 16 + (lane >> 4) * 4), dm);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t jg = k0 + jt * 16 + (lane >> 4) * 4 + r;
-                float p = 0.f, dpe = dp[r];
-                if (jg <= tg && jg < T && tg < T) p = expf(sa[r] / sqrt_dh - lse);
-                if (drop.thr16) dpe *= drop_mult(drop, (uint64_t)((bh * T + tg) * T + jg));
-                ds[r] = p * (dpe - Dt);
+                float p = 0.f;
+                if (jg <= tg && jg < T && tg < T) p = Img<CT>::ex((sizeof(CT) == 2 ? sa[r] * rsqrt_dh : sa[r] / sqrt_dh) - lse);
+                ds[jt][r] = p * (dp[r] * dm[r] - Dt);
             }
-            Img<CT>::store4(dSi + tl * LDC + jt * 16 + (lane >> 4) * 4, ds[0], ds[1], ds[2], ds[3]);
         }
-        __syncthreads();
+        // dQ^T[d][t] += sum_j K^T[d][j] dS[t][j] : dS from registers
 #pragma unroll
-        for (int i = 0; i < ND; ++i) mm16<CT>(dqacc[i], KT, LDC, i * 16, dSi, LDC, wave * 16, 64, lane);
+        for (int st = 0; st < SaK<CT>::NS64; ++st) {
+            const typename Img<CT>::V df = reg_perm<CT>(ds, st);
+#pragma unroll
+            for (int i = 0; i < ND; ++i) dqacc[i] = Img<CT>::mma(load_perm<CT>(KT, LDC, i * 16, st, lane), df, dqacc[i]);
+        }
     }
     if (tg < T) {
         CT* db = dq + (b * T + tg) * ld_d + h * DH;
@@ -198,21 +272,19 @@ __global__ __launch_bounds__(256) void sattn_bwd_dq_kernel(const CT* __restrict_
 // =============================================================================================== backward: dK, dV (per key tile)
 template <typename CT, int DH>
 __global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
-                                                            const CT* __restrict__ out, const CT* __restrict__ dout, int64_t ld_out,
-                                                            const float* __restrict__ lse_g, CT* __restrict__ dk, CT* __restrict__ dv, int64_t ld_d,
+                                                            const CT* __restrict__ dout, int64_t ld_out, const float* __restrict__ lse_g,
+                                                            const float* __restrict__ delta_g, CT* __restrict__ dk, CT* __restrict__ dv, int64_t ld_d,
                                                             int64_t T, int64_t H, DropCtx drop) {
     typedef SaDims<CT, DH> D;
-    constexpr int LDX = D::LDX, LDC = D::LDC, DHP = D::DHP, ND = DH / 16;
+    constexpr int LDX = D::LDX, LDC = D::LDC, DHP = D::DHP, ND = DH / 16, NQ = DHP / Img<CT>::KSTEP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    CT* Ki = (CT*)smem;           // [64][LDX]
+    CT* Ki = (CT*)smem;           // [64][LDX]  (Ki / Vi only to build the register fragments)
     CT* Vi = Ki + 64 * LDX;       // [64][LDX]
     CT* Qi = Vi + 64 * LDX;       // [64][LDX]
     CT* dOi = Qi + 64 * LDX;      // [64][LDX]
     CT* QT = dOi + 64 * LDX;      // [DH][LDC]
     CT* dOT = QT + DH * LDC;      // [DH][LDC]
-    CT* PdT = dOT + DH * LDC;     // [64][LDC]
-    CT* dST = PdT + 64 * LDC;     // [64][LDC]
-    float* Dv = (float*)(dST + 64 * LDC);   // [64]
+    float* Dv = (float*)(dOT + DH * LDC);   // [64]
     float* Lv = Dv + 64;                    // [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t kt = blockIdx.x;
@@ -222,12 +294,32 @@ __global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const CT* __restrict
     const CT* qb = q + (b * T) * ld + h * DH;
     const CT* kb = k + (b * T) * ld + h * DH;
     const CT* vb = v + (b * T) * ld + h * DH;
-    const CT* ob = out + (b * T) * ld_out + h * DH;
     const CT* gb = dout + (b * T) * ld_out + h * DH;
     const int kvalid = (int)((T - k0) < 64 ? (T - k0) : 64);
+    RowPrefetch<CT, DH, DHP, 64, 256> pq, pg;
+    RowPrefetch<CT, DH, DHP, 64, 256, true> pqT, pgT;
+    float pl = 0.f, pd_ = 0.f;                                // lse / delta of row q0 + tid (tid < 64)
+    auto fetch = [&](int64_t q0n) {
+        const int nv = (int)((T - q0n) < 64 ? (T - q0n) : 64);
+        pq.load(qb + q0n * ld, ld, nv, tid); pqT.load(qb + q0n * ld, ld, nv, tid);
+        pg.load(gb + q0n * ld_out, ld_out, nv, tid); pgT.load(gb + q0n * ld_out, ld_out, nv, tid);
+        if (tid < 64) {
+            const bool ok = q0n + tid < T;
+            pl = ok ? lse_g[bh * T + q0n + tid] : 0.f;
+            pd_ = ok ? delta_g[bh * T + q0n + tid] : 0.f;
+        }
+    };
+    fetch(k0);                                                // first query tile = the diagonal one
     load_rows<CT, DH, DHP>(Ki, LDX, kb + k0 * ld, ld, 64, kvalid, tid);
     load_rows<CT, DH, DHP>(Vi, LDX, vb + k0 * ld, ld, 64, kvalid, tid);
-    const float sqrt_dh = sqrtf((float)DH);
+    __syncthreads();
+    typename Img<CT>::V kf[NQ], vf[NQ];
+#pragma unroll
+    for (int kk = 0; kk < NQ; ++kk) {
+        kf[kk] = Img<CT>::load(Ki, LDX, wave * 16, kk * Img<CT>::KSTEP, lane);
+        vf[kk] = Img<CT>::load(Vi, LDX, wave * 16, kk * Img<CT>::KSTEP, lane);
+    }
+    const float sqrt_dh = sqrtf((float)DH), rsqrt_dh = 1.f / sqrt_dh;
     const int jl = wave * 16 + (lane & 15);
     const int64_t jg = k0 + jl;
     f32x4 dkacc[ND], dvacc[ND];
@@ -235,39 +327,46 @@ __global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const CT* __restrict
     for (int i = 0; i < ND; ++i) { dkacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dvacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     for (int64_t qt = kt; qt < nqt; ++qt) {
         const int64_t q0 = qt * 64;
-        const int qvalid = (int)((T - q0) < 64 ? (T - q0) : 64);
         __syncthreads();
-        load_rows<CT, DH, DHP>(Qi, LDX, qb + q0 * ld, ld, 64, qvalid, tid);
-        load_rows<CT, DH, DHP>(dOi, LDX, gb + q0 * ld_out, ld_out, 64, qvalid, tid);
-        load_rows_T<CT, DH>(QT, LDC, qb + q0 * ld, ld, 64, qvalid, tid);
-        load_rows_T<CT, DH>(dOT, LDC, gb + q0 * ld_out, ld_out, 64, qvalid, tid);
-        rows_dot<CT, DH>(Dv, gb + q0 * ld_out, ob + q0 * ld_out, ld_out, qvalid, tid);
-        if (tid < 64) Lv[tid] = (q0 + tid) < T ? lse_g[bh * T + q0 + tid] : 0.f;
+        pq.store_rows(Qi, LDX, tid);
+        pg.store_rows(dOi, LDX, tid);
+        pqT.store_T(QT, LDC, tid);
+        pgT.store_T(dOT, LDC, tid);
+        if (tid < 64) { Lv[tid] = pl; Dv[tid] = pd_; }
+        if (qt + 1 < nqt) fetch(q0 + 64);
         __syncthreads();
+        const bool diag = qt == kt;
+        float pd[4][4], ds[4][4];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            mm16<CT>(sa, Qi, LDX, tt * 16, Ki, LDX, wave * 16, DHP, lane);
-            mm16<CT>(dp, dOi, LDX, tt * 16, Vi, LDX, wave * 16, DHP, lane);
-            float pd[4], ds[4];
+            if (!(diag && tt < wave)) {                       // query sub-tile entirely before this wave's keys: masked anyway
+#pragma unroll
+                for (int kk = 0; kk < NQ; ++kk) {
+                    sa = Img<CT>::mma(Img<CT>::load(Qi, LDX, tt * 16, kk * Img<CT>::KSTEP, lane), kf[kk], sa);
+                    dp = Img<CT>::mma(Img<CT>::load(dOi, LDX, tt * 16, kk * Img<CT>::KSTEP, lane), vf[kk], dp);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int tl = tt * 16 + (lane >> 4) * 4 + r;
                 const int64_t tg = q0 + tl;
                 float p = 0.f, mult = 1.f;
-                if (jg <= tg && tg < T && jg < T) p = expf(sa[r] / sqrt_dh - Lv[tl]);
+                if (jg <= tg && tg < T && jg < T) p = Img<CT>::ex((sizeof(CT) == 2 ? sa[r] * rsqrt_dh : sa[r] / sqrt_dh) - Lv[tl]);
                 if (drop.thr16) mult = drop_mult(drop, (uint64_t)((bh * T + tg) * T + jg));
-                pd[r] = p * mult;
-                ds[r] = p * (dp[r] * mult - Dv[tl]);
+                pd[tt][r] = p * mult;
+                ds[tt][r] = p * (dp[r] * mult - Dv[tl]);
             }
-            Img<CT>::store4(PdT + jl * LDC + tt * 16 + (lane >> 4) * 4, pd[0], pd[1], pd[2], pd[3]);
-            Img<CT>::store4(dST + jl * LDC + tt * 16 + (lane >> 4) * 4, ds[0], ds[1], ds[2], ds[3]);
         }
-        __syncthreads();
+        // dV^T[d][j] += sum_t dO^T[d][t] Pd[t][j] ; dK^T[d][j] += sum_t Q^T[d][t] dS[t][j] : Pd / dS from registers
 #pragma unroll
-        for (int i = 0; i < ND; ++i) {
-            mm16<CT>(dvacc[i], dOT, LDC, i * 16, PdT, LDC, wave * 16, 64, lane);
-            mm16<CT>(dkacc[i], QT, LDC, i * 16, dST, LDC, wave * 16, 64, lane);
+        for (int st = 0; st < SaK<CT>::NS64; ++st) {
+            const typename Img<CT>::V pf = reg_perm<CT>(pd, st), df = reg_perm<CT>(ds, st);
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                dvacc[i] = Img<CT>::mma(load_perm<CT>(dOT, LDC, i * 16, st, lane), pf, dvacc[i]);
+                dkacc[i] = Img<CT>::mma(load_perm<CT>(QT, LDC, i * 16, st, lane), df, dkacc[i]);
+            }
         }
     }
     if (jg < T) {
@@ -330,13 +429,13 @@ __global__ __launch_bounds__(256) void sattn_decode_kernel(const CT* __restrict_
 }
 
 // =============================================================================================== host
-template <typename CT, int DH> static size_t sa_fwd_lds() { typedef SaDims<CT, DH> D; return sizeof(CT) * (size_t)(2 * 64 * D::LDX + DH * D::LDC + 64 * D::LDC); }
-template <typename CT, int DH> static size_t sa_dq_lds() { typedef SaDims<CT, DH> D; return sizeof(CT) * (size_t)(4 * 64 * D::LDX + DH * D::LDC + 64 * D::LDC) + 64 * sizeof(float); }
-template <typename CT, int DH> static size_t sa_dkv_lds() { typedef SaDims<CT, DH> D; return sizeof(CT) * (size_t)(4 * 64 * D::LDX + 2 * DH * D::LDC + 2 * 64 * D::LDC) + 128 * sizeof(float); }
+template <typename CT, int DH> static size_t sa_fwd_lds() { typedef SaDims<CT, DH> D; return sizeof(CT) * (size_t)(2 * 64 * D::LDX + DH * D::LDC); }
+template <typename CT, int DH> static size_t sa_dq_lds() { typedef SaDims<CT, DH> D; return sizeof(CT) * (size_t)(4 * 64 * D::LDX + DH * D::LDC) + 64 * sizeof(float); }
+template <typename CT, int DH> static size_t sa_dkv_lds() { typedef SaDims<CT, DH> D; return sizeof(CT) * (size_t)(4 * 64 * D::LDX + 2 * DH * D::LDC) + 128 * sizeof(float); }
 
 template <typename CT, int DH>
 static int run_sattn(int which, const void* q, const void* k, const void* v, int64_t ld, const void* out, const void* dout, int64_t ld_out, float* lse,
-                     void* dq, void* dk, void* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, DropCtx drop, hipStream_t st) {
+                     float* delta, void* dq, void* dk, void* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, DropCtx drop, hipStream_t st) {
     dim3 grid((unsigned)((T + 63) / 64), (unsigned)(B * H));
     static bool attr = false;
     const size_t lfwd = sa_fwd_lds<CT, DH>(), ldq = sa_dq_lds<CT, DH>(), ldkv = sa_dkv_lds<CT, DH>();
@@ -354,21 +453,21 @@ static int run_sattn(int which, const void* q, const void* k, const void* v, int
                            lse, T, H, drop);
     } else {
         hipLaunchKernelGGL(kdq, grid, dim3(256), ldq, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, (const CT*)out,
-                           (const CT*)dout, ld_out, lse, (CT*)dq, ld_d, T, H, drop);
-        hipLaunchKernelGGL(kdkv, grid, dim3(256), ldkv, st, (const CT*)q, (const CT*)k, (const CT*)v, ld,
-                           (const CT*)out, (const CT*)dout, ld_out, lse, (CT*)dk, (CT*)dv, ld_d, T, H, drop);
+                           (const CT*)dout, ld_out, lse, delta, (CT*)dq, ld_d, T, H, drop);
+        hipLaunchKernelGGL(kdkv, grid, dim3(256), ldkv, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, (const CT*)dout, ld_out, lse, delta, (CT*)dk,
+                           (CT*)dv, ld_d, T, H, drop);
     }
     EMO_LAUNCH_CHECK();
     return EMO_OK;
 }
 
 static int dispatch_sattn(int which, int dtype, int64_t dh, const void* q, const void* k, const void* v, int64_t ld, const void* out, const void* dout,
-                          int64_t ld_out, float* lse, void* dq, void* dk, void* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, DropCtx drop,
-                          hipStream_t st) {
+                          int64_t ld_out, float* lse, float* delta, void* dq, void* dk, void* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H,
+                          DropCtx drop, hipStream_t st) {
 #define SA_CASE(DHv)                                                                                                                      \
     if (dh == DHv) {                                                                                                                      \
-        if (dtype == EMO_BF16) return run_sattn<bf16_t, DHv>(which, q, k, v, ld, out, dout, ld_out, lse, dq, dk, dv, ld_d, B, T, H, drop, st); \
-        return run_sattn<float, DHv>(which, q, k, v, ld, out, dout, ld_out, lse, dq, dk, dv, ld_d, B, T, H, drop, st);                    \
+        if (dtype == EMO_BF16) return run_sattn<bf16_t, DHv>(which, q, k, v, ld, out, dout, ld_out, lse, delta, dq, dk, dv, ld_d, B, T, H, drop, st); \
+        return run_sattn<float, DHv>(which, q, k, v, ld, out, dout, ld_out, lse, delta, dq, dk, dv, ld_d, B, T, H, drop, st);             \
     }
     SA_CASE(64)
     SA_CASE(32)
@@ -392,19 +491,19 @@ extern "C" int emo_softmax_attn_fwd(const void* q, const void* k, const void* v,
     int rc = sattn_check(q, k, v, ld, ld_out, dtype, dh);
     if (rc) return rc;
     EMO_CHECK(out && lse && ((uintptr_t)out & 15) == 0, "emo_softmax_attn_fwd: bad out/lse");
-    return dispatch_sattn(0, dtype, dh, q, k, v, ld, out, nullptr, ld_out, lse, nullptr, nullptr, nullptr, 0, B, T, H, make_drop(p_drop, seed, offset),
+    return dispatch_sattn(0, dtype, dh, q, k, v, ld, out, nullptr, ld_out, lse, nullptr, nullptr, nullptr, nullptr, 0, B, T, H, make_drop(p_drop, seed, offset),
                           (hipStream_t)stream);
 }
 
 extern "C" int emo_softmax_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* out, const void* dout, int64_t ld_out,
-                                    const float* lse, void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H, int64_t dh,
-                                    float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
+                                    const float* lse, float* delta_ws, void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H,
+                                    int64_t dh, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
     int rc = sattn_check(q, k, v, ld, ld_out, dtype, dh);
     if (rc) return rc;
-    EMO_CHECK(out && dout && lse && dq && dk && dv, "emo_softmax_attn_bwd: null pointer");
+    EMO_CHECK(out && dout && lse && delta_ws && dq && dk && dv, "emo_softmax_attn_bwd: null pointer");
     EMO_CHECK(ld_d % 4 == 0 && (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)out | (uintptr_t)dout) & 15) == 0,
               "emo_softmax_attn_bwd: gradients must be 16-B aligned with ld_d %% 4 == 0");
-    return dispatch_sattn(1, dtype, dh, q, k, v, ld, out, dout, ld_out, (float*)lse, dq, dk, dv, ld_d, B, T, H, make_drop(p_drop, seed, offset),
+    return dispatch_sattn(1, dtype, dh, q, k, v, ld, out, dout, ld_out, (float*)lse, delta_ws, dq, dk, dv, ld_d, B, T, H, make_drop(p_drop, seed, offset),
                           (hipStream_t)stream);
 }
 

@@ -210,7 +210,8 @@ def softmax_attn_bwd(q, k, v, out, dout, lse, B, T, H, p_drop=0.0, seed=0, offse
     if dqkv is None:
         dqkv = torch.empty(M, 3 * HD, device=q.device, dtype=q.dtype)
     dq, dk, dv = dqkv[:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:]
-    check(lib.emo_softmax_attn_bwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(out), ptr(dout), HD, ptr(lse), ptr(dq), ptr(dk), ptr(dv), 3 * HD,
+    delta = torch.empty(B, H, T, device=q.device, dtype=torch.float32)          # dO.O per query row, handed from the dQ to the dK/dV pass
+    check(lib.emo_softmax_attn_bwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(out), ptr(dout), HD, ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), 3 * HD,
                                    dtype_code(q.dtype), B, T, H, dh, p_drop, seed, offset, stream()))
     return dq, dk, dv
 

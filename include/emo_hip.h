@@ -162,10 +162,12 @@ int emo_favor_draw_omega(const float* gauss, float* omega, int64_t n_layers, int
 int emo_softmax_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, void* out,
                          int64_t ld_out, float* lse, int dtype, int64_t B, int64_t T, int64_t H,
                          int64_t dh, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream);
+/* delta_ws: caller scratch [B,H,T] fp32 (dO.O per query row: written by the dQ pass, read by the dK/dV pass). */
 int emo_softmax_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* out,
-                         const void* dout, int64_t ld_out, const float* lse, void* dq, void* dk,
-                         void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H,
-                         int64_t dh, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream);
+                         const void* dout, int64_t ld_out, const float* lse, float* delta_ws,
+                         void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T,
+                         int64_t H, int64_t dh, float p_drop, uint64_t seed, uint64_t offset,
+                         emo_stream_t stream);
 /* decode: one query row per stream against a KV cache [n_streams, T_max, H*dh]; lens[s] = valid keys */
 int emo_softmax_attn_decode(const void* q, int64_t ld_q, const void* kcache, const void* vcache,
                             int64_t T_max, const int64_t* lens, void* out, int64_t ld_out, int dtype,
