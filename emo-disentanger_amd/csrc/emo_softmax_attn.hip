@@ -383,27 +383,55 @@ __global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const CT* __restrict
 }
 
 // =============================================================================================== decode (one query per stream)
+// One workgroup per (stream, head).  len = lens[s] + lens_off keys are valid INCLUDING the new token, whose k / v rows (k_new / v_new, may be
+// NULL) the kernel appends to the cache itself at position len - 1 (saves two index_copy launches per layer).  Score pass: dh/VE lanes share
+// a key row (16-B loads, a wave reads 64/(dh/VE) whole rows per instruction), shuffle-reduced; value pass: 16-B loads, 256/(dh/VE) keys in flight.
 template <typename CT>
-__global__ __launch_bounds__(256) void sattn_decode_kernel(const CT* __restrict__ q, int64_t ld_q, const CT* __restrict__ kc, const CT* __restrict__ vc,
-                                                           int64_t T_max, const int64_t* __restrict__ lens, CT* __restrict__ out, int64_t ld_out,
-                                                           int64_t H, int dh) {
-    extern __shared__ float sc[];            // [T_max] scores, then [256] partials
-    __shared__ float qs[128], red[4], part[256];
+__global__ __launch_bounds__(256) void sattn_decode_kernel(const CT* __restrict__ q, int64_t ld_q, CT* __restrict__ kc, CT* __restrict__ vc,
+                                                           int64_t T_max, const int64_t* __restrict__ lens, int64_t lens_off,
+                                                           const CT* __restrict__ k_new, const CT* __restrict__ v_new, int64_t ld_new,
+                                                           CT* __restrict__ out, int64_t ld_out, int64_t H, int dh) {
+    constexpr int VE = 16 / sizeof(CT);
+    extern __shared__ float sc[];            // [T_max] scores
+    __shared__ float qs[128], red[4];
+    __shared__ float part[256 * VE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t sh = blockIdx.x, s = sh / H, h = sh % H;
-    const int64_t len = lens[s];
+    const int64_t len = lens[s] + lens_off;
     const int64_t HD = H * dh;
-    if (tid < dh) qs[tid] = to_f32<CT>(q[s * ld_q + h * dh + tid]);
+    if (tid < dh) {
+        qs[tid] = to_f32<CT>(q[s * ld_q + h * dh + tid]);
+        if (k_new) {
+            kc[(s * T_max + len - 1) * HD + h * dh + tid] = k_new[s * ld_new + h * dh + tid];
+            vc[(s * T_max + len - 1) * HD + h * dh + tid] = v_new[s * ld_new + h * dh + tid];
+        }
+    }
     __syncthreads();
     const float sqrt_dh = sqrtf((float)dh);
+    const int LPR = dh / VE;                 // lanes per key row (power of two: dh in {16,32,64,128})
+    const int rl = tid / LPR, cl = (tid % LPR) * VE, RPB = 256 / LPR;
+    float qv[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) qv[e] = qs[cl + e];
     float mx = -INFINITY;
-    for (int64_t j = tid; j < len; j += 256) {
-        const CT* kr = kc + (s * T_max + j) * HD + h * dh;
+    for (int64_t j0 = 0; j0 < len; j0 += RPB) {
+        const int64_t j = j0 + rl;
         float a = 0.f;
-        for (int d = 0; d < dh; ++d) a += qs[d] * to_f32<CT>(kr[d]);
+        if (j < len) {
+            const CT* kr = kc + (s * T_max + j) * HD + h * dh + cl;
+            if constexpr (sizeof(CT) == 2) { const bf16x8 kv = *(const bf16x8*)kr;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a += qv[e] * (float)kv[e]; }
+            else { const f32x4 kv = *(const f32x4*)kr;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a += qv[e] * kv[e]; }
+        }
+        for (int o = LPR >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
         a = a / sqrt_dh;
-        sc[j] = a;
-        mx = fmaxf(mx, a);
+        if (j < len) {
+            if ((tid % LPR) == 0) sc[j] = a;
+            mx = fmaxf(mx, a);
+        }
     }
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
@@ -416,14 +444,25 @@ __global__ __launch_bounds__(256) void sattn_decode_kernel(const CT* __restrict_
     if (lane == 0) red[wave] = sum;
     __syncthreads();
     const float tot = red[0] + red[1] + red[2] + red[3];
-    const int d = tid % dh, pt = tid / dh, npt = 256 / dh;
-    float acc = 0.f;
-    for (int64_t j = pt; j < len; j += npt) acc += sc[j] * to_f32<CT>(vc[(s * T_max + j) * HD + h * dh + d]);
-    part[tid] = acc;
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    for (int64_t j = rl; j < len; j += RPB) {
+        const CT* vr = vc + (s * T_max + j) * HD + h * dh + cl;
+        const float p = sc[j];
+        if constexpr (sizeof(CT) == 2) { const bf16x8 vv = *(const bf16x8*)vr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += p * (float)vv[e]; }
+        else { const f32x4 vv = *(const f32x4*)vr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += p * vv[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) part[rl * dh + cl + e] = acc[e];
     __syncthreads();
     if (tid < dh) {
         float a = 0.f;
-        for (int p = 0; p < npt; ++p) a += part[p * dh + tid];
+        for (int p = 0; p < RPB; ++p) a += part[p * dh + tid];
         out[s * ld_out + h * dh + tid] = from_f32<CT>(a / tot);
     }
 }
@@ -507,24 +546,28 @@ extern "C" int emo_softmax_attn_bwd(const void* q, const void* k, const void* v,
                           (hipStream_t)stream);
 }
 
-extern "C" int emo_softmax_attn_decode(const void* q, int64_t ld_q, const void* kcache, const void* vcache, int64_t T_max, const int64_t* lens, void* out,
-                                       int64_t ld_out, int dtype, int64_t n_streams, int64_t H, int64_t dh, emo_stream_t stream) {
+extern "C" int emo_softmax_attn_decode(const void* q, int64_t ld_q, void* kcache, void* vcache, int64_t T_max, const int64_t* lens, int64_t lens_off,
+                                       const void* k_new, const void* v_new, int64_t ld_new, void* out, int64_t ld_out, int dtype, int64_t n_streams,
+                                       int64_t H, int64_t dh, emo_stream_t stream) {
     EMO_CHECK(q && kcache && vcache && lens && out, "emo_softmax_attn_decode: null pointer");
-    EMO_CHECK(dh <= 128 && 256 % dh == 0, "emo_softmax_attn_decode: d_head must divide 256 and be <= 128");
+    EMO_CHECK(dh == 16 || dh == 32 || dh == 64 || dh == 128, "emo_softmax_attn_decode: d_head must be 16, 32, 64 or 128");
     EMO_CHECK(T_max * 4 <= 128 * 1024, "emo_softmax_attn_decode: T_max too large for the LDS score buffer");
+    EMO_CHECK(!k_new == !v_new, "emo_softmax_attn_decode: k_new and v_new go together");
+    const int64_t ve = dtype == EMO_BF16 ? 8 : 4;
+    EMO_CHECK((((uintptr_t)kcache | (uintptr_t)vcache) & 15) == 0 && (H * dh) % ve == 0, "emo_softmax_attn_decode: caches must be 16-B aligned");
     dim3 grid((unsigned)(n_streams * H));
     const size_t lds = (size_t)T_max * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == EMO_F32) {
         static bool a = false;
         if (!a) { (void)hipFuncSetAttribute((const void*)sattn_decode_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); a = true; }
-        hipLaunchKernelGGL(sattn_decode_kernel<float>, grid, dim3(256), lds, st, (const float*)q, ld_q, (const float*)kcache, (const float*)vcache, T_max, lens,
-                           (float*)out, ld_out, H, (int)dh);
+        hipLaunchKernelGGL(sattn_decode_kernel<float>, grid, dim3(256), lds, st, (const float*)q, ld_q, (float*)kcache, (float*)vcache, T_max, lens, lens_off,
+                           (const float*)k_new, (const float*)v_new, ld_new, (float*)out, ld_out, H, (int)dh);
     } else {
         static bool a = false;
         if (!a) { (void)hipFuncSetAttribute((const void*)sattn_decode_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); a = true; }
-        hipLaunchKernelGGL(sattn_decode_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)q, ld_q, (const bf16_t*)kcache, (const bf16_t*)vcache, T_max,
-                           lens, (bf16_t*)out, ld_out, H, (int)dh);
+        hipLaunchKernelGGL(sattn_decode_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)q, ld_q, (bf16_t*)kcache, (bf16_t*)vcache, T_max, lens,
+                           lens_off, (const bf16_t*)k_new, (const bf16_t*)v_new, ld_new, (bf16_t*)out, ld_out, H, (int)dh);
     }
     EMO_LAUNCH_CHECK();
     return EMO_OK;

@@ -222,6 +222,46 @@ class GPT2DecodeEngine(_EngineBase):
         self.kc = [torch.zeros(n_streams, max_len, D, device=self.dev, dtype=self.dt) for _ in range(model.n_layer)]
         self.vc = [torch.zeros(n_streams, max_len, D, device=self.dev, dtype=self.dt) for _ in range(model.n_layer)]
         self.lens = torch.zeros(n_streams, device=self.dev, dtype=torch.int64)
+        # bf16 one-token steps: the Conv1D weights ([in, out]) are transposed ONCE to the k-contiguous layout of the skinny decode GEMM,
+        # ln_1 / ln_2 are folded into c_attn / c_fc (emo_hip.h: ln_c1) and the new k / v rows are appended by the attention kernel:
+        # 5 launches per layer instead of 9 general-shape ones.
+        self.fold = None
+        if self.dt == torch.bfloat16 and n_streams <= 32 and os.environ.get('EMO_DECODE_LN_FOLD', '1') != '0':
+            self._prepare_folds()
+
+    def _prepare_folds(self):
+        m, ps = self.model, self.ps
+
+        def tr(wname, bname, gamma=None, beta=None):
+            Wt = ps.f32(wname).t().contiguous()                    # [out, in]
+            if gamma is None:
+                return Wt.to(torch.bfloat16).contiguous(), None, ps.f32(bname)
+            Wg = (Wt * gamma[None, :]).to(torch.bfloat16).contiguous()
+            return Wg, Wg.float().sum(1).contiguous(), (ps.f32(bname) + Wt @ beta).contiguous()
+
+        self.fold = []
+        for l in range(m.n_layer):
+            pfx = m._layer_prefix(l)
+            self.fold.append({'attn': tr(pfx + 'attn.c_attn.weight', pfx + 'attn.c_attn.bias', ps.f32(pfx + 'ln_1.weight'), ps.f32(pfx + 'ln_1.bias')),
+                              'proj': tr(pfx + 'attn.c_proj.weight', pfx + 'attn.c_proj.bias'),
+                              'fc': tr(pfx + 'mlp.c_fc.weight', pfx + 'mlp.c_fc.bias', ps.f32(pfx + 'ln_2.weight'), ps.f32(pfx + 'ln_2.bias')),
+                              'mlp': tr(pfx + 'mlp.c_proj.weight', pfx + 'mlp.c_proj.bias')})
+
+    def _step_folded(self, x, lens, lens_off, logits_out):
+        m = self.model
+        D, H = m.d_model, m.n_head
+        for l in range(m.n_layer):
+            fd = self.fold[l]
+            Wg, c1, bb = fd['attn']
+            qkv = ops.gemm(x, Wg, bias=bb, ln_c1=c1)
+            a = ops.softmax_attn_decode(qkv[:, :D], self.kc[l], self.vc[l], lens, H, lens_off=lens_off, k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:])
+            Wt, _, bb = fd['proj']
+            h = ops.gemm(a, Wt, bias=bb, residual=x)
+            Wg, c1, bb = fd['fc']
+            f = ops.gemm(h, Wg, bias=bb, act=ops.ACT_GELU_NEW, ln_c1=c1)
+            Wt, _, bb = fd['mlp']
+            x = ops.gemm(f, Wt, bias=bb, residual=h)
+        return self._logits(x, logits_out)
 
     def _block_tail(self, pfx, x, a):
         ps = self.ps
@@ -250,10 +290,20 @@ class GPT2DecodeEngine(_EngineBase):
         return self._logits(x.view(B, T, D)[:, -1].contiguous())
 
     @torch.no_grad()
-    def step(self, tok, seg, dev_pos=False):
+    def step(self, tok, seg, dev_pos=False, logits_out=None):
         m, ps = self.model, self.ps
         D, H = m.d_model, m.n_head
         x = self._embed(tok.view(-1, 1), None if seg is None else seg.view(-1, 1), self.pos, dev_pos)
+        if self.fold is not None:
+            if dev_pos and not self.pos_auto:            # positions AND key counts come from the sampler's step counter
+                return self._step_folded(x, self.pos_dev, self.dev_pos0 + 1, logits_out)
+            self.lens.add_(1)
+            out = self._step_folded(x, self.lens, 0, logits_out)
+            if dev_pos:
+                self.pos_dev.add_(1)
+            else:
+                self.pos += 1
+            return out
         if dev_pos:
             slot = torch.arange(self.n, device=self.dev) * self.max_len + self.pos_dev      # flat cache row of each stream's new token
         self.lens.add_(1)
@@ -273,7 +323,7 @@ class GPT2DecodeEngine(_EngineBase):
             self.pos_dev.add_(1)
         else:
             self.pos += 1
-        return self._logits(x)
+        return self._logits(x, logits_out)
 
 
 def make_engine(model, n_streams, **kw):
@@ -540,7 +590,7 @@ def generate_streams(model, prompt_tok, prompt_seg, n_new, temp=1.1, top_p=0.9, 
     logits_buf = eng.prefill(prompt_tok, prompt_seg).clone()
     step_idx = torch.zeros(1, dtype=torch.long, device=dev)
 
-    fused = (not greedy) and model.kind == 'performer'
+    fused = not greedy
     if fused:
         # all loop state on the device inside OUR kernels: the sampler reads u[step[r], r], writes the token into out[r, T0 + step[r]] and
         # advances step[r]; the embedding takes position (T0 - 1) + step[r]; the logits GEMM writes straight into logits_buf

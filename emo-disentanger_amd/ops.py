@@ -216,13 +216,15 @@ def softmax_attn_bwd(q, k, v, out, dout, lse, B, T, H, p_drop=0.0, seed=0, offse
     return dq, dk, dv
 
 
-def softmax_attn_decode(q, kcache, vcache, lens, H):
+def softmax_attn_decode(q, kcache, vcache, lens, H, lens_off=0, k_new=None, v_new=None):
+    """One query row per stream against the KV caches; k_new / v_new: the new token's rows, appended in-kernel at position lens + lens_off - 1."""
     n, HD = q.shape
     T_max = kcache.shape[1]
     assert kcache.is_contiguous() and vcache.is_contiguous() and lens.dtype == torch.int64
+    assert (k_new is None) == (v_new is None) and (k_new is None or _rows(k_new) == _rows(v_new))
     out = torch.empty(n, HD, device=q.device, dtype=q.dtype)
-    check(lib.emo_softmax_attn_decode(ptr(q), _rows(q), ptr(kcache), ptr(vcache), T_max, ptr(lens), ptr(out), HD, dtype_code(q.dtype), n, H,
-                                      HD // H, stream()))
+    check(lib.emo_softmax_attn_decode(ptr(q), _rows(q), ptr(kcache), ptr(vcache), T_max, ptr(lens), lens_off, ptr(k_new), ptr(v_new),
+                                      0 if k_new is None else _rows(k_new), ptr(out), HD, dtype_code(q.dtype), n, H, HD // H, stream()))
     return out
 
 

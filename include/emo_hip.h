@@ -168,10 +168,13 @@ int emo_softmax_attn_bwd(const void* q, const void* k, const void* v, int64_t ld
                          void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T,
                          int64_t H, int64_t dh, float p_drop, uint64_t seed, uint64_t offset,
                          emo_stream_t stream);
-/* decode: one query row per stream against a KV cache [n_streams, T_max, H*dh]; lens[s] = valid keys */
-int emo_softmax_attn_decode(const void* q, int64_t ld_q, const void* kcache, const void* vcache,
-                            int64_t T_max, const int64_t* lens, void* out, int64_t ld_out, int dtype,
-                            int64_t n_streams, int64_t H, int64_t dh, emo_stream_t stream);
+/* decode: one query row per stream against a KV cache [n_streams, T_max, H*dh]; lens[s] + lens_off = valid keys INCLUDING the new
+ * token.  k_new / v_new [n_streams, H*dh] (ld_new; both or neither NULL): the new token's key / value rows, appended to the caches
+ * at position len-1 by the kernel itself (the HF `past_key_values` concat of GPT2Attention). */
+int emo_softmax_attn_decode(const void* q, int64_t ld_q, void* kcache, void* vcache, int64_t T_max,
+                            const int64_t* lens, int64_t lens_off, const void* k_new, const void* v_new,
+                            int64_t ld_new, void* out, int64_t ld_out, int dtype, int64_t n_streams,
+                            int64_t H, int64_t dh, emo_stream_t stream);
 
 /* ------------------------------------------------------------------ K9: cross-entropy with ignore_index
  * Replaces F.cross_entropy in compute_loss (model/music_performer.py:72-81).
