@@ -25,7 +25,7 @@ c_p, c_i, c_l, c_f, c_u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctype
 class Epilogue(ctypes.Structure):
     _fields_ = [('bias', c_p), ('act', c_i), ('aux_out', c_p), ('mul_aux', c_p), ('mul_mode', c_i), ('mul_scale', c_f),
                 ('p_drop', c_f), ('seed', c_u64), ('offset', c_u64), ('residual', c_p),
-                ('ln_c1', c_p), ('ln_eps', c_f), ('ln_stats_out', c_p), ('rln_x', c_p), ('rln_stats', c_p), ('rln_gamma', c_p), ('rln_beta', c_p),
+                ('ln_c1', c_p), ('ln_eps', c_f), ('ln_stats_out', c_p), ('rln_x', c_p), ('rln_stats', c_p), ('rln_gamma', c_p), ('rln_beta', c_p), ('a_rowsum', c_p), ('b_rowsum', c_p),
                 ('workspace', c_p), ('workspace_bytes', c_l)]
 
 

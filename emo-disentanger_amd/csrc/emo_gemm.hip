@@ -38,6 +38,8 @@ struct EpiParams {
     const float* rln_gamma;
     const float* rln_beta;
     float ln_eps;
+    float* a_rowsum;     // [M] += sum_k op(A)[m][k] (bias gradient riding on the wgrad GEMM), TN bf16 kernel only
+    float* b_rowsum;     // [N] += sum_k op(B)[n][k] (same for the Conv1D layout, where dY is the B operand)
     int64_t ws_stride;   // > 0: split-K partials go to C + split * ws_stride with plain stores (splitk_reduce_kernel sums them)
     int ablate;   // diagnostics only (EMO_GEMM_ABLATE): 1 = skip tile loads, 2 = skip MFMAs
 };
@@ -481,6 +483,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // bias gradient for free: rowsum_k A[m][k] = A . 1 is one more MFMA per A fragment with an all-ones operand (the A fragments are in
+    // registers anyway); only the tn == 0 column of blocks and its wn == 0 waves do it (r01: the separate column-sum launches were 2 ms/step).
+    const bool do_rs = ep.a_rowsum != nullptr && tn == 0 && wn == 0;
+    const bool do_bs = ep.b_rowsum != nullptr && tm == 0 && wm == 0;
+    f32x4 rsacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rsacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16_t one_b = (bf16_t)1.f;
+    const bf16x8 ones = {one_b, one_b, one_b, one_b, one_b, one_b, one_b, one_b};
+
     bf16x8 ra[BKT / 16], rb[BKT / 16];
     gload_tile<A_KC, BKT>(A, lda, m0, M, kbeg, kend, tid, ra);
     gload_tile<B_KC, BKT>(B, ldb, n0, N, kbeg, kend, tid, rb);
@@ -508,6 +520,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            if (do_rs) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rsacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i], rsacc[i], 0, 0, 0);
+            } else if (do_bs) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rsacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], ones, rsacc[j], 0, 0, 0);
+            }
         }
         if (more) {
             char* na = smem + (cur ^ 1) * 2 * OPB;
@@ -516,6 +535,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
         }
         __syncthreads();
         cur ^= 1;
+    }
+    if (do_rs && (lane >> 4) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
+            if (m < M) atomicAdd(ep.a_rowsum + m, rsacc[i][0]);
+        }
+    } else if (do_bs && !do_rs && (lane & 15) == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4 + r;
+                if (n < N) atomicAdd(ep.b_rowsum + n, rsacc[j][r]);
+            }
     }
     epilogue_tile128<OutT, (BKT == 64 ? 1 : 2)>(ep, C, m0, n0, M, N, acc, smem, tid, wm, wn, lane);
 }
@@ -1548,6 +1582,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         ep.mul_mode = e->mul_aux ? e->mul_mode : EMO_MUL_NONE; ep.mul_scale = e->mul_scale;
         ep.drop = make_drop(e->p_drop, e->seed, e->offset); ep.residual = e->residual;
         has_epi = e->bias || e->act || e->aux_out || ep.mul_mode || ep.drop.thr16 || e->residual;
+        ep.a_rowsum = e->a_rowsum; ep.b_rowsum = e->b_rowsum;
         ep.ln_c1 = e->ln_c1; ep.ln_stats_out = e->ln_stats_out; ep.ln_eps = e->ln_eps;
         ep.rln_x = e->rln_x; ep.rln_stats = e->rln_stats; ep.rln_gamma = e->rln_gamma; ep.rln_beta = e->rln_beta;
         EMO_CHECK(!e->rln_x || (e->rln_stats && e->rln_gamma && e->rln_beta && !e->act && !ep.drop.thr16 && !ep.mul_mode),
@@ -1555,6 +1590,27 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         EMO_CHECK(!e->ln_stats_out || e->ln_c1, "emo_gemm: ln_stats_out needs ln_c1");
     }
     const bool ln_fused = e && (e->ln_c1 || e->rln_x);
+    EMO_CHECK(!(ep.a_rowsum && ep.b_rowsum), "emo_gemm: a_rowsum and b_rowsum are exclusive");
+    if (ep.b_rowsum) {
+        EMO_CHECK(a_trans && b_trans, "emo_gemm: b_rowsum needs a_trans and b_trans (B stored [K, N]: the Conv1D wgrad layout)");
+        const bool in_kernel = dtype_in == EMO_BF16 && gemm_variant() < 3 && !use_safe_tr() && getenv("EMO_GEMM_TN32") == nullptr &&
+                               getenv("EMO_GEMM_FORCE_G3") == nullptr && getenv("EMO_GEMM_NO_ROWSUM_FUSE") == nullptr;
+        if (!in_kernel) {
+            const int rc = emo_colsum(B, dtype_in, K, N, ldb, ep.b_rowsum, 1, stream);
+            if (rc) return rc;
+            ep.b_rowsum = nullptr;
+        }
+    }
+    if (ep.a_rowsum) {
+        EMO_CHECK(a_trans, "emo_gemm: a_rowsum needs a_trans (A stored [K, M]: the wgrad layout)");
+        const bool in_kernel = dtype_in == EMO_BF16 && gemm_variant() < 3 && !use_safe_tr() && getenv("EMO_GEMM_TN32") == nullptr &&
+                               getenv("EMO_GEMM_FORCE_G3") == nullptr && getenv("EMO_GEMM_NO_ROWSUM_FUSE") == nullptr;
+        if (!in_kernel) {                                   // other kernels: the plain column-sum launch over A [K, M]
+            const int rc = emo_colsum(A, dtype_in, K, M, lda, ep.a_rowsum, 1, stream);
+            if (rc) return rc;
+            ep.a_rowsum = nullptr;
+        }
+    }
     const bool big = dtype_in == EMO_BF16;
     const int variant = big ? gemm_variant() : 0;
     if (big && M <= 32 && !a_trans && !b_trans && (K % 32) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0 &&

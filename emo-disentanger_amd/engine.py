@@ -188,17 +188,16 @@ def join_side_stream():
         torch.cuda.current_stream().wait_stream(_SIDE['stream'])
 
 
-def _timed_wgrad(a, b, out):
-    ops.gemm(a, b, a_trans=True, b_trans=True, out=out, accumulate=True)
+def _timed_wgrad(a, b, out, a_rowsum=None, b_rowsum=None):
+    """dW += a^T b.  a_rowsum / b_rowsum: the bias gradient (column sums of dY) taken inside the same GEMM from the operand fragments."""
+    ops.gemm(a, b, a_trans=True, b_trans=True, out=out, accumulate=True, a_rowsum=a_rowsum, b_rowsum=b_rowsum)
 
 
 def _wgrad(ps, wname, bname, dy, xin, fused_rows=None, bias_done=False):
     """dW[N,K] += dy[M,N]^T xin[M,K] ; db[N] += colsum(dy)   (nn.Linear layout).  bias_done: the column sums were already
     accumulated by the LayerNorm-backward kernel that produced dy."""
     with _side_stream(dy, xin):
-        _timed_wgrad(dy, xin, ps.g(wname, fused_rows))
-        if not bias_done:
-            ops.colsum(dy, out=ps.g(bname, fused_rows), accumulate=True)
+        _timed_wgrad(dy, xin, ps.g(wname, fused_rows), a_rowsum=None if bias_done else ps.g(bname, fused_rows))
 
 
 def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
@@ -246,8 +245,7 @@ def gpt2_block_fwd(ps, pfx, x, B, T, H, p, seed, off, save):
 def _wgrad_conv1d(ps, wname, bname, xin, dy):
     """dW[K,N] += xin[M,K]^T dy[M,N] ; db[N] += colsum(dy)   (HF Conv1D layout)."""
     with _side_stream(dy, xin):
-        _timed_wgrad(xin, dy, ps.g(wname))
-        ops.colsum(dy, out=ps.g(bname), accumulate=True)
+        _timed_wgrad(xin, dy, ps.g(wname), b_rowsum=ps.g(bname))
 
 
 def gpt2_block_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
@@ -352,8 +350,7 @@ class LogitsFn(torch.autograd.Function):
             padded = p16
         g = padded[:, :V]
         with _side_stream(padded, ctx.h2):
-            _timed_wgrad(g, ctx.h2, ps.g('dec_out_proj.weight'))
-            ops.colsum(g, out=ps.g('dec_out_proj.bias'), accumulate=True)
+            _timed_wgrad(g, ctx.h2, ps.g('dec_out_proj.weight'), a_rowsum=ps.g('dec_out_proj.bias'))
         dh = ops.gemm(g, ps.w('dec_out_proj.weight'), b_trans=True)
         join_side_stream()
         return None, dh.view(ctx.shp)

@@ -73,6 +73,9 @@ typedef struct {
     const float* rln_stats;   /* [M,2] (mean, rstd) of the rln_x rows */
     const float* rln_gamma;   /* [N] */
     const float* rln_beta;    /* [N] */
+    float* a_rowsum;      /* NULL or [M] fp32: += sum_k op(A)[m][k]; needs a_trans.  For a weight gradient dW = dY^T X this is the bias
+                           * gradient (column sums of dY), taken inside the GEMM from the operand fragments instead of a second pass. */
+    float* b_rowsum;      /* NULL or [N] fp32: += sum_k op(B)[n][k]; needs a_trans and b_trans (HF Conv1D layout, where dY is the B operand) */
     void* workspace;      /* NULL or caller scratch for split-K partial sums (plain fp32-output GEMMs = weight gradients): */
     int64_t workspace_bytes; /* with it the splits are summed in a fixed order by a reduce kernel (deterministic, no atomics);
                               * without it they are fp32 atomics into C.  Size: emo_gemm_workspace_bytes(). */

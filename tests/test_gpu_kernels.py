@@ -195,6 +195,26 @@ def test_gemm_skinny_layernorm_folding(M):
         ops.gemm(_r(64, K, seed=1).to(torch.bfloat16).cuda(), Wg, ln_c1=c1)
 
 
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('Mred,N,K', [(4096 + 40, 328, 200), (1000, 136, 264), (8192, 1536, 512)])
+def test_gemm_wgrad_carries_the_bias_gradient(dt, Mred, N, K):
+    # dW += dY^T X with db += colsum(dY) taken inside the same launch (a_rowsum: nn.Linear layout; b_rowsum: HF Conv1D layout);
+    # fp32 and the non-TN kernels fall back to the column-sum launch behind the same entry point
+    ops = _ops()
+    dY, X = _r(Mred, N, seed=12, dt=dt).cuda(), _r(Mred, K, seed=13, dt=dt).cuda()
+    ref_w, ref_b = dY.double().T @ X.double(), dY.double().sum(0)
+    tol = 1.0 if dt == torch.float32 else 0.3
+    db0 = _r(N, seed=3).cuda()
+    dw, db = torch.zeros(N, K, device='cuda'), db0.clone()
+    ops.gemm(dY, X, a_trans=True, b_trans=True, out=dw, accumulate=True, a_rowsum=db)
+    _close(dw, ref_w, dt, mult=tol)
+    _close(db - db0, ref_b, dt, mult=tol)
+    dw2, db2 = torch.zeros(K, N, device='cuda'), db0.clone()
+    ops.gemm(X, dY, a_trans=True, b_trans=True, out=dw2, accumulate=True, b_rowsum=db2)
+    _close(dw2, ref_w.T, dt, mult=tol)
+    _close(db2 - db0, ref_b, dt, mult=tol)
+
+
 def test_gemm_bf16_safe_and_tr_paths_agree(monkeypatch):
     # the transposed-operand fragments are fetched with ds_read_b64_tr_b16; EMO_GEMM_SAFE_TR=1 (read at first use)
     # selects a scalar-read variant of the same kernel; both are compared with the reference in the layout tests.
