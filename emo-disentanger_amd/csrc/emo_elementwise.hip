@@ -373,8 +373,10 @@ extern "C" int emo_layernorm_bwd(const void* dy, const void* x, const float* gam
     DropCtx drop = make_drop(p_drop, seed, offset);
     if (dtype == EMO_BF16 && D == 512 && getenv("EMO_LN_GENERIC") == nullptr &&
         ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres | (uintptr_t)dx_drop | (uintptr_t)gamma) & 15) == 0)) {
-        int64_t b8 = cdiv64(M, 4);
-        if (b8 > 2048) b8 = 2048;
+        // every block ends with 3 x 512 fp32 atomics (dgamma, dbeta, dcol): ~25 us per 1024 blocks (r01 sweep), so a block takes >= 32 rows
+        int64_t b8 = cdiv64(M, 32);
+        if (b8 > 1024) b8 = 1024;
+        { const char* eb = getenv("EMO_LN_BWD_BLOCKS"); if (eb && atoi(eb) > 0) b8 = atoi(eb); }
         hipLaunchKernelGGL(layernorm_bwd_bf16_d512_kernel, dim3((unsigned)b8), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
                            (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dx_drop, dgamma, dbeta, dcol, M, drop);
         EMO_LAUNCH_CHECK();

@@ -13,7 +13,7 @@ def t(fn, iters=30, warm=3):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 
-M, D = 131072, 512
+M, D = int(os.environ.get('M', 131072)), 512
 bf = torch.bfloat16
 x = torch.randn(M, D, device='cuda').to(bf); dy = torch.randn(M, D, device='cuda').to(bf); dres = torch.randn(M, D, device='cuda').to(bf)
 g, b = torch.ones(D, device='cuda'), torch.zeros(D, device='cuda')
