@@ -95,3 +95,46 @@ def test_data_parallel_plumbing_gloo_world2():
     assert np.allclose(f0, m0 + m1) and np.array_equal(f0, f1)   # grad all-reduce = sum; 1/world is folded into the clip coef
     assert not p0.any() and not p1.any()                   # replicas start from rank 0's weights
     assert x0 == x1 == 2.0                                 # bench timing = max over ranks
+
+
+def test_checkpoint_contract_param_order_and_init_rule():
+    """The reference resumes optimizers by PARAMETER ORDER (stock Adam.state_dict(), train.py:318-326) and loads flat state dicts
+    (train.py:304-311): names, order and shapes must match the imported reference (fixture: named_parameters() of the real MusicGPT2),
+    and fresh models must follow weights_init (transformer_helpers.py:24-40): Linear/Embedding N(0, 0.01), bias 0, LayerNorm weight
+    N(1, 0.01); HF Conv1D keeps its own N(0, 0.02)."""
+    import json
+    import os
+    import numpy as np
+    import torch
+    from emo_disentanger_amd.model.music_gpt2 import MusicGPT2
+    from emo_disentanger_amd.model.music_performer import MusicPerformer
+    from oracle.weights import make_state_dict
+    G = os.path.join(os.path.dirname(__file__), 'golden')
+    man = json.load(open(os.path.join(G, 'manifest.json')))
+    for name, c in man.items():
+        ref_names = [str(n) for n in np.load(os.path.join(G, name + '.npz'))['grad_names']]
+        nseg = None if c.get('noseg') else 2
+        m = MusicGPT2(c['V'], c['L'], c['H'], c['d'], c['dff'], c['d'], use_segment_emb=nseg is not None, n_segment_types=nseg)
+        assert [n for n, _ in m.named_parameters()] == ref_names, name
+        sd = make_state_dict('gpt2', c['V'], c['L'], c['H'], c['d'], c['dff'], n_segment_types=nseg, seed=1)      # keys asserted == reference's at fixture time
+        msd = m.state_dict()
+        assert list(msd.keys()) == list(sd.keys()) and all(tuple(msd[k].shape) == tuple(sd[k].shape) for k in sd), name
+    torch.manual_seed(0)
+    g = MusicGPT2(327, 2, 8, 512, 2048, 512, use_segment_emb=True, n_segment_types=2).state_dict()
+    p = MusicPerformer(327, 2, 8, 512, 2048, 512, favor_feature_dims=128, use_segment_emb=True, n_segment_types=2).state_dict()
+
+    def stat(t):
+        return float(t.float().mean()), float(t.float().std())
+    for k, (mu, sd_) in {'token_emb.emb_lookup.weight': (0.0, 0.01), 'dec_out_proj.weight': (0.0, 0.01), 'transformer_decoder.0.ln_1.weight': (1.0, 0.01),
+                         'transformer_decoder.0.attn.c_attn.weight': (0.0, 0.02), 'transformer_decoder.0.mlp.c_proj.weight': (0.0, 0.02)}.items():
+        m_, s_ = stat(g[k])
+        assert abs(m_ - mu) < 3e-3 and abs(s_ - sd_) < 0.15 * sd_, (k, m_, s_)
+    assert float(g['dec_out_proj.bias'].abs().max()) == 0.0 and float(g['transformer_decoder.0.ln_1.bias'].abs().max()) == 0.0
+    lp = 'transformer_decoder.decoder_layers.0.'
+    for k, (mu, sd_) in {lp + 'attention.query_projection.weight': (0.0, 0.01), lp + 'linear1.weight': (0.0, 0.01), lp + 'norm1.weight': (1.0, 0.01),
+                         'segemb.emb_lookup.weight': (0.0, 0.01)}.items():
+        m_, s_ = stat(p[k])
+        assert abs(m_ - mu) < 3e-3 and abs(s_ - sd_) < 0.15 * sd_, (k, m_, s_)
+    assert float(p[lp + 'linear1.bias'].abs().max()) == 0.0
+    # loaders filter 'feature_map.omega' (train.py:306, inference.py:411): the buffer is in the state dict under that name
+    assert any(k.endswith('inner_attention.feature_map.omega') for k in p)
