@@ -82,13 +82,14 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
 
     serial = instrumented(False)
     overlapped = instrumented(True) if engine._SIDE['on'] else {}
-    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_wgrad.json')
+    pmc_files = {'TN': os.path.join(ROOT, 'profiles', 'r01_pmc_wgrad.json'), 'NN': os.path.join(ROOT, 'profiles', 'r01_pmc_dgrad.json')}
 
     def entry(kind):
         d = serial[kind]
         achieved = d['flops'] / d['ms'] / 1e9
         traffic = None      # HBM bytes per launch from rocprofv3 PMC passes (collected offline, committed under profiles/)
-        if kind == 'TN' and os.path.exists(pmc) and B * T == 131072:
+        pmc = pmc_files.get(kind)
+        if pmc and os.path.exists(pmc) and B * T == 131072:
             traffic = json.load(open(pmc)).get('traffic_bytes_per_launch')
         return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,

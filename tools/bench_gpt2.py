@@ -7,7 +7,7 @@ from emo_disentanger_amd.model.music_gpt2 import MusicGPT2
 from emo_disentanger_amd.optim import FusedAdam
 from emo_disentanger_amd.data import synthetic_batch
 B, T = int(os.environ.get('B', 16)), int(os.environ.get('T', 2048))
-m = MusicGPT2(327, 12, 8, 512, 2048, 512, use_segment_emb=True, n_segment_types=2, dropout=0.1, compute_dtype='bf16').cuda().train()
+m = MusicGPT2(327, 12, 8, 512, 2048, 512, use_segment_emb=True, n_segment_types=2, dropout=float(os.environ.get('DROPOUT', 0.1)), compute_dtype='bf16').cuda().train()
 opt = FusedAdam(m, lr=1e-5, max_grad_norm=0.5)
 b = synthetic_batch(327, B, T, device='cuda')
 def step():
