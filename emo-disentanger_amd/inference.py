@@ -572,61 +572,91 @@ def _resume_windowed(model, event2idx, idx2event, s, max_events, skip_check, tem
     return s.result()
 
 
+class _Chain:
+    """One lock-step group of streams: engine + device-side loop state + (optionally) the captured step graph on its own HIP stream."""
+
+    def __init__(self, model, ptok, pseg, n_new, U, temp, top_p, greedy, seg_value, redraw):
+        self.n, self.T0 = ptok.shape
+        n, T0, dev = self.n, self.T0, ptok.device
+        self.eng = make_engine(model, n, redraw=redraw) if model.kind == 'performer' else make_engine(model, n)
+        eng = self.eng
+        self.out = torch.empty(n, T0 + n_new, dtype=torch.long, device=dev)
+        self.out[:, :T0] = ptok
+        out = self.out
+        seg_col = torch.full((n,), seg_value, dtype=torch.long, device=dev)
+        logits_buf = eng.prefill(ptok, pseg).clone()
+        if not greedy:
+            # all loop state on the device inside OUR kernels: the sampler reads u[step[r], r], writes the token into out[r, T0 + step[r]] and
+            # advances step[r]; the embedding takes position (T0 - 1) + step[r]; the logits GEMM writes straight into logits_buf
+            # (5 fewer launches per token than the torch index_select / scatter_ / add_ / copy_ version below).
+            step_ctr = torch.zeros(n, dtype=torch.long, device=dev)
+            eng.pos_dev, eng.dev_pos0, eng.pos_auto = step_ctr, T0 - 1, False
+            nxt_buf = torch.empty(n, dtype=torch.long, device=dev)
+
+            def one_step():
+                ops.sample_nucleus_step(logits_buf, temp, top_p, U, step_ctr, seq=out, col0=T0, out=nxt_buf)
+                eng.step(nxt_buf, seg_col, dev_pos=True, logits_out=logits_buf)
+        else:
+            step_idx = torch.zeros(1, dtype=torch.long, device=dev)
+
+            def one_step():
+                u = U.index_select(0, step_idx).view(n)
+                nxt = sample_on_device(logits_buf, temp, top_p, u, greedy)
+                out.scatter_(1, (step_idx + T0).expand(n, 1), nxt.view(n, 1))
+                logits_buf.copy_(eng.step(nxt, seg_col, dev_pos=True))
+                step_idx.add_(1)
+        self.one_step = one_step
+        self.graph, self.stream = None, None
+
+    def capture(self):
+        dev = self.out.device
+        self.graph = torch.cuda.CUDAGraph()
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.one_step()
+
+
 @torch.no_grad()
-def generate_streams(model, prompt_tok, prompt_seg, n_new, temp=1.1, top_p=0.9, greedy=False, seed=0, seg_value=1, use_graph=True):
+def generate_streams(model, prompt_tok, prompt_seg, n_new, temp=1.1, top_p=0.9, greedy=False, seed=0, seg_value=1, use_graph=True, chains=None):
     """BASELINE configs[3]: n parallel streams in lock-step (grammar checks off => fixed token count).  Everything stays
-    on the GPU: recurrent/KV state, positions, sampling, token buffer.  One decode step is ~110 small launches, so the
-    step (sample -> append -> embed -> 12 layers -> logits) is captured ONCE in a hipGraph and replayed per token.
+    on the GPU: recurrent/KV state, positions, sampling, token buffer.  One decode step is ~64 small DEPENDENT launches, so the
+    step (sample -> append -> embed -> 12 layers -> logits) is captured ONCE in a hipGraph and replayed per token.  `chains` > 1 splits the
+    streams into independent groups whose graphs replay on separate HIP streams (same tokens as one group: every stream keeps its own
+    uniform draws); measured r01: SLOWER (0.52 / 0.89 / 0.60 / 1.11 ms per step for 1 / 2 / 4 / 8 chains) — the replays are issued by one
+    host thread and do not overlap — so the default is one chain.
     Returns int64 [n, T0 + n_new]."""
     n, T0 = prompt_tok.shape
     dev = prompt_tok.device
-    eng = make_engine(model, n)
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     U = torch.rand(max(n_new, 1), n, device=dev, generator=gen)
-    out = torch.empty(n, T0 + n_new, dtype=torch.long, device=dev)
-    out[:, :T0] = prompt_tok
-    seg_col = torch.full((n,), seg_value, dtype=torch.long, device=dev)
-    logits_buf = eng.prefill(prompt_tok, prompt_seg).clone()
-    step_idx = torch.zeros(1, dtype=torch.long, device=dev)
-
-    fused = not greedy
-    if fused:
-        # all loop state on the device inside OUR kernels: the sampler reads u[step[r], r], writes the token into out[r, T0 + step[r]] and
-        # advances step[r]; the embedding takes position (T0 - 1) + step[r]; the logits GEMM writes straight into logits_buf
-        # (5 fewer launches per token than the torch index_select / scatter_ / add_ / copy_ version below).
-        step_ctr = torch.zeros(n, dtype=torch.long, device=dev)
-        eng.pos_dev, eng.dev_pos0, eng.pos_auto = step_ctr, T0 - 1, False
-        nxt_buf = torch.empty(n, dtype=torch.long, device=dev)
-
-        def one_step():
-            ops.sample_nucleus_step(logits_buf, temp, top_p, U, step_ctr, seq=out, col0=T0, out=nxt_buf)
-            eng.step(nxt_buf, seg_col, dev_pos=True, logits_out=logits_buf)
-    else:
-        def one_step():
-            u = U.index_select(0, step_idx).view(n)
-            nxt = sample_on_device(logits_buf, temp, top_p, u, greedy)
-            out.scatter_(1, (step_idx + T0).expand(n, 1), nxt.view(n, 1))
-            logits_buf.copy_(eng.step(nxt, seg_col, dev_pos=True))
-            step_idx.add_(1)
-
-    if n_new <= 0:
-        return out
-    one_step()                                   # eager first step (also warms every kernel / attribute cache)
-    if n_new == 1:
-        return out
-    if not use_graph:
-        for _ in range(n_new - 1):
-            one_step()
-        return out
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    side = torch.cuda.Stream(device=dev)
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        with torch.cuda.graph(graph, stream=side):
-            one_step()
-    torch.cuda.current_stream().wait_stream(side)
-    for _ in range(n_new - 1):
-        graph.replay()
-    return out
+    if chains is None:
+        chains = int(os.environ.get('EMO_GEN_CHAINS', 1))
+    if not use_graph or n_new <= 2 or chains < 1 or n % chains != 0 or n // chains < 1:
+        chains = 1
+    m = n // chains
+    cs = []
+    for c in range(chains):
+        rows = slice(c * m, (c + 1) * m)
+        cs.append(_Chain(model, prompt_tok[rows].contiguous(), prompt_seg[rows].contiguous(), n_new, U[:, rows].contiguous(), temp, top_p, greedy,
+                         seg_value, redraw=(c == 0)))
+    if n_new > 0:
+        for ch in cs:
+            ch.one_step()                        # eager first step (also warms every kernel / attribute cache)
+        if not use_graph:
+            for _ in range(n_new - 1):
+                cs[0].one_step()
+        elif n_new > 1:
+            torch.cuda.synchronize()
+            for ch in cs:
+                ch.capture()
+            main = torch.cuda.current_stream()
+            for _ in range(n_new - 1):
+                for ch in cs:
+                    with torch.cuda.stream(ch.stream):
+                        ch.graph.replay()
+            for ch in cs:
+                main.wait_stream(ch.stream)
+    return cs[0].out if chains == 1 else torch.cat([ch.out for ch in cs], 0)
