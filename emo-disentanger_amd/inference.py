@@ -653,10 +653,15 @@ def generate_streams(model, prompt_tok, prompt_seg, n_new, temp=1.1, top_p=0.9, 
             for ch in cs:
                 ch.capture()
             main = torch.cuda.current_stream()
+            t_host = time.perf_counter()
             for _ in range(n_new - 1):
                 for ch in cs:
                     with torch.cuda.stream(ch.stream):
                         ch.graph.replay()
+            if os.environ.get('EMO_GEN_TIMING'):            # diagnostics: host time to ENQUEUE the replays vs time until the GPU is done
+                t_enq = time.perf_counter() - t_host
+                torch.cuda.synchronize()
+                print('[gen timing] enqueue %.3f ms/step, total %.3f ms/step' % (1e3 * t_enq / (n_new - 1), 1e3 * (time.perf_counter() - t_host) / (n_new - 1)))
             for ch in cs:
                 main.wait_stream(ch.stream)
     return cs[0].out if chains == 1 else torch.cat([ch.out for ch in cs], 0)
