@@ -51,6 +51,11 @@ __device__ __forceinline__ typename Img<CT>::V reg_perm(const float (&s)[4][4], 
         return s[step >> 2][step & 3];
     }
 }
+// bf16 speed mode works in the base-2 domain: scores are scaled by log2(e)/sqrt(dh) once, so every probability is ONE v_exp_f32 after one
+// subtract / fma (the kernels are VALU-bound: ~20 VALU ops per score element against 0.25 clk of MFMA).  Parity mode (fp32) keeps expf and the
+// reference's division by sqrt(dh).
+#define EMO_LOG2E 1.4426950408889634f
+#define EMO_LN2 0.6931471805599453f
 template <typename CT> struct SaK { static constexpr int NS64 = 64 / Img<CT>::KSTEP; };   // MFMA steps over a 64-wide k range
 
 template <typename CT, int DH>
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const CT* __restrict__ q
     typename Img<CT>::V qf[NQ];                              // this wave's 16 query rows stay in registers for the whole sweep
 #pragma unroll
     for (int kk = 0; kk < NQ; ++kk) qf[kk] = Img<CT>::load(Qi, LDX, wave * 16, kk * Img<CT>::KSTEP, lane);
-    const float sqrt_dh = sqrtf((float)DH), rsqrt_dh = 1.f / sqrt_dh;
+    const float sqrt_dh = sqrtf((float)DH), rsqrt_dh = 1.f / sqrt_dh, c2 = rsqrt_dh * EMO_LOG2E;
     const int tl = wave * 16 + (lane & 15);        // local query row
     const int64_t tg = q0 + tl;                    // global query index
     float m_run = -INFINITY, l_run = 0.f;
@@ -115,9 +120,11 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const CT* __restrict__ q
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t jg = k0 + jt * 16 + (lane >> 4) * 4 + r;
-                float val = sizeof(CT) == 2 ? acc[r] * rsqrt_dh : acc[r] / sqrt_dh;     // parity mode keeps the reference's division
-                if (jg > tg || jg >= T) val = -INFINITY;
+                float val = sizeof(CT) == 2 ? acc[r] * c2 : acc[r] / sqrt_dh;           // bf16: base-2 domain; parity mode keeps the reference's division
+                if (diag) {                              // only the diagonal tile touches the causal boundary or the end of the sequence
+                    const int jl = jt * 16 + (lane >> 4) * 4 + r;
+                    if (jl > tl || k0 + jl >= T) val = -INFINITY;
+                }
                 s[jt][r] = val;
                 mx = fmaxf(mx, val);
             }
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const CT* __restrict__ q
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float m_new = fmaxf(m_run, mx);
         if (m_new == -INFINITY) m_new = 0.f;
-        const float alpha = __expf(m_run - m_new);
+        const float alpha = sizeof(CT) == 2 ? __builtin_amdgcn_exp2f(m_run - m_new) : __expf(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const CT* __restrict__ q
             if (drop.thr16) drop_mult4(drop, (uint64_t)((bh * T + tg) * T + k0 + jt * 16 + (lane >> 4) * 4), dm);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = Img<CT>::ex(s[jt][r] - m_new);
+                const float p = sizeof(CT) == 2 ? __builtin_amdgcn_exp2f(s[jt][r] - m_new) : Img<CT>::ex(s[jt][r] - m_new);
                 psum += p;
                 s[jt][r] = p * dm[r];
             }
@@ -161,14 +168,14 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const CT* __restrict__ q
             const int d0 = i * 16 + (lane >> 4) * 4;
             Img<CT>::store4(ob + d0, oacc[i][0] * inv, oacc[i][1] * inv, oacc[i][2] * inv, oacc[i][3] * inv);
         }
-        if ((lane >> 4) == 0) lse_g[bh * T + tg] = m_run + logf(l_run);
+        if ((lane >> 4) == 0) lse_g[bh * T + tg] = (sizeof(CT) == 2 ? m_run * EMO_LN2 : m_run) + logf(l_run);
     }
 }
 
 // =============================================================================================== backward: dQ (per query tile)
 // Also exports delta[t] = dO[t].O[t] (one value per query row) for the dK/dV pass, which used to recompute it for every (key tile, query tile) pair.
 template <typename CT, int DH>
-__global__ __launch_bounds__(256) void sattn_bwd_dq_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+__global__ __launch_bounds__(256, 2) void sattn_bwd_dq_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
                                                            const CT* __restrict__ out, const CT* __restrict__ dout, int64_t ld_out,
                                                            const float* __restrict__ lse_g, float* __restrict__ delta_g, CT* __restrict__ dq, int64_t ld_d,
                                                            int64_t T, int64_t H, DropCtx drop) {
@@ -210,7 +217,8 @@ __global__ __launch_bounds__(256) void sattn_bwd_dq_kernel(const CT* __restrict_
     const float sqrt_dh = sqrtf((float)DH), rsqrt_dh = 1.f / sqrt_dh;
     const int tl = wave * 16 + (lane & 15);
     const int64_t tg = q0 + tl;
-    const float lse = tg < T ? lse_g[bh * T + tg] : 0.f;
+    const float lse = tg < T ? lse_g[bh * T + tg] : INFINITY;      // rows past the end: p = exp(-inf) = 0
+    const float c2 = rsqrt_dh * EMO_LOG2E, lse2 = lse * EMO_LOG2E;
     const float Dt = Dv[tl];
     if (delta_g && tid < qvalid) delta_g[bh * T + q0 + tid] = Dv[tid];
     f32x4 dqacc[ND];
@@ -244,9 +252,11 @@ __global__ __launch_bounds__(256) void sattn_bwd_dq_kernel(const CT* __restrict_
             if (drop.thr16) drop_mult4(drop, (uint64_t)((bh * T + tg) * T + k0 + jt * 16 + (lane >> 4) * 4), dm);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t jg = k0 + jt * 16 + (lane >> 4) * 4 + r;
-                float p = 0.f;
-                if (jg <= tg && jg < T && tg < T) p = Img<CT>::ex((sizeof(CT) == 2 ? sa[r] * rsqrt_dh : sa[r] / sqrt_dh) - lse);
+                float p = sizeof(CT) == 2 ? __builtin_amdgcn_exp2f(sa[r] * c2 - lse2) : Img<CT>::ex(sa[r] / sqrt_dh - lse);
+                if (diag) {                              // causal boundary / end of the sequence only on the diagonal tile
+                    const int jl = jt * 16 + (lane >> 4) * 4 + r;
+                    if (jl > tl || k0 + jl >= T) p = 0.f;
+                }
                 ds[jt][r] = p * (dp[r] * dm[r] - Dt);
             }
         }
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(256) void sattn_bwd_dq_kernel(const CT* __restrict_
 
 // =============================================================================================== backward: dK, dV (per key tile)
 template <typename CT, int DH>
-__global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+__global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 2 : 1)) void sattn_bwd_dkv_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
                                                             const CT* __restrict__ dout, int64_t ld_out, const float* __restrict__ lse_g,
                                                             const float* __restrict__ delta_g, CT* __restrict__ dk, CT* __restrict__ dv, int64_t ld_d,
                                                             int64_t T, int64_t H, DropCtx drop) {
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const CT* __restrict
         pg.load(gb + q0n * ld_out, ld_out, nv, tid); pgT.load(gb + q0n * ld_out, ld_out, nv, tid);
         if (tid < 64) {
             const bool ok = q0n + tid < T;
-            pl = ok ? lse_g[bh * T + q0n + tid] : 0.f;
+            pl = ok ? lse_g[bh * T + q0n + tid] * (sizeof(CT) == 2 ? EMO_LOG2E : 1.f) : INFINITY;      // rows past the end: p = exp(-inf) = 0
             pd_ = ok ? delta_g[bh * T + q0n + tid] : 0.f;
         }
     };
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const CT* __restrict
         kf[kk] = Img<CT>::load(Ki, LDX, wave * 16, kk * Img<CT>::KSTEP, lane);
         vf[kk] = Img<CT>::load(Vi, LDX, wave * 16, kk * Img<CT>::KSTEP, lane);
     }
-    const float sqrt_dh = sqrtf((float)DH), rsqrt_dh = 1.f / sqrt_dh;
+    const float sqrt_dh = sqrtf((float)DH), rsqrt_dh = 1.f / sqrt_dh, c2 = rsqrt_dh * EMO_LOG2E;
     const int jl = wave * 16 + (lane & 15);
     const int64_t jg = k0 + jl;
     f32x4 dkacc[ND], dvacc[ND];
@@ -351,8 +361,8 @@ __global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const CT* __restrict
             for (int r = 0; r < 4; ++r) {
                 const int tl = tt * 16 + (lane >> 4) * 4 + r;
                 const int64_t tg = q0 + tl;
-                float p = 0.f, mult = 1.f;
-                if (jg <= tg && tg < T && jg < T) p = Img<CT>::ex((sizeof(CT) == 2 ? sa[r] * rsqrt_dh : sa[r] / sqrt_dh) - Lv[tl]);
+                float p = sizeof(CT) == 2 ? __builtin_amdgcn_exp2f(sa[r] * c2 - Lv[tl]) : Img<CT>::ex(sa[r] / sqrt_dh - Lv[tl]), mult = 1.f;
+                if (diag && jl > tl) p = 0.f;            // causal boundary only on the diagonal tile (rows past the end carry lse = +inf)
                 if (drop.thr16) mult = drop_mult(drop, (uint64_t)((bh * T + tg) * T + jg));
                 pd[tt][r] = p * mult;
                 ds[tt][r] = p * (dp[r] * mult - Dv[tl]);
