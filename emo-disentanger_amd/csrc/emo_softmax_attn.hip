@@ -41,6 +41,21 @@ __device__ __forceinline__ typename Img<CT>::V load_perm(const CT* img, int ld, 
         return p[(step >> 2) * 16 + (step & 3)];
     }
 }
+// bf16 only: the same permuted-k fragment of the TRANSPOSE of a row-major image rm[k][ld] (k = row index, operand rows = columns col0..col0+15),
+// fetched with ds_read_b64_tr_b16: per 16-lane group a [4 k][16 columns] block, lane i supplies the address of (row k0 + i/4, columns (i%4)*4..)
+// and receives column i.  Replaces the explicitly transposed V^T / K^T / Q^T / dO^T images (2-byte scattered LDS stores + a second prefetch).
+__device__ __forceinline__ bf16x8 load_perm_tr(const bf16_t* rm, int ld, int col0, int step, int lane) {
+    const int i = lane & 15, kc = lane >> 4;
+    bf16x8 v;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const bf16_t* p = rm + ((2 * step + h) * 16 + kc * 4 + (i >> 2)) * ld + col0 + (i & 3) * 4;
+        const short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
+        const bf16x4 tb = __builtin_bit_cast(bf16x4, t);
+        v[h * 4 + 0] = tb[0]; v[h * 4 + 1] = tb[1]; v[h * 4 + 2] = tb[2]; v[h * 4 + 3] = tb[3];
+    }
+    return v;
+}
 // the matching register operand built from s[jt][r]
 template <typename CT>
 __device__ __forceinline__ typename Img<CT>::V reg_perm(const float (&s)[4][4], int step) {
@@ -67,7 +82,8 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const CT* __restrict__ q
     extern __shared__ __attribute__((aligned(16))) char smem[];
     CT* Qi = (CT*)smem;          // [64][LDX]
     CT* Ki = Qi + 64 * LDX;      // [64][LDX]
-    CT* VT = Ki + 64 * LDX;      // [DH][LDC]
+    CT* VT = Ki + 64 * LDX;      // fp32: V^T [DH][LDC]; bf16: V row-major [64][LDX] read through ds_read_b64_tr_b16
+    constexpr bool TR = sizeof(CT) == 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t qt = (int64_t)gridDim.x - 1 - blockIdx.x;   // longest tiles first
     const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
@@ -77,7 +93,7 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const CT* __restrict__ q
     const CT* vb = v + (b * T) * ld + h * DH;
     const int qvalid = (int)((T - q0) < 64 ? (T - q0) : 64);
     RowPrefetch<CT, DH, DHP, 64, 256> pk;
-    RowPrefetch<CT, DH, DHP, 64, 256, true> pv;              // only stored transposed
+    RowPrefetch<CT, DH, DHP, 64, 256, !TR> pv;               // fp32: only stored transposed (row-fast mapping)
     {
         const int kv0 = (int)(T < 64 ? T : 64);
         pk.load(kb, ld, kv0, tid);
@@ -100,7 +116,7 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const CT* __restrict__ q
         const int64_t k0 = kt * 64;
         __syncthreads();                                     // every wave is done with the previous K / V images
         pk.store_rows(Ki, LDX, tid);
-        pv.store_T(VT, LDC, tid);
+        if constexpr (TR) pv.store_rows(VT, LDX, tid); else pv.store_T(VT, LDC, tid);
         if (kt < qt) {                                       // next key tile stays in flight during this tile's math
             const int64_t kn = k0 + 64;
             const int nv = (int)((T - kn) < 64 ? (T - kn) : 64);
@@ -157,7 +173,10 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const CT* __restrict__ q
         for (int st = 0; st < SaK<CT>::NS64; ++st) {
             const typename Img<CT>::V pf = reg_perm<CT>(s, st);
 #pragma unroll
-            for (int i = 0; i < ND; ++i) oacc[i] = Img<CT>::mma(load_perm<CT>(VT, LDC, i * 16, st, lane), pf, oacc[i]);
+            for (int i = 0; i < ND; ++i) {
+                if constexpr (TR) oacc[i] = Img<CT>::mma(load_perm_tr((const bf16_t*)VT, LDX, i * 16, st, lane), pf, oacc[i]);
+                else oacc[i] = Img<CT>::mma(load_perm<CT>(VT, LDC, i * 16, st, lane), pf, oacc[i]);
+            }
         }
     }
     if (tg < T) {
@@ -187,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_dq_kernel(const CT* __restri
     CT* Ki = dOi + 64 * LDX;      // [64][LDX]
     CT* Vi = Ki + 64 * LDX;       // [64][LDX]
     CT* KT = Vi + 64 * LDX;       // [DH][LDC]
-    float* Dv = (float*)(KT + DH * LDC);   // [64]
+    float* Dv = (float*)(KT + (sizeof(CT) == 2 ? 0 : DH * LDC));   // [64]  (bf16: no K^T image)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t qt = (int64_t)gridDim.x - 1 - blockIdx.x;
     const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
@@ -198,11 +217,13 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_dq_kernel(const CT* __restri
     const CT* ob = out + (b * T) * ld_out + h * DH;
     const CT* gb = dout + (b * T) * ld_out + h * DH;
     const int qvalid = (int)((T - q0) < 64 ? (T - q0) : 64);
+    constexpr bool TR = sizeof(CT) == 2;                     // bf16: K^T fragments come from Ki through ds_read_b64_tr_b16
     RowPrefetch<CT, DH, DHP, 64, 256> pk, pv;
     RowPrefetch<CT, DH, DHP, 64, 256, true> pkT;
     {
         const int kv0 = (int)(T < 64 ? T : 64);
-        pk.load(kb, ld, kv0, tid); pv.load(vb, ld, kv0, tid); pkT.load(kb, ld, kv0, tid);
+        pk.load(kb, ld, kv0, tid); pv.load(vb, ld, kv0, tid);
+        if constexpr (!TR) pkT.load(kb, ld, kv0, tid);
     }
     load_rows<CT, DH, DHP>(Qi, LDX, qb + q0 * ld, ld, 64, qvalid, tid);
     load_rows<CT, DH, DHP>(dOi, LDX, gb + q0 * ld_out, ld_out, 64, qvalid, tid);
@@ -229,11 +250,12 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_dq_kernel(const CT* __restri
         __syncthreads();
         pk.store_rows(Ki, LDX, tid);
         pv.store_rows(Vi, LDX, tid);
-        pkT.store_T(KT, LDC, tid);
+        if constexpr (!TR) pkT.store_T(KT, LDC, tid);
         if (kt < qt) {
             const int64_t kn = k0 + 64;
             const int nv = (int)((T - kn) < 64 ? (T - kn) : 64);
-            pk.load(kb + kn * ld, ld, nv, tid); pv.load(vb + kn * ld, ld, nv, tid); pkT.load(kb + kn * ld, ld, nv, tid);
+            pk.load(kb + kn * ld, ld, nv, tid); pv.load(vb + kn * ld, ld, nv, tid);
+            if constexpr (!TR) pkT.load(kb + kn * ld, ld, nv, tid);
         }
         __syncthreads();
         const bool diag = kt == qt;
@@ -265,7 +287,10 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_dq_kernel(const CT* __restri
         for (int st = 0; st < SaK<CT>::NS64; ++st) {
             const typename Img<CT>::V df = reg_perm<CT>(ds, st);
 #pragma unroll
-            for (int i = 0; i < ND; ++i) dqacc[i] = Img<CT>::mma(load_perm<CT>(KT, LDC, i * 16, st, lane), df, dqacc[i]);
+            for (int i = 0; i < ND; ++i) {
+                if constexpr (TR) dqacc[i] = Img<CT>::mma(load_perm_tr((const bf16_t*)Ki, LDX, i * 16, st, lane), df, dqacc[i]);
+                else dqacc[i] = Img<CT>::mma(load_perm<CT>(KT, LDC, i * 16, st, lane), df, dqacc[i]);
+            }
         }
     }
     if (tg < T) {
@@ -294,7 +319,7 @@ __global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 2 : 1)) void sattn_bwd_dkv_
     CT* dOi = Qi + 64 * LDX;      // [64][LDX]
     CT* QT = dOi + 64 * LDX;      // [DH][LDC]
     CT* dOT = QT + DH * LDC;      // [DH][LDC]
-    float* Dv = (float*)(dOT + DH * LDC);   // [64]
+    float* Dv = (float*)(QT + (sizeof(CT) == 2 ? 0 : 2 * DH * LDC));   // [64]  (bf16: no Q^T / dO^T images)
     float* Lv = Dv + 64;                    // [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t kt = blockIdx.x;
@@ -306,13 +331,15 @@ __global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 2 : 1)) void sattn_bwd_dkv_
     const CT* vb = v + (b * T) * ld + h * DH;
     const CT* gb = dout + (b * T) * ld_out + h * DH;
     const int kvalid = (int)((T - k0) < 64 ? (T - k0) : 64);
+    constexpr bool TR = sizeof(CT) == 2;                     // bf16: Q^T / dO^T fragments come from Qi / dOi through ds_read_b64_tr_b16
     RowPrefetch<CT, DH, DHP, 64, 256> pq, pg;
     RowPrefetch<CT, DH, DHP, 64, 256, true> pqT, pgT;
     float pl = 0.f, pd_ = 0.f;                                // lse / delta of row q0 + tid (tid < 64)
     auto fetch = [&](int64_t q0n) {
         const int nv = (int)((T - q0n) < 64 ? (T - q0n) : 64);
-        pq.load(qb + q0n * ld, ld, nv, tid); pqT.load(qb + q0n * ld, ld, nv, tid);
-        pg.load(gb + q0n * ld_out, ld_out, nv, tid); pgT.load(gb + q0n * ld_out, ld_out, nv, tid);
+        pq.load(qb + q0n * ld, ld, nv, tid);
+        pg.load(gb + q0n * ld_out, ld_out, nv, tid);
+        if constexpr (!TR) { pqT.load(qb + q0n * ld, ld, nv, tid); pgT.load(gb + q0n * ld_out, ld_out, nv, tid); }
         if (tid < 64) {
             const bool ok = q0n + tid < T;
             pl = ok ? lse_g[bh * T + q0n + tid] * (sizeof(CT) == 2 ? EMO_LOG2E : 1.f) : INFINITY;      // rows past the end: p = exp(-inf) = 0
@@ -340,8 +367,7 @@ __global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 2 : 1)) void sattn_bwd_dkv_
         __syncthreads();
         pq.store_rows(Qi, LDX, tid);
         pg.store_rows(dOi, LDX, tid);
-        pqT.store_T(QT, LDC, tid);
-        pgT.store_T(dOT, LDC, tid);
+        if constexpr (!TR) { pqT.store_T(QT, LDC, tid); pgT.store_T(dOT, LDC, tid); }
         if (tid < 64) { Lv[tid] = pl; Dv[tid] = pd_; }
         if (qt + 1 < nqt) fetch(q0 + 64);
         __syncthreads();
@@ -374,8 +400,13 @@ __global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 2 : 1)) void sattn_bwd_dkv_
             const typename Img<CT>::V pf = reg_perm<CT>(pd, st), df = reg_perm<CT>(ds, st);
 #pragma unroll
             for (int i = 0; i < ND; ++i) {
-                dvacc[i] = Img<CT>::mma(load_perm<CT>(dOT, LDC, i * 16, st, lane), pf, dvacc[i]);
-                dkacc[i] = Img<CT>::mma(load_perm<CT>(QT, LDC, i * 16, st, lane), df, dkacc[i]);
+                if constexpr (TR) {
+                    dvacc[i] = Img<CT>::mma(load_perm_tr((const bf16_t*)dOi, LDX, i * 16, st, lane), pf, dvacc[i]);
+                    dkacc[i] = Img<CT>::mma(load_perm_tr((const bf16_t*)Qi, LDX, i * 16, st, lane), df, dkacc[i]);
+                } else {
+                    dvacc[i] = Img<CT>::mma(load_perm<CT>(dOT, LDC, i * 16, st, lane), pf, dvacc[i]);
+                    dkacc[i] = Img<CT>::mma(load_perm<CT>(QT, LDC, i * 16, st, lane), df, dkacc[i]);
+                }
             }
         }
     }
@@ -478,9 +509,9 @@ __global__ __launch_bounds__(256) void sattn_decode_kernel(const CT* __restrict_
 }
 
 // =============================================================================================== host
-template <typename CT, int DH> static size_t sa_fwd_lds() { typedef SaDims<CT, DH> D; return sizeof(CT) * (size_t)(2 * 64 * D::LDX + DH * D::LDC); }
-template <typename CT, int DH> static size_t sa_dq_lds() { typedef SaDims<CT, DH> D; return sizeof(CT) * (size_t)(4 * 64 * D::LDX + DH * D::LDC) + 64 * sizeof(float); }
-template <typename CT, int DH> static size_t sa_dkv_lds() { typedef SaDims<CT, DH> D; return sizeof(CT) * (size_t)(4 * 64 * D::LDX + 2 * DH * D::LDC) + 128 * sizeof(float); }
+template <typename CT, int DH> static size_t sa_fwd_lds() { typedef SaDims<CT, DH> D; return sizeof(CT) * (size_t)(2 * 64 * D::LDX + CMax<DH * D::LDC, 64 * D::LDX>::v); }
+template <typename CT, int DH> static size_t sa_dq_lds() { typedef SaDims<CT, DH> D; return sizeof(CT) * (size_t)(4 * 64 * D::LDX + (sizeof(CT) == 2 ? 0 : DH * D::LDC)) + 64 * sizeof(float); }
+template <typename CT, int DH> static size_t sa_dkv_lds() { typedef SaDims<CT, DH> D; return sizeof(CT) * (size_t)(4 * 64 * D::LDX + (sizeof(CT) == 2 ? 0 : 2 * DH * D::LDC)) + 128 * sizeof(float); }
 
 template <typename CT, int DH>
 static int run_sattn(int which, const void* q, const void* k, const void* v, int64_t ld, const void* out, const void* dout, int64_t ld_out, float* lse,
