@@ -1,0 +1,57 @@
+"""CPU: the stage-1 (Transformer-XL lead-sheet LM) oracle restatement against fixtures recorded from the IMPORTED reference
+(tools/make_golden_stage1.py).  Test infrastructure for the next hot-path row: no product code involved yet."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+CASES = sorted(json.load(open(os.path.join(G, 'txl_manifest.json'))).items())
+
+
+@pytest.mark.parametrize('name,c', CASES)
+def test_txl_oracle_forward_loss_and_grads_match_reference(name, c):
+    from oracle import txl_ref
+    g = np.load(os.path.join(G, name + '.npz'))
+    sd = txl_ref.make_state_dict_txl(c['V'], c['L'], c['H'], c['d'], c['dff'], seed=c['seed'], scale=c['scale'])
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != 'decoder.pos_emb.inv_freq'}
+    leaf['decoder.pos_emb.inv_freq'] = sd['decoder.pos_emb.inv_freq']
+    x, tgt = torch.from_numpy(g['x']), torch.from_numpy(g['tgt'])
+    logits, mems = txl_ref.forward(leaf, x, c['L'], c['H'])
+    assert mems is None
+    lg = logits.detach()
+    np.testing.assert_allclose(lg[..., :8].numpy(), g['logits_head'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(torch.logsumexp(lg, -1).numpy(), g['logits_lse'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(lg[0].numpy(), g['logits_row0'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(lg[-1].numpy(), g['logits_rowlast'], rtol=0, atol=2e-5)
+    loss = txl_ref.loss(leaf, logits, tgt)
+    assert abs(float(loss.detach()) - float(g['loss'])) < 1e-5
+    loss.backward()
+    names = [str(n) for n in g['grad_names']]
+    assert names == [k for k in sd if k != 'decoder.pos_emb.inv_freq']            # parameter registration order = optimizer state order
+    for n, ref in zip(names, g['grad_norms']):
+        got = float(leaf[n].grad.norm())
+        assert abs(got - ref) <= 2e-4 * max(ref, 1e-3), (n, got, ref)
+    # the embedding's padding row (index V-1) never appears in x here; F.embedding in the oracle has no padding_idx, the reference does:
+    # equal gradients as long as the pad id is not an input token (stage-1 batches pad only the targets' tail)
+    assert int((x == c['V'] - 1).sum()) == 0
+
+
+@pytest.mark.parametrize('name,c', CASES)
+def test_txl_oracle_generation_with_memory_matches_reference(name, c):
+    from oracle import txl_ref
+    g = np.load(os.path.join(G, name + '.npz'))
+    sd = txl_ref.make_state_dict_txl(c['V'], c['L'], c['H'], c['d'], c['dff'], seed=c['seed'], scale=c['scale'])
+    x = torch.from_numpy(g['x'])
+    prime, mem_len = c['T'] // 2, c['T']
+    with torch.no_grad():
+        lg, mems = txl_ref.forward(sd, x[:prime, :1], c['L'], c['H'], mems=None, mem_len=mem_len)
+        outs = [lg[-1, 0].numpy()]
+        for i in range(c['gen']):
+            lg, mems = txl_ref.forward(sd, x[prime + i:prime + i + 1, :1], c['L'], c['H'], mems=mems, mem_len=mem_len)
+            outs.append(lg[-1, 0].numpy())
+    np.testing.assert_allclose(np.stack(outs), g['gen_logits'], rtol=0, atol=3e-5)
+    assert mems[0].shape[0] == int(g['mem_len_after'])
+    np.testing.assert_allclose(outs[-1], g['gen_full_last'], rtol=0, atol=5e-5)   # cached steps == full recompute of the prefix
