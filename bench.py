@@ -45,7 +45,8 @@ def time_kernel(fn, iters=10, warm=3):
 
 
 GEMM_KERNELS = {   # layout class of ops.gemm -> the kernel instance it launches at the bench shapes (names as in the rocprofv3 summary)
-    'TN': ('gemm_bf16_kernel<false,false,false,float,64> + splitk_reduce_kernel', 'wgrad dW = dY^T X, reduction over the B*T tokens'),
+    'TN': ('gemm_bf16_kernel<false,false,false,float,64,RS> (RS=1: with the bias gradient, RS=0: without) + splitk_reduce_kernel',
+           'wgrad dW = dY^T X, reduction over the B*T tokens'),
     'NN': ('gemm_bf16_glds_kernel<true,false,bf16,32,2>', 'dgrad dX = dY W'),
     'NT': ('gemm_bf16_glds_kernel<true,true,bf16,32,3>', 'forward Y = X W^T + fused epilogue, K = 512'),
     'NT/K>1024': ('gemm_bf16_glds_kernel<true,true,bf16,64,2>', 'forward Y = X W^T + fused epilogue, K = 2048'),

@@ -456,8 +456,10 @@ __device__ __forceinline__ bf16x8 lfrag(const char* lds, int rbase, int ks, int 
     }
 }
 
-template <bool A_KC, bool B_KC, bool SAFE, typename OutT, int BKT = GB_K>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda,
+// RS: 0 = plain, 1 = also a_rowsum, 2 = also b_rowsum (separate instances so that the plain wgrad carries neither the extra accumulators nor
+// the branches; the register cap keeps two blocks per CU)
+template <bool A_KC, bool B_KC, bool SAFE, typename OutT, int BKT = GB_K, int RS = 0>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                         const bf16_t* __restrict__ B, int64_t ldb,
                                                         OutT* __restrict__ C, int64_t M, int64_t N, int64_t K,
                                                         int64_t k_per_split, EpiParams ep) {
@@ -484,12 +486,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // bias gradient for free: rowsum_k A[m][k] = A . 1 is one more MFMA per A fragment with an all-ones operand (the A fragments are in
-    // registers anyway); only the tn == 0 column of blocks and its wn == 0 waves do it (r01: the separate column-sum launches were 2 ms/step).
-    const bool do_rs = ep.a_rowsum != nullptr && tn == 0 && wn == 0;
-    const bool do_bs = ep.b_rowsum != nullptr && tm == 0 && wm == 0;
-    f32x4 rsacc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rsacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // registers anyway; r01: the separate column-sum launches were 2 ms/step).  All tiles_n blocks of a row of tiles see the same A tile, so
+    // block tn takes the K steps with step % tiles_n == tn and each of its two waves along n takes half of the 4 fragments: +2 MFMAs on
+    // 1/tiles_n of the steps, evenly spread (doing it all in the tn == 0 blocks made those blocks 18 % slower and the kernel with them).
+    constexpr bool do_rs = RS == 1, do_bs = RS == 2;
+    f32x4 rsacc[2];
+    rsacc[0] = rsacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bf16_t one_b = (bf16_t)1.f;
     const bf16x8 ones = {one_b, one_b, one_b, one_b, one_b, one_b, one_b, one_b};
 
@@ -500,6 +502,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     lstore_tile<B_KC, BKT>(smem + OPB, tid, rb);
     __syncthreads();
     int cur = 0;
+    int rs_n = (int)((kbeg / BKT) % tiles_n), rs_m = (int)((kbeg / BKT) % tiles_m);   // which block of the tile row / column owns this K step's rowsum
     for (int64_t k0 = kbeg; k0 < kend; k0 += BKT) {
         const bool more = (k0 + BKT) < kend;
         if (more) {
@@ -520,12 +523,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-            if (do_rs) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rsacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i], rsacc[i], 0, 0, 0);
-            } else if (do_bs) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) rsacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], ones, rsacc[j], 0, 0, 0);
+            if (do_rs && rs_n == (int)tn) {
+                if (wn == 0) {                         // wave-uniform branches: constant register indices, no selects
+                    rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[0], rsacc[0], 0, 0, 0);
+                    rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[1], rsacc[1], 0, 0, 0);
+                } else {
+                    rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[2], rsacc[0], 0, 0, 0);
+                    rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[3], rsacc[1], 0, 0, 0);
+                }
+            } else if (do_bs && rs_m == (int)tm) {
+                if (wm == 0) {
+                    rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], ones, rsacc[0], 0, 0, 0);
+                    rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], ones, rsacc[1], 0, 0, 0);
+                } else {
+                    rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[2], ones, rsacc[0], 0, 0, 0);
+                    rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[3], ones, rsacc[1], 0, 0, 0);
+                }
             }
         }
         if (more) {
@@ -535,19 +548,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
         }
         __syncthreads();
         cur ^= 1;
+        if (++rs_n == (int)tiles_n) rs_n = 0;
+        if (++rs_m == (int)tiles_m) rs_m = 0;
     }
     if (do_rs && (lane >> 4) == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
+        for (int i = 0; i < 2; ++i) {
+            const int64_t m = m0 + wm * 64 + (2 * wn + i) * 16 + (lane & 15);
             if (m < M) atomicAdd(ep.a_rowsum + m, rsacc[i][0]);
         }
     } else if (do_bs && !do_rs && (lane & 15) == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4 + r;
+                const int64_t n = n0 + wn * 64 + (2 * wm + j) * 16 + (lane >> 4) * 4 + r;
                 if (n < N) atomicAdd(ep.b_rowsum + n, rsacc[j][r]);
             }
     }
@@ -1028,6 +1043,21 @@ static bool use_safe_tr() {
 template <bool A_KC, bool B_KC, bool SAFE, typename OutT>
 static void launch_bf16(dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C,
                         int64_t M, int64_t N, int64_t K, int64_t kps, const EpiParams& ep) {
+    if constexpr (!A_KC && !B_KC && !SAFE && sizeof(OutT) == 4) {       // the wgrad layout: bias-gradient variants
+        if (ep.a_rowsum || ep.b_rowsum) {
+            auto k1 = gemm_bf16_kernel<A_KC, B_KC, SAFE, OutT, GB_K, 1>;
+            auto k2 = gemm_bf16_kernel<A_KC, B_KC, SAFE, OutT, GB_K, 2>;
+            static bool attr_rs = false;
+            if (!attr_rs) {
+                (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+                (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+                attr_rs = true;
+            }
+            if (ep.a_rowsum) hipLaunchKernelGGL(k1, grid, dim3(256), 65536, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
+            else hipLaunchKernelGGL(k2, grid, dim3(256), 65536, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
+            return;
+        }
+    }
     auto kfn = gemm_bf16_kernel<A_KC, B_KC, SAFE, OutT>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1593,7 +1623,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     EMO_CHECK(!(ep.a_rowsum && ep.b_rowsum), "emo_gemm: a_rowsum and b_rowsum are exclusive");
     if (ep.b_rowsum) {
         EMO_CHECK(a_trans && b_trans, "emo_gemm: b_rowsum needs a_trans and b_trans (B stored [K, N]: the Conv1D wgrad layout)");
-        const bool in_kernel = dtype_in == EMO_BF16 && gemm_variant() < 3 && !use_safe_tr() && getenv("EMO_GEMM_TN32") == nullptr &&
+        const bool in_kernel = dtype_in == EMO_BF16 && dtype_out == EMO_F32 && gemm_variant() < 3 && !use_safe_tr() && getenv("EMO_GEMM_TN32") == nullptr &&
                                getenv("EMO_GEMM_FORCE_G3") == nullptr && getenv("EMO_GEMM_NO_ROWSUM_FUSE") == nullptr;
         if (!in_kernel) {
             const int rc = emo_colsum(B, dtype_in, K, N, ldb, ep.b_rowsum, 1, stream);
@@ -1603,8 +1633,8 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     }
     if (ep.a_rowsum) {
         EMO_CHECK(a_trans, "emo_gemm: a_rowsum needs a_trans (A stored [K, M]: the wgrad layout)");
-        const bool in_kernel = dtype_in == EMO_BF16 && gemm_variant() < 3 && !use_safe_tr() && getenv("EMO_GEMM_TN32") == nullptr &&
-                               getenv("EMO_GEMM_FORCE_G3") == nullptr && getenv("EMO_GEMM_NO_ROWSUM_FUSE") == nullptr;
+        const bool in_kernel = dtype_in == EMO_BF16 && dtype_out == EMO_F32 && b_trans && gemm_variant() < 3 && !use_safe_tr() &&
+                               getenv("EMO_GEMM_TN32") == nullptr && getenv("EMO_GEMM_FORCE_G3") == nullptr && getenv("EMO_GEMM_NO_ROWSUM_FUSE") == nullptr;
         if (!in_kernel) {                                   // other kernels: the plain column-sum launch over A [K, M]
             const int rc = emo_colsum(A, dtype_in, K, M, lda, ep.a_rowsum, 1, stream);
             if (rc) return rc;
