@@ -106,9 +106,9 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
     return roof
 
 
-def generation_bench(model, n_streams=32, prompt=64, n_new=256, top_p=0.9, temp=1.1):
-    """BASELINE configs[3] (bounded): 32 parallel streams, nucleus p=0.9, recurrent FAVOR+ state in HBM, hipGraph-replayed
-    decode step; tokens/s = streams * new tokens / wall time (prefill of the 64-token prompt included)."""
+def generation_bench(model, n_streams=32, prompt=64, n_new=2048 - 64, top_p=0.9, temp=1.1):
+    """BASELINE configs[3]: 32 parallel streams, 64-token prompt, generate to 2048 tokens, nucleus p=0.9, recurrent FAVOR+ state in HBM,
+    hipGraph-replayed decode step; tokens/s = streams * new tokens / wall time (engine set-up, prefill of the prompt and graph capture included)."""
     from emo_disentanger_amd import inference as inf
     dev = next(model.parameters()).device
     g = torch.Generator().manual_seed(7)
