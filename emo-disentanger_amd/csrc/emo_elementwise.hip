@@ -548,33 +548,33 @@ extern "C" int emo_accuracy_counts(const float* logits, const int64_t* tgt, cons
 }
 
 // ================================================================================================ K10 nucleus sampling
-// One 256-thread block per stream.  probs = softmax(l/temp) (fp32, as NumPy on fp32 logits); rank sort (descending, ties by
+// One 512-thread block per stream.  probs = softmax(l/temp) (fp32, as NumPy on fp32 logits); rank sort (descending, ties by
 // ascending index) of <= 1024 entries in LDS; inclusive cumsum in np.cumsum's sequential fp32 order; last_index = SECOND position
 // whose cumsum exceeds top_p (reference inference.py:93-94 keeps the crossing token — SURVEY F12); where the reference would raise
 // IndexError (single crossing) all sorted tokens are kept.  Draw: cdf over the renormalised (f64) candidates, searchsorted(u, right).
 // Serial work is two tight prefix scans (fp32 by wave 0, f64 by wave 1, concurrently); because both prefixes are monotone the
 // crossing positions are COUNTS (#{cum <= top_p}, #{run <= target}) taken by all threads.  r01: 62 us (bitonic network + three
 // branchy single-thread loops) -> see profiles.
-__global__ __launch_bounds__(256) void nucleus_kernel(const float* __restrict__ logits, int64_t V, float temp, float top_p,
+__global__ __launch_bounds__(512) void nucleus_kernel(const float* __restrict__ logits, int64_t V, float temp, float top_p,
                                                       const float* __restrict__ u, int64_t* __restrict__ out, int64_t* __restrict__ step,
                                                       int64_t* __restrict__ seq, int64_t ld_seq, int64_t col0) {
     __shared__ __attribute__((aligned(16))) float sp[1024 + 8], sq[1024 + 8], cumf[1024 + 8];
     __shared__ __attribute__((aligned(16))) double cumd[1024 + 8];
     __shared__ int si[1024];
-    __shared__ float red[4];
-    __shared__ int cnt[4];
+    __shared__ float red[8];
+    __shared__ int cnt[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* l = logits + (int64_t)blockIdx.x * V;
     const int Vp = ((int)V + 7) & ~7;
     float mx = -INFINITY;
-    for (int c = tid; c < V; c += 256) mx = fmaxf(mx, l[c] / temp);
+    for (int c = tid; c < V; c += 512) mx = fmaxf(mx, l[c] / temp);
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
     __syncthreads();
     float s = 0.f;
-    for (int c = tid; c < V; c += 256) {
+    for (int c = tid; c < V; c += 512) {
         const float e = expf(l[c] / temp - mx);
         sp[c] = e;
         s += e;
@@ -582,11 +582,11 @@ __global__ __launch_bounds__(256) void nucleus_kernel(const float* __restrict__ 
     s = wave_sum(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
-    const float tot = red[0] + red[1] + red[2] + red[3];
-    for (int c = tid; c < V; c += 256) sq[c] = sp[c] / tot;
-    for (int c = (int)V + tid; c < Vp + 8; c += 256) sq[c] = -1.f;        // never greater than or equal to a probability
+    const float tot = red[0] + red[1] + red[2] + red[3] + red[4] + red[5] + red[6] + red[7];
+    for (int c = tid; c < V; c += 512) sq[c] = sp[c] / tot;
+    for (int c = (int)V + tid; c < Vp + 8; c += 512) sq[c] = -1.f;        // never greater than or equal to a probability
     __syncthreads();
-    for (int c = tid; c < Vp; c += 256) {
+    for (int c = tid; c < Vp; c += 512) {
         if (c < V) {
             const float pc = sq[c];
             int rank = 0;
@@ -625,11 +625,11 @@ __global__ __launch_bounds__(256) void nucleus_kernel(const float* __restrict__ 
     __syncthreads();
     // first crossing i1 = #{i < V : cum_i <= top_p}; cum is non-decreasing, so the second crossing is i1 + 1
     int c1 = 0;
-    for (int i = tid; i < V; i += 256) c1 += (cumf[i] <= top_p) ? 1 : 0;
+    for (int i = tid; i < V; i += 512) c1 += (cumf[i] <= top_p) ? 1 : 0;
     c1 = (int)wave_sum((float)c1);
     if (lane == 0) cnt[wave] = c1;
     __syncthreads();
-    const int i1 = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    const int i1 = cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4] + cnt[5] + cnt[6] + cnt[7];
     int last;
     if (i1 >= V) last = V < 3 ? (int)V : 3;       // no crossing
     else if (i1 + 1 >= V) last = (int)V;          // single crossing (reference: IndexError)
@@ -638,12 +638,12 @@ __global__ __launch_bounds__(256) void nucleus_kernel(const float* __restrict__ 
     const double target = (double)u[kstep * gridDim.x + blockIdx.x] * cumd[last - 1];
     __syncthreads();
     int c2 = 0;
-    for (int i = tid; i < last; i += 256) c2 += (cumd[i] <= target) ? 1 : 0;
+    for (int i = tid; i < last; i += 512) c2 += (cumd[i] <= target) ? 1 : 0;
     c2 = (int)wave_sum((float)c2);
     if (lane == 0) cnt[wave] = c2;
     __syncthreads();
     if (tid == 0) {
-        int pick = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        int pick = cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4] + cnt[5] + cnt[6] + cnt[7];
         if (pick >= last) pick = last - 1;
         out[blockIdx.x] = (int64_t)si[pick];
         if (seq) seq[(int64_t)blockIdx.x * ld_seq + col0 + kstep] = (int64_t)si[pick];
@@ -655,7 +655,7 @@ extern "C" int emo_sample_nucleus(const float* logits, int64_t rows, int64_t V, 
     EMO_CHECK(logits && u && out && rows > 0, "emo_sample_nucleus: bad args");
     EMO_CHECK(V > 0 && V <= 1024, "emo_sample_nucleus: V must be <= 1024 (got %lld)", (long long)V);
     EMO_CHECK(temperature > 0.f, "emo_sample_nucleus: temperature must be > 0");
-    hipLaunchKernelGGL(nucleus_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, V, temperature, top_p, u, out, (int64_t*)nullptr,
+    hipLaunchKernelGGL(nucleus_kernel, dim3((unsigned)rows), dim3(512), 0, (hipStream_t)stream, logits, V, temperature, top_p, u, out, (int64_t*)nullptr,
                        (int64_t*)nullptr, (int64_t)0, (int64_t)0);
     EMO_LAUNCH_CHECK();
     return EMO_OK;
@@ -665,7 +665,7 @@ extern "C" int emo_sample_nucleus_step(const float* logits, int64_t rows, int64_
     EMO_CHECK(logits && u_steps && out && step && rows > 0, "emo_sample_nucleus_step: bad args");
     EMO_CHECK(V > 0 && V <= 1024, "emo_sample_nucleus_step: V must be <= 1024 (got %lld)", (long long)V);
     EMO_CHECK(temperature > 0.f, "emo_sample_nucleus_step: temperature must be > 0");
-    hipLaunchKernelGGL(nucleus_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, V, temperature, top_p, u_steps, out, step, seq,
+    hipLaunchKernelGGL(nucleus_kernel, dim3((unsigned)rows), dim3(512), 0, (hipStream_t)stream, logits, V, temperature, top_p, u_steps, out, step, seq,
                        ld_seq, col0);
     EMO_LAUNCH_CHECK();
     return EMO_OK;

@@ -1005,6 +1005,13 @@ __global__ __launch_bounds__(256) void favor_decode_fast_kernel(const CT* __rest
         const int f = g + R * i;
         st[i] = f < F ? *(const f32x4*)(Sb + f * DH + d4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    // the omega column and z of this thread's feature do not depend on q / k either: requested before the barrier, next to the state
+    float wcol[DH], zold = 0.f;
+    if (tid < F) {
+#pragma unroll
+        for (int d = 0; d < DH; ++d) wcol[d] = omega[d * MF + (tid % MF)];
+        zold = state_z[sh * F + tid];
+    }
     if (tid < DH) {
         xq[tid] = to_f32<CT>(q[s * ld + h * DH + tid]);
         xk[tid] = to_f32<CT>(k[s * ld + h * DH + tid]);
@@ -1014,12 +1021,11 @@ __global__ __launch_bounds__(256) void favor_decode_fast_kernel(const CT* __rest
     const float cs = rsqrtf(sqrtf((float)DH)), half_ln_f = 0.5f * logf((float)F);
     float dn = 0.f;
     if (tid < F) {
-        const int m = tid % MF;
         const float sgn = tid < MF ? 1.f : -1.f;
         float uq = 0.f, uk = 0.f, nq = 0.f, nk = 0.f;
 #pragma unroll
         for (int d = 0; d < DH; ++d) {
-            const float w = omega[d * MF + m];
+            const float w = wcol[d];
             uq += xq[d] * w; uk += xk[d] * w;
             nq += xq[d] * xq[d]; nk += xk[d] * xk[d];
         }
@@ -1027,7 +1033,7 @@ __global__ __launch_bounds__(256) void favor_decode_fast_kernel(const CT* __rest
         const float pk = __expf(sgn * cs * uk - (0.5f * cs * cs * nk + half_ln_f));
         fq[tid] = pq;
         fk[tid] = pk;
-        const float z = state_z[sh * F + tid] + pk;
+        const float z = zold + pk;
         state_z[sh * F + tid] = z;
         dn = pq * z;
     }
