@@ -887,7 +887,8 @@ static void dispatch_g3(bool akc, bool bkc, dim3 grid, hipStream_t st, const bf1
 // One wave per 16 output columns, the whole K loop in registers: weight rows (nn.Linear [N,K]) and the M
 // activation rows are fetched as MFMA fragments straight from global memory (16 B per lane, no LDS —
 // the guide's rule for M <= 16 GEMV-like shapes), 4 K-steps of loads in flight.
-template <typename OutT, int NW = 4>
+// CW: k width of a wave's chunk (128; 64 for the 16-wave K = 2048 variant so that the 16 tiles fit the LDS)
+template <typename OutT, int NW = 4, int CW = 128>
 __global__ __launch_bounds__(64 * NW) void gemm_bf16_skinny_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                                OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, EpiParams ep) {
     // block = 16 output columns; its NW waves split the K range (shorter dependent chains, NW x the loads in flight) and
@@ -905,7 +906,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_skinny_kernel(const bf16_t*
     // so the kernel multiplies the RAW rows by the gamma-scaled weights (prepared once by the caller, like c1 and the folded bias), gets
     // mean / rstd of its A rows from the fragments it loads anyway, and applies them in the epilogue (ep.ln_c1).  A residual that is itself
     // a LayerNorm output is rebuilt from the raw tensor and the statistics an earlier kernel exported (ep.rln_*, ep.ln_stats_out).
-    constexpr int LDT = 144, TROWS = 48;                    // tile rows 0..31: A, 32..47: B
+    constexpr int LDT = CW + 16, TROWS = 48;                // tile rows 0..31: A, 32..47: B; row stride = 8 (mod 16) dwords
+    constexpr int CPR = CW / 8, RPI = 64 / CPR, NA = 32 / RPI, NB = 16 / RPI;   // 16-B chunks per row, rows per load instruction, loads per lane
     extern __shared__ __attribute__((aligned(16))) char skinny_smem[];
     bf16_t* tile = (bf16_t*)skinny_smem + (threadIdx.x >> 6) * (TROWS * LDT);
     f32x4 (*red)[2][64] = (f32x4 (*)[2][64])(skinny_smem + (size_t)NW * TROWS * LDT * sizeof(bf16_t));
@@ -917,44 +919,44 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_skinny_kernel(const bf16_t*
     int64_t ke = kb + kq;
     if (ke > K) ke = K;
     // loader mapping: item = lane + 64 j -> (row = item / 16, 16-B chunk = item % 16); A: j < 8 (32 rows), B: j < 4 (16 rows)
-    const int lrow = lane >> 4, lch = lane & 15;
-    const bf16_t* ga[8];
-    const bf16_t* gb[4];
+    const int lrow = lane / CPR, lch = lane % CPR;
+    const bf16_t* ga[NA];
+    const bf16_t* gb[NB];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        int64_t m = lrow + 4 * j;
+    for (int j = 0; j < NA; ++j) {
+        int64_t m = lrow + RPI * j;
         if (m > M - 1) m = M - 1;
         ga[j] = A + m * lda + lch * 8;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int64_t nn = n0 + lrow + 4 * j;
+    for (int j = 0; j < NB; ++j) {
+        int64_t nn = n0 + lrow + RPI * j;
         if (nn > N - 1) nn = N - 1;
         gb[j] = B + nn * ldb + lch * 8;
     }
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const bool ln = ep.ln_c1 != nullptr;
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;        // sum / sum of squares of this lane's slices of rows (lane&15) / 16 + (lane&15)
-    bf16x8 ra[8], rb[4];
+    bf16x8 ra[NA], rb[NB];
     const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
     auto fetch = [&](int64_t k) {
-        const bool ok = k + lch * 8 < ke;                   // chunk tail (ke - k < 128): the missing k columns read as zeros
+        const bool ok = k + lch * 8 < ke;                   // chunk tail (ke - k < CW): the missing k columns read as zeros
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ra[j] = ok ? *(const bf16x8*)(ga[j] + k) : zero8;
+        for (int j = 0; j < NA; ++j) ra[j] = ok ? *(const bf16x8*)(ga[j] + k) : zero8;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rb[j] = ok ? *(const bf16x8*)(gb[j] + k) : zero8;
+        for (int j = 0; j < NB; ++j) rb[j] = ok ? *(const bf16x8*)(gb[j] + k) : zero8;
     };
     if (kb < ke) fetch(kb);
-    for (int64_t k = kb; k < ke; k += 128) {
+    for (int64_t k = kb; k < ke; k += CW) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *(bf16x8*)(tile + (lrow + 4 * j) * LDT + lch * 8) = ra[j];
+        for (int j = 0; j < NA; ++j) *(bf16x8*)(tile + (lrow + RPI * j) * LDT + lch * 8) = ra[j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *(bf16x8*)(tile + (32 + lrow + 4 * j) * LDT + lch * 8) = rb[j];
-        if (k + 128 < ke) fetch(k + 128);                   // in flight during this chunk's MFMAs
+        for (int j = 0; j < NB; ++j) *(bf16x8*)(tile + (32 + lrow + RPI * j) * LDT + lch * 8) = rb[j];
+        if (k + CW < ke) fetch(k + CW);                     // in flight during this chunk's MFMAs
         __builtin_amdgcn_wave_barrier();                    // wave-private tile: LDS operations of one wave complete in program order
-        const int steps = (int)(((ke - k) < 128 ? (ke - k) : 128) / 32);
+        const int steps = (int)(((ke - k) < CW ? (ke - k) : CW) / 32);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CW / 32; ++u) {
             if (u < steps) {
                 const bf16x8 fb = *(const bf16x8*)(tile + (32 + (lane & 15)) * LDT + u * 32 + (lane >> 4) * 8);
                 const bf16x8 fa0 = *(const bf16x8*)(tile + (lane & 15) * LDT + u * 32 + (lane >> 4) * 8);
@@ -1646,17 +1648,17 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     if (big && M <= 32 && !a_trans && !b_trans && (K % 32) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0 &&
         !accumulate && getenv("EMO_GEMM_NO_SKINNY") == nullptr) {
         dim3 g((unsigned)cdiv64(N, 16));
-        const int nw = K >= 1024 ? 8 : 4;
-#define SKINNY_LAUNCH(OutT, NWv)                                                                                                            \
+        const int nw = (K >= 2048 && getenv("EMO_SKINNY_NW8") == nullptr) ? 16 : (K >= 1024 ? 8 : 4);   // 16 waves x two 64-wide chunks at K = 2048
+#define SKINNY_LAUNCH(OutT, NWv, CWv)                                                                                                       \
     do {                                                                                                                                    \
-        constexpr size_t lds_ = (size_t)NWv * 48 * 144 * 2 + sizeof(f32x4) * (NWv - 1) * 2 * 64 + sizeof(float) * NWv * 2 * 16 * 2;          \
-        auto kfn = gemm_bf16_skinny_kernel<OutT, NWv>;                                                                                      \
+        constexpr size_t lds_ = (size_t)NWv * 48 * (CWv + 16) * 2 + sizeof(f32x4) * (NWv - 1) * 2 * 64 + sizeof(float) * NWv * 2 * 16 * 2;   \
+        auto kfn = gemm_bf16_skinny_kernel<OutT, NWv, CWv>;                                                                                 \
         static bool attr_ = false;                                                                                                          \
         if (!attr_) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); attr_ = true; }   \
         hipLaunchKernelGGL(kfn, g, dim3(64 * NWv), lds_, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (OutT*)C, M, N, K, ep);          \
     } while (0)
-        if (dtype_out == EMO_F32) { if (nw == 8) SKINNY_LAUNCH(float, 8); else SKINNY_LAUNCH(float, 4); }
-        else { if (nw == 8) SKINNY_LAUNCH(bf16_t, 8); else SKINNY_LAUNCH(bf16_t, 4); }
+        if (dtype_out == EMO_F32) { if (nw == 16) SKINNY_LAUNCH(float, 16, 64); else if (nw == 8) SKINNY_LAUNCH(float, 8, 128); else SKINNY_LAUNCH(float, 4, 128); }
+        else { if (nw == 16) SKINNY_LAUNCH(bf16_t, 16, 64); else if (nw == 8) SKINNY_LAUNCH(bf16_t, 8, 128); else SKINNY_LAUNCH(bf16_t, 4, 128); }
 #undef SKINNY_LAUNCH
         EMO_LAUNCH_CHECK();
         return EMO_OK;
