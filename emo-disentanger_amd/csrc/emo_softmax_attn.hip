@@ -613,3 +613,354 @@ extern "C" int emo_softmax_attn_decode(const void* q, int64_t ld_q, void* kcache
     EMO_LAUNCH_CHECK();
     return EMO_OK;
 }
+
+// =============================================================================================== relative-position attention (stage-1 Transformer-XL)
+// RelPartialLearnableMultiHeadAttn (stage1_compose/model/optimus_txl_decoder.py:301-391), forward + one-query decode.
+//   score[i][j] = ((q_i + u).k_j + (q_i + v).R[dist])/sqrt(dh),  dist = i - j >= 0   (u = r_w_bias, v = r_r_bias, R = r_net(pos_emb))
+// The reference materialises BD = (q+v).R^T for all positions and re-labels it with the pad-and-view trick `_rel_shift` (:280-293); R only
+// depends on the distance, so the caller passes r_dist [n_dist, H*dh] indexed BY DISTANCE and the kernel gathers.  Tile kernel = the flash
+// forward above plus, per key tile, one more product P2[c][t] = Rwin[c].(q_t + v) over the 80 distances c a wave's 16 rows can see; the
+// skew c = t - j + 63 moves P2 between lanes through a small wave-private LDS buffer.  Probabilities: softmax -> dropout -> p / (sum p + 1e-8)
+// (:361-363); the kernel tracks l = sum e and E = sum drop(e) online, out = sum drop(e) v / (E + 1e-8 l); zden = E / l + 1e-8 saved with lse.
+template <typename CT, int DH>
+__global__ __launch_bounds__(256) void relattn_fwd_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+                                                          const CT* __restrict__ rd, int64_t ld_r, int64_t n_dist, const float* __restrict__ ub,
+                                                          const float* __restrict__ vb_, CT* __restrict__ out, int64_t ld_out, float* __restrict__ lse_g,
+                                                          float* __restrict__ zden_g, int64_t T, int64_t H, DropCtx drop) {
+    typedef SaDims<CT, DH> D;
+    constexpr int LDX = D::LDX, LDC = D::LDC, DHP = D::DHP, ND = DH / 16, NQ = DHP / Img<CT>::KSTEP, SKW = 84;
+    constexpr bool TR = sizeof(CT) == 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    CT* Qi = (CT*)smem;                       // [64][LDX]  (q + u, then q + v: only to build the register fragments)
+    CT* Ki = Qi + 64 * LDX;                   // [64][LDX]
+    CT* VT = Ki + 64 * LDX;                   // fp32: V^T [DH][LDC]; bf16: V row-major [64][LDX]
+    CT* Rw = VT + CMax<DH * LDC, 64 * LDX>::v;   // [128][LDX]  R rows of the distance window d0 .. d0+127
+    float* sk = (float*)(Rw + 128 * LDX);     // [4 waves][16 t][SKW]  skew buffer
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t qt = (int64_t)gridDim.x - 1 - blockIdx.x;
+    const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int64_t q0 = qt * 64;
+    const CT* qb = q + (b * T) * ld + h * DH;
+    const CT* kb = k + (b * T) * ld + h * DH;
+    const CT* vb = v + (b * T) * ld + h * DH;
+    const CT* rb = rd + h * DH;
+    const int qvalid = (int)((T - q0) < 64 ? (T - q0) : 64);
+    RowPrefetch<CT, DH, DHP, 64, 256> pk;
+    RowPrefetch<CT, DH, DHP, 64, 256, !TR> pv;
+    constexpr int VE = 16 / sizeof(CT), CH = DH / VE, RNI = (128 * CH + 255) / 256;
+    CT rr[RNI][VE];                           // prefetched R window rows
+    auto fetch_r = [&](int64_t d0) {
+#pragma unroll
+        for (int i = 0; i < RNI; ++i) {
+            const int it = tid + 256 * i;
+            const int row = it / CH, c = (it % CH) * VE;
+            const int64_t dist = d0 + row;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) rr[i][e] = from_f32<CT>(0.f);
+            if (it < 128 * CH && dist >= 0 && dist < n_dist) {
+                if constexpr (sizeof(CT) == 2) *(bf16x8*)rr[i] = *(const bf16x8*)(rb + dist * ld_r + c);
+                else *(f32x4*)rr[i] = *(const f32x4*)(rb + dist * ld_r + c);
+            }
+        }
+    };
+    auto store_r = [&]() {
+#pragma unroll
+        for (int i = 0; i < RNI; ++i) {
+            const int it = tid + 256 * i;
+            if (it < 128 * CH) {
+                const int row = it / CH, c = (it % CH) * VE;
+                if constexpr (sizeof(CT) == 2) *(bf16x8*)(Rw + row * LDX + c) = *(const bf16x8*)rr[i];
+                else {
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) Rw[row * LDX + c + e] = rr[i][e];
+                }
+            }
+        }
+        if constexpr (DHP > DH) {
+            for (int it = tid; it < 128 * (DHP - DH); it += 256) Rw[(it / (DHP - DH)) * LDX + DH + it % (DHP - DH)] = from_f32<CT>(0.f);
+        }
+    };
+    {
+        const int kv0 = (int)(T < 64 ? T : 64);
+        pk.load(kb, ld, kv0, tid);
+        pv.load(vb, ld, kv0, tid);
+        fetch_r(q0 - 63);
+    }
+    // fragments of (q + u) and (q + v) for this wave's 16 query rows
+    typename Img<CT>::V quf[NQ], qvf[NQ];
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* bias = (pass == 0 ? ub : vb_) + h * DH;
+        __syncthreads();
+        for (int it = tid; it < 64 * DHP; it += 256) {
+            const int r = it / DHP, d = it % DHP;
+            float x = 0.f;
+            if (r < qvalid && d < DH) x = to_f32<CT>(qb[(q0 + r) * ld + d]) + bias[d];
+            Qi[r * LDX + d] = from_f32<CT>(x);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < NQ; ++kk) {
+            if (pass == 0) quf[kk] = Img<CT>::load(Qi, LDX, wave * 16, kk * Img<CT>::KSTEP, lane);
+            else qvf[kk] = Img<CT>::load(Qi, LDX, wave * 16, kk * Img<CT>::KSTEP, lane);
+        }
+    }
+    const float sqrt_dh = sqrtf((float)DH), rsqrt_dh = 1.f / sqrt_dh, c2 = rsqrt_dh * EMO_LOG2E;
+    const int tl = wave * 16 + (lane & 15);
+    const int64_t tg = q0 + tl;
+    float m_run = -INFINITY, l_run = 0.f, e_run = 0.f;
+    f32x4 oacc[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) oacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float* skw = sk + (wave * 16 + (lane & 15)) * SKW;       // this lane's query row of the wave-private skew buffer
+
+    for (int64_t kt = 0; kt <= qt; ++kt) {
+        const int64_t k0 = kt * 64;
+        __syncthreads();
+        pk.store_rows(Ki, LDX, tid);
+        if constexpr (TR) pv.store_rows(VT, LDX, tid); else pv.store_T(VT, LDC, tid);
+        store_r();
+        if (kt < qt) {
+            const int64_t kn = k0 + 64;
+            const int nv = (int)((T - kn) < 64 ? (T - kn) : 64);
+            pk.load(kb + kn * ld, ld, nv, tid);
+            pv.load(vb + kn * ld, ld, nv, tid);
+            fetch_r(q0 - kn - 63);
+        }
+        __syncthreads();
+        // P2[c][t] = Rwin[c].(q_t + v) for the window rows this wave can reach: c = t_l - j_l + 63 in [16w, 16w + 78] -> tiles w .. w+4
+#pragma unroll
+        for (int ci = 0; ci < 5; ++ci) {
+            f32x4 a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NQ; ++kk) a2 = Img<CT>::mma(Img<CT>::load(Rw, LDX, (wave + ci) * 16, kk * Img<CT>::KSTEP, lane), qvf[kk], a2);
+            *(f32x4*)(skw + ci * 16 + (lane >> 4) * 4) = a2;                 // sk[t][c - 16w]
+        }
+        __builtin_amdgcn_wave_barrier();
+        float s[4][4];
+        float mx = -INFINITY;
+        const bool diag = kt == qt;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (!(diag && jt > wave)) {
+#pragma unroll
+                for (int kk = 0; kk < NQ; ++kk) acc = Img<CT>::mma(Img<CT>::load(Ki, LDX, jt * 16, kk * Img<CT>::KSTEP, lane), quf[kk], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jl = jt * 16 + (lane >> 4) * 4 + r;
+                const float bd = skw[(lane & 15) + 63 - jl];               // c - 16w = (16w + (l&15)) - jl + 63 - 16w
+                float val = sizeof(CT) == 2 ? (acc[r] + bd) * c2 : (acc[r] + bd) / sqrt_dh;
+                if (diag && (jl > tl || k0 + jl >= T)) val = -INFINITY;
+                s[jt][r] = val;
+                mx = fmaxf(mx, val);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float m_new = fmaxf(m_run, mx);
+        if (m_new == -INFINITY) m_new = 0.f;
+        const float alpha = sizeof(CT) == 2 ? __builtin_amdgcn_exp2f(m_run - m_new) : __expf(m_run - m_new);
+        float psum = 0.f, esum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            float dm[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop.thr16) drop_mult4(drop, (uint64_t)((bh * T + tg) * T + k0 + jt * 16 + (lane >> 4) * 4), dm);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = sizeof(CT) == 2 ? __builtin_amdgcn_exp2f(s[jt][r] - m_new) : Img<CT>::ex(s[jt][r] - m_new);
+                psum += p;
+                s[jt][r] = p * dm[r];
+                esum += s[jt][r];
+            }
+        }
+        psum += __shfl_xor(psum, 16, 64); psum += __shfl_xor(psum, 32, 64);
+        esum += __shfl_xor(esum, 16, 64); esum += __shfl_xor(esum, 32, 64);
+        l_run = l_run * alpha + psum;
+        e_run = e_run * alpha + esum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) oacc[i] *= alpha;
+#pragma unroll
+        for (int st = 0; st < SaK<CT>::NS64; ++st) {
+            const typename Img<CT>::V pf = reg_perm<CT>(s, st);
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                if constexpr (TR) oacc[i] = Img<CT>::mma(load_perm_tr((const bf16_t*)VT, LDX, i * 16, st, lane), pf, oacc[i]);
+                else oacc[i] = Img<CT>::mma(load_perm<CT>(VT, LDC, i * 16, st, lane), pf, oacc[i]);
+            }
+        }
+    }
+    if (tg < T) {
+        const float inv = 1.f / (e_run + 1e-8f * l_run);
+        CT* ob = out + (b * T + tg) * ld_out + h * DH;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int d0 = i * 16 + (lane >> 4) * 4;
+            Img<CT>::store4(ob + d0, oacc[i][0] * inv, oacc[i][1] * inv, oacc[i][2] * inv, oacc[i][3] * inv);
+        }
+        if ((lane >> 4) == 0) {
+            lse_g[bh * T + tg] = (sizeof(CT) == 2 ? m_run * EMO_LN2 : m_run) + logf(l_run);
+            if (zden_g) zden_g[bh * T + tg] = e_run / l_run + 1e-8f;
+        }
+    }
+}
+
+// one query per stream against a KV cache, keys j in [j0, len): score_j = ((q+u).k_j + (q+v).R[len-1-j]) / sqrt(dh)
+template <typename CT>
+__global__ __launch_bounds__(256) void relattn_decode_kernel(const CT* __restrict__ q, int64_t ld_q, CT* __restrict__ kc, CT* __restrict__ vc, int64_t T_max,
+                                                             const int64_t* __restrict__ lens, int64_t lens_off, int64_t mem_len,
+                                                             const CT* __restrict__ k_new, const CT* __restrict__ v_new, int64_t ld_new,
+                                                             const CT* __restrict__ rd, int64_t ld_r, const float* __restrict__ ub,
+                                                             const float* __restrict__ vb_, CT* __restrict__ out, int64_t ld_out, int64_t H, int dh) {
+    constexpr int VE = 16 / sizeof(CT);
+    extern __shared__ float sc[];            // [T_max] scores
+    __shared__ float qu[128], qv[128], red[4];
+    __shared__ float part[256 * VE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t sh = blockIdx.x, s = sh / H, h = sh % H;
+    const int64_t len = lens[s] + lens_off;
+    const int64_t j0 = (mem_len > 0 && len - 1 - mem_len > 0) ? len - 1 - mem_len : 0;      // the memory keeps the last mem_len positions
+    const int64_t HD = H * dh;
+    if (tid < dh) {
+        const float x = to_f32<CT>(q[s * ld_q + h * dh + tid]);
+        qu[tid] = x + ub[h * dh + tid];
+        qv[tid] = x + vb_[h * dh + tid];
+        if (k_new) {
+            kc[(s * T_max + len - 1) * HD + h * dh + tid] = k_new[s * ld_new + h * dh + tid];
+            vc[(s * T_max + len - 1) * HD + h * dh + tid] = v_new[s * ld_new + h * dh + tid];
+        }
+    }
+    __syncthreads();
+    const float sqrt_dh = sqrtf((float)dh);
+    const int LPR = dh / VE;
+    const int rl = tid / LPR, cl = (tid % LPR) * VE, RPB = 256 / LPR;
+    float mx = -INFINITY;
+    for (int64_t jb = j0; jb < len; jb += RPB) {
+        const int64_t j = jb + rl;
+        float a = 0.f;
+        if (j < len) {
+            const CT* kr = kc + (s * T_max + j) * HD + h * dh + cl;
+            const CT* rr = rd + (len - 1 - j) * ld_r + h * dh + cl;
+            if constexpr (sizeof(CT) == 2) { const bf16x8 kv = *(const bf16x8*)kr, rv = *(const bf16x8*)rr;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a += qu[cl + e] * (float)kv[e] + qv[cl + e] * (float)rv[e]; }
+            else { const f32x4 kv = *(const f32x4*)kr, rv = *(const f32x4*)rr;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a += qu[cl + e] * kv[e] + qv[cl + e] * rv[e]; }
+        }
+        for (int o = LPR >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        a = a / sqrt_dh;
+        if (j < len) {
+            if ((tid % LPR) == 0) sc[j - j0] = a;
+            mx = fmaxf(mx, a);
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int64_t j = tid; j < len - j0; j += 256) { float p = expf(sc[j] - mx); sc[j] = p; sum += p; }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    for (int64_t j = j0 + rl; j < len; j += RPB) {
+        const CT* vr = vc + (s * T_max + j) * HD + h * dh + cl;
+        const float p = sc[j - j0];
+        if constexpr (sizeof(CT) == 2) { const bf16x8 vv = *(const bf16x8*)vr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += p * (float)vv[e]; }
+        else { const f32x4 vv = *(const f32x4*)vr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += p * vv[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) part[rl * dh + cl + e] = acc[e];
+    __syncthreads();
+    if (tid < dh) {
+        float a = 0.f;
+        for (int p = 0; p < RPB; ++p) a += part[p * dh + tid];
+        out[s * ld_out + h * dh + tid] = from_f32<CT>(a / tot / (1.f + 1e-8f));     // eval: p / (sum p + 1e-8) with sum p = 1
+    }
+}
+
+template <typename CT, int DH> static size_t ra_fwd_lds() {
+    typedef SaDims<CT, DH> D;
+    return sizeof(CT) * (size_t)(2 * 64 * D::LDX + CMax<DH * D::LDC, 64 * D::LDX>::v + 128 * D::LDX) + sizeof(float) * 4 * 16 * 84;
+}
+template <typename CT, int DH>
+static int run_relattn(const void* q, const void* k, const void* v, int64_t ld, const void* rd, int64_t ld_r, int64_t n_dist, const float* ub, const float* vb,
+                       void* out, int64_t ld_out, float* lse, float* zden, int64_t B, int64_t T, int64_t H, DropCtx drop, hipStream_t st) {
+    dim3 grid((unsigned)((T + 63) / 64), (unsigned)(B * H));
+    const size_t lds = ra_fwd_lds<CT, DH>();
+    auto kf = relattn_fwd_kernel<CT, DH>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(kf, grid, dim3(256), lds, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, (const CT*)rd, ld_r, n_dist, ub, vb, (CT*)out, ld_out, lse,
+                       zden, T, H, drop);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
+extern "C" int emo_relpos_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const void* r_dist, int64_t ld_r, int64_t n_dist,
+                                   const float* r_w_bias, const float* r_r_bias, void* out, int64_t ld_out, float* lse, float* zden, int dtype, int64_t B,
+                                   int64_t T, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
+    int rc = sattn_check(q, k, v, ld, ld_out, dtype, dh);
+    if (rc) return rc;
+    EMO_CHECK(r_dist && r_w_bias && r_r_bias && out && lse, "emo_relpos_attn_fwd: null pointer");
+    const int64_t ve = dtype == EMO_BF16 ? 8 : 4;
+    EMO_CHECK(ld_r % ve == 0 && ((uintptr_t)r_dist & 15) == 0 && ((uintptr_t)out & 15) == 0, "emo_relpos_attn_fwd: r_dist / out must keep rows 16-B aligned");
+    EMO_CHECK(n_dist >= T, "emo_relpos_attn_fwd: r_dist needs a row for every distance 0 .. T-1");
+    const DropCtx drop = make_drop(p_drop, seed, offset);
+    hipStream_t st = (hipStream_t)stream;
+#define RA_CASE(DHv)                                                                                                                                   \
+    if (dh == DHv) {                                                                                                                                   \
+        if (dtype == EMO_BF16) return run_relattn<bf16_t, DHv>(q, k, v, ld, r_dist, ld_r, n_dist, r_w_bias, r_r_bias, out, ld_out, lse, zden, B, T, H, drop, st); \
+        return run_relattn<float, DHv>(q, k, v, ld, r_dist, ld_r, n_dist, r_w_bias, r_r_bias, out, ld_out, lse, zden, B, T, H, drop, st);               \
+    }
+    RA_CASE(64)
+    RA_CASE(32)
+    RA_CASE(16)
+#undef RA_CASE
+    emo_set_error("emo_relpos_attn_fwd: unsupported d_head=%lld (built: 16, 32, 64)", (long long)dh);
+    return EMO_ERR_UNSUPPORTED;
+}
+
+extern "C" int emo_relpos_attn_decode(const void* q, int64_t ld_q, void* kcache, void* vcache, int64_t T_max, const int64_t* lens, int64_t lens_off,
+                                      int64_t mem_len, const void* k_new, const void* v_new, int64_t ld_new, const void* r_dist, int64_t ld_r, int64_t n_dist,
+                                      const float* r_w_bias, const float* r_r_bias, void* out, int64_t ld_out, int dtype, int64_t n_streams, int64_t H,
+                                      int64_t dh, emo_stream_t stream) {
+    EMO_CHECK(q && kcache && vcache && lens && out && r_dist && r_w_bias && r_r_bias, "emo_relpos_attn_decode: null pointer");
+    EMO_CHECK(dh == 16 || dh == 32 || dh == 64 || dh == 128, "emo_relpos_attn_decode: d_head must be 16, 32, 64 or 128");
+    EMO_CHECK(T_max * 4 <= 128 * 1024, "emo_relpos_attn_decode: T_max too large for the LDS score buffer");
+    EMO_CHECK(!k_new == !v_new, "emo_relpos_attn_decode: k_new and v_new go together");
+    EMO_CHECK(n_dist >= T_max, "emo_relpos_attn_decode: r_dist needs a row for every distance 0 .. T_max-1");
+    const int64_t ve = dtype == EMO_BF16 ? 8 : 4;
+    EMO_CHECK((((uintptr_t)kcache | (uintptr_t)vcache | (uintptr_t)r_dist) & 15) == 0 && (H * dh) % ve == 0 && ld_r % ve == 0,
+              "emo_relpos_attn_decode: caches / r_dist must be 16-B aligned");
+    dim3 grid((unsigned)(n_streams * H));
+    const size_t lds = (size_t)T_max * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EMO_F32) {
+        static bool a = false;
+        if (!a) { (void)hipFuncSetAttribute((const void*)relattn_decode_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); a = true; }
+        hipLaunchKernelGGL(relattn_decode_kernel<float>, grid, dim3(256), lds, st, (const float*)q, ld_q, (float*)kcache, (float*)vcache, T_max, lens, lens_off,
+                           mem_len, (const float*)k_new, (const float*)v_new, ld_new, (const float*)r_dist, ld_r, r_w_bias, r_r_bias, (float*)out, ld_out, H,
+                           (int)dh);
+    } else {
+        static bool a = false;
+        if (!a) { (void)hipFuncSetAttribute((const void*)relattn_decode_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); a = true; }
+        hipLaunchKernelGGL(relattn_decode_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)q, ld_q, (bf16_t*)kcache, (bf16_t*)vcache, T_max, lens,
+                           lens_off, mem_len, (const bf16_t*)k_new, (const bf16_t*)v_new, ld_new, (const bf16_t*)r_dist, ld_r, r_w_bias, r_r_bias,
+                           (bf16_t*)out, ld_out, H, (int)dh);
+    }
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}

@@ -12,7 +12,7 @@ from ._lib import (ACT_GELU_NEW, ACT_NONE, ACT_RELU, BF16, F32, MUL_DGELU_NEW, M
                    dtype_code, lib, ptr, stream)
 
 __all__ = ['gemm', 'colsum', 'embed_fwd', 'embed_bwd', 'layernorm_fwd', 'layernorm_bwd', 'dropout_apply', 'favor_attn_fwd',
-           'favor_attn_bwd', 'favor_decode_step', 'favor_draw_omega', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'xent_fwd',
+           'favor_attn_bwd', 'favor_decode_step', 'favor_draw_omega', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'relpos_attn_fwd', 'relpos_attn_decode', 'xent_fwd',
            'xent_bwd', 'argmax', 'sample_nucleus', 'sample_nucleus_step', 'accuracy_counts', 'sumsq', 'clip_coef', 'adam_step', 'cast',
            'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW']
 
@@ -225,6 +225,31 @@ def softmax_attn_decode(q, kcache, vcache, lens, H, lens_off=0, k_new=None, v_ne
     out = torch.empty(n, HD, device=q.device, dtype=q.dtype)
     check(lib.emo_softmax_attn_decode(ptr(q), _rows(q), ptr(kcache), ptr(vcache), T_max, ptr(lens), lens_off, ptr(k_new), ptr(v_new),
                                       0 if k_new is None else _rows(k_new), ptr(out), HD, dtype_code(q.dtype), n, H, HD // H, stream()))
+    return out
+
+
+def relpos_attn_fwd(q, k, v, r_dist, r_w_bias, r_r_bias, B, T, H, p_drop=0.0, seed=0, offset=0):
+    """Transformer-XL relative-position causal attention (stage 1).  q,k,v [B*T, H*dh] views; r_dist [>=T, H*dh] indexed by distance."""
+    M, HD = q.shape
+    dh = HD // H
+    assert M == B * T and _rows(q) == _rows(k) == _rows(v) and r_dist.shape[0] >= T and r_dist.dtype == q.dtype
+    assert r_w_bias.dtype == torch.float32 and r_r_bias.dtype == torch.float32 and r_w_bias.is_contiguous() and r_r_bias.is_contiguous()
+    out = torch.empty(M, HD, device=q.device, dtype=q.dtype)
+    lse = torch.empty(B, H, T, device=q.device, dtype=torch.float32)
+    zden = torch.empty(B, H, T, device=q.device, dtype=torch.float32)
+    check(lib.emo_relpos_attn_fwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(r_dist), _rows(r_dist), r_dist.shape[0], ptr(r_w_bias), ptr(r_r_bias), ptr(out), HD,
+                                  ptr(lse), ptr(zden), dtype_code(q.dtype), B, T, H, dh, p_drop, seed, offset, stream()))
+    return out, lse, zden
+
+
+def relpos_attn_decode(q, kcache, vcache, lens, H, r_dist, r_w_bias, r_r_bias, mem_len=0, lens_off=0, k_new=None, v_new=None):
+    n, HD = q.shape
+    T_max = kcache.shape[1]
+    assert kcache.is_contiguous() and vcache.is_contiguous() and lens.dtype == torch.int64 and r_dist.shape[0] >= T_max
+    out = torch.empty(n, HD, device=q.device, dtype=q.dtype)
+    check(lib.emo_relpos_attn_decode(ptr(q), _rows(q), ptr(kcache), ptr(vcache), T_max, ptr(lens), lens_off, mem_len, ptr(k_new), ptr(v_new),
+                                     0 if k_new is None else _rows(k_new), ptr(r_dist), _rows(r_dist), r_dist.shape[0], ptr(r_w_bias), ptr(r_r_bias),
+                                     ptr(out), HD, dtype_code(q.dtype), n, H, HD // H, stream()))
     return out
 
 

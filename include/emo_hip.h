@@ -179,6 +179,30 @@ int emo_softmax_attn_decode(const void* q, int64_t ld_q, void* kcache, void* vca
                             int64_t ld_new, void* out, int64_t ld_out, int dtype, int64_t n_streams,
                             int64_t H, int64_t dh, emo_stream_t stream);
 
+/* ------------------------------------------------------------------ K5r: relative-position causal attention (stage-1 Transformer-XL)
+ * SURVEY §8 f-1.  Replaces RelPartialLearnableMultiHeadAttn's score / softmax / value product
+ * (stage1_compose/model/optimus_txl_decoder.py:331-366) including `_rel_shift` (:280-293):
+ *   score[i][j] = ((q_i + r_w_bias).k_j + (q_i + r_r_bias).R[i-j]) / sqrt(dh),  j <= i
+ *   prob = softmax -> dropout -> p / (sum_j p + 1e-8);  out = prob v
+ * q,k,v: [B*T, H*dh] views (row stride ld; batch-major).  r_dist [n_dist >= T, H*dh] (ld_r) = r_net(pos_emb) indexed BY DISTANCE
+ * (row d = the reference's r_head_k[klen-1-d]).  r_w_bias / r_r_bias [H, dh] fp32.  lse [B,H,T], zden [B,H,T] (may be NULL:
+ * the renormalisation denominator E/l + 1e-8) are saved for the backward pass (next round).  Forward only so far. */
+int emo_relpos_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const void* r_dist,
+                        int64_t ld_r, int64_t n_dist, const float* r_w_bias, const float* r_r_bias,
+                        void* out, int64_t ld_out, float* lse, float* zden, int dtype, int64_t B,
+                        int64_t T, int64_t H, int64_t dh, float p_drop, uint64_t seed,
+                        uint64_t offset, emo_stream_t stream);
+/* one query row per stream against a KV cache (the reference re-projects its cached hidden states `mems` every step,
+ * plain_transformer.py:52-59; k / v of a position do not change, so they are cached instead).  Keys j in
+ * [max(0, len-1-mem_len), len) with len = lens[s] + lens_off; the distance of key j is len-1-j.  k_new / v_new as in
+ * emo_softmax_attn_decode.  Eval semantics (no dropout). */
+int emo_relpos_attn_decode(const void* q, int64_t ld_q, void* kcache, void* vcache, int64_t T_max,
+                           const int64_t* lens, int64_t lens_off, int64_t mem_len, const void* k_new,
+                           const void* v_new, int64_t ld_new, const void* r_dist, int64_t ld_r,
+                           int64_t n_dist, const float* r_w_bias, const float* r_r_bias, void* out,
+                           int64_t ld_out, int dtype, int64_t n_streams, int64_t H, int64_t dh,
+                           emo_stream_t stream);
+
 /* ------------------------------------------------------------------ K9: cross-entropy with ignore_index
  * Replaces F.cross_entropy in compute_loss (model/music_performer.py:72-81).
  * fwd: row_lse[m]; acc[0] += sum of -logp over kept rows, acc[1] += #kept rows (caller zeroes acc).

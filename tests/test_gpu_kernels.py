@@ -224,6 +224,52 @@ def test_gemm_bf16_safe_and_tr_paths_agree(monkeypatch):
     _close(out, A.double().T @ Bm.double(), torch.bfloat16, mult=0.3)
 
 
+# ------------------------------------------------------------------------------------------- relative-position attention (stage 1)
+def _relattn_ref(q, k, v, R, u, vb):
+    """q,k,v [B,T,H,dh] double; R [n_dist,H,dh] by distance; u, vb [H,dh].  The reference's AC + rel_shift(BD) written with explicit distances."""
+    B, T, H, dh = q.shape
+    AC = torch.einsum('bihd,bjhd->bhij', q + u, k)
+    idx = (torch.arange(T)[:, None] - torch.arange(T)[None, :]).clamp(min=0)           # distance i - j (masked entries: any valid row)
+    BD = torch.einsum('bihd,ijhd->bhij', q + vb, R[idx])
+    sc = (AC + BD) / dh ** 0.5
+    sc = sc.masked_fill(torch.triu(torch.ones(T, T), 1).bool(), -float('inf'))
+    p = torch.softmax(sc, -1)
+    p = p / (p.sum(-1, keepdim=True) + 1e-8)
+    return torch.einsum('bhij,bjhd->bihd', p, v)
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('B,T,H,dh', [(2, 150, 2, 64), (1, 70, 3, 32), (2, 33, 2, 16), (1, 256, 1, 64), (1, 129, 2, 64)])
+def test_relpos_attention_fwd_and_decode(dt, B, T, H, dh):
+    ops = _ops()
+    HD = H * dh
+    qkv = _r(B * T, 3 * HD, seed=1, dt=dt, scale=0.7)
+    R = _r(T + 5, HD, seed=2, dt=dt, scale=0.7)
+    u, vb = _r(H, dh, seed=3, scale=0.3), _r(H, dh, seed=4, scale=0.3)
+    q, k, v = [qkv[:, i * HD:(i + 1) * HD].double().view(B, T, H, dh) for i in range(3)]
+    ref = _relattn_ref(q, k, v, R.double().view(-1, H, dh), u.double(), vb.double())
+    qc = qkv.cuda()
+    out, lse, zden = ops.relpos_attn_fwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], R.cuda(), u.cuda(), vb.cuda(), B, T, H)
+    _close(out.view(B, T, H, dh), ref, dt, mult=3)
+    _close(zden, torch.full((B, H, T), 1.0), torch.float32, scale=1.0, mult=10)
+    # one-token decode against a KV cache == the last row of the full attention (and the row before it, with the memory one shorter)
+    T_max = T + 5
+    kc = torch.zeros(B, T_max, HD, dtype=dt, device='cuda'); vc = torch.zeros(B, T_max, HD, dtype=dt, device='cuda')
+    x3 = qc.view(B, T, 3 * HD)
+    kc[:, :T - 1] = x3[:, :T - 1, HD:2 * HD]; vc[:, :T - 1] = x3[:, :T - 1, 2 * HD:]
+    last = x3[:, T - 1].contiguous()
+    lens = torch.full((B,), T, dtype=torch.long, device='cuda')
+    o = ops.relpos_attn_decode(last[:, :HD], kc, vc, lens, H, R.cuda(), u.cuda(), vb.cuda(), k_new=last[:, HD:2 * HD], v_new=last[:, 2 * HD:])
+    _close(o.view(B, H, dh), ref[:, T - 1], dt, mult=3)
+    assert torch.equal(kc[:, T - 1], x3[:, T - 1, HD:2 * HD])                      # appended in-kernel
+    # sliding memory: only the last mem_len keys (+ the token itself) are attended
+    ml = 20
+    if T > ml + 2:
+        o2 = ops.relpos_attn_decode(last[:, :HD], kc, vc, lens, H, R.cuda(), u.cuda(), vb.cuda(), mem_len=ml)
+        ref2 = _relattn_ref(q[:, T - 1 - ml:], k[:, T - 1 - ml:], v[:, T - 1 - ml:], R.double().view(-1, H, dh), u.double(), vb.double())[:, -1]
+        _close(o2.view(B, H, dh), ref2, dt, mult=3)
+
+
 # ------------------------------------------------------------------------------------------- embedding / LN / xent
 @pytest.mark.parametrize('dt', DT)
 def test_embed_fwd_bwd(dt):
