@@ -1,0 +1,253 @@
+"""Stage-1 lead-sheet language model (Transformer-XL decoder), SURVEY §8 f-1 — inference path.
+
+Mirrors /root/reference/stage1_compose/model/plain_transformer.py:14-93 (PlainTransformer: constructor, forward, generate, compute_loss) on
+top of OptimusTXLDecoder with attn_type 0 (optimus_txl_decoder.py:299-391, 700-925): same constructor arguments, parameter names, registration
+order (= optimizer state order) and state-dict keys, so reference checkpoints load unchanged.  Built so far: the evaluation forward pass and
+token-by-token generation with memory on the HIP kernels (relative-position attention: emo_relpos_attn_fwd / _decode); the TRAINING path
+(attention backward with the relative term) is the next build step and raises NotImplementedError.
+
+The reference keeps `mems` = the hidden states of the last mem_len positions per layer and re-projects them to keys / values at every step
+(:309-316); the key / value of a position never changes, so the engine caches K and V instead (`TXLMemory`, returned where the reference
+returns its list of tensors and accepted back by generate()).  R = r_net(pos_emb) depends only on the distance and is computed once per
+engine.  Layout: the reference is time-major ([T, B] tokens, [T, B, V] logits); the kernels work batch-major internally."""
+import os
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from emo_disentanger_amd import engine, ops
+from emo_disentanger_amd._lib import EmoError
+
+
+def weights_init(m):
+    """stage1_compose/model/transformer_helpers.py:24-66 (the branches this model reaches)."""
+    name = m.__class__.__name__
+    if name.find('Linear') != -1:
+        nn.init.normal_(m.weight, 0.0, 0.01)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0.0)
+    elif name.find('Embedding') != -1:
+        if hasattr(m, 'weight'):
+            nn.init.normal_(m.weight, 0.0, 0.01)
+    elif name.find('LayerNorm') != -1:
+        nn.init.normal_(m.weight, 1.0, 0.01)
+        nn.init.constant_(m.bias, 0.0)
+    elif name.find('TXLDecoder') != -1:
+        nn.init.normal_(m.r_w_bias, 0.0, 0.01)
+        nn.init.normal_(m.r_r_bias, 0.0, 0.01)
+
+
+class WordEmbedding(nn.Module):
+    def __init__(self, n_token, d_embed, d_proj, emb_scale=0.5, pad_idx=None):
+        super().__init__()
+        if d_proj != d_embed:
+            raise NotImplementedError('d_word_embed != d_model (emb_proj) is not used by any stage-1 YAML and is not built')
+        self.n_token, self.d_embed, self.d_proj = n_token, d_embed, d_proj
+        self.emb_scale = d_proj ** emb_scale
+        self.emb_lookup = nn.Embedding(n_token, d_embed, padding_idx=n_token - 1 if pad_idx is None else pad_idx)
+
+
+class PositionalEmbedding(nn.Module):
+    def __init__(self, demb):
+        super().__init__()
+        self.demb = demb
+        self.register_buffer('inv_freq', 1 / (10000 ** (torch.arange(0.0, demb, 2.0) / demb)))
+
+    def forward(self, pos_seq):
+        s = torch.outer(pos_seq, self.inv_freq)
+        return torch.cat([s.sin(), s.cos()], dim=-1)
+
+
+class _RelAttn(nn.Module):                      # parameter container: RelPartialLearnableMultiHeadAttn
+    def __init__(self, n_head, d_model, d_head):
+        super().__init__()
+        self.qkv_net = nn.Linear(d_model, 3 * n_head * d_head, bias=False)
+        self.o_net = nn.Linear(n_head * d_head, d_model, bias=False)
+        self.layer_norm = nn.LayerNorm(d_model)
+        self.r_net = nn.Linear(d_model, n_head * d_head, bias=False)
+
+
+class _PosFF(nn.Module):                        # parameter container: PositionwiseFF (CoreNet indices 0 and 3 hold the Linears)
+    def __init__(self, d_model, d_inner, dropout):
+        super().__init__()
+        self.CoreNet = nn.Sequential(nn.Linear(d_model, d_inner), nn.ReLU(inplace=True), nn.Dropout(dropout), nn.Linear(d_inner, d_model), nn.Dropout(dropout))
+        self.layer_norm = nn.LayerNorm(d_model)
+
+
+class _DecoderLayer(nn.Module):
+    def __init__(self, n_head, d_model, d_head, d_inner, dropout):
+        super().__init__()
+        self.dec_attn = _RelAttn(n_head, d_model, d_head)
+        self.pos_ff = _PosFF(d_model, d_inner, dropout)
+
+
+class OptimusTXLDecoder(nn.Module):             # the class name matters: weights_init matches 'TXLDecoder'
+    def __init__(self, n_layer, n_head, d_model, d_head, d_inner, dropout, tgt_len, mem_len, pre_lnorm):
+        super().__init__()
+        self.n_layer, self.n_head, self.d_model, self.d_head = n_layer, n_head, d_model, d_head
+        self.tgt_len, self.mem_len, self.ext_len, self.pre_lnorm = tgt_len, mem_len, 0, pre_lnorm
+        self.r_w_bias = nn.Parameter(torch.zeros(n_head, d_head))
+        self.r_r_bias = nn.Parameter(torch.zeros(n_head, d_head))
+        self.layers = nn.ModuleList([_DecoderLayer(n_head, d_model, d_head, d_inner, dropout) for _ in range(n_layer)])
+        self.pos_emb = PositionalEmbedding(d_model)
+
+
+class TXLMemory:
+    """What generate() hands back in place of the reference's list of `mems` tensors: per-layer K / V caches of one lock-step group of streams."""
+
+    def __init__(self, model, n_streams, max_len):
+        ps = model._ensure_store()
+        self.n, self.max_len, self.len = n_streams, max_len, 0
+        D, L = model.dec_d_model, model.dec_n_layer
+        self.kc = [torch.zeros(n_streams, max_len, D, device=ps.device, dtype=ps.compute_dtype) for _ in range(L)]
+        self.vc = [torch.zeros(n_streams, max_len, D, device=ps.device, dtype=ps.compute_dtype) for _ in range(L)]
+        self.lens = torch.zeros(n_streams, device=ps.device, dtype=torch.int64)
+        self.r_dist = model._r_by_distance(max_len)
+
+    def __len__(self):                    # the reference's callers only test / print len(mems)
+        return len(self.kc) + 1
+
+
+class PlainTransformer(nn.Module):
+    def __init__(self, d_word_embed, vocab_size, dec_n_layer, dec_n_head, dec_d_model, dec_d_ff, dec_mem_len, dec_tgt_len,
+                 dec_dropout=0.1, dec_activation='relu', pad_index=None, pre_lnorm=False, compute_dtype=None, max_gen_len=4096):
+        super().__init__()
+        self.d_word_embed, self.vocab_size = d_word_embed, vocab_size
+        self.dec_n_layer, self.dec_n_head, self.dec_d_model, self.dec_d_ff = dec_n_layer, dec_n_head, dec_d_model, dec_d_ff
+        self.dec_dropout, self.dec_activation, self.dec_mem_len, self.dec_tgt_len = dec_dropout, dec_activation, dec_mem_len, dec_tgt_len
+        self.word_emb = WordEmbedding(vocab_size, d_word_embed, dec_d_model)
+        self.emb_dropout = nn.Dropout(dec_dropout)
+        self.pad_index = vocab_size - 1 if pad_index is None else pad_index
+        self.decoder = OptimusTXLDecoder(dec_n_layer, dec_n_head, dec_d_model, dec_d_model // dec_n_head, dec_d_ff, dec_dropout,
+                                         tgt_len=dec_tgt_len, mem_len=dec_mem_len, pre_lnorm=pre_lnorm)
+        self.dec_out_proj = nn.Linear(dec_d_model, vocab_size)
+        self.apply(weights_init)
+        self._compute_dtype = engine._dt(compute_dtype or os.environ.get('EMO_COMPUTE_DTYPE', 'bf16'))
+        self._store, self._max_gen_len, self._zero_pe_buf = None, max_gen_len, None
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _ensure_store(self):
+        if self._store is None or not self._store.intact() or self._store.compute_dtype != self._compute_dtype:
+            self._store = engine.ParamStore(self, self._compute_dtype, [])
+        self._store.sync_mirror()
+        return self._store
+
+    def set_compute_dtype(self, name):
+        self._compute_dtype, self._store = engine._dt(name), None
+        return self
+
+    def _zero_pe(self, n):
+        if self._zero_pe_buf is None or self._zero_pe_buf.shape[0] < n or self._zero_pe_buf.device != self._store.device:
+            self._zero_pe_buf = torch.zeros(max(n, 64), self.dec_d_model, device=self._store.device)
+        return self._zero_pe_buf
+
+    def _r_by_distance(self, n_dist):
+        """R[l][d] = r_net_l(pos_emb(d)) for d = 0 .. n_dist-1 (evaluation: no dropout on pos_emb), in the compute dtype.  Row d is the
+        reference's r_head_k[klen-1-d] (optimus_txl_decoder.py:318, 791-796)."""
+        ps = self._ensure_store()
+        pe = self.decoder.pos_emb(torch.arange(n_dist, device=ps.device, dtype=torch.float32)).to(ps.compute_dtype).contiguous()
+        return [ops.gemm(pe, ps.w('decoder.layers.%d.dec_attn.r_net.weight' % l)) for l in range(self.dec_n_layer)]
+
+    def _embed(self, tok_bm, pos0=0):
+        ps = self._store
+        B, T = tok_bm.shape
+        return ops.embed_fwd(tok_bm, None, ps.f32('word_emb.emb_lookup.weight'), None, self._zero_pe(pos0 + T), ps.compute_dtype,
+                             float(self.word_emb.emb_scale)).view(-1, self.dec_d_model)
+
+    def _layer(self, l, x, attn_fn):
+        """One RelPartialLearnableDecoderLayer (:526-557) in evaluation mode; attn_fn(qkv) -> attention vectors [M, D]."""
+        ps, p = self._store, 'decoder.layers.%d.' % l
+        a, f = p + 'dec_attn.', p + 'pos_ff.'
+        pre = self.decoder.pre_lnorm
+        n = ops.layernorm_fwd(x, ps.f32(a + 'layer_norm.weight'), ps.f32(a + 'layer_norm.bias'))[0] if pre else x
+        vec = attn_fn(ops.gemm(n, ps.w(a + 'qkv_net.weight')))
+        h = ops.gemm(vec, ps.w(a + 'o_net.weight'), residual=x)
+        if not pre:
+            h = ops.layernorm_fwd(h, ps.f32(a + 'layer_norm.weight'), ps.f32(a + 'layer_norm.bias'))[0]
+        n2 = ops.layernorm_fwd(h, ps.f32(f + 'layer_norm.weight'), ps.f32(f + 'layer_norm.bias'))[0] if pre else h
+        g = ops.gemm(n2, ps.w(f + 'CoreNet.0.weight'), bias=ps.f32(f + 'CoreNet.0.bias'), act=ops.ACT_RELU)
+        o = ops.gemm(g, ps.w(f + 'CoreNet.3.weight'), bias=ps.f32(f + 'CoreNet.3.bias'), residual=h)
+        return o if pre else ops.layernorm_fwd(o, ps.f32(f + 'layer_norm.weight'), ps.f32(f + 'layer_norm.bias'))[0]
+
+    def _logits(self, h):
+        ps = self._store
+        return ops.gemm(h, ps.w('dec_out_proj.weight'), bias=ps.f32('dec_out_proj.bias'), out_dtype=torch.float32)
+
+    def _check_eval(self):
+        if self.training and self.dec_dropout > 0:
+            raise NotImplementedError('stage-1 training path (dropout + the backward of the relative-position attention) is the next build step; '
+                                      'call .eval() for the inference path')
+
+    # ------------------------------------------------------------------ reference API
+    @torch.no_grad()
+    def _prefill(self, dec_input, mem=None):
+        """Full-segment pass: dec_input int64 [T, B] -> (hidden [B*T, D], B, T); fills `mem` (K / V of every position) when given."""
+        if not dec_input.is_cuda:
+            raise EmoError('inputs must be GPU tensors (the HIP path has no CPU fallback)')
+        ps = self._ensure_store()
+        tok = dec_input.t().contiguous().long()
+        B, T = tok.shape
+        D, H = self.dec_d_model, self.dec_n_head
+        r_dist = mem.r_dist if mem is not None else self._r_by_distance(T)
+        x = self._embed(tok)
+        rw, rr = ps.f32('decoder.r_w_bias'), ps.f32('decoder.r_r_bias')
+        for l in range(self.dec_n_layer):
+            def attn(qkv, l=l):
+                if mem is not None:
+                    mem.kc[l][:, :T].copy_(qkv[:, D:2 * D].view(B, T, D))
+                    mem.vc[l][:, :T].copy_(qkv[:, 2 * D:].view(B, T, D))
+                return ops.relpos_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], r_dist[l], rw, rr, B, T, H)[0]
+            x = self._layer(l, x, attn)
+        if mem is not None:
+            mem.len = T
+            mem.lens.fill_(T)
+        return x, B, T
+
+    def forward(self, dec_input, dec_mems, dec_seg_len=None, return_avg_attn=False):
+        """plain_transformer.py:62-80.  dec_input int64 [T, B]; returns (logits fp32 [T, B, V], new_mems).  mem_len = 0 (every training / validation
+        YAML): new_mems is the empty list, as in the reference."""
+        self._check_eval()
+        if return_avg_attn or dec_seg_len is not None:
+            raise NotImplementedError('return_avg_attn / dec_seg_len are analysis paths of the reference and are not built')
+        if dec_mems is not None and len(dec_mems) > 0:
+            raise NotImplementedError('segment-level recurrence inside forward() (mem_len > 0 with incoming mems) is not built; use generate()')
+        h, B, T = self._prefill(dec_input)
+        logits = self._logits(h).view(B, T, self.vocab_size).permute(1, 0, 2)
+        return logits, []
+
+    @torch.no_grad()
+    def generate(self, dec_input, dec_mems):
+        """plain_transformer.py:52-59: first call = the whole primer [L, B] with dec_mems = tuple(); later calls one token [[id]] with the memory
+        returned by the previous call.  Returns (logits fp32 [V] of the last position of stream 0, memory)."""
+        if self.training:
+            raise NotImplementedError('generate() is an evaluation path: call .eval()')
+        D, H = self.dec_d_model, self.dec_n_head
+        if not isinstance(dec_mems, TXLMemory):
+            mem = TXLMemory(self, dec_input.shape[1], self._max_gen_len)
+            h, B, T = self._prefill(dec_input, mem)
+            return self._logits(h.view(B, T, D)[:, -1].contiguous())[0], mem
+        mem, ps = dec_mems, self._ensure_store()
+        if dec_input.shape[0] != 1:
+            raise NotImplementedError('generate() with memory takes one new token per call (the reference loop, inference_utils.py:66-77)')
+        if mem.len >= mem.max_len:
+            raise EmoError('generation longer than max_gen_len=%d: construct the model with a larger max_gen_len' % mem.max_len)
+        tok = dec_input.t().contiguous().long()
+        x = self._embed(tok)
+        mem.lens.add_(1)
+        mem.len += 1
+        rw, rr = ps.f32('decoder.r_w_bias'), ps.f32('decoder.r_r_bias')
+        for l in range(self.dec_n_layer):
+            def attn(qkv, l=l):
+                return ops.relpos_attn_decode(qkv[:, :D], mem.kc[l], mem.vc[l], mem.lens, H, mem.r_dist[l], rw, rr, mem_len=self.dec_mem_len,
+                                              k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:])
+            x = self._layer(l, x, attn)
+        return self._logits(x)[0], mem
+
+    def compute_loss(self, dec_logits, dec_tgt, reduction='mean'):
+        """plain_transformer.py:82-93 (evaluation use: validation loss); the fused cross-entropy of the stage-2 path."""
+        if reduction != 'mean':
+            raise NotImplementedError("only reduction='mean' (the reference's only use) is built")
+        V = dec_logits.size(-1)
+        ce = engine.XentFn.apply(dec_logits.reshape(-1, V).contiguous(), dec_tgt.contiguous().view(-1).long(), self.pad_index).float()
+        return {'ce_loss': ce, 'total_loss': ce}
