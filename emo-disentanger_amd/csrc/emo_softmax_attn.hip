@@ -807,6 +807,208 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const CT* __restrict__
     }
 }
 
+// Backward, query-tile organised (first version of the stage-1 training path).  With a_ij = m_ij p_ij / Z_i the final attention weight
+// (m = dropout multiplier, Z_i = sum_j m_ij p_ij + 1e-8 saved by the forward), dA_ij = dO_i.v_j and r1_i = dO_i.O_i:
+//     ds_ij = p_ij ( m_ij (dA_ij - r1_i) / Z_i - 1e-8 r1_i / Z_i )
+// The kernel recomputes p (content + relative term, as the forward), forms ds in registers, accumulates dq_content = ds.K / sqrt(dh) and
+// writes three dense by-products the host turns into the remaining gradients with plain GEMMs:
+//   A_nat  [B,H,T,T]  = a_ij                      -> dV = A^T dO
+//   dS_nat [B,H,T,T]  = ds_ij / sqrt(dh)          -> dK = dS^T (q + u)
+//   dS_skew[H,B,T,ND] = the same values at column (i - j) -> dR = dS_skew^T (q + v),  dq_relative = dS_skew R
+// (entries the causal mask removes are never written: the buffers arrive zeroed).  A fused dK/dV pass with its own skew is the follow-up.
+template <typename CT, int DH>
+__global__ __launch_bounds__(256, 2) void relattn_bwd_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+                                                             const CT* __restrict__ rd, int64_t ld_r, int64_t n_dist, const float* __restrict__ ub,
+                                                             const float* __restrict__ vb_, const CT* __restrict__ out, const CT* __restrict__ dout,
+                                                             int64_t ld_out, const float* __restrict__ lse_g, const float* __restrict__ zden_g,
+                                                             CT* __restrict__ dq, int64_t ld_d, CT* __restrict__ a_nat, CT* __restrict__ ds_nat,
+                                                             CT* __restrict__ ds_skew, int64_t nd_skew, int64_t ld_nat, int64_t B, int64_t T, int64_t H,
+                                                             DropCtx drop) {
+    typedef SaDims<CT, DH> D;
+    constexpr int LDX = D::LDX, LDC = D::LDC, DHP = D::DHP, ND = DH / 16, NQ = DHP / Img<CT>::KSTEP, SKW = 84;
+    constexpr bool TR = sizeof(CT) == 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    CT* Qi = (CT*)smem;                       // [64][LDX]  scratch image for the register fragments (q + u, q + v, dO)
+    CT* Ki = Qi + 64 * LDX;                   // [64][LDX]
+    CT* Vi = Ki + 64 * LDX;                   // [64][LDX]
+    CT* KT = Vi + 64 * LDX;                   // fp32 only: K^T [DH][LDC]
+    CT* Rw = KT + (TR ? 0 : DH * LDC);        // [128][LDX]
+    float* sk = (float*)(Rw + 128 * LDX);     // [4][16][SKW]
+    float* Dv = sk + 4 * 16 * SKW;            // [64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t qt = (int64_t)gridDim.x - 1 - blockIdx.x;
+    const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int64_t q0 = qt * 64;
+    const CT* qb = q + (b * T) * ld + h * DH;
+    const CT* kb = k + (b * T) * ld + h * DH;
+    const CT* vb = v + (b * T) * ld + h * DH;
+    const CT* ob = out + (b * T) * ld_out + h * DH;
+    const CT* gb = dout + (b * T) * ld_out + h * DH;
+    const CT* rb = rd + h * DH;
+    const int qvalid = (int)((T - q0) < 64 ? (T - q0) : 64);
+    RowPrefetch<CT, DH, DHP, 64, 256> pk, pv;
+    RowPrefetch<CT, DH, DHP, 64, 256, true> pkT;
+    constexpr int VE = 16 / sizeof(CT), CH = DH / VE, RNI = (128 * CH + 255) / 256;
+    CT rr[RNI][VE];
+    auto fetch_r = [&](int64_t d0) {
+#pragma unroll
+        for (int i = 0; i < RNI; ++i) {
+            const int it = tid + 256 * i;
+            const int row = it / CH, c = (it % CH) * VE;
+            const int64_t dist = d0 + row;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) rr[i][e] = from_f32<CT>(0.f);
+            if (it < 128 * CH && dist >= 0 && dist < n_dist) {
+                if constexpr (sizeof(CT) == 2) *(bf16x8*)rr[i] = *(const bf16x8*)(rb + dist * ld_r + c);
+                else *(f32x4*)rr[i] = *(const f32x4*)(rb + dist * ld_r + c);
+            }
+        }
+    };
+    auto store_r = [&]() {
+#pragma unroll
+        for (int i = 0; i < RNI; ++i) {
+            const int it = tid + 256 * i;
+            if (it < 128 * CH) {
+                const int row = it / CH, c = (it % CH) * VE;
+                if constexpr (sizeof(CT) == 2) *(bf16x8*)(Rw + row * LDX + c) = *(const bf16x8*)rr[i];
+                else {
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) Rw[row * LDX + c + e] = rr[i][e];
+                }
+            }
+        }
+        if constexpr (DHP > DH) {
+            for (int it = tid; it < 128 * (DHP - DH); it += 256) Rw[(it / (DHP - DH)) * LDX + DH + it % (DHP - DH)] = from_f32<CT>(0.f);
+        }
+    };
+    {
+        const int kv0 = (int)(T < 64 ? T : 64);
+        pk.load(kb, ld, kv0, tid); pv.load(vb, ld, kv0, tid);
+        if constexpr (!TR) pkT.load(kb, ld, kv0, tid);
+        fetch_r(q0 - 63);
+    }
+    rows_dot<CT, DH>(Dv, gb + q0 * ld_out, ob + q0 * ld_out, ld_out, qvalid, tid);
+    typename Img<CT>::V quf[NQ], qvf[NQ], gf[NQ];
+    for (int pass = 0; pass < 3; ++pass) {
+        const float* bias = (pass == 0 ? ub : vb_) + h * DH;
+        __syncthreads();
+        for (int it = tid; it < 64 * DHP; it += 256) {
+            const int r = it / DHP, d = it % DHP;
+            float x = 0.f;
+            if (r < qvalid && d < DH) x = pass < 2 ? to_f32<CT>(qb[(q0 + r) * ld + d]) + bias[d] : to_f32<CT>(gb[(q0 + r) * ld_out + d]);
+            Qi[r * LDX + d] = from_f32<CT>(x);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < NQ; ++kk) {
+            const typename Img<CT>::V f = Img<CT>::load(Qi, LDX, wave * 16, kk * Img<CT>::KSTEP, lane);
+            if (pass == 0) quf[kk] = f; else if (pass == 1) qvf[kk] = f; else gf[kk] = f;
+        }
+    }
+    const float sqrt_dh = sqrtf((float)DH), rsqrt_dh = 1.f / sqrt_dh, c2 = rsqrt_dh * EMO_LOG2E;
+    const int tl = wave * 16 + (lane & 15);
+    const int64_t tg = q0 + tl;
+    const bool row_ok = tg < T;
+    const float lse = row_ok ? lse_g[bh * T + tg] : INFINITY;
+    const float lse2 = lse * EMO_LOG2E;
+    const float zinv = row_ok ? 1.f / zden_g[bh * T + tg] : 0.f;
+    const float r1 = Dv[tl], r2 = 1e-8f * r1 * zinv;
+    f32x4 dqacc[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) dqacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float* skw = sk + (wave * 16 + (lane & 15)) * SKW;
+    CT* an_row = a_nat + (bh * T + tg) * ld_nat;
+    CT* dn_row = ds_nat + (bh * T + tg) * ld_nat;
+    CT* sk_row = ds_skew + ((h * B + b) * T + tg) * nd_skew;
+    for (int64_t kt = 0; kt <= qt; ++kt) {
+        const int64_t k0 = kt * 64;
+        __syncthreads();
+        pk.store_rows(Ki, LDX, tid);
+        pv.store_rows(Vi, LDX, tid);
+        if constexpr (!TR) pkT.store_T(KT, LDC, tid);
+        store_r();
+        if (kt < qt) {
+            const int64_t kn = k0 + 64;
+            const int nv = (int)((T - kn) < 64 ? (T - kn) : 64);
+            pk.load(kb + kn * ld, ld, nv, tid); pv.load(vb + kn * ld, ld, nv, tid);
+            if constexpr (!TR) pkT.load(kb + kn * ld, ld, nv, tid);
+            fetch_r(q0 - kn - 63);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ci = 0; ci < 5; ++ci) {
+            f32x4 a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NQ; ++kk) a2 = Img<CT>::mma(Img<CT>::load(Rw, LDX, (wave + ci) * 16, kk * Img<CT>::KSTEP, lane), qvf[kk], a2);
+            *(f32x4*)(skw + ci * 16 + (lane >> 4) * 4) = a2;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const bool diag = kt == qt;
+        float ds[4][4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            const bool live = !(diag && jt > wave);
+            if (live) {
+#pragma unroll
+                for (int kk = 0; kk < NQ; ++kk) {
+                    sa = Img<CT>::mma(Img<CT>::load(Ki, LDX, jt * 16, kk * Img<CT>::KSTEP, lane), quf[kk], sa);
+                    dp = Img<CT>::mma(Img<CT>::load(Vi, LDX, jt * 16, kk * Img<CT>::KSTEP, lane), gf[kk], dp);
+                }
+            }
+            float dm[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop.thr16) drop_mult4(drop, (uint64_t)((bh * T + tg) * T + k0 + jt * 16 + (lane >> 4) * 4), dm);
+            float av[4], dv4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jl = jt * 16 + (lane >> 4) * 4 + r;
+                const float sc = sa[r] + skw[(lane & 15) + 63 - jl];
+                float p = sizeof(CT) == 2 ? __builtin_amdgcn_exp2f(sc * c2 - lse2) : Img<CT>::ex(sc / sqrt_dh - lse);
+                if (diag && (jl > tl || k0 + jl >= T)) p = 0.f;
+                const float mp = dm[r] * p;
+                av[r] = mp * zinv;
+                ds[jt][r] = p * (dm[r] * (dp[r] - r1) * zinv - r2);
+                dv4[r] = ds[jt][r] * rsqrt_dh;
+            }
+            if (live && row_ok) {
+                const int64_t jg0 = k0 + jt * 16 + (lane >> 4) * 4;
+                if (jg0 + 3 < T && (ld_nat & 3) == 0) {
+                    Img<CT>::store4(an_row + jg0, av[0], av[1], av[2], av[3]);
+                    Img<CT>::store4(dn_row + jg0, dv4[0], dv4[1], dv4[2], dv4[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (jg0 + r < T) { an_row[jg0 + r] = from_f32<CT>(av[r]); dn_row[jg0 + r] = from_f32<CT>(dv4[r]); }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t dist = tg - (jg0 + r);
+                    if (dist >= 0 && jg0 + r < T) sk_row[dist] = from_f32<CT>(dv4[r]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // dQ_content^T[d][t] += sum_j K^T[d][j] dS[t][j]
+#pragma unroll
+        for (int st = 0; st < SaK<CT>::NS64; ++st) {
+            const typename Img<CT>::V df = reg_perm<CT>(ds, st);
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                if constexpr (TR) dqacc[i] = Img<CT>::mma(load_perm_tr((const bf16_t*)Ki, LDX, i * 16, st, lane), df, dqacc[i]);
+                else dqacc[i] = Img<CT>::mma(load_perm<CT>(KT, LDC, i * 16, st, lane), df, dqacc[i]);
+            }
+        }
+    }
+    if (row_ok) {
+        CT* db = dq + (b * T + tg) * ld_d + h * DH;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int d0 = i * 16 + (lane >> 4) * 4;
+            Img<CT>::store4(db + d0, dqacc[i][0] * rsqrt_dh, dqacc[i][1] * rsqrt_dh, dqacc[i][2] * rsqrt_dh, dqacc[i][3] * rsqrt_dh);
+        }
+    }
+}
+
 // one query per stream against a KV cache, keys j in [j0, len): score_j = ((q+u).k_j + (q+v).R[len-1-j]) / sqrt(dh)
 template <typename CT>
 __global__ __launch_bounds__(256) void relattn_decode_kernel(const CT* __restrict__ q, int64_t ld_q, CT* __restrict__ kc, CT* __restrict__ vc, int64_t T_max,
@@ -930,6 +1132,55 @@ extern "C" int emo_relpos_attn_fwd(const void* q, const void* k, const void* v, 
     RA_CASE(16)
 #undef RA_CASE
     emo_set_error("emo_relpos_attn_fwd: unsupported d_head=%lld (built: 16, 32, 64)", (long long)dh);
+    return EMO_ERR_UNSUPPORTED;
+}
+
+template <typename CT, int DH> static size_t ra_bwd_lds() {
+    typedef SaDims<CT, DH> D;
+    return sizeof(CT) * (size_t)(3 * 64 * D::LDX + (sizeof(CT) == 2 ? 0 : DH * D::LDC) + 128 * D::LDX) + sizeof(float) * (4 * 16 * 84 + 64);
+}
+template <typename CT, int DH>
+static int run_relattn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* rd, int64_t ld_r, int64_t n_dist, const float* ub,
+                           const float* vb, const void* out, const void* dout, int64_t ld_out, const float* lse, const float* zden, void* dq, int64_t ld_d,
+                           void* a_nat, void* ds_nat, void* ds_skew, int64_t nd_skew, int64_t ld_nat, int64_t B, int64_t T, int64_t H, DropCtx drop,
+                           hipStream_t st) {
+    dim3 grid((unsigned)((T + 63) / 64), (unsigned)(B * H));
+    const size_t lds = ra_bwd_lds<CT, DH>();
+    auto kf = relattn_bwd_kernel<CT, DH>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(kf, grid, dim3(256), lds, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, (const CT*)rd, ld_r, n_dist, ub, vb, (const CT*)out,
+                       (const CT*)dout, ld_out, lse, zden, (CT*)dq, ld_d, (CT*)a_nat, (CT*)ds_nat, (CT*)ds_skew, nd_skew, ld_nat, B, T, H, drop);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
+extern "C" int emo_relpos_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* r_dist, int64_t ld_r, int64_t n_dist,
+                                   const float* r_w_bias, const float* r_r_bias, const void* out, const void* dout, int64_t ld_out, const float* lse,
+                                   const float* zden, void* dq, int64_t ld_d, void* a_nat, void* ds_nat, int64_t ld_nat, void* ds_skew, int64_t nd_skew, int dtype,
+                                   int64_t B, int64_t T, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
+    int rc = sattn_check(q, k, v, ld, ld_out, dtype, dh);
+    if (rc) return rc;
+    EMO_CHECK(r_dist && r_w_bias && r_r_bias && out && dout && lse && zden && dq && a_nat && ds_nat && ds_skew, "emo_relpos_attn_bwd: null pointer");
+    const int64_t ve = dtype == EMO_BF16 ? 8 : 4;
+    EMO_CHECK(ld_r % ve == 0 && ld_d % 4 == 0 && (((uintptr_t)r_dist | (uintptr_t)dq | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)a_nat | (uintptr_t)ds_nat) & 15) == 0,
+              "emo_relpos_attn_bwd: pointers must be 16-B aligned");
+    EMO_CHECK(n_dist >= T && nd_skew >= T && ld_nat >= T, "emo_relpos_attn_bwd: r_dist / ds_skew / a_nat need a column for every distance / key 0 .. T-1");
+    const DropCtx drop = make_drop(p_drop, seed, offset);
+    hipStream_t st = (hipStream_t)stream;
+#define RAB_CASE(DHv)                                                                                                                                  \
+    if (dh == DHv) {                                                                                                                                   \
+        if (dtype == EMO_BF16)                                                                                                                         \
+            return run_relattn_bwd<bf16_t, DHv>(q, k, v, ld, r_dist, ld_r, n_dist, r_w_bias, r_r_bias, out, dout, ld_out, lse, zden, dq, ld_d, a_nat, ds_nat,  \
+                                                ds_skew, nd_skew, ld_nat, B, T, H, drop, st);                                                                 \
+        return run_relattn_bwd<float, DHv>(q, k, v, ld, r_dist, ld_r, n_dist, r_w_bias, r_r_bias, out, dout, ld_out, lse, zden, dq, ld_d, a_nat, ds_nat,       \
+                                           ds_skew, nd_skew, ld_nat, B, T, H, drop, st);                                                                      \
+    }
+    RAB_CASE(64)
+    RAB_CASE(32)
+    RAB_CASE(16)
+#undef RAB_CASE
+    emo_set_error("emo_relpos_attn_bwd: unsupported d_head=%lld (built: 16, 32, 64)", (long long)dh);
     return EMO_ERR_UNSUPPORTED;
 }
 

@@ -186,12 +186,24 @@ int emo_softmax_attn_decode(const void* q, int64_t ld_q, void* kcache, void* vca
  *   prob = softmax -> dropout -> p / (sum_j p + 1e-8);  out = prob v
  * q,k,v: [B*T, H*dh] views (row stride ld; batch-major).  r_dist [n_dist >= T, H*dh] (ld_r) = r_net(pos_emb) indexed BY DISTANCE
  * (row d = the reference's r_head_k[klen-1-d]).  r_w_bias / r_r_bias [H, dh] fp32.  lse [B,H,T], zden [B,H,T] (may be NULL:
- * the renormalisation denominator E/l + 1e-8) are saved for the backward pass (next round).  Forward only so far. */
+ * the renormalisation denominator E/l + 1e-8) are saved for the backward pass. */
 int emo_relpos_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const void* r_dist,
                         int64_t ld_r, int64_t n_dist, const float* r_w_bias, const float* r_r_bias,
                         void* out, int64_t ld_out, float* lse, float* zden, int dtype, int64_t B,
                         int64_t T, int64_t H, int64_t dh, float p_drop, uint64_t seed,
                         uint64_t offset, emo_stream_t stream);
+/* Backward, first version: recomputes the probabilities per query tile, returns dq_content = ds.K/sqrt(dh) in dq and three dense
+ * by-products (dtype of q; must arrive ZEROED, the kernel only writes the causal part):
+ *   a_nat  [B,H,T,ld_nat]   final attention weights a_ij             (dV = a^T dO)
+ *   ds_nat [B,H,T,ld_nat]   d score_ij / sqrt(dh)                    (dK = ds^T (q + r_w_bias))
+ *   ds_skew[H,B,T,nd_skew]  the same values at column i-j            (dR = ds_skew^T (q + r_r_bias), dq_relative = ds_skew R)
+ * which the caller turns into dk, dv, dR, dq_relative and the two bias gradients with emo_gemm (model/plain_transformer.py). */
+int emo_relpos_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* r_dist,
+                        int64_t ld_r, int64_t n_dist, const float* r_w_bias, const float* r_r_bias,
+                        const void* out, const void* dout, int64_t ld_out, const float* lse,
+                        const float* zden, void* dq, int64_t ld_d, void* a_nat, void* ds_nat,
+                        int64_t ld_nat, void* ds_skew, int64_t nd_skew, int dtype, int64_t B, int64_t T, int64_t H,
+                        int64_t dh, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream);
 /* one query row per stream against a KV cache (the reference re-projects its cached hidden states `mems` every step,
  * plain_transformer.py:52-59; k / v of a position do not change, so they are cached instead).  Keys j in
  * [max(0, len-1-mem_len), len) with len = lens[s] + lens_off; the distance of key j is len-1-j.  k_new / v_new as in

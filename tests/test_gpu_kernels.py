@@ -270,6 +270,31 @@ def test_relpos_attention_fwd_and_decode(dt, B, T, H, dh):
         _close(o2.view(B, H, dh), ref2, dt, mult=3)
 
 
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('B,T,H,dh', [(2, 150, 2, 64), (1, 70, 3, 32), (2, 33, 2, 16), (1, 128, 1, 64)])
+def test_relpos_attention_backward(dt, B, T, H, dh):
+    ops = _ops()
+    HD = H * dh
+    qkv = _r(B * T, 3 * HD, seed=1, dt=dt, scale=0.7)
+    R = _r(T, HD, seed=2, dt=dt, scale=0.7)
+    u, vb = _r(H, dh, seed=3, scale=0.3), _r(H, dh, seed=4, scale=0.3)
+    leaf = [t.double().requires_grad_(True) for t in (qkv, R, u, vb)]
+    q, k, v = [leaf[0][:, i * HD:(i + 1) * HD].view(B, T, H, dh) for i in range(3)]
+    ref = _relattn_ref(q, k, v, leaf[1].view(T, H, dh), leaf[2], leaf[3])
+    dout = _r(B, T, H, dh, seed=5, dt=dt)
+    ref.backward(dout.double())
+    qc = qkv.cuda()
+    out, lse, zden = ops.relpos_attn_fwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], R.cuda(), u.cuda(), vb.cuda(), B, T, H)
+    dqkv, dR, du, dvb = ops.relpos_attn_bwd(qc, R.cuda(), u.cuda(), vb.cuda(), out, dout.view(B * T, HD).cuda(), lse, zden, B, T, H)
+    gs = float(leaf[0].grad.abs().max())
+    _close(dqkv[:, 2 * HD:], leaf[0].grad[:, 2 * HD:], dt, scale=gs, mult=4)
+    _close(dqkv[:, HD:2 * HD], leaf[0].grad[:, HD:2 * HD], dt, scale=gs, mult=4)
+    _close(dqkv[:, :HD], leaf[0].grad[:, :HD], dt, scale=gs, mult=4)
+    _close(dR, leaf[1].grad, dt, scale=float(leaf[1].grad.abs().max()), mult=6)
+    _close(du, leaf[2].grad, dt, scale=float(leaf[2].grad.abs().max()), mult=8)
+    _close(dvb, leaf[3].grad, dt, scale=float(leaf[3].grad.abs().max()), mult=8)
+
+
 # ------------------------------------------------------------------------------------------- embedding / LN / xent
 @pytest.mark.parametrize('dt', DT)
 def test_embed_fwd_bwd(dt):
