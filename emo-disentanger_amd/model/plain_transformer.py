@@ -2,9 +2,9 @@
 
 Mirrors /root/reference/stage1_compose/model/plain_transformer.py:14-93 (PlainTransformer: constructor, forward, generate, compute_loss) on
 top of OptimusTXLDecoder with attn_type 0 (optimus_txl_decoder.py:299-391, 700-925): same constructor arguments, parameter names, registration
-order (= optimizer state order) and state-dict keys, so reference checkpoints load unchanged.  Built so far: the evaluation forward pass and
-token-by-token generation with memory on the HIP kernels (relative-position attention: emo_relpos_attn_fwd / _decode); the TRAINING path
-(attention backward with the relative term) is the next build step and raises NotImplementedError.
+order (= optimizer state order) and state-dict keys, so reference checkpoints load unchanged.  Evaluation forward, training forward /
+backward (all eight dropout sites of the reference) and token-by-token generation with memory run on the HIP kernels (relative-position
+attention: emo_relpos_attn_fwd / _bwd / _decode); the backward of the attention is a first version (dense by-products + GEMMs).
 
 The reference keeps `mems` = the hidden states of the last mem_len positions per layer and re-projects them to keys / values at every step
 (:309-316); the key / value of a position never changes, so the engine caches K and V instead (`TXLMemory`, returned where the reference
@@ -93,6 +93,105 @@ class OptimusTXLDecoder(nn.Module):             # the class name matters: weight
         self.pos_emb = PositionalEmbedding(d_model)
 
 
+def _txl_layer_fwd(ps, p, x, r_dist, B, T, H, pd, seed, off, pre, save):
+    """RelPartialLearnableDecoderLayer (:526-557) = rel. attention (:301-391) + PositionwiseFF (:28-66), training or evaluation."""
+    D = x.shape[1]
+    a, f = p + 'dec_attn.', p + 'pos_ff.'
+    if not pre:
+        raise NotImplementedError('post-LN (pre_lnorm=False) training is not built: every stage-1 YAML sets pre_lnorm: True')
+    n, m1, r1 = ops.layernorm_fwd(x, ps.f32(a + 'layer_norm.weight'), ps.f32(a + 'layer_norm.bias'))
+    qkv = ops.gemm(n, ps.w(a + 'qkv_net.weight'))
+    vec, lse, zden = ops.relpos_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], r_dist, ps.f32('decoder.r_w_bias'), ps.f32('decoder.r_r_bias'),
+                                         B, T, H, p_drop=pd, seed=seed, offset=off + 1)
+    h = ops.gemm(vec, ps.w(a + 'o_net.weight'), p_drop=pd, seed=seed, offset=off + 2, residual=x)
+    n2, m2, r2 = ops.layernorm_fwd(h, ps.f32(f + 'layer_norm.weight'), ps.f32(f + 'layer_norm.bias'))
+    g = ops.gemm(n2, ps.w(f + 'CoreNet.0.weight'), bias=ps.f32(f + 'CoreNet.0.bias'), act=ops.ACT_RELU, p_drop=pd, seed=seed, offset=off + 3)
+    o = ops.gemm(g, ps.w(f + 'CoreNet.3.weight'), bias=ps.f32(f + 'CoreNet.3.bias'), p_drop=pd, seed=seed, offset=off + 4, residual=h)
+    if save is not None:
+        save.update(x=x, m1=m1, r1=r1, n=n, qkv=qkv, vec=vec, lse=lse, zden=zden, h=h, m2=m2, r2=r2, n2=n2, g=g, r_dist=r_dist)
+    return o
+
+
+def _txl_layer_bwd(ps, p, dout, pe_d, B, T, H, pd, seed, off, s):
+    D = dout.shape[1]
+    a, f = p + 'dec_attn.', p + 'pos_ff.'
+    inv = 1.0 / (1.0 - pd) if pd > 0 else 1.0
+    wg = lambda dy, xin, wname, bname=None: ops.gemm(dy, xin, a_trans=True, b_trans=True, out=ps.g(wname), accumulate=True,
+                                                     a_rowsum=None if bname is None else ps.g(bname))
+    dyd = ops.dropout_apply(dout, pd, seed, off + 4) if pd > 0 else dout
+    wg(dyd, s['g'], f + 'CoreNet.3.weight', f + 'CoreNet.3.bias')
+    dg = ops.gemm(dyd, ps.w(f + 'CoreNet.3.weight'), b_trans=True, mul_aux=s['g'], mul_mode=ops.MUL_NONZERO, mul_scale=inv)
+    wg(dg, s['n2'], f + 'CoreNet.0.weight', f + 'CoreNet.0.bias')
+    dn2 = ops.gemm(dg, ps.w(f + 'CoreNet.0.weight'), b_trans=True)
+    dh, _ = ops.layernorm_bwd(dn2, s['h'], ps.f32(f + 'layer_norm.weight'), s['m2'], s['r2'], ps.g(f + 'layer_norm.weight'), ps.g(f + 'layer_norm.bias'),
+                              dres=dout)
+    dad = ops.dropout_apply(dh, pd, seed, off + 2) if pd > 0 else dh
+    wg(dad, s['vec'], a + 'o_net.weight')
+    dvec = ops.gemm(dad, ps.w(a + 'o_net.weight'), b_trans=True)
+    dqkv, dR, d_rw, d_rr = ops.relpos_attn_bwd(s['qkv'], s['r_dist'], ps.f32('decoder.r_w_bias'), ps.f32('decoder.r_r_bias'), s['vec'], dvec, s['lse'],
+                                               s['zden'], B, T, H, p_drop=pd, seed=seed, offset=off + 1)
+    ps.g('decoder.r_w_bias').add_(d_rw)
+    ps.g('decoder.r_r_bias').add_(d_rr)
+    wg(dR.to(ps.compute_dtype), pe_d, a + 'r_net.weight')                     # R = r_net(dropout(pos_emb)): dW_r += dR^T pos_emb
+    wg(dqkv, s['n'], a + 'qkv_net.weight')
+    dn = ops.gemm(dqkv, ps.w(a + 'qkv_net.weight'), b_trans=True)
+    dx, _ = ops.layernorm_bwd(dn, s['x'], ps.f32(a + 'layer_norm.weight'), s['m1'], s['r1'], ps.g(a + 'layer_norm.weight'), ps.g(a + 'layer_norm.bias'),
+                              dres=dh)
+    return dx
+
+
+class TXLStackFn(torch.autograd.Function):
+    """tokens [B, T] -> final hidden states [B, T, D] (OptimusTXLDecoder._forward :750-925 with attn_type 0, mem_len 0).  Dropout sites as in
+    the reference: emb_dropout AND decoder.drop on the embedding, decoder.drop on pos_emb, dropatt on the probabilities, drop on the attention
+    output, the two CoreNet dropouts, decoder.drop on the final hidden state.  Parameter gradients go straight into the flat grad buffer."""
+
+    @staticmethod
+    def forward(ctx, model, tok, anchor, need_bwd):
+        ps = model._store
+        B, T = tok.shape
+        D, H, L = model.dec_d_model, model.dec_n_head, model.dec_n_layer
+        pd = model.dec_dropout if model.training else 0.0
+        model._fwd_counter += 1
+        seed, base = model._seed, model._fwd_counter * 4096
+        x = ops.embed_fwd(tok, None, ps.f32('word_emb.emb_lookup.weight'), None, model._zero_pe(T), ps.compute_dtype, float(model.word_emb.emb_scale),
+                          p_drop=pd, seed=seed, offset=base).view(B * T, D)
+        if pd > 0:
+            x = ops.dropout_apply(x, pd, seed, base + 1)
+        pe = model.decoder.pos_emb(torch.arange(T, device=ps.device, dtype=torch.float32)).to(ps.compute_dtype).contiguous()   # row d = distance d
+        pe_d = ops.dropout_apply(pe, pd, seed, base + 3) if pd > 0 else pe
+        saves = []
+        for l in range(L):
+            sv = {} if need_bwd else None
+            r_dist = ops.gemm(pe_d, ps.w('decoder.layers.%d.dec_attn.r_net.weight' % l))
+            x = _txl_layer_fwd(ps, 'decoder.layers.%d.' % l, x, r_dist, B, T, H, pd, seed, base + 8 * (l + 1), model.decoder.pre_lnorm, sv)
+            saves.append(sv)
+        if pd > 0:
+            x = ops.dropout_apply(x, pd, seed, base + 2)
+        ctx.model, ctx.saves, ctx.tok, ctx.pe_d = model, saves, tok, pe_d
+        ctx.cfg = (B, T, D, H, L, pd, seed, base)
+        return x.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, ps = ctx.model, ctx.model._store
+        B, T, D, H, L, pd, seed, base = ctx.cfg
+        ps.ensure_grads()
+        dx = dout.reshape(B * T, D)
+        if dx.dtype != ps.compute_dtype or not dx.is_contiguous():
+            dx = dx.to(ps.compute_dtype).contiguous()
+        if pd > 0:
+            dx = ops.dropout_apply(dx, pd, seed, base + 2)
+        for l in reversed(range(L)):
+            dx = _txl_layer_bwd(ps, 'decoder.layers.%d.' % l, dx, ctx.pe_d, B, T, H, pd, seed, base + 8 * (l + 1), ctx.saves[l])
+            ctx.saves[l] = None
+        if pd > 0:
+            dx = ops.dropout_apply(dx, pd, seed, base + 1)
+        gE = ps.g('word_emb.emb_lookup.weight')
+        ops.embed_bwd(ctx.tok, None, dx, gE, None, float(model.word_emb.emb_scale), p_drop=pd, seed=seed, offset=base)
+        gE[model.word_emb.emb_lookup.padding_idx].zero_()            # nn.Embedding(padding_idx): that row never receives a gradient
+        return None, None, None, None
+
+
 class TXLMemory:
     """What generate() hands back in place of the reference's list of `mems` tensors: per-layer K / V caches of one lock-step group of streams."""
 
@@ -125,6 +224,7 @@ class PlainTransformer(nn.Module):
         self.apply(weights_init)
         self._compute_dtype = engine._dt(compute_dtype or os.environ.get('EMO_COMPUTE_DTYPE', 'bf16'))
         self._store, self._max_gen_len, self._zero_pe_buf = None, max_gen_len, None
+        self._fwd_counter, self._seed = 0, int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
 
     # ------------------------------------------------------------------ engine plumbing
     def _ensure_store(self):
@@ -136,6 +236,9 @@ class PlainTransformer(nn.Module):
     def set_compute_dtype(self, name):
         self._compute_dtype, self._store = engine._dt(name), None
         return self
+
+    def set_dropout_seed(self, seed):
+        self._seed, self._fwd_counter = int(seed), 0
 
     def _zero_pe(self, n):
         if self._zero_pe_buf is None or self._zero_pe_buf.shape[0] < n or self._zero_pe_buf.device != self._store.device:
@@ -174,11 +277,6 @@ class PlainTransformer(nn.Module):
         ps = self._store
         return ops.gemm(h, ps.w('dec_out_proj.weight'), bias=ps.f32('dec_out_proj.bias'), out_dtype=torch.float32)
 
-    def _check_eval(self):
-        if self.training and self.dec_dropout > 0:
-            raise NotImplementedError('stage-1 training path (dropout + the backward of the relative-position attention) is the next build step; '
-                                      'call .eval() for the inference path')
-
     # ------------------------------------------------------------------ reference API
     @torch.no_grad()
     def _prefill(self, dec_input, mem=None):
@@ -207,11 +305,18 @@ class PlainTransformer(nn.Module):
     def forward(self, dec_input, dec_mems, dec_seg_len=None, return_avg_attn=False):
         """plain_transformer.py:62-80.  dec_input int64 [T, B]; returns (logits fp32 [T, B, V], new_mems).  mem_len = 0 (every training / validation
         YAML): new_mems is the empty list, as in the reference."""
-        self._check_eval()
         if return_avg_attn or dec_seg_len is not None:
             raise NotImplementedError('return_avg_attn / dec_seg_len are analysis paths of the reference and are not built')
         if dec_mems is not None and len(dec_mems) > 0:
             raise NotImplementedError('segment-level recurrence inside forward() (mem_len > 0 with incoming mems) is not built; use generate()')
+        anchor = self.word_emb.emb_lookup.weight
+        if self.training or (torch.is_grad_enabled() and anchor.requires_grad):
+            if not dec_input.is_cuda:
+                raise EmoError('inputs must be GPU tensors (the HIP path has no CPU fallback)')
+            self._ensure_store()
+            tok = dec_input.t().contiguous().long()
+            h = TXLStackFn.apply(self, tok, anchor, torch.is_grad_enabled() and anchor.requires_grad)
+            return engine.LogitsFn.apply(self, h).permute(1, 0, 2), []
         h, B, T = self._prefill(dec_input)
         logits = self._logits(h).view(B, T, self.vocab_size).permute(1, 0, 2)
         return logits, []

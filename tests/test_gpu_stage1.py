@@ -29,7 +29,7 @@ def test_stage1_forward_and_loss_match_reference_fp32(name, c):
     x, tgt = torch.from_numpy(g['x']).cuda(), torch.from_numpy(g['tgt']).cuda()
     logits, mems = m(x, tuple())
     assert mems == [] and logits.shape == (c['T'], x.shape[1], c['V']) and logits.dtype == torch.float32
-    lg = logits.cpu()
+    lg = logits.detach().cpu()
     scale = float(np.abs(g['logits_row0']).max())
     tol = 2e-4 * max(scale, 1.0)
     np.testing.assert_allclose(lg[..., :8].numpy(), g['logits_head'], rtol=0, atol=tol)
@@ -42,7 +42,7 @@ def test_stage1_forward_and_loss_match_reference_fp32(name, c):
     safe = (top2[..., 0] - top2[..., 1]) > 1e-3
     assert torch.equal(lg.argmax(-1)[safe], torch.from_numpy(g['argmax'])[safe])                 # greedy ids bit-exact where the margin allows
     loss = m.compute_loss(logits, tgt)['total_loss']
-    assert abs(float(loss) - float(g['loss'])) < 1e-4
+    assert abs(float(loss.detach()) - float(g['loss'])) < 1e-4
 
 
 @pytest.mark.parametrize('name,c', CASES)
@@ -67,15 +67,73 @@ def test_stage1_generation_with_memory(name, c, dtype):
         assert (got.argmax(-1)[safe] == ref.argmax(-1)[safe]).all()
 
 
-def test_stage1_bf16_forward_close_and_training_path_is_refused():
+def test_stage1_bf16_forward_close():
     name, c = CASES[1]
     g = np.load(os.path.join(G, name + '.npz'))
     m, _ = _model(c, 'bf16')
     x = torch.from_numpy(g['x']).cuda()
     logits, _ = m(x, tuple())
     scale = float(np.abs(g['logits_row0']).max())
-    assert float((logits[0].cpu() - torch.from_numpy(g['logits_row0'])).abs().max()) <= 6e-2 * scale
-    assert float((logits[-1].cpu() - torch.from_numpy(g['logits_rowlast'])).abs().max()) <= 6e-2 * scale
-    m.train()
-    with pytest.raises(NotImplementedError, match='training path'):
-        m(x, tuple())
+    assert float((logits[0].detach().cpu() - torch.from_numpy(g['logits_row0'])).abs().max()) <= 6e-2 * scale
+    assert float((logits[-1].detach().cpu() - torch.from_numpy(g['logits_rowlast'])).abs().max()) <= 6e-2 * scale
+
+
+@pytest.mark.parametrize('name,c', CASES)
+def test_stage1_training_step_gradients_match_reference_fp32(name, c):
+    # the reference fixture: model.train() with dropout 0, loss.backward(), per-parameter gradient norms in registration order
+    from emo_disentanger_amd.model.plain_transformer import PlainTransformer
+    from oracle.txl_ref import make_state_dict_txl
+    g = np.load(os.path.join(G, name + '.npz'))
+    sd = make_state_dict_txl(c['V'], c['L'], c['H'], c['d'], c['dff'], seed=c['seed'], scale=c['scale'])
+    m = PlainTransformer(c['d'], c['V'], c['L'], c['H'], c['d'], c['dff'], 0, c['T'], dec_dropout=0.0, pre_lnorm=True, compute_dtype='fp32')
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    x, tgt = torch.from_numpy(g['x']).cuda(), torch.from_numpy(g['tgt']).cuda()
+    logits, mems = m(x, tuple())
+    loss = m.compute_loss(logits, tgt)['total_loss']
+    assert abs(float(loss.detach()) - float(g['loss'])) < 1e-4
+    loss.backward()
+    names = [n for n, _ in m.named_parameters()]
+    assert names == [str(n) for n in g['grad_names']]
+    for (n, p), ref in zip(m.named_parameters(), g['grad_norms']):
+        got = float(p.grad.norm())
+        assert abs(got - ref) <= 2e-3 * max(ref, 1e-3), (n, got, ref)
+    pad = m.word_emb.emb_lookup.padding_idx
+    assert float(m.word_emb.emb_lookup.weight.grad[pad].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_stage1_training_with_dropout_is_seeded_and_trains(dtype):
+    from emo_disentanger_amd.model.plain_transformer import PlainTransformer
+    from oracle.txl_ref import make_state_dict_txl
+    name, c = CASES[1]
+    g = np.load(os.path.join(G, name + '.npz'))
+    sd = make_state_dict_txl(c['V'], c['L'], c['H'], c['d'], c['dff'], seed=c['seed'], scale=c['scale'])
+    m = PlainTransformer(c['d'], c['V'], c['L'], c['H'], c['d'], c['dff'], 0, c['T'], dec_dropout=0.1, pre_lnorm=True, compute_dtype=dtype)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    x, tgt = torch.from_numpy(g['x']).cuda(), torch.from_numpy(g['tgt']).cuda()
+
+    def run(seed):
+        m.set_dropout_seed(seed)
+        m.zero_grad()
+        loss = m.compute_loss(m(x, tuple())[0], tgt)['total_loss']
+        loss.backward()
+        return float(loss.detach()), torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+    l1, g1 = run(5)
+    l2, g2 = run(5)
+    l3, g3 = run(6)
+    assert abs(l1 - l2) < 1e-5 and torch.allclose(g1, g2, rtol=0, atol=2e-5 * float(g1.abs().max()))      # same seed: same masks forward AND backward (up to atomic summation order)
+    assert abs(l1 - l3) > 1e-4 and np.isfinite(l1) and np.isfinite(l3) and bool(torch.isfinite(g3).all())
+    assert abs(l1 - float(g['loss'])) < 0.5                                                   # dropout perturbs, it does not break
+    # a few plain SGD steps on one batch reduce the loss (the backward points downhill through every dropout site)
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    m.set_dropout_seed(11)
+    first = None
+    for it in range(12):
+        opt.zero_grad()
+        loss = m.compute_loss(m(x, tuple())[0], tgt)['total_loss']
+        loss.backward()
+        opt.step()
+        first = float(loss.detach()) if first is None else first
+    assert float(loss.detach()) < first - 0.05
