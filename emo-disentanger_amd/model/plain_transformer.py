@@ -334,7 +334,15 @@ class PlainTransformer(nn.Module):
             return self._logits(h.view(B, T, D)[:, -1].contiguous())[0], mem
         mem, ps = dec_mems, self._ensure_store()
         if dec_input.shape[0] != 1:
-            raise NotImplementedError('generate() with memory takes one new token per call (the reference loop, inference_utils.py:66-77)')
+            # the reference loop re-submits the whole primer with the memory of the primer when the very first sample is rejected
+            # (inference_utils.py:67-70 + `continue`); token i of a segment sees the memory and tokens <= i, which is what feeding them one at a
+            # time does as long as the window does not slide inside the segment
+            if self.dec_mem_len > 0 and mem.len + dec_input.shape[0] > self.dec_mem_len + 1:
+                raise NotImplementedError('a multi-token segment that overflows mem_len while it is processed is not built')
+            logits = None
+            for i in range(dec_input.shape[0]):
+                logits, mem = self.generate(dec_input[i:i + 1], mem)
+            return logits, mem
         if mem.len >= mem.max_len:
             raise EmoError('generation longer than max_gen_len=%d: construct the model with a larger max_gen_len' % mem.max_len)
         tok = dec_input.t().contiguous().long()

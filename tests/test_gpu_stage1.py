@@ -137,3 +137,34 @@ def test_stage1_training_with_dropout_is_seeded_and_trains(dtype):
         opt.step()
         first = float(loss.detach()) if first is None else first
     assert float(loss.detach()) < first - 0.05
+
+
+def test_stage1_generate_plain_xl_reproduces_reference_traces():
+    # the REAL reference loop (inference_utils.py:51-134) was traced with NumPy-seeded sampling on a tiny imported model: same seeds => same
+    # sampled words (incl. the rejected ones, after which the reference re-feeds the last token and so duplicates it in the memory) and output
+    from emo_disentanger_amd import stage1_inference as s1
+    from emo_disentanger_amd.model.plain_transformer import PlainTransformer
+    from oracle.txl_ref import make_state_dict_txl
+    g = json.load(open(os.path.join(G, 'txl_generate.json')))
+    c = g['model']
+    e2i = {e: i for i, e in enumerate(g['events'])}
+    i2e = {i: e for e, i in e2i.items()}
+    sd = make_state_dict_txl(c['V'], c['L'], c['H'], c['d'], c['dff'], seed=c['seed'], scale=c['scale'])
+    m = PlainTransformer(c['d'], c['V'], c['L'], c['H'], c['d'], c['dff'], c['T'], c['T'], dec_dropout=0.1, pre_lnorm=True, compute_dtype='fp32')
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    for run in g['runs']:
+        np.random.seed(run['seed'])
+        orig = s1.nucleus
+        rec = []
+        s1.nucleus = lambda probs, p, orig=orig, rec=rec: (lambda w: (rec.append(int(w)), w)[1])(orig(probs, p))
+        try:
+            if run['error'] is not None:
+                with pytest.raises(ValueError, match='key generation failed'):
+                    s1.generate_plain_xl(m, e2i, i2e, temp=1.2, top_p=0.9, **run['kw'])
+            else:
+                out, _ = s1.generate_plain_xl(m, e2i, i2e, temp=1.2, top_p=0.9, **run['kw'])
+                assert out == run['generated'], run['seed']
+            assert rec == run['sampled'], run['seed']
+        finally:
+            s1.nucleus = orig
