@@ -822,8 +822,8 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_kernel(const CT* __restric
                                                              const float* __restrict__ vb_, const CT* __restrict__ out, const CT* __restrict__ dout,
                                                              int64_t ld_out, const float* __restrict__ lse_g, const float* __restrict__ zden_g,
                                                              CT* __restrict__ dq, int64_t ld_d, CT* __restrict__ a_nat, CT* __restrict__ ds_nat,
-                                                             CT* __restrict__ ds_skew, int64_t nd_skew, int64_t ld_nat, int64_t B, int64_t T, int64_t H,
-                                                             DropCtx drop) {
+                                                             CT* __restrict__ ds_skew, int64_t nd_skew, int64_t ld_nat, float* __restrict__ delta_g,
+                                                             int64_t B, int64_t T, int64_t H, DropCtx drop) {
     typedef SaDims<CT, DH> D;
     constexpr int LDX = D::LDX, LDC = D::LDC, DHP = D::DHP, ND = DH / 16, NQ = DHP / Img<CT>::KSTEP, SKW = 84;
     constexpr bool TR = sizeof(CT) == 2;
@@ -913,6 +913,7 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_kernel(const CT* __restric
     const float lse2 = lse * EMO_LOG2E;
     const float zinv = row_ok ? 1.f / zden_g[bh * T + tg] : 0.f;
     const float r1 = Dv[tl], r2 = 1e-8f * r1 * zinv;
+    if (delta_g && tid < qvalid) delta_g[bh * T + q0 + tid] = Dv[tid];
     f32x4 dqacc[ND];
 #pragma unroll
     for (int i = 0; i < ND; ++i) dqacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -972,7 +973,8 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_kernel(const CT* __restric
             }
             if (live && row_ok) {
                 const int64_t jg0 = k0 + jt * 16 + (lane >> 4) * 4;
-                if (jg0 + 3 < T && (ld_nat & 3) == 0) {
+                if (!a_nat) {
+                } else if (jg0 + 3 < T && (ld_nat & 3) == 0) {
                     Img<CT>::store4(an_row + jg0, av[0], av[1], av[2], av[3]);
                     Img<CT>::store4(dn_row + jg0, dv4[0], dv4[1], dv4[2], dv4[3]);
                 } else {
@@ -1005,6 +1007,182 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_kernel(const CT* __restric
         for (int i = 0; i < ND; ++i) {
             const int d0 = i * 16 + (lane >> 4) * 4;
             Img<CT>::store4(db + d0, dqacc[i][0] * rsqrt_dh, dqacc[i][1] * rsqrt_dh, dqacc[i][2] * rsqrt_dh, dqacc[i][3] * rsqrt_dh);
+        }
+    }
+}
+
+// Backward, key-tile pass: dK and dV (replaces the dense a / ds matrices + per-(b, h) GEMMs of the first version).  qu = q + r_w_bias and
+// qv = q + r_r_bias arrive materialised ([B*T, H*dh], pitch ld_q).  A wave owns 16 key rows; for a 16-row query sub-tile tt the relative term
+// only touches two 16-row tiles of the distance window (c = t - j + 63 in [16(tt-w)+48, 16(tt-w)+78]), skewed through a [16][32] buffer.
+template <typename CT, int DH>
+__global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 2 : 1)) void relattn_bwd_dkv_kernel(
+    const CT* __restrict__ qu, const CT* __restrict__ qv, int64_t ld_q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+    const CT* __restrict__ rd, int64_t ld_r, int64_t n_dist, const CT* __restrict__ dout, int64_t ld_out, const float* __restrict__ lse_g,
+    const float* __restrict__ zden_g, const float* __restrict__ delta_g, CT* __restrict__ dk, CT* __restrict__ dv, int64_t ld_d, int64_t T, int64_t H,
+    DropCtx drop) {
+    typedef SaDims<CT, DH> D;
+    constexpr int LDX = D::LDX, LDC = D::LDC, DHP = D::DHP, ND = DH / 16, NQ = DHP / Img<CT>::KSTEP, SKW = 36;
+    constexpr bool TR = sizeof(CT) == 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    CT* Ki = (CT*)smem;           // [64][LDX]  (Ki / Vi only to build the register fragments)
+    CT* Vi = Ki + 64 * LDX;       // [64][LDX]
+    CT* Qu = Vi + 64 * LDX;       // [64][LDX]
+    CT* Qv = Qu + 64 * LDX;       // [64][LDX]
+    CT* dOi = Qv + 64 * LDX;      // [64][LDX]
+    CT* Rw = dOi + 64 * LDX;      // [128][LDX]
+    CT* QT = Rw + 128 * LDX;      // fp32 only: (q+u)^T, dO^T [DH][LDC] each
+    CT* dOT = QT + DH * LDC;
+    float* sk = (float*)(QT + (TR ? 0 : 2 * DH * LDC));   // [4][16][SKW]
+    float* Dv = sk + 4 * 16 * SKW;  // [64] r1
+    float* Lv = Dv + 64;            // [64] lse (base-2 in bf16 mode)
+    float* Zv = Lv + 64;            // [64] 1 / zden
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t kt = blockIdx.x;
+    const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int64_t k0 = kt * 64;
+    const int64_t nqt = (T + 63) / 64;
+    const CT* qub = qu + (b * T) * ld_q + h * DH;
+    const CT* qvb = qv + (b * T) * ld_q + h * DH;
+    const CT* kb = k + (b * T) * ld + h * DH;
+    const CT* vb = v + (b * T) * ld + h * DH;
+    const CT* gb = dout + (b * T) * ld_out + h * DH;
+    const CT* rb = rd + h * DH;
+    const int kvalid = (int)((T - k0) < 64 ? (T - k0) : 64);
+    RowPrefetch<CT, DH, DHP, 64, 256> pq, pq2, pg;
+    RowPrefetch<CT, DH, DHP, 64, 256, true> pqT, pgT;
+    constexpr int VE = 16 / sizeof(CT), CH = DH / VE, RNI = (128 * CH + 255) / 256;
+    CT rr[RNI][VE];
+    float pl = 0.f, pz = 0.f, pd_ = 0.f;
+    auto fetch = [&](int64_t q0n) {
+        const int nv = (int)((T - q0n) < 64 ? (T - q0n) : 64);
+        pq.load(qub + q0n * ld_q, ld_q, nv, tid);
+        pq2.load(qvb + q0n * ld_q, ld_q, nv, tid);
+        pg.load(gb + q0n * ld_out, ld_out, nv, tid);
+        if constexpr (!TR) { pqT.load(qub + q0n * ld_q, ld_q, nv, tid); pgT.load(gb + q0n * ld_out, ld_out, nv, tid); }
+        const int64_t d0 = q0n - k0 - 63;
+#pragma unroll
+        for (int i = 0; i < RNI; ++i) {
+            const int it = tid + 256 * i;
+            const int row = it / CH, c = (it % CH) * VE;
+            const int64_t dist = d0 + row;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) rr[i][e] = from_f32<CT>(0.f);
+            if (it < 128 * CH && dist >= 0 && dist < n_dist) {
+                if constexpr (sizeof(CT) == 2) *(bf16x8*)rr[i] = *(const bf16x8*)(rb + dist * ld_r + c);
+                else *(f32x4*)rr[i] = *(const f32x4*)(rb + dist * ld_r + c);
+            }
+        }
+        if (tid < 64) {
+            const bool ok = q0n + tid < T;
+            pl = ok ? lse_g[bh * T + q0n + tid] * (sizeof(CT) == 2 ? EMO_LOG2E : 1.f) : INFINITY;
+            pz = ok ? 1.f / zden_g[bh * T + q0n + tid] : 0.f;
+            pd_ = ok ? delta_g[bh * T + q0n + tid] : 0.f;
+        }
+    };
+    fetch(k0);
+    load_rows<CT, DH, DHP>(Ki, LDX, kb + k0 * ld, ld, 64, kvalid, tid);
+    load_rows<CT, DH, DHP>(Vi, LDX, vb + k0 * ld, ld, 64, kvalid, tid);
+    __syncthreads();
+    typename Img<CT>::V kf[NQ], vf[NQ];
+#pragma unroll
+    for (int kk = 0; kk < NQ; ++kk) {
+        kf[kk] = Img<CT>::load(Ki, LDX, wave * 16, kk * Img<CT>::KSTEP, lane);
+        vf[kk] = Img<CT>::load(Vi, LDX, wave * 16, kk * Img<CT>::KSTEP, lane);
+    }
+    const float sqrt_dh = sqrtf((float)DH), rsqrt_dh = 1.f / sqrt_dh, c2 = rsqrt_dh * EMO_LOG2E;
+    const int jl = wave * 16 + (lane & 15);
+    const int64_t jg = k0 + jl;
+    float* skw = sk + wave * 16 * SKW;
+    f32x4 dkacc[ND], dvacc[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) { dkacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dvacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int64_t qt = kt; qt < nqt; ++qt) {
+        const int64_t q0 = qt * 64;
+        __syncthreads();
+        pq.store_rows(Qu, LDX, tid);
+        pq2.store_rows(Qv, LDX, tid);
+        pg.store_rows(dOi, LDX, tid);
+        if constexpr (!TR) { pqT.store_T(QT, LDC, tid); pgT.store_T(dOT, LDC, tid); }
+#pragma unroll
+        for (int i = 0; i < RNI; ++i) {
+            const int it = tid + 256 * i;
+            if (it < 128 * CH) {
+                const int row = it / CH, c = (it % CH) * VE;
+                if constexpr (sizeof(CT) == 2) *(bf16x8*)(Rw + row * LDX + c) = *(const bf16x8*)rr[i];
+                else {
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) Rw[row * LDX + c + e] = rr[i][e];
+                }
+            }
+        }
+        if constexpr (DHP > DH) {
+            for (int it = tid; it < 128 * (DHP - DH); it += 256) Rw[(it / (DHP - DH)) * LDX + DH + it % (DHP - DH)] = from_f32<CT>(0.f);
+        }
+        if (tid < 64) { Lv[tid] = pl; Zv[tid] = pz; Dv[tid] = pd_; }
+        if (qt + 1 < nqt) fetch(q0 + 64);
+        __syncthreads();
+        const bool diag = qt == kt;
+        float pd[4][4], ds[4][4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            const bool live = !(diag && tt < wave);
+            if (live) {
+#pragma unroll
+                for (int kk = 0; kk < NQ; ++kk) {
+                    sa = Img<CT>::mma(Img<CT>::load(Qu, LDX, tt * 16, kk * Img<CT>::KSTEP, lane), kf[kk], sa);
+                    dp = Img<CT>::mma(Img<CT>::load(dOi, LDX, tt * 16, kk * Img<CT>::KSTEP, lane), vf[kk], dp);
+                }
+                const int ct0 = tt - wave + 3;                // window tiles ct0, ct0 + 1 hold c = t - j + 63 for this (tt, wave)
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci) {
+                    f32x4 a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < NQ; ++kk)
+                        a2 = Img<CT>::mma(Img<CT>::load(Rw, LDX, (ct0 + ci) * 16, kk * Img<CT>::KSTEP, lane), Img<CT>::load(Qv, LDX, tt * 16, kk * Img<CT>::KSTEP, lane), a2);
+                    *(f32x4*)(skw + (lane & 15) * SKW + ci * 16 + (lane >> 4) * 4) = a2;        // buf[t_loc][c - 16 ct0]
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tq = (lane >> 4) * 4 + r;           // query row inside the sub-tile
+                const int tl = tt * 16 + tq;
+                const int64_t tg = q0 + tl;
+                const float bd = live ? skw[tq * SKW + tq - (lane & 15) + 15] : 0.f;
+                const float sc = sa[r] + bd;
+                float p = sizeof(CT) == 2 ? __builtin_amdgcn_exp2f(sc * c2 - Lv[tl]) : Img<CT>::ex(sc / sqrt_dh - Lv[tl]), mult = 1.f;
+                if (diag && jl > tl) p = 0.f;
+                if (drop.thr16) mult = drop_mult(drop, (uint64_t)((bh * T + tg) * T + jg));
+                const float zi = Zv[tl], r1 = Dv[tl];
+                pd[tt][r] = p * mult * zi;
+                ds[tt][r] = p * (mult * (dp[r] - r1) * zi - 1e-8f * r1 * zi);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int st = 0; st < SaK<CT>::NS64; ++st) {
+            const typename Img<CT>::V pf = reg_perm<CT>(pd, st), df = reg_perm<CT>(ds, st);
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                if constexpr (TR) {
+                    dvacc[i] = Img<CT>::mma(load_perm_tr((const bf16_t*)dOi, LDX, i * 16, st, lane), pf, dvacc[i]);
+                    dkacc[i] = Img<CT>::mma(load_perm_tr((const bf16_t*)Qu, LDX, i * 16, st, lane), df, dkacc[i]);
+                } else {
+                    dvacc[i] = Img<CT>::mma(load_perm<CT>(dOT, LDC, i * 16, st, lane), pf, dvacc[i]);
+                    dkacc[i] = Img<CT>::mma(load_perm<CT>(QT, LDC, i * 16, st, lane), df, dkacc[i]);
+                }
+            }
+        }
+    }
+    if (jg < T) {
+        CT* dkb = dk + (b * T + jg) * ld_d + h * DH;
+        CT* dvb = dv + (b * T + jg) * ld_d + h * DH;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int d0 = i * 16 + (lane >> 4) * 4;
+            Img<CT>::store4(dkb + d0, dkacc[i][0] * rsqrt_dh, dkacc[i][1] * rsqrt_dh, dkacc[i][2] * rsqrt_dh, dkacc[i][3] * rsqrt_dh);
+            Img<CT>::store4(dvb + d0, dvacc[i][0], dvacc[i][1], dvacc[i][2], dvacc[i][3]);
         }
     }
 }
@@ -1142,26 +1320,26 @@ template <typename CT, int DH> static size_t ra_bwd_lds() {
 template <typename CT, int DH>
 static int run_relattn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* rd, int64_t ld_r, int64_t n_dist, const float* ub,
                            const float* vb, const void* out, const void* dout, int64_t ld_out, const float* lse, const float* zden, void* dq, int64_t ld_d,
-                           void* a_nat, void* ds_nat, void* ds_skew, int64_t nd_skew, int64_t ld_nat, int64_t B, int64_t T, int64_t H, DropCtx drop,
-                           hipStream_t st) {
+                           void* a_nat, void* ds_nat, void* ds_skew, int64_t nd_skew, int64_t ld_nat, float* delta, int64_t B, int64_t T, int64_t H,
+                           DropCtx drop, hipStream_t st) {
     dim3 grid((unsigned)((T + 63) / 64), (unsigned)(B * H));
     const size_t lds = ra_bwd_lds<CT, DH>();
     auto kf = relattn_bwd_kernel<CT, DH>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     hipLaunchKernelGGL(kf, grid, dim3(256), lds, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, (const CT*)rd, ld_r, n_dist, ub, vb, (const CT*)out,
-                       (const CT*)dout, ld_out, lse, zden, (CT*)dq, ld_d, (CT*)a_nat, (CT*)ds_nat, (CT*)ds_skew, nd_skew, ld_nat, B, T, H, drop);
+                       (const CT*)dout, ld_out, lse, zden, (CT*)dq, ld_d, (CT*)a_nat, (CT*)ds_nat, (CT*)ds_skew, nd_skew, ld_nat, delta, B, T, H, drop);
     EMO_LAUNCH_CHECK();
     return EMO_OK;
 }
 
 extern "C" int emo_relpos_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* r_dist, int64_t ld_r, int64_t n_dist,
                                    const float* r_w_bias, const float* r_r_bias, const void* out, const void* dout, int64_t ld_out, const float* lse,
-                                   const float* zden, void* dq, int64_t ld_d, void* a_nat, void* ds_nat, int64_t ld_nat, void* ds_skew, int64_t nd_skew, int dtype,
+                                   const float* zden, void* dq, int64_t ld_d, void* a_nat, void* ds_nat, int64_t ld_nat, void* ds_skew, int64_t nd_skew, float* delta, int dtype,
                                    int64_t B, int64_t T, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
     int rc = sattn_check(q, k, v, ld, ld_out, dtype, dh);
     if (rc) return rc;
-    EMO_CHECK(r_dist && r_w_bias && r_r_bias && out && dout && lse && zden && dq && a_nat && ds_nat && ds_skew, "emo_relpos_attn_bwd: null pointer");
+    EMO_CHECK(r_dist && r_w_bias && r_r_bias && out && dout && lse && zden && dq && ds_skew && (!a_nat == !ds_nat), "emo_relpos_attn_bwd: null pointer");
     const int64_t ve = dtype == EMO_BF16 ? 8 : 4;
     EMO_CHECK(ld_r % ve == 0 && ld_d % 4 == 0 && (((uintptr_t)r_dist | (uintptr_t)dq | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)a_nat | (uintptr_t)ds_nat) & 15) == 0,
               "emo_relpos_attn_bwd: pointers must be 16-B aligned");
@@ -1172,15 +1350,62 @@ extern "C" int emo_relpos_attn_bwd(const void* q, const void* k, const void* v, 
     if (dh == DHv) {                                                                                                                                   \
         if (dtype == EMO_BF16)                                                                                                                         \
             return run_relattn_bwd<bf16_t, DHv>(q, k, v, ld, r_dist, ld_r, n_dist, r_w_bias, r_r_bias, out, dout, ld_out, lse, zden, dq, ld_d, a_nat, ds_nat,  \
-                                                ds_skew, nd_skew, ld_nat, B, T, H, drop, st);                                                                 \
+                                                ds_skew, nd_skew, ld_nat, delta, B, T, H, drop, st);                                                          \
         return run_relattn_bwd<float, DHv>(q, k, v, ld, r_dist, ld_r, n_dist, r_w_bias, r_r_bias, out, dout, ld_out, lse, zden, dq, ld_d, a_nat, ds_nat,       \
-                                           ds_skew, nd_skew, ld_nat, B, T, H, drop, st);                                                                      \
+                                           ds_skew, nd_skew, ld_nat, delta, B, T, H, drop, st);                                                               \
     }
     RAB_CASE(64)
     RAB_CASE(32)
     RAB_CASE(16)
 #undef RAB_CASE
     emo_set_error("emo_relpos_attn_bwd: unsupported d_head=%lld (built: 16, 32, 64)", (long long)dh);
+    return EMO_ERR_UNSUPPORTED;
+}
+
+template <typename CT, int DH> static size_t ra_dkv_lds() {
+    typedef SaDims<CT, DH> D;
+    return sizeof(CT) * (size_t)(5 * 64 * D::LDX + 128 * D::LDX + (sizeof(CT) == 2 ? 0 : 2 * DH * D::LDC)) + sizeof(float) * (4 * 16 * 36 + 3 * 64);
+}
+template <typename CT, int DH>
+static int run_relattn_dkv(const void* qu, const void* qv, int64_t ld_q, const void* k, const void* v, int64_t ld, const void* rd, int64_t ld_r, int64_t n_dist,
+                           const void* dout, int64_t ld_out, const float* lse, const float* zden, const float* delta, void* dk, void* dv, int64_t ld_d,
+                           int64_t B, int64_t T, int64_t H, DropCtx drop, hipStream_t st) {
+    dim3 grid((unsigned)((T + 63) / 64), (unsigned)(B * H));
+    const size_t lds = ra_dkv_lds<CT, DH>();
+    auto kf = relattn_bwd_dkv_kernel<CT, DH>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(kf, grid, dim3(256), lds, st, (const CT*)qu, (const CT*)qv, ld_q, (const CT*)k, (const CT*)v, ld, (const CT*)rd, ld_r, n_dist,
+                       (const CT*)dout, ld_out, lse, zden, delta, (CT*)dk, (CT*)dv, ld_d, T, H, drop);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
+extern "C" int emo_relpos_attn_bwd_kv(const void* qu, const void* qv, int64_t ld_q, const void* k, const void* v, int64_t ld, const void* r_dist, int64_t ld_r,
+                                      int64_t n_dist, const void* dout, int64_t ld_out, const float* lse, const float* zden, const float* delta, void* dk,
+                                      void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H, int64_t dh, float p_drop, uint64_t seed,
+                                      uint64_t offset, emo_stream_t stream) {
+    int rc = sattn_check(qu, k, v, ld, ld_out, dtype, dh);
+    if (rc) return rc;
+    EMO_CHECK(qv && r_dist && dout && lse && zden && delta && dk && dv, "emo_relpos_attn_bwd_kv: null pointer");
+    const int64_t ve = dtype == EMO_BF16 ? 8 : 4;
+    EMO_CHECK(ld_r % ve == 0 && ld_q % ve == 0 && ld_d % 4 == 0 &&
+              (((uintptr_t)r_dist | (uintptr_t)qu | (uintptr_t)qv | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)dout) & 15) == 0,
+              "emo_relpos_attn_bwd_kv: pointers must be 16-B aligned");
+    EMO_CHECK(n_dist >= T, "emo_relpos_attn_bwd_kv: r_dist needs a row for every distance 0 .. T-1");
+    const DropCtx drop = make_drop(p_drop, seed, offset);
+    hipStream_t st = (hipStream_t)stream;
+#define RAK_CASE(DHv)                                                                                                                                  \
+    if (dh == DHv) {                                                                                                                                   \
+        if (dtype == EMO_BF16)                                                                                                                         \
+            return run_relattn_dkv<bf16_t, DHv>(qu, qv, ld_q, k, v, ld, r_dist, ld_r, n_dist, dout, ld_out, lse, zden, delta, dk, dv, ld_d, B, T, H, drop, st); \
+        return run_relattn_dkv<float, DHv>(qu, qv, ld_q, k, v, ld, r_dist, ld_r, n_dist, dout, ld_out, lse, zden, delta, dk, dv, ld_d, B, T, H, drop, st);      \
+    }
+    RAK_CASE(64)
+    RAK_CASE(32)
+    RAK_CASE(16)
+#undef RAK_CASE
+    emo_set_error("emo_relpos_attn_bwd_kv: unsupported d_head=%lld (built: 16, 32, 64)", (long long)dh);
     return EMO_ERR_UNSUPPORTED;
 }
 

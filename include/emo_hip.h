@@ -197,13 +197,22 @@ int emo_relpos_attn_fwd(const void* q, const void* k, const void* v, int64_t ld,
  *   a_nat  [B,H,T,ld_nat]   final attention weights a_ij             (dV = a^T dO)
  *   ds_nat [B,H,T,ld_nat]   d score_ij / sqrt(dh)                    (dK = ds^T (q + r_w_bias))
  *   ds_skew[H,B,T,nd_skew]  the same values at column i-j            (dR = ds_skew^T (q + r_r_bias), dq_relative = ds_skew R)
- * which the caller turns into dk, dv, dR, dq_relative and the two bias gradients with emo_gemm (model/plain_transformer.py). */
+ * which the caller turns into dR, dq_relative and the two bias gradients (and, without emo_relpos_attn_bwd_kv, dk / dv) with emo_gemm.
+ * a_nat / ds_nat may both be NULL.  delta (may be NULL) [B,H,T] fp32: dO.O per query row, for emo_relpos_attn_bwd_kv. */
 int emo_relpos_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* r_dist,
                         int64_t ld_r, int64_t n_dist, const float* r_w_bias, const float* r_r_bias,
                         const void* out, const void* dout, int64_t ld_out, const float* lse,
                         const float* zden, void* dq, int64_t ld_d, void* a_nat, void* ds_nat,
-                        int64_t ld_nat, void* ds_skew, int64_t nd_skew, int dtype, int64_t B, int64_t T, int64_t H,
-                        int64_t dh, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream);
+                        int64_t ld_nat, void* ds_skew, int64_t nd_skew, float* delta, int dtype, int64_t B,
+                        int64_t T, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint64_t offset,
+                        emo_stream_t stream);
+/* Key-tile pass of the backward: dk, dv in one kernel (then a_nat / ds_nat above may be NULL).  qu = q + r_w_bias, qv = q + r_r_bias
+ * [B*T, H*dh] (pitch ld_q) materialised by the caller; delta [B,H,T] = dO.O per query row as exported by emo_relpos_attn_bwd. */
+int emo_relpos_attn_bwd_kv(const void* qu, const void* qv, int64_t ld_q, const void* k, const void* v,
+                           int64_t ld, const void* r_dist, int64_t ld_r, int64_t n_dist, const void* dout,
+                           int64_t ld_out, const float* lse, const float* zden, const float* delta,
+                           void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H,
+                           int64_t dh, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream);
 /* one query row per stream against a KV cache (the reference re-projects its cached hidden states `mems` every step,
  * plain_transformer.py:52-59; k / v of a position do not change, so they are cached instead).  Keys j in
  * [max(0, len-1-mem_len), len) with len = lens[s] + lens_off; the distance of key j is len-1-j.  k_new / v_new as in
