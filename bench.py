@@ -128,6 +128,35 @@ def generation_bench(model, n_streams=32, prompt=64, n_new=2048 - 64, top_p=0.9,
             'ms_per_token_step': round(1000 * dt / n_new, 3), 'engine': 'FAVOR+ recurrent state in HBM + hipGraph replay of the decode step'}
 
 
+def stage1_bench(n_steps=10, B=4, T=512, V=200):
+    """Secondary line, BASELINE configs[4] (single GPU): the stage-1 lead-sheet LM (Transformer-XL decoder, emopia_finetune.yaml shape:
+    d512 / L12 / H8 / d_ff 2048, tgt_len 512, batch 4), bf16, dropout 0.1, fwd + bwd + clip + fused Adam on synthetic tokens."""
+    from emo_disentanger_amd.model.plain_transformer import PlainTransformer
+    from emo_disentanger_amd.optim import FusedAdam
+    m = PlainTransformer(512, V, 12, 8, 512, 2048, 0, T, dec_dropout=0.1, pre_lnorm=True, compute_dtype='bf16').cuda().train()
+    opt = FusedAdam(m, lr=1e-5, max_grad_norm=0.5)
+    g = torch.Generator().manual_seed(1)
+    x, tgt = torch.randint(0, V - 1, (T, B), generator=g).cuda(), torch.randint(0, V - 1, (T, B), generator=g).cuda()
+
+    def step():
+        opt.zero_grad()
+        loss = m.compute_loss(m(x, tuple())[0], tgt)['total_loss']
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n_steps
+    return {'metric': 'stage1 (Transformer-XL lead-sheet LM) train tokens/sec', 'value': round(B * T / dt, 1), 'unit': 'tokens/s', 'ms_per_step': round(dt * 1e3, 3),
+            'config': {'workload': 'BASELINE configs[4] shape, 1 GPU: d512 L12 H8 d_ff2048 tgt_len=%d batch=%d V=%d, bf16, dropout 0.1' % (T, B, V)},
+            'loss': round(float(loss), 4)}
+
+
 def cpu_generation_baseline(ctx=256, n_tok=4):
     """Reference-style AR step on the CPU oracle: full-prefix recompute per token (inference.py:252-272), 1 stream."""
     from oracle import model_ref
@@ -173,6 +202,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-gen', action='store_true')
+    ap.add_argument('--no-stage1', action='store_true')
     args = ap.parse_args()
 
     from emo_disentanger_amd import dp, ops
@@ -248,6 +278,8 @@ def main():
             out['gen'] = generation_bench(model)
             if not args.no_cpu_baseline:
                 out['gen']['cpu_baseline'] = cpu_generation_baseline()
+        if world == 1 and not args.no_stage1:
+            out['stage1'] = stage1_bench()
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(min(T, 2048))
         print(json.dumps(out), flush=True)
