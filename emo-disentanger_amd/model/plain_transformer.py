@@ -305,8 +305,11 @@ class PlainTransformer(nn.Module):
     def forward(self, dec_input, dec_mems, dec_seg_len=None, return_avg_attn=False):
         """plain_transformer.py:62-80.  dec_input int64 [T, B]; returns (logits fp32 [T, B, V], new_mems).  mem_len = 0 (every training / validation
         YAML): new_mems is the empty list, as in the reference."""
-        if return_avg_attn or dec_seg_len is not None:
-            raise NotImplementedError('return_avg_attn / dec_seg_len are analysis paths of the reference and are not built')
+        if return_avg_attn:
+            raise NotImplementedError('return_avg_attn is an analysis path of the reference and is not built')
+        if dec_seg_len is not None and self.dec_mem_len > 0:
+            raise NotImplementedError('per-sample memory update (dec_seg_len with mem_len > 0) is not built; every stage-1 YAML trains with mem_len 0, '
+                                      'where dec_seg_len only feeds the memory update and is a no-op')
         if dec_mems is not None and len(dec_mems) > 0:
             raise NotImplementedError('segment-level recurrence inside forward() (mem_len > 0 with incoming mems) is not built; use generate()')
         anchor = self.word_emb.emb_lookup.weight
