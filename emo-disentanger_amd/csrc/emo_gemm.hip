@@ -883,6 +883,332 @@ static void dispatch_g3(bool akc, bool bkc, dim3 grid, hipStream_t st, const bf1
 }
 
 // ================================================================================================
+// bf16 MFMA kernel, v6: 256x256x64 block tile, 8 waves, FOUR PHASES PER K-TILE with two wave groups running one barrier apart.
+// The 128^2 kernels above top out at ~840 TFLOP/s even at K=2048 (one barrier-synchronised {wait, read fragments, MFMA} step per
+// K-tile: every wave of the block reads LDS at the same time and then every wave issues MFMAs at the same time, so the matrix
+// pipe idles during the read sections), and the plain 256^2 double buffer (v3) is no better.  Here
+//   * the K-tile is staged as four 16-KB half-tiles (A rows 0-127 / 128-255, B cols 0-127 / 128-255) in a 2 x 64 KB ring;
+//     a wave owns 64 rows of EACH A half and 32 columns of EACH B half, so one phase = one (A half, B half) quadrant =
+//     16 MFMAs on 8 / 4 / 8 / 0 freshly read fragments: P1 reads B0 + A0, P2 reads B1, P3 reads A1, P4 reads nothing;
+//   * a half-tile slot is re-staged (LDS-DMA) for K-tile t+2 two phases after its last fragment read — one phase after for B0, whose
+//     reads an lgkmcnt before P1's barrier retires — one half-tile (2 DMA instructions per wave) per phase: P1: A1 of t+1, P2: B0,
+//     P3: A0, P4: B1 of t+2, with ONE counted wait per K-tile (P4: vmcnt(6) = the three newest half-tiles stay
+//     in flight) — loads live for 3-7 phases and never drain inside the loop;
+//   * waves 4-7 (the second wave of every SIMD) run one s_barrier behind waves 0-3: while one wave of a SIMD is in its MFMA
+//     section the other is in its read / stage section (s_setprio favours the MFMA wave).
+// Hazards (E_n = n-th barrier; group 0: R1 E1 M1 E2 R2 E3 M2 E4 R3 E5 M3 E6 R4 E7 M4 E8, group 1 the same shifted by one E):
+//   RAW: every wave's P4 wait precedes its P4 barrier (E7 for group 0, E8 for group 1); the first read of the new K-tile is group
+//        0's R1 after E8.  WAR: a slot read in R_p has its reads retired at the latest after E_{2p} (group 1's lgkmcnt before
+//        its M_p) and is re-staged in R_{p+2}, which group 0 starts after E_{2p+2}; B0's reads are retired before E1 / E2 already and
+//        group 0's R2 starts after E2.
+constexpr int G6_HT = 16384, G6_STAGE = 65536;
+
+template <bool KC>
+__device__ __forceinline__ void g6_offsets(int64_t ld, int64_t row0, int64_t nrows, int wave, int lane, uint32_t (&off)[2][2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = wave * 2 + i;       // wave-instruction 0..15 of the half-tile (1 KiB each)
+            if constexpr (KC) {               // [128 rows][64 k]: 8 rows x 128 B per instruction, chunk ^= row & 7
+                const int row = j * 8 + (lane >> 3), c = (lane & 7) ^ (row & 7);
+                int64_t gr = row0 + h * 128 + row;
+                if (gr > nrows - 1) gr = nrows - 1;
+                off[h][i] = (uint32_t)((gr * ld + c * 8) * 2);
+            } else {                          // [64 k][128 rows]: 4 k x 256 B per instruction, 32-B granule swizzle
+                const int k = j * 4 + (lane >> 4), p16 = lane & 15;
+                const int g = (p16 >> 1) ^ swz_k(k);
+                int64_t gr = row0 + h * 128 + (g * 2 + (p16 & 1)) * 8;
+                if (gr > nrows - 1) gr = ((nrows - 1) >> 3) << 3;
+                off[h][i] = (uint32_t)(((int64_t)k * ld + gr) * 2);
+            }
+        }
+}
+__device__ __forceinline__ void g6_issue(const char* __restrict__ base, const uint32_t (&off)[2], char* slot, int wave) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[i]),
+                                         (__attribute__((address_space(3))) void*)(slot + (wave * 2 + i) * 1024), 16, 0, 0);
+}
+#define G6_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define G6_MFMA_BEGIN() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); } while (0)
+#define G6_MFMA_END() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+// 256 x 256 accumulator tile -> global through the (idle) 128 KB of LDS, one 128-row half at a time: fp32 image [128][256] with the 16-B chunk
+// index XOR (row & 15) (fragment-layout writes conflict-free), then every thread owns 8 consecutive columns of a row (epi_row8: 16-B
+// coalesced loads / stores, 512 B or 1 KB contiguous per row).  The fragment-layout epilogue (8-B pieces, 16 rows per instruction) cost
+// ~30 us per tile here (r01: 828 -> TFLOP/s with the tile loads ablated on the K=2048 forward shape).
+template <typename OutT>
+__device__ __forceinline__ void epilogue_tile256(const EpiParams& ep, OutT* __restrict__ C, int64_t m0, int64_t n0, int64_t M, int64_t N,
+                                                 const f32x4 (&acc)[8][4], char* lds, int tid, int wr, int wc, int lane) {
+    if (ep.atomic) {
+#pragma clang loop unroll(full)
+        for (int i = 0; i < 8; ++i)
+#pragma clang loop unroll(full)
+            for (int j = 0; j < 4; ++j) {
+                const int64_t m = m0 + (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + (lane & 15);
+                const int64_t n = n0 + (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + (lane >> 4) * 4;
+                if (m < M && n < N) epi_store4_call<OutT>(ep, C, m, n, acc[i][j], N);
+            }
+        return;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wr * 64 + i * 16 + (lane & 15);
+                const int chunk = ((j >> 1) * 128 + wc * 32 + (j & 1) * 16 + (lane >> 4) * 4) >> 2;   // 16-B chunk 0..63
+                *(f32x4*)(lds + row * 1024 + ((chunk ^ (row & 15)) << 4)) = acc[4 * h + i][j];
+            }
+        __syncthreads();
+#pragma unroll 2
+        for (int it = 0; it < 8; ++it) {
+            const int idx = tid + 512 * it;
+            const int row = idx >> 5, grp = idx & 31;
+            const int64_t m = m0 + h * 128 + row, n = n0 + grp * 8;
+            if (m < M && n < N) {
+                const f32x4 lo = *(const f32x4*)(lds + row * 1024 + (((2 * grp) ^ (row & 15)) << 4));
+                const f32x4 hi = *(const f32x4*)(lds + row * 1024 + (((2 * grp + 1) ^ (row & 15)) << 4));
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                epi_row8<OutT>(ep, C, m, n, v, N);
+            }
+        }
+    }
+}
+
+// RS: 0 plain, 1 = a_rowsum (sum over k of A, per output row m), 2 = b_rowsum (sum over k of B, per output column n): the wgrad bias
+// gradient as one extra MFMA against an all-ones operand, on 1/tiles_n (1/tiles_m) of the K-tiles per block and one fragment per wave.
+template <bool A_KC, bool B_KC, typename OutT, int RS>
+__global__ __launch_bounds__(512) void gemm_bf16_g6_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                           OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, int64_t k_per_split, EpiParams ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x {A0, A1, B0, B1} x 16 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t tiles_n = (N + G3_N - 1) / G3_N, tiles_m = (M + G3_M - 1) / G3_M;
+    int64_t tm, tn, split = 0;
+    if (ep.atomic) {
+        splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
+        if (ep.ws_stride) { C += split * ep.ws_stride; ep.atomic = 0; }
+    }
+    else tile_coords(tiles_m, tiles_n, tm, tn);
+    if (tm >= tiles_m) return;
+    const int64_t m0 = tm * G3_M, n0 = tn * G3_N;
+    const int64_t kbeg = split * k_per_split;
+    const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+    if (kbeg >= kend) return;
+    const int nk = __builtin_amdgcn_readfirstlane((int)((kend - kbeg) / G3_K));
+    const int wr = wave >> 2, wc = wave & 3;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 rsacc[2];
+    rsacc[0] = rsacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16_t one_b = (bf16_t)1.f;
+    const bf16x8 ones = {one_b, one_b, one_b, one_b, one_b, one_b, one_b, one_b};
+    int rs_own = RS == 1 ? (int)((kbeg / G3_K) % tiles_n) : (RS == 2 ? (int)((kbeg / G3_K) % tiles_m) : 0);
+    const int rs_me = RS == 1 ? (int)tn : (int)tm, rs_mod = RS == 1 ? (int)tiles_n : (int)tiles_m;
+
+    uint32_t offA[2][2], offB[2][2];
+    g6_offsets<A_KC>(lda, m0, M, wave, lane, offA);
+    g6_offsets<B_KC>(ldb, n0, N, wave, lane, offB);
+    const char* gA = (const char*)A + (A_KC ? kbeg : kbeg * lda) * 2;
+    const char* gB = (const char*)B + (B_KC ? kbeg : kbeg * ldb) * 2;
+    const int64_t stepA = (A_KC ? (int64_t)G3_K : (int64_t)G3_K * lda) * 2;
+    const int64_t stepB = (B_KC ? (int64_t)G3_K : (int64_t)G3_K * ldb) * 2;
+    // L2 prefetch of K-tile t + PF (the operand streams come from HBM: with 64 KB of LDS-DMA in flight per CU the loop was bound by the
+    // miss latency, 1203 -> 827 TFLOP/s on the FFN wgrad with / without tile loads): one 4-B load per 128-B line, waves 0-3 cover A,
+    // waves 4-7 cover B, issued as the NEWEST vector-memory op before the K-tile's counted wait so that it never holds up the DMA queue.
+    const int PF = (ep.ablate >> 4) ? (ep.ablate >> 4) : 4;
+    const char* pfb = wave < 4 ? gA : gB;
+    const int64_t pfs = wave < 4 ? stepA : stepB;
+    uint32_t pfo;
+    {
+        const int r = tid & 255;
+        const bool kc = wave < 4 ? A_KC : B_KC;
+        const int64_t ld = wave < 4 ? lda : ldb, row0 = wave < 4 ? m0 : n0, nrows = wave < 4 ? M : N;
+        if (kc) { int64_t gr = row0 + r; if (gr > nrows - 1) gr = nrows - 1; pfo = (uint32_t)(gr * ld * 2); }
+        else { int64_t gr = row0 + (r & 3) * 64; if (gr > nrows - 2) gr = row0; pfo = (uint32_t)(((int64_t)(r >> 2) * ld + gr) * 2); }
+    }
+    uint32_t pft = 0;
+#define G6_ISSUE_A(h, t) g6_issue(gA + (int64_t)(t) * stepA, offA[h], smem + ((t) & 1) * G6_STAGE + (h) * G6_HT, wave)
+#define G6_ISSUE_B(h, t) g6_issue(gB + (int64_t)(t) * stepB, offB[h], smem + ((t) & 1) * G6_STAGE + (2 + (h)) * G6_HT, wave)
+    G6_ISSUE_B(0, 0); G6_ISSUE_A(0, 0); G6_ISSUE_B(1, 0); G6_ISSUE_A(1, 0);
+    if (nk > 1) {
+        G6_ISSUE_B(0, 1); G6_ISSUE_A(0, 1); G6_ISSUE_B(1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    G6_BARRIER();
+    if (wr == 1) G6_BARRIER();          // group 1 runs one barrier behind group 0
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    for (int t = 0; t < nk; ++t) {
+        const char* st = smem + (t & 1) * G6_STAGE;
+        // ---- P1: (A0, B0)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb0[j][ks] = lfrag2<B_KC, 64>(st + 2 * G6_HT, wc * 32 + j * 16, ks, lane);
+        __builtin_amdgcn_sched_barrier(0);        // B0's reads are issued (and return) first
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = lfrag2<A_KC, 64>(st, wr * 64 + i * 16, ks, lane);
+        if (t + 1 < nk && !(ep.ablate & 1)) G6_ISSUE_A(1, t + 1);
+        // retire the B0 reads before this phase's barrier (LDS reads return in order; A0 is 8 ds_read_b128 or 16 transposing reads,
+        // the counter saturates at 15): the B0 slot can then be re-staged one phase later instead of two
+        if constexpr (A_KC) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+        G6_BARRIER();
+        G6_MFMA_BEGIN();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
+        if (RS == 2 && rs_own == rs_me) {       // B0 columns: fragment j = wr of this wave's pair
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (wr == 0) rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[0][ks], ones, rsacc[0], 0, 0, 0);
+                else rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[1][ks], ones, rsacc[0], 0, 0, 0);
+            }
+        }
+        G6_MFMA_END();
+        G6_BARRIER();
+        // ---- P2: (A0, B1)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = lfrag2<B_KC, 64>(st + 3 * G6_HT, wc * 32 + j * 16, ks, lane);
+        if (t + 2 < nk && !(ep.ablate & 1)) G6_ISSUE_B(0, t + 2);
+        G6_BARRIER();
+        G6_MFMA_BEGIN();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[i][2 + j], 0, 0, 0);
+        if (RS == 1 && rs_own == rs_me) {       // A0 rows: fragment i = wc
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (wc == 0) rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[0][ks], rsacc[0], 0, 0, 0);
+                else if (wc == 1) rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[1][ks], rsacc[0], 0, 0, 0);
+                else if (wc == 2) rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[2][ks], rsacc[0], 0, 0, 0);
+                else rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[3][ks], rsacc[0], 0, 0, 0);
+            }
+        }
+        if (RS == 2 && rs_own == rs_me) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (wr == 0) rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[0][ks], ones, rsacc[1], 0, 0, 0);
+                else rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[1][ks], ones, rsacc[1], 0, 0, 0);
+            }
+        }
+        G6_MFMA_END();
+        G6_BARRIER();
+        // ---- P3: (A1, B1); re-stage B0, A0 for K-tile t + 2
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = lfrag2<A_KC, 64>(st + G6_HT, wr * 64 + i * 16, ks, lane);
+        if (t + 2 < nk && !(ep.ablate & 1)) G6_ISSUE_A(0, t + 2);
+        G6_BARRIER();
+        G6_MFMA_BEGIN();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[4 + i][2 + j], 0, 0, 0);
+        G6_MFMA_END();
+        G6_BARRIER();
+        // ---- P4: (A1, B0); re-stage B1 for K-tile t + 2; the one counted wait of the K-tile
+        if (t + 2 < nk && !(ep.ablate & 1)) {
+            G6_ISSUE_B(1, t + 2);
+            if (t + PF < nk && !(ep.ablate & 2)) {
+                asm volatile("global_load_dword %0, %1, off" : "+v"(pft) : "v"(pfb + (int64_t)(t + PF) * pfs + pfo) : "memory");
+                asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        G6_BARRIER();
+        G6_MFMA_BEGIN();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[4 + i][j], 0, 0, 0);
+        if (RS == 1 && rs_own == rs_me) {       // A1 rows
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (wc == 0) rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[0][ks], rsacc[1], 0, 0, 0);
+                else if (wc == 1) rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[1][ks], rsacc[1], 0, 0, 0);
+                else if (wc == 2) rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[2][ks], rsacc[1], 0, 0, 0);
+                else rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[3][ks], rsacc[1], 0, 0, 0);
+            }
+        }
+        G6_MFMA_END();
+        G6_BARRIER();
+        if (RS != 0) { if (++rs_own == rs_mod) rs_own = 0; }
+    }
+    if (wr == 0) G6_BARRIER();
+    asm volatile("" :: "v"(pft));
+#undef G6_ISSUE_A
+#undef G6_ISSUE_B
+    if (RS == 1 && (lane >> 4) == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t m = m0 + h * 128 + wr * 64 + wc * 16 + (lane & 15);
+            if (m < M) atomicAdd(ep.a_rowsum + m, rsacc[h][0]);
+        }
+    }
+    if (RS == 2 && (lane & 15) == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t n = n0 + h * 128 + wc * 32 + wr * 16 + (lane >> 4) * 4 + r;
+                if (n < N) atomicAdd(ep.b_rowsum + n, rsacc[h][r]);
+            }
+    }
+    epilogue_tile256<OutT>(ep, C, m0, n0, M, N, acc, smem, tid, wr, wc, lane);
+}
+
+template <bool A_KC, bool B_KC, typename OutT, int RS>
+static void launch_g6(dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int64_t M, int64_t N,
+                      int64_t K, int64_t kps, const EpiParams& ep) {
+    auto kfn = gemm_bf16_g6_kernel<A_KC, B_KC, OutT, RS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G6_STAGE);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(512), 2 * G6_STAGE, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
+}
+template <typename OutT>
+static void dispatch_g6(bool akc, bool bkc, int rs, dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C,
+                        int64_t M, int64_t N, int64_t K, int64_t kps, const EpiParams& ep) {
+    if (!akc && !bkc) {                  // the wgrad layout carries the bias-gradient instances
+        if (rs == 1) launch_g6<false, false, OutT, 1>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+        else if (rs == 2) launch_g6<false, false, OutT, 2>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+        else launch_g6<false, false, OutT, 0>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    }
+    else if (akc && bkc) launch_g6<true, true, OutT, 0>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    else if (akc && !bkc) launch_g6<true, false, OutT, 0>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+    else launch_g6<false, true, OutT, 0>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+}
+
+// ================================================================================================
 // skinny GEMM for the decode step (M <= 32 rows: n streams x 1 token): weight-bandwidth / launch bound.
 // One wave per 16 output columns, the whole K loop in registers: weight rows (nn.Linear [N,K]) and the M
 // activation rows are fetched as MFMA fragments straight from global memory (16 B per lane, no LDS —
@@ -1584,11 +1910,35 @@ static int64_t choose_splits(int64_t M, int64_t N, int64_t K, bool big, bool has
 }
 
 #define EMO_GEMM_MAX_SPLITS 32
+// v6 (256^2 four-phase kernel) eligibility.  kind 0: split-K wgrad (both operands token-major, plain fp32 output); kind 1: single-pass
+// GEMM with a long reduction.  EMO_GEMM_G6=0 disables it, =1 forces it for every eligible shape (K % 64 == 0, M, N multiples of 256).
+static int g6_mode() {
+    static int m = -1;
+    if (m < 0) { const char* e = getenv("EMO_GEMM_G6"); m = e ? atoi(e) + 1 : 0; }   // 0 = heuristic, 1 = off, 2 = forced
+    return m;
+}
+static bool g6_shape_ok(int64_t M, int64_t N, int64_t K) { return (M % G3_M) == 0 && (N % G3_N) == 0 && (K % G3_K) == 0 && K >= 2 * G3_K; }
+// split count of the v6 wgrad: all tiles of a split run on ONE XCD (32 CUs, one 128-KB block per CU), so a split costs `tiles` CUs
+static int64_t g6_wgrad_splits(int64_t M, int64_t N, int64_t K, int64_t max_ws_splits) {
+    const int64_t tiles = (M / G3_M) * (N / G3_N);
+    int64_t per_xcd = tiles >= 32 ? 1 : 32 / tiles;
+    int64_t splits = 8 * per_xcd;
+    const int64_t max_by_k = K / (8 * G3_K);
+    while (splits > 8 && splits > max_by_k) splits -= 8;
+    if (splits > max_by_k) splits = max_by_k > 0 ? max_by_k : 1;
+    if (max_ws_splits > 0 && splits > max_ws_splits) splits = max_ws_splits >= 8 ? (max_ws_splits / 8) * 8 : max_ws_splits;
+    { const char* fs = getenv("EMO_GEMM_SPLITS"); if (fs && atoi(fs) > 0) splits = atoi(fs); }
+    return splits < 1 ? 1 : splits;
+}
 extern "C" int64_t emo_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype_in, int dtype_out) {
     if (dtype_out != EMO_F32 || M <= 0 || N <= 0 || K <= 0) return 0;
     const bool big = dtype_in == EMO_BF16;
     const int64_t BMt = big ? GB_M : 64, BNt = big ? GB_N : 64, BKt = big ? (gemm_variant() >= 2 ? G2_BK : GB_K) : 16;
-    const int64_t splits = choose_splits(M, N, K, big, false, dtype_out, BMt, BNt, BKt, EMO_GEMM_MAX_SPLITS);
+    int64_t splits = choose_splits(M, N, K, big, false, dtype_out, BMt, BNt, BKt, EMO_GEMM_MAX_SPLITS);
+    if (big && g6_mode() != 1 && g6_shape_ok(M, N, K) && K >= 4096) {           // the caller's layout is not known here: size for both kernels
+        const int64_t s6 = g6_wgrad_splits(M, N, K, 0);
+        if (s6 > splits) splits = s6;
+    }
     return splits > 1 ? splits * M * N * (int64_t)sizeof(float) : 0;
 }
 
@@ -1623,10 +1973,18 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     }
     const bool ln_fused = e && (e->ln_c1 || e->rln_x);
     EMO_CHECK(!(ep.a_rowsum && ep.b_rowsum), "emo_gemm: a_rowsum and b_rowsum are exclusive");
+    bool use_g6 = false;
+    if (dtype_in == EMO_BF16 && gemm_variant() >= 2 && !use_safe_tr() && g6_mode() != 1 && g6_shape_ok(M, N, K) && !ln_fused && M > 32 &&
+        (lda & 7) == 0 && (ldb & 7) == 0 && getenv("EMO_GEMM_FORCE_G3") == nullptr && getenv("EMO_GEMM_TN32") == nullptr) {
+        // measured r01 (tools/bench_g6.py, 131072 tokens): FFN wgrads 725 -> 840-890 TFLOP/s, fused-QKV wgrad 548 -> 581, the 4-tile
+        // 512 x 512 wgrad 575 -> 500 (64 splits), K = 1536 / 2048 single-pass GEMMs within noise of the 128^2 kernels -> wgrad only
+        const bool wgrad = a_trans && b_trans && dtype_out == EMO_F32 && !has_epi && ldc == N && (M / G3_M) * (N / G3_N) >= 12 && K >= 32768;
+        use_g6 = g6_mode() == 2 || wgrad;
+    }
     if (ep.b_rowsum) {
         EMO_CHECK(a_trans && b_trans, "emo_gemm: b_rowsum needs a_trans and b_trans (B stored [K, N]: the Conv1D wgrad layout)");
         const bool in_kernel = dtype_in == EMO_BF16 && dtype_out == EMO_F32 && gemm_variant() < 3 && !use_safe_tr() && getenv("EMO_GEMM_TN32") == nullptr &&
-                               getenv("EMO_GEMM_FORCE_G3") == nullptr && getenv("EMO_GEMM_NO_ROWSUM_FUSE") == nullptr;
+                               getenv("EMO_GEMM_FORCE_G3") == nullptr && getenv("EMO_GEMM_NO_ROWSUM_FUSE") == nullptr;   // (v6 carries it too: a_trans && b_trans)
         if (!in_kernel) {
             const int rc = emo_colsum(B, dtype_in, K, N, ldb, ep.b_rowsum, 1, stream);
             if (rc) return rc;
@@ -1675,6 +2033,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         use_g3 = n_ok && enough && false;
     }
     if (big && variant >= 2 && !use_safe_tr() && (K % G3_K) == 0 && M >= 8 && N >= 8 && getenv("EMO_GEMM_FORCE_G3") != nullptr) use_g3 = true;
+    if (use_g6) use_g3 = true;                                // same 256 x 256 x 64 tile grid; the kernel is chosen at the launch below
     const int64_t BMt = big ? (use_g3 ? G3_M : GB_M) : 64, BNt = big ? (use_g3 ? G3_N : GB_N) : 64;
     const int64_t BKt = big ? (use_g3 ? G3_K : (variant >= 2 ? G2_BK : GB_K)) : 16;
     const int64_t tiles_m = cdiv64(M, BMt), tiles_n = cdiv64(N, BNt);
@@ -1685,6 +2044,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     const bool ws_ok = ws && ldc == N && ((M * N) & 3) == 0 && ((uintptr_t)ws & 15) == 0 && getenv("EMO_GEMM_SPLIT_ATOMIC") == nullptr;
     int64_t max_ws_splits = ws_ok ? ws_bytes / (M * N * (int64_t)sizeof(float)) : 0;
     int64_t splits = choose_splits(M, N, K, big, has_epi, dtype_out, BMt, BNt, BKt, max_ws_splits >= 2 ? max_ws_splits : 0);
+    if (use_g6) splits = (a_trans && b_trans && dtype_out == EMO_F32 && !has_epi && K >= 4096 && ldc == N) ? g6_wgrad_splits(M, N, K, max_ws_splits >= 2 ? max_ws_splits : 0) : 1;
     if (ldc != N) splits = 1;                                // split-K partials need a contiguous C: a strided output view runs unsplit
     int64_t kps = cdiv64(cdiv64(K, splits), BKt) * BKt;
     splits = cdiv64(K, kps);
@@ -1736,6 +2096,10 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         } else if (use_g4) {
             if (dtype_out == EMO_F32) { if (bkc) launch_g4<true, float>(st, a, lda, b, ldb, C, M, N, K, ep); else launch_g4<false, float>(st, a, lda, b, ldb, C, M, N, K, ep); }
             else { if (bkc) launch_g4<true, bf16_t>(st, a, lda, b, ldb, C, M, N, K, ep); else launch_g4<false, bf16_t>(st, a, lda, b, ldb, C, M, N, K, ep); }
+        } else if (use_g6 && span_ok && (kps % G3_K) == 0) {
+            const int rs = ep.a_rowsum ? 1 : (ep.b_rowsum ? 2 : 0);
+            if (dtype_out == EMO_F32) dispatch_g6<float>(akc, bkc, rs, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
+            else dispatch_g6<bf16_t>(akc, bkc, rs, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
         } else if (use_g3 && span_ok && (kps % G3_K) == 0) {
             if (dtype_out == EMO_F32) dispatch_g3<float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
             else dispatch_g3<bf16_t>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);

@@ -2,6 +2,7 @@
 reference of the same op.  Tolerances: EMO_F32 paths 2e-5 (exact-f32 MFMA, reassociation only);
 EMO_BF16 paths 3e-2 relative to the tensor scale (bf16 storage, fp32 accumulate)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -162,6 +163,36 @@ def test_gemm_splitk_workspace_stays_inside_its_bounds(splits, monkeypatch):
         torch.cuda.synchronize()
         assert bool((buf[need:] == 0x5A).all()), 'workspace overrun'
         _close(out, dY.double().T @ X.double(), dt, mult=1.0 if dt == torch.float32 else 0.3)
+
+
+def test_gemm_v6_wgrad_default_dispatch_matches_torch_and_is_deterministic():
+    # >= 12 tiles of 256^2 and >= 32768 tokens: the four-phase 256^2 split-K kernel with the fused bias gradient and a workspace
+    ops = _ops()
+    from emo_disentanger_amd._lib import lib
+    M, N, K = 1024, 768, 32768
+    assert lib.emo_gemm_workspace_bytes(M, N, K, 1, 0) >= 16 * M * N * 4
+    dy, x = (_r(K, M, seed=1) * 0.5).to(torch.bfloat16).cuda(), (_r(K, N, seed=2) * 0.5).to(torch.bfloat16).cuda()
+    outs = []
+    for _ in range(3):
+        dw, db = torch.zeros(M, N, device='cuda'), torch.zeros(M, device='cuda')
+        ops.gemm(dy, x, a_trans=True, b_trans=True, out=dw, a_rowsum=db)
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    ref = dy.double().T @ x.double()
+    assert float((outs[0].double() - ref).abs().max() / ref.abs().max()) < 1e-4
+    want = dy.double().sum(0)
+    assert float((db.double() - want).abs().max() / want.abs().max()) < 1e-4
+
+
+def test_gemm_v6_forced_all_layouts():
+    # EMO_GEMM_G6 is read once per process: the forced-mode sweep (NN / NT / TN / TT, bf16 + fp32 outputs, fused epilogue, odd K-tile
+    # counts, both bias-gradient flavours, run-to-run bitwise stability) runs in a child
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EMO_GEMM_G6='1')
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_g6.py')], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize('M', [1, 7, 32])
