@@ -891,7 +891,7 @@ static void dispatch_g3(bool akc, bool bkc, dim3 grid, hipStream_t st, const bf1
 //     a wave owns 64 rows of EACH A half and 32 columns of EACH B half, so one phase = one (A half, B half) quadrant =
 //     16 MFMAs on 8 / 4 / 8 / 0 freshly read fragments: P1 reads B0 + A0, P2 reads B1, P3 reads A1, P4 reads nothing;
 //   * a half-tile slot is re-staged (LDS-DMA) for K-tile t+2 two phases after its last fragment read — one phase after for B0, whose
-//     reads an lgkmcnt before P1's barrier retires — one half-tile (2 DMA instructions per wave) per phase: P1: A1 of t+1, P2: B0,
+//     reads an lgkmcnt before P1's barrier retires — P1 (12 of the 24 fragment reads): none, P2: A1 of t+1 and B0 of t+2,
 //     P3: A0, P4: B1 of t+2, with ONE counted wait per K-tile (P4: vmcnt(6) = the three newest half-tiles stay
 //     in flight) — loads live for 3-7 phases and never drain inside the loop;
 //   * waves 4-7 (the second wave of every SIMD) run one s_barrier behind waves 0-3: while one wave of a SIMD is in its MFMA
@@ -1045,8 +1045,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_g6_kernel(const bf16_t* __restr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     G6_BARRIER();
-    if (wr == 1) G6_BARRIER();          // group 1 runs one barrier behind group 0
+    const int grp = (ep.ablate & 4) ? (wave & 1) : (wave >> 2);      // the two waves of a SIMD must be in different groups
+    if (grp == 1) G6_BARRIER();         // group 1 runs one barrier behind group 0
     bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    // diagnostics (EMO_GEMM_ABLATE & 8, mul_aux = debug buffer): per-wave cycle totals of the 8 barrier-delimited sections of a K-tile
+    const bool dbg = (ep.ablate & 8) != 0;
+    uint64_t dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dprev = dbg ? __builtin_readcyclecounter() : 0;
+#define G6_STAMP(slot) do { if (dbg) { const uint64_t c_ = __builtin_readcyclecounter(); dsum[slot] += c_ - dprev; dprev = c_; } } while (0)
     for (int t = 0; t < nk; ++t) {
         const char* st = smem + (t & 1) * G6_STAGE;
         // ---- P1: (A0, B0)
@@ -1059,11 +1064,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_g6_kernel(const bf16_t* __restr
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) fa[i][ks] = lfrag2<A_KC, 64>(st, wr * 64 + i * 16, ks, lane);
-        if (t + 1 < nk && !(ep.ablate & 1)) G6_ISSUE_A(1, t + 1);
         // retire the B0 reads before this phase's barrier (LDS reads return in order; A0 is 8 ds_read_b128 or 16 transposing reads,
         // the counter saturates at 15): the B0 slot can then be re-staged one phase later instead of two
         if constexpr (A_KC) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
         G6_BARRIER();
+        G6_STAMP(0);
         G6_MFMA_BEGIN();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -1080,13 +1085,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_g6_kernel(const bf16_t* __restr
         }
         G6_MFMA_END();
         G6_BARRIER();
+        G6_STAMP(1);
         // ---- P2: (A0, B1)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = lfrag2<B_KC, 64>(st + 3 * G6_HT, wc * 32 + j * 16, ks, lane);
+        if (t + 1 < nk && !(ep.ablate & 1)) G6_ISSUE_A(1, t + 1);     // (P1 carries 12 of the K-tile's 24 fragment reads: no DMA issue there)
         if (t + 2 < nk && !(ep.ablate & 1)) G6_ISSUE_B(0, t + 2);
         G6_BARRIER();
+        G6_STAMP(2);
         G6_MFMA_BEGIN();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -1112,6 +1120,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_g6_kernel(const bf16_t* __restr
         }
         G6_MFMA_END();
         G6_BARRIER();
+        G6_STAMP(3);
         // ---- P3: (A1, B1); re-stage B0, A0 for K-tile t + 2
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1119,6 +1128,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_g6_kernel(const bf16_t* __restr
             for (int ks = 0; ks < 2; ++ks) fa[i][ks] = lfrag2<A_KC, 64>(st + G6_HT, wr * 64 + i * 16, ks, lane);
         if (t + 2 < nk && !(ep.ablate & 1)) G6_ISSUE_A(0, t + 2);
         G6_BARRIER();
+        G6_STAMP(4);
         G6_MFMA_BEGIN();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -1128,6 +1138,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_g6_kernel(const bf16_t* __restr
                 for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[4 + i][2 + j], 0, 0, 0);
         G6_MFMA_END();
         G6_BARRIER();
+        G6_STAMP(5);
         // ---- P4: (A1, B0); re-stage B1 for K-tile t + 2; the one counted wait of the K-tile
         if (t + 2 < nk && !(ep.ablate & 1)) {
             G6_ISSUE_B(1, t + 2);
@@ -1141,6 +1152,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_g6_kernel(const bf16_t* __restr
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         G6_BARRIER();
+        G6_STAMP(6);
         G6_MFMA_BEGIN();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -1159,9 +1171,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_g6_kernel(const bf16_t* __restr
         }
         G6_MFMA_END();
         G6_BARRIER();
+        G6_STAMP(7);
         if (RS != 0) { if (++rs_own == rs_mod) rs_own = 0; }
     }
-    if (wr == 0) G6_BARRIER();
+    if (grp == 0) G6_BARRIER();
     asm volatile("" :: "v"(pft));
 #undef G6_ISSUE_A
 #undef G6_ISSUE_B
@@ -1182,6 +1195,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_g6_kernel(const bf16_t* __restr
             }
     }
     epilogue_tile256<OutT>(ep, C, m0, n0, M, N, acc, smem, tid, wr, wc, lane);
+    if (dbg && blockIdx.x == 0 && lane == 0 && ep.mul_aux) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ((float*)ep.mul_aux)[wave * 8 + q] = (float)dsum[q] / (float)nk;
+        ((float*)ep.mul_aux)[64 + wave] = (float)((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3);   // HW_ID.SIMD_ID
+    }
+#undef G6_STAMP
 }
 
 template <bool A_KC, bool B_KC, typename OutT, int RS>
@@ -1935,7 +1954,7 @@ extern "C" int64_t emo_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int
     const bool big = dtype_in == EMO_BF16;
     const int64_t BMt = big ? GB_M : 64, BNt = big ? GB_N : 64, BKt = big ? (gemm_variant() >= 2 ? G2_BK : GB_K) : 16;
     int64_t splits = choose_splits(M, N, K, big, false, dtype_out, BMt, BNt, BKt, EMO_GEMM_MAX_SPLITS);
-    if (big && g6_mode() != 1 && g6_shape_ok(M, N, K) && K >= 4096) {           // the caller's layout is not known here: size for both kernels
+    if (big && g6_mode() != 1 && g6_shape_ok(M, N, K) && (g6_mode() == 2 ? K >= 4096 : (K >= 32768 && (M / G3_M) * (N / G3_N) >= 12))) {   // layout unknown here: size for both kernels
         const int64_t s6 = g6_wgrad_splits(M, N, K, 0);
         if (s6 > splits) splits = s6;
     }
