@@ -888,20 +888,25 @@ static void dispatch_g3(bool akc, bool bkc, dim3 grid, hipStream_t st, const bf1
 // K-tile: every wave of the block reads LDS at the same time and then every wave issues MFMAs at the same time, so the matrix
 // pipe idles during the read sections), and the plain 256^2 double buffer (v3) is no better.  Here
 //   * the K-tile is staged as four 16-KB half-tiles (A rows 0-127 / 128-255, B cols 0-127 / 128-255) in a 2 x 64 KB ring;
-//     a wave owns 64 rows of EACH A half and 32 columns of EACH B half, so one phase = one (A half, B half) quadrant =
-//     16 MFMAs on 8 / 4 / 8 / 0 freshly read fragments: P1 reads B0 + A0, P2 reads B1, P3 reads A1, P4 reads nothing;
-//   * a half-tile slot is re-staged (LDS-DMA) for K-tile t+2 two phases after its last fragment read — one phase after for B0, whose
-//     reads an lgkmcnt before P1's barrier retires — P1 (12 of the 24 fragment reads): none, P2: A1 of t+1 and B0 of t+2,
-//     P3: A0, P4: B1 of t+2, with ONE counted wait per K-tile (P4: vmcnt(6) = the three newest half-tiles stay
-//     in flight) — loads live for 3-7 phases and never drain inside the loop;
-//   * waves 4-7 (the second wave of every SIMD) run one s_barrier behind waves 0-3: while one wave of a SIMD is in its MFMA
-//     section the other is in its read / stage section (s_setprio favours the MFMA wave).
+//     a wave owns 64 rows of EACH A half and 32 columns of EACH B half (wave tile 128 x 64);
+//   * one phase = one k-half (32) of one A half against all four B fragments = 16 MFMAs on 16 distinct accumulators:
+//     P1 reads B.k0 + A0.k0 (8 fragments), P2 B.k1 + A0.k1 (8), P3 A1.k0 (4), P4 A1.k1 (4).  (The first version split by
+//     quadrant, 12 / 4 / 8 / 0 fragments: the 12-fragment phase was 24 transposing reads on the wgrad layout — more than the 15
+//     outstanding LDS ops a wave can have — and took 1050 cycles against 470 for the others.)
+//   * a half-tile slot is re-staged (LDS-DMA, 2 instructions per wave) two phases after its last fragment read, one half-tile per
+//     phase: P1: B0 of t+1, P2: B1 of t+1, P3: A1 of t+1, P4: A0 of t+2 — loads live for 2-4 phases and are retired by two COUNTED
+//     waits per K-tile (P2: vmcnt(6) -> A1 of t, read in P3;  P4: vmcnt(4) -> A0, B0, B1 of t+1, read in the next P1); the queue
+//     never drains inside the loop;
+//   * waves 4-7 (the second wave of every SIMD: HW_ID.SIMD_ID of waves w and w+4 is equal) run one s_barrier behind waves 0-3:
+//     while one wave of a SIMD is in its MFMA section the other is in its read / stage section (s_setprio favours the MFMA wave).
 // Hazards (E_n = n-th barrier; group 0: R1 E1 M1 E2 R2 E3 M2 E4 R3 E5 M3 E6 R4 E7 M4 E8, group 1 the same shifted by one E):
-//   RAW: every wave's P4 wait precedes its P4 barrier (E7 for group 0, E8 for group 1); the first read of the new K-tile is group
-//        0's R1 after E8.  WAR: a slot read in R_p has its reads retired at the latest after E_{2p} (group 1's lgkmcnt before
-//        its M_p) and is re-staged in R_{p+2}, which group 0 starts after E_{2p+2}; B0's reads are retired before E1 / E2 already and
-//        group 0's R2 starts after E2.
+//   RAW: a wave's wait sits before the first barrier of its phase p (E_{2p-1} for group 0, E_{2p} for group 1); the data is first read
+//        in R_{p+1}, which group 0 starts after E_{2p}.  WAR: a slot read in R_p has its reads retired at the latest after E_{2p}
+//        (group 1's lgkmcnt before its M_p) and is re-staged in R_{p+2} or later, which group 0 starts after E_{2p+2}.
 constexpr int G6_HT = 16384, G6_STAGE = 65536;
+#ifndef G6_PROFILE
+#define G6_PROFILE 0      // 1: per-section cycle stamps (EMO_GEMM_ABLATE & 8, tools/g6_phases.py); costs registers, diagnostics builds only
+#endif
 
 template <bool KC>
 __device__ __forceinline__ void g6_offsets(int64_t ld, int64_t row0, int64_t nrows, int wave, int lane, uint32_t (&off)[2][2]) {
@@ -1020,164 +1025,128 @@ __global__ __launch_bounds__(512) void gemm_bf16_g6_kernel(const bf16_t* __restr
     const char* gB = (const char*)B + (B_KC ? kbeg : kbeg * ldb) * 2;
     const int64_t stepA = (A_KC ? (int64_t)G3_K : (int64_t)G3_K * lda) * 2;
     const int64_t stepB = (B_KC ? (int64_t)G3_K : (int64_t)G3_K * ldb) * 2;
-    // L2 prefetch of K-tile t + PF (the operand streams come from HBM: with 64 KB of LDS-DMA in flight per CU the loop was bound by the
-    // miss latency, 1203 -> 827 TFLOP/s on the FFN wgrad with / without tile loads): one 4-B load per 128-B line, waves 0-3 cover A,
-    // waves 4-7 cover B, issued as the NEWEST vector-memory op before the K-tile's counted wait so that it never holds up the DMA queue.
-    const int PF = (ep.ablate >> 4) ? (ep.ablate >> 4) : 4;
-    const char* pfb = wave < 4 ? gA : gB;
-    const int64_t pfs = wave < 4 ? stepA : stepB;
-    uint32_t pfo;
-    {
-        const int r = tid & 255;
-        const bool kc = wave < 4 ? A_KC : B_KC;
-        const int64_t ld = wave < 4 ? lda : ldb, row0 = wave < 4 ? m0 : n0, nrows = wave < 4 ? M : N;
-        if (kc) { int64_t gr = row0 + r; if (gr > nrows - 1) gr = nrows - 1; pfo = (uint32_t)(gr * ld * 2); }
-        else { int64_t gr = row0 + (r & 3) * 64; if (gr > nrows - 2) gr = row0; pfo = (uint32_t)(((int64_t)(r >> 2) * ld + gr) * 2); }
-    }
-    uint32_t pft = 0;
 #define G6_ISSUE_A(h, t) g6_issue(gA + (int64_t)(t) * stepA, offA[h], smem + ((t) & 1) * G6_STAGE + (h) * G6_HT, wave)
 #define G6_ISSUE_B(h, t) g6_issue(gB + (int64_t)(t) * stepB, offB[h], smem + ((t) & 1) * G6_STAGE + (2 + (h)) * G6_HT, wave)
+    const bool noload = (ep.ablate & 1) != 0;     // diagnostics: no tile DMA inside the loop
     G6_ISSUE_B(0, 0); G6_ISSUE_A(0, 0); G6_ISSUE_B(1, 0); G6_ISSUE_A(1, 0);
     if (nk > 1) {
-        G6_ISSUE_B(0, 1); G6_ISSUE_A(0, 1); G6_ISSUE_B(1, 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        G6_ISSUE_A(0, 1);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     G6_BARRIER();
-    const int grp = (ep.ablate & 4) ? (wave & 1) : (wave >> 2);      // the two waves of a SIMD must be in different groups
+    const int grp = (ep.ablate & 4) ? (wave & 1) : (wave >> 2);      // the two waves of a SIMD (w, w + 4) must be in different groups
     if (grp == 1) G6_BARRIER();         // group 1 runs one barrier behind group 0
-    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
-    // diagnostics (EMO_GEMM_ABLATE & 8, mul_aux = debug buffer): per-wave cycle totals of the 8 barrier-delimited sections of a K-tile
+    bf16x8 fa[4], fb[4][2];
+#if G6_PROFILE
     const bool dbg = (ep.ablate & 8) != 0;
     uint64_t dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dprev = dbg ? __builtin_readcyclecounter() : 0;
 #define G6_STAMP(slot) do { if (dbg) { const uint64_t c_ = __builtin_readcyclecounter(); dsum[slot] += c_ - dprev; dprev = c_; } } while (0)
+#else
+#define G6_STAMP(slot) do { } while (0)
+#endif
+#define G6_READ_B(ks)                                                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                                       \
+        fb[j][ks] = lfrag2<B_KC, 64>(st + (2 + (j >> 1)) * G6_HT, wc * 32 + (j & 1) * 16, ks, lane)
+#define G6_READ_A(h, ks)                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = lfrag2<A_KC, 64>(st + (h) * G6_HT, wr * 64 + i * 16, ks, lane)
+#define G6_MMA(h, ks)                                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                                   \
+            acc[4 * (h) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i], acc[4 * (h) + i][j], 0, 0, 0)
+    // bias-gradient MFMAs against the all-ones operand: fragment i = wc of the A half (RS = 1) / fragments j = wr, 2 + wr of B (RS = 2);
+    // wave-uniform branches keep the register indices static
+#define G6_RS_A(h)                                                                                                                     \
+    if (RS == 1 && rs_own == rs_me) {                                                                                                  \
+        if (wc == 0) rsacc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[0], rsacc[h], 0, 0, 0);                                \
+        else if (wc == 1) rsacc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[1], rsacc[h], 0, 0, 0);                           \
+        else if (wc == 2) rsacc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[2], rsacc[h], 0, 0, 0);                           \
+        else rsacc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[3], rsacc[h], 0, 0, 0);                                        \
+    }
+#define G6_RS_B(ks)                                                                                                                    \
+    if (RS == 2 && rs_own == rs_me) {                                                                                                  \
+        if (wr == 0) {                                                                                                                 \
+            rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][ks], ones, rsacc[0], 0, 0, 0);                                     \
+            rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[2][ks], ones, rsacc[1], 0, 0, 0);                                     \
+        } else {                                                                                                                       \
+            rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1][ks], ones, rsacc[0], 0, 0, 0);                                     \
+            rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[3][ks], ones, rsacc[1], 0, 0, 0);                                     \
+        }                                                                                                                              \
+    }
     for (int t = 0; t < nk; ++t) {
         const char* st = smem + (t & 1) * G6_STAGE;
-        // ---- P1: (A0, B0)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fb0[j][ks] = lfrag2<B_KC, 64>(st + 2 * G6_HT, wc * 32 + j * 16, ks, lane);
-        __builtin_amdgcn_sched_barrier(0);        // B0's reads are issued (and return) first
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = lfrag2<A_KC, 64>(st, wr * 64 + i * 16, ks, lane);
-        // retire the B0 reads before this phase's barrier (LDS reads return in order; A0 is 8 ds_read_b128 or 16 transposing reads,
-        // the counter saturates at 15): the B0 slot can then be re-staged one phase later instead of two
-        if constexpr (A_KC) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+        const bool more = t + 1 < nk && !noload;
+        // ---- P1: k-half 0 of (A0, B0|B1)
+        G6_READ_B(0);
+        G6_READ_A(0, 0);
+        if (more) G6_ISSUE_B(0, t + 1);
         G6_BARRIER();
         G6_STAMP(0);
         G6_MFMA_BEGIN();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
-        if (RS == 2 && rs_own == rs_me) {       // B0 columns: fragment j = wr of this wave's pair
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                if (wr == 0) rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[0][ks], ones, rsacc[0], 0, 0, 0);
-                else rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[1][ks], ones, rsacc[0], 0, 0, 0);
-            }
-        }
+        G6_MMA(0, 0);
+        G6_RS_A(0);
+        G6_RS_B(0);
         G6_MFMA_END();
         G6_BARRIER();
         G6_STAMP(1);
-        // ---- P2: (A0, B1)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = lfrag2<B_KC, 64>(st + 3 * G6_HT, wc * 32 + j * 16, ks, lane);
-        if (t + 1 < nk && !(ep.ablate & 1)) G6_ISSUE_A(1, t + 1);     // (P1 carries 12 of the K-tile's 24 fragment reads: no DMA issue there)
-        if (t + 2 < nk && !(ep.ablate & 1)) G6_ISSUE_B(0, t + 2);
-        G6_BARRIER();
-        G6_STAMP(2);
-        G6_MFMA_BEGIN();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[i][2 + j], 0, 0, 0);
-        if (RS == 1 && rs_own == rs_me) {       // A0 rows: fragment i = wc
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                if (wc == 0) rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[0][ks], rsacc[0], 0, 0, 0);
-                else if (wc == 1) rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[1][ks], rsacc[0], 0, 0, 0);
-                else if (wc == 2) rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[2][ks], rsacc[0], 0, 0, 0);
-                else rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[3][ks], rsacc[0], 0, 0, 0);
-            }
-        }
-        if (RS == 2 && rs_own == rs_me) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                if (wr == 0) rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[0][ks], ones, rsacc[1], 0, 0, 0);
-                else rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[1][ks], ones, rsacc[1], 0, 0, 0);
-            }
-        }
-        G6_MFMA_END();
-        G6_BARRIER();
-        G6_STAMP(3);
-        // ---- P3: (A1, B1); re-stage B0, A0 for K-tile t + 2
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = lfrag2<A_KC, 64>(st + G6_HT, wr * 64 + i * 16, ks, lane);
-        if (t + 2 < nk && !(ep.ablate & 1)) G6_ISSUE_A(0, t + 2);
-        G6_BARRIER();
-        G6_STAMP(4);
-        G6_MFMA_BEGIN();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[4 + i][2 + j], 0, 0, 0);
-        G6_MFMA_END();
-        G6_BARRIER();
-        G6_STAMP(5);
-        // ---- P4: (A1, B0); re-stage B1 for K-tile t + 2; the one counted wait of the K-tile
-        if (t + 2 < nk && !(ep.ablate & 1)) {
-            G6_ISSUE_B(1, t + 2);
-            if (t + PF < nk && !(ep.ablate & 2)) {
-                asm volatile("global_load_dword %0, %1, off" : "+v"(pft) : "v"(pfb + (int64_t)(t + PF) * pfs + pfo) : "memory");
-                asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            }
+        // ---- P2: k-half 1 of (A0, B0|B1); the wait that makes A1 of this K-tile readable in P3
+        G6_READ_B(1);
+        G6_READ_A(0, 1);
+        if (more) {
+            G6_ISSUE_B(1, t + 1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // newer than A1(t): A0, B0, B1 of t + 1
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         G6_BARRIER();
-        G6_STAMP(6);
+        G6_STAMP(2);
         G6_MFMA_BEGIN();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[4 + i][j], 0, 0, 0);
-        if (RS == 1 && rs_own == rs_me) {       // A1 rows
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                if (wc == 0) rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[0][ks], rsacc[1], 0, 0, 0);
-                else if (wc == 1) rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[1][ks], rsacc[1], 0, 0, 0);
-                else if (wc == 2) rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[2][ks], rsacc[1], 0, 0, 0);
-                else rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[3][ks], rsacc[1], 0, 0, 0);
+        G6_MMA(0, 1);
+        G6_RS_A(0);
+        G6_RS_B(1);
+        G6_MFMA_END();
+        G6_BARRIER();
+        G6_STAMP(3);
+        // ---- P3: k-half 0 of (A1, B0|B1)
+        G6_READ_A(1, 0);
+        if (more) G6_ISSUE_A(1, t + 1);
+        G6_BARRIER();
+        G6_STAMP(4);
+        G6_MFMA_BEGIN();
+        G6_MMA(1, 0);
+        G6_RS_A(1);
+        G6_MFMA_END();
+        G6_BARRIER();
+        G6_STAMP(5);
+        // ---- P4: k-half 1 of (A1, B0|B1); the wait that makes A0, B0, B1 of K-tile t + 1 readable in its P1
+        G6_READ_A(1, 1);
+        if (more) {
+            if (t + 2 < nk) {
+                G6_ISSUE_A(0, t + 2);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // newer than B1(t + 1): A1 of t + 1, A0 of t + 2
+            } else {
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             }
         }
+        G6_BARRIER();
+        G6_STAMP(6);
+        G6_MFMA_BEGIN();
+        G6_MMA(1, 1);
+        G6_RS_A(1);
         G6_MFMA_END();
         G6_BARRIER();
         G6_STAMP(7);
         if (RS != 0) { if (++rs_own == rs_mod) rs_own = 0; }
     }
     if (grp == 0) G6_BARRIER();
-    asm volatile("" :: "v"(pft));
 #undef G6_ISSUE_A
 #undef G6_ISSUE_B
+#undef G6_READ_A
+#undef G6_READ_B
+#undef G6_MMA
+#undef G6_RS_A
+#undef G6_RS_B
     if (RS == 1 && (lane >> 4) == 0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -1195,11 +1164,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_g6_kernel(const bf16_t* __restr
             }
     }
     epilogue_tile256<OutT>(ep, C, m0, n0, M, N, acc, smem, tid, wr, wc, lane);
+#if G6_PROFILE
     if (dbg && blockIdx.x == 0 && lane == 0 && ep.mul_aux) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) ((float*)ep.mul_aux)[wave * 8 + q] = (float)dsum[q] / (float)nk;
         ((float*)ep.mul_aux)[64 + wave] = (float)((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3);   // HW_ID.SIMD_ID
     }
+#endif
 #undef G6_STAMP
 }
 
@@ -1929,11 +1900,13 @@ static int64_t choose_splits(int64_t M, int64_t N, int64_t K, bool big, bool has
 }
 
 #define EMO_GEMM_MAX_SPLITS 32
-// v6 (256^2 four-phase kernel) eligibility.  kind 0: split-K wgrad (both operands token-major, plain fp32 output); kind 1: single-pass
-// GEMM with a long reduction.  EMO_GEMM_G6=0 disables it, =1 forces it for every eligible shape (K % 64 == 0, M, N multiples of 256).
+// v6 (256^2 four-phase kernel) dispatch.  OFF by default: in microbenchmarks it beats the 128^2 kernels on the long reductions (FFN wgrad
+// 680-705 -> 800-820 TFLOP/s, 8192^3 NT 906 -> 1155), but INSIDE the training step the 128^2 wgrad runs at ~890 TFLOP/s (its dY operand was
+// just written and is still on-die) against 864 for v6, and the K = 2048 forward is equal (663 vs 667): 65.6 vs 65.5 ms/step.
+// EMO_GEMM_G6=1 forces it for every eligible shape (K % 64 == 0, M and N multiples of 256), =2 enables it for the >= 12-tile wgrads only.
 static int g6_mode() {
     static int m = -1;
-    if (m < 0) { const char* e = getenv("EMO_GEMM_G6"); m = e ? atoi(e) + 1 : 0; }   // 0 = heuristic, 1 = off, 2 = forced
+    if (m < 0) { const char* e = getenv("EMO_GEMM_G6"); m = e ? atoi(e) + 1 : 1; }   // 1 = off (default), 2 = forced, 3 = wgrad heuristic
     return m;
 }
 static bool g6_shape_ok(int64_t M, int64_t N, int64_t K) { return (M % G3_M) == 0 && (N % G3_N) == 0 && (K % G3_K) == 0 && K >= 2 * G3_K; }
@@ -1998,7 +1971,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         // measured r01 (tools/bench_g6.py, 131072 tokens): FFN wgrads 725 -> 840-890 TFLOP/s, fused-QKV wgrad 548 -> 581, the 4-tile
         // 512 x 512 wgrad 575 -> 500 (64 splits), K = 1536 / 2048 single-pass GEMMs within noise of the 128^2 kernels -> wgrad only
         const bool wgrad = a_trans && b_trans && dtype_out == EMO_F32 && !has_epi && ldc == N && (M / G3_M) * (N / G3_N) >= 12 && K >= 32768;
-        use_g6 = g6_mode() == 2 || wgrad;
+        use_g6 = g6_mode() == 2 || (g6_mode() == 3 && wgrad);
     }
     if (ep.b_rowsum) {
         EMO_CHECK(a_trans && b_trans, "emo_gemm: b_rowsum needs a_trans and b_trans (B stored [K, N]: the Conv1D wgrad layout)");

@@ -165,12 +165,11 @@ def test_gemm_splitk_workspace_stays_inside_its_bounds(splits, monkeypatch):
         _close(out, dY.double().T @ X.double(), dt, mult=1.0 if dt == torch.float32 else 0.3)
 
 
-def test_gemm_v6_wgrad_default_dispatch_matches_torch_and_is_deterministic():
-    # >= 12 tiles of 256^2 and >= 32768 tokens: the four-phase 256^2 split-K kernel with the fused bias gradient and a workspace
+def test_gemm_large_wgrad_matches_torch_and_is_deterministic():
+    # 12 output tiles of 256^2, 32768 tokens: split-K with a workspace and the fused bias gradient (128^2 kernel by default, the 256^2
+    # four-phase kernel with EMO_GEMM_G6=2)
     ops = _ops()
-    from emo_disentanger_amd._lib import lib
     M, N, K = 1024, 768, 32768
-    assert lib.emo_gemm_workspace_bytes(M, N, K, 1, 0) >= 16 * M * N * 4
     dy, x = (_r(K, M, seed=1) * 0.5).to(torch.bfloat16).cuda(), (_r(K, N, seed=2) * 0.5).to(torch.bfloat16).cuda()
     outs = []
     for _ in range(3):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase cycle profile of the v6 GEMM (EMO_GEMM_ABLATE=8 stamps s_memtime at every barrier exit; block 0 reports cycles per K-tile
-for the 8 barrier-delimited sections, per wave).  Run with EMO_GEMM_G6=1 EMO_GEMM_ABLATE=8 [ +1 no loads, +2 no prefetch ]."""
+for the 8 barrier-delimited sections, per wave).  Needs a diagnostics build of the library (make CXXFLAGS+=-DG6_PROFILE=1); run with
+EMO_GEMM_G6=1 EMO_GEMM_ABLATE=8 [ +1: no tile DMA inside the loop, +4: both waves of a SIMD in the same group ]."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
