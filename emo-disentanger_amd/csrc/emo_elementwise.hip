@@ -81,31 +81,60 @@ extern "C" int emo_embed_fwd(const int64_t* tok, const int64_t* seg, const float
 }
 
 // backward: block = (64-column slice) x (token chunk); per-block LDS table [(V+n_seg) x 64] fp32
-// accumulated with ds_add_f32, flushed once with global atomics.
+// accumulated with ds_add_f32, flushed once with global atomics.  The 84-KB table allows one block per CU, so the block is 8 waves and
+// every wave keeps 8 token rows in flight (ids through scalar loads, all 8 gradient loads issued before the first LDS atomic): (A single-wave-per-slice variant
+// with plain ds_read / add / ds_write instead of atomics was slower, 1070 us: one wave per CU cannot hide the HBM latency of 128-B rows.)
+constexpr int EB_THREADS = 512, EB_U = 8;
 template <typename T>
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ seg,
+__global__ __launch_bounds__(EB_THREADS) void embed_bwd_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ seg,
                                                         const T* __restrict__ dout, float* __restrict__ dE, float* __restrict__ dS,
                                                         int64_t M, int64_t D, int64_t V, int64_t n_seg, int64_t rows_per_block,
                                                         float scale, DropCtx drop) {
     extern __shared__ float tab[];  // (V + n_seg) * 64
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int NW = EB_THREADS / 64;
     const int64_t col = (int64_t)blockIdx.x * 64 + lane;
     const int64_t rows_tab = V + n_seg;
-    for (int64_t i = threadIdx.x; i < rows_tab * 64; i += 256) tab[i] = 0.f;
+    for (int64_t i = threadIdx.x; i < rows_tab * 64; i += EB_THREADS) tab[i] = 0.f;
     __syncthreads();
     const int64_t mbeg = (int64_t)blockIdx.y * rows_per_block;
     int64_t mend = mbeg + rows_per_block;
     if (mend > M) mend = M;
+    // LDS float atomics run at ~0.4 lane-adds per clock per CU and ARE this kernel's time (r01: 671 us with, 354 us without the segment rows,
+    // independent of the id distribution and of the flush count): the <= 2 segment rows are a column sum and stay in registers
+    const bool seg_regs = n_seg <= 2;
+    float s0 = 0.f, s1 = 0.f;
     if (col < D) {
-        for (int64_t m = mbeg + wave; m < mend; m += 4) {
-            float g = to_f32<T>(dout[m * D + col]) * drop_mult(drop, (uint64_t)(m * D + col)) * scale;
-            atomicAdd(&tab[tok[m] * 64 + lane], g);
-            if (seg) atomicAdd(&tab[(V + seg[m]) * 64 + lane], g);
+        for (int64_t m0 = mbeg + wave * EB_U; m0 < mend; m0 += NW * EB_U) {
+            float g[EB_U];
+            int64_t tk[EB_U], sg[EB_U];
+#pragma unroll
+            for (int u = 0; u < EB_U; ++u) {
+                const int64_t m = m0 + u < mend ? m0 + u : mend - 1;
+                tk[u] = tok[m];
+                sg[u] = seg ? seg[m] : 0;
+                g[u] = to_f32<T>(dout[m * D + col]);
+            }
+#pragma unroll
+            for (int u = 0; u < EB_U; ++u) {
+                if (m0 + u < mend) {
+                    const float v = g[u] * drop_mult(drop, (uint64_t)((m0 + u) * D + col)) * scale;
+                    atomicAdd(&tab[tk[u] * 64 + lane], v);
+                    if (seg) {
+                        if (seg_regs) { s0 += sg[u] == 0 ? v : 0.f; s1 += sg[u] == 1 ? v : 0.f; }
+                        else atomicAdd(&tab[(V + sg[u]) * 64 + lane], v);
+                    }
+                }
+            }
+        }
+        if (seg && seg_regs) {
+            if (s0 != 0.f) atomicAdd(dS + col, s0);
+            if (n_seg > 1 && s1 != 0.f) atomicAdd(dS + D + col, s1);
         }
     }
     __syncthreads();
     if (col < D) {
-        for (int64_t r = wave; r < rows_tab; r += 4) {
+        for (int64_t r = wave; r < (seg_regs ? V : rows_tab); r += NW) {
             float v = tab[r * 64 + lane];
             if (v != 0.f) {
                 if (r < V) atomicAdd(dE + r * D + col, v);
@@ -124,7 +153,8 @@ extern "C" int emo_embed_bwd(const int64_t* tok, const int64_t* seg, const void*
     const size_t lds = (size_t)(V + n_seg) * 64 * sizeof(float);
     EMO_CHECK(lds <= 160 * 1024, "emo_embed_bwd: vocabulary of %lld rows does not fit the LDS table", (long long)(V + n_seg));
     const int64_t M = B * T;
-    int64_t rpb = 2048;
+    int64_t rpb = 4096;      // 8 column slices x 32 chunks = 256 blocks at the bench shape (one 84-KB block per CU)
+    { const char* e = getenv("EMO_EMBED_RPB"); if (e && atoi(e) > 0) rpb = atoi(e); }
     if (rpb > M) rpb = M;
     dim3 grid((unsigned)cdiv64(D, 64), (unsigned)cdiv64(M, rpb));
     DropCtx drop = make_drop(p_drop, seed, offset);
@@ -132,11 +162,11 @@ extern "C" int emo_embed_bwd(const int64_t* tok, const int64_t* seg, const void*
     if (dtype == EMO_F32) {
         static bool a = false;
         if (!a) { (void)hipFuncSetAttribute((const void*)embed_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a = true; }
-        hipLaunchKernelGGL(embed_bwd_kernel<float>, grid, dim3(256), lds, st, tok, seg, (const float*)dout, dE, dS, M, D, V, n_seg, rpb, scale, drop);
+        hipLaunchKernelGGL(embed_bwd_kernel<float>, grid, dim3(EB_THREADS), lds, st, tok, seg, (const float*)dout, dE, dS, M, D, V, n_seg, rpb, scale, drop);
     } else {
         static bool a = false;
         if (!a) { (void)hipFuncSetAttribute((const void*)embed_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a = true; }
-        hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, grid, dim3(256), lds, st, tok, seg, (const bf16_t*)dout, dE, dS, M, D, V, n_seg, rpb, scale, drop);
+        hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, grid, dim3(EB_THREADS), lds, st, tok, seg, (const bf16_t*)dout, dE, dS, M, D, V, n_seg, rpb, scale, drop);
     }
     EMO_LAUNCH_CHECK();
     return EMO_OK;
