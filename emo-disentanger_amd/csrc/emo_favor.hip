@@ -21,6 +21,16 @@
 // 8 waves per workgroup (one workgroup per (b,h), ~120-155 KB LDS => 1 workgroup per CU): two waves per SIMD so that
 // one wave's LDS / exp / global phases overlap the other's MFMAs.
 constexpr int FT = 512, FW = FT / 64;
+// bf16 chunk sizes (tokens per scan step) of the forward / dq / dk,dv kernels at d_head 64, 128 features
+#ifndef FAVOR_CFB
+#define FAVOR_CFB 64
+#endif
+#ifndef FAVOR_CQB
+#define FAVOR_CQB 64
+#endif
+#ifndef FAVOR_CKB
+#define FAVOR_CKB 64
+#endif
 #ifndef FAVOR_PAD16
 #define FAVOR_PAD16 0
 #endif
@@ -1238,7 +1248,7 @@ static int dispatch_favor(int which, int dtype, int64_t dh, int64_t mf, const vo
         return run_favor<float, DHv, MFv, CFf, CQf, CKf>(which, q, k, v, ld, omega, out, ld_out, den, sS, sz, dout, dq, dk, dv, ld_d, B, T, H, eps, ws,      \
                                                          ws_bytes, st);                                                                      \
     }
-    FAVOR_CASE(64, 64, 64, 64, 64, 32, 32, 16)
+    FAVOR_CASE(64, 64, FAVOR_CFB, FAVOR_CQB, FAVOR_CKB, 32, 32, 16)
     FAVOR_CASE(32, 64, 64, 64, 64, 32, 32, 32)
     FAVOR_CASE(32, 32, 64, 64, 64, 32, 32, 32)
     FAVOR_CASE(16, 16, 64, 64, 64, 32, 32, 32)
