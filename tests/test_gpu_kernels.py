@@ -379,6 +379,22 @@ def test_layernorm_fwd_bwd(dt, D):
     _close(dxd, ops.dropout_apply(dx, 0.25, 9, 2), dt)
 
 
+@pytest.mark.parametrize('M', [4096, 4101, 8193])
+def test_layernorm_fwd_bf16_d512_fast_path(M):
+    # >= 4096 rows of 512 bf16 columns take the one-16-B-load-per-lane kernel (two rows per wave step: odd row counts exercise the tail)
+    ops = _ops()
+    D = 512
+    x = (_r(M, D, seed=1) * 1.7 + 0.3).to(torch.bfloat16)
+    gm, bt = _r(D, seed=2) * 0.1 + 1, _r(D, seed=3)
+    y, mean, rstd = ops.layernorm_fwd(x.cuda(), gm.cuda(), bt.cuda())
+    xd = x.double()
+    ref = torch.nn.functional.layer_norm(xd, (D,), gm.double(), bt.double(), 1e-5)
+    _close(y, ref, torch.bfloat16)
+    assert float((mean.cpu().double() - xd.mean(1)).abs().max()) < 1e-5
+    want_rstd = 1.0 / torch.sqrt(xd.var(1, unbiased=False) + 1e-5)
+    assert float(((rstd.cpu().double() - want_rstd) / want_rstd).abs().max()) < 1e-5
+
+
 def test_xent_fwd_bwd_and_accuracy():
     ops = _ops()
     from oracle import host_ref
