@@ -251,8 +251,8 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
         const int valid = (int)((tend - t0) < C ? (tend - t0) : C);
         __syncthreads();
         if (!(abl & 1)) {
-        if constexpr (!SO) pq.store_rows(Xq, LDX, tid);
-        pk.store_rows(Xk, LDX, tid);
+        if constexpr (!SO) pq.store_rows_off(Xq, LDX, tid, offq, cs * cs, half_ln_f);
+        pk.store_rows_off(Xk, LDX, tid, offk, cs * cs, half_ln_f);
         }
         if (!(abl & 2)) pv.store_T(VT, LDC, tid);
         if (t0 + C < tend) {                       // next chunk's q/k/v stay in flight during this chunk's compute
@@ -260,11 +260,6 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
             if constexpr (!SO) pq.load(qb + (t0 + C) * ld, ld, vn, tid);
             pk.load(kb + (t0 + C) * ld, ld, vn, tid);
             pv.load(vb + (t0 + C) * ld, ld, vn, tid);
-        }
-        __syncthreads();
-        if (!(abl & 4)) {
-        if constexpr (!SO) row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
-        row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
         }
         __syncthreads();
         if (!(abl & 8)) {
@@ -590,8 +585,8 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
         const int valid = (int)((tend - t0) < C ? (tend - t0) : C);
         __syncthreads();
         if (!(abl & 1)) {
-        pq.store_rows(Xq, LDX, tid);
-        pk.store_rows(Xk, LDX, tid);
+        pq.store_rows_off(Xq, LDX, tid, offq, cs * cs, half_ln_f);
+        pk.store_rows_off(Xk, LDX, tid, offk, cs * cs, half_ln_f);
         pv.store_rows(Vr, LDX, tid);
         }
         if (!(abl & 2)) pv.store_T(VT, LDC, tid);
@@ -604,9 +599,6 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
             pg.load(gb + tn_ * ld_out, ld_out, vn, tid); po.load(ob + tn_ * ld_out, ld_out, vn, tid);
             load_den<CT, DH, DHP, C>(dn, dg + tn_, vn, tid);
         }
-        __syncthreads();
-        row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
-        row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
         __syncthreads();
         if (!(abl & 8)) {
         features_rowmajor<CT, DHP, MF, C>(Qf, LDF, WT, Xq, LDX, offq, cs, C, wave, lane);
@@ -791,9 +783,9 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
         const int valid = (int)((tend - t0) < C ? (tend - t0) : C);
         __syncthreads();
         if (!(abl & 1)) {
-        pq.store_rows(Xq, LDX, tid);
+        pq.store_rows_off(Xq, LDX, tid, offq, cs * cs, half_ln_f);
         if constexpr (!SO) {
-            pk.store_rows(Xk, LDX, tid);
+            pk.store_rows_off(Xk, LDX, tid, offk, cs * cs, half_ln_f);
             pv.store_rows(Vr, LDX, tid);
         }
         }
@@ -806,9 +798,6 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
             pg.load(gb + tn_ * ld_out, ld_out, C, tid); po.load(ob + tn_ * ld_out, ld_out, C, tid);
             load_den<CT, DH, DHP, C>(dn, dg + tn_, C, tid);
         }
-        __syncthreads();
-        row_offsets<CT, DH, C>(Xq, LDX, offq, cs * cs, half_ln_f, tid);
-        if constexpr (!SO) row_offsets<CT, DH, C>(Xk, LDX, offk, cs * cs, half_ln_f, tid);
         __syncthreads();
         if (!(abl & 8)) {
         if constexpr (!SO) {

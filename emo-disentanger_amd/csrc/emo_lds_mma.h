@@ -163,6 +163,22 @@ struct RowPrefetch {
             for (int it = tid; it < ROWS * (NCP - NC); it += NTHR) img[(it / (NCP - NC)) * ld + NC + it % (NCP - NC)] = from_f32<CT>(0.f);
         }
     }
+    // store_rows + the FAVOR+ feature offset of every row, off[row] = 0.5 * c2 * |row|^2 + half_ln_f, from the registers (the CH lanes that
+    // hold one row are consecutive: xor-shuffle reduce) — the separate LDS pass over the image and its barrier were 8.6 % of the forward kernel
+    __device__ __forceinline__ void store_rows_off(CT* img, int ld, int tid, float* off, float c2, float half_ln_f) const {
+        static_assert(!ROWFAST && (CH & (CH - 1)) == 0 && CH <= 64 && NTHR % CH == 0, "row pieces must sit in consecutive lanes");
+        store_rows(img, ld, tid);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int it = tid + NTHR * i;
+            float sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) { const float x = to_f32<CT>(r[i][e]); sq += x * x; }
+#pragma unroll
+            for (int o = CH >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+            if (it < ROWS * CH && (it % CH) == 0) off[it / CH] = 0.5f * c2 * sq + half_ln_f;
+        }
+    }
     // transposed image [NC][ld] (k = row index)
     __device__ __forceinline__ void store_T(CT* img, int ld, int tid) const {
 #pragma unroll
