@@ -103,7 +103,7 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
     roof = entry(order[0])
     roof['timing'] = 'HIP events on the launch stream around every GEMM launch in %d real training steps (kernels serialized on one stream)' % n_steps
     roof['rocprof_summary'] = ('profiles/r01_bench_train_rocprof_stats.txt = rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-gen --no-stage1` '
-                               '(training kernels only: this kernel 320.4 us average over 720 launches); profiles/r01_bench_final_rocprof_stats.txt = the full default command, '
+                               '(training kernels only: this kernel 319.5 us average over 720 launches); profiles/r01_bench_final_rocprof_stats.txt = the full default command, '
                                'where the stage-1 and generation legs launch the same kernel instance on small shapes and pull its average down')
     roof['roofline_others'] = [entry(k) for k in order[1:]]
     return roof
