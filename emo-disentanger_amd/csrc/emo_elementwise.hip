@@ -115,11 +115,30 @@ __global__ __launch_bounds__(EB_THREADS) void embed_bwd_kernel(const int64_t* __
                 sg[u] = seg ? seg[m] : 0;
                 g[u] = to_f32<T>(dout[m * D + col]);
             }
+            // rows of this step that carry the same id (wave-uniform scalars: music tokens repeat a lot) are summed in registers first,
+            // so the LDS atomic unit — the bottleneck — sees one add per distinct id
+            float vv[EB_U];
+            bool dead[EB_U];
+#pragma unroll
+            for (int u = 0; u < EB_U; ++u) {
+                vv[u] = (m0 + u < mend) ? g[u] * drop_mult(drop, (uint64_t)((m0 + u) * D + col)) * scale : 0.f;
+                dead[u] = !(m0 + u < mend);
+            }
+            float segv[EB_U];
+#pragma unroll
+            for (int u = 0; u < EB_U; ++u) segv[u] = vv[u];
+#pragma unroll
+            for (int u = EB_U - 1; u > 0; --u) {
+#pragma unroll
+                for (int w = u - 1; w >= 0; --w) {
+                    if (!dead[u] && !dead[w] && tk[u] == tk[w]) { vv[w] += vv[u]; dead[u] = true; }
+                }
+            }
 #pragma unroll
             for (int u = 0; u < EB_U; ++u) {
                 if (m0 + u < mend) {
-                    const float v = g[u] * drop_mult(drop, (uint64_t)((m0 + u) * D + col)) * scale;
-                    atomicAdd(&tab[tk[u] * 64 + lane], v);
+                    const float v = segv[u];
+                    if (!dead[u]) atomicAdd(&tab[tk[u] * 64 + lane], vv[u]);
                     if (seg) {
                         if (seg_regs) { s0 += sg[u] == 0 ? v : 0.f; s1 += sg[u] == 1 ? v : 0.f; }
                         else atomicAdd(&tab[(V + sg[u]) * 64 + lane], v);
