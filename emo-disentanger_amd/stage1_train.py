@@ -58,6 +58,27 @@ def log_epoch(log_file, log_data, init_time, is_init=False):
                                                             round(time.time() - init_time, 2)))
 
 
+def setup_data_parallel(model):
+    """BASELINE configs[4] trains stage 1 data-parallel (the reference itself has no distributed code): one process per GPU, rank 0's weights
+    broadcast once, per-rank dropout streams; every rank iterates its own shard of the batches (the caller's sampler).  Returns (rank, world)."""
+    from . import dp
+    rank, _, world = dp.init_distributed()
+    if world > 1:
+        dp.sync_model_from_rank0(model)
+    return rank, world
+
+
+def _average_gradients(model):
+    """The one exchange of the stage-1 DP step: sum all-reduce of the flat fp32 gradient buffer (the parameters' .grad are views into it),
+    scaled by 1 / world, placed between backward() and the clip so that the clip sees the global gradient (train.py:60-61)."""
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        from . import dp
+        flat = model._ensure_store().flat_grad
+        dp.allreduce_sum_(flat)
+        flat.mul_(1.0 / dist.get_world_size())
+
+
 def train(epoch, model, dloader, optim, sched, pad_token, cfg, state):
     model.train()
     recons_loss_rec, accum_samples = 0., 0
@@ -78,6 +99,7 @@ def train(epoch, model, dloader, optim, sched, pad_token, cfg, state):
             losses = model.compute_loss(dec_logits, dec_target)
             total_acc, chord_acc, melody_acc, others_acc = compute_accuracy(dec_logits.detach(), dec_target, inp_chord, inp_melody, pad_token)
             losses['total_loss'].backward()
+            _average_gradients(model)
             torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)
             optim.step()
             recons_loss_rec += batch_samples['id'].size(0) * losses['ce_loss'].item()

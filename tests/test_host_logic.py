@@ -71,6 +71,17 @@ def _dp_worker(rank, world, port, q):
     params = torch.full((10,), float(rank))
     dp.broadcast_([params])
     mx = dp.max_over_ranks(1.0 + rank, 'cpu')
+    # the stage-1 loop's exchange (stage1_train._average_gradients): mean over ranks of the model's flat gradient buffer
+    from emo_disentanger_amd import stage1_train as s1
+
+    class _Store:
+        flat_grad = torch.full((7,), 1.0 + 2.0 * rank)
+
+    class _Model:
+        def _ensure_store(self):
+            return _Store
+    s1._average_gradients(_Model())
+    assert torch.allclose(_Store.flat_grad, torch.full((7,), 2.0))
     q.put((rank, mine.numpy().copy(), flat.numpy().copy(), params.numpy().copy(), mx))   # by value (tensor FD passing races the exit)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
