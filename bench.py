@@ -76,7 +76,7 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
             rec, ops.GEMM_TIMING = ops.GEMM_TIMING, None
             engine._SIDE['on'] = was
         by = {}
-        for kind, e0, e1, fl, by_ in rec:
+        for kind, e0, e1, fl, by_ in (r[:5] for r in rec):
             d = by.setdefault(kind, {'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'n': 0})
             d['ms'] += e0.elapsed_time(e1); d['flops'] += fl; d['bytes'] += by_; d['n'] += 1
         return by

@@ -77,7 +77,7 @@ def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumu
     if GEMM_TIMING is not None:
         e1.record()
         GEMM_TIMING.append((('T' if a_trans else 'N') + ('N' if b_trans else 'T') + ('/K>1024' if K > 1024 and not a_trans and not b_trans else ''), e0, e1, 2.0 * M * N * K,
-                            (M * K + N * K) * A.element_size() + M * N * out.element_size()))
+                            (M * K + N * K) * A.element_size() + M * N * out.element_size(), (M, N, K)))
     return out
 
 
