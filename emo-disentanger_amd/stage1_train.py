@@ -83,7 +83,7 @@ def train(epoch, model, dloader, optim, sched, pad_token, cfg, state):
     model.train()
     recons_loss_rec, accum_samples = 0., 0
     say = print if cfg.verbose else (lambda *a, **k: None)
-    say('[epoch {:03d}] training ...'.format(epoch))
+    say('[train] epoch %d' % epoch)
     st = time.time()
     dev = next(model.parameters()).device
     for batch_idx, batch_samples in enumerate(dloader):
@@ -112,9 +112,8 @@ def train(epoch, model, dloader, optim, sched, pad_token, cfg, state):
                 lf = os.path.join(cfg.ckpt_dir, cfg.log_file)
                 log_epoch(lf, {'ep': epoch, 'steps': state.train_steps, 'ce_loss': recons_loss_rec / accum_samples, 'time': time.time() - st},
                           state.init_time, is_init=not os.path.exists(lf))
-        say('-- ep {:03d} | batch {:03d}: loss = {:.4f}, total_acc = {:.4f}, chord_acc = {:.4f}, melody_acc = {:.4f}, others_acc = {:.4f}, '
-            'step = {}, time_elapsed = {:.2f} secs'.format(epoch, batch_idx, recons_loss_rec / accum_samples, total_acc, chord_acc, melody_acc, others_acc,
-                                                           state.train_steps, time.time() - st))
+        say('[train] epoch %d batch %d  ce %.4f  acc all/chord/melody/other %.4f %.4f %.4f %.4f  step %d  %.1f s' %
+            (epoch, batch_idx, recons_loss_rec / accum_samples, total_acc, chord_acc, melody_acc, others_acc, state.train_steps, time.time() - st))
     return recons_loss_rec / accum_samples, time.time() - st
 
 
@@ -123,7 +122,7 @@ def validate(epoch, model, dloader, pad_token, rounds=1, verbose=True):
     rec = [[], [], [], [], []]
     dev = next(model.parameters()).device
     if verbose:
-        print('[epoch {:03d}] validating ...'.format(epoch))
+        print('[validate] epoch %d' % epoch)
     with torch.no_grad():
         for r in range(rounds):
             for batch_idx, batch_samples in enumerate(dloader):
