@@ -1856,9 +1856,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             int accumulate) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
+    // four independent partial sums: up to 32 loads per thread, 4 in flight instead of a dependent chain (fixed order: still deterministic)
     f32x4 a = accumulate ? ((const f32x4*)out)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < splits; ++s) a += *(const f32x4*)(ws + s * stride + 4 * i);
-    ((f32x4*)out)[i] = a;
+    f32x4 b = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+    const float* p = ws + 4 * i;
+    int s = 0;
+    for (; s + 4 <= splits; s += 4) {
+        const f32x4 x0 = *(const f32x4*)(p + (int64_t)s * stride), x1 = *(const f32x4*)(p + (int64_t)(s + 1) * stride);
+        const f32x4 x2 = *(const f32x4*)(p + (int64_t)(s + 2) * stride), x3 = *(const f32x4*)(p + (int64_t)(s + 3) * stride);
+        a += x0; b += x1; c += x2; d += x3;
+    }
+    for (; s < splits; ++s) a += *(const f32x4*)(p + (int64_t)s * stride);
+    ((f32x4*)out)[i] = (a + b) + (c + d);
 }
 
 // number of K-splits for a plain fp32-output GEMM (wgrad).  max_ws_splits > 0: partials go to a caller workspace (plain stores +
