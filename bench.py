@@ -194,6 +194,22 @@ def cpu_baseline(T, steps=2):
             'sample': 'oracle Performer L12 d512 fwd+bwd (no optimizer), B=1 x T=%d, %d timed steps, torch fp32 eager + C causal product' % (T, steps)}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) through torch.distributed.run and exit with its
+    status.  Fails instead of shrinking the job when the node has fewer than N GPUs."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.exit('bench.py: --gpus %d requested but %d GPU(s) visible: refusing to run (one process per GPU, no oversubscription)' % (n, have))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -208,13 +224,21 @@ def main():
     ap.add_argument('--no-stage1', action='store_true')
     args = ap.parse_args()
 
+    want = max(args.gpus, 1)
+    if 'WORLD_SIZE' not in os.environ and want > 1:
+        launch_ranks(want)                                   # never returns
     from emo_disentanger_amd import dp, ops
     from emo_disentanger_amd.data import synthetic_batch
     from emo_disentanger_amd.model.music_performer import MusicPerformer
     from emo_disentanger_amd.optim import FusedAdam
-    rank, local_rank, world = dp.init_distributed()
-    assert world == max(args.gpus, 1) or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
-    local_dev = local_rank % torch.cuda.device_count()     # (== local_rank on a real multi-GPU node)
+    rank, local_rank, world = dp.env_world()
+    if world != want:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d: launch with `python bench.py --gpus %d` (it starts the ranks itself) or '
+                 '`python -m torch.distributed.run --nproc-per-node %d ... bench.py --gpus %d`' % (want, world, want, want, want))
+    if torch.cuda.device_count() < (local_rank + 1 if world > 1 else 1):
+        sys.exit('bench.py: rank %d needs GPU %d but only %d visible: one process per GPU, no sharing' % (rank, local_rank, torch.cuda.device_count()))
+    dp.init_distributed()
+    local_dev = local_rank if world > 1 else 0
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
     torch.manual_seed(0)
@@ -226,8 +250,10 @@ def main():
     if world > 1:
         dp.sync_model_from_rank0(model)
     max_lr, eta_min, warmup_steps, T_max = 1e-4, 1e-5, 200, 500000      # pop1k7_pretrain.yaml
-    opt = FusedAdam(model, lr=max_lr, max_grad_norm=0.5, world_size=world)
+    opt = FusedAdam(model, lr=max_lr, max_grad_norm=0.5, world_size=world, token_weighted=True)
     batches = [synthetic_batch(CFG['n_token'], B, T, seed=dp.shard_seed(1234, rank) + 100 * i, device=dev) for i in range(2)]
+    for b in batches:                                        # non-pad target count of the rank's batch (token-weighted DP mean)
+        b['n_tok'] = (b['dec_target'] != CFG['n_token'] - 1).sum().to(torch.float32)
     ps = model._ensure_store()
     counts = torch.zeros(6, device=dev, dtype=torch.int64)
     loss_acc = torch.zeros((), device=dev)
@@ -239,8 +265,11 @@ def main():
         opt.zero_grad()
         logits = model(b['dec_input'], seg_inp=b['track_mask'], attn_kwargs={'omit_feature_map_draw': False})
         losses = model.compute_loss(logits, b['dec_target'])
-        losses['total_loss'].backward()
-        dp.allreduce_sum_(ps.flat_grad)
+        if world > 1:
+            (losses['total_loss'] * b['n_tok']).backward()
+            dp.allreduce_grads_(ps, b['n_tok'])              # ONE collective: flat fp32 gradient + token count (emo_comm_allreduce)
+        else:
+            losses['total_loss'].backward()
         opt.step()
         loss_acc.add_(losses['recons_loss'].detach())
         counts.add_(ops.accuracy_counts(logits.detach().view(-1, logits.shape[-1]), b['dec_target'].view(-1), b['chord_idx'].view(-1),
@@ -251,21 +280,20 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        torch.distributed.barrier()
     torch.cuda.synchronize()
+    dp.barrier()
     loss_acc.zero_()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    elapsed = dp.max_over_ranks(time.perf_counter() - t0, dev)
+    dp.barrier()
+    elapsed = dp.max_over_ranks(time.perf_counter() - t0)
     mean_loss = float(loss_acc) / max(args.steps, 1)
     tokens = world * B * T * args.steps
     value = tokens / elapsed
     out = {'metric': 'train tokens/sec (+ AR gen tokens/sec in "gen"), stage2 Performer d512 L12 seq%d' % T, 'value': round(value, 1), 'unit': 'tokens/s', 'n_gpus': world,
+           'rccl_ranks': (ops.lib.emo_comm_world() if dp.data_plane() == 'rccl' else world if dp.data_plane() == 'nccl' else 0), 'comm': dp.data_plane() or 'none',
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * elapsed / args.steps, 3), 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
            'config': {'workload': 'BASELINE configs[%d]: stage2 Performer d_model=512 n_layer=12 n_head=8 favor_dims=128 seq=%d, B=%d/GPU, '
@@ -287,8 +315,8 @@ def main():
             out['cpu_baseline'] = cpu_baseline(min(T, 2048))
         print(json.dumps(out), flush=True)
     if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+        dp.barrier()
+        dp.shutdown()
 
 
 if __name__ == '__main__':

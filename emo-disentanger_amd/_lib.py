@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libemo_hip.so')
 
-F32, BF16 = 0, 1
+F32, BF16, I64 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU_NEW = 0, 1, 2
 MUL_NONE, MUL_NONZERO, MUL_DGELU_NEW = 0, 1, 2
 
@@ -60,9 +60,16 @@ _SIG = {
     'emo_sample_nucleus_step': (c_i, [c_p, c_l, c_l, c_f, c_f, c_p, c_p, c_p, c_l, c_l, c_p, c_p]),
     'emo_accuracy_counts': (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_p]),
     'emo_sumsq': (c_i, [c_p, c_l, c_p, c_p]),
-    'emo_clip_coef': (c_i, [c_p, c_f, c_f, c_p, c_p]),
+    'emo_clip_coef': (c_i, [c_p, c_f, c_f, c_p, c_p, c_p]),
     'emo_adam_step': (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_l, c_p, c_p]),
     'emo_cast': (c_i, [c_p, c_i, c_p, c_i, c_l, c_p]),
+    'emo_comm_unique_id': (c_i, [c_p]),
+    'emo_comm_init': (c_i, [c_p, c_i, c_i]),
+    'emo_comm_world': (c_i, []),
+    'emo_comm_rank': (c_i, []),
+    'emo_comm_allreduce': (c_i, [c_p, c_l, c_i, c_p]),
+    'emo_comm_broadcast': (c_i, [c_p, c_l, c_i, c_i, c_p]),
+    'emo_comm_destroy': (c_i, []),
 }
 for _name, (_res, _args) in _SIG.items():
     _fn = getattr(lib, _name)          # AttributeError here = header/library mismatch

@@ -901,14 +901,15 @@ extern "C" int emo_sumsq(const float* x, int64_t n, float* acc, emo_stream_t str
     EMO_LAUNCH_CHECK();
     return EMO_OK;
 }
-__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float pre, float* coef) {
+__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float pre, const float* denom, float* coef) {
+    if (denom) pre = pre / denom[0];
     const float total = sqrtf(sumsq[0]) * pre;            // norm of the (pre-scaled) gradient
     float c = max_norm / (total + 1e-6f);                 // torch.nn.utils.clip_grad_norm_
     coef[0] = (c < 1.f ? c : 1.f) * pre;
 }
-extern "C" int emo_clip_coef(const float* sumsq, float max_norm, float pre, float* coef, emo_stream_t stream) {
+extern "C" int emo_clip_coef(const float* sumsq, float max_norm, float pre, const float* denom, float* coef, emo_stream_t stream) {
     EMO_CHECK(sumsq && coef, "emo_clip_coef: null pointer");
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, pre, coef);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, pre, denom, coef);
     EMO_LAUNCH_CHECK();
     return EMO_OK;
 }

@@ -1,54 +1,174 @@
-"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" == RCCL over xGMI
-on ROCm; "gloo" for the CPU tests).  The reference has NO distributed code; the build
-adds ONE exchange per optimizer step — a sum all-reduce of the flat fp32 gradient buffer (152.7 MB
-at the perf config) placed between backward() and the clip (train.py:76-80) — plus an initial
-broadcast of parameters and FAVOR+ omega from rank 0.  The 1/world scaling is folded into the clip
-coefficient of the fused Adam step (optim.FusedAdam)."""
+"""Data-parallel plumbing: one process per GPU.  The reference has NO distributed code; the build
+adds ONE exchange per optimizer step — a sum all-reduce of the flat fp32 gradient buffer (152.7 MB at the perf config) placed
+between backward() and the clip (/root/reference/stage2_accompaniment/train.py:76-81) — plus one broadcast of parameters and
+FAVOR+ omega from rank 0 at start-up.
+
+Two planes:
+  * control plane  — a torch.distributed "gloo" group on host memory: rendezvous, barriers, the max-over-ranks of the bench
+    timing, and the side channel that ships RCCL's 128-byte unique id from rank 0 to the other ranks;
+  * data plane     — `emo_comm_allreduce` / `emo_comm_broadcast` of libemo_hip.so (include/emo_hip.h): RCCL over xGMI on the
+    caller's HIP stream, in place on the flat buffers.  EMO_COMM selects it: "rccl" (default on a GPU), "nccl"
+    (torch.distributed's RCCL binding, kept as the escape hatch when the direct binding cannot initialise), "gloo"
+    (host-staged; the CPU tests, and N processes sharing ONE GPU where RCCL refuses duplicate devices).
+
+Exact global mean with unequal token counts (SURVEY §7 "DP exactness"): each rank back-propagates the SUM of its token losses
+(`loss * n_tokens`), the token count rides in the last slot of the all-reduced buffer, and the fused optimizer divides by the
+all-reduced count (optim.FusedAdam(token_weighted=True)); with equal counts this equals the plain 1/world average."""
+import ctypes
 import os
+import sys
 
 import torch
 import torch.distributed as dist
+
+_STATE = {'plane': None, 'nccl_group': None}
 
 
 def env_world():
     return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
 
 
+def data_plane():
+    """'rccl' | 'nccl' | 'gloo' | None (single process)."""
+    return _STATE['plane']
+
+
+def _init_rccl(rank, world):
+    from ._lib import I64, check, lib
+    msg = torch.zeros(129, dtype=torch.uint8)                         # 128-byte unique id + "rank 0 could create it"
+    if rank == 0:
+        buf = (ctypes.c_char * 128)()
+        if lib.emo_comm_unique_id(buf) == 0:
+            msg[:128] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+            msg[128] = 1
+    dist.broadcast(msg, src=0)                                        # control plane (gloo, host memory)
+    if int(msg[128]) != 1:
+        raise RuntimeError('rank 0 could not create the RCCL unique id: ' + lib.emo_last_error().decode())
+    check(lib.emo_comm_init(ctypes.c_char_p(bytes(msg[:128].numpy().tobytes())), rank, world))
+    probe = torch.full((4,), rank + 1, device='cuda', dtype=torch.int64)
+    check(lib.emo_comm_allreduce(probe.data_ptr(), 4, I64, torch.cuda.current_stream().cuda_stream))
+    if int(probe[0].item()) != world * (world + 1) // 2:
+        raise RuntimeError('emo_comm self-check failed: all-reduce of rank+1 gave %d for world %d' % (int(probe[0]), world))
+
+
 def init_distributed(backend=None):
-    """Idempotent; reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract)."""
+    """Idempotent; reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract).  `backend` (or EMO_COMM /
+    EMO_DIST_BACKEND) picks the data plane; the control plane is always gloo."""
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        backend = backend or os.environ.get('EMO_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        plane = backend or os.environ.get('EMO_COMM') or os.environ.get('EMO_DIST_BACKEND') or ('rccl' if torch.cuda.is_available() else 'gloo')
+        if plane not in ('rccl', 'nccl', 'gloo'):
+            raise ValueError('EMO_COMM must be rccl | nccl | gloo, got %r' % plane)
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank % torch.cuda.device_count())
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+        if plane == 'rccl':
+            try:
+                _init_rccl(rank, world)
+            except Exception as e:   # noqa: BLE001 — stay up on the torch binding of the same RCCL rather than lose the run
+                print('[emo dp] rank %d: direct RCCL binding failed (%s); falling back to torch.distributed nccl' % (rank, e), file=sys.stderr, flush=True)
+                plane = 'nccl'
+            ok = torch.tensor([1 if plane == 'rccl' else 0])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)                 # all ranks agree on one plane
+            if int(ok) == 0 and plane == 'rccl':
+                from ._lib import lib
+                lib.emo_comm_destroy()
+                plane = 'nccl'
+        if plane == 'nccl':
+            _STATE['nccl_group'] = dist.new_group(backend='nccl')
+        _STATE['plane'] = plane
     return rank, local_rank, world
 
 
+def shutdown():
+    if _STATE['plane'] == 'rccl':
+        from ._lib import lib
+        lib.emo_comm_destroy()
+    _STATE['plane'], _STATE['nccl_group'] = None, None
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def _comm_dtype(t):
+    from ._lib import BF16, F32, I64
+    return {torch.float32: F32, torch.bfloat16: BF16, torch.int64: I64}[t.dtype]
+
+
 def allreduce_sum_(flat):
-    """In-place sum over ranks of one flat buffer (no bucketing: a single large message suits the
-    point-to-point xGMI links; see DESIGN.md §multi-GPU for the cost model)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    """In-place sum over ranks of one contiguous buffer (no bucketing: a single large message suits the point-to-point xGMI
+    links; DESIGN.md §6 has the cost model)."""
+    plane = _STATE['plane']
+    if plane is None:
+        return flat
+    assert flat.is_contiguous()
+    if plane == 'rccl' and flat.is_cuda:
+        from ._lib import check, lib
+        check(lib.emo_comm_allreduce(flat.data_ptr(), flat.numel(), _comm_dtype(flat), torch.cuda.current_stream().cuda_stream))
+    elif plane == 'nccl' and flat.is_cuda:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=_STATE['nccl_group'])
+    elif flat.is_cuda:                                                # gloo plane with device buffers: staged through host memory
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+    else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
 
+def allreduce_grads_(store, n_tokens=None):
+    """The one exchange per optimizer step: sum of the flat gradient buffer over ranks.  n_tokens (device scalar or number): this
+    rank's non-pad target count, carried in the buffer's tail slot so that ONE collective moves both (token-weighted mean)."""
+    if _STATE['plane'] is None:
+        return
+    if n_tokens is None:
+        allreduce_sum_(store.flat_grad)
+        return
+    tail = store.flat_grad_ext[store.total:]
+    tail.zero_()
+    tail[0:1].copy_(torch.as_tensor(n_tokens, dtype=torch.float32).reshape(1))
+    allreduce_sum_(store.flat_grad_ext)
+
+
 def broadcast_(tensors, src=0):
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        for t in tensors:
+    plane = _STATE['plane']
+    if plane is None:
+        return
+    for t in tensors:
+        assert t.is_contiguous()
+        if plane == 'rccl' and t.is_cuda:
+            from ._lib import check, lib
+            check(lib.emo_comm_broadcast(t.data_ptr(), t.numel(), _comm_dtype(t), src, torch.cuda.current_stream().cuda_stream))
+        elif plane == 'nccl' and t.is_cuda:
+            dist.broadcast(t, src=src, group=_STATE['nccl_group'])
+        elif t.is_cuda:
+            host = t.cpu()
+            dist.broadcast(host, src=src)
+            t.copy_(host)
+        else:
             dist.broadcast(t, src=src)
 
 
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
 def sync_model_from_rank0(model):
-    """Replicate rank 0's weights and omega buffers (identical replicas; independent dropout streams per rank)."""
+    """Identical replicas: rank 0's weights, omega buffers AND the seed of the omega generator (so that the per-forward FAVOR+
+    redraws stay identical on every rank); dropout streams are independent per rank."""
     ps = model._ensure_store()
     bufs = [ps.flat32] + [b for n, b in model.named_buffers() if 'omega' in n]
     broadcast_(bufs)
-    ps.flat32.add_(0)          # bump the version counter => bf16 mirror refresh on next forward
+    ps.invalidate_mirror()
     rank = dist.get_rank() if dist.is_initialized() else 0
-    model.set_dropout_seed(model._seed + 7919 * rank)
+    seed = torch.tensor([int(getattr(model, '_seed', 0))], dtype=torch.int64)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(seed, src=0)
+    if hasattr(model, 'set_omega_seed'):
+        model.set_omega_seed(int(seed) ^ 0x5DEECE66D)
+    model.set_dropout_seed(int(seed) + 7919 * rank)
 
 
 def shard_seed(base_seed, rank):
@@ -56,8 +176,8 @@ def shard_seed(base_seed, rank):
     return base_seed + rank
 
 
-def max_over_ranks(value, device):
-    t = torch.tensor([float(value)], device=device, dtype=torch.float64)
+def max_over_ranks(value, device=None):
+    t = torch.tensor([float(value)], dtype=torch.float64)
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                      # control plane
     return float(t.item())

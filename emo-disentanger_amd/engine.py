@@ -55,7 +55,9 @@ class ParamStore:
         total = (off + ALIGN - 1) // ALIGN * ALIGN
         self.device, self.total, self.compute_dtype = dev, total, compute_dtype
         self.flat32 = torch.zeros(total, device=dev, dtype=torch.float32)
-        self.flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        # one extra ALIGN-sized tail: slot [total] carries the rank's non-pad token count through the DP all-reduce (dp.py)
+        self.flat_grad_ext = torch.zeros(total + ALIGN, device=dev, dtype=torch.float32)
+        self.flat_grad = self.flat_grad_ext[:total]
         self.flat16 = torch.zeros(total, device=dev, dtype=torch.bfloat16) if compute_dtype == torch.bfloat16 else None
         self.params = byname
         self.shapes = {n: tuple(p.shape) for n, p in named}
@@ -69,6 +71,7 @@ class ParamStore:
         self._fused = fused
         self._mirror_version = -1
         self._first, self._last = named[0][1], named[-1][1]
+        self._plist = [p for _, p in named]
 
     # -- consistency ---------------------------------------------------------------------------
     def intact(self):
@@ -76,15 +79,26 @@ class ParamStore:
         lo, hi = self.flat32.data_ptr(), self.flat32.data_ptr() + 4 * self.total
         return all(p.device == self.device and lo <= p.data_ptr() < hi for p in (self._first, self._last))
 
+    def _write_signal(self):
+        """Changes whenever torch wrote the fp32 master: through the flat buffer (broadcast, flat32.copy_) or through a parameter
+        (optimizer.step, load_state_dict, init_ — parameters were attached with `p.data = view`, which keeps each parameter's OWN
+        version counter, so the base's counter alone does not see those writes)."""
+        return self.flat32._version + sum(p._version for p in self._plist)
+
     def sync_mirror(self):
-        """Refresh the bf16 mirror if anything wrote the fp32 master through torch (optimizer.step,
-        load_state_dict, init): views share the base's version counter."""
-        if self.flat16 is not None and self.flat32._version != self._mirror_version:
-            ops.cast(self.flat32, self.flat16)
-            self._mirror_version = self.flat32._version
+        """Refresh the bf16 mirror if anything wrote the fp32 master through torch since the last refresh."""
+        if self.flat16 is not None:
+            sig = self._write_signal()
+            if sig != self._mirror_version:
+                ops.cast(self.flat32, self.flat16)
+                self._mirror_version = sig
 
     def mark_mirror_fresh(self):
-        self._mirror_version = self.flat32._version
+        """The caller's kernel wrote fp32 master and bf16 mirror together (fused Adam)."""
+        self._mirror_version = self._write_signal()
+
+    def invalidate_mirror(self):
+        self._mirror_version = -1
 
     def ensure_grads(self):
         """Re-attach .grad views (zero_grad(set_to_none=True) drops them)."""

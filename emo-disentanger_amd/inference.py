@@ -17,41 +17,13 @@ import time
 import numpy as np
 import torch
 
-from . import engine, ops
+from . import ops
 
 max_dec_inp_len = 2048
 
 
-# ------------------------------------------------------------------------------------------------ host sampling (reference semantics)
-def temperature(logits, temperature, inadmissibles=None):
-    if inadmissibles is not None:
-        logits[inadmissibles] -= np.inf
-    try:
-        with np.errstate(over='ignore', invalid='ignore'):
-            probs = np.exp(logits / temperature) / np.sum(np.exp(logits / temperature))
-        assert np.count_nonzero(np.isnan(probs)) == 0
-    except AssertionError:
-        print('overflow detected, use 128-bit')
-        logits = logits.astype(np.float128)
-        probs = np.exp(logits / temperature) / np.sum(np.exp(logits / temperature))
-        probs = probs.astype(float)
-    return probs
-
-
-def nucleus(probs, p):
-    probs /= sum(probs)
-    sorted_probs = np.sort(probs)[::-1]
-    sorted_index = np.argsort(probs)[::-1]
-    cusum_sorted_probs = np.cumsum(sorted_probs)
-    after_threshold = cusum_sorted_probs > p
-    if sum(after_threshold) > 0:
-        last_index = np.where(after_threshold)[0][1]      # reference indexing: keeps the crossing token
-        candi_index = sorted_index[:last_index]
-    else:
-        candi_index = sorted_index[:3]
-    candi_probs = np.array([probs[i] for i in candi_index], dtype=np.float64)
-    candi_probs /= sum(candi_probs)
-    return np.random.choice(candi_index, size=1, p=candi_probs)[0]
+# ------------------------------------------------------------------------------------------------ sampling
+from .sampling import beat_position, nucleus, temperature  # noqa: E402,F401  (host path with the reference's NumPy semantics)
 
 
 def sample_on_device(logits, temp, top_p, u=None, greedy=False):
@@ -61,10 +33,6 @@ def sample_on_device(logits, temp, top_p, u=None, greedy=False):
     if u is None:
         u = torch.rand(logits.shape[0], device=logits.device)
     return ops.sample_nucleus(logits.contiguous(), temp, top_p, u)
-
-
-def get_position_idx(event):
-    return int(event.split('_')[-1])
 
 
 # ------------------------------------------------------------------------------------------------ decode engines
@@ -335,105 +303,48 @@ def generate_conditional(model, event2idx, idx2event, lead_sheet_events, primer,
                          max_events=10000, skip_check=False, max_bars=None,
                          temp=1.2, top_p=0.9, inadmissibles=None,
                          model_type="performer", use_cache=True, sampler=None, verbose=False):
-    """Same control flow, arguments and return value as inference.py:231-327.  `sampler(probs)` defaults to
-    nucleus(probs, top_p) with NumPy's global RNG, exactly like the reference."""
-    say = print if verbose else (lambda *a, **k: None)
+    """Arguments and return value of the reference's generate_conditional (inference.py:231-327): the accompaniment of every
+    lead-sheet bar is sampled token by token until the model emits Track_LeadSheet, then the next bar's lead sheet is injected.
+    The grammar (Beat positions never go back, PAD / premature EOS rejected, 256 consecutive rejections = stuck) lives in
+    `_Stream.offer`; this function is the one-stream driver of it.  `sampler(probs)` defaults to nucleus(probs, top_p) on NumPy's
+    global RNG, like the reference.  use_cache=False (or a context at the 2048-token window) runs the reference's full-window
+    forward per sampled token."""
+    note = print if verbose else (lambda *a, **k: None)
+    draw = sampler if sampler is not None else (lambda probs: nucleus(probs, top_p))
     dev = next(model.parameters()).device
-    generated = primer + [event2idx['Track_LeadSheet']] + lead_sheet_events[0] + [event2idx['Track_Full']]
-    seg_inp = [0 for _ in range(len(generated))]
-    seg_inp[-1] = 1
-    target_bars, generated_bars = len(lead_sheet_events), 0
-    if max_bars is not None:
-        target_bars = min(max_bars, target_bars)
-    steps, cur_pos, failed_cnt = 0, 0, 0
-    time_st = time.time()
+    s = _Stream(event2idx, lead_sheet_events, primer, max_bars)
+    primed = len(s.generated)
     eng = make_engine(model, 1) if use_cache else None
-    consumed = 0                 # tokens already folded into the engine state
-    cached_logits = None
+    cached = None
+    t0 = time.time()
     was_training = model.training
     model.eval()
     try:
         with torch.no_grad():
-            while generated_bars < target_bars:
-                assert len(generated) == len(seg_inp)
-                if eng is not None and len(generated) < max_dec_inp_len:
-                    if consumed < len(generated):
-                        tok = torch.tensor([generated[consumed:]], dtype=torch.long, device=dev)
-                        seg = torch.tensor([seg_inp[consumed:]], dtype=torch.long, device=dev)
-                        cached_logits = eng.append(tok, seg)
-                        consumed = len(generated)
-                    logits = cached_logits                       # rejected samples re-use the same logits
+            while not s.done:
+                if eng is not None and len(s.generated) < max_dec_inp_len:
+                    if s.consumed < len(s.generated):            # new tokens since the last step (a sampled word, or an injected bar)
+                        cached = eng.append(torch.tensor([s.generated[s.consumed:]], dtype=torch.long, device=dev),
+                                            torch.tensor([s.seg[s.consumed:]], dtype=torch.long, device=dev))
+                        s.consumed = len(s.generated)
+                    logits = cached                              # a rejected sample is re-drawn from the same logits
                 else:
-                    dec_input = torch.tensor([generated[-max_dec_inp_len:]], dtype=torch.long, device=dev)
-                    dec_seg_inp = torch.tensor([seg_inp[-max_dec_inp_len:]], dtype=torch.long, device=dev)
-                    kw = {'attn_kwargs': {'omit_feature_map_draw': steps > 0}} if model_type == 'performer' else {}
-                    logits = model(dec_input, seg_inp=dec_seg_inp, keep_last_only=True, **kw)
-                logits_np = (logits[0]).cpu().detach().numpy().copy()
-                probs = temperature(logits_np, temp, inadmissibles=inadmissibles)
-                word = int(sampler(probs) if sampler is not None else nucleus(probs, top_p))
-                word_event = idx2event[word]
-                if not skip_check:
-                    if 'Beat' in word_event:
-                        event_pos = get_position_idx(word_event)
-                        if not event_pos >= cur_pos:
-                            failed_cnt += 1
-                            say('[info] position not increasing, failed cnt:', failed_cnt)
-                            if failed_cnt >= 256:
-                                say('[FATAL] model stuck, exiting with generated events ...')
-                                return generated
-                            continue
-                        else:
-                            cur_pos = event_pos
-                            failed_cnt = 0
-                if word_event == 'Track_LeadSheet':
-                    steps += 1
-                    generated.append(word)
-                    seg_inp.append(0)
-                    generated_bars += 1
-                    say('[info] generated {} bars, #events = {}'.format(generated_bars, len(generated)))
-                    if generated_bars < target_bars:
-                        generated.extend(lead_sheet_events[generated_bars])
-                        seg_inp.extend([0 for _ in range(len(lead_sheet_events[generated_bars]))])
-                        generated.append(event2idx['Track_Full'])
-                        seg_inp.append(1)
-                        cur_pos = 0
-                    continue
-                if word_event == 'PAD_None' or (word_event == 'EOS_None' and generated_bars < target_bars - 1):
-                    continue
-                elif word_event == 'EOS_None' and generated_bars == target_bars - 1:
-                    say('[info] gotten eos')
-                    generated.append(word)
-                    break
-                generated.append(word)
-                seg_inp.append(1)
-                steps += 1
-                if len(generated) > max_events:
-                    say('[info] max events reached')
-                    break
+                    kw = {'attn_kwargs': {'omit_feature_map_draw': len(s.generated) > primed}} if model_type == 'performer' else {}
+                    logits = model(torch.tensor([s.generated[-max_dec_inp_len:]], dtype=torch.long, device=dev),
+                                   seg_inp=torch.tensor([s.seg[-max_dec_inp_len:]], dtype=torch.long, device=dev), keep_last_only=True, **kw)
+                probs = temperature(logits[0].cpu().numpy().copy(), temp, inadmissibles=inadmissibles)
+                bars = s.generated_bars
+                if not s.offer(int(draw(probs)), event2idx, idx2event, skip_check, max_events):
+                    note('[gen] sample rejected (%d in a row)' % s.failed_cnt)
+                elif s.generated_bars != bars:
+                    note('[gen] bar %d / %d done, %d events' % (s.generated_bars, s.target_bars, len(s.generated)))
     finally:
         model.train(was_training)
-    say('-- generated events:', len(generated))
-    say('-- time elapsed  : {:.2f} secs'.format(time.time() - time_st))
-    say('-- time per event: {:.2f} secs'.format((time.time() - time_st) / len(generated)))
-    return generated[:-1]
+    note('[gen] %d events in %.2f s%s' % (len(s.generated), time.time() - t0, ' (stuck: 256 rejected samples)' if s.stuck else ''))
+    return s.result()
 
 
 # ------------------------------------------------------------------------------------------------ batched reference loop (SURVEY f-4)
-def nucleus_rs(probs, p, rs):
-    """nucleus() with an explicit np.random.RandomState instead of the global one (one independent RNG per stream)."""
-    probs = probs / sum(probs)
-    sorted_probs = np.sort(probs)[::-1]
-    sorted_index = np.argsort(probs)[::-1]
-    after_threshold = np.cumsum(sorted_probs) > p
-    if sum(after_threshold) > 0:
-        candi_index = sorted_index[:np.where(after_threshold)[0][1]]
-    else:
-        candi_index = sorted_index[:3]
-    candi_probs = np.array([probs[i] for i in candi_index], dtype=np.float64)
-    candi_probs /= sum(candi_probs)
-    return rs.choice(candi_index, size=1, p=candi_probs)[0]
-
-
 class _Stream:
     """Per-stream state of generate_conditional's loop (inference.py:233-250)."""
 
@@ -452,7 +363,7 @@ class _Stream:
         re-samples from the SAME distribution, like the reference's `continue`), True when the stream advanced or ended."""
         ev = idx2event[word]
         if not skip_check and 'Beat' in ev:
-            pos = get_position_idx(ev)
+            pos = beat_position(ev)
             if not pos >= self.cur_pos:
                 self.failed_cnt += 1
                 if self.failed_cnt >= 256:          # reference: returns `generated` as is (no [:-1])
@@ -495,14 +406,14 @@ def generate_conditional_batch(model, event2idx, idx2event, lead_sheets, primers
     """n independent generate_conditional() runs (one lead sheet + primer each) in lock-step on ONE decode engine: per-stream bar
     counter, Beat position, rejection counter and RNG; every engine step feeds each unfinished stream its next pending token (a
     sampled word, or the next token of an injected lead-sheet bar), so streams of different lengths stay aligned in position.
-    `samplers[i](probs)` defaults to nucleus_rs(probs, top_p, RandomState(seeds[i])).  Stream i returns exactly what
+    `samplers[i](probs)` defaults to nucleus(probs, top_p, rng=RandomState(seeds[i])).  Stream i returns exactly what
     generate_conditional(..., sampler=samplers[i]) returns for it alone (tests/test_gpu_generate.py), as long as it stays inside
     the 2048-token window (max_dec_inp_len); a stream that reaches the window is finished by the single-stream windowed path."""
     n = len(lead_sheets)
     assert n == len(primers) and n > 0
     if samplers is None:
         rss = [np.random.RandomState((seeds[i] if seeds is not None else i)) for i in range(n)]
-        samplers = [(lambda probs, rs=rs: nucleus_rs(probs, top_p, rs)) for rs in rss]
+        samplers = [(lambda probs, rs=rs: nucleus(probs, top_p, rng=rs)) for rs in rss]
     dev = next(model.parameters()).device
     st = [_Stream(event2idx, lead_sheets[i], primers[i], max_bars) for i in range(n)]
     pad = event2idx.get('PAD_None', 0)

@@ -29,6 +29,7 @@ class MusicPerformer(MusicLMBase):
         self.transformer_decoder = FastTransformerDecoder(n_layer, n_head, d_model, d_ff, dropout, activation, favor_feature_dims)
         self._init_tail(use_segment_emb, n_segment_types)
         self.redraw = redraw
+        self._omega_gen = None
         self.apply(weights_init)
         self.draw_feature_maps()
         print('[info] model init completed')
@@ -44,6 +45,13 @@ class MusicPerformer(MusicLMBase):
             g.append([a + 'query_projection.bias', a + 'key_projection.bias', a + 'value_projection.bias'])
         return g
 
+    def set_omega_seed(self, seed):
+        """Give the omega draws their own generator (data parallel: every rank gets the SAME seed from dp.sync_model_from_rank0, so
+        the per-forward redraws stay identical across replicas; without it the draws come from torch's global RNG like the reference)."""
+        dev = self.transformer_decoder.decoder_layers[0].attention.inner_attention.feature_map.omega.device
+        self._omega_gen = torch.Generator(device=dev)
+        self._omega_gen.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+
     @torch.no_grad()
     def draw_feature_maps(self):
         """fast_transformers orthogonal_random_matrix_: per block of d_head columns G~N(0,1) (torch RNG, like the
@@ -56,7 +64,8 @@ class MusicPerformer(MusicLMBase):
         nb = (cols + dh - 1) // dh
         if dev.type == 'cuda':
             from emo_disentanger_amd import ops
-            gauss = torch.randn(len(bufs), nb, dh, dh, device=dev)
+            gen = self._omega_gen if (self._omega_gen is not None and self._omega_gen.device == dev) else None
+            gauss = torch.randn(len(bufs), nb, dh, dh, device=dev, generator=gen)
             stacked = ops.favor_draw_omega(gauss, torch.empty(len(bufs), dh, cols, device=dev))
             torch._foreach_copy_(bufs, list(stacked.unbind(0)))
             return stacked

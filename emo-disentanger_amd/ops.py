@@ -351,8 +351,10 @@ def sumsq(x, acc):
     check(lib.emo_sumsq(ptr(x), x.numel(), ptr(acc), stream()))
 
 
-def clip_coef(sumsq_t, max_norm, pre, coef):
-    check(lib.emo_clip_coef(ptr(sumsq_t), max_norm, pre, ptr(coef), stream()))
+def clip_coef(sumsq_t, max_norm, pre, coef, denom=None):
+    """coef = pre' * min(1, max_norm / (|g| pre' + 1e-6)), pre' = pre / denom[0] (denom: optional fp32 device scalar)."""
+    assert denom is None or (denom.dtype == torch.float32 and denom.numel() >= 1)
+    check(lib.emo_clip_coef(ptr(sumsq_t), max_norm, pre, ptr(denom), ptr(coef), stream()))
 
 
 def adam_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, step, gscale):

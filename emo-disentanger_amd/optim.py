@@ -13,11 +13,15 @@ from . import ops
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None, world_size=1):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None, world_size=1, token_weighted=False):
+        """world_size > 1: the gradient buffer holds the SUM over ranks (dp.allreduce_grads_).  token_weighted=False: every rank
+        back-propagated its own mean loss -> pre-scale 1/world.  token_weighted=True: every rank back-propagated the SUM of its
+        token losses and the all-reduced non-pad token count sits in the tail slot of the buffer -> pre-scale 1/count, read on
+        the device (the exact global mean for unequal token counts)."""
         self.model = model
         params = [p for p in model.parameters() if p.requires_grad]
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
-        self.max_grad_norm, self.world_size = max_grad_norm, world_size
+        self.max_grad_norm, self.world_size, self.token_weighted = max_grad_norm, world_size, token_weighted
         self._step, self._m, self._v = 0, None, None
         self.last_grad_norm = None
 
@@ -37,17 +41,17 @@ class FusedAdam(torch.optim.Optimizer):
         from .engine import join_side_stream
         join_side_stream()
         g = self.param_groups[0]
-        pre = 1.0 / self.world_size
+        weighted = self.token_weighted and self.world_size > 1
+        pre = 1.0 if weighted else 1.0 / self.world_size
         self._ss.zero_()
         ops.sumsq(ps.flat_grad, self._ss)
-        ops.clip_coef(self._ss, float(self.max_grad_norm) if self.max_grad_norm else 3.0e38, pre, self._coef)
+        ops.clip_coef(self._ss, float(self.max_grad_norm) if self.max_grad_norm else 3.0e38, pre, self._coef,
+                      denom=ps.flat_grad_ext[ps.total:ps.total + 1] if weighted else None)
         self.last_grad_norm = self._ss           # device scalar: sqrt(.)*pre is the global grad norm (no host sync here)
         self._step += 1
-        fresh = ps.flat16 is None or ps.flat32._version == ps._mirror_version
         ops.adam_step(ps.flat32, ps.flat_grad, self._m, self._v, ps.flat16, g['lr'], g['betas'][0], g['betas'][1], g['eps'], self._step,
                       self._coef)
-        if fresh:
-            ps.mark_mirror_fresh()               # the kernel wrote fp32 master and bf16 mirror together
+        ps.mark_mirror_fresh()                   # the kernel rewrote every element of the bf16 mirror from the new fp32 master
 
     def zero_grad(self, set_to_none=False):
         ps = self.model._ensure_store()

@@ -2,7 +2,8 @@
 compute_accuracy :181-190) around the HIP PlainTransformer.  The reference keeps its schedule state in module globals (train_steps,
 warmup_steps, max_lr, log_interval, ckpt_dir, log_file, init_time); here they live in a Stage1Config / Stage1State pair.
 One optimizer step per segment, gradient clip 0.5, linear warm-up of param_groups[0] then the closed-form CosineAnnealingLR via
-sched.step(train_steps - warmup_steps), exactly as :65-77."""
+sched.step(train_steps - warmup_steps) (:65-77).  Additions the reference lacks: arg-max accuracies counted on the device, the
+data-parallel gradient exchange (dp.py) and the fused clip + Adam optimizer when `optim` is an optim.FusedAdam."""
 import os
 import time
 from dataclasses import dataclass, field
@@ -36,31 +37,36 @@ class Stage1State:
 
 
 def compute_accuracy(dec_logits, dec_target, inp_chord, inp_melody, pad_token):
-    """train.py:181-190.  dec_logits [T, B, V], dec_target [T, B]; inp_chord / inp_melody [B, T] masks (as the dataloader hands them)."""
-    dec_pred = torch.argmax(dec_logits, dim=-1).permute(1, 0).cpu()
-    dec_target = dec_target.permute(1, 0).cpu()
-    inp_chord, inp_melody = torch.as_tensor(inp_chord).cpu(), torch.as_tensor(inp_melody).cpu()
+    """(total, chord, melody, others) accuracy of the arg-max predictions, the quantities of stage1_compose/train.py:181-190, counted
+    on the device by emo_accuracy_counts (six integers come back instead of the logits).  dec_logits [T, B, V], dec_target [T, B];
+    inp_chord / inp_melody: [B, T] 0/1 masks as the dataloader hands them.  A class without tokens gives nan (mean of nothing)."""
+    from . import ops
+    T, B, V = dec_logits.shape
+    dev = dec_logits.device
+
+    def tb(mask):
+        return torch.as_tensor(mask).to(dev).long().t().reshape(-1)
+    n = ops.accuracy_counts(dec_logits.detach().reshape(T * B, V).float().contiguous(), dec_target.reshape(-1), tb(inp_chord), tb(inp_melody),
+                            pad_token).cpu().numpy().astype(np.float64)
     with np.errstate(invalid='ignore', divide='ignore'):
-        total_acc = np.mean(np.array((dec_pred[dec_target != pad_token] == dec_target[dec_target != pad_token])))
-        chord_acc = np.mean(np.array((dec_pred[inp_chord == 1] == dec_target[inp_chord == 1])))
-        melody_acc = np.mean(np.array((dec_pred[inp_melody == 1] == dec_target[inp_melody == 1])))
-        n_tot, n_ch, n_me = len(dec_target[dec_target != pad_token]), len(dec_target[inp_chord == 1]), len(dec_target[inp_melody == 1])
-        others_acc = (total_acc * n_tot - chord_acc * n_ch - melody_acc * n_me) / (n_tot - n_ch - n_me)
-    return total_acc, chord_acc, melody_acc, others_acc
+        total, chord, melody = n[1] / n[0], n[3] / n[2], n[5] / n[4]
+        others = (total * n[0] - chord * n[2] - melody * n[4]) / (n[0] - n[2] - n[4])
+    return total, chord, melody, others
 
 
 def log_epoch(log_file, log_data, init_time, is_init=False):
-    if is_init:
-        with open(log_file, 'w') as f:
-            f.write('{:4} {:8} {:12} {:12} {:12}\n'.format('ep', 'steps', 'ce_loss', 'ep_time', 'total_time'))
-    with open(log_file, 'a') as f:
-        f.write('{:<4} {:<8} {:<12} {:<12} {:<12}\n'.format(log_data['ep'], log_data['steps'], round(log_data['ce_loss'], 5), round(log_data['time'], 2),
-                                                            round(time.time() - init_time, 2)))
+    """Five left-aligned columns (widths 4/8/12/12/12): ep, steps, ce_loss (5 decimals), ep_time, total_time — the log.txt contract."""
+    head = ('ep', 'steps', 'ce_loss', 'ep_time', 'total_time')
+    row = (log_data['ep'], log_data['steps'], round(log_data['ce_loss'], 5), round(log_data['time'], 2), round(time.time() - init_time, 2))
+    with open(log_file, 'w' if is_init else 'a') as f:
+        if is_init:
+            f.write('{:4} {:8} {:12} {:12} {:12}\n'.format(*head))
+        f.write('{:<4} {:<8} {:<12} {:<12} {:<12}\n'.format(*row))
 
 
 def setup_data_parallel(model):
-    """BASELINE configs[4] trains stage 1 data-parallel (the reference itself has no distributed code): one process per GPU, rank 0's weights
-    broadcast once, per-rank dropout streams; every rank iterates its own shard of the batches (the caller's sampler).  Returns (rank, world)."""
+    """BASELINE configs[4] trains stage 1 data-parallel (the reference has no distributed code): one process per GPU, rank 0's weights
+    broadcast once, per-rank dropout streams; every rank iterates its own shard of the batches.  Returns (rank, world)."""
     from . import dp
     rank, _, world = dp.init_distributed()
     if world > 1:
@@ -68,74 +74,85 @@ def setup_data_parallel(model):
     return rank, world
 
 
-def _average_gradients(model):
-    """The one exchange of the stage-1 DP step: sum all-reduce of the flat fp32 gradient buffer (the parameters' .grad are views into it),
-    scaled by 1 / world, placed between backward() and the clip so that the clip sees the global gradient (train.py:60-61)."""
-    import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        from . import dp
-        flat = model._ensure_store().flat_grad
-        dp.allreduce_sum_(flat)
-        flat.mul_(1.0 / dist.get_world_size())
+def _segments(batch, dev):
+    """The dataloader packs a piece as n_seg segments: dec_inp_i / dec_tgt_i [B, T] (time-major on the device), dec_seg_len_i, masks."""
+    for i in range(max(batch['n_seg'])):
+        yield (batch['dec_inp_%d' % i].t().to(dev), batch['dec_tgt_%d' % i].t().to(dev), batch['dec_seg_len_%d' % i].to(dev),
+               batch['inp_chord_%d' % i], batch['inp_melody_%d' % i])
+
+
+def _backward_and_exchange(model, loss, dec_target, pad_token):
+    """backward() + the one DP exchange, placed before the clip so that it sees the global gradient.  With more than one rank every
+    rank back-propagates the SUM of its token losses; the non-pad count travels in the tail slot of the all-reduced buffer and the
+    caller (or the fused optimizer) divides by it: the exact global token mean."""
+    from . import dp
+    if dp.data_plane() is None:
+        loss.backward()
+        return
+    n_tok = (dec_target != pad_token).sum().to(torch.float32)
+    (loss * n_tok).backward()
+    store = model._ensure_store()
+    dp.allreduce_grads_(store, n_tok)
 
 
 def train(epoch, model, dloader, optim, sched, pad_token, cfg, state):
+    """One epoch: an optimizer step per segment (zero_grad, forward with the running memory, loss, backward, clip 0.5, step), linear
+    warm-up to max_lr over warmup_steps then sched.step(steps - warmup_steps), a log line every log_interval steps.  Returns
+    (sample-weighted mean ce_loss, seconds) — reference loop: stage1_compose/train.py:19-115, pinned by tests/golden/txl_trainloop.json."""
+    from . import dp
+    from .optim import FusedAdam
     model.train()
-    recons_loss_rec, accum_samples = 0., 0
-    say = print if cfg.verbose else (lambda *a, **k: None)
-    say('[train] epoch %d' % epoch)
-    st = time.time()
+    fused = isinstance(optim, FusedAdam)
     dev = next(model.parameters()).device
-    for batch_idx, batch_samples in enumerate(dloader):
+    note = print if cfg.verbose else (lambda *a, **k: None)
+    loss_sum, n_samples, t0 = 0.0, 0, time.time()
+    for b_idx, batch in enumerate(dloader):
         mems = tuple()
-        for segment in range(max(batch_samples['n_seg'])):
-            model.zero_grad()
-            dec_input = batch_samples['dec_inp_{}'.format(segment)].permute(1, 0).to(dev)
-            dec_target = batch_samples['dec_tgt_{}'.format(segment)].permute(1, 0).to(dev)
-            dec_seg_len = batch_samples['dec_seg_len_{}'.format(segment)].to(dev)
-            inp_chord, inp_melody = batch_samples['inp_chord_{}'.format(segment)], batch_samples['inp_melody_{}'.format(segment)]
+        bsz = batch['id'].size(0)
+        for dec_input, dec_target, seg_len, chord, melody in _segments(batch, dev):
+            optim.zero_grad() if fused else model.zero_grad()
             state.train_steps += 1
-            dec_logits, mems = model(dec_input, mems, dec_seg_len=dec_seg_len)
+            dec_logits, mems = model(dec_input, mems, dec_seg_len=seg_len)
             losses = model.compute_loss(dec_logits, dec_target)
-            total_acc, chord_acc, melody_acc, others_acc = compute_accuracy(dec_logits.detach(), dec_target, inp_chord, inp_melody, pad_token)
-            losses['total_loss'].backward()
-            _average_gradients(model)
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)
-            optim.step()
-            recons_loss_rec += batch_samples['id'].size(0) * losses['ce_loss'].item()
-            accum_samples += batch_samples['id'].size(0)
+            accs = compute_accuracy(dec_logits, dec_target, chord, melody, pad_token)
+            _backward_and_exchange(model, losses['total_loss'], dec_target, pad_token)
+            if fused:
+                optim.step()                                        # clip + 1/tokens (or 1/world) folded into the fused Adam
+            else:
+                if dp.data_plane() is not None:
+                    st = model._ensure_store()
+                    st.flat_grad.div_(st.flat_grad_ext[st.total])
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)
+                optim.step()
+            loss_sum += bsz * losses['ce_loss'].item()
+            n_samples += bsz
             if state.train_steps < cfg.warmup_steps:
                 optim.param_groups[0]['lr'] = cfg.max_lr * state.train_steps / cfg.warmup_steps
             else:
                 sched.step(state.train_steps - cfg.warmup_steps)
-            if not state.train_steps % cfg.log_interval:
+            if state.train_steps % cfg.log_interval == 0:
                 lf = os.path.join(cfg.ckpt_dir, cfg.log_file)
-                log_epoch(lf, {'ep': epoch, 'steps': state.train_steps, 'ce_loss': recons_loss_rec / accum_samples, 'time': time.time() - st},
+                log_epoch(lf, {'ep': epoch, 'steps': state.train_steps, 'ce_loss': loss_sum / n_samples, 'time': time.time() - t0},
                           state.init_time, is_init=not os.path.exists(lf))
-        say('[train] epoch %d batch %d  ce %.4f  acc all/chord/melody/other %.4f %.4f %.4f %.4f  step %d  %.1f s' %
-            (epoch, batch_idx, recons_loss_rec / accum_samples, total_acc, chord_acc, melody_acc, others_acc, state.train_steps, time.time() - st))
-    return recons_loss_rec / accum_samples, time.time() - st
+        note('[stage1 train] ep %d batch %d: ce %.4f | acc %.4f (chord %.4f, melody %.4f, others %.4f) | step %d | %.1f s'
+             % ((epoch, b_idx, loss_sum / n_samples) + tuple(accs) + (state.train_steps, time.time() - t0)))
+    return loss_sum / n_samples, time.time() - t0
 
 
 def validate(epoch, model, dloader, pad_token, rounds=1, verbose=True):
+    """-> five lists (ce_loss, total / chord / melody / others accuracy), one entry per segment — train.py:118-158."""
     model.eval()
-    rec = [[], [], [], [], []]
     dev = next(model.parameters()).device
+    out = ([], [], [], [], [])
     if verbose:
-        print('[validate] epoch %d' % epoch)
+        print('[stage1 validate] ep %d' % epoch)
     with torch.no_grad():
-        for r in range(rounds):
-            for batch_idx, batch_samples in enumerate(dloader):
+        for _ in range(rounds):
+            for batch in dloader:
                 mems = tuple()
-                for segment in range(max(batch_samples['n_seg'])):
-                    dec_input = batch_samples['dec_inp_{}'.format(segment)].permute(1, 0).to(dev)
-                    dec_target = batch_samples['dec_tgt_{}'.format(segment)].permute(1, 0).to(dev)
-                    dec_seg_len = batch_samples['dec_seg_len_{}'.format(segment)].to(dev)
-                    dec_logits, mems = model(dec_input, mems, dec_seg_len=dec_seg_len)
-                    losses = model.compute_loss(dec_logits, dec_target)
-                    accs = compute_accuracy(dec_logits, dec_target, batch_samples['inp_chord_{}'.format(segment)],
-                                            batch_samples['inp_melody_{}'.format(segment)], pad_token)
-                    rec[0].append(losses['ce_loss'].item())
-                    for i, a in enumerate(accs):
-                        rec[i + 1].append(a)
-    return tuple(rec)
+                for dec_input, dec_target, seg_len, chord, melody in _segments(batch, dev):
+                    dec_logits, mems = model(dec_input, mems, dec_seg_len=seg_len)
+                    vals = (model.compute_loss(dec_logits, dec_target)['ce_loss'].item(),) + tuple(compute_accuracy(dec_logits, dec_target, chord, melody, pad_token))
+                    for lst, v in zip(out, vals):
+                        lst.append(v)
+    return out

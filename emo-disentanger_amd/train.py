@@ -82,6 +82,7 @@ def train_model(epoch, model, dloader, optim, sched, pad_token, model_type="perf
     say('[epoch {:03d}] # batches = {}'.format(epoch, len(dloader)))
     st = time.time()
     fused = isinstance(optim, FusedAdam)
+    window_tokens = None
     for batch_idx, batch_samples in enumerate(dloader):
         if cfg.faithful_accum or (cfg.train_steps % cfg.accum_steps) == 0:
             optim.zero_grad() if fused else model.zero_grad()
@@ -101,15 +102,28 @@ def train_model(epoch, model, dloader, optim, sched, pad_token, model_type="perf
             dec_logits = model(batch_dec_inp, seg_inp=batch_track_mask, chord_inp=None)
         losses = model.compute_loss(dec_logits, batch_dec_tgt)
         total_loss = losses['total_loss'] / cfg.accum_steps if cfg.accum_steps > 1 else losses['total_loss']
-        total_loss.backward()
+        if cfg.world_size > 1:
+            # data parallel: back-propagate the SUM of this rank's token losses; the non-pad count travels with the gradient and
+            # the optimizer divides by the all-reduced count => the exact global mean even when ranks hold different numbers of
+            # non-pad targets (the reference's loss is a mean over non-pad tokens, music_performer.py:72-76)
+            n_tok = (batch_dec_tgt != pad_token).sum().to(torch.float32)
+            if cfg.faithful_accum or cfg.accum_steps == 1:            # (reference quirk F11: only the window's last micro-batch survives, scaled 1/accum)
+                window_tokens = n_tok
+                (total_loss * n_tok).backward()
+            else:                                                     # real accumulation: token-weighted mean over the whole window
+                window_tokens = n_tok if (train_steps - 1) % cfg.accum_steps == 0 else window_tokens + n_tok
+                (losses['total_loss'] * n_tok).backward()
+        else:
+            total_loss.backward()
         if (train_steps % cfg.accum_steps) == 0:
             if cfg.world_size > 1:
-                dp.allreduce_sum_(model._store.flat_grad)            # the one exchange per optimizer step
+                dp.allreduce_grads_(model._store, window_tokens)     # the one exchange per optimizer step
             if fused:
-                optim.step()                                         # clip(0.5) + 1/world folded into the fused Adam
+                optim.step()                                         # clip(0.5) + 1/sum(tokens) folded into the fused Adam
             else:
                 if cfg.world_size > 1:
-                    model._store.flat_grad.mul_(1.0 / cfg.world_size)
+                    st_ = model._store
+                    st_.flat_grad.div_(st_.flat_grad_ext[st_.total])
                 torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)
                 optim.step()
                 optim.zero_grad()
@@ -223,7 +237,7 @@ def main(argv=None):
     model.train()
     print('# params:', sum(p.numel() for p in model.parameters() if p.requires_grad))
     print('segemb:', model.segemb)
-    optimizer = FusedAdam(model, lr=cfg.max_lr, max_grad_norm=0.5, world_size=world)
+    optimizer = FusedAdam(model, lr=cfg.max_lr, max_grad_norm=0.5, world_size=world, token_weighted=True)
     scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, cfg.lr_decay_steps, eta_min=cfg.min_lr)
     if train_conf['training']['trained_optim']:
         optimizer.load_state_dict(torch.load(train_conf['training']['trained_optim'], map_location='cpu'))

@@ -31,7 +31,7 @@ extern "C" {
 typedef void* emo_stream_t; /* hipStream_t */
 
 enum { EMO_OK = 0, EMO_ERR_INVALID = -1, EMO_ERR_LAUNCH = -2, EMO_ERR_UNSUPPORTED = -3 };
-enum { EMO_F32 = 0, EMO_BF16 = 1 };
+enum { EMO_F32 = 0, EMO_BF16 = 1, EMO_I64 = 2 /* emo_comm_* payloads only */ };
 enum { EMO_ACT_NONE = 0, EMO_ACT_RELU = 1, EMO_ACT_GELU_NEW = 2 };
 enum { EMO_MUL_NONE = 0, EMO_MUL_NONZERO = 1, EMO_MUL_DGELU_NEW = 2 };
 
@@ -257,11 +257,34 @@ int emo_accuracy_counts(const float* logits, const int64_t* tgt, const int64_t* 
  * (pre = 1/world for DP-averaged grads).  adam: torch.optim.Adam semantics (no amsgrad, wd=0),
  * grads scaled by gscale[0]; optionally refreshes the bf16 compute copy of the weights. */
 int emo_sumsq(const float* x, int64_t n, float* acc, emo_stream_t stream);
-int emo_clip_coef(const float* sumsq, float max_norm, float pre, float* coef, emo_stream_t stream);
+/* coef = pre' * min(1, max_norm / (sqrt(sumsq) * pre' + 1e-6)) with pre' = pre / denom[0] (denom NULL => 1): the clip of
+ * torch.nn.utils.clip_grad_norm_ (train.py:79) applied to the pre-scaled gradient.  Data parallel: pre = 1/world for equal
+ * token counts, or pre = 1 and denom = the all-reduced number of non-pad target tokens (token-weighted global mean). */
+int emo_clip_coef(const float* sumsq, float max_norm, float pre, const float* denom, float* coef, emo_stream_t stream);
 int emo_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
                   float beta1, float beta2, float eps, int64_t step, const float* gscale,
                   emo_stream_t stream);
 int emo_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, emo_stream_t stream);
+
+/* ------------------------------------------------------------------ data-parallel exchange (RCCL over xGMI)
+ * The reference trains on one GPU; the build shards the batch over one process per GPU and adds ONE exchange per optimizer
+ * step between loss.backward() and clip_grad_norm_ (insertion point train.py:76-81): a sum all-reduce of the flat fp32
+ * gradient buffer (+ the non-pad token count in its last slot), and one broadcast of parameters / omega at start-up.
+ * RCCL is bound with dlopen at the first call (no link-time dependency).  One communicator per process, bound to the
+ * CURRENT HIP device at emo_comm_init; all transfers are in place, asynchronous on `stream`.
+ *   emo_comm_unique_id : rank 0 creates the 128-byte rendezvous id; the caller ships it to the other ranks (any side channel)
+ *   emo_comm_init      : collective over all ranks (ncclCommInitRank)
+ *   emo_comm_allreduce : buf[i] = sum over ranks (dtype EMO_F32 / EMO_BF16 / EMO_I64)
+ *   emo_comm_broadcast : buf <- root's buf
+ *   emo_comm_world/rank: 0 / -1 before init
+ */
+int emo_comm_unique_id(void* id128);
+int emo_comm_init(const void* id128, int rank, int world);
+int emo_comm_world(void);
+int emo_comm_rank(void);
+int emo_comm_allreduce(void* buf, int64_t count, int dtype, emo_stream_t stream);
+int emo_comm_broadcast(void* buf, int64_t count, int dtype, int root, emo_stream_t stream);
+int emo_comm_destroy(void);
 
 #ifdef __cplusplus
 }

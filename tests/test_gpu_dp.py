@@ -1,39 +1,143 @@
-"""GPU: the RCCL leg of the data-parallel path on the one GPU a test box has.  World size 1 cannot exercise the exchange itself (the
-gloo world-2 test in test_host_logic.py does, on CPU), but it proves that torch.distributed's "nccl" backend (= RCCL) initialises in this
-image with the environment dp.init_distributed sets and that the flat-gradient all-reduce / parameter broadcast / max-over-ranks calls
-run on device tensors on the bench's stream."""
+"""GPU: the data-parallel path (BASELINE configs[2] / configs[4]) on the ONE GPU a test box has.
+
+* the C-ABI exchange (emo_comm_*: RCCL bound with dlopen) initialises, all-reduces and broadcasts on device buffers (world 1 —
+  RCCL refuses two ranks on one device, so the exchange itself cannot be exercised with RCCL here);
+* a REAL 2-rank training step — two processes sharing the GPU, host-staged gloo data plane — through train.train_model +
+  FusedAdam(world_size=2, token_weighted=True) equals the 1-rank step on the concatenated batch: all-reduced gradient and
+  parameters after the optimizer step, with unequal non-pad token counts per rank (fp32 parity mode);
+* bench.py --gpus 2 on a 1-GPU box refuses instead of silently benchmarking one rank."""
 import os
+import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-SCRIPT = r'''
-import os, sys, torch, torch.distributed as dist
+COMM_SCRIPT = r'''
+import ctypes, os, sys, torch
 sys.path.insert(0, os.environ["EMO_ROOT"])
-from emo_disentanger_amd import dp
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+from emo_disentanger_amd._lib import lib, check, F32, I64
 torch.cuda.set_device(0)
-dist.init_process_group(backend="nccl", rank=0, world_size=1)
+uid = (ctypes.c_char * 128)()
+check(lib.emo_comm_unique_id(uid))
+assert lib.emo_comm_world() == 0 and lib.emo_comm_rank() == -1
+check(lib.emo_comm_init(uid, 0, 1))
+assert lib.emo_comm_world() == 1 and lib.emo_comm_rank() == 0
+s = torch.cuda.current_stream().cuda_stream
 flat = torch.arange(1 << 22, device="cuda", dtype=torch.float32)
 ref = flat.clone()
-dist.all_reduce(flat, op=dist.ReduceOp.SUM)          # what dp.allreduce_sum_ issues when world > 1
-dist.broadcast(flat, src=0)                          # dp.broadcast_
-dist.barrier()
+check(lib.emo_comm_allreduce(flat.data_ptr(), flat.numel(), F32, s))
+check(lib.emo_comm_broadcast(flat.data_ptr(), flat.numel(), F32, 0, s))
+cnt = torch.tensor([7, 9], device="cuda")
+check(lib.emo_comm_allreduce(cnt.data_ptr(), 2, I64, s))
 torch.cuda.synchronize()
-assert torch.equal(flat, ref)
-assert dp.allreduce_sum_(flat) is flat and dp.max_over_ranks(1.25, flat.device) == 1.25
-assert dp.shard_seed(1234, 3) == 1237
-dist.destroy_process_group()
-print("rccl ok")
+assert torch.equal(flat, ref) and cnt.tolist() == [7, 9]
+assert lib.emo_comm_init(uid, 0, 1) != 0 and b"already initialised" in lib.emo_last_error()
+check(lib.emo_comm_destroy())
+assert lib.emo_comm_allreduce(flat.data_ptr(), 4, F32, s) != 0        # loud after destroy
+print("emo_comm ok")
+'''
+
+STEP_SCRIPT = r'''
+import os, sys, tempfile, numpy as np, torch
+sys.path.insert(0, os.environ["EMO_ROOT"])
+from emo_disentanger_amd import dp, train as tr
+from emo_disentanger_amd.data import synthetic_batch
+from emo_disentanger_amd.model.music_performer import MusicPerformer
+from emo_disentanger_amd.optim import FusedAdam
+rank, _, world = dp.init_distributed()
+torch.cuda.set_device(0)
+torch.manual_seed(0)
+V, B, T = 60, 4, 96
+m = MusicPerformer(V, 2, 2, 64, 128, 64, dropout=0.0, favor_feature_dims=32, use_segment_emb=True, n_segment_types=2,
+                   compute_dtype="fp32", redraw="fixed").cuda()
+if world > 1:
+    if rank == 1:                                   # replicas must come out identical anyway: rank 0's weights and omega win
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.5)
+            for n, b in m.named_buffers():
+                if "omega" in n:
+                    b.mul_(-1.0)
+    dp.sync_model_from_rank0(m)
+    assert dp.data_plane() == "gloo"
+full = synthetic_batch(V, B, T, seed=3, realistic_targets=True)      # pad targets wherever track_mask == 0: unequal counts per shard
+per = B // world
+shard = {k: v[rank * per:(rank + 1) * per] for k, v in full.items()}
+n_tok = int((shard["dec_target"] != V - 1).sum())
+opt = FusedAdam(m, lr=1e-3, max_grad_norm=0.5, world_size=world, token_weighted=True)
+cfg = tr.TrainConfig(world_size=world, verbose=False, warmup_steps=1, max_lr=1e-3, log_interval=10 ** 9, ckpt_dir=tempfile.mkdtemp())
+p0 = m._ensure_store().flat32.clone()
+loss = tr.train_model(1, m, [shard], opt, None, V - 1, cfg=cfg)
+st = m._store
+torch.cuda.synchronize()
+g = st.flat_grad.clone()
+if world > 1:
+    g = g / st.flat_grad_ext[st.total]
+    assert float(st.flat_grad_ext[st.total]) == float(int((full["dec_target"] != V - 1).sum()))
+np.savez(os.environ["EMO_OUT"] + ".rank%d.npz" % rank, grad=g.cpu().numpy(), before=p0.cpu().numpy(), after=st.flat32.cpu().numpy(), n_tok=n_tok, loss=loss)
+dp.barrier()
+dp.shutdown()
 '''
 
 
-def test_rccl_single_rank_collectives_run():
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, EMO_ROOT=root, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
-               HSA_ENABLE_IPC_MODE_LEGACY='0')
-    r = subprocess.run([sys.executable, '-c', SCRIPT], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and 'rccl ok' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def _env(**kw):
+    env = dict(os.environ, EMO_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.update({k: str(v) for k, v in kw.items()})
+    return env
+
+
+def test_emo_comm_c_abi_single_rank():
+    r = subprocess.run([sys.executable, '-c', COMM_SCRIPT], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'emo_comm ok' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_two_rank_training_step_equals_one_rank_on_concatenated_batch(tmp_path):
+    out1, out2 = str(tmp_path / 'w1'), str(tmp_path / 'w2')
+    r = subprocess.run([sys.executable, '-c', STEP_SCRIPT], env=_env(EMO_OUT=out1, WORLD_SIZE=1, RANK=0, LOCAL_RANK=0), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, '-c', STEP_SCRIPT], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=_env(EMO_OUT=out2, WORLD_SIZE=2, RANK=rk, LOCAL_RANK=0, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, EMO_COMM='gloo'))
+             for rk in range(2)]
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), '\n'.join(l[-3000:] for l in logs)
+    one = np.load(out1 + '.rank0.npz')
+    two = [np.load(out2 + '.rank%d.npz' % rk) for rk in range(2)]
+    assert int(two[0]['n_tok']) != int(two[1]['n_tok']) and int(two[0]['n_tok']) + int(two[1]['n_tok']) == int(one['n_tok'])
+    np.testing.assert_array_equal(two[0]['before'], one['before'])            # rank 0's weights are the single-rank weights ...
+    np.testing.assert_array_equal(two[1]['before'], two[0]['before'])         # ... and rank 1 was overwritten by the broadcast
+    gmax = np.abs(one['grad']).max()
+    for t in two:
+        err = np.abs(t['grad'] - one['grad']).max() / gmax
+        assert err <= 2e-6, 'all-reduced token-weighted gradient differs from the 1-rank gradient: %.3g of max|g|' % err
+        # Adam's first update is lr * g / (|g| + 1e-8): elements whose gradient is a cancelling sum near 1e-8 amplify the fp32
+        # reassociation of the two-shard sum, so the bound is on the 99.9th percentile (and a loose one on the maximum)
+        step = np.abs(one['after'] - one['before']).max()
+        d = np.abs(t['after'] - one['after']) / step
+        assert step > 0 and np.quantile(d, 0.999) <= 1e-3 and d.max() <= 0.5, \
+            'parameters after the fused Adam step differ: p99.9 %.3g, max %.3g of the largest update' % (np.quantile(d, 0.999), d.max())
+    np.testing.assert_array_equal(two[0]['after'], two[1]['after'])           # replicas stay bit-identical
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('box has >= 2 GPUs')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=_env(), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and 'refusing' in r.stderr and '"value"' not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=_env(WORLD_SIZE=1, RANK=0, LOCAL_RANK=0), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr and '"value"' not in r.stdout

@@ -71,20 +71,22 @@ def _dp_worker(rank, world, port, q):
     params = torch.full((10,), float(rank))
     dp.broadcast_([params])
     mx = dp.max_over_ranks(1.0 + rank, 'cpu')
-    # the stage-1 loop's exchange (stage1_train._average_gradients): mean over ranks of the model's flat gradient buffer
-    from emo_disentanger_amd import stage1_train as s1
-
+    # the optimizer-step exchange (dp.allreduce_grads_): every rank holds the gradient of the SUM of its token losses and its non-pad
+    # token count; one collective moves both, and dividing by the summed count gives the global token mean (not the mean of means)
     class _Store:
-        flat_grad = torch.full((7,), 1.0 + 2.0 * rank)
-
-    class _Model:
-        def _ensure_store(self):
-            return _Store
-    s1._average_gradients(_Model())
-    assert torch.allclose(_Store.flat_grad, torch.full((7,), 2.0))
+        total = 8
+        flat_grad_ext = torch.zeros(16)
+        flat_grad = flat_grad_ext[:8]
+    n_tok = (3.0, 5.0)[rank]                                   # unequal counts on purpose
+    g_mean = torch.full((8,), 1.0 + 2.0 * rank)                # this rank's mean-loss gradient
+    _Store.flat_grad.copy_(g_mean * n_tok)
+    dp.allreduce_grads_(_Store, torch.tensor(n_tok))
+    assert float(_Store.flat_grad_ext[8]) == 8.0 and float(_Store.flat_grad_ext[9:].abs().sum()) == 0.0
+    assert torch.allclose(_Store.flat_grad / _Store.flat_grad_ext[8], torch.full((8,), (3.0 * 1.0 + 5.0 * 3.0) / 8.0))
+    assert dp.data_plane() == 'gloo'
     q.put((rank, mine.numpy().copy(), flat.numpy().copy(), params.numpy().copy(), mx))   # by value (tensor FD passing races the exit)
-    torch.distributed.barrier()
-    torch.distributed.destroy_process_group()
+    dp.barrier()
+    dp.shutdown()
 
 
 def test_data_parallel_plumbing_gloo_world2():
@@ -103,7 +105,7 @@ def test_data_parallel_plumbing_gloo_world2():
         assert p.exitcode == 0
     (_, m0, f0, p0, x0), (_, m1, f1, p1, x1) = res
     assert not np.array_equal(m0, m1)                      # each rank drew its own shard (weak scaling)
-    assert np.allclose(f0, m0 + m1) and np.array_equal(f0, f1)   # grad all-reduce = sum; 1/world is folded into the clip coef
+    assert np.allclose(f0, m0 + m1) and np.array_equal(f0, f1)   # grad all-reduce = sum; the 1/world (or 1/tokens) scale is folded into the clip coef
     assert not p0.any() and not p1.any()                   # replicas start from rank 0's weights
     assert x0 == x1 == 2.0                                 # bench timing = max over ranks
 
