@@ -160,6 +160,37 @@ def stage1_bench(n_steps=10, B=4, T=512, V=200):
             'loss': round(float(loss), 4)}
 
 
+def step0_check(model, batch):
+    """Loss of the bench's OWN weights on the first sequence of its own batch, HIP path vs the CPU oracle (omega fixed, dropout 0, outside the
+    timed region; SURVEY §8(d) "Timing protocol").  bf16 = the timed compute mode, fp32 = parity mode (north_star: |dloss| <= 1e-4)."""
+    from oracle import model_ref
+    x, seg, tgt = batch['dec_input'][:1], batch['track_mask'][:1], batch['dec_target'][:1]
+    redraw, training = model.redraw, model.training
+    model.redraw = 'fixed'
+    model.eval()
+    out = {}
+    try:
+        with torch.no_grad():
+            for dt in ('fp32', 'bf16'):                         # (ends on bf16: the store of the timed run is rebuilt once)
+                model.set_compute_dtype(dt)
+                out['loss_hip_' + dt] = float(model.compute_loss(model(x, seg_inp=seg), tgt)['total_loss'])
+            sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+            t0 = time.time()
+            ref = model_ref.compute_loss(model_ref.forward('performer', sd, x.cpu(), seg.cpu(), CFG['n_layer'], CFG['n_head'], CFG['d_model']),
+                                         tgt.cpu(), CFG['n_token'])
+            out['loss_oracle'] = float(ref)
+            out['oracle_seconds'] = round(time.time() - t0, 2)
+    finally:
+        model.redraw = redraw
+        model.train(training)
+    out['abs_err_fp32'] = abs(out['loss_hip_fp32'] - out['loss_oracle'])
+    out['abs_err_bf16'] = abs(out['loss_hip_bf16'] - out['loss_oracle'])
+    out['abs_err'] = out['abs_err_bf16']
+    out['ok'] = bool(out['abs_err_fp32'] <= 1e-4 and out['abs_err_bf16'] <= 5e-3)
+    out['sample'] = 'first sequence (B=1 x T=%d) of the timed batch, the timed weights, omega fixed, dropout 0' % x.shape[1]
+    return out
+
+
 def cpu_generation_baseline(ctx=256, n_tok=4):
     """Reference-style AR step on the CPU oracle: full-prefix recompute per token (inference.py:252-272), 1 stream."""
     from oracle import model_ref
@@ -222,6 +253,7 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-gen', action='store_true')
     ap.add_argument('--no-stage1', action='store_true')
+    ap.add_argument('--no-step0-check', action='store_true')
     args = ap.parse_args()
 
     want = max(args.gpus, 1)
@@ -243,9 +275,11 @@ def main():
     dev = torch.device('cuda', local_dev)
     torch.manual_seed(0)
     B, T = args.batch, args.seq
-    model = MusicPerformer(CFG['n_token'], CFG['n_layer'], CFG['n_head'], CFG['d_model'], CFG['d_ff'], CFG['d_model'],
-                           favor_feature_dims=CFG['n_feat'], use_segment_emb=True, n_segment_types=2, dropout=0.1,
-                           compute_dtype='bf16', redraw=args.redraw).to(dev)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):             # the constructor prints '[info] model init completed' like the reference's; stdout carries ONE JSON line
+        model = MusicPerformer(CFG['n_token'], CFG['n_layer'], CFG['n_head'], CFG['d_model'], CFG['d_ff'], CFG['d_model'],
+                               favor_feature_dims=CFG['n_feat'], use_segment_emb=True, n_segment_types=2, dropout=0.1,
+                               compute_dtype='bf16', redraw=args.redraw).to(dev)
     model.train()
     if world > 1:
         dp.sync_model_from_rank0(model)
@@ -254,6 +288,7 @@ def main():
     batches = [synthetic_batch(CFG['n_token'], B, T, seed=dp.shard_seed(1234, rank) + 100 * i, device=dev) for i in range(2)]
     for b in batches:                                        # non-pad target count of the rank's batch (token-weighted DP mean)
         b['n_tok'] = (b['dec_target'] != CFG['n_token'] - 1).sum().to(torch.float32)
+    s0 = step0_check(model, batches[1]) if (world == 1 and not args.no_step0_check) else None     # batches[1] = the batch of step 1
     ps = model._ensure_store()
     counts = torch.zeros(6, device=dev, dtype=torch.int64)
     loss_acc = torch.zeros((), device=dev)
@@ -305,6 +340,8 @@ def main():
         if rank == 0:
             out['roofline'] = roof
     if rank == 0:
+        if s0 is not None:
+            out['step0_check'] = s0
         if world == 1 and not args.no_gen:
             out['gen'] = generation_bench(model)
             if not args.no_cpu_baseline:

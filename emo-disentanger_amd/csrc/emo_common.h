@@ -47,33 +47,48 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
 
 // ---------------------------------------------------------------- counter-based dropout RNG
-// One 32-bit hash per PAIR of elements (16 random bits each).  keep iff bits >= thr16,
+// One keyed 32-bit hash per PAIR of elements (16 random bits each).  keep iff bits >= thr16,
 // thr16 = round(p * 65536).  Forward and backward regenerate the same mask from
 // (seed, offset, linear element index) — nothing is stored.
+// The 64-bit key (two words derived from the 64-bit seed and the per-site offset) enters the hash at two
+// points — XORed into the multiplied counter before the first round and again between the two
+// multiply rounds — so two (seed, offset) streams are NOT index-shifted copies of one sequence (an
+// additive 32-bit key in front of a fixed hash would make them exactly that).
 __host__ __device__ __forceinline__ uint32_t emo_hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
 struct DropCtx {
-    uint32_t key;    // mixed (seed, offset)
+    uint32_t key;    // mixed (seed, offset), word 0
+    uint32_t key2;   // word 1
     uint32_t thr16;  // 0 => dropout disabled
     float scale;     // 1/(1-p)
 };
+__host__ __device__ __forceinline__ uint32_t emo_drop_hash(const DropCtx& d, uint32_t pair) {
+    uint32_t x = (pair * 0x9E3779B1u) ^ d.key;
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= d.key2; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
 __host__ __device__ __forceinline__ DropCtx make_drop(float p, uint64_t seed, uint64_t offset) {
     DropCtx d;
     d.thr16 = p > 0.f ? (uint32_t)(p * 65536.f + 0.5f) : 0u;
     d.scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
-    uint32_t k = emo_hash32((uint32_t)seed ^ 0x9E3779B9u);
-    k = emo_hash32(k ^ (uint32_t)(seed >> 32));
-    k = emo_hash32(k ^ (uint32_t)offset * 0x85EBCA6Bu ^ (uint32_t)(offset >> 32));
+    const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32), o0 = (uint32_t)offset, o1 = (uint32_t)(offset >> 32);
+    uint32_t k = emo_hash32(s0 ^ 0x9E3779B9u);
+    k = emo_hash32(k ^ s1);
+    k = emo_hash32(k ^ o0 * 0x85EBCA6Bu ^ o1);
+    uint32_t k2 = emo_hash32(s1 ^ 0xC2B2AE35u);
+    k2 = emo_hash32(k2 + o0);
+    k2 = emo_hash32(k2 ^ s0 * 0x27D4EB2Fu ^ o1 * 0x165667B1u);
     d.key = k;
+    d.key2 = k2;
     return d;
 }
 // multiplier (0 or scale) for linear element index idx
 __host__ __device__ __forceinline__ float drop_mult(const DropCtx& d, uint64_t idx) {
     if (d.thr16 == 0u) return 1.f;
     uint32_t pair = (uint32_t)(idx >> 1) ^ (uint32_t)(idx >> 33) * 0x9E3779B1u;
-    uint32_t h = emo_hash32(pair * 0x9E3779B1u + d.key);
+    uint32_t h = emo_drop_hash(d, pair);
     uint32_t bits = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
     return bits >= d.thr16 ? d.scale : 0.f;
 }
@@ -90,7 +105,7 @@ __device__ __forceinline__ void drop_mult4(const DropCtx& d, uint64_t idx0, floa
     for (int h2 = 0; h2 < 2; ++h2) {
         const uint64_t idx = idx0 + 2 * h2;
         const uint32_t pair = (uint32_t)(idx >> 1) ^ (uint32_t)(idx >> 33) * 0x9E3779B1u;
-        const uint32_t h = emo_hash32(pair * 0x9E3779B1u + d.key);
+        const uint32_t h = emo_drop_hash(d, pair);
         m[2 * h2] = (h & 0xFFFFu) >= d.thr16 ? d.scale : 0.f;
         m[2 * h2 + 1] = (h >> 16) >= d.thr16 ? d.scale : 0.f;
     }

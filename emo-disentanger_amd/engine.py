@@ -136,6 +136,38 @@ class ParamStore:
         return self._view(self.flat_grad, name, fused_rows)
 
 
+def embedding_table(ps, prefix):
+    """fp32 table the fused gather reads for TokenEmbedding `prefix` ('token_emb.' / 'segemb.'): emb_lookup.weight, or its projection
+    emb_lookup.weight @ emb_proj.weight^T [n, d_model] when d_embed != d_model (transformer_helpers.py:75-78,84-85)."""
+    E = ps.f32(prefix + 'emb_lookup.weight')
+    if prefix + 'emb_proj.weight' in ps.params:
+        return ops.gemm(E, ps.f32(prefix + 'emb_proj.weight'))
+    return E
+
+
+def embedding_table_bwd(ps, prefix, d_table):
+    """Back through the projection: dE += dT P, dP += dT^T E (d_table: gradient of the projected table, fp32 [n, d_model])."""
+    E, P = ps.f32(prefix + 'emb_lookup.weight'), ps.f32(prefix + 'emb_proj.weight')
+    ops.gemm(d_table, P, b_trans=True, out=ps.g(prefix + 'emb_lookup.weight'), accumulate=True)
+    ops.gemm(d_table, E, a_trans=True, b_trans=True, out=ps.g(prefix + 'emb_proj.weight'), accumulate=True)
+
+
+def check_ids(t, n, what, also=None):
+    """Index inputs are range-checked like torch's embedding / cross_entropy do (the kernels index LDS tables and logits rows with
+    them): one asynchronous device-side assertion, no host sync.  `also`: one extra admissible value (ignore_index).  EMO_CHECK_IDS=0
+    removes the three tiny launches."""
+    if t is None or not _CHECK_IDS:
+        return
+    ok = (t >= 0) & (t < n)
+    if also is not None:
+        ok = ok | (t == also)
+    torch._assert_async(ok.all(), '%s out of range [0, %d)' % (what, n))
+
+
+import os as _os0
+_CHECK_IDS = _os0.environ.get('EMO_CHECK_IDS', '1') != '0'
+
+
 # =================================================================================================== layer schedules
 class LayerCtx:
     __slots__ = ('t',)
@@ -295,9 +327,16 @@ class DecoderStackFn(torch.autograd.Function):
         D, H, L = model.d_model, model.n_head, model.n_layer
         p = model.dropout if model.training else 0.0
         seed, base = model._next_dropout_base()
-        E = ps.f32('token_emb.emb_lookup.weight')
-        S = ps.f32('segemb.emb_lookup.weight') if (seg is not None and model.use_segment_emb) else None
-        seg = seg if S is not None else None
+        use_seg = seg is not None and model.use_segment_emb
+        seg = seg if use_seg else None
+        E = embedding_table(ps, 'token_emb.')
+        S = embedding_table(ps, 'segemb.') if use_seg else None
+        check_ids(tok, E.shape[0], 'token ids')
+        check_ids(seg, 0 if S is None else S.shape[0], 'segment ids')
+        if model.use_pe and model.d_embed != D:
+            raise RuntimeError('The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton dimension 2: positional '
+                               'encoding of width d_embed cannot be added to d_model-wide embeddings (use_pe=True needs d_embed == d_model, '
+                               'as in the reference, music_performer.py:59-60)' % (D, model.d_embed))
         pe = model.pe.pe if model.use_pe else model._zero_pe(T, D)
         x = ops.embed_fwd(tok, seg, E, S, pe, ps.compute_dtype, float(model.token_emb.emb_scale), p_drop=p, seed=seed, offset=base).view(B * T, D)
         saves = []
@@ -327,8 +366,18 @@ class DecoderStackFn(torch.autograd.Function):
             else:
                 dx = gpt2_block_bwd(ps, model._layer_prefix(l), dx, B, T, H, p, seed, base + 8 * (l + 1), ctx.saves[l])
             ctx.saves[l] = None
-        dS = ps.g('segemb.emb_lookup.weight') if ctx.seg is not None else None
-        ops.embed_bwd(ctx.tok, ctx.seg, dx, ps.g('token_emb.emb_lookup.weight'), dS, float(model.token_emb.emb_scale), p_drop=p, seed=seed, offset=base)
+        proj = model.d_embed != D
+        if proj:                                                 # gradients of the PROJECTED tables, then back through emb_proj
+            dE = torch.zeros(model.n_token, D, device=dx.device)
+            dS = torch.zeros(model.n_segment_types, D, device=dx.device) if ctx.seg is not None else None
+        else:
+            dE = ps.g('token_emb.emb_lookup.weight')
+            dS = ps.g('segemb.emb_lookup.weight') if ctx.seg is not None else None
+        ops.embed_bwd(ctx.tok, ctx.seg, dx, dE, dS, float(model.token_emb.emb_scale), p_drop=p, seed=seed, offset=base)
+        if proj:
+            embedding_table_bwd(ps, 'token_emb.', dE)
+            if dS is not None:
+                embedding_table_bwd(ps, 'segemb.', dS)
         join_side_stream()          # all weight gradients are complete before anything downstream (all-reduce, optimizer) runs
         return None, None, None, None, None
 
@@ -380,6 +429,7 @@ class XentFn(torch.autograd.Function):
         if not l2.is_contiguous():
             l2 = l2.contiguous()
         t = tgt.reshape(-1)
+        check_ids(t, V, 'cross-entropy targets', also=ignore_index)
         lse, acc = ops.xent_fwd(l2, t, ignore_index)
         ctx.save_for_backward(l2, t, lse, acc)
         ctx.ignore, ctx.shape = ignore_index, logits.shape

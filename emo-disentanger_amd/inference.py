@@ -17,7 +17,7 @@ import time
 import numpy as np
 import torch
 
-from . import ops
+from . import engine, ops
 
 max_dec_inp_len = 2048
 
@@ -43,13 +43,17 @@ class _EngineBase:
         self.dev, self.dt = self.ps.device, self.ps.compute_dtype
         self.pos = 0
         self.pos_dev = torch.zeros(n_streams, device=self.dev, dtype=torch.int64)   # device-side positions (hipGraph replay)
+        self._tables = None
         self.dev_pos0, self.pos_auto = 0, True   # position = dev_pos0 + pos_dev[stream]; pos_auto: the engine advances pos_dev itself
 
     def _embed(self, tok, seg, pos0, dev_pos=False):
-        m, ps = self.model, self.ps
-        S = ps.f32('segemb.emb_lookup.weight') if (seg is not None and m.use_segment_emb) else None
+        m = self.model
+        if self._tables is None:                                  # snapshot, like the engine's omegas / folded weights
+            self._tables = (engine.embedding_table(self.ps, 'token_emb.'), engine.embedding_table(self.ps, 'segemb.') if m.use_segment_emb else None)
+        E, S = self._tables
+        S = S if seg is not None else None
         pe = m.pe.pe if m.use_pe else m._zero_pe(self.max_len, m.d_model)
-        return ops.embed_fwd(tok, seg if S is not None else None, ps.f32('token_emb.emb_lookup.weight'), S, pe, self.dt, float(m.token_emb.emb_scale),
+        return ops.embed_fwd(tok, seg if S is not None else None, E, S, pe, self.dt, float(m.token_emb.emb_scale),
                              pos0=self.dev_pos0 if dev_pos else pos0, pos_ids=self.pos_dev if dev_pos else None).view(-1, m.d_model)
 
     def _logits(self, h, out=None):

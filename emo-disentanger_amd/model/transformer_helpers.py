@@ -46,16 +46,22 @@ class PositionalEncoding(nn.Module):
 
 
 class TokenEmbedding(nn.Module):
+    """emb_lookup [n_token, d_embed] (+ emb_proj: Linear(d_embed, d_proj, bias=False) when the widths differ), output scaled by
+    sqrt(d_proj) — transformer_helpers.py:66-87.  The engine never runs this module's forward inside a model: because the projection
+    is linear, `emb_proj(emb_lookup(ids))` equals a gather from the PROJECTED table `emb_lookup.weight @ emb_proj.weight^T`, which is
+    one small GEMM per forward (engine.embedding_table) in front of the same fused gather kernel."""
+
     def __init__(self, n_token, d_embed, d_proj, emb_scale=0.5, pad_idx=None):
         super().__init__()
-        if d_proj != d_embed:
-            raise NotImplementedError('d_embed != d_model (emb_proj) is not used by any stage-2 config and is not built')
         self.n_token, self.d_embed, self.d_proj = n_token, d_embed, d_proj
         self.emb_scale = d_proj ** emb_scale
         self.emb_lookup = nn.Embedding(n_token, d_embed, padding_idx=pad_idx)
-        self.emb_proj = None
+        self.emb_proj = nn.Linear(d_embed, d_proj, bias=False) if d_proj != d_embed else None
 
     def forward(self, inp_tokens):
         from emo_disentanger_amd import ops
-        zero_pe = torch.zeros(inp_tokens.shape[1], self.d_embed, device=inp_tokens.device)
-        return ops.embed_fwd(inp_tokens, None, self.emb_lookup.weight, None, zero_pe, torch.float32, float(self.emb_scale))
+        table = self.emb_lookup.weight.detach()
+        if self.emb_proj is not None:
+            table = ops.gemm(table.float().contiguous(), self.emb_proj.weight.detach().float().contiguous())
+        zero_pe = torch.zeros(inp_tokens.shape[1], self.d_proj, device=inp_tokens.device)
+        return ops.embed_fwd(inp_tokens, None, table, None, zero_pe, torch.float32, float(self.emb_scale))

@@ -100,6 +100,8 @@ def make_state_dict(kind, n_token, n_layer, n_head, d_model, d_ff, d_embed=None,
         raise NotImplementedError(kind)
     if n_segment_types:
         sd['segemb.emb_lookup.weight'] = _normal(rng, (n_segment_types, d_embed), lin)
+        if d_embed != d_model:
+            sd['segemb.emb_proj.weight'] = _normal(rng, (d_model, d_embed), lin)
     return sd
 
 

@@ -53,7 +53,7 @@ rank, _, world = dp.init_distributed()
 torch.cuda.set_device(0)
 torch.manual_seed(0)
 V, B, T = 60, 4, 96
-m = MusicPerformer(V, 2, 2, 64, 128, 64, dropout=0.0, favor_feature_dims=32, use_segment_emb=True, n_segment_types=2,
+m = MusicPerformer(V, 2, 4, 64, 128, 64, dropout=0.0, favor_feature_dims=32, use_segment_emb=True, n_segment_types=2,
                    compute_dtype="fp32", redraw="fixed").cuda()
 if world > 1:
     if rank == 1:                                   # replicas must come out identical anyway: rank 0's weights and omega win

@@ -76,7 +76,7 @@ def test_generate_conditional_batch_equals_single_stream_runs(kind, skip_check):
     for i in range(len(leads)):
         rs = np.random.RandomState(seeds[i])
         single = inf.generate_conditional(model, e2i, i2e, leads[i], primers[i], max_events=150, skip_check=skip_check, temp=1.2, top_p=0.97,
-                                          model_type=kind, sampler=lambda p, rs=rs: inf.nucleus_rs(p, 0.97, rs))
+                                          model_type=kind, sampler=lambda p, rs=rs: inf.nucleus(p, 0.97, rng=rs))
         assert batch[i] == single, i
 
 

@@ -151,3 +151,14 @@ def test_checkpoint_contract_param_order_and_init_rule():
     assert float(p[lp + 'linear1.bias'].abs().max()) == 0.0
     # loaders filter 'feature_map.omega' (train.py:306, inference.py:411): the buffer is in the state dict under that name
     assert any(k.endswith('inner_attention.feature_map.omega') for k in p)
+
+
+def test_product_positional_encoding_rows_match_reference_fixture():
+    """a2: the PRODUCT's PositionalEncoding buffer (state-dict entry pe.pe, read by emo_embed_fwd) is bit-identical to rows dumped from the
+    imported reference (transformer_helpers.py:43-63), without going through load_state_dict."""
+    from emo_disentanger_amd.model.transformer_helpers import PositionalEncoding
+    z = np.load(os.path.join(G, 'pe_rows_d512.npz'))
+    pe = PositionalEncoding(512)
+    assert tuple(pe.pe.shape) == (12000, 1, 512) and pe.pe.dtype == torch.float32
+    assert np.array_equal(pe.pe[torch.from_numpy(z['rows']), 0].numpy(), z['pe'])
+    assert torch.equal(pe(7), pe.pe[:7]) and tuple(pe(7, bsz=3).shape) == (7, 3, 512)
