@@ -215,20 +215,32 @@ def main(argv=None):
     req.add_argument('-m', '--model_type', choices=['performer', 'gpt2'], required=True)
     req.add_argument('-c', '--configuration', required=True, help='one of the four stage-2 YAMLs (same keys)')
     req.add_argument('-r', '--representation', choices=['remi', 'functional'], required=True)
-    parser.add_argument('--synthetic', type=int, default=0, help='if >0: batches per epoch of synthetic EMOPIA-shaped data')
+    parser.add_argument('--synthetic', type=int, default=0, help='if >0: batches per epoch of synthetic EMOPIA-shaped data instead of the event pickles')
     parser.add_argument('--dtype', default=None, choices=[None, 'bf16', 'fp32'])
     parser.add_argument('--epochs', type=int, default=None)
+    parser.add_argument('--workers', type=int, default=8, help='DataLoader worker processes (reference: 8)')
     args = parser.parse_args(argv)
     train_conf = yaml.load(open(args.configuration, 'r'), Loader=yaml.FullLoader)
     rank, local_rank, world = dp.init_distributed()
     cfg = TrainConfig.from_yaml(train_conf, args.representation, world_size=world, verbose=rank == 0)
     torch.cuda.set_device(local_rank if world > 1 else cfg.gpuid)
     model_conf, dl = train_conf['model'], train_conf['data_loader']
-    if not args.synthetic:
-        raise SystemExit('the EMOPIA / Pop1K7 event pickles are not shipped; run with --synthetic N (batches per epoch)')
-    vocab = 327 if args.representation == 'functional' else 370
-    dloader = SyntheticLoader(vocab, dl['batch_size'], model_conf['max_len'], args.synthetic, rank=rank)
-    val_dloader = SyntheticLoader(vocab, dl['batch_size'], model_conf['max_len'], max(1, args.synthetic // 8), seed=99, rank=rank)
+    if args.synthetic:
+        vocab = 327 if args.representation == 'functional' else 370
+        dloader = SyntheticLoader(vocab, dl['batch_size'], model_conf['max_len'], args.synthetic, rank=rank)
+        val_dloader = SyntheticLoader(vocab, dl['batch_size'], model_conf['max_len'], max(1, args.synthetic // 8), seed=99, rank=rank)
+    else:                                                         # the reference's event pickles (train.py:252-285)
+        from torch.utils.data import DataLoader
+        from torch.utils.data.distributed import DistributedSampler
+        from .data import EventPieceDataset, load_split
+        data_path, vocab_path = dl['data_path'].format(args.representation), dl['vocab_path'].format(args.representation)
+        sets = [EventPieceDataset(data_dir=data_path, vocab_file=vocab_path, model_dec_seqlen=model_conf['max_len'], pieces=load_split(dl[k]),
+                                  pad_to_same=True, predict_key=False) for k in ('train_split', 'val_split')]
+        vocab = sets[0].vocab_size                                # n_token and the pad id come from the dictionary
+        print('[info] # training pieces:', len(sets[0].pieces))
+        samplers = [DistributedSampler(d, num_replicas=world, rank=rank, shuffle=True) if world > 1 else None for d in sets]
+        dloader, val_dloader = [DataLoader(d, batch_size=dl['batch_size'], shuffle=sm is None, sampler=sm, num_workers=args.workers, pin_memory=True)
+                                for d, sm in zip(sets, samplers)]
     model = build_model(args.model_type, vocab, model_conf, args.dtype).cuda()
     if train_conf['training']['trained_params']:
         load_pretrained(model, train_conf['training']['trained_params'])
@@ -247,6 +259,8 @@ def main(argv=None):
             os.makedirs(d, exist_ok=True)
         shutil.copy(args.configuration, os.path.join(cfg.ckpt_dir, 'config.yaml'))
     for ep in range(args.epochs or cfg.max_epochs):
+        if getattr(dloader, 'sampler', None) is not None and hasattr(dloader.sampler, 'set_epoch'):
+            dloader.sampler.set_epoch(ep)
         loss = train_model(ep + 1, model, dloader, optimizer, scheduler, vocab - 1, model_type=args.model_type, cfg=cfg)
         if rank == 0 and not (ep + 1) % cfg.ckpt_interval:
             torch.save(model.state_dict(), os.path.join(params_dir, 'ep{:03d}_loss{:.3f}_params.pt'.format(ep + 1, loss)))

@@ -162,3 +162,30 @@ def test_product_positional_encoding_rows_match_reference_fixture():
     assert tuple(pe.pe.shape) == (12000, 1, 512) and pe.pe.dtype == torch.float32
     assert np.array_equal(pe.pe[torch.from_numpy(z['rows']), 0].numpy(), z['pe'])
     assert torch.equal(pe(7), pe.pe[:7]) and tuple(pe(7, bsz=3).shape) == (7, 3, 512)
+
+
+def test_event_piece_dataset_matches_reference():
+    """data.EventPieceDataset on the reference's on-disk format (piece pickles + dictionary.pkl) returns, sample by sample, what the REAL
+    REMISkylineToMidiTransformerDataset returned for the same files under the same `random` seeds (fixture: tools/make_golden_dataset.py):
+    start-bar choice, padding / truncation to the window, shifted targets + EOS inside the full-arrangement spans, track mask, the
+    predict_key variant, Chord / Note flags, vocabulary size and pad id."""
+    import random
+    from emo_disentanger_amd import data
+    D = os.path.join(G, 'dataset')
+    exp = json.load(open(os.path.join(D, 'expected.json')))
+    names = ['p_long.pkl', 'p_mid.pkl', 'p_short.pkl']
+    assert data.REMISkylineToMidiTransformerDataset is data.EventPieceDataset and data.load_split(os.path.join(D, 'train.pkl')) == names[:2]
+    for key, e in exp.items():
+        ds = data.EventPieceDataset(D, os.path.join(D, 'dictionary.pkl'), pieces=names, pad_to_same=True, **e['kw'])
+        assert (ds.vocab_size, ds.pad_token) == (e['vocab_size'], e['pad_token']) and ds.piece_admissible_stbars == e['stbars']
+        it = iter(e['samples'])
+        for seed in (0, 1, 2):
+            random.seed(seed)
+            for i in range(len(ds)):
+                got, want = ds[i], next(it)
+                assert set(got) == set(want)
+                for k, v in want.items():
+                    g = got[k].tolist() if isinstance(got[k], np.ndarray) else got[k]
+                    assert g == v, (key, seed, i, k)
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=3)))           # default collation gives the train loop's [B, T] int64 tensors
+    assert batch['dec_input'].shape == (3, 400) and batch['dec_input'].dtype == torch.int64 and batch['track_mask'].max() == 1
