@@ -48,7 +48,9 @@ GEMM_KERNELS = {   # layout class of ops.gemm -> the kernel instance it launches
     'TN': ('gemm_bf16_kernel<false,false,false,float,64,RS> (RS=1: with the bias gradient, RS=0: without) + splitk_reduce_kernel',
            'wgrad dW = dY^T X, reduction over the B*T tokens'),
     'NN': ('gemm_bf16_glds_kernel<true,false,bf16,32,2>', 'dgrad dX = dY W'),
-    'NT': ('gemm_bf16_glds_kernel<true,true,bf16,32,3>', 'forward Y = X W^T + fused epilogue, K = 512'),
+    'NT': ('gemm_bf16_glds_kernel<true,true,bf16,32,3>', 'forward Y = X W^T + fused epilogue, K = 512 (shapes outside the A-stationary class)'),
+    'NT/K=512': ('gemm_astat_kernel<bf16,BITS> (A stationary in registers, weights through the LDS ring)',
+                 'K = 512 products: QKV / out-projection / FFN1 forward, FFN2 / out-projection dgrad against transposed weight mirrors'),
     'NT/K>1024': ('gemm_bf16_glds_kernel<true,true,bf16,64,2>', 'forward Y = X W^T + fused epilogue, K = 2048'),
 }
 

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'libemo_hip.so')
 
 F32, BF16, I64 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU_NEW = 0, 1, 2
-MUL_NONE, MUL_NONZERO, MUL_DGELU_NEW = 0, 1, 2
+MUL_NONE, MUL_NONZERO, MUL_DGELU_NEW, MUL_BITMASK = 0, 1, 2, 3
 
 if not os.path.exists(LIB_PATH):
     raise ImportError('libemo_hip.so not built: run `python -c "import __graft_entry__ as g; g.build()"` '
@@ -26,7 +26,7 @@ class Epilogue(ctypes.Structure):
     _fields_ = [('bias', c_p), ('act', c_i), ('aux_out', c_p), ('mul_aux', c_p), ('mul_mode', c_i), ('mul_scale', c_f),
                 ('p_drop', c_f), ('seed', c_u64), ('offset', c_u64), ('residual', c_p),
                 ('ln_c1', c_p), ('ln_eps', c_f), ('ln_stats_out', c_p), ('rln_x', c_p), ('rln_stats', c_p), ('rln_gamma', c_p), ('rln_beta', c_p), ('a_rowsum', c_p), ('b_rowsum', c_p),
-                ('workspace', c_p), ('workspace_bytes', c_l)]
+                ('mask_out', c_p), ('workspace', c_p), ('workspace_bytes', c_l)]
 
 
 _SIG = {

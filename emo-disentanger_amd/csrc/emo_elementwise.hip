@@ -878,8 +878,13 @@ extern "C" int emo_sample_nucleus_step(const float* logits, int64_t rows, int64_
 }
 
 // ================================================================================================ optimizer plumbing
+// Deterministic: every block stores its partial sum in acc[1 + block] and the block that draws the last ticket adds the partials in
+// index order into acc[0] — the same bits on every data-parallel rank for the same gradient (an atomicAdd of the partials sums in
+// arrival order, and replicas then drift apart through the clip coefficient).  acc: EMO_SUMSQ_FLOATS floats, zero-initialised ONCE by
+// the caller (the ticket word acc[1025] is returned to zero by the last block).
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ acc) {
     __shared__ float red[4];
+    __shared__ int last;
     float s = 0.f;
     const int64_t n4 = n >> 2;
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < n4; it += (int64_t)gridDim.x * blockDim.x) {
@@ -891,7 +896,21 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(acc + 1 + blockIdx.x, red[0] + red[1] + red[2] + red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add((unsigned*)(acc + 1025), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        float tot = 0.f;
+        for (unsigned b = 0; b < gridDim.x; ++b) tot += __hip_atomic_load(acc + 1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc[0] = tot;
+        __hip_atomic_store((unsigned*)(acc + 1025), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 extern "C" int emo_sumsq(const float* x, int64_t n, float* acc, emo_stream_t stream) {
     EMO_CHECK(x && acc && n > 0 && ((uintptr_t)x & 15) == 0, "emo_sumsq: bad args (x must be 16-B aligned)");

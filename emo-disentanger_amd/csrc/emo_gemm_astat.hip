@@ -1,0 +1,340 @@
+// A-stationary bf16 GEMM for the K = 512 products of the Performer layer (QKV / out-projection / FFN1 forward, FFN2 and
+// out-projection dgrad against transposed weight mirrors):  C[M,N] = epilogue(A[M,512] . B[N,512]^T), M = B*T tokens.
+//
+// Why another kernel: with K = 512 a 128x128 (or 256x256) output tile has only 8-16 K steps, so the tile prologue (first
+// operand tiles from HBM) and its epilogue are a large fixed cost per tile, and the 128^2 tile re-fetches its A rows from L2
+// for every 128 output columns in half-line (64-B) pieces (measured r01: 550-640 TFLOP/s in the training step).
+// Here the reduction dimension is short enough to keep the A operand STATIONARY IN REGISTERS:
+//   * a workgroup = 4 waves owns a 128-row panel; each wave holds its 32 rows x 512 k as MFMA operand fragments
+//     (2 x 16 fragments = 128 VGPRs), loaded ONCE from HBM straight into the fragment layout;
+//   * the block then sweeps ALL N output columns in 64-column tiles: the weight rows stream through a 4-slot LDS ring
+//     (one slot = 64 rows x 128 k = 16 KB, LDS-DMA `global_load_lds`, counted s_waitcnt vmcnt + raw s_barrier, never 0 in the
+//     loop), so the main loop is ONE pipeline of 4 * N/64 stages with one barrier per 32 MFMAs per wave and no A traffic
+//     at all: per CU only 32 B/clk of L2 reads at the MFMA peak;
+//   * the 32 x 64 accumulator tile of a wave leaves straight from registers: the weight rows of the four B fragments are
+//     permuted so that a lane owns 8 CONSECUTIVE output columns per fragment pair -> 16-B stores (bf16), 16-B residual /
+//     mask loads, half the dropout hashes; bias comes from an LDS copy (no VMEM load in the loop -> the compiler never
+//     drains the DMA ring);
+//   * two workgroups per CU (72 KB LDS, <= 256 VGPRs): one block's panel load / epilogue stores overlap the other's MFMAs.
+// LDS image of a slot: [64 rows][16 x 16-B chunks], physical chunk = logical ^ swz(row), swz(row) = (row & 3) | ((row >> 1) & 12):
+// conflict-free for the permuted-row ds_read_b128 pattern (checked against the b128 lane groups of the guide's LDS table).
+// The DMA writes LDS lane-linearly, so the swizzle is applied to the per-lane SOURCE address and again on the read.
+#include "emo_gemm_epi.h"
+
+namespace {
+constexpr int AS_K = 512, AS_BM = 128, AS_BN = 64, AS_KS = 128, AS_SLOT = AS_BN * AS_KS * 2, AS_RING = 4 * AS_SLOT;
+constexpr int AS_MAXN = 2048;                                   // bias copy in LDS: 8 KB
+
+__device__ __forceinline__ int as_swz(int row) { return (row & 3) | ((row >> 1) & 12); }
+// tile row (= output column inside the 64-column tile) that MFMA fragment f reads for its N-index i:
+// the lane with N-indices 4g..4g+3 of fragments 2h and 2h+1 then owns columns 32h + 8g .. +7
+__device__ __forceinline__ int as_nrow(int f, int i) { return 32 * (f >> 1) + 8 * (i >> 2) + 4 * (f & 1) + (i & 3); }
+
+template <int N> __device__ __forceinline__ void as_wait();
+template <> __device__ __forceinline__ void as_wait<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <> __device__ __forceinline__ void as_wait<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+template <> __device__ __forceinline__ void as_wait<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+template <> __device__ __forceinline__ void as_wait<12>() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+template <> __device__ __forceinline__ void as_wait<16>() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+
+// Epilogue operands (residual / mask rows) are fetched by inline-asm loads half a stage before the epilogue: hipcc does not see
+// them, so it cannot answer them with the `s_waitcnt vmcnt(0)` that would drain the DMA ring at every column tile; the counted
+// wait that covers them is `as_pin` (the "+v" operands order every use of the registers behind the wait).
+template <int IMM> __device__ __forceinline__ u32x4 as_load16(const char* sbase, uint32_t voff);   // wave-uniform base + per-lane 32-bit offset + immediate
+template <> __device__ __forceinline__ u32x4 as_load16<0>(const char* sbase, uint32_t voff) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+    return r;
+}
+template <> __device__ __forceinline__ u32x4 as_load16<64>(const char* sbase, uint32_t voff) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+    return r;
+}
+template <int IMM> __device__ __forceinline__ uint32_t as_load1(const char* sbase, uint32_t voff);
+template <> __device__ __forceinline__ uint32_t as_load1<0>(const char* sbase, uint32_t voff) {
+    uint32_t r;
+    asm volatile("global_load_ubyte %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+    return r;
+}
+template <> __device__ __forceinline__ uint32_t as_load1<4>(const char* sbase, uint32_t voff) {
+    uint32_t r;
+    asm volatile("global_load_ubyte %0, %1, %2 offset:4" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+    return r;
+}
+// Stores with an SGPR base + 32-bit per-lane offset (hipcc otherwise keeps one 64-bit per-lane pointer per output tensor live across the
+// whole loop, which is what pushed this kernel over 256 VGPRs).  boff: BYTE offset of the lane.
+__device__ __forceinline__ void as_store16(const void* sbase, uint32_t boff, u32x4 d) {
+    asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void as_store16_o16(const void* sbase, uint32_t boff, u32x4 d) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:16" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void as_store1(const void* sbase, uint32_t boff, uint32_t d) {
+    asm volatile("global_store_byte %0, %1, %2" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
+}
+template <typename OutT> __device__ __forceinline__ void as_store_row8(const OutT* sbase, uint32_t eoff, const float (&v)[8]) {
+    if constexpr (sizeof(OutT) == 4) {
+        as_store16(sbase, eoff * 4, (u32x4){__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1]), __builtin_bit_cast(uint32_t, v[2]), __builtin_bit_cast(uint32_t, v[3])});
+        as_store16_o16(sbase, eoff * 4, (u32x4){__builtin_bit_cast(uint32_t, v[4]), __builtin_bit_cast(uint32_t, v[5]), __builtin_bit_cast(uint32_t, v[6]), __builtin_bit_cast(uint32_t, v[7])});
+    } else {
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+        as_store16(sbase, eoff * 2, __builtin_bit_cast(u32x4, o));
+    }
+}
+template <int N> __device__ __forceinline__ void as_pin(u32x4 (&r)[4]);
+template <> __device__ __forceinline__ void as_pin<4>(u32x4 (&r)[4]) { asm volatile("s_waitcnt vmcnt(4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) :: "memory"); }
+template <int N> __device__ __forceinline__ void as_pin1(uint32_t (&r)[4]);
+template <> __device__ __forceinline__ void as_pin1<4>(uint32_t (&r)[4]) { asm volatile("s_waitcnt vmcnt(4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) :: "memory"); }
+template <> __device__ __forceinline__ void as_pin1<0>(uint32_t (&r)[4]) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) :: "memory"); }
+template <> __device__ __forceinline__ void as_pin<0>(u32x4 (&r)[4]) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) :: "memory"); }
+
+__device__ __forceinline__ void as_unpack8(const u32x4& r, float (&t)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        t[2 * i] = __builtin_bit_cast(float, r[i] << 16);
+        t[2 * i + 1] = __builtin_bit_cast(float, r[i] & 0xFFFF0000u);
+    }
+}
+
+// One 8-column group of one row.  Addresses are (wave-uniform 64-bit base) + (per-lane 32-bit element offset) so that every access uses the
+// SGPR-base addressing form (no per-lane 64-bit pointers: the kernel lives at the 256-VGPR edge).
+//   ub = m0 * ldc + n_tile0 (+32 h)   lo = row_in_wave * ldc + ecol           (C / aux_out / mul_aux / residual, elements)
+//   nb = n_tile0 + 32 h               (bias / columns)                           db = m0 * N + nb, dl = row_in_wave * N + ecol (dropout index)
+// pre_bits: the mask byte already in a register (inline-asm prefetch)
+template <typename OutT, bool PRE_BITS>
+__device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ C, int64_t ub, uint32_t lo, int nb, int ecol, int64_t db, uint32_t dl,
+                                        int64_t mb, uint32_t ml, float (&v)[8], const float* bias_lds, uint32_t pre_bits) {
+    // (the bias is already in the accumulators: they START from it)
+    if (ep.aux_out) as_store_row8<OutT>((const OutT*)ep.aux_out + ub, lo, v);
+    if (ep.act == EMO_ACT_RELU) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+    } else if (ep.act == EMO_ACT_GELU_NEW) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = gelu_new_f(v[i]);
+    }
+    if (ep.mul_mode == EMO_MUL_BITMASK) {
+        const uint32_t bits = PRE_BITS ? pre_bits : (uint32_t)((const uint8_t*)ep.mul_aux)[mb + ml];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= ((bits >> i) & 1u) ? ep.mul_scale : 0.f;
+    } else if (ep.mul_mode != EMO_MUL_NONE) {
+        float t[8];
+        {
+            float t0[4], t1[4];
+            Out4<OutT>::load((const OutT*)ep.mul_aux + ub + lo, t0);
+            Out4<OutT>::load((const OutT*)ep.mul_aux + ub + lo + 4, t1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { t[i] = t0[i]; t[4 + i] = t1[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (t[i] != 0.f ? ep.mul_scale : 0.f) : dgelu_new_f(t[i]);
+    }
+    if (ep.drop.thr16) {
+        float d0[4], d1[4];
+        const uint64_t idx = (uint64_t)db + dl;
+        drop_mult4(ep.drop, idx, d0);
+        drop_mult4(ep.drop, idx + 4, d1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] *= d0[i]; v[4 + i] *= d1[i]; }
+    }
+    if (ep.mask_out) {                                            // 1 bit per output: (value after act / dropout) != 0
+        uint32_t bits = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bits |= (v[i] != 0.f ? 1u : 0u) << i;
+        as_store1(ep.mask_out + mb, ml, bits);
+    }
+    if (ep.residual) {
+        float t[8];
+        {
+            float t0[4], t1[4];
+            Out4<OutT>::load((const OutT*)ep.residual + ub + lo, t0);
+            Out4<OutT>::load((const OutT*)ep.residual + ub + lo + 4, t1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { t[i] = t0[i]; t[4 + i] = t1[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += t[i];
+    }
+#ifdef EMO_DIAG
+    if (ep.ablate == 1) return;                                   // diagnostics: no output stores
+#endif
+    as_store_row8<OutT>(C + ub, lo, v);
+}
+
+// BITS: the 1-bit mask operand (EMO_MUL_BITMASK, 1 byte per 8 columns) is prefetched by inline-asm loads half a stage before the epilogue.
+// (16-B residual / mask rows stay plain loads in the epilogue: prefetching them needs 16 more registers than the 256 the kernel has, and a
+// spilled inline-asm destination would be copied before its data arrives.)
+template <typename OutT, bool BITS>
+__global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                           OutT* __restrict__ C, int64_t M, int64_t N, EpiParams ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [4 slots x 16 KB ring][bias: N floats]
+    float* bias_lds = (float*)(smem + AS_RING);                   // bias (or zeros): the accumulators of every column tile start from it
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t m0 = (int64_t)blockIdx.x * AS_BM + wave * 32;
+    const int n_tiles = (int)(N / AS_BN), T = n_tiles * 4;
+
+    // bias -> registers first (oldest VMEM ops), -> LDS before the loop
+    float bv[AS_MAXN / 256];
+#pragma unroll
+    for (int q = 0; q < AS_MAXN / 256; ++q) bv[q] = (ep.bias && tid + 256 * q < (int)N) ? ep.bias[tid + 256 * q] : 0.f;
+
+    // ---- the wave's 32 x 512 slice of A, directly in MFMA operand layout (lane: row lane%16, 8 consecutive k at 8*(lane/16))
+    bf16x8 a[2][16];
+    {
+        const bf16_t* ap = A + (m0 + (lane & 15)) * lda + (lane >> 4) * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) a[i][ks] = *(const bf16x8*)(ap + (int64_t)i * 16 * lda + ks * 32);
+    }
+    // ---- per-lane constants of the weight stream
+    uint32_t src[4];                                              // byte offsets of this lane's four 16-B pieces of a slot (source side, swizzled)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int row = 4 * (wave * 4 + jj) + (lane >> 4);
+        src[jj] = (uint32_t)((row * ldb + (((lane & 15) ^ as_swz(row)) << 3)) * 2);
+    }
+    uint32_t rd[4];                                               // byte offset inside a slot of fragment f at k-step 0; k-step ks: ^ (ks << 6)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {                                 // ((4 ks + c) ^ z) << 4 == (((c ^ z) << 4)) ^ (ks << 6): the k step only flips bits 6-7
+        const int row = as_nrow(f, lane & 15);
+        rd[f] = (uint32_t)(row * 256 + (((lane >> 4) ^ as_swz(row)) << 4));
+    }
+    const char* gB = (const char*)B;                              // wave-uniform: start of the NEXT stage to issue
+    const int64_t tile_step = (int64_t)AS_BN * ldb * 2 - 3 * AS_KS * 2;
+    auto issue = [&](int slot) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + src[jj]),
+                                             (__attribute__((address_space(3))) void*)(smem + slot * AS_SLOT + (wave * 4 + jj) * 1024), 16, 0, 0);
+    };
+    auto frags = [&](int slot, int ks, bf16x8 (&bf)[4]) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) bf[f] = *(const bf16x8*)(smem + slot * AS_SLOT + (rd[f] ^ (uint32_t)(ks << 6)));
+    };
+    // prologue: stages 0..2 (always exist: T >= 4)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        issue(s);
+        gB += AS_KS * 2;
+    }
+    int issued = 3;                                               // stages issued so far; stage s lives in slot s & 3 (4 stages per column tile)
+#pragma unroll
+    for (int q = 0; q < AS_MAXN / 256; ++q)
+        if (tid + 256 * q < (int)N) bias_lds[tid + 256 * q] = bv[q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    as_wait<8>();                                                 // A fragments + stage 0 landed (stages 1, 2 may be in flight)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // B fragments: 4 rotating register sets (step g of a column tile computes with set g & 3 and prefetches step g + 2 into set (g + 2) & 3,
+    // so three sets are live: the LDS round trip is covered by 16 MFMAs of the wave itself, not only by the partner wave)
+    bf16x8 bq[4][4];
+    frags(0, 0, bq[0]);
+    frags(0, 1, bq[1]);
+    // Loop invariant at the top of stage s: stage s has landed for every wave and its first fragments are in `bf`; stages s+1, s+2
+    // are in flight.  The wait + barrier + refill for stage s+1 sits in the MIDDLE of stage s (between its 2nd and 3rd k step), so no
+    // LDS-latency bubble follows a barrier, and the first fragments of stage s+1 are read under the last MFMAs of stage s.
+    // The body is branch-free: past the last stage the refill re-fetches the last column tile (harmless, drained before exit) so that
+    // every wait count is a constant.
+    const int ecol = 8 * (lane >> 4);
+    const uint32_t boff[2] = {(uint32_t)((lane & 15) * (N >> 3) + (lane >> 4)), (uint32_t)(((lane & 15) + 16) * (N >> 3) + (lane >> 4))};
+    const uint32_t eoff2[2] = {(uint32_t)((lane & 15) * ep.ldc + ecol), (uint32_t)(((lane & 15) + 16) * ep.ldc + ecol)};          // elements
+    const uint32_t doff[2] = {(uint32_t)((lane & 15) * N + ecol), (uint32_t)(((lane & 15) + 16) * N + ecol)};
+    for (int nt = 0; nt < n_tiles; ++nt) {
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {                             // accumulators start from the bias of their 4 columns (zeros in LDS without a bias)
+            const f32x4 b4 = *(const f32x4*)(bias_lds + nt * AS_BN + 32 * (f >> 1) + 4 * (f & 1) + ecol);
+            acc[0][f] = b4;
+            acc[1][f] = b4;
+        }
+        uint32_t preb[4];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks == 2) {
+                    if (BITS && kc == 3) {                        // the four mask bytes of this column tile: youngest VMEM ops at the wait below
+                        const char* op = (const char*)ep.mul_aux + m0 * (N >> 3) + nt * (AS_BN / 8);          // wave-uniform
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            preb[i * 2 + 0] = as_load1<0>(op, boff[i]);
+                            preb[i * 2 + 1] = as_load1<4>(op, boff[i]);
+                        }
+                        as_wait<8>();
+                    } else {
+#ifdef EMO_DIAG
+                        if (ep.ablate != 2)
+#endif
+                        as_wait<4>();                             // stage s+1 landed; stage s+2 (4 DMA ops) may stay in flight
+                    }
+#ifdef EMO_DIAG
+                    if (ep.ablate != 3)
+#endif
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+#ifdef EMO_DIAG
+                    if (ep.ablate != 2)
+#endif
+                    issue((kc + 3) & 3);                          // refill the slot of stage s-1: every wave is past it
+                    ++issued;
+                    gB += ((issued & 3) != 0) ? (int64_t)(AS_KS * 2) : ((issued >> 2) < n_tiles ? tile_step : (int64_t)(-3 * AS_KS * 2));
+                }
+                {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int g2 = kc * 4 + ks + 2;              // step to prefetch (compile-time after unrolling); steps 16, 17 = the next column tile's 0, 1
+                    frags((g2 >> 2) & 3, g2 & 3, bq[g2 & 3]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][f], a[i][kc * 4 + ks], acc[i][f], 0, 0, 0);
+            }
+        }
+        // ---- the wave's 32 x 64 outputs of this column tile, straight from the accumulators
+        if (BITS) as_pin1<4>(preb);                               // one refill (4 DMA ops) was issued after the mask bytes
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float v[8] = {acc[i][2 * h][0], acc[i][2 * h][1], acc[i][2 * h][2], acc[i][2 * h][3],
+                              acc[i][2 * h + 1][0], acc[i][2 * h + 1][1], acc[i][2 * h + 1][2], acc[i][2 * h + 1][3]};
+                const int nb = nt * AS_BN + 32 * h;
+                uint32_t lo = eoff2[i];
+                asm volatile("" : "+v"(lo));                     // opaque per tile: keeps (base + lane offset) out of loop-invariant 64-bit VGPR pointers
+                as_epi8<OutT, BITS>(ep, C, m0 * ep.ldc + nb, lo, nb, ecol, m0 * N + nb, doff[i], m0 * (N >> 3) + (nb >> 3), boff[i], v, bias_lds,
+                                    preb[i * 2 + h]);
+                __builtin_amdgcn_sched_barrier(0);               // one 8-column group at a time: keeps the epilogue's temporaries out of the register peak
+            }
+    }
+    as_wait<0>();                                                 // the run-ahead refills past the last stage must land before the LDS is released
+}
+}  // namespace
+
+bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int dtype_out, int64_t M, int64_t N, int64_t K,
+                        const EpiParams& ep, hipStream_t st) {
+    const bool off = getenv("EMO_GEMM_NO_ASTAT") != nullptr;      // (read per call: the parity test toggles it in-process)
+    if (off || K != AS_K || (M % AS_BM) != 0 || (N % AS_BN) != 0 || N > AS_MAXN || N < AS_BN) return false;
+    if (ep.atomic || ep.accumulate || ep.ws_stride || ep.a_rowsum || ep.b_rowsum || ep.ln_c1 || ep.rln_x) return false;
+    if ((ep.mask_out || ep.mul_mode == EMO_MUL_BITMASK) && dtype_out != EMO_BF16) return false;
+    if ((lda & 7) || (ldb & 7) || (ep.ldc & 7) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return false;
+    if ((uint64_t)(AS_BN * ldb + AS_K) * 2 >= 0xFFFF0000ull) return false;
+    const size_t lds = AS_RING + AS_MAXN * sizeof(float);
+    dim3 grid((unsigned)(M / AS_BM));
+#define AS_LAUNCH(OutT, BITS)                                                                                                              \
+    do {                                                                                                                                  \
+        auto k = gemm_astat_kernel<OutT, BITS>;                                                                                           \
+        static bool attr = false;                                                                                                         \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }      \
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, A, lda, B, ldb, (OutT*)C, M, N, ep);                                              \
+    } while (0)
+    if (dtype_out == EMO_F32) AS_LAUNCH(float, false);
+    else if (ep.mul_mode == EMO_MUL_BITMASK) AS_LAUNCH(bf16_t, true);
+    else AS_LAUNCH(bf16_t, false);
+#undef AS_LAUNCH
+    return true;
+}

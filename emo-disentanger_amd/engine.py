@@ -69,7 +69,7 @@ class ParamStore:
                 p.data = view
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
         self._fused = fused
-        self._mirror_version = -1
+        self._mirror_version, self._mirror_epoch, self._wT = -1, 0, {}
         self._first, self._last = named[0][1], named[-1][1]
         self._plist = [p for _, p in named]
 
@@ -92,10 +92,23 @@ class ParamStore:
             if sig != self._mirror_version:
                 ops.cast(self.flat32, self.flat16)
                 self._mirror_version = sig
+                self._mirror_epoch += 1
 
     def mark_mirror_fresh(self):
         """The caller's kernel wrote fp32 master and bf16 mirror together (fused Adam)."""
         self._mirror_version = self._write_signal()
+        self._mirror_epoch += 1
+
+    def wT(self, name):
+        """bf16 TRANSPOSED copy [in, out] of the nn.Linear weight `name` ([out, in]), refreshed when the mirror changes: the dgrad
+        dX = dY W then is the same k-contiguous NT product as a forward (the K = 512 dgrads run on the A-stationary kernel)."""
+        ent = self._wT.get(name)
+        if ent is None:
+            ent = self._wT[name] = [torch.empty(self.shapes[name][::-1], device=self.device, dtype=torch.bfloat16), -1]
+        if ent[1] != self._mirror_epoch:
+            ent[0].copy_(self.w(name).t())
+            ent[1] = self._mirror_epoch
+        return ent[0]
 
     def invalidate_mirror(self):
         self._mirror_version = -1
@@ -185,11 +198,15 @@ def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save):
     x1 = ops.gemm(attn, ps.w(pfx + 'attention.out_projection.weight'), bias=ps.f32(pfx + 'attention.out_projection.bias'),
                   p_drop=p, seed=seed, offset=off + 1, residual=x)
     h1, m1, r1 = ops.layernorm_fwd(x1, ps.f32(pfx + 'norm1.weight'), ps.f32(pfx + 'norm1.bias'))
-    f = ops.gemm(h1, ps.w(pfx + 'linear1.weight'), bias=ps.f32(pfx + 'linear1.bias'), act=ops.ACT_RELU, p_drop=p, seed=seed, offset=off + 2)
+    W1 = ps.w(pfx + 'linear1.weight')
+    # 1-bit relu.dropout mask for the FFN2 dgrad (1/16 of the bytes of re-reading f), when the shape runs on the A-stationary kernel
+    fmask = torch.empty(x.shape[0], W1.shape[0] // 8, device=x.device, dtype=torch.uint8) \
+        if (save is not None and ops.gemm_bitmask_ok(x.shape[0], W1.shape[0], D, h1.dtype, h1.dtype)) else None
+    f = ops.gemm(h1, W1, bias=ps.f32(pfx + 'linear1.bias'), act=ops.ACT_RELU, p_drop=p, seed=seed, offset=off + 2, mask_out=fmask)
     x2 = ops.gemm(f, ps.w(pfx + 'linear2.weight'), bias=ps.f32(pfx + 'linear2.bias'), p_drop=p, seed=seed, offset=off + 3, residual=h1)
     out, m2, r2 = ops.layernorm_fwd(x2, ps.f32(pfx + 'norm2.weight'), ps.f32(pfx + 'norm2.bias'))
     if save is not None:
-        save.t = dict(x=x, qkv=qkv, attn=attn, den=den, x1=x1, m1=m1, r1=r1, h1=h1, f=f, x2=x2, m2=m2, r2=r2, omega=omega)
+        save.t = dict(x=x, qkv=qkv, attn=attn, den=den, x1=x1, m1=m1, r1=r1, h1=h1, f=f, fmask=fmask, x2=x2, m2=m2, r2=r2, omega=omega)
     return out
 
 
@@ -255,7 +272,13 @@ def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
     if dyd is None:
         dyd = g2
     _wgrad(ps, pfx + 'linear2.weight', pfx + 'linear2.bias', dyd, s['f'], bias_done=True)
-    df = ops.gemm(dyd, ps.w(pfx + 'linear2.weight'), b_trans=True, mul_aux=s['f'], mul_mode=ops.MUL_NONZERO, mul_scale=inv)
+    bf = ps.flat16 is not None
+    if bf and s['fmask'] is not None:
+        df = ops.gemm(dyd, ps.wT(pfx + 'linear2.weight'), mul_aux=s['fmask'], mul_mode=ops.MUL_BITMASK, mul_scale=inv)
+    elif bf:     # K = 512 dgrads against the transposed mirror (NT, A-stationary kernel)
+        df = ops.gemm(dyd, ps.wT(pfx + 'linear2.weight'), mul_aux=s['f'], mul_mode=ops.MUL_NONZERO, mul_scale=inv)
+    else:
+        df = ops.gemm(dyd, ps.w(pfx + 'linear2.weight'), b_trans=True, mul_aux=s['f'], mul_mode=ops.MUL_NONZERO, mul_scale=inv)
     _wgrad(ps, pfx + 'linear1.weight', pfx + 'linear1.bias', df, s['h1'])
     dh1 = ops.gemm(df, ps.w(pfx + 'linear1.weight'), b_trans=True, residual=g2)
     g1, da = ops.layernorm_bwd(dh1, s['x1'], ps.f32(pfx + 'norm1.weight'), s['m1'], s['r1'], ps.g(pfx + 'norm1.weight'), ps.g(pfx + 'norm1.bias'),
@@ -263,7 +286,7 @@ def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
     if da is None:
         da = g1
     _wgrad(ps, pfx + 'attention.out_projection.weight', pfx + 'attention.out_projection.bias', da, s['attn'], bias_done=True)
-    dattn = ops.gemm(da, ps.w(pfx + 'attention.out_projection.weight'), b_trans=True)
+    dattn = ops.gemm(da, ps.wT(pfx + 'attention.out_projection.weight')) if bf else ops.gemm(da, ps.w(pfx + 'attention.out_projection.weight'), b_trans=True)
     qkv = s['qkv']
     dq, dk, dv = ops.favor_attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], s['omega'], s['attn'], dattn, s['den'], B, T, H)
     dqkv = dq._base if dq._base is not None else torch.cat([dq, dk, dv], 1)

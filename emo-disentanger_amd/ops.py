@@ -8,13 +8,13 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU_NEW, ACT_NONE, ACT_RELU, BF16, F32, MUL_DGELU_NEW, MUL_NONE, MUL_NONZERO, Epilogue, check,
+from ._lib import (ACT_GELU_NEW, ACT_NONE, ACT_RELU, BF16, F32, MUL_BITMASK, MUL_DGELU_NEW, MUL_NONE, MUL_NONZERO, Epilogue, check,
                    dtype_code, lib, ptr, stream)
 
 __all__ = ['gemm', 'colsum', 'embed_fwd', 'embed_bwd', 'layernorm_fwd', 'layernorm_bwd', 'dropout_apply', 'favor_attn_fwd',
            'favor_attn_bwd', 'favor_decode_step', 'favor_draw_omega', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'relpos_attn_fwd', 'relpos_attn_bwd', 'relpos_attn_decode', 'xent_fwd',
            'xent_bwd', 'argmax', 'sample_nucleus', 'sample_nucleus_step', 'accuracy_counts', 'sumsq', 'clip_coef', 'adam_step', 'cast',
-           'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW']
+           'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW', 'MUL_BITMASK', 'gemm_bitmask_ok']
 
 
 def _c(t):
@@ -50,7 +50,7 @@ def _workspace(kind, device, need):
 
 def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumulate=False, bias=None, act=ACT_NONE,
          aux_out=None, mul_aux=None, mul_mode=MUL_NONE, mul_scale=1.0, p_drop=0.0, seed=0, offset=0, residual=None,
-         ln_c1=None, ln_eps=1e-5, ln_stats_out=None, rln=None, a_rowsum=None, b_rowsum=None):
+         ln_c1=None, ln_eps=1e-5, ln_stats_out=None, rln=None, a_rowsum=None, b_rowsum=None, mask_out=None):
     """C[M,N] = epilogue(op(A) @ op(B));  a_trans: A stored [K,M];  b_trans=False: B stored [N,K] (nn.Linear),
     b_trans=True: B stored [K,N] (HF Conv1D).  ln_c1 / ln_stats_out / rln: LayerNorm folded around a decode-step GEMM (include/emo_hip.h)."""
     K, M = (A.shape if a_trans else A.shape[::-1])
@@ -65,9 +65,11 @@ def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumu
     rx, rstats, rgamma, rbeta = rln if rln is not None else (None, None, None, None)     # residual = LayerNorm(rx) from exported statistics
     assert rx is None or (rx.dtype == out.dtype and _rows(rx) == _rows(out))
     epi = Epilogue(ptr(bias), act, ptr(aux_out), ptr(mul_aux), mul_mode, mul_scale, p_drop, seed, offset, ptr(residual),
-                   ptr(ln_c1), ln_eps, ptr(ln_stats_out), ptr(rx), ptr(rstats), ptr(rgamma), ptr(rbeta), ptr(a_rowsum), ptr(b_rowsum), ptr(ws), ws_bytes)
-    for t in (aux_out, mul_aux, residual):
+                   ptr(ln_c1), ln_eps, ptr(ln_stats_out), ptr(rx), ptr(rstats), ptr(rgamma), ptr(rbeta), ptr(a_rowsum), ptr(b_rowsum), ptr(mask_out), ptr(ws), ws_bytes)
+    for t in (aux_out, residual) + (() if mul_mode == MUL_BITMASK else (mul_aux,)):
         assert t is None or (t.dtype == out.dtype and _rows(t) == _rows(out))
+    for t in (mask_out,) + ((mul_aux,) if mul_mode == MUL_BITMASK else ()):
+        assert t is None or (t.dtype == torch.uint8 and t.is_contiguous() and t.shape == (M, N // 8) and gemm_bitmask_ok(M, N, K, A.dtype, out.dtype))
     assert bias is None or bias.dtype == torch.float32
     if GEMM_TIMING is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -76,9 +78,17 @@ def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumu
                        dtype_code(A.dtype), dtype_code(out.dtype), int(accumulate), ctypes.byref(epi), stream()))
     if GEMM_TIMING is not None:
         e1.record()
-        GEMM_TIMING.append((('T' if a_trans else 'N') + ('N' if b_trans else 'T') + ('/K>1024' if K > 1024 and not a_trans and not b_trans else ''), e0, e1, 2.0 * M * N * K,
+        kind = ('T' if a_trans else 'N') + ('N' if b_trans else 'T')
+        if kind == 'NT':
+            kind += '/K>1024' if K > 1024 else ('/K=512' if (K == 512 and A.dtype == torch.bfloat16 and M % 128 == 0 and N % 64 == 0 and 64 <= N <= 2048) else '')
+        GEMM_TIMING.append((kind, e0, e1, 2.0 * M * N * K,
                             (M * K + N * K) * A.element_size() + M * N * out.element_size(), (M, N, K)))
     return out
+
+
+def gemm_bitmask_ok(M, N, K, in_dtype, out_dtype):
+    """Shape class in which emo_gemm writes / reads the 1-bit epilogue mask (mask_out / MUL_BITMASK): the A-stationary K = 512 kernel."""
+    return in_dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and K == 512 and M % 128 == 0 and N % 64 == 0 and 64 <= N <= 2048
 
 
 def colsum(X, out=None, accumulate=False):
@@ -347,7 +357,12 @@ def accuracy_counts(logits, tgt, chord, melody, pad):
     return counts
 
 
+SUMSQ_FLOATS = 1026     # emo_hip.h: EMO_SUMSQ_FLOATS
+
+
 def sumsq(x, acc):
+    """acc[0] = sum(x*x) in a fixed summation order; acc: SUMSQ_FLOATS fp32 scratch, zeroed once by the caller."""
+    assert acc.dtype == torch.float32 and acc.numel() >= SUMSQ_FLOATS
     check(lib.emo_sumsq(ptr(x), x.numel(), ptr(acc), stream()))
 
 

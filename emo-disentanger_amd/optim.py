@@ -30,7 +30,7 @@ class FusedAdam(torch.optim.Optimizer):
         if self._m is None or self._m.numel() != ps.total or self._m.device != ps.device:
             self._m = torch.zeros(ps.total, device=ps.device)
             self._v = torch.zeros(ps.total, device=ps.device)
-            self._ss = torch.zeros(1, device=ps.device)
+            self._ss = torch.zeros(ops.SUMSQ_FLOATS, device=ps.device)      # [0] = sum of squares, the rest: the kernel's ordered partials
             self._coef = torch.ones(1, device=ps.device)
         return ps
 
@@ -43,11 +43,10 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         weighted = self.token_weighted and self.world_size > 1
         pre = 1.0 if weighted else 1.0 / self.world_size
-        self._ss.zero_()
         ops.sumsq(ps.flat_grad, self._ss)
         ops.clip_coef(self._ss, float(self.max_grad_norm) if self.max_grad_norm else 3.0e38, pre, self._coef,
                       denom=ps.flat_grad_ext[ps.total:ps.total + 1] if weighted else None)
-        self.last_grad_norm = self._ss           # device scalar: sqrt(.)*pre is the global grad norm (no host sync here)
+        self.last_grad_norm = self._ss[0:1]      # device scalar: sqrt(.)*pre is the global grad norm (no host sync here)
         self._step += 1
         ops.adam_step(ps.flat32, ps.flat_grad, self._m, self._v, ps.flat16, g['lr'], g['betas'][0], g['betas'][1], g['eps'], self._step,
                       self._coef)

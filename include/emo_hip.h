@@ -33,7 +33,7 @@ typedef void* emo_stream_t; /* hipStream_t */
 enum { EMO_OK = 0, EMO_ERR_INVALID = -1, EMO_ERR_LAUNCH = -2, EMO_ERR_UNSUPPORTED = -3 };
 enum { EMO_F32 = 0, EMO_BF16 = 1, EMO_I64 = 2 /* emo_comm_* payloads only */ };
 enum { EMO_ACT_NONE = 0, EMO_ACT_RELU = 1, EMO_ACT_GELU_NEW = 2 };
-enum { EMO_MUL_NONE = 0, EMO_MUL_NONZERO = 1, EMO_MUL_DGELU_NEW = 2 };
+enum { EMO_MUL_NONE = 0, EMO_MUL_NONZERO = 1, EMO_MUL_DGELU_NEW = 2, EMO_MUL_BITMASK = 3 };
 
 int emo_version(void);
 const char* emo_last_error(void);
@@ -55,7 +55,8 @@ typedef struct {
     int act;              /* EMO_ACT_* */
     void* aux_out;        /* NULL or [M,N] (dtype_out, ld=ldc): value before the activation */
     const void* mul_aux;  /* NULL or [M,N] (dtype_out, ld=ldc), see mul_mode */
-    int mul_mode;         /* EMO_MUL_NONZERO: *= (mul_aux!=0)*mul_scale ; EMO_MUL_DGELU_NEW: *= gelu_new'(mul_aux) */
+    int mul_mode;         /* EMO_MUL_NONZERO: *= (mul_aux!=0)*mul_scale ; EMO_MUL_DGELU_NEW: *= gelu_new'(mul_aux) ;
+                           * EMO_MUL_BITMASK: mul_aux is a uint8 bit mask [M, N/8] as written by mask_out, *= bit ? mul_scale : 0 */
     float mul_scale;
     float p_drop;         /* dropout after the activation; element index = m*N+n */
     uint64_t seed, offset;
@@ -76,6 +77,9 @@ typedef struct {
     float* a_rowsum;      /* NULL or [M] fp32: += sum_k op(A)[m][k]; needs a_trans.  For a weight gradient dW = dY^T X this is the bias
                            * gradient (column sums of dY), taken inside the GEMM from the operand fragments instead of a second pass. */
     float* b_rowsum;      /* NULL or [N] fp32: += sum_k op(B)[n][k]; needs a_trans and b_trans (HF Conv1D layout, where dY is the B operand) */
+    uint8_t* mask_out;    /* NULL or [M, N/8] bytes: bit j of byte (m, n/8) = (value after act and dropout != 0) for column 8*(n/8)+j — the 1-bit
+                           * relu.dropout mask the FFN2 dgrad needs (instead of re-reading the [M,N] activation).  Only with EMO_MUL_BITMASK's
+                           * shape class: bf16 in/out, NT, K = 512, M % 128 == 0, N % 64 == 0 (the A-stationary kernel); refused elsewhere. */
     void* workspace;      /* NULL or caller scratch for split-K partial sums (plain fp32-output GEMMs = weight gradients): */
     int64_t workspace_bytes; /* with it the splits are summed in a fixed order by a reduce kernel (deterministic, no atomics);
                               * without it they are fp32 atomics into C.  Size: emo_gemm_workspace_bytes(). */
@@ -253,9 +257,11 @@ int emo_accuracy_counts(const float* logits, const int64_t* tgt, const int64_t* 
                         emo_stream_t stream);
 
 /* ------------------------------------------------------------------ optimizer plumbing (K11, SURVEY f-3)
- * sumsq: acc[0] += sum x^2.  clip_coef: coef[0] = min(1, max_norm/(sqrt(sumsq*pre*pre)+1e-6)) * pre
+ * sumsq: acc[0] = sum x^2, bitwise reproducible (fixed summation order); acc = EMO_SUMSQ_FLOATS floats of caller scratch, zeroed once
+ * before the first call (acc[1..1024] block partials, acc[1025] a ticket word the kernel returns to zero).  clip_coef: coef[0] = min(1, max_norm/(sqrt(sumsq*pre*pre)+1e-6)) * pre
  * (pre = 1/world for DP-averaged grads).  adam: torch.optim.Adam semantics (no amsgrad, wd=0),
  * grads scaled by gscale[0]; optionally refreshes the bf16 compute copy of the weights. */
+#define EMO_SUMSQ_FLOATS 1026
 int emo_sumsq(const float* x, int64_t n, float* acc, emo_stream_t stream);
 /* coef = pre' * min(1, max_norm / (sqrt(sumsq) * pre' + 1e-6)) with pre' = pre / denom[0] (denom NULL => 1): the clip of
  * torch.nn.utils.clip_grad_norm_ (train.py:79) applied to the pre-scaled gradient.  Data parallel: pre = 1/world for equal

@@ -641,9 +641,12 @@ def test_adam_and_clip_match_torch():
         p.grad = gi.clone()
         total = torch.nn.utils.clip_grad_norm_([p], 0.5)
         opt.step()
-        ss, coef = torch.zeros(1, device='cuda'), torch.zeros(1, device='cuda')
+        ss, coef = torch.zeros(ops.SUMSQ_FLOATS, device='cuda'), torch.zeros(1, device='cuda')
         ops.sumsq(gi.cuda(), ss)
-        assert abs(float(ss.sqrt()) - float(total)) < 1e-3 * float(total)
+        first = ss[0].clone()
+        ops.sumsq(gi.cuda(), ss)                                   # scratch is reusable without re-zeroing; fixed summation order => same bits
+        assert torch.equal(first, ss[0]) and float(ss[1025].view(torch.int32)) == 0
+        assert abs(float(ss[0].sqrt()) - float(total)) < 1e-3 * float(total)
         ops.clip_coef(ss, 0.5, 1.0, coef)
         ops.adam_step(pc, gi.cuda(), m, v, pb, 1e-3, 0.9, 0.999, 1e-8, step, coef)
         _close(pc, p.detach(), torch.float32, mult=2)
@@ -702,3 +705,77 @@ def test_gemm_skinny_decode_shapes(M):
         _close(out, torch.relu(A.double() @ W.double().T + bias.double()) + res.double(), dt)
         out32 = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), out_dtype=torch.float32)
         _close(out32, A.double() @ W.double().T + bias.double(), dt, mult=0.3)
+
+
+# ------------------------------------------------------------------------------------------- A-stationary K = 512 GEMM
+@pytest.mark.parametrize('M,N', [(128, 64), (384, 512), (1024, 1536), (2048, 2048)])
+@pytest.mark.parametrize('out_dt', [torch.bfloat16, torch.float32])
+def test_gemm_astat_k512_matches_reference_and_the_tiled_kernel(M, N, out_dt, monkeypatch):
+    """emo_gemm_astat.hip (A stationary in registers, weights streamed through the LDS ring) against an fp64 product, and BIT-FOR-BIT
+    against the 128^2 tiled kernel for every fused epilogue (both accumulate 16 MFMA 16x16x32 steps in k order; dropout masks are
+    indexed by m*N+n): bias, ReLU + dropout, dropout + residual, the (aux != 0) mask multiply, aux_out."""
+    ops = _ops()
+    K = 512
+    A, W = _r(M, K, seed=1, dt=torch.bfloat16).cuda(), _r(N, K, seed=2, dt=torch.bfloat16, scale=0.05).cuda()
+    bias = _r(N, seed=3).cuda()
+    res = _r(M, N, seed=4, dt=out_dt).cuda()
+    mask = (_r(M, N, seed=5) > 0.3).to(out_dt).cuda() * 1.5
+    ref = A.double() @ W.double().t()
+    cases = [dict(), dict(bias=bias), dict(bias=bias, act=ops.ACT_RELU, p_drop=0.1, seed=7, offset=3),
+             dict(bias=bias, p_drop=0.1, seed=9, offset=5, residual=res), dict(mul_aux=mask, mul_mode=ops.MUL_NONZERO, mul_scale=1.0 / 0.9),
+             dict(bias=bias, act=ops.ACT_RELU, aux_out='alloc')]
+    for kw in cases:
+        outs = []
+        for no_astat in ('', '1'):
+            if no_astat:
+                monkeypatch.setenv('EMO_GEMM_NO_ASTAT', '1')
+            else:
+                monkeypatch.delenv('EMO_GEMM_NO_ASTAT', raising=False)
+            k2 = dict(kw)
+            aux = None
+            if k2.get('aux_out') == 'alloc':
+                aux = k2['aux_out'] = torch.empty(M, N, device='cuda', dtype=out_dt)
+            outs.append((ops.gemm(A, W, out_dtype=out_dt, **k2), aux))
+        torch.cuda.synchronize()
+        (new, new_aux), (old, old_aux) = outs
+        if out_dt == torch.bfloat16 and 'bias' not in kw:
+            assert torch.equal(new, old), (sorted(kw), float((new.float() - old.float()).abs().max()))
+        elif out_dt == torch.bfloat16:        # the accumulators START from the bias here (one rounding order apart from adding it last): <= 1 bf16 ulp
+            d = (new.float() - old.float()).abs()
+            assert float((d / old.float().abs().clamp_min(0.25)).max()) <= 2 ** -7 and float((d > 0).float().mean()) < 0.02, sorted(kw)
+        else:                                 # fp32 outputs of small shapes take the split-K / register-staged kernels: same math, other summation order
+            _close(new, old, torch.float32, mult=10.0)
+        if new_aux is not None:
+            d = (new_aux.float() - old_aux.float()).abs()
+            assert float((d / old_aux.float().abs().clamp_min(0.25)).max()) <= (2 ** -7 if out_dt == torch.bfloat16 else 2e-5)
+            assert out_dt == torch.float32 or float((d > 0).float().mean()) < 0.02
+        if not kw:
+            _close(new, ref, torch.bfloat16 if out_dt == torch.bfloat16 else torch.float32, mult=1.0 if out_dt == torch.bfloat16 else 50.0)
+    monkeypatch.delenv('EMO_GEMM_NO_ASTAT', raising=False)
+    # a strided A view (the attention output / a column block of a fused projection) and a strided output view
+    big = _r(M, 3 * K, seed=6, dt=torch.bfloat16).cuda()
+    outb = torch.zeros(M, 2 * N, device='cuda', dtype=out_dt)
+    ops.gemm(big[:, K:2 * K], W, out=outb[:, N:], bias=bias)
+    _close(outb[:, N:], big[:, K:2 * K].double() @ W.double().t() + bias.double(), torch.bfloat16, mult=1.0)
+    assert float(outb[:, :N].abs().max()) == 0.0
+
+
+def test_gemm_astat_bitmask_epilogue_equals_the_activation_mask():
+    """mask_out packs (value after ReLU + dropout != 0) into 1 bit per output; EMO_MUL_BITMASK multiplies by it: the FFN2 dgrad through the
+    bit mask equals, bit for bit, the dgrad through the [M, N] activation itself (EMO_MUL_NONZERO); elsewhere the two are refused loudly."""
+    ops = _ops()
+    from emo_disentanger_amd._lib import EmoError
+    M, N, K = 640, 2048, 512
+    h, W1, b1 = _r(M, K, seed=1, dt=torch.bfloat16).cuda(), _r(N, K, seed=2, dt=torch.bfloat16, scale=0.05).cuda(), _r(N, seed=3).cuda()
+    fmask = torch.zeros(M, N // 8, device='cuda', dtype=torch.uint8)
+    f = ops.gemm(h, W1, bias=b1, act=ops.ACT_RELU, p_drop=0.1, seed=5, offset=2, mask_out=fmask)
+    f_plain = ops.gemm(h, W1, bias=b1, act=ops.ACT_RELU, p_drop=0.1, seed=5, offset=2)
+    assert torch.equal(f, f_plain)                                  # writing the mask does not change the output
+    bits = (fmask[:, :, None] >> torch.arange(8, device='cuda', dtype=torch.uint8)) & 1
+    assert torch.equal(bits.reshape(M, N).bool(), f != 0) and 0.3 < float((f != 0).float().mean()) < 0.6
+    dy, W2t = _r(M, K, seed=6, dt=torch.bfloat16).cuda(), _r(N, K, seed=7, dt=torch.bfloat16, scale=0.05).cuda()
+    a = ops.gemm(dy, W2t, mul_aux=fmask, mul_mode=ops.MUL_BITMASK, mul_scale=1.0 / 0.9)
+    b = ops.gemm(dy, W2t, mul_aux=f, mul_mode=ops.MUL_NONZERO, mul_scale=1.0 / 0.9)
+    assert torch.equal(a, b)
+    with pytest.raises((EmoError, AssertionError)):                 # outside the A-stationary shape class: refused, never ignored
+        ops.gemm(h[:100], W1, mask_out=fmask[:100])
