@@ -541,470 +541,6 @@ __global__ __launch_bounds__(256, (ST == 2 && BK == 32) ? 4 : 2) void gemm_bf16_
 }
 
 // ================================================================================================
-// bf16 MFMA kernel, v3: 256x256x64 block tile, 8 waves (2x4, wave tile 128x64 = 8x4 MFMA tiles), LDS-DMA
-// double buffer (2 x 64 KB).  PMC on v1/v2 showed the 128^2 tile is bound by the CU's vector-memory front
-// end (TA busy 61 % at only 12 B/clk/CU: half-line 64-B row pieces, 1 B of tile traffic per 64 FLOP); the
-// 256^2 tile halves the tile bytes per FLOP and fetches full 128-B lines (BK=64), and one K step carries
-// 64 MFMAs per wave (1024 MFMA cycles), enough to cover the L2 round trip of the next stage with a plain
-// double buffer: wait vmcnt(0) -> barrier -> issue stage k+1 -> compute stage k.
-constexpr int G3_M = 256, G3_N = 256, G3_K = 64, G3_OP = 32768;   // bytes per operand per stage
-
-template <bool KC>
-__device__ __forceinline__ void g3_offsets(int64_t ld, int64_t row0, int64_t nrows, int wave, int lane, uint32_t (&off)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int j = wave * 4 + i;   // wave-instruction 0..31 (1 KiB each)
-        if constexpr (KC) {
-            const int row = j * 8 + (lane >> 3), pc = lane & 7;
-            const int c = pc ^ (row & 7);
-            int64_t gr = row0 + row;
-            if (gr > nrows - 1) gr = nrows - 1;
-            off[i] = (uint32_t)((gr * ld + c * 8) * 2);
-        } else {
-            const int k = j * 2 + (lane >> 5), p16 = lane & 31;
-            const int g = (p16 >> 1) ^ swz_k(k);
-            int64_t gr = row0 + (g * 2 + (p16 & 1)) * 8;
-            if (gr > nrows - 1) gr = ((nrows - 1) >> 3) << 3;
-            off[i] = (uint32_t)(((int64_t)k * ld + gr) * 2);
-        }
-    }
-}
-__device__ __forceinline__ void g3_issue(const char* __restrict__ base, const uint32_t (&off)[4], char* stage_op, int wave) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[i]),
-                                         (__attribute__((address_space(3))) void*)(stage_op + (wave * 4 + i) * 1024), 16, 0, 0);
-}
-template <bool KC>
-__device__ __forceinline__ bf16x8 g3_frag(const char* lds, int rbase, int ks, int lane) {
-    if constexpr (KC) {
-        const int row = rbase + (lane & 15), ch = ks * 4 + (lane >> 4);
-        return *(const bf16x8*)(lds + row * 128 + ((ch ^ (row & 7)) << 4));
-    } else {
-        const int i = lane & 15, g = rbase >> 4;
-        bf16x8 v;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = ks * 32 + (lane >> 4) * 8 + h * 4 + (i >> 2);
-            const char* p = lds + k * 512 + ((g ^ swz_k(k)) << 5) + ((i & 3) << 3);
-            short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
-            bf16x4 tb = __builtin_bit_cast(bf16x4, t);
-            v[h * 4 + 0] = tb[0]; v[h * 4 + 1] = tb[1]; v[h * 4 + 2] = tb[2]; v[h * 4 + 3] = tb[3];
-        }
-        return v;
-    }
-}
-
-template <bool A_KC, bool B_KC, typename OutT>
-__global__ __launch_bounds__(512) void gemm_bf16_g3_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
-                                                           OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, int64_t k_per_split, EpiParams ep) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (32 KB A + 32 KB B)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t tiles_n = (N + G3_N - 1) / G3_N, tiles_m = (M + G3_M - 1) / G3_M;
-    int64_t tm, tn, split = 0;
-    if (ep.atomic) {
-        splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
-        if (ep.ws_stride) { C += split * ep.ws_stride; ep.atomic = 0; }
-    }
-    else tile_coords(tiles_m, tiles_n, tm, tn);
-    if (tm >= tiles_m) return;
-    const int64_t m0 = tm * G3_M, n0 = tn * G3_N;
-    const int64_t kbeg = split * k_per_split;
-    const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
-    if (kbeg >= kend) return;
-    const int nk = (int)((kend - kbeg) / G3_K);
-    const int wm = wave >> 2, wn = wave & 3;
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    uint32_t offA[4], offB[4];
-    g3_offsets<A_KC>(lda, m0, M, wave, lane, offA);
-    g3_offsets<B_KC>(ldb, n0, N, wave, lane, offB);
-    const char* gA = (const char*)A + (A_KC ? kbeg : kbeg * lda) * 2;
-    const char* gB = (const char*)B + (B_KC ? kbeg : kbeg * ldb) * 2;
-    const int64_t stepA = (A_KC ? (int64_t)G3_K : (int64_t)G3_K * lda) * 2;
-    const int64_t stepB = (B_KC ? (int64_t)G3_K : (int64_t)G3_K * ldb) * 2;
-    g3_issue(gA, offA, smem, wave);
-    g3_issue(gB, offB, smem + G3_OP, wave);
-    gA += stepA;
-    gB += stepB;
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (kt + 1 < nk) {
-            char* st = smem + ((kt + 1) & 1) * 2 * G3_OP;
-            g3_issue(gA, offA, st, wave);
-            g3_issue(gB, offB, st + G3_OP, wave);
-            gA += stepA;
-            gB += stepB;
-        }
-        const char* la = smem + (kt & 1) * 2 * G3_OP;
-        const char* lb = la + G3_OP;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[8], fb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = g3_frag<B_KC>(lb, wn * 64 + j * 16, ks, lane);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) fa[i] = g3_frag<A_KC>(la, wm * 128 + i * 16, ks, lane);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
-    }
-#pragma clang loop unroll(full)
-    for (int i = 0; i < 8; ++i)
-#pragma clang loop unroll(full)
-        for (int j = 0; j < 4; ++j) {
-            int64_t m = m0 + wm * 128 + i * 16 + (lane & 15);
-            int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-            if (m < M && n < N) epi_store4_call<OutT>(ep, C, m, n, acc[i][j], N);
-        }
-}
-
-template <bool A_KC, bool B_KC, typename OutT>
-static void launch_g3(dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int64_t M, int64_t N,
-                      int64_t K, int64_t kps, const EpiParams& ep) {
-    auto kfn = gemm_bf16_g3_kernel<A_KC, B_KC, OutT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G3_OP);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kfn, grid, dim3(512), 4 * G3_OP, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
-}
-template <typename OutT>
-static void dispatch_g3(bool akc, bool bkc, dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C,
-                        int64_t M, int64_t N, int64_t K, int64_t kps, const EpiParams& ep) {
-    if (akc && bkc) launch_g3<true, true, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-    else if (akc && !bkc) launch_g3<true, false, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-    else if (!akc && bkc) launch_g3<false, true, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-    else launch_g3<false, false, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-}
-
-// ================================================================================================
-// bf16 MFMA kernel, v6: 256x256x64 block tile, 8 waves, FOUR PHASES PER K-TILE with two wave groups running one barrier apart.
-// The 128^2 kernels above top out at ~840 TFLOP/s even at K=2048 (one barrier-synchronised {wait, read fragments, MFMA} step per
-// K-tile: every wave of the block reads LDS at the same time and then every wave issues MFMAs at the same time, so the matrix
-// pipe idles during the read sections), and the plain 256^2 double buffer (v3) is no better.  Here
-//   * the K-tile is staged as four 16-KB half-tiles (A rows 0-127 / 128-255, B cols 0-127 / 128-255) in a 2 x 64 KB ring;
-//     a wave owns 64 rows of EACH A half and 32 columns of EACH B half (wave tile 128 x 64);
-//   * one phase = one k-half (32) of one A half against all four B fragments = 16 MFMAs on 16 distinct accumulators:
-//     P1 reads B.k0 + A0.k0 (8 fragments), P2 B.k1 + A0.k1 (8), P3 A1.k0 (4), P4 A1.k1 (4).  (The first version split by
-//     quadrant, 12 / 4 / 8 / 0 fragments: the 12-fragment phase was 24 transposing reads on the wgrad layout — more than the 15
-//     outstanding LDS ops a wave can have — and took 1050 cycles against 470 for the others.)
-//   * a half-tile slot is re-staged (LDS-DMA, 2 instructions per wave) two phases after its last fragment read, one half-tile per
-//     phase: P1: B0 of t+1, P2: B1 of t+1, P3: A1 of t+1, P4: A0 of t+2 — loads live for 2-4 phases and are retired by two COUNTED
-//     waits per K-tile (P2: vmcnt(6) -> A1 of t, read in P3;  P4: vmcnt(4) -> A0, B0, B1 of t+1, read in the next P1); the queue
-//     never drains inside the loop;
-//   * waves 4-7 (the second wave of every SIMD: HW_ID.SIMD_ID of waves w and w+4 is equal) run one s_barrier behind waves 0-3:
-//     while one wave of a SIMD is in its MFMA section the other is in its read / stage section (s_setprio favours the MFMA wave).
-// Hazards (E_n = n-th barrier; group 0: R1 E1 M1 E2 R2 E3 M2 E4 R3 E5 M3 E6 R4 E7 M4 E8, group 1 the same shifted by one E):
-//   RAW: a wave's wait sits before the first barrier of its phase p (E_{2p-1} for group 0, E_{2p} for group 1); the data is first read
-//        in R_{p+1}, which group 0 starts after E_{2p}.  WAR: a slot read in R_p has its reads retired at the latest after E_{2p}
-//        (group 1's lgkmcnt before its M_p) and is re-staged in R_{p+2} or later, which group 0 starts after E_{2p+2}.
-constexpr int G6_HT = 16384, G6_STAGE = 65536;
-#ifndef G6_PROFILE
-#define G6_PROFILE 0      // 1: per-section cycle stamps (EMO_GEMM_ABLATE & 8, tools/g6_phases.py); costs registers, diagnostics builds only
-#endif
-
-template <bool KC>
-__device__ __forceinline__ void g6_offsets(int64_t ld, int64_t row0, int64_t nrows, int wave, int lane, uint32_t (&off)[2][2]) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int j = wave * 2 + i;       // wave-instruction 0..15 of the half-tile (1 KiB each)
-            if constexpr (KC) {               // [128 rows][64 k]: 8 rows x 128 B per instruction, chunk ^= row & 7
-                const int row = j * 8 + (lane >> 3), c = (lane & 7) ^ (row & 7);
-                int64_t gr = row0 + h * 128 + row;
-                if (gr > nrows - 1) gr = nrows - 1;
-                off[h][i] = (uint32_t)((gr * ld + c * 8) * 2);
-            } else {                          // [64 k][128 rows]: 4 k x 256 B per instruction, 32-B granule swizzle
-                const int k = j * 4 + (lane >> 4), p16 = lane & 15;
-                const int g = (p16 >> 1) ^ swz_k(k);
-                int64_t gr = row0 + h * 128 + (g * 2 + (p16 & 1)) * 8;
-                if (gr > nrows - 1) gr = ((nrows - 1) >> 3) << 3;
-                off[h][i] = (uint32_t)(((int64_t)k * ld + gr) * 2);
-            }
-        }
-}
-__device__ __forceinline__ void g6_issue(const char* __restrict__ base, const uint32_t (&off)[2], char* slot, int wave) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[i]),
-                                         (__attribute__((address_space(3))) void*)(slot + (wave * 2 + i) * 1024), 16, 0, 0);
-}
-#define G6_BARRIER() asm volatile("s_barrier" ::: "memory")
-#define G6_MFMA_BEGIN() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); } while (0)
-#define G6_MFMA_END() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); } while (0)
-
-// 256 x 256 accumulator tile -> global through the (idle) 128 KB of LDS, one 128-row half at a time: fp32 image [128][256] with the 16-B chunk
-// index XOR (row & 15) (fragment-layout writes conflict-free), then every thread owns 8 consecutive columns of a row (epi_row8: 16-B
-// coalesced loads / stores, 512 B or 1 KB contiguous per row).  The fragment-layout epilogue (8-B pieces, 16 rows per instruction) cost
-// ~30 us per tile here (r01: 828 -> TFLOP/s with the tile loads ablated on the K=2048 forward shape).
-template <typename OutT>
-__device__ __forceinline__ void epilogue_tile256(const EpiParams& ep, OutT* __restrict__ C, int64_t m0, int64_t n0, int64_t M, int64_t N,
-                                                 const f32x4 (&acc)[8][4], char* lds, int tid, int wr, int wc, int lane) {
-    if (ep.atomic) {
-#pragma clang loop unroll(full)
-        for (int i = 0; i < 8; ++i)
-#pragma clang loop unroll(full)
-            for (int j = 0; j < 4; ++j) {
-                const int64_t m = m0 + (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + (lane & 15);
-                const int64_t n = n0 + (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + (lane >> 4) * 4;
-                if (m < M && n < N) epi_store4_call<OutT>(ep, C, m, n, acc[i][j], N);
-            }
-        return;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wr * 64 + i * 16 + (lane & 15);
-                const int chunk = ((j >> 1) * 128 + wc * 32 + (j & 1) * 16 + (lane >> 4) * 4) >> 2;   // 16-B chunk 0..63
-                *(f32x4*)(lds + row * 1024 + ((chunk ^ (row & 15)) << 4)) = acc[4 * h + i][j];
-            }
-        __syncthreads();
-#pragma unroll 2
-        for (int it = 0; it < 8; ++it) {
-            const int idx = tid + 512 * it;
-            const int row = idx >> 5, grp = idx & 31;
-            const int64_t m = m0 + h * 128 + row, n = n0 + grp * 8;
-            if (m < M && n < N) {
-                const f32x4 lo = *(const f32x4*)(lds + row * 1024 + (((2 * grp) ^ (row & 15)) << 4));
-                const f32x4 hi = *(const f32x4*)(lds + row * 1024 + (((2 * grp + 1) ^ (row & 15)) << 4));
-                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                epi_row8<OutT>(ep, C, m, n, v, N);
-            }
-        }
-    }
-}
-
-// RS: 0 plain, 1 = a_rowsum (sum over k of A, per output row m), 2 = b_rowsum (sum over k of B, per output column n): the wgrad bias
-// gradient as one extra MFMA against an all-ones operand, on 1/tiles_n (1/tiles_m) of the K-tiles per block and one fragment per wave.
-template <bool A_KC, bool B_KC, typename OutT, int RS>
-__global__ __launch_bounds__(512) void gemm_bf16_g6_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
-                                                           OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, int64_t k_per_split, EpiParams ep) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x {A0, A1, B0, B1} x 16 KB
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t tiles_n = (N + G3_N - 1) / G3_N, tiles_m = (M + G3_M - 1) / G3_M;
-    int64_t tm, tn, split = 0;
-    if (ep.atomic) {
-        splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
-        if (ep.ws_stride) { C += split * ep.ws_stride; ep.atomic = 0; }
-    }
-    else tile_coords(tiles_m, tiles_n, tm, tn);
-    if (tm >= tiles_m) return;
-    const int64_t m0 = tm * G3_M, n0 = tn * G3_N;
-    const int64_t kbeg = split * k_per_split;
-    const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
-    if (kbeg >= kend) return;
-    const int nk = __builtin_amdgcn_readfirstlane((int)((kend - kbeg) / G3_K));
-    const int wr = wave >> 2, wc = wave & 3;
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 rsacc[2];
-    rsacc[0] = rsacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bf16_t one_b = (bf16_t)1.f;
-    const bf16x8 ones = {one_b, one_b, one_b, one_b, one_b, one_b, one_b, one_b};
-    int rs_own = RS == 1 ? (int)((kbeg / G3_K) % tiles_n) : (RS == 2 ? (int)((kbeg / G3_K) % tiles_m) : 0);
-    const int rs_me = RS == 1 ? (int)tn : (int)tm, rs_mod = RS == 1 ? (int)tiles_n : (int)tiles_m;
-
-    uint32_t offA[2][2], offB[2][2];
-    g6_offsets<A_KC>(lda, m0, M, wave, lane, offA);
-    g6_offsets<B_KC>(ldb, n0, N, wave, lane, offB);
-    const char* gA = (const char*)A + (A_KC ? kbeg : kbeg * lda) * 2;
-    const char* gB = (const char*)B + (B_KC ? kbeg : kbeg * ldb) * 2;
-    const int64_t stepA = (A_KC ? (int64_t)G3_K : (int64_t)G3_K * lda) * 2;
-    const int64_t stepB = (B_KC ? (int64_t)G3_K : (int64_t)G3_K * ldb) * 2;
-#define G6_ISSUE_A(h, t) g6_issue(gA + (int64_t)(t) * stepA, offA[h], smem + ((t) & 1) * G6_STAGE + (h) * G6_HT, wave)
-#define G6_ISSUE_B(h, t) g6_issue(gB + (int64_t)(t) * stepB, offB[h], smem + ((t) & 1) * G6_STAGE + (2 + (h)) * G6_HT, wave)
-    const bool noload = (ep.ablate & 1) != 0;     // diagnostics: no tile DMA inside the loop
-    G6_ISSUE_B(0, 0); G6_ISSUE_A(0, 0); G6_ISSUE_B(1, 0); G6_ISSUE_A(1, 0);
-    if (nk > 1) {
-        G6_ISSUE_A(0, 1);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    G6_BARRIER();
-    const int grp = (ep.ablate & 4) ? (wave & 1) : (wave >> 2);      // the two waves of a SIMD (w, w + 4) must be in different groups
-    if (grp == 1) G6_BARRIER();         // group 1 runs one barrier behind group 0
-    bf16x8 fa[4], fb[4][2];
-#if G6_PROFILE
-    const bool dbg = (ep.ablate & 8) != 0;
-    uint64_t dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dprev = dbg ? __builtin_readcyclecounter() : 0;
-#define G6_STAMP(slot) do { if (dbg) { const uint64_t c_ = __builtin_readcyclecounter(); dsum[slot] += c_ - dprev; dprev = c_; } } while (0)
-#else
-#define G6_STAMP(slot) do { } while (0)
-#endif
-#define G6_READ_B(ks)                                                                                                                  \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                                       \
-        fb[j][ks] = lfrag2<B_KC, 64>(st + (2 + (j >> 1)) * G6_HT, wc * 32 + (j & 1) * 16, ks, lane)
-#define G6_READ_A(h, ks)                                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = lfrag2<A_KC, 64>(st + (h) * G6_HT, wr * 64 + i * 16, ks, lane)
-#define G6_MMA(h, ks)                                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                       \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                                   \
-            acc[4 * (h) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i], acc[4 * (h) + i][j], 0, 0, 0)
-    // bias-gradient MFMAs against the all-ones operand: fragment i = wc of the A half (RS = 1) / fragments j = wr, 2 + wr of B (RS = 2);
-    // wave-uniform branches keep the register indices static
-#define G6_RS_A(h)                                                                                                                     \
-    if (RS == 1 && rs_own == rs_me) {                                                                                                  \
-        if (wc == 0) rsacc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[0], rsacc[h], 0, 0, 0);                                \
-        else if (wc == 1) rsacc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[1], rsacc[h], 0, 0, 0);                           \
-        else if (wc == 2) rsacc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[2], rsacc[h], 0, 0, 0);                           \
-        else rsacc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[3], rsacc[h], 0, 0, 0);                                        \
-    }
-#define G6_RS_B(ks)                                                                                                                    \
-    if (RS == 2 && rs_own == rs_me) {                                                                                                  \
-        if (wr == 0) {                                                                                                                 \
-            rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][ks], ones, rsacc[0], 0, 0, 0);                                     \
-            rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[2][ks], ones, rsacc[1], 0, 0, 0);                                     \
-        } else {                                                                                                                       \
-            rsacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1][ks], ones, rsacc[0], 0, 0, 0);                                     \
-            rsacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[3][ks], ones, rsacc[1], 0, 0, 0);                                     \
-        }                                                                                                                              \
-    }
-    for (int t = 0; t < nk; ++t) {
-        const char* st = smem + (t & 1) * G6_STAGE;
-        const bool more = t + 1 < nk && !noload;
-        // ---- P1: k-half 0 of (A0, B0|B1)
-        G6_READ_B(0);
-        G6_READ_A(0, 0);
-        if (more) G6_ISSUE_B(0, t + 1);
-        G6_BARRIER();
-        G6_STAMP(0);
-        G6_MFMA_BEGIN();
-        G6_MMA(0, 0);
-        G6_RS_A(0);
-        G6_RS_B(0);
-        G6_MFMA_END();
-        G6_BARRIER();
-        G6_STAMP(1);
-        // ---- P2: k-half 1 of (A0, B0|B1); the wait that makes A1 of this K-tile readable in P3
-        G6_READ_B(1);
-        G6_READ_A(0, 1);
-        if (more) {
-            G6_ISSUE_B(1, t + 1);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // newer than A1(t): A0, B0, B1 of t + 1
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        G6_BARRIER();
-        G6_STAMP(2);
-        G6_MFMA_BEGIN();
-        G6_MMA(0, 1);
-        G6_RS_A(0);
-        G6_RS_B(1);
-        G6_MFMA_END();
-        G6_BARRIER();
-        G6_STAMP(3);
-        // ---- P3: k-half 0 of (A1, B0|B1)
-        G6_READ_A(1, 0);
-        if (more) G6_ISSUE_A(1, t + 1);
-        G6_BARRIER();
-        G6_STAMP(4);
-        G6_MFMA_BEGIN();
-        G6_MMA(1, 0);
-        G6_RS_A(1);
-        G6_MFMA_END();
-        G6_BARRIER();
-        G6_STAMP(5);
-        // ---- P4: k-half 1 of (A1, B0|B1); the wait that makes A0, B0, B1 of K-tile t + 1 readable in its P1
-        G6_READ_A(1, 1);
-        if (more) {
-            if (t + 2 < nk) {
-                G6_ISSUE_A(0, t + 2);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // newer than B1(t + 1): A1 of t + 1, A0 of t + 2
-            } else {
-                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            }
-        }
-        G6_BARRIER();
-        G6_STAMP(6);
-        G6_MFMA_BEGIN();
-        G6_MMA(1, 1);
-        G6_RS_A(1);
-        G6_MFMA_END();
-        G6_BARRIER();
-        G6_STAMP(7);
-        if (RS != 0) { if (++rs_own == rs_mod) rs_own = 0; }
-    }
-    if (grp == 0) G6_BARRIER();
-#undef G6_ISSUE_A
-#undef G6_ISSUE_B
-#undef G6_READ_A
-#undef G6_READ_B
-#undef G6_MMA
-#undef G6_RS_A
-#undef G6_RS_B
-    if (RS == 1 && (lane >> 4) == 0) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int64_t m = m0 + h * 128 + wr * 64 + wc * 16 + (lane & 15);
-            if (m < M) atomicAdd(ep.a_rowsum + m, rsacc[h][0]);
-        }
-    }
-    if (RS == 2 && (lane & 15) == 0) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t n = n0 + h * 128 + wc * 32 + wr * 16 + (lane >> 4) * 4 + r;
-                if (n < N) atomicAdd(ep.b_rowsum + n, rsacc[h][r]);
-            }
-    }
-    epilogue_tile256<OutT>(ep, C, m0, n0, M, N, acc, smem, tid, wr, wc, lane);
-#if G6_PROFILE
-    if (dbg && blockIdx.x == 0 && lane == 0 && ep.mul_aux) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) ((float*)ep.mul_aux)[wave * 8 + q] = (float)dsum[q] / (float)nk;
-        ((float*)ep.mul_aux)[64 + wave] = (float)((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3);   // HW_ID.SIMD_ID
-    }
-#endif
-#undef G6_STAMP
-}
-
-template <bool A_KC, bool B_KC, typename OutT, int RS>
-static void launch_g6(dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int64_t M, int64_t N,
-                      int64_t K, int64_t kps, const EpiParams& ep) {
-    auto kfn = gemm_bf16_g6_kernel<A_KC, B_KC, OutT, RS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G6_STAGE);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kfn, grid, dim3(512), 2 * G6_STAGE, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
-}
-template <typename OutT>
-static void dispatch_g6(bool akc, bool bkc, int rs, dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C,
-                        int64_t M, int64_t N, int64_t K, int64_t kps, const EpiParams& ep) {
-    if (!akc && !bkc) {                  // the wgrad layout carries the bias-gradient instances
-        if (rs == 1) launch_g6<false, false, OutT, 1>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-        else if (rs == 2) launch_g6<false, false, OutT, 2>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-        else launch_g6<false, false, OutT, 0>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-    }
-    else if (akc && bkc) launch_g6<true, true, OutT, 0>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-    else if (akc && !bkc) launch_g6<true, false, OutT, 0>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-    else launch_g6<false, true, OutT, 0>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-}
-
-// ================================================================================================
 // skinny GEMM for the decode step (M <= 32 rows: n streams x 1 token): weight-bandwidth / launch bound.
 // One wave per 16 output columns, the whole K loop in registers: weight rows (nn.Linear [N,K]) and the M
 // activation rows are fetched as MFMA fragments straight from global memory (16 B per lane, no LDS —
@@ -1191,399 +727,6 @@ static void launch_bf16(dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda,
     hipLaunchKernelGGL(kfn, grid, dim3(256), 65536, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
 }
 
-// v2p: the BK=32 / 4-stage ring with SOFTWARE-PIPELINED fragments.  Ablation (EMO_GEMM_ABLATE=1: no tile loads) showed
-// the plain ring's inner loop alone reaches only ~43 % MFMA utilisation: every K step does barrier -> 8 ds_read_b128 ->
-// lgkmcnt(0) -> 16 MFMA, so the LDS latency is exposed once per step.  Here the fragments of stage k+1 are read into a
-// second register set while the MFMAs of stage k run (the ring guarantees stage k+1 has landed one step earlier), at
-// the price of one tile less in flight (2 instead of 3).
-template <bool A_KC, bool B_KC, typename OutT>
-__global__ __launch_bounds__(256) void gemm_bf16_glds_pf_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
-                                                                OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, int64_t k_per_split,
-                                                                EpiParams ep) {
-    constexpr int BK = 32, ST = 4, OPB = 128 * BK * 2, STAGE = 2 * OPB, NI = BK / 16, LPT = 2 * NI;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t tiles_n = (N + GB_N - 1) / GB_N, tiles_m = (M + GB_M - 1) / GB_M;
-    int64_t tm, tn, split = 0;
-    if (ep.atomic) {
-        splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
-        if (ep.ws_stride) { C += split * ep.ws_stride; ep.atomic = 0; }
-    }
-    else tile_coords(tiles_m, tiles_n, tm, tn);
-    if (tm >= tiles_m) return;
-    const int64_t m0 = tm * GB_M, n0 = tn * GB_N;
-    const int64_t kbeg = split * k_per_split;
-    const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
-    if (kbeg >= kend) return;
-    const int nk = (int)((kend - kbeg) / BK);
-    const int wm = wave >> 1, wn = wave & 1;
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    uint32_t offA[NI], offB[NI];
-    glds_offsets<A_KC, BK>(lda, m0, M, wave, lane, offA);
-    glds_offsets<B_KC, BK>(ldb, n0, N, wave, lane, offB);
-    const char* gA = (const char*)A + (A_KC ? kbeg : kbeg * lda) * 2;
-    const char* gB = (const char*)B + (B_KC ? kbeg : kbeg * ldb) * 2;
-    const int64_t stepA = (A_KC ? (int64_t)BK : (int64_t)BK * lda) * 2;
-    const int64_t stepB = (B_KC ? (int64_t)BK : (int64_t)BK * ldb) * 2;
-    int issued = 0;
-    auto issue_next = [&]() {
-        if (issued < nk) {
-            char* st = smem + (issued % ST) * STAGE;
-            glds_issue2<NI>(gA, offA, st, wave);
-            glds_issue2<NI>(gB, offB, st + OPB, wave);
-            gA += stepA;
-            gB += stepB;
-            ++issued;
-        }
-    };
-    issue_next(); issue_next(); issue_next();
-    // stage 0 must have landed before the first fragment read: at most (issued-1) younger tiles may stay in flight
-    if (issued >= 3) wait_vmcnt<2 * LPT>(); else if (issued == 2) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa0[i] = lfrag2<A_KC, BK>(smem, wm * 64 + i * 16, 0, lane);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fb0[j] = lfrag2<B_KC, BK>(smem + OPB, wn * 64 + j * 16, 0, lane);
-
-#define EMO_PF_STEP(CURA, CURB, NXTA, NXTB, KT)                                                                                   \
-    {                                                                                                                             \
-        const int kt_ = (KT);                                                                                                     \
-        if (kt_ + 1 < nk) {                                                                                                       \
-            /* stage kt+1 must have landed; only stage kt+2 may still be in flight */                                             \
-            if (issued > kt_ + 2) wait_vmcnt<LPT>(); else wait_vmcnt<0>();                                                        \
-            __builtin_amdgcn_s_barrier();                                                                                         \
-            asm volatile("" ::: "memory");                                                                                        \
-            issue_next();                                                                                                         \
-            const char* la_ = smem + ((kt_ + 1) % ST) * STAGE;                                                                    \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) NXTA[i] = lfrag2<A_KC, BK>(la_, wm * 64 + i * 16, 0, lane);             \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) NXTB[j] = lfrag2<B_KC, BK>(la_ + OPB, wn * 64 + j * 16, 0, lane);       \
-        }                                                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                             \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                         \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CURB[j], CURA[i], acc[i][j], 0, 0, 0);                        \
-    }
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        EMO_PF_STEP(fa0, fb0, fa1, fb1, kt)
-        EMO_PF_STEP(fa1, fb1, fa0, fb0, kt + 1)
-    }
-    if (kt < nk) EMO_PF_STEP(fa0, fb0, fa1, fb1, kt)
-#undef EMO_PF_STEP
-    epilogue_tile128<OutT>(ep, C, m0, n0, M, N, acc, smem, tid, wm, wn, lane);
-}
-
-template <bool A_KC, bool B_KC, typename OutT>
-static void launch_glds_pf(dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int64_t M, int64_t N,
-                           int64_t K, int64_t kps, const EpiParams& ep) {
-    auto kfn = gemm_bf16_glds_pf_kernel<A_KC, B_KC, OutT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kfn, grid, dim3(256), 65536, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
-}
-
-// v4: 128 x 256 block tile, 8 waves (2 x 4, wave tile 64 x 64 as in v2), BK = 32, 4-stage LDS-DMA ring (96 KB, one block
-// = 2 waves per SIMD).  The K=512 forward GEMMs are bound by the CU's vector-memory front end (ablation: tile loads alone
-// take 80 % of the kernel time at ~12-16 B/clk/CU); doubling BN cuts the tile bytes per FLOP by 25 % at unchanged
-// MFMA / LDS-read structure.  Both operands K-contiguous or B MN-contiguous (same images as v2).
-constexpr int G4_N = 256, G4_STAGE = 24576;   // per stage: 8 KB A + 16 KB B
-
-template <bool B_KC, typename OutT>
-__global__ __launch_bounds__(512) void gemm_bf16_g4_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
-                                                           OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, EpiParams ep) {
-    constexpr int BK = 32, ST = 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t tiles_n = (N + G4_N - 1) / G4_N, tiles_m = (M + GB_M - 1) / GB_M;
-    int64_t tm, tn;
-    tile_coords(tiles_m, tiles_n, tm, tn);
-    if (tm >= tiles_m) return;
-    const int64_t m0 = tm * GB_M, n0 = tn * G4_N;
-    const int nk = (int)(K / BK);
-    const int wm = wave >> 2, wn = wave & 3;
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // A tile: 8 wave-instructions (1 per wave); B tile: 16 (2 per wave)
-    uint32_t offA, offB[2];
-    {
-        const int row = wave * 16 + (lane >> 2), c = (lane & 3) ^ swz32(row);
-        int64_t gr = m0 + row;
-        if (gr > M - 1) gr = M - 1;
-        offA = (uint32_t)((gr * lda + c * 8) * 2);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int j = wave * 2 + i;
-        if constexpr (B_KC) {
-            const int row = j * 16 + (lane >> 2), c = (lane & 3) ^ swz32(row);
-            int64_t gr = n0 + row;
-            if (gr > N - 1) gr = N - 1;
-            offB[i] = (uint32_t)((gr * ldb + c * 8) * 2);
-        } else {
-            // [32 k][256 rows] = 512 B per k-row: wave-instruction j covers k-rows 2j, 2j+1
-            const int k = j * 2 + (lane >> 5), p16 = lane & 31;
-            const int g = (p16 >> 1) ^ swz_k(k);
-            int64_t gr = n0 + (g * 2 + (p16 & 1)) * 8;
-            if (gr > N - 1) gr = ((N - 1) >> 3) << 3;
-            offB[i] = (uint32_t)(((int64_t)k * ldb + gr) * 2);
-        }
-    }
-    const char* gA = (const char*)A;
-    const char* gB = (const char*)B;
-    const int64_t stepA = (int64_t)BK * 2, stepB = (B_KC ? (int64_t)BK : (int64_t)BK * ldb) * 2;
-    int issued = 0;
-    auto issue_next = [&]() {
-        if (issued < nk) {
-            char* st = smem + (issued % ST) * G4_STAGE;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + offA),
-                                             (__attribute__((address_space(3))) void*)(st + wave * 1024), 16, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + offB[i]),
-                                                 (__attribute__((address_space(3))) void*)(st + 8192 + (wave * 2 + i) * 1024), 16, 0, 0);
-            gA += stepA;
-            gB += stepB;
-            ++issued;
-        }
-    };
-    issue_next(); issue_next(); issue_next();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int newer = issued - 1 - kt;          // tiles issued after kt
-        if (newer >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (newer == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        issue_next();
-        const char* la = smem + (kt % ST) * G4_STAGE;
-        const char* lb = la + 8192;
-        bf16x8 fa[4], fb[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = lfrag2<true, BK>(la, wm * 64 + i * 16, 0, lane);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if constexpr (B_KC) fb[j] = lfrag2<true, BK>(lb, wn * 64 + j * 16, 0, lane);
-            else {
-                const int rbase = wn * 64 + j * 16, i2 = lane & 15, g = rbase >> 4;
-                bf16x8 v;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int k = (lane >> 4) * 8 + h * 4 + (i2 >> 2);
-                    const char* p = lb + k * 512 + ((g ^ swz_k(k)) << 5) + ((i2 & 3) << 3);
-                    short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
-                    bf16x4 tb = __builtin_bit_cast(bf16x4, t);
-                    v[h * 4 + 0] = tb[0]; v[h * 4 + 1] = tb[1]; v[h * 4 + 2] = tb[2]; v[h * 4 + 3] = tb[3];
-                }
-                fb[j] = v;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
-    // epilogue: two 128x128 halves (columns [0,128) = waves wn<2, [128,256) = wn>=2) through 64 KB of LDS each
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        __syncthreads();
-        if ((wn >> 1) == half) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int row = wm * 64 + i * 16 + (lane & 15);
-                    const int chunk = ((wn & 1) * 64 + j * 16 + (lane >> 4) * 4) >> 2;
-                    *(f32x4*)(smem + row * 512 + ((chunk ^ (row & 7)) << 4)) = acc[i][j];
-                }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = tid + 512 * it;   // 0..2047 : row = idx >> 4, 8-column group = idx & 15
-            const int row = idx >> 4, grp = idx & 15;
-            const int64_t m = m0 + row, n = n0 + half * 128 + grp * 8;
-            if (m < M && n < N) {
-                const f32x4 lo = *(const f32x4*)(smem + row * 512 + (((2 * grp) ^ (row & 7)) << 4));
-                const f32x4 hi = *(const f32x4*)(smem + row * 512 + (((2 * grp + 1) ^ (row & 7)) << 4));
-                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                epi_row8<OutT>(ep, C, m, n, v, N);
-            }
-        }
-    }
-}
-
-template <bool B_KC, typename OutT>
-static void launch_g4(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int64_t M, int64_t N, int64_t K,
-                      const EpiParams& ep) {
-    auto kfn = gemm_bf16_g4_kernel<B_KC, OutT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G4_STAGE);
-        attr_set = true;
-    }
-    const int64_t tiles_m8 = cdiv64(cdiv64(M, GB_M), 8) * 8, tiles_n = cdiv64(N, G4_N);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)(tiles_m8 * tiles_n)), dim3(512), 4 * G4_STAGE, st, A, lda, B, ldb, (OutT*)C, M, N, K, ep);
-}
-
-// v5: 256 x 128 block tile, FOUR waves (2 x 2, wave tile 128 x 64 = 8 x 4 MFMA tiles), BK = 32, 3-stage LDS-DMA ring
-// (72 KB => 2 blocks per CU).  Ablation of the 128^2 kernel at K=512 (EMO_GEMM_ABLATE) showed four ADDITIVE costs of
-// similar size — MFMA, fragment reads, tile DMA, and the per-tile fixed part (prologue + epilogue + C store burst);
-// the bigger wave tile cuts fragment reads per MFMA by 25 %, the bigger block tile cuts DMA bytes per FLOP by 25 % and
-// halves the number of per-tile fixed costs per FLOP.  A operand K-contiguous; B K-contiguous or MN-contiguous.
-constexpr int G5_M = 256, G5_STAGE = 24576;   // per stage: 16 KB A + 8 KB B
-
-template <bool B_KC, typename OutT>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_g5_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
-                                                              OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, EpiParams ep) {
-    constexpr int BK = 32, ST = 3;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t tiles_n = (N + GB_N - 1) / GB_N, tiles_m = (M + G5_M - 1) / G5_M;
-    int64_t tm, tn;
-    tile_coords(tiles_m, tiles_n, tm, tn);
-    if (tm >= tiles_m) return;
-    const int64_t m0 = tm * G5_M, n0 = tn * GB_N;
-    const int nk = (int)(K / BK);
-    const int wm = wave >> 1, wn = wave & 1;
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // A tile [256 rows][32 k]: 16 wave-instructions (4 per wave); B tile [128][32]: 8 (2 per wave)
-    uint32_t offA[4], offB[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 16 + (lane >> 2), c = (lane & 3) ^ swz32(row);
-        int64_t gr = m0 + row;
-        if (gr > M - 1) gr = M - 1;
-        offA[i] = (uint32_t)((gr * lda + c * 8) * 2);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int j = wave * 2 + i;
-        if constexpr (B_KC) {
-            const int row = j * 16 + (lane >> 2), c = (lane & 3) ^ swz32(row);
-            int64_t gr = n0 + row;
-            if (gr > N - 1) gr = N - 1;
-            offB[i] = (uint32_t)((gr * ldb + c * 8) * 2);
-        } else {
-            const int k = j * 4 + (lane >> 4), p16 = lane & 15;
-            const int g = (p16 >> 1) ^ swz_k(k);
-            int64_t gr = n0 + (g * 2 + (p16 & 1)) * 8;
-            if (gr > N - 1) gr = ((N - 1) >> 3) << 3;
-            offB[i] = (uint32_t)(((int64_t)k * ldb + gr) * 2);
-        }
-    }
-    const char* gA = (const char*)A;
-    const char* gB = (const char*)B;
-    const int64_t stepA = (int64_t)BK * 2, stepB = (B_KC ? (int64_t)BK : (int64_t)BK * ldb) * 2;
-    int issued = 0;
-    auto issue_next = [&]() {
-        if (issued < nk) {
-            char* st = smem + (issued % ST) * G5_STAGE;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + offA[i]),
-                                                 (__attribute__((address_space(3))) void*)(st + (wave * 4 + i) * 1024), 16, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + offB[i]),
-                                                 (__attribute__((address_space(3))) void*)(st + 16384 + (wave * 2 + i) * 1024), 16, 0, 0);
-            gA += stepA;
-            gB += stepB;
-            ++issued;
-        }
-    };
-    issue_next(); issue_next();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int newer = issued - 1 - kt;          // tiles issued after kt (6 DMA instructions per tile per thread)
-        if (newer >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        issue_next();
-        const char* la = smem + (kt % ST) * G5_STAGE;
-        const char* lb = la + 16384;
-        bf16x8 fa[8], fb[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = lfrag2<B_KC, BK>(lb, wn * 64 + j * 16, 0, lane);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) fa[i] = lfrag2<true, BK>(la, wm * 128 + i * 16, 0, lane);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
-    // epilogue: four 64-row slabs through 32 KB of LDS (the ring is idle now)
-#pragma clang loop unroll(full)
-    for (int pass = 0; pass < 4; ++pass) {
-        __syncthreads();
-        if (wm == (pass >> 1)) {
-#pragma clang loop unroll(full)
-            for (int ii = 0; ii < 4; ++ii)
-#pragma clang loop unroll(full)
-                for (int j = 0; j < 4; ++j) {
-                    const int row = ii * 16 + (lane & 15);
-                    const int chunk = (wn * 64 + j * 16 + (lane >> 4) * 4) >> 2;
-                    *(f32x4*)(smem + row * 512 + ((chunk ^ (row & 7)) << 4)) = acc[(pass & 1) * 4 + ii][j];
-                }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = tid + 256 * it;   // 0..1023 : row = idx >> 4 (64 rows), 8-column group = idx & 15
-            const int row = idx >> 4, grp = idx & 15;
-            const int64_t m = m0 + pass * 64 + row, n = n0 + grp * 8;
-            if (m < M && n < N) {
-                const f32x4 lo = *(const f32x4*)(smem + row * 512 + (((2 * grp) ^ (row & 7)) << 4));
-                const f32x4 hi = *(const f32x4*)(smem + row * 512 + (((2 * grp + 1) ^ (row & 7)) << 4));
-                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                epi_row8<OutT>(ep, C, m, n, v, N);
-            }
-        }
-    }
-}
-
-template <bool B_KC, typename OutT>
-static void launch_g5(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int64_t M, int64_t N, int64_t K,
-                      const EpiParams& ep) {
-    auto kfn = gemm_bf16_g5_kernel<B_KC, OutT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * G5_STAGE);
-        attr_set = true;
-    }
-    const int64_t tiles_m8 = cdiv64(cdiv64(M, G5_M), 8) * 8, tiles_n = cdiv64(N, GB_N);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)(tiles_m8 * tiles_n)), dim3(256), 3 * G5_STAGE, st, A, lda, B, ldb, (OutT*)C, M, N, K, ep);
-}
-
-static int g_glds_bk = -1;   // EMO_GEMM_BK=32|64 forces one LDS-DMA geometry (default: per-shape heuristic)
-static int glds_bk() {
-    if (g_glds_bk < 0) {
-        const char* e = getenv("EMO_GEMM_BK");
-        g_glds_bk = !e ? 0 : ((e[0] == '6') ? 64 : 32);
-    }
-    return g_glds_bk;
-}
-static bool g_glds_bk_forced() { return glds_bk() != 0; }
-
 template <bool A_KC, bool B_KC, typename OutT, int BK, int ST>
 static void launch_glds(dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int64_t M, int64_t N,
                         int64_t K, int64_t kps, const EpiParams& ep) {
@@ -1612,20 +755,8 @@ static void dispatch_glds(bool akc, bool bkc, dim3 grid, hipStream_t st, const b
     // limits the K=512 GEMMs, so OCCUPANCY wins over prefetch depth: a 3-stage ring of 32-deep tiles (48 KB LDS, 3 blocks
     // per CU) beats the 4-stage ring (64 KB, 2 blocks) by 13-16 % (qkv 575 vs 509, ffn1 659 vs 568 TFLOP/s); for the
     // long reduction (K=2048) the double buffer of full 128-B lines is best (842 vs 796); for MN-contiguous B (dgrad)
-    // the 2-stage ring of 32-deep tiles (32 KB) is best.  EMO_GEMM_ST / EMO_GEMM_BK / EMO_GEMM_PF force one geometry.
+    // the 2-stage ring of 32-deep tiles (32 KB, 4 blocks per CU) is best (in-step A/B of the other geometries: DESIGN.md §4.1).
     const bool can64 = (kps % 64) == 0 && (K % 64) == 0;
-    static const int st_env = getenv("EMO_GEMM_ST") ? atoi(getenv("EMO_GEMM_ST")) : 0;
-    static const bool use_pf = getenv("EMO_GEMM_PF") != nullptr;
-    if (st_env == 4 || g_glds_bk_forced() || use_pf) {
-        const int bk = g_glds_bk_forced() ? glds_bk() : 32;
-        if (bk == 64 && can64) dispatch_glds2<OutT, 64, 2>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-        else if (use_pf && akc && bkc) launch_glds_pf<true, true, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-        else if (use_pf && akc && !bkc) launch_glds_pf<true, false, OutT>(grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-        else dispatch_glds2<OutT, 32, 4>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
-        return;
-    }
-    if (st_env == 3) { dispatch_glds2<OutT, 32, 3>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep); return; }
-    if (st_env == 2) { dispatch_glds2<OutT, 32, 2>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep); return; }
     if (bkc && K > 1024 && can64) dispatch_glds2<OutT, 64, 2>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
     else if (bkc) dispatch_glds2<OutT, 32, 3>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
     else dispatch_glds2<OutT, 32, 2>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
@@ -1638,13 +769,6 @@ static int gemm_variant() {
         g_gemm_variant = (e && e[0] >= '1' && e[0] <= '3') ? (e[0] - '0') : 2;
     }
     return g_gemm_variant;
-}
-
-template <typename OutT>
-static void launch_bf16_tn32(dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int64_t M, int64_t N,
-                             int64_t K, int64_t kps, const EpiParams& ep) {
-    auto kfn = gemm_bf16_kernel<false, false, false, OutT, 32>;
-    hipLaunchKernelGGL(kfn, grid, dim3(256), 32768, st, A, lda, B, ldb, (OutT*)C, M, N, K, kps, ep);
 }
 
 template <bool SAFE, typename OutT>
@@ -1715,37 +839,11 @@ static int64_t choose_splits(int64_t M, int64_t N, int64_t K, bool big, bool has
 }
 
 #define EMO_GEMM_MAX_SPLITS 32
-// v6 (256^2 four-phase kernel) dispatch.  OFF by default: in microbenchmarks it beats the 128^2 kernels on the long reductions (FFN wgrad
-// 680-705 -> 800-820 TFLOP/s, 8192^3 NT 906 -> 1155), but INSIDE the training step the 128^2 wgrad runs at ~890 TFLOP/s (its dY operand was
-// just written and is still on-die) against 864 for v6, and the K = 2048 forward is equal (663 vs 667): 65.6 vs 65.5 ms/step.
-// EMO_GEMM_G6=1 forces it for every eligible shape (K % 64 == 0, M and N multiples of 256), =2 enables it for the >= 12-tile wgrads only.
-static int g6_mode() {
-    static int m = -1;
-    if (m < 0) { const char* e = getenv("EMO_GEMM_G6"); m = e ? atoi(e) + 1 : 1; }   // 1 = off (default), 2 = forced, 3 = wgrad heuristic
-    return m;
-}
-static bool g6_shape_ok(int64_t M, int64_t N, int64_t K) { return (M % G3_M) == 0 && (N % G3_N) == 0 && (K % G3_K) == 0 && K >= 2 * G3_K; }
-// split count of the v6 wgrad: all tiles of a split run on ONE XCD (32 CUs, one 128-KB block per CU), so a split costs `tiles` CUs
-static int64_t g6_wgrad_splits(int64_t M, int64_t N, int64_t K, int64_t max_ws_splits) {
-    const int64_t tiles = (M / G3_M) * (N / G3_N);
-    int64_t per_xcd = tiles >= 32 ? 1 : 32 / tiles;
-    int64_t splits = 8 * per_xcd;
-    const int64_t max_by_k = K / (8 * G3_K);
-    while (splits > 8 && splits > max_by_k) splits -= 8;
-    if (splits > max_by_k) splits = max_by_k > 0 ? max_by_k : 1;
-    if (max_ws_splits > 0 && splits > max_ws_splits) splits = max_ws_splits >= 8 ? (max_ws_splits / 8) * 8 : max_ws_splits;
-    { const char* fs = getenv("EMO_GEMM_SPLITS"); if (fs && atoi(fs) > 0) splits = atoi(fs); }
-    return splits < 1 ? 1 : splits;
-}
 extern "C" int64_t emo_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype_in, int dtype_out) {
     if (dtype_out != EMO_F32 || M <= 0 || N <= 0 || K <= 0) return 0;
     const bool big = dtype_in == EMO_BF16;
     const int64_t BMt = big ? GB_M : 64, BNt = big ? GB_N : 64, BKt = big ? (gemm_variant() >= 2 ? G2_BK : GB_K) : 16;
     int64_t splits = choose_splits(M, N, K, big, false, dtype_out, BMt, BNt, BKt, EMO_GEMM_MAX_SPLITS);
-    if (big && g6_mode() != 1 && g6_shape_ok(M, N, K) && (g6_mode() == 2 ? K >= 4096 : (K >= 32768 && (M / G3_M) * (N / G3_N) >= 12))) {   // layout unknown here: size for both kernels
-        const int64_t s6 = g6_wgrad_splits(M, N, K, 0);
-        if (s6 > splits) splits = s6;
-    }
     return splits > 1 ? splits * M * N * (int64_t)sizeof(float) : 0;
 }
 
@@ -1764,7 +862,9 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     ep.ldc = ldc;
     ep.accumulate = accumulate;
     ep.drop = make_drop(0.f, 0, 0);
+#ifdef EMO_DIAG
     { const char* ab = getenv("EMO_GEMM_ABLATE"); ep.ablate = ab ? atoi(ab) : 0; }
+#endif
     bool has_epi = false;
     if (e) {
         ep.bias = e->bias; ep.act = e->act; ep.aux_out = e->aux_out; ep.mul_aux = e->mul_aux;
@@ -1780,18 +880,9 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     }
     const bool ln_fused = e && (e->ln_c1 || e->rln_x);
     EMO_CHECK(!(ep.a_rowsum && ep.b_rowsum), "emo_gemm: a_rowsum and b_rowsum are exclusive");
-    bool use_g6 = false;
-    if (dtype_in == EMO_BF16 && gemm_variant() >= 2 && !use_safe_tr() && g6_mode() != 1 && g6_shape_ok(M, N, K) && !ln_fused && M > 32 &&
-        (lda & 7) == 0 && (ldb & 7) == 0 && getenv("EMO_GEMM_FORCE_G3") == nullptr && getenv("EMO_GEMM_TN32") == nullptr) {
-        // measured r01 (tools/bench_g6.py, 131072 tokens): FFN wgrads 725 -> 840-890 TFLOP/s, fused-QKV wgrad 548 -> 581, the 4-tile
-        // 512 x 512 wgrad 575 -> 500 (64 splits), K = 1536 / 2048 single-pass GEMMs within noise of the 128^2 kernels -> wgrad only
-        const bool wgrad = a_trans && b_trans && dtype_out == EMO_F32 && !has_epi && ldc == N && (M / G3_M) * (N / G3_N) >= 12 && K >= 32768;
-        use_g6 = g6_mode() == 2 || (g6_mode() == 3 && wgrad);
-    }
     if (ep.b_rowsum) {
         EMO_CHECK(a_trans && b_trans, "emo_gemm: b_rowsum needs a_trans and b_trans (B stored [K, N]: the Conv1D wgrad layout)");
-        const bool in_kernel = dtype_in == EMO_BF16 && dtype_out == EMO_F32 && gemm_variant() < 3 && !use_safe_tr() && getenv("EMO_GEMM_TN32") == nullptr &&
-                               getenv("EMO_GEMM_FORCE_G3") == nullptr && getenv("EMO_GEMM_NO_ROWSUM_FUSE") == nullptr;   // (v6 carries it too: a_trans && b_trans)
+        const bool in_kernel = dtype_in == EMO_BF16 && dtype_out == EMO_F32 && gemm_variant() < 3 && !use_safe_tr();
         if (!in_kernel) {
             const int rc = emo_colsum(B, dtype_in, K, N, ldb, ep.b_rowsum, 1, stream);
             if (rc) return rc;
@@ -1800,8 +891,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     }
     if (ep.a_rowsum) {
         EMO_CHECK(a_trans, "emo_gemm: a_rowsum needs a_trans (A stored [K, M]: the wgrad layout)");
-        const bool in_kernel = dtype_in == EMO_BF16 && dtype_out == EMO_F32 && b_trans && gemm_variant() < 3 && !use_safe_tr() &&
-                               getenv("EMO_GEMM_TN32") == nullptr && getenv("EMO_GEMM_FORCE_G3") == nullptr && getenv("EMO_GEMM_NO_ROWSUM_FUSE") == nullptr;
+        const bool in_kernel = dtype_in == EMO_BF16 && dtype_out == EMO_F32 && b_trans && gemm_variant() < 3 && !use_safe_tr();
         if (!in_kernel) {                                   // other kernels: the plain column-sum launch over A [K, M]
             const int rc = emo_colsum(A, dtype_in, K, M, lda, ep.a_rowsum, 1, stream);
             if (rc) return rc;
@@ -1811,9 +901,9 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     const bool big = dtype_in == EMO_BF16;
     const int variant = big ? gemm_variant() : 0;
     if (big && M <= 32 && !a_trans && !b_trans && (K % 32) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0 &&
-        !accumulate && getenv("EMO_GEMM_NO_SKINNY") == nullptr) {
+        !accumulate) {
         dim3 g((unsigned)cdiv64(N, 16));
-        const int nw = (K >= 2048 && getenv("EMO_SKINNY_NW8") == nullptr) ? 16 : (K >= 1024 ? 8 : 4);   // 16 waves x two 64-wide chunks at K = 2048
+        const int nw = K >= 2048 ? 16 : (K >= 1024 ? 8 : 4);   // 16 waves x two 64-wide chunks at K = 2048
 #define SKINNY_LAUNCH(OutT, NWv, CWv)                                                                                                       \
     do {                                                                                                                                    \
         constexpr size_t lds_ = (size_t)NWv * 48 * (CWv + 16) * 2 + sizeof(f32x4) * (NWv - 1) * 2 * 64 + sizeof(float) * NWv * 2 * 16 * 2;   \
@@ -1835,20 +925,8 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     }
     EMO_CHECK(!ep.mask_out && ep.mul_mode != EMO_MUL_BITMASK, "emo_gemm: mask_out / EMO_MUL_BITMASK need bf16 in/out, NT, K = 512, M %% 128 == 0, N %% 64 == 0, N <= 2048");
     EMO_CHECK(!ln_fused, "emo_gemm: the LayerNorm-folded epilogue (ln_c1 / rln_x) exists only on the skinny path (bf16, M <= 32, NT, K %% 32 == 0)");
-    // v3 (256^2 tile) when the problem fills the chip with 256^2 tiles and N does not waste a tile
-    bool use_g3 = false;
-    if (big && variant >= 2 && !use_safe_tr() && (K % G3_K) == 0 && M >= 256) {
-        const int64_t t3 = cdiv64(M, G3_M) * cdiv64(N, G3_N);
-        const bool n_ok = (N % G3_N) == 0 || N >= 4 * G3_N;
-        const bool enough = t3 >= 512 || (dtype_out == EMO_F32 && !has_epi && K >= 64 * G3_K);   // split-K refills the grid
-        // measured r01: with 1 block/CU the exposed prologue/epilogue makes the 256^2 kernel SLOWER than the 128^2 ones at
-        // K=512 (293 vs 505 TFLOP/s) and no faster at K=2048 -> kept for experiments only (EMO_GEMM_FORCE_G3=1)
-        use_g3 = n_ok && enough && false;
-    }
-    if (big && variant >= 2 && !use_safe_tr() && (K % G3_K) == 0 && M >= 8 && N >= 8 && getenv("EMO_GEMM_FORCE_G3") != nullptr) use_g3 = true;
-    if (use_g6) use_g3 = true;                                // same 256 x 256 x 64 tile grid; the kernel is chosen at the launch below
-    const int64_t BMt = big ? (use_g3 ? G3_M : GB_M) : 64, BNt = big ? (use_g3 ? G3_N : GB_N) : 64;
-    const int64_t BKt = big ? (use_g3 ? G3_K : (variant >= 2 ? G2_BK : GB_K)) : 16;
+    const int64_t BMt = big ? GB_M : 64, BNt = big ? GB_N : 64;
+    const int64_t BKt = big ? (variant >= 2 ? G2_BK : GB_K) : 16;
     const int64_t tiles_m = cdiv64(M, BMt), tiles_n = cdiv64(N, BNt);
     const int64_t tiles_m8 = cdiv64(tiles_m, 8) * 8;
     // split-K: only for plain fp32 outputs (wgrad) when the tile grid cannot fill the chip
@@ -1857,7 +935,6 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     const bool ws_ok = ws && ldc == N && ((M * N) & 3) == 0 && ((uintptr_t)ws & 15) == 0 && getenv("EMO_GEMM_SPLIT_ATOMIC") == nullptr;
     int64_t max_ws_splits = ws_ok ? ws_bytes / (M * N * (int64_t)sizeof(float)) : 0;
     int64_t splits = choose_splits(M, N, K, big, has_epi, dtype_out, BMt, BNt, BKt, max_ws_splits >= 2 ? max_ws_splits : 0);
-    if (use_g6) splits = (a_trans && b_trans && dtype_out == EMO_F32 && !has_epi && K >= 4096 && ldc == N) ? g6_wgrad_splits(M, N, K, max_ws_splits >= 2 ? max_ws_splits : 0) : 1;
     if (ldc != N) splits = 1;                                // split-K partials need a contiguous C: a strided output view runs unsplit
     int64_t kps = cdiv64(cdiv64(K, splits), BKt) * BKt;
     splits = cdiv64(K, kps);
@@ -1893,37 +970,13 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         const bf16_t* b = (const bf16_t*)B;
         const bool akc = !a_trans, bkc = !b_trans;
         const bool safe = use_safe_tr();
-        const int64_t rowsA = a_trans ? (use_g3 ? G3_K : G2_BK) : M, rowsB = b_trans ? (use_g3 ? G3_K : G2_BK) : N;
+        const int64_t rowsA = a_trans ? G2_BK : M, rowsB = b_trans ? G2_BK : N;
         const int64_t spanA = (rowsA * lda + (a_trans ? M : 0)) * 2, spanB = (rowsB * ldb + (b_trans ? N : 0)) * 2;
         const bool span_ok = spanA < (int64_t)0xFFFF0000 && spanB < (int64_t)0xFFFF0000;
         const bool glds_ok = !safe && variant >= 2 && (akc || variant >= 3) && (K % G2_BK) == 0 && (kps % G2_BK) == 0 && M >= 8 && N >= 8 && span_ok;
-        static const bool g4_on = getenv("EMO_GEMM_G4") != nullptr;   // 128x256 tile: measured no faster than 128x128 (r01) -> opt-in
-        const bool use_g4 = g4_on && !safe && variant >= 2 && akc && splits == 1 && !accumulate && (K % G2_BK) == 0 && (N % G4_N) == 0 && span_ok &&
-                            cdiv64(M, GB_M) * (N / G4_N) >= 512 && K <= 1024;
-        static const bool g5_on = getenv("EMO_GEMM_G5") != nullptr;
-        const bool use_g5 = g5_on && !safe && variant >= 2 && akc && splits == 1 && !accumulate && (K % G2_BK) == 0 && span_ok &&
-                            cdiv64(M, G5_M) * cdiv64(N, GB_N) >= 512;
-        if (use_g5) {
-            if (dtype_out == EMO_F32) { if (bkc) launch_g5<true, float>(st, a, lda, b, ldb, C, M, N, K, ep); else launch_g5<false, float>(st, a, lda, b, ldb, C, M, N, K, ep); }
-            else { if (bkc) launch_g5<true, bf16_t>(st, a, lda, b, ldb, C, M, N, K, ep); else launch_g5<false, bf16_t>(st, a, lda, b, ldb, C, M, N, K, ep); }
-        } else if (use_g4) {
-            if (dtype_out == EMO_F32) { if (bkc) launch_g4<true, float>(st, a, lda, b, ldb, C, M, N, K, ep); else launch_g4<false, float>(st, a, lda, b, ldb, C, M, N, K, ep); }
-            else { if (bkc) launch_g4<true, bf16_t>(st, a, lda, b, ldb, C, M, N, K, ep); else launch_g4<false, bf16_t>(st, a, lda, b, ldb, C, M, N, K, ep); }
-        } else if (use_g6 && span_ok && (kps % G3_K) == 0) {
-            const int rs = ep.a_rowsum ? 1 : (ep.b_rowsum ? 2 : 0);
-            if (dtype_out == EMO_F32) dispatch_g6<float>(akc, bkc, rs, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
-            else dispatch_g6<bf16_t>(akc, bkc, rs, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
-        } else if (use_g3 && span_ok && (kps % G3_K) == 0) {
-            if (dtype_out == EMO_F32) dispatch_g3<float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
-            else dispatch_g3<bf16_t>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
-        } else if (use_g3) {
-            emo_set_error("emo_gemm: internal tile-selection error");
-            return EMO_ERR_INVALID;
-        } else if (glds_ok) {
+        if (glds_ok) {
             if (dtype_out == EMO_F32) dispatch_glds<float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
             else dispatch_glds<bf16_t>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
-        } else if (!akc && !bkc && !safe && getenv("EMO_GEMM_TN32") != nullptr && dtype_out == EMO_F32) {
-            launch_bf16_tn32<float>(grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
         } else if (dtype_out == EMO_F32) {   // register-staged v1 (same 128^2 grid; any K, predicated edges)
             if (safe) dispatch_bf16<true, float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
             else dispatch_bf16<false, float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
