@@ -1,5 +1,5 @@
 import os, sys, time, json
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from emo_disentanger_amd.model.music_performer import MusicPerformer
 from emo_disentanger_amd import inference as inf
