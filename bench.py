@@ -66,17 +66,22 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
     stretched in-step average is reported next to the serialized one."""
     from emo_disentanger_amd import engine, ops
 
+    extra = {}
+
     def instrumented(side_on):
         was = engine._SIDE['on']
         engine._SIDE['on'] = side_on and was
-        ops.GEMM_TIMING = []
+        ops.GEMM_TIMING, ops.KERNEL_TIMING = [], {}
         try:
             for _ in range(n_steps):
                 step_fn()
             torch.cuda.synchronize()
         finally:
             rec, ops.GEMM_TIMING = ops.GEMM_TIMING, None
+            other, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
             engine._SIDE['on'] = was
+        extra.clear()
+        extra.update(other)
         by = {}
         for kind, e0, e1, fl, by_ in (r[:5] for r in rec):
             d = by.setdefault(kind, {'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'n': 0})
@@ -107,8 +112,68 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
     roof['rocprof_summary'] = ('profiles/r01_bench_train_rocprof_stats.txt = rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-gen --no-stage1` '
                                '(training kernels only: this kernel 319.5 us average over 720 launches); profiles/r01_bench_final_rocprof_stats.txt = the full default command, '
                                'where the stage-1 and generation legs launch the same kernel instance on small shapes and pull its average down')
-    roof['roofline_others'] = [entry(k) for k in order[1:]]
+    roof['roofline_others'] = [entry(k) for k in order[1:]] + [attn_entry(k, v, n_steps) for k, v in sorted(extra.items())]
     return roof
+
+
+ATTN_KERNELS = {'favor_fwd': ('favor_fwd_kernel', 'hbm', 'FAVOR+ causal linear attention forward: features + chunked prefix-sum scan; bytes = q, k, v read + out written (4*512*e per token*layer)'),
+                'favor_bwd': ('favor_bwd_dq_kernel + favor_bwd_dkv_kernel', 'hbm', 'FAVOR+ backward (forward sweep dq, reverse sweep dk/dv); bytes = 7*512*e per token*layer'),
+                'sattn_fwd': ('sattn_fwd_kernel', 'mfma', 'GPT-2 causal softmax attention forward (flash tiles): 2 matmuls, causal half'),
+                'sattn_bwd': ('sattn_bwd_dq_kernel + sattn_bwd_dkv_kernel', 'mfma', 'GPT-2 attention backward: 7 matmuls, causal half')}
+
+
+def attn_entry(kind, rec, n_steps):
+    """roofline entry of an attention kernel class from in-situ HIP-event brackets (ops._timed)."""
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rec)
+    fl, by = sum(r[2] for r in rec), sum(r[3] for r in rec)
+    name, bound, what = ATTN_KERNELS[kind]
+    if bound == 'hbm':
+        ach, peak, unit = by / ms / 1e6, PEAK_HBM_GBS, 'GB/s'
+    else:
+        ach, peak, unit = fl / ms / 1e9, PEAK_BF16_TFLOPS, 'TFLOP/s'
+    return {'bound': bound, 'achieved': round(ach, 1), 'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4), 'traffic': None, 'kernel': '%s (%s)' % (name, what),
+            'launches_timed': len(rec), 'avg_launch_ms': round(ms / len(rec), 4), 'total_ms_per_step': round(ms / n_steps, 2),
+            'algorithmic_flops_per_launch': round(fl / len(rec)), 'algorithmic_bytes_per_launch': round(by / len(rec))}
+
+
+def gpt2_bench(n_steps=6, B=16, T=2048):
+    """Secondary line: the GPT-2 backbone of the same hot path (north_star: masked-softmax attention) at the pop1k7_pretrain_gpt2 shape
+    (d512 / L12 / H8), B=16 x T=2048, bf16, dropout 0.1, fwd + bwd + clip + fused Adam on synthetic tokens; the flash-attention kernels are
+    timed in situ with HIP events."""
+    import contextlib
+    from emo_disentanger_amd import ops
+    from emo_disentanger_amd.data import synthetic_batch
+    from emo_disentanger_amd.model.music_gpt2 import MusicGPT2
+    from emo_disentanger_amd.optim import FusedAdam
+    with contextlib.redirect_stdout(sys.stderr):
+        m = MusicGPT2(CFG['n_token'], 12, 8, 512, 2048, 512, use_segment_emb=True, n_segment_types=2, dropout=0.1, compute_dtype='bf16').cuda().train()
+    opt = FusedAdam(m, lr=1e-5, max_grad_norm=0.5)
+    b = synthetic_batch(CFG['n_token'], B, T, device='cuda')
+
+    def step():
+        opt.zero_grad()
+        loss = m.compute_loss(m(b['dec_input'], seg_inp=b['track_mask']), b['dec_target'])['total_loss']
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n_steps
+    ops.KERNEL_TIMING = {}
+    try:
+        step()
+        step()
+        torch.cuda.synchronize()
+    finally:
+        rec, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
+    return {'metric': 'GPT-2 backbone train tokens/sec', 'value': round(B * T / dt, 1), 'unit': 'tokens/s', 'ms_per_step': round(dt * 1e3, 3),
+            'config': {'workload': 'stage2 GPT-2 d512 L12 H8 d_ff2048, B=%d x T=%d, bf16, dropout 0.1 (attention-probability dropout in-kernel), fused Adam' % (B, T)},
+            'loss': round(float(loss.detach()), 4), 'roofline': [attn_entry(k, v, 2) for k, v in sorted(rec.items())]}
 
 
 def generation_bench(model, n_streams=32, prompt=64, n_new=2048 - 64, top_p=0.9, temp=1.1):
@@ -211,20 +276,40 @@ def cpu_generation_baseline(ctx=256, n_tok=4):
 
 
 def cpu_baseline(T, steps=2):
-    """Oracle (CPU restatement of the reference path: torch fp32 eager + the C causal-product) timed on the host cores."""
+    """Oracle (CPU restatement of the reference path: torch fp32 eager + the C causal-product) timed on the host cores: forward + loss +
+    backward + clip(0.5) + Adam on B=1 x T tokens, all cores (`value`) and 8 threads (`value_8_threads`, the survey container's core count)."""
     from oracle import model_ref
     from oracle.weights import make_state_dict, synthetic_batch
     sd = make_state_dict('performer', CFG['n_token'], CFG['n_layer'], CFG['n_head'], CFG['d_model'], CFG['d_ff'], favor_feature_dims=CFG['n_feat'], seed=0)
     b = synthetic_batch(CFG['n_token'], 1, T, seed=1234)
     cores = torch.get_num_threads()
     args = ('performer', sd, b, CFG['n_token'], CFG['n_layer'], CFG['n_head'], CFG['d_model'])
-    model_ref.loss_and_grads(*args, p_drop=0.1, training=True)        # warm-up (also builds the C kernel)
+    params = {k: torch.nn.Parameter(v.clone()) for k, v in sd.items() if v.is_floating_point() and not k.endswith('pe.pe') and 'omega' not in k}
+    opt = torch.optim.Adam(params.values(), lr=1e-4)
+
+    def one_step():
+        _, _, grads = model_ref.loss_and_grads(*args, p_drop=0.1, training=True)
+        for k, p in params.items():
+            p.grad = grads[k]
+        torch.nn.utils.clip_grad_norm_(params.values(), 0.5)
+        opt.step()
+    one_step()                                                        # warm-up (also builds the C kernel)
     t0 = time.time()
     for _ in range(steps):
-        model_ref.loss_and_grads(*args, p_drop=0.1, training=True)
+        one_step()
     dt = (time.time() - t0) / steps
-    return {'value': round(T / dt, 1), 'unit': 'tokens/s', 'cores': cores, 'kind': 'port',
-            'sample': 'oracle Performer L12 d512 fwd+bwd (no optimizer), B=1 x T=%d, %d timed steps, torch fp32 eager + C causal product' % (T, steps)}
+    out = {'value': round(T / dt, 1), 'unit': 'tokens/s', 'cores': cores, 'kind': 'port',
+           'sample': 'oracle Performer L12 d512 fwd + bwd + clip + Adam, B=1 x T=%d, %d timed steps, torch fp32 eager + C causal product' % (T, steps)}
+    if cores > 8:
+        torch.set_num_threads(8)
+        os.environ['OMP_NUM_THREADS'] = '8'
+        try:
+            t0 = time.time()
+            one_step()
+            out['value_8_threads'] = round(T / (time.time() - t0), 1)
+        finally:
+            torch.set_num_threads(cores)
+    return out
 
 
 def launch_ranks(n):
@@ -255,6 +340,7 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-gen', action='store_true')
     ap.add_argument('--no-stage1', action='store_true')
+    ap.add_argument('--no-gpt2', action='store_true')
     ap.add_argument('--no-step0-check', action='store_true')
     args = ap.parse_args()
 
@@ -350,6 +436,10 @@ def main():
                 out['gen']['cpu_baseline'] = cpu_generation_baseline()
         if world == 1 and not args.no_stage1:
             out['stage1'] = stage1_bench()
+        if world == 1 and not args.no_gpt2:
+            del model, opt                                   # (the Performer's 21 GB of saved activations are not needed any more)
+            torch.cuda.empty_cache()
+            out['gpt2'] = gpt2_bench()
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(min(T, 2048))
         print(json.dumps(out), flush=True)

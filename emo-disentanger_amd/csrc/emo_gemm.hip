@@ -972,7 +972,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         EMO_LAUNCH_CHECK();
         return EMO_OK;
     }
-    EMO_CHECK(!ep.mask_out && ep.mul_mode != EMO_MUL_BITMASK, "emo_gemm: mask_out / EMO_MUL_BITMASK need bf16 in/out, NT, K = 512, M %% 128 == 0, N %% 64 == 0, N <= 2048");
+    EMO_CHECK(!ep.mask_out && ep.mul_mode != EMO_MUL_BITMASK, "emo_gemm: mask_out / EMO_MUL_BITMASK need bf16 in/out, NT, K = 512, M %% 128 == 0, M >= 32768, N %% 64 == 0, N <= 2048");
     EMO_CHECK(!ln_fused, "emo_gemm: the LayerNorm-folded epilogue (ln_c1 / rln_x) exists only on the skinny path (bf16, M <= 32, NT, K %% 32 == 0)");
     const int64_t BMt = big ? GB_M : 64, BNt = big ? GB_N : 64;
     const int64_t BKt = big ? (variant >= 2 ? G2_BK : GB_K) : 16;

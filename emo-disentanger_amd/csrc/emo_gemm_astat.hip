@@ -23,6 +23,7 @@
 
 namespace {
 constexpr int AS_K = 512, AS_BM = 128, AS_BN = 64, AS_KS = 128, AS_SLOT = AS_BN * AS_KS * 2, AS_RING = 4 * AS_SLOT;
+constexpr int AS_MIN_BLOCKS = 256;                             // = EMO_ASTAT_MIN_ROWS / 128 (ops.gemm_bitmask_ok mirrors it)
 constexpr int AS_MAXN = 2048;                                   // bias copy in LDS: 8 KB
 
 __device__ __forceinline__ int as_swz(int row) { return (row & 3) | ((row >> 1) & 12); }
@@ -318,7 +319,9 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
 bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int dtype_out, int64_t M, int64_t N, int64_t K,
                         const EpiParams& ep, hipStream_t st) {
     const bool off = getenv("EMO_GEMM_NO_ASTAT") != nullptr;      // (read per call: the parity test toggles it in-process)
-    if (off || K != AS_K || (M % AS_BM) != 0 || (N % AS_BN) != 0 || N > AS_MAXN || N < AS_BN) return false;
+    // one block owns a 128-row panel and sweeps all of N: the grid is M / 128 blocks, so small token counts (the reference's batch_size 4,
+    // stage 1) leave most CUs idle where the 128 x 128 tiling has N / 128 times more blocks -> A-stationary only from one block per CU up
+    if (off || K != AS_K || (M % AS_BM) != 0 || M < (int64_t)AS_BM * AS_MIN_BLOCKS || (N % AS_BN) != 0 || N > AS_MAXN || N < AS_BN) return false;
     if (ep.atomic || ep.accumulate || ep.ws_stride || ep.a_rowsum || ep.b_rowsum || ep.ln_c1 || ep.rln_x) return false;
     if ((ep.mask_out || ep.mul_mode == EMO_MUL_BITMASK) && dtype_out != EMO_BF16) return false;
     if ((lda & 7) || (ldb & 7) || (ep.ldc & 7) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return false;

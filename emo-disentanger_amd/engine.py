@@ -272,7 +272,7 @@ def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
     if dyd is None:
         dyd = g2
     _wgrad(ps, pfx + 'linear2.weight', pfx + 'linear2.bias', dyd, s['f'], bias_done=True)
-    bf = ps.flat16 is not None
+    bf = ps.flat16 is not None and D == 512 and dout.shape[0] % 128 == 0 and dout.shape[0] >= ops.ASTAT_MIN_ROWS     # the A-stationary K = 512 class
     if bf and s['fmask'] is not None:
         df = ops.gemm(dyd, ps.wT(pfx + 'linear2.weight'), mul_aux=s['fmask'], mul_mode=ops.MUL_BITMASK, mul_scale=inv)
     elif bf:     # K = 512 dgrads against the transposed mirror (NT, A-stationary kernel)

@@ -33,6 +33,26 @@ def _rows(t):
 
 _ws_cache = {}
 GEMM_TIMING = None   # bench.py sets this to a list: every GEMM launch is then bracketed by HIP events on its launch stream (in situ)
+KERNEL_TIMING = None  # bench.py sets this to a dict kind -> list of (event0, event1, algorithmic flops, algorithmic bytes) for the attention kernels
+
+
+class _timed:
+    """with _timed(kind, flops, bytes): brackets the launches inside with HIP events on torch's current stream when bench.py asked for it."""
+
+    def __init__(self, kind, flops, nbytes):
+        self.kind, self.flops, self.nbytes = kind, flops, nbytes
+
+    def __enter__(self):
+        if KERNEL_TIMING is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if KERNEL_TIMING is not None:
+            self.e1.record()
+            KERNEL_TIMING.setdefault(self.kind, []).append((self.e0, self.e1, self.flops, self.nbytes))
+        return False
 
 
 def _workspace(kind, device, need):
@@ -80,15 +100,18 @@ def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumu
         e1.record()
         kind = ('T' if a_trans else 'N') + ('N' if b_trans else 'T')
         if kind == 'NT':
-            kind += '/K>1024' if K > 1024 else ('/K=512' if (K == 512 and A.dtype == torch.bfloat16 and M % 128 == 0 and N % 64 == 0 and 64 <= N <= 2048) else '')
+            kind += '/K>1024' if K > 1024 else ('/K=512' if (K == 512 and A.dtype == torch.bfloat16 and M % 128 == 0 and M >= ASTAT_MIN_ROWS and N % 64 == 0 and 64 <= N <= 2048) else '')
         GEMM_TIMING.append((kind, e0, e1, 2.0 * M * N * K,
                             (M * K + N * K) * A.element_size() + M * N * out.element_size(), (M, N, K)))
     return out
 
 
+ASTAT_MIN_ROWS = 128 * 256      # emo_gemm_astat.hip: one 128-row panel per block, at least one block per CU
+
+
 def gemm_bitmask_ok(M, N, K, in_dtype, out_dtype):
     """Shape class in which emo_gemm writes / reads the 1-bit epilogue mask (mask_out / MUL_BITMASK): the A-stationary K = 512 kernel."""
-    return in_dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and K == 512 and M % 128 == 0 and N % 64 == 0 and 64 <= N <= 2048
+    return in_dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and K == 512 and M % 128 == 0 and M >= ASTAT_MIN_ROWS and N % 64 == 0 and 64 <= N <= 2048
 
 
 def colsum(X, out=None, accumulate=False):
@@ -165,8 +188,10 @@ def favor_attn_fwd(q, k, v, omega, B, T, H, eps=1e-6, want_state=False):
     S = torch.empty(B, H, n_feat, dh, device=q.device, dtype=torch.float32) if want_state else None
     z = torch.empty(B, H, n_feat, device=q.device, dtype=torch.float32) if want_state else None
     ws, ws_bytes = _favor_workspace(q.device, B, T, H, dh, n_feat)
-    check(lib.emo_favor_attn_fwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(omega), ptr(out), HD, ptr(den), ptr(S), ptr(z), dtype_code(q.dtype),
-                                 B, T, H, dh, n_feat, eps, ptr(ws), ws_bytes, stream()))
+    # algorithmic HBM bytes: read q, k, v + write out = 4 * H*dh * e per token
+    with _timed('favor_fwd', 0.0, 4.0 * M * HD * q.element_size()):
+        check(lib.emo_favor_attn_fwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(omega), ptr(out), HD, ptr(den), ptr(S), ptr(z), dtype_code(q.dtype),
+                                     B, T, H, dh, n_feat, eps, ptr(ws), ws_bytes, stream()))
     return (out, den, S, z) if want_state else (out, den)
 
 
@@ -180,8 +205,10 @@ def favor_attn_bwd(q, k, v, omega, out, dout, den, B, T, H, dqkv=None, eps=1e-6)
         dqkv = torch.empty(M, 3 * HD, device=q.device, dtype=q.dtype)
     dq, dk, dv = dqkv[:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:]
     ws, ws_bytes = _favor_workspace(q.device, B, T, H, dh, n_feat)
-    check(lib.emo_favor_attn_bwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(omega), ptr(out), ptr(dout), HD, ptr(den), ptr(dq), ptr(dk), ptr(dv),
-                                 3 * HD, dtype_code(q.dtype), B, T, H, dh, n_feat, eps, ptr(ws), ws_bytes, stream()))
+    # read q, k, v, dout (+ out) + write dq, dk, dv = 7 * H*dh * e per token
+    with _timed('favor_bwd', 0.0, 7.0 * M * HD * q.element_size()):
+        check(lib.emo_favor_attn_bwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(omega), ptr(out), ptr(dout), HD, ptr(den), ptr(dq), ptr(dk), ptr(dv),
+                                     3 * HD, dtype_code(q.dtype), B, T, H, dh, n_feat, eps, ptr(ws), ws_bytes, stream()))
     return dq, dk, dv
 
 
@@ -208,8 +235,10 @@ def softmax_attn_fwd(q, k, v, B, T, H, p_drop=0.0, seed=0, offset=0):
     assert M == B * T and _rows(q) == _rows(k) == _rows(v)
     out = torch.empty(M, HD, device=q.device, dtype=q.dtype)
     lse = torch.empty(B, H, T, device=q.device, dtype=torch.float32)
-    check(lib.emo_softmax_attn_fwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(out), HD, ptr(lse), dtype_code(q.dtype), B, T, H, dh, p_drop,
-                                   seed, offset, stream()))
+    # 2 matmuls (Q K^T, P V) of 2*T*T*dh FLOP per (b, h), half of the tiles skipped by the causal mask
+    with _timed('sattn_fwd', 0.5 * 2 * 2.0 * B * H * T * T * dh, 4.0 * M * HD * q.element_size()):
+        check(lib.emo_softmax_attn_fwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(out), HD, ptr(lse), dtype_code(q.dtype), B, T, H, dh, p_drop,
+                                       seed, offset, stream()))
     return out, lse
 
 
@@ -221,8 +250,10 @@ def softmax_attn_bwd(q, k, v, out, dout, lse, B, T, H, p_drop=0.0, seed=0, offse
         dqkv = torch.empty(M, 3 * HD, device=q.device, dtype=q.dtype)
     dq, dk, dv = dqkv[:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:]
     delta = torch.empty(B, H, T, device=q.device, dtype=torch.float32)          # dO.O per query row, handed from the dQ to the dK/dV pass
-    check(lib.emo_softmax_attn_bwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(out), ptr(dout), HD, ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), 3 * HD,
-                                   dtype_code(q.dtype), B, T, H, dh, p_drop, seed, offset, stream()))
+    # dQ pass: S, dP, dQ; dK/dV pass: S, dP, dV, dK = 7 matmuls, causal half
+    with _timed('sattn_bwd', 0.5 * 7 * 2.0 * B * H * T * T * dh, 8.0 * M * HD * q.element_size()):
+        check(lib.emo_softmax_attn_bwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(out), ptr(dout), HD, ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), 3 * HD,
+                                       dtype_code(q.dtype), B, T, H, dh, p_drop, seed, offset, stream()))
     return dq, dk, dv
 
 

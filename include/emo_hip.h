@@ -79,7 +79,7 @@ typedef struct {
     float* b_rowsum;      /* NULL or [N] fp32: += sum_k op(B)[n][k]; needs a_trans and b_trans (HF Conv1D layout, where dY is the B operand) */
     uint8_t* mask_out;    /* NULL or [M, N/8] bytes: bit j of byte (m, n/8) = (value after act and dropout != 0) for column 8*(n/8)+j — the 1-bit
                            * relu.dropout mask the FFN2 dgrad needs (instead of re-reading the [M,N] activation).  Only with EMO_MUL_BITMASK's
-                           * shape class: bf16 in/out, NT, K = 512, M % 128 == 0, N % 64 == 0 (the A-stationary kernel); refused elsewhere. */
+                           * shape class: bf16 in/out, NT, K = 512, M % 128 == 0, M >= 32768, N % 64 == 0, N <= 2048 (the A-stationary kernel); refused elsewhere. */
     void* workspace;      /* NULL or caller scratch for split-K partial sums (plain fp32-output GEMMs = weight gradients): */
     int64_t workspace_bytes; /* with it the splits are summed in a fixed order by a reduce kernel (deterministic, no atomics);
                               * without it they are fp32 atomics into C.  Size: emo_gemm_workspace_bytes(). */
