@@ -90,7 +90,8 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
 
     serial = instrumented(False)
     overlapped = instrumented(True) if engine._SIDE['on'] else {}
-    pmc_files = {'TN': os.path.join(ROOT, 'profiles', 'r01_pmc_wgrad.json'), 'NN': os.path.join(ROOT, 'profiles', 'r01_pmc_dgrad.json')}
+    pmc_files = {'TN': os.path.join(ROOT, 'profiles', 'r01_pmc_wgrad.json'), 'NN': os.path.join(ROOT, 'profiles', 'r01_pmc_dgrad.json'),
+                 'NT/K=512': os.path.join(ROOT, 'profiles', 'r02_pmc_astat.json')}
 
     def entry(kind):
         d = serial[kind]
@@ -98,7 +99,10 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
         traffic = None      # HBM bytes per launch from rocprofv3 PMC passes (collected offline, committed under profiles/)
         pmc = pmc_files.get(kind)
         if pmc and os.path.exists(pmc) and B * T == 131072:
-            traffic = json.load(open(pmc)).get('traffic_bytes_per_launch')
+            j = json.load(open(pmc))
+            traffic = j.get('traffic_bytes_per_launch')
+            if 'ratio' in j:         # counters were collected on ONE shape of the class: scale the class's algorithmic bytes by its measured ratio
+                traffic = round(j['ratio'] * d['bytes'] / d['n'])
         return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
                 'kernel': '%s (%s)' % GEMM_KERNELS.get(kind, (kind, 'other GEMM')), 'launches_timed': d['n'], 'avg_launch_ms': round(d['ms'] / d['n'], 4),
@@ -109,9 +113,8 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
     order = sorted(serial, key=lambda k: -serial[k]['ms'])
     roof = entry(order[0])
     roof['timing'] = 'HIP events on the launch stream around every GEMM launch in %d real training steps (kernels serialized on one stream)' % n_steps
-    roof['rocprof_summary'] = ('profiles/r01_bench_train_rocprof_stats.txt = rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-gen --no-stage1` '
-                               '(training kernels only: this kernel 319.5 us average over 720 launches); profiles/r01_bench_final_rocprof_stats.txt = the full default command, '
-                               'where the stage-1 and generation legs launch the same kernel instance on small shapes and pull its average down')
+    roof['rocprof_summary'] = ('profiles/r02_bench_train_rocprof_stats.txt = rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3 --no-cpu-baseline '
+                               '--no-gen --no-stage1 --no-gpt2 --no-step0-check` (training kernels only); PMC traffic: profiles/r02_pmc_astat.json, r01_pmc_dgrad.json, r01_pmc_wgrad.json')
     roof['roofline_others'] = [entry(k) for k in order[1:]] + [attn_entry(k, v, n_steps) for k, v in sorted(extra.items())]
     return roof
 
