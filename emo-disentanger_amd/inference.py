@@ -580,3 +580,80 @@ def generate_streams(model, prompt_tok, prompt_seg, n_new, temp=1.1, top_p=0.9, 
             for ch in cs:
                 main.wait_stream(ch.stream)
     return cs[0].out if chains == 1 else torch.cat([ch.out for ch in cs], 0)
+
+
+# ------------------------------------------------------------------------------------------------ command line (reference inference.py:330-485)
+def read_lead_sheet(path, event2idx):
+    """A stage-1 output file: one event per line, optionally a Key_* line first, bars opened by Bar_None.  -> (key event, [[ids of bar 0], ...])"""
+    events = open(path).read().splitlines()
+    key = events[0] if events and 'Key' in events[0] else 'Key_C'
+    starts = [i for i, e in enumerate(events) if e == 'Bar_None'] + [len(events)]
+    return key, [[event2idx[e] for e in events[a:b]] for a, b in zip(starts[:-1], starts[1:])]
+
+
+def emotions_of(file_name):
+    for tag, cands in (('Positive', ['Q1', 'Q4']), ('Negative', ['Q2', 'Q3']), ('Q1', ['Q1']), ('Q2', ['Q2']), ('Q3', ['Q3']), ('Q4', ['Q4']), ('None', ['None'])):
+        if tag in file_name:
+            return cands
+    raise ValueError('wrong emotion label')
+
+
+def main(argv=None):
+    """Same flags as the reference's stage-2 inference.py (-m / -c / -r / -i / -o): every lead sheet found in the output directory gets its
+    accompaniment, all jobs of a run in lock-step on ONE decode engine (--streams at a time).  The generated events are written as text
+    (`<piece>_<emotion>_full.txt`, one event per line); turning them into MIDI is the reference's convert2midi.py (needs miditoolkit) and
+    is run on those files when that module is importable."""
+    import argparse
+    import yaml
+    from . import train as tr
+    from .data import load_vocab
+    ap = argparse.ArgumentParser(description='stage-2 accompaniment generation on MI355X')
+    req = ap.add_argument_group('required arguments')
+    req.add_argument('-m', '--model_type', choices=['performer', 'gpt2'], required=True)
+    req.add_argument('-c', '--configuration', required=True)
+    req.add_argument('-r', '--representation', choices=['remi', 'functional'], required=True)
+    ap.add_argument('-i', '--inference_params', required=True, help='checkpoint (.pt state dict)')
+    ap.add_argument('-o', '--output_dir', required=True, help='directory holding the stage-1 lead sheets; results are written next to them')
+    ap.add_argument('--streams', type=int, default=32, help='lead sheets generated in lock-step on one decode engine')
+    ap.add_argument('--max_bars', type=int, default=128)
+    ap.add_argument('--dtype', default=None, choices=[None, 'bf16', 'fp32'])
+    args = ap.parse_args(argv)
+    conf = yaml.load(open(args.configuration), Loader=yaml.FullLoader)
+    torch.cuda.set_device(conf['training']['gpuid'])
+    event2idx, idx2event, pad = load_vocab(conf['data_loader']['vocab_path'].format(args.representation))
+    model = tr.build_model(args.model_type, pad + 1, conf['model'], args.dtype).cuda()
+    tr.load_pretrained(model, args.inference_params)
+    model.eval()
+    temp, top_p = (1.1, 0.99) if args.model_type == 'performer' else (1.2, 0.97)
+    print('[info] temp = %s | top_p = %s' % (temp, top_p))
+    pat = 'roman.txt' if args.representation == 'functional' else '.txt'
+    jobs = []
+    for f in sorted(os.listdir(args.output_dir)):
+        if pat not in f or f.endswith('_full.txt'):
+            continue
+        key, bars = read_lead_sheet(os.path.join(args.output_dir, f), event2idx)
+        for e in emotions_of(f):
+            out = os.path.join(args.output_dir, '_'.join(f.split('_')[:2]) + '_' + e + '_full.txt')
+            if os.path.exists(out):
+                print('[info] %s exists, skipping ...' % out)
+                continue
+            primer = [event2idx['Emotion_%s' % e]] + ([event2idx[key]] if args.representation == 'functional' else []) + [event2idx['Tempo_110']]
+            jobs.append((out, key, bars, primer))
+    print('[# jobs]', len(jobs))
+    for i in range(0, len(jobs), args.streams):
+        group = jobs[i:i + args.streams]
+        gen = generate_conditional_batch(model, event2idx, idx2event, [g[2] for g in group], [g[3] for g in group], max_bars=args.max_bars,
+                                         temp=temp, top_p=top_p, seeds=list(range(i, i + len(group))))
+        for (out, key, _, _), ids in zip(group, gen):
+            with open(out, 'w') as fh:
+                fh.write('\n'.join([key] + [idx2event[w] for w in ids]) + '\n')
+            print('[info] wrote', out, len(ids), 'events')
+    try:
+        import convert2midi  # noqa: F401  (the reference's module, if the user put it on the path together with miditoolkit)
+        print('[info] convert2midi is importable: run it on the *_full.txt files to obtain MIDI')
+    except ImportError:
+        print('[info] event files written; MIDI conversion (reference convert2midi.py, needs miditoolkit) is outside this package')
+
+
+if __name__ == '__main__':
+    main()

@@ -189,3 +189,21 @@ def test_event_piece_dataset_matches_reference():
                     assert g == v, (key, seed, i, k)
     batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=3)))           # default collation gives the train loop's [B, T] int64 tensors
     assert batch['dec_input'].shape == (3, 400) and batch['dec_input'].dtype == torch.int64 and batch['track_mask'].max() == 1
+
+
+def test_lead_sheet_reader_and_emotion_candidates(tmp_path):
+    """Host helpers of the generation command line (reference inference.py:149-165, 431-447): bars are split at Bar_None, a leading Key_* line
+    is the key (default Key_C), the emotion candidates come from the file name, unknown names raise ValueError('wrong emotion label')."""
+    from emo_disentanger_amd import inference as inf
+    e2i = {e: i for i, e in enumerate(['Key_G', 'Bar_None', 'Beat_0', 'Chord_I_M', 'Note_Pitch_60', 'Beat_8'])}
+    f = tmp_path / 'samp_00_Positive_roman.txt'
+    f.write_text('\n'.join(['Key_G', 'Bar_None', 'Beat_0', 'Chord_I_M', 'Bar_None', 'Beat_8', 'Note_Pitch_60']) + '\n')
+    key, bars = inf.read_lead_sheet(str(f), e2i)
+    assert key == 'Key_G' and bars == [[1, 2, 3], [1, 5, 4]]
+    g = tmp_path / 'x_Q3.txt'
+    g.write_text('Bar_None\nBeat_0\n')
+    assert inf.read_lead_sheet(str(g), e2i) == ('Key_C', [[1, 2]])
+    assert inf.emotions_of('samp_00_Positive_roman.txt') == ['Q1', 'Q4'] and inf.emotions_of('a_Negative.txt') == ['Q2', 'Q3']
+    assert inf.emotions_of('a_Q2_x.txt') == ['Q2'] and inf.emotions_of('a_None.txt') == ['None']
+    with pytest.raises(ValueError, match='wrong emotion label'):
+        inf.emotions_of('plain.txt')
