@@ -66,7 +66,7 @@ template <> __device__ __forceinline__ uint32_t as_load1<4>(const char* sbase, u
 // Stores with an SGPR base + 32-bit per-lane offset (hipcc otherwise keeps one 64-bit per-lane pointer per output tensor live across the
 // whole loop, which is what pushed this kernel over 256 VGPRs).  boff: BYTE offset of the lane.
 __device__ __forceinline__ void as_store16(const void* sbase, uint32_t boff, u32x4 d) {
-    asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void as_store16_o16(const void* sbase, uint32_t boff, u32x4 d) {
     asm volatile("global_store_dwordx4 %0, %1, %2 offset:16" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
