@@ -66,6 +66,9 @@ template <> __device__ __forceinline__ uint32_t as_load1<4>(const char* sbase, u
 // Stores with an SGPR base + 32-bit per-lane offset (hipcc otherwise keeps one 64-bit per-lane pointer per output tensor live across the
 // whole loop, which is what pushed this kernel over 256 VGPRs).  boff: BYTE offset of the lane.
 __device__ __forceinline__ void as_store16(const void* sbase, uint32_t boff, u32x4 d) {
+    asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void as_store16_nt(const void* sbase, uint32_t boff, u32x4 d) {
     asm volatile("global_store_dwordx4 %0, %1, %2 nt" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void as_store16_o16(const void* sbase, uint32_t boff, u32x4 d) {
@@ -74,7 +77,7 @@ __device__ __forceinline__ void as_store16_o16(const void* sbase, uint32_t boff,
 __device__ __forceinline__ void as_store1(const void* sbase, uint32_t boff, uint32_t d) {
     asm volatile("global_store_byte %0, %1, %2" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
 }
-template <typename OutT> __device__ __forceinline__ void as_store_row8(const OutT* sbase, uint32_t eoff, const float (&v)[8]) {
+template <typename OutT> __device__ __forceinline__ void as_store_row8(const OutT* sbase, uint32_t eoff, const float (&v)[8], bool nt = false) {
     if constexpr (sizeof(OutT) == 4) {
         as_store16(sbase, eoff * 4, (u32x4){__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1]), __builtin_bit_cast(uint32_t, v[2]), __builtin_bit_cast(uint32_t, v[3])});
         as_store16_o16(sbase, eoff * 4, (u32x4){__builtin_bit_cast(uint32_t, v[4]), __builtin_bit_cast(uint32_t, v[5]), __builtin_bit_cast(uint32_t, v[6]), __builtin_bit_cast(uint32_t, v[7])});
@@ -82,7 +85,8 @@ template <typename OutT> __device__ __forceinline__ void as_store_row8(const Out
         bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
-        as_store16(sbase, eoff * 2, __builtin_bit_cast(u32x4, o));
+        if (nt) as_store16_nt(sbase, eoff * 2, __builtin_bit_cast(u32x4, o));
+        else as_store16(sbase, eoff * 2, __builtin_bit_cast(u32x4, o));
     }
 }
 template <int N> __device__ __forceinline__ void as_pin(u32x4 (&r)[4]);
@@ -162,7 +166,7 @@ __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ 
 #ifdef EMO_DIAG
     if (ep.ablate == 1) return;                                   // diagnostics: no output stores
 #endif
-    as_store_row8<OutT>(C + ub, lo, v);
+    as_store_row8<OutT>(C + ub, lo, v, ep.nt_store != 0);
 }
 
 // BITS: the 1-bit mask operand (EMO_MUL_BITMASK, 1 byte per 8 columns) is prefetched by inline-asm loads half a stage before the epilogue.
@@ -317,7 +321,8 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
 }  // namespace
 
 bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int dtype_out, int64_t M, int64_t N, int64_t K,
-                        const EpiParams& ep, hipStream_t st) {
+                        const EpiParams& ep_in, hipStream_t st) {
+    EpiParams ep = ep_in;
     const bool off = getenv("EMO_GEMM_NO_ASTAT") != nullptr;      // (read per call: the parity test toggles it in-process)
     // one block owns a 128-row panel and sweeps all of N: the grid is M / 128 blocks, so small token counts (the reference's batch_size 4,
     // stage 1) leave most CUs idle where the 128 x 128 tiling has N / 128 times more blocks -> A-stationary only from one block per CU up
@@ -328,6 +333,10 @@ bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t l
     if ((uint64_t)(AS_BN * ldb + AS_K) * 2 >= 0xFFFF0000ull) return false;
     const size_t lds = AS_RING + AS_MAXN * sizeof(float);
     dim3 grid((unsigned)(M / AS_BM));
+    // outputs beyond the 256-MB MALL are streamed with non-temporal stores (r02 in-step A/B: leaves L2 / MALL to the operands of the
+    // kernels around it, 61.1 -> 60.5 ms/step); smaller outputs are read back by the next kernel and stay cacheable
+    ep.nt_store = (M * N * 2 >= (int64_t)256 << 20) ? 1 : 0;
+    { const char* e = getenv("EMO_ASTAT_NT"); if (e) ep.nt_store = atoi(e); }
 #define AS_LAUNCH(OutT, BITS)                                                                                                              \
     do {                                                                                                                                  \
         auto k = gemm_astat_kernel<OutT, BITS>;                                                                                           \
