@@ -69,7 +69,7 @@ __device__ __forceinline__ void features_rowmajor(CT* Ff, int ldf, const CT* WT,
             if (NT % FW != 0 && tile >= NT) break;
         const int rt = tile / (C / 16), ct = tile % (C / 16);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        mm16<CT>(acc, WT, ldx, rt * 16, X, ldx, ct * 16, DHP, lane);
+        mm16<CT, DHP>(acc, WT, ldx, rt * 16, X, ldx, ct * 16, lane);
         const int t = ct * 16 + (lane & 15), m0 = rt * 16 + (lane >> 4) * 4;
         const float o = off[t];
         const float ok = t < valid_rows ? 1.f : 0.f;
@@ -93,7 +93,7 @@ __device__ __forceinline__ void features_both(CT* Ff, int ldf, CT* FTt, int ldt,
         if (NT % FW != 0 && tile >= NT) break;
         const int rt = tile / (C / 16), ct = tile % (C / 16);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        mm16<CT>(acc, WT, ldx, rt * 16, X, ldx, ct * 16, DHP, lane);
+        mm16<CT, DHP>(acc, WT, ldx, rt * 16, X, ldx, ct * 16, lane);
         const int t = ct * 16 + (lane & 15), m0 = rt * 16 + (lane >> 4) * 4;
         const float o = off[t];
         const float ok = t < valid_rows ? 1.f : 0.f;
@@ -119,7 +119,7 @@ __device__ __forceinline__ void features_transposed(CT* FT, int ldt, const CT* W
             if (NT % FW != 0 && tile >= NT) break;
         const int rt = tile / (MF / 16), ct = tile % (MF / 16);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        mm16<CT>(acc, X, ldx, rt * 16, WT, ldx, ct * 16, DHP, lane);
+        mm16<CT, DHP>(acc, X, ldx, rt * 16, WT, ldx, ct * 16, lane);
         const int t0 = rt * 16 + (lane >> 4) * 4, m = ct * 16 + (lane & 15);
         float p[4], n[4];
 #pragma unroll
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
             if (NT % FW != 0 && tile >= NT) break;
                 const int jt = tile / (C / 16), tt = tile % (C / 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                if (jt <= tt) mm16<CT>(acc, Kf, LDF, jt * 16, Qf, LDF, tt * 16, F, lane);
+                if (jt <= tt) mm16<CT, F>(acc, Kf, LDF, jt * 16, Qf, LDF, tt * 16, lane);
                 const int t = tt * 16 + (lane & 15), j0 = jt * 16 + (lane >> 4) * 4;
                 Img<CT>::store4(Am + t * LDC + j0, j0 <= t ? acc[0] : 0.f, j0 + 1 <= t ? acc[1] : 0.f, j0 + 2 <= t ? acc[2] : 0.f,
                                 j0 + 3 <= t ? acc[3] : 0.f);
@@ -316,8 +316,8 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
             if (NT % FW != 0 && tile >= NT) break;
                 const int dt = tile / (C / 16), tt = tile % (C / 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                mm16<CT>(acc, VT, LDC, dt * 16, Am, LDC, tt * 16, CP, lane);
-                mm16<CT>(acc, ST, LDF, dt * 16, Qf, LDF, tt * 16, F, lane);
+                mm16<CT, CP>(acc, VT, LDC, dt * 16, Am, LDC, tt * 16, lane);
+                mm16<CT, F>(acc, ST, LDF, dt * 16, Qf, LDF, tt * 16, lane);
                 const int t = tt * 16 + (lane & 15), d0 = dt * 16 + (lane >> 4) * 4;
                 if (t < valid) {
                     const float inv = 1.f / dens[t];
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
             const int tile = wave + FW * i;
             if (tile < NTS) {
                 const int ft = tile / (DH / 16), dt = tile % (DH / 16);
-                mm16<CT>(sacc[i], KfT, LDC, ft * 16, VT, LDC, dt * 16, CP, lane);
+                mm16<CT, CP>(sacc[i], KfT, LDC, ft * 16, VT, LDC, dt * 16, lane);
                 if constexpr (!SO) {
                     const int d = dt * 16 + (lane & 15), f0 = ft * 16 + (lane >> 4) * 4;
                     Img<CT>::store4(ST + d * LDF + f0, sacc[i][0], sacc[i][1], sacc[i][2], sacc[i][3]);
@@ -479,7 +479,7 @@ __device__ __forceinline__ void dx_from_adiff(const CT* W, int ldw, const CT* Ad
             if (NT % FW != 0 && tile >= NT) break;
         const int dt = tile / (C / 16), tt = tile % (C / 16);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        mm16<CT>(acc, W, ldw, dt * 16, Adiff, lda, tt * 16, MFP, lane);
+        mm16<CT, MFP>(acc, W, ldw, dt * 16, Adiff, lda, tt * 16, lane);
         const int t = tt * 16 + (lane & 15), d0 = dt * 16 + (lane >> 4) * 4;
         if (t < valid) {
             const float sa = sumA[t];
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
             if (NT % FW != 0 && tile >= NT) break;
                 const int jt = tile / (C / 16), tt = tile % (C / 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                if (jt <= tt) mm16<CT>(acc, Vr, LDX, jt * 16, G, LDX, tt * 16, DHP, lane);
+                if (jt <= tt) mm16<CT, DHP>(acc, Vr, LDX, jt * 16, G, LDX, tt * 16, lane);
                 const int t = tt * 16 + (lane & 15), j0 = jt * 16 + (lane >> 4) * 4;
                 const float dd = dD[t];
                 Img<CT>::store4(Pm + t * LDC + j0, j0 <= t ? acc[0] + dd : 0.f, j0 + 1 <= t ? acc[1] + dd : 0.f,
@@ -629,10 +629,10 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
             if (NP % FW != 0 && pr >= NP) break;
                 const int ft = pr / (C / 16), tt = pr % (C / 16);
                 f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f};
-                mm16<CT>(aP, KfT, LDC, ft * 16, Pm, LDC, tt * 16, CP, lane);
-                mm16<CT>(aP, SF, LDX, ft * 16, G, LDX, tt * 16, DHP, lane);
-                mm16<CT>(aM, KfT, LDC, MF + ft * 16, Pm, LDC, tt * 16, CP, lane);
-                mm16<CT>(aM, SF, LDX, MF + ft * 16, G, LDX, tt * 16, DHP, lane);
+                mm16<CT, CP>(aP, KfT, LDC, ft * 16, Pm, LDC, tt * 16, lane);
+                mm16<CT, DHP>(aP, SF, LDX, ft * 16, G, LDX, tt * 16, lane);
+                mm16<CT, CP>(aM, KfT, LDC, MF + ft * 16, Pm, LDC, tt * 16, lane);
+                mm16<CT, DHP>(aM, SF, LDX, MF + ft * 16, G, LDX, tt * 16, lane);
                 const int t = tt * 16 + (lane & 15), m0 = ft * 16 + (lane >> 4) * 4;
                 jac_epilogue<CT, MF>(aP, aM, Qf, LDF, Adiff, LDM, sumA, zz, dD[t], t, m0, lane);
             }
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
             const int tile = wave + FW * i;
             if (tile < NTS) {
                 const int dt = tile / (F / 16), ft = tile % (F / 16);
-                mm16<CT>(sacc[i], VT, LDC, dt * 16, KfT, LDC, ft * 16, CP, lane);
+                mm16<CT, CP>(sacc[i], VT, LDC, dt * 16, KfT, LDC, ft * 16, lane);
             }
         }
         __syncthreads();   // all reads of SF / zz for this chunk are done
@@ -819,8 +819,8 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
                 const int tt = tile / (C / 16), jt = tile % (C / 16);
                 f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aA = {0.f, 0.f, 0.f, 0.f};
                 if (tt >= jt) {
-                    mm16<CT>(aP, G, LDX, tt * 16, Vr, LDX, jt * 16, DHP, lane);
-                    mm16<CT>(aA, Qf, LDF, tt * 16, Kf, LDF, jt * 16, F, lane);
+                    mm16<CT, DHP>(aP, G, LDX, tt * 16, Vr, LDX, jt * 16, lane);
+                    mm16<CT, F>(aA, Qf, LDF, tt * 16, Kf, LDF, jt * 16, lane);
                 }
                 const int j = jt * 16 + (lane & 15), tb = tt * 16 + (lane >> 4) * 4;
                 float p[4], a[4];
@@ -846,10 +846,10 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
             if (NP % FW != 0 && pr >= NP) break;
                 const int ft = pr / (C / 16), jt = pr % (C / 16);
                 f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f};
-                mm16<CT>(aP, QfT, LDC, ft * 16, PmT, LDC, jt * 16, CP, lane);
-                mm16<CT>(aP, RF, LDX, ft * 16, Vr, LDX, jt * 16, DHP, lane);
-                mm16<CT>(aM, QfT, LDC, MF + ft * 16, PmT, LDC, jt * 16, CP, lane);
-                mm16<CT>(aM, RF, LDX, MF + ft * 16, Vr, LDX, jt * 16, DHP, lane);
+                mm16<CT, CP>(aP, QfT, LDC, ft * 16, PmT, LDC, jt * 16, lane);
+                mm16<CT, DHP>(aP, RF, LDX, ft * 16, Vr, LDX, jt * 16, lane);
+                mm16<CT, CP>(aM, QfT, LDC, MF + ft * 16, PmT, LDC, jt * 16, lane);
+                mm16<CT, DHP>(aM, RF, LDX, MF + ft * 16, Vr, LDX, jt * 16, lane);
                 const int j = jt * 16 + (lane & 15), m0 = ft * 16 + (lane >> 4) * 4;
                 jac_epilogue<CT, MF>(aP, aM, Kf, LDF, Adiff, LDM, sumA, rr, 1.f, j, m0, lane);
             }
@@ -862,8 +862,8 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
             if (NT % FW != 0 && tile >= NT) break;
                 const int dt = tile / (C / 16), jt = tile % (C / 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                mm16<CT>(acc, GT, LDC, dt * 16, AmT, LDC, jt * 16, CP, lane);
-                mm16<CT>(acc, RT, LDF, dt * 16, Kf, LDF, jt * 16, F, lane);
+                mm16<CT, CP>(acc, GT, LDC, dt * 16, AmT, LDC, jt * 16, lane);
+                mm16<CT, F>(acc, RT, LDF, dt * 16, Kf, LDF, jt * 16, lane);
                 const int j = jt * 16 + (lane & 15), d0 = dt * 16 + (lane >> 4) * 4;
                 if (j < valid) Img<CT>::store4(dvb + (t0 + j) * ld_d + d0, acc[0], acc[1], acc[2], acc[3]);
             }
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
             const int tile = wave + FW * i;
             if (tile < NTS) {
                 const int dt = tile / (F / 16), ft = tile % (F / 16);
-                mm16<CT>(racc[i], GT, LDC, dt * 16, QfT, LDC, ft * 16, CP, lane);
+                mm16<CT, CP>(racc[i], GT, LDC, dt * 16, QfT, LDC, ft * 16, lane);
             }
         }
         if constexpr (!SO) {
