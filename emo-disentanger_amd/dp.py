@@ -44,6 +44,8 @@ def _init_rccl(rank, world):
     dist.broadcast(msg, src=0)                                        # control plane (gloo, host memory)
     if int(msg[128]) != 1:
         raise RuntimeError('rank 0 could not create the RCCL unique id: ' + lib.emo_last_error().decode())
+    torch.empty(1, device='cuda')                                     # the HIP context of this thread is on the rank's device before RCCL binds it
+    torch.cuda.synchronize()
     check(lib.emo_comm_init(ctypes.c_char_p(bytes(msg[:128].numpy().tobytes())), rank, world))
     probe = torch.full((4,), rank + 1, device='cuda', dtype=torch.int64)
     check(lib.emo_comm_allreduce(probe.data_ptr(), 4, I64, torch.cuda.current_stream().cuda_stream))
