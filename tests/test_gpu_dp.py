@@ -85,6 +85,40 @@ dp.shutdown()
 '''
 
 
+STAGE1_SCRIPT = r'''
+import os, sys, tempfile, numpy as np, torch
+sys.path.insert(0, os.environ["EMO_ROOT"])
+from emo_disentanger_amd import dp, stage1_train as st
+from emo_disentanger_amd.model.plain_transformer import PlainTransformer
+from emo_disentanger_amd.optim import FusedAdam
+torch.cuda.set_device(0)
+torch.manual_seed(0)
+V, B, T = 40, 4, 48
+m = PlainTransformer(64, V, 2, 4, 64, 128, 0, T, dec_dropout=0.0, pre_lnorm=True, compute_dtype="fp32").cuda()
+rank, world = st.setup_data_parallel(m)              # rank 0's weights broadcast (both ranks built the same ones here)
+g = np.random.default_rng(5)
+x = g.integers(0, V - 1, size=(B, T), dtype=np.int64)
+tgt = np.concatenate([x[:, 1:], np.full((B, 1), V - 2, dtype=np.int64)], 1)
+for b in range(B):
+    tgt[b, T - 3 - 4 * b:] = V - 1                   # a different number of pad targets per sequence -> unequal counts per rank
+per = B // world
+sl = slice(rank * per, (rank + 1) * per)
+z = np.zeros((per, T), dtype=np.int64)
+batch = {"id": torch.arange(per), "n_seg": [1] * per, "dec_inp_0": torch.from_numpy(x[sl]), "dec_tgt_0": torch.from_numpy(tgt[sl]),
+         "dec_seg_len_0": torch.full((per,), T, dtype=torch.long), "inp_chord_0": torch.from_numpy(z), "inp_melody_0": torch.from_numpy(z.copy())}
+opt = FusedAdam(m, lr=1e-3, max_grad_norm=0.5, world_size=world, token_weighted=True) if os.environ["EMO_S1_OPT"] == "fused" else torch.optim.Adam(m.parameters(), lr=1e-3)
+cfg = st.Stage1Config(warmup_steps=10 ** 6, max_lr=1e-3, log_interval=10 ** 9, ckpt_dir=tempfile.mkdtemp(), verbose=False)
+opt.param_groups[0]["lr"] = 1e-3
+p0 = m._ensure_store().flat32.clone()
+st.train(1, m, [batch], opt, None, V - 1, cfg, st.Stage1State())
+ps = m._store
+torch.cuda.synchronize()
+np.savez(os.environ["EMO_OUT"] + ".rank%d.npz" % rank, before=p0.cpu().numpy(), after=ps.flat32.cpu().numpy())
+dp.barrier()
+dp.shutdown()
+'''
+
+
 def _free_port():
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
@@ -141,3 +175,28 @@ def test_bench_refuses_more_ranks_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
                        env=_env(WORLD_SIZE=1, RANK=0, LOCAL_RANK=0), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr and '"value"' not in r.stdout
+
+
+@pytest.mark.parametrize('opt', ['fused', 'adam'])
+def test_stage1_two_rank_step_equals_one_rank(tmp_path, opt):
+    """BASELINE configs[4] (stage-1 lead-sheet LM, data parallel): stage1_train.train with 2 ranks (token-count-weighted exchange, fused
+    clip + Adam or the reference's torch.optim.Adam behind clip_grad_norm_) equals the 1-rank step on the concatenated batch."""
+    out1, out2 = str(tmp_path / 'w1'), str(tmp_path / 'w2')
+    r = subprocess.run([sys.executable, '-c', STAGE1_SCRIPT], env=_env(EMO_OUT=out1, WORLD_SIZE=1, RANK=0, LOCAL_RANK=0, EMO_S1_OPT=opt), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, '-c', STAGE1_SCRIPT], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=_env(EMO_OUT=out2, WORLD_SIZE=2, RANK=rk, LOCAL_RANK=0, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, EMO_COMM='gloo',
+                                       EMO_S1_OPT=opt)) for rk in range(2)]
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), '\n'.join(l[-3000:] for l in logs)
+    one = np.load(out1 + '.rank0.npz')
+    two = [np.load(out2 + '.rank%d.npz' % rk) for rk in range(2)]
+    step = np.abs(one['after'] - one['before']).max()
+    assert step > 0
+    for t in two:
+        np.testing.assert_array_equal(t['before'], one['before'])
+        d = np.abs(t['after'] - one['after']) / step
+        assert np.quantile(d, 0.999) <= 1e-3 and d.max() <= 0.5, (np.quantile(d, 0.999), d.max())
+    np.testing.assert_array_equal(two[0]['after'], two[1]['after'])
