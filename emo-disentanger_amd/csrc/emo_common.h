@@ -47,7 +47,7 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
 
 // ---------------------------------------------------------------- counter-based dropout RNG
-// One keyed 32-bit hash per PAIR of elements (16 random bits each).  keep iff bits >= thr16,
+// One keyed 32-bit hash per FOUR elements (16 random bits each, see drop_mult).  keep iff bits >= thr16,
 // thr16 = round(p * 65536).  Forward and backward regenerate the same mask from
 // (seed, offset, linear element index) — nothing is stored.
 // The 64-bit key (two words derived from the 64-bit seed and the per-site offset) enters the hash at two
@@ -84,31 +84,37 @@ __host__ __device__ __forceinline__ DropCtx make_drop(float p, uint64_t seed, ui
     d.key2 = k2;
     return d;
 }
+// One keyed hash serves FOUR consecutive elements (16 random bits each): elements 4q, 4q+1 take the two halves of h = hash(q),
+// elements 4q+2, 4q+3 the halves of xorshift32(h).  The hash's three 32-bit multiplies are quarter-rate VALU ops; r02 s_memtime
+// stamps put the relu + dropout epilogue of a GEMM column tile at 41 % of a wave's cycles with one hash per element pair.
+__host__ __device__ __forceinline__ uint32_t emo_xs32(uint32_t x) {
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    return x;
+}
 // multiplier (0 or scale) for linear element index idx
 __host__ __device__ __forceinline__ float drop_mult(const DropCtx& d, uint64_t idx) {
     if (d.thr16 == 0u) return 1.f;
-    uint32_t pair = (uint32_t)(idx >> 1) ^ (uint32_t)(idx >> 33) * 0x9E3779B1u;
-    uint32_t h = emo_drop_hash(d, pair);
-    uint32_t bits = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
+    const uint32_t quad = (uint32_t)(idx >> 2) ^ (uint32_t)(idx >> 34) * 0x9E3779B1u;
+    uint32_t h = emo_drop_hash(d, quad);
+    if (idx & 2) h = emo_xs32(h);
+    const uint32_t bits = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
     return bits >= d.thr16 ? d.scale : 0.f;
 }
 
-// 4 consecutive elements starting at an EVEN index: two hashes instead of four; bit-identical to drop_mult()
+// 4 consecutive elements: one hash when the start index is a multiple of 4; bit-identical to drop_mult()
 __device__ __forceinline__ void drop_mult4(const DropCtx& d, uint64_t idx0, float (&m)[4]) {
     if (d.thr16 == 0u) { m[0] = m[1] = m[2] = m[3] = 1.f; return; }
-    if (idx0 & 1) {
+    if (idx0 & 3) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) m[i] = drop_mult(d, idx0 + i);
         return;
     }
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-        const uint64_t idx = idx0 + 2 * h2;
-        const uint32_t pair = (uint32_t)(idx >> 1) ^ (uint32_t)(idx >> 33) * 0x9E3779B1u;
-        const uint32_t h = emo_drop_hash(d, pair);
-        m[2 * h2] = (h & 0xFFFFu) >= d.thr16 ? d.scale : 0.f;
-        m[2 * h2 + 1] = (h >> 16) >= d.thr16 ? d.scale : 0.f;
-    }
+    const uint32_t quad = (uint32_t)(idx0 >> 2) ^ (uint32_t)(idx0 >> 34) * 0x9E3779B1u;
+    const uint32_t h = emo_drop_hash(d, quad), h2 = emo_xs32(h);
+    m[0] = (h & 0xFFFFu) >= d.thr16 ? d.scale : 0.f;
+    m[1] = (h >> 16) >= d.thr16 ? d.scale : 0.f;
+    m[2] = (h2 & 0xFFFFu) >= d.thr16 ? d.scale : 0.f;
+    m[3] = (h2 >> 16) >= d.thr16 ? d.scale : 0.f;
 }
 
 // ---------------------------------------------------------------- wave / block reductions

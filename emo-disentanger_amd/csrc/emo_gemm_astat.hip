@@ -63,19 +63,21 @@ template <> __device__ __forceinline__ uint32_t as_load1<4>(const char* sbase, u
     asm volatile("global_load_ubyte %0, %1, %2 offset:4" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
     return r;
 }
+// (every asm store ends with `s_nop 1`: a VALU write to the data registers of a > 8-byte VMEM store needs one wait state after it, and hipcc's
+// hazard recogniser does not look inside an asm statement — without it one row in ~30000 came out with garbage in its first dword.)
 // Stores with an SGPR base + 32-bit per-lane offset (hipcc otherwise keeps one 64-bit per-lane pointer per output tensor live across the
 // whole loop, which is what pushed this kernel over 256 VGPRs).  boff: BYTE offset of the lane.
 __device__ __forceinline__ void as_store16(const void* sbase, uint32_t boff, u32x4 d) {
-    asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void as_store16_nt(const void* sbase, uint32_t boff, u32x4 d) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void as_store16_o16(const void* sbase, uint32_t boff, u32x4 d) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 offset:16" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:16\n\ts_nop 1" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void as_store1(const void* sbase, uint32_t boff, uint32_t d) {
-    asm volatile("global_store_byte %0, %1, %2" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
+    asm volatile("global_store_byte %0, %1, %2\n\ts_nop 1" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
 }
 template <typename OutT> __device__ __forceinline__ void as_store_row8(const OutT* sbase, uint32_t eoff, const float (&v)[8], bool nt = false) {
     if constexpr (sizeof(OutT) == 4) {
@@ -109,59 +111,74 @@ __device__ __forceinline__ void as_unpack8(const u32x4& r, float (&t)[8]) {
 //   ub = m0 * ldc + n_tile0 (+32 h)   lo = row_in_wave * ldc + ecol           (C / aux_out / mul_aux / residual, elements)
 //   nb = n_tile0 + 32 h               (bias / columns)                           db = m0 * N + nb, dl = row_in_wave * N + ecol (dropout index)
 // pre_bits: the mask byte already in a register (inline-asm prefetch)
-template <typename OutT, bool PRE_BITS>
+// The epilogue is specialised at COMPILE time (FL = feature flags): with run-time `ep.*` tests the column-tile epilogue was ~650 lines of
+// branchy code per tile (dead mul / residual / aux paths with their own `s_waitcnt vmcnt(0)`, per-lane parity branches of the dropout
+// hash) and took 35-52 % of a wave's cycles (s_memtime, tools/astat_cycles.py); the flag sets the Performer step uses are straight-line.
+enum { AF_RELU = 1, AF_DROP = 2, AF_RES = 4, AF_BITS = 8, AF_MASKOUT = 16, AF_GENERIC = 32 };
+
+// 8 consecutive elements starting at a multiple of 8 of a 32-bit linear index: two hashes + two xorshifts, no parity branch, no 64-bit
+// arithmetic (bit-identical to drop_mult(); the launcher sends outputs of 2^32 elements or more to the generic epilogue)
+__device__ __forceinline__ void as_drop8(const DropCtx& d, uint32_t idx0, float (&v)[8]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t h = emo_drop_hash(d, (idx0 >> 2) + q), h2 = emo_xs32(h);
+        v[4 * q] *= (h & 0xFFFFu) >= d.thr16 ? d.scale : 0.f;
+        v[4 * q + 1] *= (h >> 16) >= d.thr16 ? d.scale : 0.f;
+        v[4 * q + 2] *= (h2 & 0xFFFFu) >= d.thr16 ? d.scale : 0.f;
+        v[4 * q + 3] *= (h2 >> 16) >= d.thr16 ? d.scale : 0.f;
+    }
+}
+
+template <typename OutT, int FL>
 __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ C, int64_t ub, uint32_t lo, int nb, int ecol, int64_t db, uint32_t dl,
                                         int64_t mb, uint32_t ml, float (&v)[8], const float* bias_lds, uint32_t pre_bits) {
     // (the bias is already in the accumulators: they START from it)
-    if (ep.aux_out) as_store_row8<OutT>((const OutT*)ep.aux_out + ub, lo, v);
-    if (ep.act == EMO_ACT_RELU) {
+    constexpr bool G = (FL & AF_GENERIC) != 0;
+    if (G && ep.aux_out) as_store_row8<OutT>((const OutT*)ep.aux_out + ub, lo, v);
+    if ((FL & AF_RELU) || (G && ep.act == EMO_ACT_RELU)) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
-    } else if (ep.act == EMO_ACT_GELU_NEW) {
+    } else if (G && ep.act == EMO_ACT_GELU_NEW) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = gelu_new_f(v[i]);
     }
-    if (ep.mul_mode == EMO_MUL_BITMASK) {
-        const uint32_t bits = PRE_BITS ? pre_bits : (uint32_t)((const uint8_t*)ep.mul_aux)[mb + ml];
+    if (FL & AF_BITS) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= ((pre_bits >> i) & 1u) ? ep.mul_scale : 0.f;
+    } else if (G && ep.mul_mode == EMO_MUL_BITMASK) {
+        const uint32_t bits = (uint32_t)((const uint8_t*)ep.mul_aux)[mb + ml];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] *= ((bits >> i) & 1u) ? ep.mul_scale : 0.f;
-    } else if (ep.mul_mode != EMO_MUL_NONE) {
-        float t[8];
-        {
-            float t0[4], t1[4];
-            Out4<OutT>::load((const OutT*)ep.mul_aux + ub + lo, t0);
-            Out4<OutT>::load((const OutT*)ep.mul_aux + ub + lo + 4, t1);
+    } else if (G && ep.mul_mode != EMO_MUL_NONE) {
+        float t0[4], t1[4];
+        Out4<OutT>::load((const OutT*)ep.mul_aux + ub + lo, t0);
+        Out4<OutT>::load((const OutT*)ep.mul_aux + ub + lo + 4, t1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { t[i] = t0[i]; t[4 + i] = t1[i]; }
+        for (int i = 0; i < 4; ++i) {
+            v[i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (t0[i] != 0.f ? ep.mul_scale : 0.f) : dgelu_new_f(t0[i]);
+            v[4 + i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (t1[i] != 0.f ? ep.mul_scale : 0.f) : dgelu_new_f(t1[i]);
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (t[i] != 0.f ? ep.mul_scale : 0.f) : dgelu_new_f(t[i]);
     }
-    if (ep.drop.thr16) {
+    if (FL & AF_DROP) as_drop8(ep.drop, (uint32_t)db + dl, v);
+    else if (G && ep.drop.thr16) {
         float d0[4], d1[4];
-        const uint64_t idx = (uint64_t)db + dl;
-        drop_mult4(ep.drop, idx, d0);
-        drop_mult4(ep.drop, idx + 4, d1);
+        drop_mult4(ep.drop, (uint64_t)db + dl, d0);
+        drop_mult4(ep.drop, (uint64_t)db + dl + 4, d1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[i] *= d0[i]; v[4 + i] *= d1[i]; }
     }
-    if (ep.mask_out) {                                            // 1 bit per output: (value after act / dropout) != 0
+    if ((FL & AF_MASKOUT) || (G && ep.mask_out)) {               // 1 bit per output: (value after act / dropout) != 0
         uint32_t bits = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) bits |= (v[i] != 0.f ? 1u : 0u) << i;
         as_store1(ep.mask_out + mb, ml, bits);
     }
-    if (ep.residual) {
-        float t[8];
-        {
-            float t0[4], t1[4];
-            Out4<OutT>::load((const OutT*)ep.residual + ub + lo, t0);
-            Out4<OutT>::load((const OutT*)ep.residual + ub + lo + 4, t1);
+    if ((FL & AF_RES) || (G && ep.residual)) {
+        float t0[4], t1[4];
+        Out4<OutT>::load((const OutT*)ep.residual + ub + lo, t0);
+        Out4<OutT>::load((const OutT*)ep.residual + ub + lo + 4, t1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { t[i] = t0[i]; t[4 + i] = t1[i]; }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += t[i];
+        for (int i = 0; i < 4; ++i) { v[i] += t0[i]; v[4 + i] += t1[i]; }
     }
 #ifdef EMO_DIAG
     if (ep.ablate == 1) return;                                   // diagnostics: no output stores
@@ -172,9 +189,10 @@ __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ 
 // BITS: the 1-bit mask operand (EMO_MUL_BITMASK, 1 byte per 8 columns) is prefetched by inline-asm loads half a stage before the epilogue.
 // (16-B residual / mask rows stay plain loads in the epilogue: prefetching them needs 16 more registers than the 256 the kernel has, and a
 // spilled inline-asm destination would be copied before its data arrives.)
-template <typename OutT, bool BITS>
+template <typename OutT, int FL>
 __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                            OutT* __restrict__ C, int64_t M, int64_t N, EpiParams ep) {
+    constexpr bool BITS = (FL & AF_BITS) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [4 slots x 16 KB ring][bias: N floats]
     float* bias_lds = (float*)(smem + AS_RING);                   // bias (or zeros): the accumulators of every column tile start from it
     const int tid = threadIdx.x, lane = tid & 63;
@@ -249,6 +267,9 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
     const uint32_t boff[2] = {(uint32_t)((lane & 15) * (N >> 3) + (lane >> 4)), (uint32_t)(((lane & 15) + 16) * (N >> 3) + (lane >> 4))};
     const uint32_t eoff2[2] = {(uint32_t)((lane & 15) * ep.ldc + ecol), (uint32_t)(((lane & 15) + 16) * ep.ldc + ecol)};          // elements
     const uint32_t doff[2] = {(uint32_t)((lane & 15) * N + ecol), (uint32_t)(((lane & 15) + 16) * N + ecol)};
+#ifdef EMO_DIAG
+    uint64_t t_wait = 0, t_epi = 0, t_loop0 = __builtin_readcyclecounter();
+#endif
     for (int nt = 0; nt < n_tiles; ++nt) {
         f32x4 acc[2][4];
 #pragma unroll
@@ -263,6 +284,9 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 if (ks == 2) {
+#ifdef EMO_DIAG
+                    const uint64_t tw0 = __builtin_readcyclecounter();
+#endif
                     if (BITS && kc == 3) {                        // the four mask bytes of this column tile: youngest VMEM ops at the wait below
                         const char* op = (const char*)ep.mul_aux + m0 * (N >> 3) + nt * (AS_BN / 8);          // wave-uniform
 #pragma unroll
@@ -283,6 +307,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
 #ifdef EMO_DIAG
+                    t_wait += __builtin_readcyclecounter() - tw0;
                     if (ep.ablate != 2)
 #endif
                     issue((kc + 3) & 3);                          // refill the slot of stage s-1: every wave is past it
@@ -301,6 +326,9 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
             }
         }
         // ---- the wave's 32 x 64 outputs of this column tile, straight from the accumulators
+#ifdef EMO_DIAG
+        const uint64_t te0 = __builtin_readcyclecounter();
+#endif
         if (BITS) as_pin1<4>(preb);                               // one refill (4 DMA ops) was issued after the mask bytes
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -311,11 +339,23 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                 const int nb = nt * AS_BN + 32 * h;
                 uint32_t lo = eoff2[i];
                 asm volatile("" : "+v"(lo));                     // opaque per tile: keeps (base + lane offset) out of loop-invariant 64-bit VGPR pointers
-                as_epi8<OutT, BITS>(ep, C, m0 * ep.ldc + nb, lo, nb, ecol, m0 * N + nb, doff[i], m0 * (N >> 3) + (nb >> 3), boff[i], v, bias_lds,
+                as_epi8<OutT, FL>(ep, C, m0 * ep.ldc + nb, lo, nb, ecol, m0 * N + nb, doff[i], m0 * (N >> 3) + (nb >> 3), boff[i], v, bias_lds,
                                     preb[i * 2 + h]);
                 __builtin_amdgcn_sched_barrier(0);               // one 8-column group at a time: keeps the epilogue's temporaries out of the register peak
             }
+#ifdef EMO_DIAG
+        t_epi += __builtin_readcyclecounter() - te0;
+#endif
     }
+#ifdef EMO_DIAG
+    if (ep.ablate == 8 && ep.rln_stats && lane == 0) {
+        unsigned long long* dg = (unsigned long long*)ep.rln_stats;   // (diagnostics: the otherwise unused rln_stats pointer carries the counter buffer)
+        atomicAdd(dg + 0, (unsigned long long)t_wait);
+        atomicAdd(dg + 1, (unsigned long long)t_epi);
+        atomicAdd(dg + 2, (unsigned long long)(__builtin_readcyclecounter() - t_loop0));
+        atomicAdd(dg + 3, 1ull);
+    }
+#endif
     as_wait<0>();                                                 // the run-ahead refills past the last stage must land before the LDS is released
 }
 }  // namespace
@@ -337,16 +377,28 @@ bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t l
     // kernels around it, 61.1 -> 60.5 ms/step); smaller outputs are read back by the next kernel and stay cacheable
     ep.nt_store = (M * N * 2 >= (int64_t)256 << 20) ? 1 : 0;
     { const char* e = getenv("EMO_ASTAT_NT"); if (e) ep.nt_store = atoi(e); }
-#define AS_LAUNCH(OutT, BITS)                                                                                                              \
+#define AS_LAUNCH(OutT, FLv)                                                                                                              \
     do {                                                                                                                                  \
-        auto k = gemm_astat_kernel<OutT, BITS>;                                                                                           \
+        auto k = gemm_astat_kernel<OutT, FLv>;                                                                                            \
         static bool attr = false;                                                                                                         \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }      \
         hipLaunchKernelGGL(k, grid, dim3(256), lds, st, A, lda, B, ldb, (OutT*)C, M, N, ep);                                              \
     } while (0)
-    if (dtype_out == EMO_F32) AS_LAUNCH(float, false);
-    else if (ep.mul_mode == EMO_MUL_BITMASK) AS_LAUNCH(bf16_t, true);
-    else AS_LAUNCH(bf16_t, false);
+    // feature flags of this launch; the sets the Performer layer uses have their own straight-line instantiation, the rest runs the generic one
+    int fl = (ep.act == EMO_ACT_RELU ? AF_RELU : 0) | (ep.drop.thr16 ? AF_DROP : 0) | (ep.residual ? AF_RES : 0) | (ep.mul_mode == EMO_MUL_BITMASK ? AF_BITS : 0) |
+             (ep.mask_out ? AF_MASKOUT : 0);
+    const bool other = ep.aux_out || ep.act == EMO_ACT_GELU_NEW || (ep.mul_mode != EMO_MUL_NONE && ep.mul_mode != EMO_MUL_BITMASK) ||
+                       (ep.drop.thr16 && (uint64_t)M * (uint64_t)N >= (1ull << 32));
+    if (dtype_out == EMO_F32) AS_LAUNCH(float, AF_GENERIC);
+    else if (other) AS_LAUNCH(bf16_t, AF_GENERIC);
+    else if (fl == 0) AS_LAUNCH(bf16_t, 0);
+    else if (fl == AF_RELU) AS_LAUNCH(bf16_t, AF_RELU);
+    else if (fl == (AF_RELU | AF_DROP)) AS_LAUNCH(bf16_t, AF_RELU | AF_DROP);
+    else if (fl == (AF_RELU | AF_DROP | AF_MASKOUT)) AS_LAUNCH(bf16_t, AF_RELU | AF_DROP | AF_MASKOUT);
+    else if (fl == AF_RES) AS_LAUNCH(bf16_t, AF_RES);
+    else if (fl == (AF_DROP | AF_RES)) AS_LAUNCH(bf16_t, AF_DROP | AF_RES);
+    else if (fl == AF_BITS) AS_LAUNCH(bf16_t, AF_BITS);
+    else AS_LAUNCH(bf16_t, AF_GENERIC);
 #undef AS_LAUNCH
     return true;
 }
