@@ -64,12 +64,16 @@ template <typename CT, int DHP, int MF, int C>
 __device__ __forceinline__ void features_rowmajor(CT* Ff, int ldf, const CT* WT, const CT* X, int ldx, const float* off, float cs,
                                                   int valid_rows, int wave, int lane) {
     constexpr int NT = (MF / 16) * (C / 16);
+    static_assert(FW % (C / 16) == 0, "a wave's tiles share the token block");
+    const int ct = wave % (C / 16);
+    Frags<CT, DHP> xf;
+    xf.load(X, ldx, ct * 16, lane);
     _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
             const int tile = wave + FW * tile_i;
             if (NT % FW != 0 && tile >= NT) break;
-        const int rt = tile / (C / 16), ct = tile % (C / 16);
+        const int rt = tile / (C / 16);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        mm16<CT, DHP>(acc, WT, ldx, rt * 16, X, ldx, ct * 16, lane);
+        mm16_c<CT, DHP>(acc, WT, ldx, rt * 16, xf, lane);
         const int t = ct * 16 + (lane & 15), m0 = rt * 16 + (lane >> 4) * 4;
         const float o = off[t];
         const float ok = t < valid_rows ? 1.f : 0.f;
@@ -87,13 +91,17 @@ template <typename CT, int DHP, int MF, int C>
 __device__ __forceinline__ void features_both(CT* Ff, int ldf, CT* FTt, int ldt, const CT* WT, const CT* X, int ldx, const float* off, float cs,
                                               int valid_rows, int wave, int lane) {
     constexpr int NT = (MF / 16) * (C / 16);
+    static_assert(FW % (C / 16) == 0, "a wave's tiles share the token block");
+    const int ct = wave % (C / 16);
+    Frags<CT, DHP> xf;
+    xf.load(X, ldx, ct * 16, lane);
 #pragma unroll
     for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
         const int tile = wave + FW * tile_i;
         if (NT % FW != 0 && tile >= NT) break;
-        const int rt = tile / (C / 16), ct = tile % (C / 16);
+        const int rt = tile / (C / 16);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        mm16<CT, DHP>(acc, WT, ldx, rt * 16, X, ldx, ct * 16, lane);
+        mm16_c<CT, DHP>(acc, WT, ldx, rt * 16, xf, lane);
         const int t = ct * 16 + (lane & 15), m0 = rt * 16 + (lane >> 4) * 4;
         const float o = off[t];
         const float ok = t < valid_rows ? 1.f : 0.f;
@@ -114,12 +122,16 @@ template <typename CT, int DHP, int MF, int C>
 __device__ __forceinline__ void features_transposed(CT* FT, int ldt, const CT* WT, const CT* X, int ldx, const float* off, float cs,
                                                     int valid_rows, int wave, int lane) {
     constexpr int NT = (MF / 16) * (C / 16);
+    static_assert(FW % (MF / 16) == 0, "a wave's tiles share the feature block");
+    const int ct = wave % (MF / 16);
+    Frags<CT, DHP> wf;
+    wf.load(WT, ldx, ct * 16, lane);
     _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
             const int tile = wave + FW * tile_i;
             if (NT % FW != 0 && tile >= NT) break;
-        const int rt = tile / (MF / 16), ct = tile % (MF / 16);
+        const int rt = tile / (MF / 16);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        mm16<CT, DHP>(acc, X, ldx, rt * 16, WT, ldx, ct * 16, lane);
+        mm16_c<CT, DHP>(acc, X, ldx, rt * 16, wf, lane);
         const int t0 = rt * 16 + (lane >> 4) * 4, m = ct * 16 + (lane & 15);
         float p[4], n[4];
 #pragma unroll
@@ -275,12 +287,15 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
         // A[t][j] = Qf[t].Kf[j] masked j<=t : rows<->j (R=Kf), col<->t (C=Qf)
         if (!(abl & 16)) {
             constexpr int NT = (C / 16) * (C / 16);
+            const int tt = wave % (C / 16);
+            Frags<CT, F> qff;
+            qff.load(Qf, LDF, tt * 16, lane);
             _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
             const int tile = wave + FW * tile_i;
             if (NT % FW != 0 && tile >= NT) break;
-                const int jt = tile / (C / 16), tt = tile % (C / 16);
+                const int jt = tile / (C / 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                if (jt <= tt) mm16<CT, F>(acc, Kf, LDF, jt * 16, Qf, LDF, tt * 16, lane);
+                if (jt <= tt) mm16_c<CT, F>(acc, Kf, LDF, jt * 16, qff, lane);
                 const int t = tt * 16 + (lane & 15), j0 = jt * 16 + (lane >> 4) * 4;
                 Img<CT>::store4(Am + t * LDC + j0, j0 <= t ? acc[0] : 0.f, j0 + 1 <= t ? acc[1] : 0.f, j0 + 2 <= t ? acc[2] : 0.f,
                                 j0 + 3 <= t ? acc[3] : 0.f);
@@ -311,13 +326,18 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
         // out^T: rows<->d, col<->t : VT.Am^T (K=C) + ST.Qf^T (K=F)
         if (!(abl & 64)) {
             constexpr int NT = (DH / 16) * (C / 16);
+            const int tt = wave % (C / 16);
+            Frags<CT, CP> amf;
+            Frags<CT, F> qff;
+            amf.load(Am, LDC, tt * 16, lane);
+            qff.load(Qf, LDF, tt * 16, lane);
             _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
             const int tile = wave + FW * tile_i;
             if (NT % FW != 0 && tile >= NT) break;
-                const int dt = tile / (C / 16), tt = tile % (C / 16);
+                const int dt = tile / (C / 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                mm16<CT, CP>(acc, VT, LDC, dt * 16, Am, LDC, tt * 16, lane);
-                mm16<CT, F>(acc, ST, LDF, dt * 16, Qf, LDF, tt * 16, lane);
+                mm16_c<CT, CP>(acc, VT, LDC, dt * 16, amf, lane);
+                mm16_c<CT, F>(acc, ST, LDF, dt * 16, qff, lane);
                 const int t = tt * 16 + (lane & 15), d0 = dt * 16 + (lane >> 4) * 4;
                 if (t < valid) {
                     const float inv = 1.f / dens[t];
@@ -328,18 +348,22 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
         __syncthreads();
         }   // !SO
         // state: S[f][d] += sum_j KfT[f][j] VT[d][j]; mirror ST[d][f]; z += colsum
-        if (!(abl & 128))
+        if (!(abl & 128)) {
+        static_assert(FW % (DH / 16) == 0, "a wave's state tiles share the d block");
+        Frags<CT, CP> vtf;
+        vtf.load(VT, LDC, (wave % (DH / 16)) * 16, lane);
 #pragma unroll
         for (int i = 0; i < NTS_W; ++i) {
             const int tile = wave + FW * i;
             if (tile < NTS) {
                 const int ft = tile / (DH / 16), dt = tile % (DH / 16);
-                mm16<CT, CP>(sacc[i], KfT, LDC, ft * 16, VT, LDC, dt * 16, lane);
+                mm16_c<CT, CP>(sacc[i], KfT, LDC, ft * 16, vtf, lane);
                 if constexpr (!SO) {
                     const int d = dt * 16 + (lane & 15), f0 = ft * 16 + (lane >> 4) * 4;
                     Img<CT>::store4(ST + d * LDF + f0, sacc[i][0], sacc[i][1], sacc[i][2], sacc[i][3]);
                 }
             }
+        }
         }
         if constexpr (sizeof(CT) == 2 && C == 64 && 4 * F <= FT) {
             const int f = tid >> 2, part = tid & 3;
@@ -474,12 +498,15 @@ template <typename CT, int DH, int MFP, int C>
 __device__ __forceinline__ void dx_from_adiff(const CT* W, int ldw, const CT* Adiff, int lda, const float* sumA, const CT* __restrict__ xg,
                                               int64_t ld, CT* __restrict__ dxg, int64_t ld_d, float cs, int valid, int wave, int lane) {
     constexpr int NT = (DH / 16) * (C / 16);
+    const int tt = wave % (C / 16);
+    Frags<CT, MFP> adf;
+    adf.load(Adiff, lda, tt * 16, lane);
     _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
             const int tile = wave + FW * tile_i;
             if (NT % FW != 0 && tile >= NT) break;
-        const int dt = tile / (C / 16), tt = tile % (C / 16);
+        const int dt = tile / (C / 16);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        mm16<CT, MFP>(acc, W, ldw, dt * 16, Adiff, lda, tt * 16, lane);
+        mm16_c<CT, MFP>(acc, W, ldw, dt * 16, adf, lane);
         const int t = tt * 16 + (lane & 15), d0 = dt * 16 + (lane >> 4) * 4;
         if (t < valid) {
             const float sa = sumA[t];
@@ -607,12 +634,15 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
         // P[t][j] = dN_t.v_j + dD_t, masked j<=t : rows<->j (R=Vr), col<->t (C=G)
         if (!(abl & 16)) {
             constexpr int NT = (C / 16) * (C / 16);
+            const int tt = wave % (C / 16);
+            Frags<CT, DHP> gf;
+            gf.load(G, LDX, tt * 16, lane);
             _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
             const int tile = wave + FW * tile_i;
             if (NT % FW != 0 && tile >= NT) break;
-                const int jt = tile / (C / 16), tt = tile % (C / 16);
+                const int jt = tile / (C / 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                if (jt <= tt) mm16<CT, DHP>(acc, Vr, LDX, jt * 16, G, LDX, tt * 16, lane);
+                if (jt <= tt) mm16_c<CT, DHP>(acc, Vr, LDX, jt * 16, gf, lane);
                 const int t = tt * 16 + (lane & 15), j0 = jt * 16 + (lane >> 4) * 4;
                 const float dd = dD[t];
                 Img<CT>::store4(Pm + t * LDC + j0, j0 <= t ? acc[0] + dd : 0.f, j0 + 1 <= t ? acc[1] + dd : 0.f,
@@ -624,15 +654,20 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
         zero_adiff_pad<CT, MF, MFP, C>(Adiff, LDM, tid);
         if (!(abl & 32)) {
             constexpr int NP = (MF / 16) * (C / 16);
+            const int tt = wave % (C / 16);
+            Frags<CT, CP> pmf;
+            Frags<CT, DHP> gf;
+            pmf.load(Pm, LDC, tt * 16, lane);
+            gf.load(G, LDX, tt * 16, lane);
             _Pragma("unroll") for (int pr_i = 0; pr_i < (NP + FW - 1) / FW; ++pr_i) {
             const int pr = wave + FW * pr_i;
             if (NP % FW != 0 && pr >= NP) break;
-                const int ft = pr / (C / 16), tt = pr % (C / 16);
+                const int ft = pr / (C / 16);
                 f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f};
-                mm16<CT, CP>(aP, KfT, LDC, ft * 16, Pm, LDC, tt * 16, lane);
-                mm16<CT, DHP>(aP, SF, LDX, ft * 16, G, LDX, tt * 16, lane);
-                mm16<CT, CP>(aM, KfT, LDC, MF + ft * 16, Pm, LDC, tt * 16, lane);
-                mm16<CT, DHP>(aM, SF, LDX, MF + ft * 16, G, LDX, tt * 16, lane);
+                mm16_c<CT, CP>(aP, KfT, LDC, ft * 16, pmf, lane);
+                mm16_c<CT, DHP>(aP, SF, LDX, ft * 16, gf, lane);
+                mm16_c<CT, CP>(aM, KfT, LDC, MF + ft * 16, pmf, lane);
+                mm16_c<CT, DHP>(aM, SF, LDX, MF + ft * 16, gf, lane);
                 const int t = tt * 16 + (lane & 15), m0 = ft * 16 + (lane >> 4) * 4;
                 jac_epilogue<CT, MF>(aP, aM, Qf, LDF, Adiff, LDM, sumA, zz, dD[t], t, m0, lane);
             }
@@ -640,14 +675,20 @@ __global__ __launch_bounds__(FT) void favor_bwd_dq_kernel(const CT* __restrict__
         __syncthreads();
         if (!(abl & 64)) dx_from_adiff<CT, DH, MFP, C>(W, LDM, Adiff, LDM, sumA, qb + t0 * ld, ld, dqb + t0 * ld_d, ld_d, cs, valid, wave, lane);
         // state S[f][d] (+)= ; mirror SF[f][d0..] ; z += colsum(KfT)
-        if (!(abl & 128))
+        if (!(abl & 128)) {
+        static_assert(FW % (F / 16) == 0 || (F / 16) % FW == 0, "state tiles of a wave share the feature block");
+        constexpr bool SH = FW % (F / 16) == 0;
+        Frags<CT, CP> kff;
+        if constexpr (SH) kff.load(KfT, LDC, (wave % (F / 16)) * 16, lane);
 #pragma unroll
         for (int i = 0; i < NTS_W; ++i) {
             const int tile = wave + FW * i;
             if (tile < NTS) {
                 const int dt = tile / (F / 16), ft = tile % (F / 16);
-                mm16<CT, CP>(sacc[i], VT, LDC, dt * 16, KfT, LDC, ft * 16, lane);
+                if constexpr (SH) mm16_c<CT, CP>(sacc[i], VT, LDC, dt * 16, kff, lane);
+                else mm16<CT, CP>(sacc[i], VT, LDC, dt * 16, KfT, LDC, ft * 16, lane);
             }
+        }
         }
         __syncthreads();   // all reads of SF / zz for this chunk are done
 #pragma unroll
@@ -813,14 +854,19 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
         // AmT[j][t] = Qf_t.Kf_j       (t>=j) : rows<->t (R=Qf), col<->j (C=Kf)
         if (!(abl & 16)) {
             constexpr int NT = (C / 16) * (C / 16);
+            const int jt = wave % (C / 16);
+            Frags<CT, DHP> vrf;
+            Frags<CT, F> kff;
+            vrf.load(Vr, LDX, jt * 16, lane);
+            kff.load(Kf, LDF, jt * 16, lane);
             _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
             const int tile = wave + FW * tile_i;
             if (NT % FW != 0 && tile >= NT) break;
-                const int tt = tile / (C / 16), jt = tile % (C / 16);
+                const int tt = tile / (C / 16);
                 f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aA = {0.f, 0.f, 0.f, 0.f};
                 if (tt >= jt) {
-                    mm16<CT, DHP>(aP, G, LDX, tt * 16, Vr, LDX, jt * 16, lane);
-                    mm16<CT, F>(aA, Qf, LDF, tt * 16, Kf, LDF, jt * 16, lane);
+                    mm16_c<CT, DHP>(aP, G, LDX, tt * 16, vrf, lane);
+                    mm16_c<CT, F>(aA, Qf, LDF, tt * 16, kff, lane);
                 }
                 const int j = jt * 16 + (lane & 15), tb = tt * 16 + (lane >> 4) * 4;
                 float p[4], a[4];
@@ -841,15 +887,20 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
         zero_adiff_pad<CT, MF, MFP, C>(Adiff, LDM, tid);
         if (!(abl & 32)) {
             constexpr int NP = (MF / 16) * (C / 16);
+            const int jt = wave % (C / 16);
+            Frags<CT, CP> pmf;
+            Frags<CT, DHP> vrf;
+            pmf.load(PmT, LDC, jt * 16, lane);
+            vrf.load(Vr, LDX, jt * 16, lane);
             _Pragma("unroll") for (int pr_i = 0; pr_i < (NP + FW - 1) / FW; ++pr_i) {
             const int pr = wave + FW * pr_i;
             if (NP % FW != 0 && pr >= NP) break;
-                const int ft = pr / (C / 16), jt = pr % (C / 16);
+                const int ft = pr / (C / 16);
                 f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f};
-                mm16<CT, CP>(aP, QfT, LDC, ft * 16, PmT, LDC, jt * 16, lane);
-                mm16<CT, DHP>(aP, RF, LDX, ft * 16, Vr, LDX, jt * 16, lane);
-                mm16<CT, CP>(aM, QfT, LDC, MF + ft * 16, PmT, LDC, jt * 16, lane);
-                mm16<CT, DHP>(aM, RF, LDX, MF + ft * 16, Vr, LDX, jt * 16, lane);
+                mm16_c<CT, CP>(aP, QfT, LDC, ft * 16, pmf, lane);
+                mm16_c<CT, DHP>(aP, RF, LDX, ft * 16, vrf, lane);
+                mm16_c<CT, CP>(aM, QfT, LDC, MF + ft * 16, pmf, lane);
+                mm16_c<CT, DHP>(aM, RF, LDX, MF + ft * 16, vrf, lane);
                 const int j = jt * 16 + (lane & 15), m0 = ft * 16 + (lane >> 4) * 4;
                 jac_epilogue<CT, MF>(aP, aM, Kf, LDF, Adiff, LDM, sumA, rr, 1.f, j, m0, lane);
             }
@@ -857,13 +908,18 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
         // dV^T: rows<->d, col<->j : GT.AmT^T (K=C) + RT.Kf^T (K=F)
         if (!(abl & 2)) {
             constexpr int NT = (DH / 16) * (C / 16);
+            const int jt = wave % (C / 16);
+            Frags<CT, CP> amf;
+            Frags<CT, F> kff;
+            amf.load(AmT, LDC, jt * 16, lane);
+            kff.load(Kf, LDF, jt * 16, lane);
             _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
             const int tile = wave + FW * tile_i;
             if (NT % FW != 0 && tile >= NT) break;
-                const int dt = tile / (C / 16), jt = tile % (C / 16);
+                const int dt = tile / (C / 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                mm16<CT, CP>(acc, GT, LDC, dt * 16, AmT, LDC, jt * 16, lane);
-                mm16<CT, F>(acc, RT, LDF, dt * 16, Kf, LDF, jt * 16, lane);
+                mm16_c<CT, CP>(acc, GT, LDC, dt * 16, amf, lane);
+                mm16_c<CT, F>(acc, RT, LDF, dt * 16, kff, lane);
                 const int j = jt * 16 + (lane & 15), d0 = dt * 16 + (lane >> 4) * 4;
                 if (j < valid) Img<CT>::store4(dvb + (t0 + j) * ld_d + d0, acc[0], acc[1], acc[2], acc[3]);
             }
@@ -872,14 +928,19 @@ __global__ __launch_bounds__(FT) void favor_bwd_dkv_kernel(const CT* __restrict_
         if (!(abl & 64)) dx_from_adiff<CT, DH, MFP, C>(W, LDM, Adiff, LDM, sumA, kb + t0 * ld, ld, dkb + t0 * ld_d, ld_d, cs, valid, wave, lane);
         }   // !SO
         // state R[f][d] += sum_t QfT[f][t] GT[d][t]
-        if (!(abl & 128))
+        if (!(abl & 128)) {
+        constexpr bool SH = FW % (F / 16) == 0;
+        Frags<CT, CP> qtf;
+        if constexpr (SH) qtf.load(QfT, LDC, (wave % (F / 16)) * 16, lane);
 #pragma unroll
         for (int i = 0; i < NTS_W; ++i) {
             const int tile = wave + FW * i;
             if (tile < NTS) {
                 const int dt = tile / (F / 16), ft = tile % (F / 16);
-                mm16<CT, CP>(racc[i], GT, LDC, dt * 16, QfT, LDC, ft * 16, lane);
+                if constexpr (SH) mm16_c<CT, CP>(racc[i], GT, LDC, dt * 16, qtf, lane);
+                else mm16<CT, CP>(racc[i], GT, LDC, dt * 16, QfT, LDC, ft * 16, lane);
             }
+        }
         }
         if constexpr (!SO) {
         __syncthreads();   // all reads of RF / RT / rr for this chunk are done

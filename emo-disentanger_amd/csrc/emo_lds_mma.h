@@ -48,6 +48,33 @@ __device__ __forceinline__ void mm16(f32x4& acc, const CT* R, int ldr, int rrow0
     for (int s = 0; s < NS; ++s) acc = Img<CT>::mma(a[s], b[s], acc);
 }
 
+// The same product with ONE operand's fragments already in registers: the tiles a wave owns inside a phase share an operand row block
+// (tile = wave + FW * i with FW a multiple of the tile-grid width), so that operand is read from LDS once per phase instead of once per
+// tile — the FAVOR+ kernels are LDS-bound (r01 PMC: LDS array busy 64-86 % of the kernel time) and 28-40 % of their fragment reads
+// were such repeats.
+template <typename CT, int K> struct Frags {
+    static constexpr int NS = K / Img<CT>::KSTEP;
+    typename Img<CT>::V f[NS];
+    __device__ __forceinline__ void load(const CT* img, int ld, int row0, int lane) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) f[s] = Img<CT>::load(img, ld, row0, s * Img<CT>::KSTEP, lane);
+    }
+};
+template <typename CT, int K>   // second operand preloaded
+__device__ __forceinline__ void mm16_c(f32x4& acc, const CT* R, int ldr, int rrow0, const Frags<CT, K>& c, int lane) {
+    Frags<CT, K> a;
+    a.load(R, ldr, rrow0, lane);
+#pragma unroll
+    for (int s = 0; s < Frags<CT, K>::NS; ++s) acc = Img<CT>::mma(a.f[s], c.f[s], acc);
+}
+template <typename CT, int K>   // first operand preloaded
+__device__ __forceinline__ void mm16_r(f32x4& acc, const Frags<CT, K>& r, const CT* Cc, int ldc, int crow0, int lane) {
+    Frags<CT, K> b;
+    b.load(Cc, ldc, crow0, lane);
+#pragma unroll
+    for (int s = 0; s < Frags<CT, K>::NS; ++s) acc = Img<CT>::mma(r.f[s], b.f[s], acc);
+}
+
 template <int A, int B> struct CMax { static constexpr int v = A > B ? A : B; };
 
 // ---- global row tile [rows x NC] -> LDS image [rows][ld] (zero-fill invalid rows and pad columns up to NCP)
