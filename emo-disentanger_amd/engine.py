@@ -344,7 +344,7 @@ class DecoderStackFn(torch.autograd.Function):
     flat grad buffer (the ``.grad`` views); the node returns None for them."""
 
     @staticmethod
-    def forward(ctx, model, tok, seg, anchor, need_bwd):
+    def forward(ctx, model, tok, seg, anchor, need_bwd, chord=None):
         ps = model._store
         B, T = tok.shape
         D, H, L = model.d_model, model.n_head, model.n_layer
@@ -361,7 +361,20 @@ class DecoderStackFn(torch.autograd.Function):
                                'encoding of width d_embed cannot be added to d_model-wide embeddings (use_pe=True needs d_embed == d_model, '
                                'as in the reference, music_performer.py:59-60)' % (D, model.d_embed))
         pe = model.pe.pe if model.use_pe else model._zero_pe(T, D)
-        x = ops.embed_fwd(tok, seg, E, S, pe, ps.compute_dtype, float(model.token_emb.emb_scale), p_drop=p, seed=seed, offset=base).view(B * T, D)
+        cp = None
+        if chord is None:
+            x = ops.embed_fwd(tok, seg, E, S, pe, ps.compute_dtype, float(model.token_emb.emb_scale), p_drop=p, seed=seed, offset=base).view(B * T, D)
+        else:
+            # x_emb += chord_emb(chord_inp) (music_performer.py:56-57) sits between the gather and the dropout the gather kernel fuses, so
+            # this (never-used-by-the-call-sites) option runs unfused: gather without dropout, one K = 12 (padded to 32) GEMM, dropout.
+            cp = torch.zeros(B * T, 32, device=tok.device, dtype=ps.compute_dtype)
+            cp[:, :12] = chord.reshape(B * T, 12)
+            wp = torch.zeros(D, 32, device=tok.device, dtype=ps.compute_dtype)
+            wp[:, :12] = ps.w('chord_emb.weight')
+            e = ops.embed_fwd(tok, seg, E, S, pe, torch.float32, float(model.token_emb.emb_scale)).view(B * T, D)
+            x = (e + ops.gemm(cp, wp, bias=ps.f32('chord_emb.bias'), out_dtype=torch.float32)).to(ps.compute_dtype)
+            if p > 0.0:
+                x = ops.dropout_apply(x, p, seed, base)
         saves = []
         omegas = model._omegas() if model.kind == 'performer' else None
         for l in range(L):
@@ -371,7 +384,7 @@ class DecoderStackFn(torch.autograd.Function):
             else:
                 x = gpt2_block_fwd(ps, model._layer_prefix(l), x, B, T, H, p, seed, base + 8 * (l + 1), sv)
             saves.append(sv)
-        ctx.model, ctx.saves, ctx.tok, ctx.seg = model, saves, tok, seg
+        ctx.model, ctx.saves, ctx.tok, ctx.seg, ctx.chord = model, saves, tok, seg, cp
         ctx.cfg = (B, T, D, H, L, p, seed, base)
         return x.view(B, T, D)
 
@@ -396,13 +409,19 @@ class DecoderStackFn(torch.autograd.Function):
         else:
             dE = ps.g('token_emb.emb_lookup.weight')
             dS = ps.g('segemb.emb_lookup.weight') if ctx.seg is not None else None
-        ops.embed_bwd(ctx.tok, ctx.seg, dx, dE, dS, float(model.token_emb.emb_scale), p_drop=p, seed=seed, offset=base)
+        if ctx.chord is None:
+            ops.embed_bwd(ctx.tok, ctx.seg, dx, dE, dS, float(model.token_emb.emb_scale), p_drop=p, seed=seed, offset=base)
+        else:
+            dxm = ops.dropout_apply(dx.contiguous(), p, seed, base) if p > 0.0 else dx.contiguous()
+            ops.embed_bwd(ctx.tok, ctx.seg, dxm, dE, dS, float(model.token_emb.emb_scale))
+            ps.g('chord_emb.weight').add_(ops.gemm(dxm, ctx.chord, a_trans=True, b_trans=True, out_dtype=torch.float32)[:, :12])
+            ops.colsum(dxm, out=ps.g('chord_emb.bias'), accumulate=True)
         if proj:
             embedding_table_bwd(ps, 'token_emb.', dE)
             if dS is not None:
                 embedding_table_bwd(ps, 'segemb.', dS)
         join_side_stream()          # all weight gradients are complete before anything downstream (all-reduce, optimizer) runs
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
 class LogitsFn(torch.autograd.Function):

@@ -19,9 +19,7 @@ class MusicLMBase(nn.Module):
         self.n_token, self.n_layer, self.n_head = n_token, n_layer, n_head
         self.d_model, self.d_ff, self.d_embed = d_model, d_ff, d_embed
         self.dropout, self.activation, self.use_pe = dropout, activation, use_pe
-        if use_chord_mhot_emb:
-            raise NotImplementedError('use_chord_mhot_emb=True is never used by the reference call sites (train.py:293,301) and is not built')
-        self.use_chord_mhot_emb = False
+        self.use_chord_mhot_emb = bool(use_chord_mhot_emb)
         self.token_emb = TokenEmbedding(n_token, d_embed, d_model)
         self.pe = PositionalEncoding(d_embed)
         self.dec_out_proj = nn.Linear(d_model, n_token)
@@ -38,6 +36,8 @@ class MusicLMBase(nn.Module):
             self.n_segment_types = n_segment_types
         else:
             self.segemb = None
+        if self.use_chord_mhot_emb:                      # music_performer.py:42-44 (registered after segemb: same parameter order)
+            self.chord_emb = nn.Linear(12, self.d_model)
 
     # ------------------------------------------------------------------ engine plumbing
     @property
@@ -74,7 +74,8 @@ class MusicLMBase(nn.Module):
 
     # ------------------------------------------------------------------ reference API
     def forward(self, x, seg_inp=None, chord_inp=None, keep_last_only=False, attn_kwargs=None):
-        """music_performer.py:50-70 / music_gpt2.py:70-92.  x, seg_inp: int64 [B,T] on the GPU.
+        """music_performer.py:50-70 / music_gpt2.py:70-92.  x, seg_inp: int64 [B,T] on the GPU; chord_inp: [B,T,12] multi-hot pitch
+        classes, used only by a model built with use_chord_mhot_emb (x_emb += chord_emb(chord_inp), :56-57).
         Returns fp32 logits [B,T,V] (or [B,V] with keep_last_only)."""
         if not x.is_cuda:
             raise EmoError('inputs must be GPU tensors (the HIP path has no CPU fallback)')
@@ -84,7 +85,9 @@ class MusicLMBase(nn.Module):
         need_bwd = torch.is_grad_enabled() and anchor.requires_grad
         if seg_inp is not None and not self.use_segment_emb:
             seg_inp = None
-        h = engine.DecoderStackFn.apply(self, x.long(), None if seg_inp is None else seg_inp.long(), anchor, need_bwd)
+        if chord_inp is not None and not self.use_chord_mhot_emb:
+            chord_inp = None
+        h = engine.DecoderStackFn.apply(self, x.long(), None if seg_inp is None else seg_inp.long(), anchor, need_bwd, chord_inp)
         if keep_last_only:
             h = h[:, -1, :]
         return engine.LogitsFn.apply(self, h)

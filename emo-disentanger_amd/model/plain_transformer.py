@@ -93,22 +93,31 @@ class OptimusTXLDecoder(nn.Module):             # the class name matters: weight
         self.pos_emb = PositionalEmbedding(d_model)
 
 
-def _txl_layer_fwd(ps, p, x, r_dist, B, T, H, pd, seed, off, pre, save):
-    """RelPartialLearnableDecoderLayer (:526-557) = rel. attention (:301-391) + PositionwiseFF (:28-66), training or evaluation."""
+def _txl_layer_fwd(ps, p, x, r_dist, B, T, H, pd, seed, off, pre, save, mem=None):
+    """RelPartialLearnableDecoderLayer (:526-557) = rel. attention (:301-391) + PositionwiseFF (:28-66), training or evaluation.
+    mem [B, mlen, D] (segment recurrence, :312-321): keys / values come from LayerNorm + qkv_net of cat([mem, x]) and query i sees keys
+    j <= mlen + i at distance mlen + i - j — exactly causal attention over the concatenated sequence restricted to its last T query rows,
+    which is how it is run (the first mlen output rows are dropped; their queries cost compute but no extra kernel)."""
     D = x.shape[1]
+    mlen = 0 if mem is None else mem.shape[1]
+    K = mlen + T
+    xq = x
+    if mlen:
+        x = torch.cat([mem, x.view(B, T, D)], 1).reshape(B * K, D)
     a, f = p + 'dec_attn.', p + 'pos_ff.'
     if not pre:
         raise NotImplementedError('post-LN (pre_lnorm=False) training is not built: every stage-1 YAML sets pre_lnorm: True')
     n, m1, r1 = ops.layernorm_fwd(x, ps.f32(a + 'layer_norm.weight'), ps.f32(a + 'layer_norm.bias'))
     qkv = ops.gemm(n, ps.w(a + 'qkv_net.weight'))
     vec, lse, zden = ops.relpos_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], r_dist, ps.f32('decoder.r_w_bias'), ps.f32('decoder.r_r_bias'),
-                                         B, T, H, p_drop=pd, seed=seed, offset=off + 1)
-    h = ops.gemm(vec, ps.w(a + 'o_net.weight'), p_drop=pd, seed=seed, offset=off + 2, residual=x)
+                                         B, K, H, p_drop=pd, seed=seed, offset=off + 1)
+    vq = vec.view(B, K, D)[:, mlen:].reshape(B * T, D) if mlen else vec
+    h = ops.gemm(vq, ps.w(a + 'o_net.weight'), p_drop=pd, seed=seed, offset=off + 2, residual=xq)
     n2, m2, r2 = ops.layernorm_fwd(h, ps.f32(f + 'layer_norm.weight'), ps.f32(f + 'layer_norm.bias'))
     g = ops.gemm(n2, ps.w(f + 'CoreNet.0.weight'), bias=ps.f32(f + 'CoreNet.0.bias'), act=ops.ACT_RELU, p_drop=pd, seed=seed, offset=off + 3)
     o = ops.gemm(g, ps.w(f + 'CoreNet.3.weight'), bias=ps.f32(f + 'CoreNet.3.bias'), p_drop=pd, seed=seed, offset=off + 4, residual=h)
     if save is not None:
-        save.update(x=x, m1=m1, r1=r1, n=n, qkv=qkv, vec=vec, lse=lse, zden=zden, h=h, m2=m2, r2=r2, n2=n2, g=g, r_dist=r_dist)
+        save.update(x=x, m1=m1, r1=r1, n=n, qkv=qkv, vec=vec, vq=vq, mlen=mlen, lse=lse, zden=zden, h=h, m2=m2, r2=r2, n2=n2, g=g, r_dist=r_dist)
     return o
 
 
@@ -126,18 +135,25 @@ def _txl_layer_bwd(ps, p, dout, pe_d, B, T, H, pd, seed, off, s):
     dh, _ = ops.layernorm_bwd(dn2, s['h'], ps.f32(f + 'layer_norm.weight'), s['m2'], s['r2'], ps.g(f + 'layer_norm.weight'), ps.g(f + 'layer_norm.bias'),
                               dres=dout)
     dad = ops.dropout_apply(dh, pd, seed, off + 2) if pd > 0 else dh
-    wg(dad, s['vec'], a + 'o_net.weight')
+    wg(dad, s['vq'], a + 'o_net.weight')
     dvec = ops.gemm(dad, ps.w(a + 'o_net.weight'), b_trans=True)
+    mlen = s['mlen']
+    K = mlen + T
+    if mlen:                                                    # memory rows: no output gradient (their outputs were dropped), no input gradient
+        pad = lambda t: torch.cat([t.new_zeros(B, mlen, D), t.view(B, T, D)], 1).reshape(B * K, D)
+        dvec, dh_res = pad(dvec), pad(dh)
+    else:
+        dh_res = dh
     dqkv, dR, d_rw, d_rr = ops.relpos_attn_bwd(s['qkv'], s['r_dist'], ps.f32('decoder.r_w_bias'), ps.f32('decoder.r_r_bias'), s['vec'], dvec, s['lse'],
-                                               s['zden'], B, T, H, p_drop=pd, seed=seed, offset=off + 1)
+                                               s['zden'], B, K, H, p_drop=pd, seed=seed, offset=off + 1)
     ps.g('decoder.r_w_bias').add_(d_rw)
     ps.g('decoder.r_r_bias').add_(d_rr)
     wg(dR.to(ps.compute_dtype), pe_d, a + 'r_net.weight')                     # R = r_net(dropout(pos_emb)): dW_r += dR^T pos_emb
     wg(dqkv, s['n'], a + 'qkv_net.weight')
     dn = ops.gemm(dqkv, ps.w(a + 'qkv_net.weight'), b_trans=True)
     dx, _ = ops.layernorm_bwd(dn, s['x'], ps.f32(a + 'layer_norm.weight'), s['m1'], s['r1'], ps.g(a + 'layer_norm.weight'), ps.g(a + 'layer_norm.bias'),
-                              dres=dh)
-    return dx
+                              dres=dh_res)
+    return dx.view(B, K, D)[:, mlen:].reshape(B * T, D) if mlen else dx
 
 
 class TXLStackFn(torch.autograd.Function):
@@ -146,9 +162,12 @@ class TXLStackFn(torch.autograd.Function):
     output, the two CoreNet dropouts, decoder.drop on the final hidden state.  Parameter gradients go straight into the flat grad buffer."""
 
     @staticmethod
-    def forward(ctx, model, tok, anchor, need_bwd):
+    def forward(ctx, model, tok, anchor, need_bwd, mems=None):
+        """mems: None or L+1 tensors [B, mlen, D] (compute dtype): the previous segments' layer inputs.  The layer inputs of THIS segment
+        (the reference's `hids`, :783-841) are left in model._hids for the memory update."""
         ps = model._store
         B, T = tok.shape
+        mlen = 0 if mems is None else mems[0].shape[1]
         D, H, L = model.dec_d_model, model.dec_n_head, model.dec_n_layer
         pd = model.dec_dropout if model.training else 0.0
         model._fwd_counter += 1
@@ -157,14 +176,17 @@ class TXLStackFn(torch.autograd.Function):
                           p_drop=pd, seed=seed, offset=base).view(B * T, D)
         if pd > 0:
             x = ops.dropout_apply(x, pd, seed, base + 1)
-        pe = model.decoder.pos_emb(torch.arange(T, device=ps.device, dtype=torch.float32)).to(ps.compute_dtype).contiguous()   # row d = distance d
+        pe = model.decoder.pos_emb(torch.arange(mlen + T, device=ps.device, dtype=torch.float32)).to(ps.compute_dtype).contiguous()   # row d = distance d
         pe_d = ops.dropout_apply(pe, pd, seed, base + 3) if pd > 0 else pe
-        saves = []
+        saves, hids = [], [x]
         for l in range(L):
             sv = {} if need_bwd else None
             r_dist = ops.gemm(pe_d, ps.w('decoder.layers.%d.dec_attn.r_net.weight' % l))
-            x = _txl_layer_fwd(ps, 'decoder.layers.%d.' % l, x, r_dist, B, T, H, pd, seed, base + 8 * (l + 1), model.decoder.pre_lnorm, sv)
+            x = _txl_layer_fwd(ps, 'decoder.layers.%d.' % l, x, r_dist, B, T, H, pd, seed, base + 8 * (l + 1), model.decoder.pre_lnorm, sv,
+                               mem=None if not mlen else mems[l])
             saves.append(sv)
+            hids.append(x)
+        model._hids = hids if model.dec_mem_len > 0 else None
         if pd > 0:
             x = ops.dropout_apply(x, pd, seed, base + 2)
         ctx.model, ctx.saves, ctx.tok, ctx.pe_d = model, saves, tok, pe_d
@@ -189,7 +211,7 @@ class TXLStackFn(torch.autograd.Function):
         gE = ps.g('word_emb.emb_lookup.weight')
         ops.embed_bwd(ctx.tok, None, dx, gE, None, float(model.word_emb.emb_scale), p_drop=pd, seed=seed, offset=base)
         gE[model.word_emb.emb_lookup.padding_idx].zero_()            # nn.Embedding(padding_idx): that row never receives a gradient
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 class TXLMemory:
@@ -307,12 +329,9 @@ class PlainTransformer(nn.Module):
         YAML): new_mems is the empty list, as in the reference."""
         if return_avg_attn:
             raise NotImplementedError('return_avg_attn is an analysis path of the reference and is not built')
-        if dec_seg_len is not None and self.dec_mem_len > 0:
-            raise NotImplementedError('per-sample memory update (dec_seg_len with mem_len > 0) is not built; every stage-1 YAML trains with mem_len 0, '
-                                      'where dec_seg_len only feeds the memory update and is a no-op')
-        if dec_mems is not None and len(dec_mems) > 0:
-            raise NotImplementedError('segment-level recurrence inside forward() (mem_len > 0 with incoming mems) is not built; use generate()')
         anchor = self.word_emb.emb_lookup.weight
+        if self.dec_mem_len > 0 or (dec_mems is not None and len(dec_mems) > 0):
+            return self._forward_with_memory(dec_input, dec_mems, dec_seg_len, anchor)
         if self.training or (torch.is_grad_enabled() and anchor.requires_grad):
             if not dec_input.is_cuda:
                 raise EmoError('inputs must be GPU tensors (the HIP path has no CPU fallback)')
@@ -323,6 +342,46 @@ class PlainTransformer(nn.Module):
         h, B, T = self._prefill(dec_input)
         logits = self._logits(h).view(B, T, self.vocab_size).permute(1, 0, 2)
         return logits, []
+
+    def _forward_with_memory(self, dec_input, dec_mems, dec_seg_len, anchor):
+        """Segment-level recurrence (optimus_txl_decoder.py:750-925 with mems, memory update :702-748).  dec_mems: () / [] for the first
+        segment, then the list this method returned: L+1 tensors [mlen, B, D] (time-major like the reference's, compute dtype, detached)."""
+        if not dec_input.is_cuda:
+            raise EmoError('inputs must be GPU tensors (the HIP path has no CPU fallback)')
+        if self.dec_mem_len <= 0:
+            raise NotImplementedError('incoming mems with mem_len = 0 (attend to a memory that is never updated) is not built')
+        ps = self._ensure_store()
+        L, D = self.dec_n_layer, self.dec_d_model
+        tok = dec_input.t().contiguous().long()
+        B, T = tok.shape
+        if isinstance(dec_mems, (tuple, list)) and len(dec_mems) == 1 and isinstance(dec_mems[0], (tuple, list)):
+            dec_mems = dec_mems[0]                               # the reference accepts the list wrapped in a 1-tuple (:754-756)
+        mems = None
+        if dec_mems is not None and len(dec_mems) > 0 and dec_mems[0].numel() > 0:
+            assert len(dec_mems) == L + 1, 'len(mems) must be n_layer + 1'
+            mems = [m.detach().to(ps.compute_dtype).permute(1, 0, 2).contiguous() for m in dec_mems]      # [B, mlen, D]
+        mlen = 0 if mems is None else mems[0].shape[1]
+        h = TXLStackFn.apply(self, tok, anchor, torch.is_grad_enabled() and anchor.requires_grad, mems)
+        logits = engine.LogitsFn.apply(self, h).permute(1, 0, 2)
+        hids, self._hids = self._hids, None
+        new_mems = []
+        with torch.no_grad():
+            for i in range(L + 1):
+                hid = hids[i].detach().view(B, T, D)
+                old = mems[i] if mems is not None else hid.new_zeros(B, 0, D)
+                if dec_seg_len is None:                          # :719-724 (ext_len = 0): the last mem_len of the mlen + T cached steps
+                    cat = torch.cat([old, hid], 1)
+                    new_mems.append(cat[:, max(0, mlen + T - self.dec_mem_len):].permute(1, 0, 2).contiguous())
+                else:                                            # :726-746: per sample, its first dec_seg_len[b] steps; left-padded with zeros
+                    assert dec_seg_len.shape[0] == B
+                    rows = []
+                    for b_i in range(B):
+                        c = torch.cat([old[b_i], hid[b_i, :int(dec_seg_len[b_i])]], 0)
+                        rows.append(c[max(0, c.shape[0] - self.dec_mem_len):])
+                    width = max(r.shape[0] for r in rows)
+                    rows = [torch.cat([r.new_zeros(width - r.shape[0], D), r], 0) for r in rows]
+                    new_mems.append(torch.stack(rows, 1))
+        return logits, new_mems
 
     @torch.no_grad()
     def generate(self, dec_input, dec_mems):

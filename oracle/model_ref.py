@@ -125,8 +125,8 @@ def causal_linear_attention(q, k, v, omega, eps=1e-6, form='prefix'):
 
 
 # ----------------------------------------------------------------------------- prologue / epilogue
-def prologue(sd, x, seg_inp, d_model, p_drop=0.0, training=False):
-    """music_performer.py:51-62: (E[x] (*proj))*sqrt(d) + (S[seg])*sqrt(d) + PE[:T] -> dropout."""
+def prologue(sd, x, seg_inp, d_model, p_drop=0.0, training=False, chord_inp=None):
+    """music_performer.py:51-62: (E[x] (*proj))*sqrt(d) + (S[seg])*sqrt(d) (+ chord_emb(chord_inp), :56-57) + PE[:T] -> dropout."""
     emb = F.embedding(x, sd['token_emb.emb_lookup.weight'])
     if 'token_emb.emb_proj.weight' in sd:
         emb = F.linear(emb, sd['token_emb.emb_proj.weight'])
@@ -136,6 +136,8 @@ def prologue(sd, x, seg_inp, d_model, p_drop=0.0, training=False):
         if 'segemb.emb_proj.weight' in sd:
             s = F.linear(s, sd['segemb.emb_proj.weight'])
         emb = emb + s * (d_model ** 0.5)
+    if chord_inp is not None and 'chord_emb.weight' in sd:
+        emb = emb + F.linear(chord_inp, sd['chord_emb.weight'], sd['chord_emb.bias'])
     T = x.size(1)
     h = emb + sd['pe.pe'][:T].permute(1, 0, 2)
     return F.dropout(h, p_drop, training)
@@ -171,10 +173,10 @@ def performer_layer(sd, p, h, n_head, omega, p_drop=0.0, training=False, form='p
 
 
 def performer_forward(sd, x, seg_inp, n_layer, n_head, d_model, omegas=None, keep_last_only=False,
-                      p_drop=0.0, training=False, form='prefix'):
+                      p_drop=0.0, training=False, form='prefix', chord_inp=None):
     """MusicPerformer.forward (music_performer.py:50-70). `omegas`: list of [dh,F/2]
     (the reference redraws omega every forward — SURVEY F8 — so parity runs inject it)."""
-    h = prologue(sd, x, seg_inp, d_model, p_drop, training)
+    h = prologue(sd, x, seg_inp, d_model, p_drop, training, chord_inp)
     for l in range(n_layer):
         p = 'transformer_decoder.decoder_layers.%d.' % l
         om = omegas[l] if omegas is not None else sd[p + 'attention.inner_attention.feature_map.omega']
@@ -212,9 +214,9 @@ def gpt2_block(sd, p, h, n_head, p_drop=0.0, training=False):
     return h + F.dropout(f, p_drop, training)
 
 
-def gpt2_forward(sd, x, seg_inp, n_layer, n_head, d_model, keep_last_only=False, p_drop=0.0, training=False):
+def gpt2_forward(sd, x, seg_inp, n_layer, n_head, d_model, keep_last_only=False, p_drop=0.0, training=False, chord_inp=None):
     """MusicGPT2.forward (music_gpt2.py:70-92): no final ln_f."""
-    h = prologue(sd, x, seg_inp, d_model, p_drop, training)
+    h = prologue(sd, x, seg_inp, d_model, p_drop, training, chord_inp)
     for i in range(n_layer):
         h = gpt2_block(sd, 'transformer_decoder.%d.' % i, h, n_head, p_drop, training)
     return logits_head(sd, h, keep_last_only)
@@ -233,6 +235,8 @@ def loss_and_grads(kind, sd, batch, n_token, n_layer, n_head, d_model, **kw):
               if v.is_floating_point() and not k.endswith('pe.pe') and 'omega' not in k}
     full = dict(sd)
     full.update(params)
+    if torch.is_tensor(batch.get('chords_mhot')) and 'chord_emb.weight' in sd:
+        kw = dict(kw, chord_inp=batch['chords_mhot'])
     logits = forward(kind, full, batch['dec_input'], batch['track_mask'], n_layer, n_head, d_model, **kw)
     loss = compute_loss(logits, batch['dec_target'], n_token)
     loss.backward()

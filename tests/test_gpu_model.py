@@ -255,3 +255,40 @@ def test_embedding_projection_d_embed_differs_from_d_model(kind):
     m.use_pe = True
     with pytest.raises(RuntimeError, match='must match the size'):
         m(b['dec_input'].cuda(), seg_inp=b['track_mask'].cuda())
+
+
+@pytest.mark.parametrize('kind,p_drop', [('performer', 0.0), ('gpt2', 0.0), ('performer', 0.1)])
+def test_chord_multi_hot_embedding(kind, p_drop):
+    """music_performer.py:42-44,56-57: use_chord_mhot_emb adds chord_emb = Linear(12, d_model) of a multi-hot pitch-class vector to the
+    embeddings before PE and dropout (no reference call site turns it on).  Parameter order, logits, loss and all gradients against
+    the oracle; with dropout on, the step still runs and the chord weights receive a gradient."""
+    from emo_disentanger_amd.model.music_gpt2 import MusicGPT2
+    from emo_disentanger_amd.model.music_performer import MusicPerformer
+    from oracle import model_ref
+    from oracle.weights import make_state_dict, synthetic_batch
+    V, L, H, d, dff, B, T = 50, 2, 4, 64, 128, 2, 40
+    sd = make_state_dict(kind, V, L, H, d, dff, favor_feature_dims=32, seed=11, scale=3.0)
+    g = torch.Generator().manual_seed(3)
+    sd['chord_emb.weight'], sd['chord_emb.bias'] = torch.randn(d, 12, generator=g) * 0.05, torch.randn(d, generator=g) * 0.05
+    kw = dict(dropout=p_drop, use_segment_emb=True, n_segment_types=2, use_chord_mhot_emb=True, compute_dtype='fp32')
+    m = MusicPerformer(V, L, H, d, dff, d, favor_feature_dims=32, redraw='fixed', **kw) if kind == 'performer' else MusicGPT2(V, L, H, d, dff, d, **kw)
+    names = [n for n, _ in m.named_parameters()]
+    assert names[-2:] == ['chord_emb.weight', 'chord_emb.bias'] and names.index('segemb.emb_lookup.weight') < names.index('chord_emb.weight')
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    b = synthetic_batch(V, B, T, seed=5)
+    chord = (torch.rand(B, T, 12, generator=g) < 0.3).float()
+    logits = m(b['dec_input'].cuda(), seg_inp=b['track_mask'].cuda(), chord_inp=chord.cuda())
+    loss = m.compute_loss(logits, b['dec_target'].cuda())['total_loss']
+    loss.backward()
+    if p_drop > 0.0:
+        assert torch.isfinite(loss) and float(m.chord_emb.weight.grad.abs().max()) > 0 and float(m.chord_emb.bias.grad.abs().max()) > 0
+        return
+    rloss, rlogits, rgrads = model_ref.loss_and_grads(kind, sd, dict(b, chords_mhot=chord), V, L, H, d)
+    assert abs(float(loss) - float(rloss)) <= 1e-4
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), rlogits.numpy(), rtol=3e-4, atol=3e-4)
+    gmax = max(float(v.abs().max()) for v in rgrads.values())
+    for k, p in m.named_parameters():
+        assert float((p.grad.cpu() - rgrads[k]).abs().max()) <= 2e-3 * gmax, k
+    plain = m(b['dec_input'].cuda(), seg_inp=b['track_mask'].cuda())              # chord_inp=None: the term is skipped (:56)
+    assert not torch.allclose(plain, logits)

@@ -236,3 +236,48 @@ def test_stage1_train_loop_reproduces_reference_trace(tmp_path):
     for k, v in m.state_dict().items():
         ref = g['final_param_sums'][k]
         assert abs(float(v.double().sum()) - ref) <= 2e-3 * max(abs(ref), 1.0), (k, float(v.double().sum()), ref)
+
+
+@pytest.mark.parametrize('name', ['txl_mems_shared', 'txl_mems_persample'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_stage1_segment_recurrence_in_forward(name, dtype):
+    """forward() with mem_len > 0 (optimus_txl_decoder.py:702-748, 750-925): two segments thread their memory (shared update / per-sample
+    update with dec_seg_len), a third one is trained on — logits, memory tensors, loss and gradient norms against the imported reference
+    (tools/make_golden_stage1_mems.py).  fp32: loss within 1e-4."""
+    from emo_disentanger_amd.model.plain_transformer import PlainTransformer
+    from oracle.txl_ref import make_state_dict_txl
+    g = np.load(os.path.join(G, name + '.npz'))
+    V, L, H, d, dff, T, B, mem_len, seed = (int(v) for v in g['cfg'])
+    sd = make_state_dict_txl(V, L, H, d, dff, seed=seed, scale=float(g['scale']))
+    m = PlainTransformer(d, V, L, H, d, dff, mem_len, T, dec_dropout=0.0, pre_lnorm=True, compute_dtype=dtype)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    xs, seg = torch.from_numpy(g['x']).cuda(), g['seg_len']
+    tol = 3e-4 if dtype == 'fp32' else 0.15
+    mems = tuple()
+    for i in range(2):
+        with torch.no_grad():
+            lg, mems = m(xs[i], mems, dec_seg_len=None if seg.size == 0 else torch.from_numpy(seg[i]))
+        assert len(mems) == L + 1 and tuple(mems[0].shape) == tuple(g['mem%d_shape' % i])
+        np.testing.assert_allclose(lg.cpu().numpy(), g['logits%d' % i], rtol=0, atol=tol)
+        np.testing.assert_allclose(mems[0].float().cpu().numpy(), g['mem%d_first' % i], rtol=0, atol=tol)
+        np.testing.assert_allclose(mems[-1].float().cpu().numpy(), g['mem%d_last' % i], rtol=0, atol=tol * 4)
+    m.zero_grad()
+    lg, m3 = m(xs[2], mems)
+    loss = m.compute_loss(lg, torch.from_numpy(g['tgt']).cuda())['total_loss']
+    loss.backward()
+    assert tuple(m3[0].shape) == tuple(g['mem2_shape']) and not m3[0].requires_grad
+    assert abs(float(loss.detach()) - float(g['loss'])) < (1e-4 if dtype == 'fp32' else 3e-2)
+    np.testing.assert_allclose(lg.detach().cpu().numpy(), g['logits2'], rtol=0, atol=tol)
+    params = dict(m.named_parameters())
+    rel = 2e-3 if dtype == 'fp32' else 8e-2
+    gmax = float(g['grad_norms'].max())
+    for n, want in zip(g['grad_names'], g['grad_norms']):
+        got = float(params[str(n)].grad.norm())
+        assert abs(got - want) <= rel * max(want, 0.02 * gmax), (str(n), got, want)
+    if dtype == 'fp32':
+        lyr = m.decoder.layers
+        for got, key in ((lyr[0].dec_attn.qkv_net.weight.grad[:, :8], 'g_qkv0'), (lyr[0].dec_attn.layer_norm.weight.grad, 'g_ln0'),
+                         (m.decoder.r_w_bias.grad, 'g_rw'), (m.decoder.r_r_bias.grad, 'g_rr'), (lyr[1].dec_attn.r_net.weight.grad[:, :8], 'g_rnet1')):
+            want = g[key]
+            np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=2e-3 * float(np.abs(want).max()))

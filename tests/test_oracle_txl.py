@@ -55,3 +55,31 @@ def test_txl_oracle_generation_with_memory_matches_reference(name, c):
     np.testing.assert_allclose(np.stack(outs), g['gen_logits'], rtol=0, atol=3e-5)
     assert mems[0].shape[0] == int(g['mem_len_after'])
     np.testing.assert_allclose(outs[-1], g['gen_full_last'], rtol=0, atol=5e-5)   # cached steps == full recompute of the prefix
+
+
+@pytest.mark.parametrize('name', ['txl_mems_shared', 'txl_mems_persample'])
+def test_oracle_segment_recurrence_matches_reference(name):
+    """Two segments through forward() with mem_len > 0 (shared and per-sample memory update, optimus_txl_decoder.py:702-748), then loss and
+    backward on a third one — fixtures made by tools/make_golden_stage1_mems.py from the imported reference."""
+    from oracle import txl_ref
+    g = np.load(os.path.join(G, name + '.npz'))
+    V, L, H, d, dff, T, B, mem_len, seed = (int(v) for v in g['cfg'])
+    sd = txl_ref.make_state_dict_txl(V, L, H, d, dff, seed=seed, scale=float(g['scale']))
+    leaf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'inv_freq' not in k else v) for k, v in sd.items()}
+    xs, seg = torch.from_numpy(g['x']), g['seg_len']
+    mems = None
+    for i in range(2):
+        with torch.no_grad():
+            lg, mems = txl_ref.forward(sd, xs[i], L, H, mems=mems, mem_len=mem_len, dec_seg_len=None if seg.size == 0 else torch.from_numpy(seg[i]))
+        np.testing.assert_allclose(lg.numpy(), g['logits%d' % i], rtol=0, atol=2e-5)
+        assert tuple(mems[0].shape) == tuple(g['mem%d_shape' % i])
+        np.testing.assert_allclose(mems[0].numpy(), g['mem%d_first' % i], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(mems[-1].numpy(), g['mem%d_last' % i], rtol=0, atol=2e-5)
+    lg, m3 = txl_ref.forward(leaf, xs[2], L, H, mems=mems, mem_len=mem_len)
+    loss = txl_ref.loss(leaf, lg, torch.from_numpy(g['tgt']))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g['loss'])) < 2e-5 and tuple(m3[0].shape) == tuple(g['mem2_shape'])
+    np.testing.assert_allclose(lg.detach().numpy(), g['logits2'], rtol=0, atol=2e-5)
+    for n, want in zip(g['grad_names'], g['grad_norms']):
+        got = float(leaf[str(n)].grad.norm()) if leaf[str(n)].grad is not None else 0.0
+        assert abs(got - want) <= 1e-4 * max(1.0, want), n
