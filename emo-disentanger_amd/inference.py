@@ -95,7 +95,7 @@ class PerformerDecodeEngine(_EngineBase):
         def fold(wname, bname, rows, gamma, beta):
             W = ps.f32(wname, rows)
             Wg = (W * gamma[None, :]).to(torch.bfloat16).contiguous()
-            return Wg, Wg.float().sum(1).contiguous(), (ps.f32(bname, rows) + W @ beta).contiguous()
+            return Wg, Wg.float().sum(1).contiguous(), (ps.f32(bname, rows) + (W * beta[None, :]).sum(1)).contiguous()
 
         L = m.n_layer
         pf = [m._layer_prefix(l) for l in range(L)]
@@ -209,7 +209,7 @@ class GPT2DecodeEngine(_EngineBase):
             if gamma is None:
                 return Wt.to(torch.bfloat16).contiguous(), None, ps.f32(bname)
             Wg = (Wt * gamma[None, :]).to(torch.bfloat16).contiguous()
-            return Wg, Wg.float().sum(1).contiguous(), (ps.f32(bname) + Wt @ beta).contiguous()
+            return Wg, Wg.float().sum(1).contiguous(), (ps.f32(bname) + (Wt * beta[None, :]).sum(1)).contiguous()
 
         self.fold = []
         for l in range(m.n_layer):
