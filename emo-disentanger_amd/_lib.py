@@ -50,7 +50,9 @@ _SIG = {
     'emo_softmax_attn_bwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p]),
     'emo_relpos_attn_fwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p]),
     'emo_relpos_attn_bwd_kv': (c_i, [c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p]),
-    'emo_relpos_attn_bwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p]),
+    'emo_relpos_attn_bwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p]),
+    'emo_relpos_attn_bwd_r': (c_i, [c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p]),
+    'emo_relpos_attn_bwd_r_workspace_bytes': (c_l, [c_l, c_l, c_l, c_l]),
     'emo_relpos_attn_decode': (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_p]),
     'emo_softmax_attn_decode': (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_l, c_l, c_l, c_p]),
     'emo_xent_fwd': (c_i, [c_p, c_p, c_l, c_l, c_l, c_p, c_p, c_p]),

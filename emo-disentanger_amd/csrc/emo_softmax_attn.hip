@@ -810,20 +810,19 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const CT* __restrict__
 // Backward, query-tile organised (first version of the stage-1 training path).  With a_ij = m_ij p_ij / Z_i the final attention weight
 // (m = dropout multiplier, Z_i = sum_j m_ij p_ij + 1e-8 saved by the forward), dA_ij = dO_i.v_j and r1_i = dO_i.O_i:
 //     ds_ij = p_ij ( m_ij (dA_ij - r1_i) / Z_i - 1e-8 r1_i / Z_i )
-// The kernel recomputes p (content + relative term, as the forward), forms ds in registers, accumulates dq_content = ds.K / sqrt(dh) and
-// writes three dense by-products the host turns into the remaining gradients with plain GEMMs:
-//   A_nat  [B,H,T,T]  = a_ij                      -> dV = A^T dO
-//   dS_nat [B,H,T,T]  = ds_ij / sqrt(dh)          -> dK = dS^T (q + u)
-//   dS_skew[H,B,T,ND] = the same values at column (i - j) -> dR = dS_skew^T (q + v),  dq_relative = dS_skew R
-// (entries the causal mask removes are never written: the buffers arrive zeroed).  A fused dK/dV pass with its own skew is the follow-up.
+// The kernel recomputes p (content + relative term, as the forward), forms ds in registers and accumulates BOTH parts of dq:
+//   dq_content[t] = sum_j ds[t][j] k_j / sqrt(dh)                       (ds stays in registers as the MFMA operand)
+//   dq_rel[t]     = sum_j ds[t][j] R[t - j] / sqrt(dh) = sum_c S2[t][c] Rwin[c]   with the skew column c = t_l - j_l + 63:
+// each wave scatters its 16 x 64 ds values into a [16 t][c' = c - 16w] image (it re-uses the wave's P2 skew buffer, which is dead by then)
+// and multiplies it with the TRANSPOSED window rows (ds_read_b64_tr_b16 in bf16 mode).  dq = dq_content + dq_rel; dq_rel also goes out on its
+// own because d r_r_bias = colsum(dq_rel) and d r_w_bias = colsum(dq) - colsum(dq_rel).  dK / dV: relattn_bwd_dkv_kernel; dR: relattn_bwd_dr_kernel.
 template <typename CT, int DH>
-__global__ __launch_bounds__(256, 2) void relattn_bwd_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+__global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 2 : 1)) void relattn_bwd_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
                                                              const CT* __restrict__ rd, int64_t ld_r, int64_t n_dist, const float* __restrict__ ub,
                                                              const float* __restrict__ vb_, const CT* __restrict__ out, const CT* __restrict__ dout,
                                                              int64_t ld_out, const float* __restrict__ lse_g, const float* __restrict__ zden_g,
-                                                             CT* __restrict__ dq, int64_t ld_d, CT* __restrict__ a_nat, CT* __restrict__ ds_nat,
-                                                             CT* __restrict__ ds_skew, int64_t nd_skew, int64_t ld_nat, float* __restrict__ delta_g,
-                                                             int64_t B, int64_t T, int64_t H, DropCtx drop) {
+                                                             CT* __restrict__ dq, int64_t ld_d, CT* __restrict__ dq_rel, int64_t ld_rel,
+                                                             float* __restrict__ delta_g, int64_t T, int64_t H, DropCtx drop) {
     typedef SaDims<CT, DH> D;
     constexpr int LDX = D::LDX, LDC = D::LDC, DHP = D::DHP, ND = DH / 16, NQ = DHP / Img<CT>::KSTEP, SKW = 84;
     constexpr bool TR = sizeof(CT) == 2;
@@ -914,13 +913,14 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_kernel(const CT* __restric
     const float zinv = row_ok ? 1.f / zden_g[bh * T + tg] : 0.f;
     const float r1 = Dv[tl], r2 = 1e-8f * r1 * zinv;
     if (delta_g && tid < qvalid) delta_g[bh * T + q0 + tid] = Dv[tid];
-    f32x4 dqacc[ND];
+    f32x4 dqacc[ND], dracc[ND];
 #pragma unroll
-    for (int i = 0; i < ND; ++i) dqacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < ND; ++i) dqacc[i] = dracc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float* skw = sk + (wave * 16 + (lane & 15)) * SKW;
-    CT* an_row = a_nat + (bh * T + tg) * ld_nat;
-    CT* dn_row = ds_nat + (bh * T + tg) * ld_nat;
-    CT* sk_row = ds_skew + ((h * B + b) * T + tg) * nd_skew;
+    // skew image of ds: [16 t][LD2] over the wave's P2 buffer (16 * SKW floats).  bf16: k padded to 96 (3 MFMA steps), f32: k = 80.
+    constexpr int LD2 = TR ? 104 : 84;
+    static_assert(16 * LD2 * sizeof(CT) <= 16 * SKW * sizeof(float), "ds skew image must fit the P2 skew buffer");
+    CT* s2 = (CT*)(sk + wave * 16 * SKW);
     for (int64_t kt = 0; kt <= qt; ++kt) {
         const int64_t k0 = kt * 64;
         __syncthreads();
@@ -959,37 +959,56 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_kernel(const CT* __restric
             }
             float dm[4] = {1.f, 1.f, 1.f, 1.f};
             if (drop.thr16) drop_mult4(drop, (uint64_t)((bh * T + tg) * T + k0 + jt * 16 + (lane >> 4) * 4), dm);
-            float av[4], dv4[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int jl = jt * 16 + (lane >> 4) * 4 + r;
                 const float sc = sa[r] + skw[(lane & 15) + 63 - jl];
                 float p = sizeof(CT) == 2 ? __builtin_amdgcn_exp2f(sc * c2 - lse2) : Img<CT>::ex(sc / sqrt_dh - lse);
                 if (diag && (jl > tl || k0 + jl >= T)) p = 0.f;
-                const float mp = dm[r] * p;
-                av[r] = mp * zinv;
-                ds[jt][r] = p * (dm[r] * (dp[r] - r1) * zinv - r2);
-                dv4[r] = ds[jt][r] * rsqrt_dh;
-            }
-            if (live && row_ok) {
-                const int64_t jg0 = k0 + jt * 16 + (lane >> 4) * 4;
-                if (!a_nat) {
-                } else if (jg0 + 3 < T && (ld_nat & 3) == 0) {
-                    Img<CT>::store4(an_row + jg0, av[0], av[1], av[2], av[3]);
-                    Img<CT>::store4(dn_row + jg0, dv4[0], dv4[1], dv4[2], dv4[3]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (jg0 + r < T) { an_row[jg0 + r] = from_f32<CT>(av[r]); dn_row[jg0 + r] = from_f32<CT>(dv4[r]); }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t dist = tg - (jg0 + r);
-                    if (dist >= 0 && jg0 + r < T) sk_row[dist] = from_f32<CT>(dv4[r]);
-                }
+                ds[jt][r] = row_ok ? p * (dm[r] * (dp[r] - r1) * zinv - r2) : 0.f;
             }
         }
         __builtin_amdgcn_wave_barrier();
+        // ds -> skew image (the P2 values are dead): zero, then one element per (t, j) at column c' = t_l - j_l + 63 (in [0, 78])
+        {
+            const u32x4 z4 = {0u, 0u, 0u, 0u};
+            for (int i = lane; i < (int)(16 * LD2 * sizeof(CT) / 16); i += 64) ((u32x4*)s2)[i] = z4;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s2[(lane & 15) * LD2 + (lane & 15) + 63 - (jt * 16 + (lane >> 4) * 4 + r)] = from_f32<CT>(ds[jt][r]);
+        __builtin_amdgcn_wave_barrier();
+        // dQ_rel^T[d][t] += sum_c' Rwin^T[d][16w + c'] S2[t][c']
+        if constexpr (TR) {
+#pragma unroll
+            for (int st = 0; st < 3; ++st) {
+                const bf16x8 sf = load_perm<CT>(s2, LD2, 0, st, lane);
+#pragma unroll
+                for (int i = 0; i < ND; ++i) {
+                    bf16x8 rf;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {            // load_perm_tr with the window row clamped (rows past 127 only meet zero columns)
+                        int row = wave * 16 + (2 * st + hh) * 16 + (lane >> 4) * 4 + ((lane & 15) >> 2);
+                        row = row > 127 ? 127 : row;
+                        const bf16_t* pr = (const bf16_t*)Rw + row * LDX + i * 16 + (lane & 3) * 4;
+                        const short4v t4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)pr);
+                        const bf16x4 tb = __builtin_bit_cast(bf16x4, t4);
+                        rf[hh * 4 + 0] = tb[0]; rf[hh * 4 + 1] = tb[1]; rf[hh * 4 + 2] = tb[2]; rf[hh * 4 + 3] = tb[3];
+                    }
+                    dracc[i] = Img<CT>::mma(rf, sf, dracc[i]);
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int st = 0; st < 20; ++st) {
+                const float sf = s2[(lane & 15) * LD2 + 4 * st + (lane >> 4)];
+#pragma unroll
+                for (int i = 0; i < ND; ++i)
+                    dracc[i] = Img<CT>::mma(Rw[(wave * 16 + 4 * st + (lane >> 4)) * LDX + i * 16 + (lane & 15)], sf, dracc[i]);
+            }
+        }
         // dQ_content^T[d][t] += sum_j K^T[d][j] dS[t][j]
 #pragma unroll
         for (int st = 0; st < SaK<CT>::NS64; ++st) {
@@ -1003,10 +1022,13 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_kernel(const CT* __restric
     }
     if (row_ok) {
         CT* db = dq + (b * T + tg) * ld_d + h * DH;
+        CT* dr = dq_rel + (b * T + tg) * ld_rel + h * DH;
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const int d0 = i * 16 + (lane >> 4) * 4;
-            Img<CT>::store4(db + d0, dqacc[i][0] * rsqrt_dh, dqacc[i][1] * rsqrt_dh, dqacc[i][2] * rsqrt_dh, dqacc[i][3] * rsqrt_dh);
+            Img<CT>::store4(dr + d0, dracc[i][0] * rsqrt_dh, dracc[i][1] * rsqrt_dh, dracc[i][2] * rsqrt_dh, dracc[i][3] * rsqrt_dh);
+            Img<CT>::store4(db + d0, (dqacc[i][0] + dracc[i][0]) * rsqrt_dh, (dqacc[i][1] + dracc[i][1]) * rsqrt_dh,
+                            (dqacc[i][2] + dracc[i][2]) * rsqrt_dh, (dqacc[i][3] + dracc[i][3]) * rsqrt_dh);
         }
     }
 }
@@ -1015,7 +1037,7 @@ __global__ __launch_bounds__(256, 2) void relattn_bwd_kernel(const CT* __restric
 // qv = q + r_r_bias arrive materialised ([B*T, H*dh], pitch ld_q).  A wave owns 16 key rows; for a 16-row query sub-tile tt the relative term
 // only touches two 16-row tiles of the distance window (c = t - j + 63 in [16(tt-w)+48, 16(tt-w)+78]), skewed through a [16][32] buffer.
 template <typename CT, int DH>
-__global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 2 : 1)) void relattn_bwd_dkv_kernel(
+__global__ __launch_bounds__(256, 1) void relattn_bwd_dkv_kernel(
     const CT* __restrict__ qu, const CT* __restrict__ qv, int64_t ld_q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
     const CT* __restrict__ rd, int64_t ld_r, int64_t n_dist, const CT* __restrict__ dout, int64_t ld_out, const float* __restrict__ lse_g,
     const float* __restrict__ zden_g, const float* __restrict__ delta_g, CT* __restrict__ dk, CT* __restrict__ dv, int64_t ld_d, int64_t T, int64_t H,
@@ -1188,6 +1210,201 @@ __global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 2 : 1)) void relattn_bwd_dk
 }
 
 // one query per stream against a KV cache, keys j in [j0, len): score_j = ((q+u).k_j + (q+v).R[len-1-j]) / sqrt(dh)
+// Backward, distance-window pass: dR[dist] = sum_{b, i} ds[b, i, i - dist] (q_i + v) / sqrt(dh), the gradient of the by-distance rows r_dist.
+// For a pair (query tile qt, key tile kt) the 64 x 64 ds values land on the 127 distances 64 (qt - kt) - 63 .. + 63, i.e. on a window that only
+// depends on the diagonal delta = qt - kt.  One workgroup therefore owns ONE diagonal of one (b, h): it walks the pairs (kt + delta, kt),
+// recomputes ds like the query-tile pass (the R window stays in LDS for the whole walk), scatters it into a block-wide skew image
+// S2[64 t][128 c] (c = t_l - j_l + 63) and accumulates  dRwin[c][d] += sum_t S2^T[c][t] qv[t][d]  in MFMA accumulators over the whole
+// diagonal (both operands through transposed LDS reads) — the partial windows [B*H, n_tiles, 128, dh] go to a workspace and
+// relattn_dr_reduce_kernel adds the (at most two) windows covering each distance over the batch, in a fixed order (deterministic).
+// This replaces the dense [H, B*T, T] skewed ds matrix + one GEMM per head of the first version.
+template <typename CT, int DH>
+__global__ __launch_bounds__(256) void relattn_bwd_dr_kernel(const CT* __restrict__ qu, const CT* __restrict__ qv, int64_t ld_q, const CT* __restrict__ k,
+                                                             const CT* __restrict__ v, int64_t ld, const CT* __restrict__ rd, int64_t ld_r, int64_t n_dist,
+                                                             const CT* __restrict__ dout, int64_t ld_out, const float* __restrict__ lse_g,
+                                                             const float* __restrict__ zden_g, const float* __restrict__ delta_g, float* __restrict__ part,
+                                                             int64_t T, int64_t H, DropCtx drop) {
+    typedef SaDims<CT, DH> D;
+    constexpr int LDX = D::LDX, DHP = D::DHP, ND = DH / 16, NQ = DHP / Img<CT>::KSTEP, SKW = 84;
+    constexpr bool TR = sizeof(CT) == 2;
+    constexpr int LDS2 = TR ? 136 : 130;                      // S2 row pitch (128 columns + pad)
+    constexpr int S2SZ = CMax<2 * 64 * LDX, 64 * LDS2>::v;    // the skew image re-uses the (q + u) and dO images
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    CT* Qu = (CT*)smem;                       // [64][LDX]  q + u   } only feed the register fragments; then S2 [64][LDS2] lives here
+    CT* Go = Qu + 64 * LDX;                   // [64][LDX]  dO      }
+    CT* S2 = Qu;
+    CT* Qv = Qu + S2SZ;                       // [64][LDX]  q + v (fragments AND the operand of the dR product)
+    CT* Ki = Qv + 64 * LDX;                   // [64][LDX]
+    CT* Vi = Ki + 64 * LDX;                   // [64][LDX]
+    CT* Rw = Vi + 64 * LDX;                   // [128][LDX] window rows: distance 64 delta - 63 + c
+    float* sk = (float*)(Rw + 128 * LDX);     // [4][16][SKW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t nt = (T + 63) / 64;
+    const int64_t dl = blockIdx.x;            // diagonal: qt = kt + dl (dl = 0 is the longest walk and starts first)
+    const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
+    const CT* qub = qu + (b * T) * ld_q + h * DH;
+    const CT* qvb = qv + (b * T) * ld_q + h * DH;
+    const CT* kb = k + (b * T) * ld + h * DH;
+    const CT* vb = v + (b * T) * ld + h * DH;
+    const CT* gb = dout + (b * T) * ld_out + h * DH;
+    const CT* rb = rd + h * DH;
+    {   // the window rows, once
+        constexpr int VE = 16 / sizeof(CT), CH = DH / VE;
+        for (int it = tid; it < 128 * CH; it += 256) {
+            const int row = it / CH, c = (it % CH) * VE;
+            const int64_t dist = 64 * dl - 63 + row;
+            CT tmp[VE];
+#pragma unroll
+            for (int e = 0; e < VE; ++e) tmp[e] = from_f32<CT>(0.f);
+            if (dist >= 0 && dist < n_dist) {
+                if constexpr (sizeof(CT) == 2) *(bf16x8*)tmp = *(const bf16x8*)(rb + dist * ld_r + c);
+                else *(f32x4*)tmp = *(const f32x4*)(rb + dist * ld_r + c);
+            }
+#pragma unroll
+            for (int e = 0; e < VE; ++e) Rw[row * LDX + c + e] = tmp[e];
+        }
+        if constexpr (DHP > DH) {
+            for (int it = tid; it < 128 * (DHP - DH); it += 256) Rw[(it / (DHP - DH)) * LDX + DH + it % (DHP - DH)] = from_f32<CT>(0.f);
+        }
+    }
+    RowPrefetch<CT, DH, DHP, 64, 256> pqu, pqv, pg, pk, pv;
+    float pl = INFINITY, pz = 0.f, pdl = 0.f;
+    auto fetch = [&](int64_t kt) {
+        const int64_t q0 = (kt + dl) * 64, k0 = kt * 64;
+        const int nq = (int)((T - q0) < 64 ? (T - q0) : 64), nk = (int)((T - k0) < 64 ? (T - k0) : 64);
+        pqu.load(qub + q0 * ld_q, ld_q, nq, tid);
+        pqv.load(qvb + q0 * ld_q, ld_q, nq, tid);
+        pg.load(gb + q0 * ld_out, ld_out, nq, tid);
+        pk.load(kb + k0 * ld, ld, nk, tid);
+        pv.load(vb + k0 * ld, ld, nk, tid);
+        const int64_t tg = q0 + wave * 16 + (lane & 15);
+        const bool ok = tg < T;
+        pl = ok ? lse_g[bh * T + tg] : INFINITY;
+        pz = ok ? 1.f / zden_g[bh * T + tg] : 0.f;
+        pdl = ok ? delta_g[bh * T + tg] : 0.f;
+    };
+    fetch(0);
+    const float sqrt_dh = sqrtf((float)DH), rsqrt_dh = 1.f / sqrt_dh, c2 = rsqrt_dh * EMO_LOG2E;
+    const int tl = wave * 16 + (lane & 15);
+    f32x4 racc[2][ND];                        // window rows 32 w .. 32 w + 31 x all d
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < ND; ++i) racc[a][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float* skw = sk + (wave * 16 + (lane & 15)) * SKW;
+    const bool diag = dl == 0;
+    for (int64_t kt = 0; kt + dl < nt; ++kt) {
+        const int64_t q0 = (kt + dl) * 64, k0 = kt * 64;
+        const int64_t tg = q0 + tl;
+        __syncthreads();                      // the previous pair's dR product has read S2 / Qv
+        pqu.store_rows(Qu, LDX, tid);
+        pqv.store_rows(Qv, LDX, tid);
+        pg.store_rows(Go, LDX, tid);
+        pk.store_rows(Ki, LDX, tid);
+        pv.store_rows(Vi, LDX, tid);
+        const float lse = pl, lse2 = pl * EMO_LOG2E, zinv = pz, r1 = pdl, r2 = 1e-8f * pdl * pz;
+        const bool row_ok = tg < T;
+        if (kt + 1 + dl < nt) fetch(kt + 1);
+        __syncthreads();
+        typename Img<CT>::V quf[NQ], qvf[NQ], gf[NQ];
+#pragma unroll
+        for (int kk = 0; kk < NQ; ++kk) {
+            quf[kk] = Img<CT>::load(Qu, LDX, wave * 16, kk * Img<CT>::KSTEP, lane);
+            qvf[kk] = Img<CT>::load(Qv, LDX, wave * 16, kk * Img<CT>::KSTEP, lane);
+            gf[kk] = Img<CT>::load(Go, LDX, wave * 16, kk * Img<CT>::KSTEP, lane);
+        }
+        __syncthreads();                      // Qu / Go are dead: S2 may overwrite them
+        {
+            const u32x4 z4 = {0u, 0u, 0u, 0u};
+            u32x4* zr = (u32x4*)(S2 + wave * 16 * LDS2);
+            for (int i = lane; i < (int)(16 * LDS2 * sizeof(CT) / 16); i += 64) zr[i] = z4;
+        }
+#pragma unroll
+        for (int ci = 0; ci < 5; ++ci) {
+            f32x4 a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NQ; ++kk) a2 = Img<CT>::mma(Img<CT>::load(Rw, LDX, (wave + ci) * 16, kk * Img<CT>::KSTEP, lane), qvf[kk], a2);
+            *(f32x4*)(skw + ci * 16 + (lane >> 4) * 4) = a2;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            if (!(diag && jt > wave)) {
+#pragma unroll
+                for (int kk = 0; kk < NQ; ++kk) {
+                    sa = Img<CT>::mma(Img<CT>::load(Ki, LDX, jt * 16, kk * Img<CT>::KSTEP, lane), quf[kk], sa);
+                    dp = Img<CT>::mma(Img<CT>::load(Vi, LDX, jt * 16, kk * Img<CT>::KSTEP, lane), gf[kk], dp);
+                }
+            }
+            float dm[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop.thr16) drop_mult4(drop, (uint64_t)((bh * T + tg) * T + k0 + jt * 16 + (lane >> 4) * 4), dm);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jl = jt * 16 + (lane >> 4) * 4 + r;
+                const float sc = sa[r] + skw[(lane & 15) + 63 - jl];
+                float p = sizeof(CT) == 2 ? __builtin_amdgcn_exp2f(sc * c2 - lse2) : Img<CT>::ex(sc / sqrt_dh - lse);
+                if ((diag && jl > tl) || k0 + jl >= T) p = 0.f;
+                const float dsv = row_ok ? p * (dm[r] * (dp[r] - r1) * zinv - r2) * rsqrt_dh : 0.f;
+                S2[tl * LDS2 + tl - jl + 63] = from_f32<CT>(dsv);
+            }
+        }
+        __syncthreads();                      // S2 complete
+        // dRwin[c][d] += sum_t S2[t][c] qv[t][d]
+        if constexpr (TR) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 qf[ND];
+#pragma unroll
+                for (int i = 0; i < ND; ++i) qf[i] = load_perm_tr((const bf16_t*)Qv, LDX, i * 16, st, lane);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const bf16x8 sf = load_perm_tr((const bf16_t*)S2, LDS2, (2 * wave + a) * 16, st, lane);
+#pragma unroll
+                    for (int i = 0; i < ND; ++i) racc[a][i] = Img<CT>::mma(sf, qf[i], racc[a][i]);
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int st = 0; st < 16; ++st) {
+                const int t = 4 * st + (lane >> 4);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const float sf = S2[t * LDS2 + (2 * wave + a) * 16 + (lane & 15)];
+#pragma unroll
+                    for (int i = 0; i < ND; ++i) racc[a][i] = Img<CT>::mma(sf, Qv[t * LDX + i * 16 + (lane & 15)], racc[a][i]);
+                }
+            }
+        }
+    }
+    float* po = part + ((bh * nt + dl) * 128) * DH;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) po[((2 * wave + a) * 16 + (lane >> 4) * 4 + r) * DH + i * 16 + (lane & 15)] = racc[a][i][r];
+}
+
+// dR[dist][h * dh + d] = sum_b (window delta_hi row c + window delta_hi - 1 row c + 64),  delta_hi = (dist + 63) / 64,  c = dist + 63 - 64 delta_hi
+__global__ __launch_bounds__(256) void relattn_dr_reduce_kernel(const float* __restrict__ part, float* __restrict__ dR, int64_t ld_dr, int64_t B, int64_t T,
+                                                                int64_t H, int dh) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t HD = H * dh;
+    if (idx >= T * HD) return;
+    const int64_t dist = idx / HD, h = (idx % HD) / dh;
+    const int d = (int)(idx % dh);
+    const int64_t nt = (T + 63) / 64, dhi = (dist + 63) / 64;
+    const int c = (int)(dist + 63 - 64 * dhi);
+    float s = 0.f;
+    for (int64_t b = 0; b < B; ++b) {
+        const float* pb = part + ((b * H + h) * nt) * 128 * dh;
+        if (dhi < nt) s += pb[(dhi * 128 + c) * dh + d];
+        if (dhi >= 1) s += pb[((dhi - 1) * 128 + c + 64) * dh + d];
+    }
+    dR[dist * ld_dr + h * dh + d] = s;
+}
+
 template <typename CT>
 __global__ __launch_bounds__(256) void relattn_decode_kernel(const CT* __restrict__ q, int64_t ld_q, CT* __restrict__ kc, CT* __restrict__ vc, int64_t T_max,
                                                              const int64_t* __restrict__ lens, int64_t lens_off, int64_t mem_len,
@@ -1320,45 +1537,100 @@ template <typename CT, int DH> static size_t ra_bwd_lds() {
 template <typename CT, int DH>
 static int run_relattn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* rd, int64_t ld_r, int64_t n_dist, const float* ub,
                            const float* vb, const void* out, const void* dout, int64_t ld_out, const float* lse, const float* zden, void* dq, int64_t ld_d,
-                           void* a_nat, void* ds_nat, void* ds_skew, int64_t nd_skew, int64_t ld_nat, float* delta, int64_t B, int64_t T, int64_t H,
-                           DropCtx drop, hipStream_t st) {
+                           void* dq_rel, int64_t ld_rel, float* delta, int64_t B, int64_t T, int64_t H, DropCtx drop, hipStream_t st) {
     dim3 grid((unsigned)((T + 63) / 64), (unsigned)(B * H));
     const size_t lds = ra_bwd_lds<CT, DH>();
     auto kf = relattn_bwd_kernel<CT, DH>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     hipLaunchKernelGGL(kf, grid, dim3(256), lds, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, (const CT*)rd, ld_r, n_dist, ub, vb, (const CT*)out,
-                       (const CT*)dout, ld_out, lse, zden, (CT*)dq, ld_d, (CT*)a_nat, (CT*)ds_nat, (CT*)ds_skew, nd_skew, ld_nat, delta, B, T, H, drop);
+                       (const CT*)dout, ld_out, lse, zden, (CT*)dq, ld_d, (CT*)dq_rel, ld_rel, delta, T, H, drop);
     EMO_LAUNCH_CHECK();
     return EMO_OK;
 }
 
 extern "C" int emo_relpos_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* r_dist, int64_t ld_r, int64_t n_dist,
                                    const float* r_w_bias, const float* r_r_bias, const void* out, const void* dout, int64_t ld_out, const float* lse,
-                                   const float* zden, void* dq, int64_t ld_d, void* a_nat, void* ds_nat, int64_t ld_nat, void* ds_skew, int64_t nd_skew, float* delta, int dtype,
+                                   const float* zden, void* dq, int64_t ld_d, void* dq_rel, int64_t ld_rel, float* delta, int dtype,
                                    int64_t B, int64_t T, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
     int rc = sattn_check(q, k, v, ld, ld_out, dtype, dh);
     if (rc) return rc;
-    EMO_CHECK(r_dist && r_w_bias && r_r_bias && out && dout && lse && zden && dq && ds_skew && (!a_nat == !ds_nat), "emo_relpos_attn_bwd: null pointer");
+    EMO_CHECK(r_dist && r_w_bias && r_r_bias && out && dout && lse && zden && dq && dq_rel, "emo_relpos_attn_bwd: null pointer");
     const int64_t ve = dtype == EMO_BF16 ? 8 : 4;
-    EMO_CHECK(ld_r % ve == 0 && ld_d % 4 == 0 && (((uintptr_t)r_dist | (uintptr_t)dq | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)a_nat | (uintptr_t)ds_nat) & 15) == 0,
+    EMO_CHECK(ld_r % ve == 0 && ld_d % 4 == 0 && ld_rel % 4 == 0 && (((uintptr_t)r_dist | (uintptr_t)dq | (uintptr_t)dq_rel | (uintptr_t)out | (uintptr_t)dout) & 15) == 0,
               "emo_relpos_attn_bwd: pointers must be 16-B aligned");
-    EMO_CHECK(n_dist >= T && nd_skew >= T && ld_nat >= T, "emo_relpos_attn_bwd: r_dist / ds_skew / a_nat need a column for every distance / key 0 .. T-1");
+    EMO_CHECK(n_dist >= T, "emo_relpos_attn_bwd: r_dist needs a row for every distance 0 .. T-1");
     const DropCtx drop = make_drop(p_drop, seed, offset);
     hipStream_t st = (hipStream_t)stream;
 #define RAB_CASE(DHv)                                                                                                                                  \
     if (dh == DHv) {                                                                                                                                   \
         if (dtype == EMO_BF16)                                                                                                                         \
-            return run_relattn_bwd<bf16_t, DHv>(q, k, v, ld, r_dist, ld_r, n_dist, r_w_bias, r_r_bias, out, dout, ld_out, lse, zden, dq, ld_d, a_nat, ds_nat,  \
-                                                ds_skew, nd_skew, ld_nat, delta, B, T, H, drop, st);                                                          \
-        return run_relattn_bwd<float, DHv>(q, k, v, ld, r_dist, ld_r, n_dist, r_w_bias, r_r_bias, out, dout, ld_out, lse, zden, dq, ld_d, a_nat, ds_nat,       \
-                                           ds_skew, nd_skew, ld_nat, delta, B, T, H, drop, st);                                                               \
+            return run_relattn_bwd<bf16_t, DHv>(q, k, v, ld, r_dist, ld_r, n_dist, r_w_bias, r_r_bias, out, dout, ld_out, lse, zden, dq, ld_d, dq_rel, ld_rel,  \
+                                                delta, B, T, H, drop, st);                                                          \
+        return run_relattn_bwd<float, DHv>(q, k, v, ld, r_dist, ld_r, n_dist, r_w_bias, r_r_bias, out, dout, ld_out, lse, zden, dq, ld_d, dq_rel, ld_rel,       \
+                                           delta, B, T, H, drop, st);                                                               \
     }
     RAB_CASE(64)
     RAB_CASE(32)
     RAB_CASE(16)
 #undef RAB_CASE
     emo_set_error("emo_relpos_attn_bwd: unsupported d_head=%lld (built: 16, 32, 64)", (long long)dh);
+    return EMO_ERR_UNSUPPORTED;
+}
+
+template <typename CT, int DH> static size_t ra_dr_lds() {
+    typedef SaDims<CT, DH> D;
+    return sizeof(CT) * (size_t)(CMax<2 * 64 * D::LDX, 64 * (sizeof(CT) == 2 ? 136 : 130)>::v + 3 * 64 * D::LDX + 128 * D::LDX) + sizeof(float) * (4 * 16 * 84);
+}
+template <typename CT, int DH>
+static int run_relattn_dr(const void* qu, const void* qv, int64_t ld_q, const void* k, const void* v, int64_t ld, const void* rd, int64_t ld_r, int64_t n_dist,
+                          const void* dout, int64_t ld_out, const float* lse, const float* zden, const float* delta, float* dR, int64_t ld_dr, float* part,
+                          int64_t B, int64_t T, int64_t H, DropCtx drop, hipStream_t st) {
+    dim3 grid((unsigned)((T + 63) / 64), (unsigned)(B * H));
+    const size_t lds = ra_dr_lds<CT, DH>();
+    auto kf = relattn_bwd_dr_kernel<CT, DH>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(kf, grid, dim3(256), lds, st, (const CT*)qu, (const CT*)qv, ld_q, (const CT*)k, (const CT*)v, ld, (const CT*)rd, ld_r, n_dist,
+                       (const CT*)dout, ld_out, lse, zden, delta, part, T, H, drop);
+    EMO_LAUNCH_CHECK();
+    const int64_t n = T * H * DH;
+    hipLaunchKernelGGL(relattn_dr_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)part, dR, ld_dr, B, T, H, DH);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
+extern "C" int64_t emo_relpos_attn_bwd_r_workspace_bytes(int64_t B, int64_t T, int64_t H, int64_t dh) {
+    return B * H * ((T + 63) / 64) * 128 * dh * (int64_t)sizeof(float);
+}
+
+extern "C" int emo_relpos_attn_bwd_r(const void* qu, const void* qv, int64_t ld_q, const void* k, const void* v, int64_t ld, const void* r_dist, int64_t ld_r,
+                                     int64_t n_dist, const void* dout, int64_t ld_out, const float* lse, const float* zden, const float* delta, float* dR,
+                                     int64_t ld_dr, void* workspace, int64_t workspace_bytes, int dtype, int64_t B, int64_t T, int64_t H, int64_t dh,
+                                     float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
+    int rc = sattn_check(qu, k, v, ld, ld_out, dtype, dh);
+    if (rc) return rc;
+    EMO_CHECK(qv && r_dist && dout && lse && zden && delta && dR && workspace, "emo_relpos_attn_bwd_r: null pointer");
+    const int64_t ve = dtype == EMO_BF16 ? 8 : 4;
+    EMO_CHECK(ld_r % ve == 0 && ld_q % ve == 0 && (((uintptr_t)r_dist | (uintptr_t)qu | (uintptr_t)qv | (uintptr_t)dout | (uintptr_t)workspace) & 15) == 0,
+              "emo_relpos_attn_bwd_r: pointers must be 16-B aligned");
+    EMO_CHECK(n_dist >= T && ld_dr >= H * dh, "emo_relpos_attn_bwd_r: r_dist needs a row for every distance 0 .. T-1, dR a column for every (h, d)");
+    EMO_CHECK(workspace_bytes >= emo_relpos_attn_bwd_r_workspace_bytes(B, T, H, dh), "emo_relpos_attn_bwd_r: workspace too small (emo_relpos_attn_bwd_r_workspace_bytes)");
+    const DropCtx drop = make_drop(p_drop, seed, offset);
+    hipStream_t st = (hipStream_t)stream;
+#define RAR_CASE(DHv)                                                                                                                                  \
+    if (dh == DHv) {                                                                                                                                   \
+        if (dtype == EMO_BF16)                                                                                                                         \
+            return run_relattn_dr<bf16_t, DHv>(qu, qv, ld_q, k, v, ld, r_dist, ld_r, n_dist, dout, ld_out, lse, zden, delta, dR, ld_dr, (float*)workspace, B, T, \
+                                               H, drop, st);                                                                                           \
+        return run_relattn_dr<float, DHv>(qu, qv, ld_q, k, v, ld, r_dist, ld_r, n_dist, dout, ld_out, lse, zden, delta, dR, ld_dr, (float*)workspace, B, T, H,  \
+                                          drop, st);                                                                                                   \
+    }
+    RAR_CASE(64)
+    RAR_CASE(32)
+    RAR_CASE(16)
+#undef RAR_CASE
+    emo_set_error("emo_relpos_attn_bwd_r: unsupported d_head=%lld (built: 16, 32, 64)", (long long)dh);
     return EMO_ERR_UNSUPPORTED;
 }
 

@@ -285,37 +285,32 @@ def relpos_attn_fwd(q, k, v, r_dist, r_w_bias, r_r_bias, B, T, H, p_drop=0.0, se
 
 def relpos_attn_bwd(qkv, r_dist, r_w_bias, r_r_bias, out, dout, lse, zden, B, T, H, p_drop=0.0, seed=0, offset=0):
     """Backward of relpos_attn_fwd.  qkv [B*T, 3*H*dh] (the fused projection).  Returns dqkv [B*T, 3*H*dh], dR [T, H*dh] fp32 (gradient of
-    r_dist rows 0..T-1), d r_w_bias [H, dh], d r_r_bias [H, dh] fp32.  Query-tile pass: dq_content + the skewed ds matrix; key-tile pass: dk, dv;
-    dR and the relative part of dq are one GEMM per head over the skewed ds (include/emo_hip.h)."""
+    r_dist rows 0..T-1), d r_w_bias [H, dh], d r_r_bias [H, dh] fp32.  Three kernels, each recomputing the probabilities of its tiles:
+    query-tile pass (dq = content + relative part), key-tile pass (dk, dv), distance-window pass (dR) — include/emo_hip.h."""
     M, D3 = qkv.shape
     D = D3 // 3
     dh = D // H
     dt, dev = qkv.dtype, qkv.device
     assert M == B * T and out.is_contiguous() and dout.is_contiguous() and qkv.is_contiguous()
-    nd = (T + 7) // 8 * 8
     dqkv = torch.empty(M, D3, device=dev, dtype=dt)
-    ds_skew = torch.zeros(H, B * T, nd, device=dev, dtype=dt)
+    dq_rel = torch.empty(M, D, device=dev, dtype=dt)
     delta = torch.empty(B, H, T, device=dev, dtype=torch.float32)
     q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
     check(lib.emo_relpos_attn_bwd(ptr(q), ptr(k), ptr(v), D3, ptr(r_dist), _rows(r_dist), r_dist.shape[0], ptr(r_w_bias), ptr(r_r_bias), ptr(out),
-                                  ptr(dout), D, ptr(lse), ptr(zden), ptr(dqkv), D3, None, None, nd, ptr(ds_skew), nd, ptr(delta), dtype_code(dt),
-                                  B, T, H, dh, p_drop, seed, offset, stream()))
-    d_rw = colsum(dqkv[:, :D]).view(H, dh)                      # sum over (b, i) of dq_content = d r_w_bias
+                                  ptr(dout), D, ptr(lse), ptr(zden), ptr(dqkv), D3, ptr(dq_rel), D, ptr(delta), dtype_code(dt), B, T, H, dh, p_drop,
+                                  seed, offset, stream()))
+    d_rr = colsum(dq_rel)                                       # sum over (b, i) of the relative part of dq = d r_r_bias
+    d_rw = (colsum(dqkv[:, :D]) - d_rr).view(H, dh)             # ... of the content part = d r_w_bias
     qf = q.float()
     qu, qv = (qf + r_w_bias.view(1, D)).to(dt), (qf + r_r_bias.view(1, D)).to(dt)
     check(lib.emo_relpos_attn_bwd_kv(ptr(qu), ptr(qv), D, ptr(k), ptr(v), D3, ptr(r_dist), _rows(r_dist), r_dist.shape[0], ptr(dout), D, ptr(lse),
                                      ptr(zden), ptr(delta), ptr(dqkv[:, D:2 * D]), ptr(dqkv[:, 2 * D:]), D3, dtype_code(dt), B, T, H, dh, p_drop, seed,
                                      offset, stream()))
-    dR = torch.zeros(H, nd, dh, device=dev, dtype=torch.float32)
-    rs = torch.zeros(H, nd, device=dev, dtype=torch.float32)
-    rpad = r_dist[:nd] if r_dist.shape[0] >= nd else torch.cat([r_dist, r_dist.new_zeros(nd - r_dist.shape[0], D)])
-    for h in range(H):
-        cols = slice(h * dh, (h + 1) * dh)
-        gemm(ds_skew[h], q[:, cols], a_trans=True, b_trans=True, out=dR[h], accumulate=True, a_rowsum=rs[h])       # dR = ds_skew^T q (+ rowsum x v below)
-        gemm(ds_skew[h], rpad[:, cols], b_trans=True, residual=dqkv[:, cols], out=dqkv[:, cols])                     # dq += ds_skew R
-    dR += rs[:, :, None] * r_r_bias[:, None, :]
-    d_rr = torch.einsum('hn,nhd->hd', rs[:, :T], r_dist[:T].float().view(T, H, dh))
-    return dqkv, dR[:, :T].permute(1, 0, 2).reshape(T, D).contiguous(), d_rw, d_rr
+    dR = torch.empty(T, D, device=dev, dtype=torch.float32)
+    ws, ws_bytes = _workspace('relpos_dr', dev, lib.emo_relpos_attn_bwd_r_workspace_bytes(B, T, H, dh))
+    check(lib.emo_relpos_attn_bwd_r(ptr(qu), ptr(qv), D, ptr(k), ptr(v), D3, ptr(r_dist), _rows(r_dist), r_dist.shape[0], ptr(dout), D, ptr(lse),
+                                    ptr(zden), ptr(delta), ptr(dR), D, ptr(ws), ws_bytes, dtype_code(dt), B, T, H, dh, p_drop, seed, offset, stream()))
+    return dqkv, dR, d_rw, d_rr.view(H, dh)
 
 
 def relpos_attn_decode(q, kcache, vcache, lens, H, r_dist, r_w_bias, r_r_bias, mem_len=0, lens_off=0, k_new=None, v_new=None):

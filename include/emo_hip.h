@@ -196,21 +196,28 @@ int emo_relpos_attn_fwd(const void* q, const void* k, const void* v, int64_t ld,
                         void* out, int64_t ld_out, float* lse, float* zden, int dtype, int64_t B,
                         int64_t T, int64_t H, int64_t dh, float p_drop, uint64_t seed,
                         uint64_t offset, emo_stream_t stream);
-/* Backward, first version: recomputes the probabilities per query tile, returns dq_content = ds.K/sqrt(dh) in dq and three dense
- * by-products (dtype of q; must arrive ZEROED, the kernel only writes the causal part):
- *   a_nat  [B,H,T,ld_nat]   final attention weights a_ij             (dV = a^T dO)
- *   ds_nat [B,H,T,ld_nat]   d score_ij / sqrt(dh)                    (dK = ds^T (q + r_w_bias))
- *   ds_skew[H,B,T,nd_skew]  the same values at column i-j            (dR = ds_skew^T (q + r_r_bias), dq_relative = ds_skew R)
- * which the caller turns into dR, dq_relative and the two bias gradients (and, without emo_relpos_attn_bwd_kv, dk / dv) with emo_gemm.
- * a_nat / ds_nat may both be NULL.  delta (may be NULL) [B,H,T] fp32: dO.O per query row, for emo_relpos_attn_bwd_kv. */
+/* Backward, query-tile pass: recomputes the probabilities per query tile and returns dq = dq_content + dq_relative
+ * (dq_content = ds.K/sqrt(dh), dq_relative[i] = sum_j ds_ij R[i-j]/sqrt(dh), both accumulated in-kernel) plus dq_rel = the relative part
+ * alone ([B*T, H*dh], pitch ld_rel, dtype of q): d r_r_bias = colsum(dq_rel), d r_w_bias = colsum(dq) - colsum(dq_rel).
+ * delta (may be NULL) [B,H,T] fp32: dO.O per query row, for emo_relpos_attn_bwd_kv / emo_relpos_attn_bwd_r. */
 int emo_relpos_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* r_dist,
                         int64_t ld_r, int64_t n_dist, const float* r_w_bias, const float* r_r_bias,
                         const void* out, const void* dout, int64_t ld_out, const float* lse,
-                        const float* zden, void* dq, int64_t ld_d, void* a_nat, void* ds_nat,
-                        int64_t ld_nat, void* ds_skew, int64_t nd_skew, float* delta, int dtype, int64_t B,
-                        int64_t T, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint64_t offset,
-                        emo_stream_t stream);
-/* Key-tile pass of the backward: dk, dv in one kernel (then a_nat / ds_nat above may be NULL).  qu = q + r_w_bias, qv = q + r_r_bias
+                        const float* zden, void* dq, int64_t ld_d, void* dq_rel, int64_t ld_rel,
+                        float* delta, int dtype, int64_t B, int64_t T, int64_t H, int64_t dh,
+                        float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream);
+/* Distance-window pass of the backward: dR [T, ld_dr] fp32 (overwritten) = gradient of r_dist rows 0..T-1,
+ * dR[dist][h*dh + d] = sum_{b,i} ds[b,h,i,i-dist] (q_i + r_r_bias)[d] / sqrt(dh).  One workgroup per (b, h, tile diagonal); the partial
+ * windows go through `workspace` (emo_relpos_attn_bwd_r_workspace_bytes) and are summed in a fixed order (deterministic).  qu, qv, delta as
+ * for emo_relpos_attn_bwd_kv.  Replaces the reference's autograd through _rel_shift (optimus_txl_decoder.py:280-293, 331-366). */
+int64_t emo_relpos_attn_bwd_r_workspace_bytes(int64_t B, int64_t T, int64_t H, int64_t dh);
+int emo_relpos_attn_bwd_r(const void* qu, const void* qv, int64_t ld_q, const void* k, const void* v,
+                          int64_t ld, const void* r_dist, int64_t ld_r, int64_t n_dist, const void* dout,
+                          int64_t ld_out, const float* lse, const float* zden, const float* delta,
+                          float* dR, int64_t ld_dr, void* workspace, int64_t workspace_bytes, int dtype,
+                          int64_t B, int64_t T, int64_t H, int64_t dh, float p_drop, uint64_t seed,
+                          uint64_t offset, emo_stream_t stream);
+/* Key-tile pass of the backward: dk, dv in one kernel.  qu = q + r_w_bias, qv = q + r_r_bias
  * [B*T, H*dh] (pitch ld_q) materialised by the caller; delta [B,H,T] = dO.O per query row as exported by emo_relpos_attn_bwd. */
 int emo_relpos_attn_bwd_kv(const void* qu, const void* qv, int64_t ld_q, const void* k, const void* v,
                            int64_t ld, const void* r_dist, int64_t ld_r, int64_t n_dist, const void* dout,
