@@ -73,8 +73,11 @@ __device__ __forceinline__ typename Img<CT>::V reg_perm(const float (&s)[4][4], 
 #define EMO_LN2 0.6931471805599453f
 template <typename CT> struct SaK { static constexpr int NS64 = 64 / Img<CT>::KSTEP; };   // MFMA steps over a 64-wide k range
 
+// Occupancy: the kernels are latency-bound per wave (r02: halving the LDS traffic per flop with 32 query rows per wave made the forward 22 %
+// SLOWER at 2 waves/SIMD, dropping one of the two barriers per key tile changed nothing, while capping the registers at 128 for a fourth
+// wave per SIMD gave +13 %), so the bf16 forward and dQ kernels are bounded to 4 workgroups per CU.
 template <typename CT, int DH>
-__global__ __launch_bounds__(256) void sattn_fwd_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+__global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 4 : 1)) void sattn_fwd_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
                                                         CT* __restrict__ out, int64_t ld_out, float* __restrict__ lse_g, int64_t T, int64_t H,
                                                         DropCtx drop) {
     typedef SaDims<CT, DH> D;
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const CT* __restrict__ q
 // =============================================================================================== backward: dQ (per query tile)
 // Also exports delta[t] = dO[t].O[t] (one value per query row) for the dK/dV pass, which used to recompute it for every (key tile, query tile) pair.
 template <typename CT, int DH>
-__global__ __launch_bounds__(256, 2) void sattn_bwd_dq_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+__global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 4 : 2)) void sattn_bwd_dq_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
                                                            const CT* __restrict__ out, const CT* __restrict__ dout, int64_t ld_out,
                                                            const float* __restrict__ lse_g, float* __restrict__ delta_g, CT* __restrict__ dq, int64_t ld_d,
                                                            int64_t T, int64_t H, DropCtx drop) {
