@@ -180,8 +180,13 @@ __device__ __forceinline__ float seg_sum(const float* __restrict__ ws, int64_t s
 // "state only" launch (SO = true) computes every segment's state increment into S_ws [B*H, P, F, DH] / z_ws [B*H, P, F]; the main
 // launch then starts each segment from the sum of the increments before it.  P = 1 is the plain single-pass scan.
 // SO = true: "state only" pass of the segment-parallel scan (writes the segment's state increment to S_ws / z_ws).
+// bf16 (TRV): TWO workgroups per CU.  A barrier-delimited phase costs about the same latency whatever its size (chunk 32 on two workgroups =
+// chunk 64 on one, 16-wave workgroups are slower), so the way to more throughput is a second, independent scan on the same CU — which needs
+// the images under 80 KB: no transposed copies (K features and V are kept row-major only; the products that contract over the token index
+// read them with ds_read_b64_tr_b16 in the permuted k order, the other operand with two 8-B reads), the A matrix re-uses the q rows and the
+// V rows re-use the k rows (both dead after the feature phase; V goes to LDS one phase later).  79.9 KB + 1.3 KB of vectors.
 template <typename CT, int DH, int MF, int C, bool SO>
-__global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
+__global__ __launch_bounds__(FT, (sizeof(CT) == 2 && C == 64) ? 2 : 1) void favor_fwd_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
                                                         const float* __restrict__ omega, CT* __restrict__ out, int64_t ld_out,
                                                         float* __restrict__ den_g, float* __restrict__ state_S, float* __restrict__ state_z,
                                                         int64_t T, int64_t H, float eps, float* __restrict__ S_ws, float* __restrict__ z_ws,
@@ -189,15 +194,17 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
     typedef FavorDims<CT, DH, MF, C, 0> D;
     constexpr int F = D::F, LDX = D::LDX, LDC = D::LDC, LDF = D::LDF, DHP = D::DHP, CP = D::CP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool TRV = sizeof(CT) == 2 && C == 64;
     CT* WT = (CT*)smem;                 // [MF][LDX]
-    CT* Xq = WT + MF * LDX;             // [C][LDX]
-    CT* Xk = Xq + C * LDX;              // [C][LDX]
-    CT* VT = Xk + C * LDX;              // [DH][LDC]
-    CT* Qf = VT + DH * LDC;             // [C][LDF]
+    CT* Xq = WT + MF * LDX;             // [C][LDX]   TRV: re-used by Am [C][LDC] after the feature phase
+    CT* Xk = Xq + C * CMax<LDX, LDC>::v;   // [C][LDX]   TRV: re-used by the V rows Vr [C][LDX] after the feature phase
+    CT* VT = Xk + C * LDX;              // [DH][LDC]  (not TRV)
+    CT* Vr = Xk;
+    CT* Qf = TRV ? VT : VT + DH * LDC;  // [C][LDF]
     CT* Kf = Qf + C * LDF;              // [C][LDF]
-    CT* KfT = Kf + C * LDF;             // [F][LDC]
-    CT* Am = KfT + F * LDC;             // [C][LDC]
-    CT* ST = Am + C * LDC;              // [DH][LDF]   S^T mirror (k = f)
+    CT* KfT = Kf + C * LDF;             // [F][LDC]   (not TRV)
+    CT* Am = TRV ? Xq : KfT + F * LDC;  // [C][LDC]
+    CT* ST = TRV ? KfT : Am + C * LDC;  // [DH][LDF]   S^T mirror (k = f)
     float* offq = (float*)(ST + DH * LDF);
     float* offk = offq + C;
     float* dens = offk + C;
@@ -223,9 +230,11 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
     // omega^T image, zero state
     zero_img(WT, MF * LDX, tid);
     zero_img(ST, DH * LDF, tid);
-    zero_img(VT, DH * LDC, tid);
-    zero_img(KfT, F * LDC, tid);
-    zero_img(Am, C * LDC, tid);
+    if constexpr (!TRV) {
+        zero_img(VT, DH * LDC, tid);
+        zero_img(KfT, F * LDC, tid);
+        zero_img(Am, C * LDC, tid);
+    }
     for (int i = tid; i < F; i += FT) zz[i] = 0.f;
     __syncthreads();
     for (int i = tid; i < DH * MF; i += FT) { const int d = i / MF, m = i % MF; WT[m * LDX + d] = from_f32<CT>(omega[i]); }
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
         for (int f = tid; f < F; f += FT) zz[f] = seg_sum(z_ws + bh * P * (int64_t)F, F, 0, p_seg, f);
     }
     RowPrefetch<CT, DH, DHP, C, FT> pq, pk;
-    RowPrefetch<CT, DH, DHP, C, FT, true> pv;   // only ever stored transposed
+    RowPrefetch<CT, DH, DHP, C, FT, !TRV> pv;   // not TRV: only ever stored transposed
     if (tbeg < tend) {
         const int v0 = (int)((tend - tbeg) < C ? (tend - tbeg) : C);
         if constexpr (!SO) pq.load(qb + tbeg * ld, ld, v0, tid);
@@ -266,16 +275,20 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
         if constexpr (!SO) pq.store_rows_off(Xq, LDX, tid, offq, cs * cs, half_ln_f);
         pk.store_rows_off(Xk, LDX, tid, offk, cs * cs, half_ln_f);
         }
-        if (!(abl & 2)) pv.store_T(VT, LDC, tid);
-        if (t0 + C < tend) {                       // next chunk's q/k/v stay in flight during this chunk's compute
-            const int vn = (int)((tend - t0 - C) < C ? (tend - t0 - C) : C);
+        if constexpr (!TRV) { if (!(abl & 2)) pv.store_T(VT, LDC, tid); }
+        const bool more = t0 + C < tend;
+        const int vn = more ? (int)((tend - t0 - C) < C ? (tend - t0 - C) : C) : 0;
+        if (more) {                                // next chunk's q/k/v stay in flight during this chunk's compute
             if constexpr (!SO) pq.load(qb + (t0 + C) * ld, ld, vn, tid);
             pk.load(kb + (t0 + C) * ld, ld, vn, tid);
-            pv.load(vb + (t0 + C) * ld, ld, vn, tid);
+            if constexpr (!TRV) pv.load(vb + (t0 + C) * ld, ld, vn, tid);
         }
         __syncthreads();
         if (!(abl & 8)) {
-        if constexpr (!SO) {
+        if constexpr (TRV) {
+            if constexpr (!SO) features_rowmajor<CT, DHP, MF, C>(Qf, LDF, WT, Xq, LDX, offq, cs, C, wave, lane);
+            features_rowmajor<CT, DHP, MF, C>(Kf, LDF, WT, Xk, LDX, offk, cs, valid, wave, lane);
+        } else if constexpr (!SO) {
             features_rowmajor<CT, DHP, MF, C>(Qf, LDF, WT, Xq, LDX, offq, cs, C, wave, lane);
             features_both<CT, DHP, MF, C>(Kf, LDF, KfT, LDC, WT, Xk, LDX, offk, cs, valid, wave, lane);
         } else {
@@ -283,6 +296,11 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
         }
         }
         __syncthreads();
+        if constexpr (TRV) {                       // the k rows are dead: the V rows take their place (read from the out phase on)
+            pv.store_rows(Vr, LDX, tid);
+            if (more) pv.load(vb + (t0 + C) * ld, ld, vn, tid);
+            if constexpr (SO) __syncthreads();
+        }
         if constexpr (!SO) {
         // A[t][j] = Qf[t].Kf[j] masked j<=t : rows<->j (R=Kf), col<->t (C=Qf)
         if (!(abl & 16)) {
@@ -329,14 +347,21 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
             const int tt = wave % (C / 16);
             Frags<CT, CP> amf;
             Frags<CT, F> qff;
-            amf.load(Am, LDC, tt * 16, lane);
+            typename Img<CT>::V amp[2];
+            if constexpr (TRV) { amp[0] = load_perm<CT>(Am, LDC, tt * 16, 0, lane); amp[1] = load_perm<CT>(Am, LDC, tt * 16, 1, lane); }
+            else amf.load(Am, LDC, tt * 16, lane);
             qff.load(Qf, LDF, tt * 16, lane);
             _Pragma("unroll") for (int tile_i = 0; tile_i < (NT + FW - 1) / FW; ++tile_i) {
             const int tile = wave + FW * tile_i;
             if (NT % FW != 0 && tile >= NT) break;
                 const int dt = tile / (C / 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                mm16_c<CT, CP>(acc, VT, LDC, dt * 16, amf, lane);
+                if constexpr (TRV) {
+                    acc = Img<CT>::mma(load_perm_tr((const bf16_t*)Vr, LDX, dt * 16, 0, lane), amp[0], acc);
+                    acc = Img<CT>::mma(load_perm_tr((const bf16_t*)Vr, LDX, dt * 16, 1, lane), amp[1], acc);
+                } else {
+                    mm16_c<CT, CP>(acc, VT, LDC, dt * 16, amf, lane);
+                }
                 mm16_c<CT, F>(acc, ST, LDF, dt * 16, qff, lane);
                 const int t = tt * 16 + (lane & 15), d0 = dt * 16 + (lane >> 4) * 4;
                 if (t < valid) {
@@ -351,13 +376,24 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
         if (!(abl & 128)) {
         static_assert(FW % (DH / 16) == 0, "a wave's state tiles share the d block");
         Frags<CT, CP> vtf;
-        vtf.load(VT, LDC, (wave % (DH / 16)) * 16, lane);
+        typename Img<CT>::V vtr[2];
+        if constexpr (TRV) {
+            vtr[0] = load_perm_tr((const bf16_t*)Vr, LDX, (wave % (DH / 16)) * 16, 0, lane);
+            vtr[1] = load_perm_tr((const bf16_t*)Vr, LDX, (wave % (DH / 16)) * 16, 1, lane);
+        } else {
+            vtf.load(VT, LDC, (wave % (DH / 16)) * 16, lane);
+        }
 #pragma unroll
         for (int i = 0; i < NTS_W; ++i) {
             const int tile = wave + FW * i;
             if (tile < NTS) {
                 const int ft = tile / (DH / 16), dt = tile % (DH / 16);
-                mm16_c<CT, CP>(sacc[i], KfT, LDC, ft * 16, vtf, lane);
+                if constexpr (TRV) {
+                    sacc[i] = Img<CT>::mma(load_perm_tr((const bf16_t*)Kf, LDF, ft * 16, 0, lane), vtr[0], sacc[i]);
+                    sacc[i] = Img<CT>::mma(load_perm_tr((const bf16_t*)Kf, LDF, ft * 16, 1, lane), vtr[1], sacc[i]);
+                } else {
+                    mm16_c<CT, CP>(sacc[i], KfT, LDC, ft * 16, vtf, lane);
+                }
                 if constexpr (!SO) {
                     const int d = dt * 16 + (lane & 15), f0 = ft * 16 + (lane >> 4) * 4;
                     Img<CT>::store4(ST + d * LDF + f0, sacc[i][0], sacc[i][1], sacc[i][2], sacc[i][3]);
@@ -365,7 +401,17 @@ __global__ __launch_bounds__(FT) void favor_fwd_kernel(const CT* __restrict__ q,
             }
         }
         }
-        if constexpr (sizeof(CT) == 2 && C == 64 && 4 * F <= FT) {
+        if constexpr (TRV) {                       // z[f] += column sums of the row-major K features: 4 lanes per f, 16 rows each
+            const int f = tid >> 2, part = tid & 3;
+            if (f < F) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) s += (float)Kf[(part * 16 + j) * LDF + f];
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                if (part == 0) zz[f] += s;
+            }
+        } else if constexpr (sizeof(CT) == 2 && C == 64 && 4 * F <= FT) {
             const int f = tid >> 2, part = tid & 3;
             if (f < F) {
                 float s = sum_contig<CT, 16>(KfT + f * LDC + part * 16);
@@ -1176,7 +1222,9 @@ extern "C" int emo_favor_draw_omega(const float* gauss, float* omega, int64_t n_
 // =============================================================================================== host
 template <typename CT, int DH, int MF, int C> static size_t fwd_lds() {
     typedef FavorDims<CT, DH, MF, C, 0> D;
-    return sizeof(CT) * (size_t)(MF * D::LDX + 2 * C * D::LDX + DH * D::LDC + 2 * C * D::LDF + D::F * D::LDC + C * D::LDC + DH * D::LDF) +
+    if (sizeof(CT) == 2 && C == 64)   // TRV layout (two workgroups per CU)
+        return sizeof(CT) * (size_t)(MF * D::LDX + C * CMax<D::LDX, D::LDC>::v + C * D::LDX + 2 * C * D::LDF + DH * D::LDF) + sizeof(float) * (size_t)(3 * C + D::F);
+    return sizeof(CT) * (size_t)(MF * D::LDX + C * CMax<D::LDX, D::LDC>::v + C * D::LDX + DH * D::LDC + 2 * C * D::LDF + D::F * D::LDC + C * D::LDC + DH * D::LDF) +
            sizeof(float) * (size_t)(3 * C + D::F);
 }
 template <typename CT, int DH, int MF, int C> static size_t dq_lds() {

@@ -75,6 +75,47 @@ __device__ __forceinline__ void mm16_r(f32x4& acc, const Frags<CT, K>& r, const 
     for (int s = 0; s < Frags<CT, K>::NS; ++s) acc = Img<CT>::mma(r.f[s], b.f[s], acc);
 }
 
+// fragment of an LDS image [rows][ld] (k contiguous) in the PERMUTED k order of the score registers: a lane that owns S[j][t] for
+// j = jt*16 + (l>>4)*4 + r (r = 0..3) feeds P straight from registers into the next MFMA if the other operand is read as
+//   bf16: step s (32 k):  e = 0..7  <->  k = (2s + e/4)*16 + (l>>4)*4 + e%4          (two 8-B reads)
+//   f32 : step (jt, r)    <->  k = jt*16 + (l>>4)*4 + r                              (one 4-B read)
+// (the contraction index order is free as long as both operands agree), so the probabilities never go through LDS.
+template <typename CT>
+__device__ __forceinline__ typename Img<CT>::V load_perm(const CT* img, int ld, int row0, int step, int lane) {
+    const CT* p = img + (row0 + (lane & 15)) * ld + (lane >> 4) * 4;
+    if constexpr (sizeof(CT) == 2) {
+        const bf16x4 lo = *(const bf16x4*)(p + (2 * step) * 16), hi = *(const bf16x4*)(p + (2 * step + 1) * 16);
+        return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    } else {
+        return p[(step >> 2) * 16 + (step & 3)];
+    }
+}
+// bf16 only: the same permuted-k fragment of the TRANSPOSE of a row-major image rm[k][ld] (k = row index, operand rows = columns col0..col0+15),
+// fetched with ds_read_b64_tr_b16: per 16-lane group a [4 k][16 columns] block, lane i supplies the address of (row k0 + i/4, columns (i%4)*4..)
+// and receives column i.  Replaces the explicitly transposed V^T / K^T / Q^T / dO^T images (2-byte scattered LDS stores + a second prefetch).
+__device__ __forceinline__ bf16x8 load_perm_tr(const bf16_t* rm, int ld, int col0, int step, int lane) {
+    const int i = lane & 15, kc = lane >> 4;
+    bf16x8 v;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const bf16_t* p = rm + ((2 * step + h) * 16 + kc * 4 + (i >> 2)) * ld + col0 + (i & 3) * 4;
+        const short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
+        const bf16x4 tb = __builtin_bit_cast(bf16x4, t);
+        v[h * 4 + 0] = tb[0]; v[h * 4 + 1] = tb[1]; v[h * 4 + 2] = tb[2]; v[h * 4 + 3] = tb[3];
+    }
+    return v;
+}
+// the matching register operand built from s[jt][r]
+template <typename CT>
+__device__ __forceinline__ typename Img<CT>::V reg_perm(const float (&s)[4][4], int step) {
+    if constexpr (sizeof(CT) == 2) {
+        return (bf16x8){(bf16_t)s[2 * step][0], (bf16_t)s[2 * step][1], (bf16_t)s[2 * step][2], (bf16_t)s[2 * step][3],
+                        (bf16_t)s[2 * step + 1][0], (bf16_t)s[2 * step + 1][1], (bf16_t)s[2 * step + 1][2], (bf16_t)s[2 * step + 1][3]};
+    } else {
+        return s[step >> 2][step & 3];
+    }
+}
+
 template <int A, int B> struct CMax { static constexpr int v = A > B ? A : B; };
 
 // ---- global row tile [rows x NC] -> LDS image [rows][ld] (zero-fill invalid rows and pad columns up to NCP)
