@@ -384,6 +384,7 @@ def main():
     counts = torch.zeros(6, device=dev, dtype=torch.int64)
     loss_acc = torch.zeros((), device=dev)
     state = {'step': 0}
+    exchange = dp.GradExchange(model, ps) if world > 1 else None
 
     def step():
         state['step'] += 1
@@ -392,8 +393,9 @@ def main():
         logits = model(b['dec_input'], seg_inp=b['track_mask'], attn_kwargs={'omit_feature_map_draw': False})
         losses = model.compute_loss(logits, b['dec_target'])
         if world > 1:
+            exchange.arm()                                   # the late layers' all-reduce overlaps the rest of the backward (dp.GradExchange)
             (losses['total_loss'] * b['n_tok']).backward()
-            dp.allreduce_grads_(ps, b['n_tok'])              # ONE collective: flat fp32 gradient + token count (emo_comm_allreduce)
+            exchange.finish(b['n_tok'])                      # flat fp32 gradient + token count in up to 3 pieces (emo_comm_allreduce)
         else:
             losses['total_loss'].backward()
         opt.step()

@@ -21,7 +21,7 @@ import sys
 import torch
 import torch.distributed as dist
 
-_STATE = {'plane': None, 'nccl_group': None}
+_STATE = {'plane': None, 'nccl_group': None, 'bucketed_steps': 0}
 
 
 def env_world():
@@ -131,6 +131,95 @@ def allreduce_grads_(store, n_tokens=None):
     tail.zero_()
     tail[0:1].copy_(torch.as_tensor(n_tokens, dtype=torch.float32).reshape(1))
     allreduce_sum_(store.flat_grad_ext)
+
+
+def _late_layer_range(model, store):
+    """(a, b, split): the flat-buffer element range [a, b) that holds exactly the parameters of decoder layers split .. L-1 (the layers
+    whose gradients are complete first in the backward sweep), or None when the layout does not allow it."""
+    if not hasattr(model, '_layer_prefix') or not hasattr(model, 'n_layer') or model.n_layer < 2:
+        return None
+    L = model.n_layer
+    split = L // 2
+    try:
+        late = tuple(model._layer_prefix(l) for l in range(split, L))
+    except NotImplementedError:
+        return None
+    ends = sorted(store.offsets.values()) + [store.total]
+    nxt = {o: e for o, e in zip(ends[:-1], ends[1:])}                 # offset -> offset of the next parameter (alignment padding included)
+    inside = [n for n in store.offsets if n.startswith(late)]
+    if not inside:
+        return None
+    a, b = min(store.offsets[n] for n in inside), max(nxt[store.offsets[n]] for n in inside)
+    if any(a <= o < b for n, o in store.offsets.items() if not n.startswith(late)):
+        return None                                                   # not contiguous: keep the single exchange
+    return a, b, split
+
+
+class GradExchange:
+    """The gradient exchange of one optimizer step, overlapped with the backward sweep: the gradients of the late
+    decoder layers (L/2 .. L-1, complete half-way through the backward) are all-reduced on a communication stream while the early layers
+    are still being back-propagated; the rest of the flat buffer (embeddings, output projection, early layers, the token-count tail)
+    follows when the backward is done.  All collectives of a step go to ONE stream in the same order on every rank.  Planes without
+    asynchronous collectives (gloo) and models without the layer hook fall back to the single all-reduce of allreduce_grads_.
+    EMO_DP_BUCKETS=0 disables the split, =force enables it on the gloo plane too (tests)."""
+
+    def __init__(self, model, store=None):
+        self.model, self.store = model, store or model._ensure_store()
+        self.range = _late_layer_range(model, self.store)
+        self.stream, self._fired = None, False
+
+    def _enabled(self):
+        mode = os.environ.get('EMO_DP_BUCKETS', '1')
+        return self.range is not None and mode != '0' and (_STATE['plane'] in ('rccl', 'nccl') or (mode == 'force' and _STATE['plane'] is not None))
+
+    def arm(self):
+        """Call before backward() of the micro-step that ends the accumulation window."""
+        self._fired = False
+        if self._enabled():
+            self.model._bwd_hook = self._on_layer
+
+    def _comm(self):
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=self.store.device)
+        return self.stream
+
+    def _on_layer(self, l):
+        if self._fired or l != self.range[2]:
+            return
+        from .engine import join_side_stream
+        join_side_stream()                                            # the weight gradients of layers >= split run on the side stream
+        cs = self._comm()
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
+            allreduce_sum_(self.store.flat_grad_ext[self.range[0]:self.range[1]])
+        self._fired = True
+
+    def finish(self, n_tokens=None):
+        """Call after backward(): exchanges what is left; on return the current stream sees the summed gradients."""
+        self.model._bwd_hook = None
+        if _STATE['plane'] is None:
+            return
+        if not self._fired:
+            allreduce_grads_(self.store, n_tokens)
+            return
+        st = self.store
+        a, b = self.range[0], self.range[1]
+        end = st.total
+        if n_tokens is not None:
+            tail = st.flat_grad_ext[st.total:]
+            tail.zero_()
+            tail[0:1].copy_(torch.as_tensor(n_tokens, dtype=torch.float32).reshape(1))
+            end = st.flat_grad_ext.numel()
+        cs, main = self._comm(), torch.cuda.current_stream()
+        cs.wait_stream(main)
+        with torch.cuda.stream(cs):
+            if a > 0:
+                allreduce_sum_(st.flat_grad_ext[:a])
+            if end > b:
+                allreduce_sum_(st.flat_grad_ext[b:end])
+        main.wait_stream(cs)
+        self._fired = False
+        _STATE['bucketed_steps'] += 1
 
 
 def broadcast_(tensors, src=0):

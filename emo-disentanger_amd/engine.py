@@ -402,6 +402,9 @@ class DecoderStackFn(torch.autograd.Function):
             else:
                 dx = gpt2_block_bwd(ps, model._layer_prefix(l), dx, B, T, H, p, seed, base + 8 * (l + 1), ctx.saves[l])
             ctx.saves[l] = None
+            hook = getattr(model, '_bwd_hook', None)                 # data parallel: dp.GradExchange starts the late layers' all-reduce here
+            if hook is not None:
+                hook(l)
         proj = model.d_embed != D
         if proj:                                                 # gradients of the PROJECTED tables, then back through emb_proj
             dE = torch.zeros(model.n_token, D, device=dx.device)

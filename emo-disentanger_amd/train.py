@@ -82,7 +82,7 @@ def train_model(epoch, model, dloader, optim, sched, pad_token, model_type="perf
     say('[epoch {:03d}] # batches = {}'.format(epoch, len(dloader)))
     st = time.time()
     fused = isinstance(optim, FusedAdam)
-    window_tokens = None
+    window_tokens, exchange = None, None
     for batch_idx, batch_samples in enumerate(dloader):
         if cfg.faithful_accum or (cfg.train_steps % cfg.accum_steps) == 0:
             optim.zero_grad() if fused else model.zero_grad()
@@ -107,6 +107,10 @@ def train_model(epoch, model, dloader, optim, sched, pad_token, model_type="perf
             # the optimizer divides by the all-reduced count => the exact global mean even when ranks hold different numbers of
             # non-pad targets (the reference's loss is a mean over non-pad tokens, music_performer.py:72-76)
             n_tok = (batch_dec_tgt != pad_token).sum().to(torch.float32)
+            if exchange is None:
+                exchange = dp.GradExchange(model)
+            if (train_steps % cfg.accum_steps) == 0:
+                exchange.arm()                                        # the late layers' all-reduce starts inside this backward
             if cfg.faithful_accum or cfg.accum_steps == 1:            # (reference quirk F11: only the window's last micro-batch survives, scaled 1/accum)
                 window_tokens = n_tok
                 (total_loss * n_tok).backward()
@@ -117,7 +121,7 @@ def train_model(epoch, model, dloader, optim, sched, pad_token, model_type="perf
             total_loss.backward()
         if (train_steps % cfg.accum_steps) == 0:
             if cfg.world_size > 1:
-                dp.allreduce_grads_(model._store, window_tokens)     # the one exchange per optimizer step
+                exchange.finish(window_tokens)                       # the one exchange per optimizer step, in up to 3 pieces
             if fused:
                 optim.step()                                         # clip(0.5) + 1/sum(tokens) folded into the fused Adam
             else:

@@ -79,6 +79,8 @@ g = st.flat_grad.clone()
 if world > 1:
     g = g / st.flat_grad_ext[st.total]
     assert float(st.flat_grad_ext[st.total]) == float(int((full["dec_target"] != V - 1).sum()))
+if world > 1:
+    assert dp._STATE['bucketed_steps'] == (1 if os.environ.get("EMO_DP_BUCKETS") == "force" else 0)     # late-layer bucket + rest, or one all-reduce
 np.savez(os.environ["EMO_OUT"] + ".rank%d.npz" % rank, grad=g.cpu().numpy(), before=p0.cpu().numpy(), after=st.flat32.cpu().numpy(), n_tok=n_tok, loss=loss)
 dp.barrier()
 dp.shutdown()
@@ -136,14 +138,17 @@ def test_emo_comm_c_abi_single_rank():
     assert r.returncode == 0 and 'emo_comm ok' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
-def test_two_rank_training_step_equals_one_rank_on_concatenated_batch(tmp_path):
+@pytest.mark.parametrize('buckets', ['1', 'force'])
+def test_two_rank_training_step_equals_one_rank_on_concatenated_batch(tmp_path, buckets):
+    # buckets = force: dp.GradExchange splits the exchange (late layers' gradients during the backward, the rest after it) on the gloo plane too
     out1, out2 = str(tmp_path / 'w1'), str(tmp_path / 'w2')
     r = subprocess.run([sys.executable, '-c', STEP_SCRIPT], env=_env(EMO_OUT=out1, WORLD_SIZE=1, RANK=0, LOCAL_RANK=0), capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, '-c', STEP_SCRIPT], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
-                              env=_env(EMO_OUT=out2, WORLD_SIZE=2, RANK=rk, LOCAL_RANK=0, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, EMO_COMM='gloo'))
+                              env=_env(EMO_OUT=out2, WORLD_SIZE=2, RANK=rk, LOCAL_RANK=0, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, EMO_COMM='gloo',
+                                       EMO_DP_BUCKETS=buckets))
              for rk in range(2)]
     logs = [p.communicate(timeout=900)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), '\n'.join(l[-3000:] for l in logs)
