@@ -117,6 +117,30 @@ __device__ __forceinline__ void drop_mult4(const DropCtx& d, uint64_t idx0, floa
     m[3] = (h2 >> 16) >= d.thr16 ? d.scale : 0.f;
 }
 
+// Key-stationary layout (attention dK/dV passes): a lane owns ONE key column j and 4 query rows t0 .. t0+3, so its four elements are T apart
+// and drop_mult4 does not apply — but the 4 lanes of a quad own keys 4q .. 4q+3 of the SAME rows, i.e. the four 16-bit fields of one hash
+// per row.  Lane c of the quad hashes row t0 + c and the words travel by DPP quad broadcasts: 1 hash per lane per 4 rows instead of 4 (the
+// per-element hashes made the GPT-2 dK/dV kernel 2.8x the dQ kernel).  idx_own = linear index of (row t0 + (lane & 3), key j & ~3); it must
+// be a multiple of 4 (T % 4 == 0 and j & 3 == lane & 3).  Bit-identical to drop_mult().
+template <int R> __device__ __forceinline__ uint32_t emo_quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, R * 0x55, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void drop_mult_col4(const DropCtx& d, uint64_t idx_own, int lane, float (&m)[4]) {
+    const uint32_t quad = (uint32_t)(idx_own >> 2) ^ (uint32_t)(idx_own >> 34) * 0x9E3779B1u;
+    const uint32_t h = emo_drop_hash(d, quad), h2 = emo_xs32(h);
+    const bool hi_word = lane & 2, hi_half = lane & 1;
+    // (all eight broadcasts are executed by every lane BEFORE the per-lane selects: a `cond ? bcast(a) : bcast(b)` would put the DPP moves
+    // under divergent EXEC masks, where a disabled source lane reads as 0)
+    const uint32_t a0 = emo_quad_bcast<0>(h), a1 = emo_quad_bcast<1>(h), a2 = emo_quad_bcast<2>(h), a3 = emo_quad_bcast<3>(h);
+    const uint32_t b0 = emo_quad_bcast<0>(h2), b1 = emo_quad_bcast<1>(h2), b2 = emo_quad_bcast<2>(h2), b3 = emo_quad_bcast<3>(h2);
+    const uint32_t w0 = hi_word ? b0 : a0, w1 = hi_word ? b1 : a1, w2 = hi_word ? b2 : a2, w3 = hi_word ? b3 : a3;
+    const uint32_t sh = hi_half ? 16u : 0u;
+    m[0] = ((w0 >> sh) & 0xFFFFu) >= d.thr16 ? d.scale : 0.f;
+    m[1] = ((w1 >> sh) & 0xFFFFu) >= d.thr16 ? d.scale : 0.f;
+    m[2] = ((w2 >> sh) & 0xFFFFu) >= d.thr16 ? d.scale : 0.f;
+    m[3] = ((w3 >> sh) & 0xFFFFu) >= d.thr16 ? d.scale : 0.f;
+}
+
 // ---------------------------------------------------------------- wave / block reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

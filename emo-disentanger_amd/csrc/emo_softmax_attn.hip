@@ -346,13 +346,16 @@ __global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 2 : 1)) void sattn_bwd_dkv_
                     dp = Img<CT>::mma(Img<CT>::load(dOi, LDX, tt * 16, kk * Img<CT>::KSTEP, lane), vf[kk], dp);
                 }
             }
+            float dm[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop.thr16 && (T & 3) == 0)                  // one hash per lane for the 4 rows (shared inside the key quad)
+                drop_mult_col4(drop, (uint64_t)((bh * T + q0 + tt * 16 + (lane >> 4) * 4 + (lane & 3)) * T + (jg & ~(int64_t)3)), lane, dm);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int tl = tt * 16 + (lane >> 4) * 4 + r;
                 const int64_t tg = q0 + tl;
-                float p = sizeof(CT) == 2 ? __builtin_amdgcn_exp2f(sa[r] * c2 - Lv[tl]) : Img<CT>::ex(sa[r] / sqrt_dh - Lv[tl]), mult = 1.f;
+                float p = sizeof(CT) == 2 ? __builtin_amdgcn_exp2f(sa[r] * c2 - Lv[tl]) : Img<CT>::ex(sa[r] / sqrt_dh - Lv[tl]), mult = dm[r];
                 if (diag && jl > tl) p = 0.f;            // causal boundary only on the diagonal tile (rows past the end carry lse = +inf)
-                if (drop.thr16) mult = drop_mult(drop, (uint64_t)((bh * T + tg) * T + jg));
+                if (drop.thr16 && (T & 3) != 0) mult = drop_mult(drop, (uint64_t)((bh * T + tg) * T + jg));
                 pd[tt][r] = p * mult;
                 ds[tt][r] = p * (dp[r] * mult - Dv[tl]);
             }
@@ -1129,6 +1132,9 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dkv_kernel(
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            float dm[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop.thr16 && (T & 3) == 0)
+                drop_mult_col4(drop, (uint64_t)((bh * T + q0 + tt * 16 + (lane >> 4) * 4 + (lane & 3)) * T + (jg & ~(int64_t)3)), lane, dm);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int tq = (lane >> 4) * 4 + r;           // query row inside the sub-tile
@@ -1136,9 +1142,9 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dkv_kernel(
                 const int64_t tg = q0 + tl;
                 const float bd = live ? skw[tq * SKW + tq - (lane & 15) + 15] : 0.f;
                 const float sc = sa[r] + bd;
-                float p = sizeof(CT) == 2 ? __builtin_amdgcn_exp2f(sc * c2 - Lv[tl]) : Img<CT>::ex(sc / sqrt_dh - Lv[tl]), mult = 1.f;
+                float p = sizeof(CT) == 2 ? __builtin_amdgcn_exp2f(sc * c2 - Lv[tl]) : Img<CT>::ex(sc / sqrt_dh - Lv[tl]), mult = dm[r];
                 if (diag && jl > tl) p = 0.f;
-                if (drop.thr16) mult = drop_mult(drop, (uint64_t)((bh * T + tg) * T + jg));
+                if (drop.thr16 && (T & 3) != 0) mult = drop_mult(drop, (uint64_t)((bh * T + tg) * T + jg));
                 const float zi = Zv[tl], r1 = Dv[tl];
                 pd[tt][r] = p * mult * zi;
                 ds[tt][r] = p * (mult * (dp[r] - r1) * zi - 1e-8f * r1 * zi);
