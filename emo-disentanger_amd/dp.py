@@ -179,18 +179,25 @@ class GradExchange:
             self.model._bwd_hook = self._on_layer
 
     def _comm(self):
-        if self.stream is None:
+        """The communication stream (None for host buffers: the gloo collectives are synchronous there)."""
+        if self.stream is None and torch.device(self.store.device).type == 'cuda':
             self.stream = torch.cuda.Stream(device=self.store.device)
         return self.stream
+
+    @staticmethod
+    def _on(cs):
+        import contextlib
+        return torch.cuda.stream(cs) if cs is not None else contextlib.nullcontext()
 
     def _on_layer(self, l):
         if self._fired or l != self.range[2]:
             return
-        from .engine import join_side_stream
-        join_side_stream()                                            # the weight gradients of layers >= split run on the side stream
         cs = self._comm()
-        cs.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(cs):
+        if cs is not None:
+            from .engine import join_side_stream
+            join_side_stream()                                        # the weight gradients of layers >= split run on the side stream
+            cs.wait_stream(torch.cuda.current_stream())
+        with self._on(cs):
             allreduce_sum_(self.store.flat_grad_ext[self.range[0]:self.range[1]])
         self._fired = True
 
@@ -210,14 +217,16 @@ class GradExchange:
             tail.zero_()
             tail[0:1].copy_(torch.as_tensor(n_tokens, dtype=torch.float32).reshape(1))
             end = st.flat_grad_ext.numel()
-        cs, main = self._comm(), torch.cuda.current_stream()
-        cs.wait_stream(main)
-        with torch.cuda.stream(cs):
+        cs = self._comm()
+        if cs is not None:
+            cs.wait_stream(torch.cuda.current_stream())
+        with self._on(cs):
             if a > 0:
                 allreduce_sum_(st.flat_grad_ext[:a])
             if end > b:
                 allreduce_sum_(st.flat_grad_ext[b:end])
-        main.wait_stream(cs)
+        if cs is not None:
+            torch.cuda.current_stream().wait_stream(cs)
         self._fired = False
         _STATE['bucketed_steps'] += 1
 

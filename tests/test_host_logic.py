@@ -84,6 +84,38 @@ def _dp_worker(rank, world, port, q):
     assert float(_Store.flat_grad_ext[8]) == 8.0 and float(_Store.flat_grad_ext[9:].abs().sum()) == 0.0
     assert torch.allclose(_Store.flat_grad / _Store.flat_grad_ext[8], torch.full((8,), (3.0 * 1.0 + 5.0 * 3.0) / 8.0))
     assert dp.data_plane() == 'gloo'
+    # the overlapped exchange (dp.GradExchange): the late layers' contiguous range goes first, from the backward hook; the rest + the
+    # token-count tail after the backward.  Flat layout like ParamStore's: emb | out-proj | layer 0..3 | segemb, 8-element aligned.
+    class _Model:
+        n_layer = 4
+        _bwd_hook = None
+        def _layer_prefix(self, l):
+            return 'dec.%d.' % l
+    class _Store2:
+        device = 'cpu'
+        offsets = {'emb.w': 0, 'out.w': 16, 'dec.0.a': 24, 'dec.0.b': 32, 'dec.1.a': 40, 'dec.2.a': 56, 'dec.2.b': 64, 'dec.3.a': 72, 'seg.w': 88}
+        total = 96
+        flat_grad_ext = torch.zeros(104)
+        flat_grad = flat_grad_ext[:96]
+    os.environ['EMO_DP_BUCKETS'] = 'force'
+    m2 = _Model()
+    ex = dp.GradExchange(m2, _Store2)
+    assert ex.range == (56, 88, 2)                              # layers 2..3
+    _Store2.flat_grad.copy_(torch.arange(96.) * (rank + 1))
+    ex.arm()
+    assert m2._bwd_hook is not None
+    m2._bwd_hook(3)                                             # nothing yet: layer 3 done, layer 2 still running
+    assert float(_Store2.flat_grad[60]) == 60.0 * (rank + 1)
+    m2._bwd_hook(2)                                             # layers 2..3 complete: their range is summed now, the rest is untouched
+    assert float(_Store2.flat_grad[60]) == 60.0 * 3 and float(_Store2.flat_grad[10]) == 10.0 * (rank + 1) and float(_Store2.flat_grad[90]) == 90.0 * (rank + 1)
+    ex.finish(torch.tensor(n_tok))
+    assert m2._bwd_hook is None and torch.equal(_Store2.flat_grad, torch.arange(96.) * 3) and float(_Store2.flat_grad_ext[96]) == 8.0
+    _Store2.flat_grad.copy_(torch.arange(96.) * (rank + 1))    # a step whose hook never fires (stage-1 model): one all-reduce in finish()
+    ex.arm()
+    ex.finish(torch.tensor(n_tok))
+    assert torch.equal(_Store2.flat_grad, torch.arange(96.) * 3) and float(_Store2.flat_grad_ext[96]) == 8.0
+    _Store2.offsets['stray'] = 60                               # a foreign parameter inside the range: no split
+    assert dp.GradExchange(m2, _Store2).range is None
     q.put((rank, mine.numpy().copy(), flat.numpy().copy(), params.numpy().copy(), mx))   # by value (tensor FD passing races the exit)
     dp.barrier()
     dp.shutdown()
