@@ -301,21 +301,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
     const bf16_t one_b = (bf16_t)1.f;
     const bf16x8 ones = {one_b, one_b, one_b, one_b, one_b, one_b, one_b, one_b};
 
-    bf16x8 ra[BKT / 16], rb[BKT / 16];
-    gload_tile<A_KC, BKT>(A, lda, m0, M, kbeg, kend, tid, ra);
-    gload_tile<B_KC, BKT>(B, ldb, n0, N, kbeg, kend, tid, rb);
-    lstore_tile<A_KC, BKT>(smem, tid, ra);
-    lstore_tile<B_KC, BKT>(smem + OPB, tid, rb);
-    __syncthreads();
-    int cur = 0;
+    // Two K tiles are in flight in registers (r02: with ONE, every K step ended in `s_waitcnt vmcnt(0)` on loads issued at its own start —
+    // PMC: MFMA pipe 32 % busy, LDS 32 %, no bank conflicts, waves waiting 37 % of their cycles): tile t+2 is requested at the start of
+    // step t, tile t+1 (requested a whole step earlier) goes to the other LDS buffer at the end of step t.  The loop is unrolled by two so
+    // that both register sets and both LDS buffers are addressed statically.
+    bf16x8 ra0[BKT / 16], rb0[BKT / 16], ra1[BKT / 16], rb1[BKT / 16];
     int rs_n = (int)((kbeg / BKT) % tiles_n), rs_m = (int)((kbeg / BKT) % tiles_m);   // which block of the tile row / column owns this K step's rowsum
-    for (int64_t k0 = kbeg; k0 < kend; k0 += BKT) {
-        const bool more = (k0 + BKT) < kend;
-        if (more) {
-            gload_tile<A_KC, BKT>(A, lda, m0, M, k0 + BKT, kend, tid, ra);
-            gload_tile<B_KC, BKT>(B, ldb, n0, N, k0 + BKT, kend, tid, rb);
-        }
-        const char* la = smem + cur * 2 * OPB;
+    auto compute = [&](const char* la) {
         const char* lb = la + OPB;
 #pragma unroll
         for (int ks = 0; ks < BKT / 32; ++ks) {
@@ -347,16 +339,43 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
                 }
             }
         }
-        if (more) {
-            char* na = smem + (cur ^ 1) * 2 * OPB;
-            lstore_tile<A_KC, BKT>(na, tid, ra);
-            lstore_tile<B_KC, BKT>(na + OPB, tid, rb);
-        }
-        __syncthreads();
-        cur ^= 1;
         if (++rs_n == (int)tiles_n) rs_n = 0;
         if (++rs_m == (int)tiles_m) rs_m = 0;
+    };
+    char* const s0 = smem;
+    char* const s1 = smem + 2 * OPB;
+    gload_tile<A_KC, BKT>(A, lda, m0, M, kbeg, kend, tid, ra0);
+    gload_tile<B_KC, BKT>(B, ldb, n0, N, kbeg, kend, tid, rb0);
+    lstore_tile<A_KC, BKT>(s0, tid, ra0);
+    lstore_tile<B_KC, BKT>(s0 + OPB, tid, rb0);
+    if (kbeg + BKT < kend) {
+        gload_tile<A_KC, BKT>(A, lda, m0, M, kbeg + BKT, kend, tid, ra1);
+        gload_tile<B_KC, BKT>(B, ldb, n0, N, kbeg + BKT, kend, tid, rb1);
     }
+    __syncthreads();
+    for (int64_t k0 = kbeg; k0 < kend; k0 += 2 * BKT) {
+        // step t: LDS buffer 0 is current, register set 1 holds tile t+1
+        if (k0 + 2 * BKT < kend) {
+            gload_tile<A_KC, BKT>(A, lda, m0, M, k0 + 2 * BKT, kend, tid, ra0);
+            gload_tile<B_KC, BKT>(B, ldb, n0, N, k0 + 2 * BKT, kend, tid, rb0);
+        }
+        compute(s0);
+        if (k0 + BKT >= kend) break;
+        lstore_tile<A_KC, BKT>(s1, tid, ra1);
+        lstore_tile<B_KC, BKT>(s1 + OPB, tid, rb1);
+        __syncthreads();
+        // step t+1: LDS buffer 1 is current, register set 0 holds tile t+2
+        if (k0 + 3 * BKT < kend) {
+            gload_tile<A_KC, BKT>(A, lda, m0, M, k0 + 3 * BKT, kend, tid, ra1);
+            gload_tile<B_KC, BKT>(B, ldb, n0, N, k0 + 3 * BKT, kend, tid, rb1);
+        }
+        compute(s1);
+        if (k0 + 2 * BKT >= kend) break;
+        lstore_tile<A_KC, BKT>(s0, tid, ra0);
+        lstore_tile<B_KC, BKT>(s0 + OPB, tid, rb0);
+        __syncthreads();
+    }
+    __syncthreads();                                   // the epilogue stages through the same LDS
     if (do_rs && (lane >> 4) == 0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
