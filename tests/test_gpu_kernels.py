@@ -290,7 +290,8 @@ def test_relpos_attention_fwd_and_decode(dt, B, T, H, dh):
 
 
 @pytest.mark.parametrize('dt', DT)
-@pytest.mark.parametrize('B,T,H,dh', [(2, 150, 2, 64), (1, 70, 3, 32), (2, 33, 2, 16), (1, 128, 1, 64), (1, 330, 2, 64), (3, 64, 1, 32)])
+@pytest.mark.parametrize('B,T,H,dh', [(2, 150, 2, 64), (1, 70, 3, 32), (2, 33, 2, 16), (1, 128, 1, 64), (1, 330, 2, 64), (3, 64, 1, 32),
+                                      (1, 2400, 1, 64)])     # the last one: tgt_len of the stage-1 YAMLs (38 tiles, 38 diagonals)
 def test_relpos_attention_backward(dt, B, T, H, dh):
     ops = _ops()
     HD = H * dh
