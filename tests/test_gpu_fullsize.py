@@ -1,0 +1,62 @@
+"""GPU: size-independent properties at BASELINE configs[1]'s FULL size (B = 64 sequences x T = 2048: the kernel instances, tile counts and
+grid sizes that bench.py times — A-stationary GEMMs, bit-mask FFN dgrad, one-segment FAVOR+ scans — none of which a B = 1 run reaches).
+The oracle cannot run this size in a test; the properties tie it to the B = 1 run that IS checked against the oracle
+(tests/test_gpu_model.py::test_performer_at_benchmark_shape_matches_oracle):
+  * batch independence — a sequence's logits inside the full batch equal its logits when it is run alone;
+  * causality — changing tokens from position t0 on leaves every logit before t0 bit-identical;
+  * gradients — with every target outside one sequence set to the pad id, loss and parameter gradients of the full batch equal those of
+    that sequence alone (the mean runs over non-pad targets), while every backward kernel still runs at the full size."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SHAPE = dict(V=327, L=12, H=8, d=512, dff=2048, nf=128, B=64, T=2048)
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+def test_full_size_batch_properties(dtype):
+    from emo_disentanger_amd.model.music_performer import MusicPerformer
+    from oracle.weights import make_state_dict, synthetic_batch
+    c = SHAPE
+    V, B, T, pad = c['V'], c['B'], c['T'], c['V'] - 1
+    sd = make_state_dict('performer', V, c['L'], c['H'], c['d'], c['dff'], favor_feature_dims=c['nf'], seed=0, scale=2.5)
+    m = MusicPerformer(V, c['L'], c['H'], c['d'], c['dff'], c['d'], dropout=0.0, favor_feature_dims=c['nf'], use_segment_emb=True, n_segment_types=2,
+                       compute_dtype=dtype, redraw='fixed')
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    b = synthetic_batch(V, B, T, seed=4321)
+    x, seg, tgt = b['dec_input'].cuda(), b['track_mask'].cuda(), b['dec_target'].cuda()
+    pick, t0 = 7, 1500
+    lt, gt_ = (5e-2, 0.2) if dtype == 'bf16' else (5e-4, 2e-3)
+    # ---- gradients: only sequence `pick` carries targets
+    tgt_one = torch.full_like(tgt, pad)
+    tgt_one[pick] = tgt[pick]
+    logits = m(x, seg_inp=seg)
+    loss = m.compute_loss(logits, tgt_one)['total_loss']
+    loss.backward()
+    g_full = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    full = logits.detach()
+    m.zero_grad()
+    l1 = m(x[pick:pick + 1], seg_inp=seg[pick:pick + 1])
+    loss1 = m.compute_loss(l1, tgt[pick:pick + 1])['total_loss']
+    loss1.backward()
+    # ---- batch independence
+    assert float((full[pick] - l1.detach()[0]).abs().max()) <= lt
+    assert abs(float(loss.detach()) - float(loss1.detach())) <= (6e-4 if dtype == 'bf16' else 1e-4)
+    gmax = max(float(p.grad.abs().max()) for p in m.parameters())
+    for k, p in m.named_parameters():
+        d = g_full[k] - p.grad
+        if dtype == 'fp32':
+            assert float(d.abs().max()) <= gt_ * gmax, k
+        else:
+            assert float(d.norm()) <= gt_ * max(float(p.grad.norm()), 0.02 * gmax * p.grad.numel() ** 0.5), k
+    # ---- causality (evaluation of the same weights; no gradients needed)
+    with torch.no_grad():
+        x2 = x.clone()
+        for s in (3, 40):
+            x2[s, t0:] = (x2[s, t0:] + 1 + s) % (V - 1)
+        other = m(x2, seg_inp=seg)
+    assert torch.equal(other[:, :t0], full[:, :t0])
+    assert not torch.equal(other[3, t0:], full[3, t0:]) and torch.equal(other[5], full[5])
+    assert np.isfinite(float(full.abs().max()))
