@@ -14,21 +14,25 @@ pytestmark = pytest.mark.gpu
 SHAPE = dict(V=327, L=12, H=8, d=512, dff=2048, nf=128, B=64, T=2048)
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
-def test_full_size_batch_properties(dtype):
+@pytest.mark.parametrize('kind,dtype', [('performer', 'bf16'), ('performer', 'fp32'), ('gpt2', 'bf16'), ('gpt2', 'fp32')])
+def test_full_size_batch_properties(kind, dtype):
+    from emo_disentanger_amd.model.music_gpt2 import MusicGPT2
     from emo_disentanger_amd.model.music_performer import MusicPerformer
     from oracle.weights import make_state_dict, synthetic_batch
     c = SHAPE
-    V, B, T, pad = c['V'], c['B'], c['T'], c['V'] - 1
-    sd = make_state_dict('performer', V, c['L'], c['H'], c['d'], c['dff'], favor_feature_dims=c['nf'], seed=0, scale=2.5)
-    m = MusicPerformer(V, c['L'], c['H'], c['d'], c['dff'], c['d'], dropout=0.0, favor_feature_dims=c['nf'], use_segment_emb=True, n_segment_types=2,
-                       compute_dtype=dtype, redraw='fixed')
+    V, B, T, pad = c['V'], (c['B'] if kind == 'performer' else 16), c['T'], c['V'] - 1      # GPT-2: the B = 16 of the bench's `gpt2` object
+    sd = make_state_dict(kind, V, c['L'], c['H'], c['d'], c['dff'], favor_feature_dims=c['nf'], seed=0, scale=2.5)
+    kw = dict(dropout=0.0, use_segment_emb=True, n_segment_types=2, compute_dtype=dtype)
+    m = (MusicPerformer(V, c['L'], c['H'], c['d'], c['dff'], c['d'], favor_feature_dims=c['nf'], redraw='fixed', **kw) if kind == 'performer'
+         else MusicGPT2(V, c['L'], c['H'], c['d'], c['dff'], c['d'], **kw))
     m.load_state_dict(sd)
     m = m.cuda().train()
     b = synthetic_batch(V, B, T, seed=4321)
     x, seg, tgt = b['dec_input'].cuda(), b['track_mask'].cuda(), b['dec_target'].cuda()
     pick, t0 = 7, 1500
     lt, gt_ = (5e-2, 0.2) if dtype == 'bf16' else (5e-4, 2e-3)
+    if (kind, dtype) == ('gpt2', 'bf16'):
+        lt = 0.3          # softmax attention at this weight scale amplifies the bf16 rounding differences between the two kernel sets (logits up to ~12; measured 0.16); the fp32 case pins the structure
     # ---- gradients: only sequence `pick` carries targets
     tgt_one = torch.full_like(tgt, pad)
     tgt_one[pick] = tgt[pick]
@@ -54,7 +58,7 @@ def test_full_size_batch_properties(dtype):
     # ---- causality (evaluation of the same weights; no gradients needed)
     with torch.no_grad():
         x2 = x.clone()
-        for s in (3, 40):
+        for s in (3, B - 2):
             x2[s, t0:] = (x2[s, t0:] + 1 + s) % (V - 1)
         other = m(x2, seg_inp=seg)
     assert torch.equal(other[:, :t0], full[:, :t0])
