@@ -7,7 +7,7 @@
 // Chunked prefix-sum evaluation (chunk C tokens): the intra-chunk part is a masked C x C product,
 // the inter-chunk part goes through the running state, which lives in MFMA accumulators (fp32
 // registers) for the whole scan and is mirrored to LDS once per chunk as an MFMA operand.
-// One workgroup (4 waves) per (b,h); every contraction is an "NT" product of two LDS images
+// One workgroup (8 waves) per (b,h); every contraction is an "NT" product of two LDS images
 // whose reduction index is contiguous, so fragments are single ds_read_b128 (bf16) / ds_read_b32
 // (exact-f32 mode on v_mfma_f32_16x16x4_f32).  Image row strides are padded (+16 B) so that the
 // 16 rows of a fragment read hit distinct bank groups.
@@ -18,8 +18,8 @@
 
 #include "emo_lds_mma.h"
 
-// 8 waves per workgroup (one workgroup per (b,h), ~120-155 KB LDS => 1 workgroup per CU): two waves per SIMD so that
-// one wave's LDS / exp / global phases overlap the other's MFMAs.
+// 8 waves per workgroup, one workgroup per (b, h, time segment).  Backward kernels: 120-155 KB of LDS => one workgroup per CU (two waves
+// per SIMD); bf16 forward: 81 KB => two workgroups per CU (see favor_fwd_kernel).
 constexpr int FT = 512, FW = FT / 64;
 // bf16 chunk sizes (tokens per scan step) of the forward / dq / dk,dv kernels at d_head 64, 128 features
 #ifndef FAVOR_CFB
