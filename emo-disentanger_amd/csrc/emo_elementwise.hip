@@ -921,7 +921,7 @@ extern "C" int emo_sumsq(const float* x, int64_t n, float* acc, emo_stream_t str
     return EMO_OK;
 }
 __global__ void clip_coef_kernel(const float* sumsq, float max_norm, float pre, const float* denom, float* coef) {
-    if (denom) pre = pre / denom[0];
+    if (denom) pre = denom[0] > 0.f ? pre / denom[0] : 0.f;   // no non-pad target on any rank: the summed gradient is exactly zero, keep it so
     const float total = sqrtf(sumsq[0]) * pre;            // norm of the (pre-scaled) gradient
     float c = max_norm / (total + 1e-6f);                 // torch.nn.utils.clip_grad_norm_
     coef[0] = (c < 1.f ? c : 1.f) * pre;

@@ -34,28 +34,38 @@ def data_plane():
 
 
 def _init_rccl(rank, world):
+    """Two steps, so that a rank that cannot even bind RCCL never leaves the others blocked inside ncclCommInitRank:
+    (1) LOCAL — every rank dlopen()s RCCL and resolves its symbols (emo_comm_unique_id does both; the id a non-zero rank draws is
+    thrown away) and the ranks agree on the outcome over the gloo control plane; (2) only if ALL ranks could bind: rank 0's id is
+    shipped and the collective ncclCommInitRank + a probe all-reduce run.  Raises the same exception on every rank."""
     from ._lib import I64, check, lib
-    msg = torch.zeros(129, dtype=torch.uint8)                         # 128-byte unique id + "rank 0 could create it"
+    buf = (ctypes.c_char * 128)()
+    bound = lib.emo_comm_unique_id(buf) == 0
+    ok = torch.tensor([1 if bound else 0])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)                         # control plane (gloo, host memory)
+    if int(ok) == 0:
+        raise RuntimeError('RCCL could not be bound on every rank (rank %d: %s)' % (rank, 'ok' if bound else lib.emo_last_error().decode()))
+    msg = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
-        buf = (ctypes.c_char * 128)()
-        if lib.emo_comm_unique_id(buf) == 0:
-            msg[:128] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
-            msg[128] = 1
-    dist.broadcast(msg, src=0)                                        # control plane (gloo, host memory)
-    if int(msg[128]) != 1:
-        raise RuntimeError('rank 0 could not create the RCCL unique id: ' + lib.emo_last_error().decode())
+        msg[:] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+    dist.broadcast(msg, src=0)
     torch.empty(1, device='cuda')                                     # the HIP context of this thread is on the rank's device before RCCL binds it
     torch.cuda.synchronize()
-    check(lib.emo_comm_init(ctypes.c_char_p(bytes(msg[:128].numpy().tobytes())), rank, world))
+    check(lib.emo_comm_init(ctypes.c_char_p(bytes(msg.numpy().tobytes())), rank, world))
     probe = torch.full((4,), rank + 1, device='cuda', dtype=torch.int64)
     check(lib.emo_comm_allreduce(probe.data_ptr(), 4, I64, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()                                          # an asynchronous RCCL error surfaces here, not as a wrong sum
     if int(probe[0].item()) != world * (world + 1) // 2:
         raise RuntimeError('emo_comm self-check failed: all-reduce of rank+1 gave %d for world %d' % (int(probe[0]), world))
 
 
-def init_distributed(backend=None):
+def init_distributed(backend=None, strict=None):
     """Idempotent; reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract).  `backend` (or EMO_COMM /
-    EMO_DIST_BACKEND) picks the data plane; the control plane is always gloo."""
+    EMO_DIST_BACKEND) picks the data plane; the control plane is always gloo.  strict (or EMO_COMM_STRICT=1): no fall-back from the
+    C-ABI RCCL plane to torch.distributed's binding — the failure is raised (bench.py: a run that lands on another plane would not be
+    measuring emo_comm_*)."""
+    if strict is None:
+        strict = os.environ.get('EMO_COMM_STRICT', '0') == '1'
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -70,6 +80,8 @@ def init_distributed(backend=None):
             try:
                 _init_rccl(rank, world)
             except Exception as e:   # noqa: BLE001 — stay up on the torch binding of the same RCCL rather than lose the run
+                if strict:
+                    raise
                 print('[emo dp] rank %d: direct RCCL binding failed (%s); falling back to torch.distributed nccl' % (rank, e), file=sys.stderr, flush=True)
                 plane = 'nccl'
             ok = torch.tensor([1 if plane == 'rccl' else 0])
@@ -124,6 +136,7 @@ def allreduce_grads_(store, n_tokens=None):
     rank's non-pad target count, carried in the buffer's tail slot so that ONE collective moves both (token-weighted mean)."""
     if _STATE['plane'] is None:
         return
+    store.tail_tokens = n_tokens is not None                          # FusedAdam.step checks this against its token_weighted mode
     if n_tokens is None:
         allreduce_sum_(store.flat_grad)
         return
@@ -210,6 +223,7 @@ class GradExchange:
             allreduce_grads_(self.store, n_tokens)
             return
         st = self.store
+        st.tail_tokens = n_tokens is not None
         a, b = self.range[0], self.range[1]
         end = st.total
         if n_tokens is not None:

@@ -42,6 +42,13 @@ class FusedAdam(torch.optim.Optimizer):
         join_side_stream()
         g = self.param_groups[0]
         weighted = self.token_weighted and self.world_size > 1
+        if self.world_size > 1:
+            # the exchange (dp.allreduce_grads_ / GradExchange.finish) records whether the tail slot carries the all-reduced token
+            # count; dividing a token-SUM gradient by the world size, or a mean gradient by an empty tail slot, must not pass silently
+            tail = getattr(ps, 'tail_tokens', None)
+            if tail is not None and tail != self.token_weighted:
+                raise RuntimeError('FusedAdam(token_weighted=%s) but the gradient exchange %s the token count in the tail slot'
+                                   % (self.token_weighted, 'carried' if tail else 'did not carry'))
         pre = 1.0 if weighted else 1.0 / self.world_size
         ops.sumsq(ps.flat_grad, self._ss)
         ops.clip_coef(self._ss, float(self.max_grad_norm) if self.max_grad_norm else 3.0e38, pre, self._coef,

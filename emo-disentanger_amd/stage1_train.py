@@ -74,9 +74,24 @@ def setup_data_parallel(model):
     return rank, world
 
 
-def _segments(batch, dev):
-    """The dataloader packs a piece as n_seg segments: dec_inp_i / dec_tgt_i [B, T] (time-major on the device), dec_seg_len_i, masks."""
-    for i in range(max(batch['n_seg'])):
+def _n_segments(batch, synced=False):
+    """Segments of this batch.  The collate sets n_seg to the max over the batch's samples (stage1_compose/dataloader.py:195), so ranks
+    holding different pieces would run different numbers of optimizer steps — and one gradient all-reduce belongs to each step.  Under
+    data parallelism (synced=True) the count is the MAX over ranks (control plane); a rank without that segment runs a zero-token step."""
+    from . import dp
+    n = int(max(batch['n_seg']))
+    if synced and dp.data_plane() is not None:
+        n = int(dp.max_over_ranks(n))
+    return n
+
+
+def _segments(batch, dev, synced=False):
+    """The dataloader packs a piece as n_seg segments: dec_inp_i / dec_tgt_i [B, T] (time-major on the device), dec_seg_len_i, masks.
+    Yields None for a segment index this rank's batch does not have (only with synced=True, see _n_segments)."""
+    for i in range(_n_segments(batch, synced)):
+        if ('dec_inp_%d' % i) not in batch:
+            yield None
+            continue
         yield (batch['dec_inp_%d' % i].t().to(dev), batch['dec_tgt_%d' % i].t().to(dev), batch['dec_seg_len_%d' % i].to(dev),
                batch['inp_chord_%d' % i], batch['inp_melody_%d' % i])
 
@@ -89,10 +104,16 @@ def _backward_and_exchange(model, loss, dec_target, pad_token):
     if dp.data_plane() is None:
         loss.backward()
         return
-    n_tok = (dec_target != pad_token).sum().to(torch.float32)
-    (loss * n_tok).backward()
     store = model._ensure_store()
-    dp.allreduce_grads_(store, n_tok)
+    n_tok = 0 if dec_target is None else int((dec_target != pad_token).sum().item())
+    if n_tok > 0:
+        (loss * float(n_tok)).backward()
+    else:
+        # no segment left on this rank, or a segment that is all padding: the mean over zero tokens is NaN and NaN * 0 would poison
+        # every replica through the sum — contribute an exactly-zero gradient and a zero token count instead
+        store.ensure_grads()
+        store.flat_grad.zero_()
+    dp.allreduce_grads_(store, float(n_tok))
 
 
 def train(epoch, model, dloader, optim, sched, pad_token, cfg, state):
@@ -106,37 +127,45 @@ def train(epoch, model, dloader, optim, sched, pad_token, cfg, state):
     dev = next(model.parameters()).device
     note = print if cfg.verbose else (lambda *a, **k: None)
     loss_sum, n_samples, t0 = 0.0, 0, time.time()
+    accs = (float('nan'),) * 4
     for b_idx, batch in enumerate(dloader):
         mems = tuple()
         bsz = batch['id'].size(0)
-        for dec_input, dec_target, seg_len, chord, melody in _segments(batch, dev):
+        for seg in _segments(batch, dev, synced=True):
             optim.zero_grad() if fused else model.zero_grad()
             state.train_steps += 1
-            dec_logits, mems = model(dec_input, mems, dec_seg_len=seg_len)
-            losses = model.compute_loss(dec_logits, dec_target)
-            accs = compute_accuracy(dec_logits, dec_target, chord, melody, pad_token)
-            _backward_and_exchange(model, losses['total_loss'], dec_target, pad_token)
+            if seg is not None:
+                dec_input, dec_target, seg_len, chord, melody = seg
+                dec_logits, mems = model(dec_input, mems, dec_seg_len=seg_len)
+                losses = model.compute_loss(dec_logits, dec_target)
+                accs = compute_accuracy(dec_logits, dec_target, chord, melody, pad_token)
+                _backward_and_exchange(model, losses['total_loss'], dec_target, pad_token)
+            else:                                                   # another rank still has a segment: take part in its step (same collectives)
+                _backward_and_exchange(model, None, None, pad_token)
             if fused:
                 optim.step()                                        # clip + 1/tokens (or 1/world) folded into the fused Adam
             else:
                 if dp.data_plane() is not None:
                     st = model._ensure_store()
-                    st.flat_grad.div_(st.flat_grad_ext[st.total])
+                    st.flat_grad.div_(st.flat_grad_ext[st.total].clamp_min(1.0))   # global count 0 -> the gradient is exactly zero anyway
                 torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)
                 optim.step()
-            loss_sum += bsz * losses['ce_loss'].item()
-            n_samples += bsz
+            if seg is not None:
+                ce = losses['ce_loss'].item()
+                if ce == ce or dp.data_plane() is None:             # (DP: an all-pad segment has no loss — nan, not counted)
+                    loss_sum += bsz * ce
+                    n_samples += bsz
             if state.train_steps < cfg.warmup_steps:
                 optim.param_groups[0]['lr'] = cfg.max_lr * state.train_steps / cfg.warmup_steps
             else:
                 sched.step(state.train_steps - cfg.warmup_steps)
             if state.train_steps % cfg.log_interval == 0:
                 lf = os.path.join(cfg.ckpt_dir, cfg.log_file)
-                log_epoch(lf, {'ep': epoch, 'steps': state.train_steps, 'ce_loss': loss_sum / n_samples, 'time': time.time() - t0},
+                log_epoch(lf, {'ep': epoch, 'steps': state.train_steps, 'ce_loss': loss_sum / max(n_samples, 1), 'time': time.time() - t0},
                           state.init_time, is_init=not os.path.exists(lf))
         note('[stage1 train] ep %d batch %d: ce %.4f | acc %.4f (chord %.4f, melody %.4f, others %.4f) | step %d | %.1f s'
-             % ((epoch, b_idx, loss_sum / n_samples) + tuple(accs) + (state.train_steps, time.time() - t0)))
-    return loss_sum / n_samples, time.time() - t0
+             % ((epoch, b_idx, loss_sum / max(n_samples, 1)) + tuple(accs) + (state.train_steps, time.time() - t0)))
+    return loss_sum / max(n_samples, 1), time.time() - t0
 
 
 def validate(epoch, model, dloader, pad_token, rounds=1, verbose=True):

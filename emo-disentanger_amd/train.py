@@ -29,6 +29,22 @@ class TrainConfig:
         self.__dict__.update(locals())
         del self.__dict__['self']
         self.train_steps = 0
+        self.window_tokens = None         # token count of the open accumulation window (kept across epochs)
+        self._rng = None
+
+    def shared_rng(self):
+        """The FAVOR+ redraw decision (`random() > feat_redraw_prob`, train.py:61) must fall the same way on every rank, or the
+        replicas' omega generators — seeded identically by dp.sync_model_from_rank0 — drift apart.  Single process: the `random`
+        module, as in the reference; data parallel: one generator per process seeded with a value rank 0 broadcasts."""
+        if self._rng is None:
+            if self.world_size > 1 and dp.data_plane() is not None:
+                import torch.distributed as dist
+                seed = torch.tensor([random.getrandbits(62)], dtype=torch.int64)
+                dist.broadcast(seed, src=0)                           # control plane (gloo)
+                self._rng = random.Random(int(seed))
+            else:
+                self._rng = random
+        return self._rng
 
     @classmethod
     def from_yaml(cls, conf, representation='functional', **kw):
@@ -76,13 +92,16 @@ def train_model(epoch, model, dloader, optim, sched, pad_token, model_type="perf
     cfg = cfg or TrainConfig()
     model.train()
     dev = next(model.parameters()).device
-    recons_loss_rec, accum_samples = 0., 0
+    # running loss sum: a DEVICE scalar (fp64) — read back only where the reference prints / logs it, so that a quiet run
+    # (verbose=False) has no host sync inside the step (r02: .item() + a 6-counter .cpu() per optimizer step)
+    recons_loss_rec, accum_samples = torch.zeros((), device=dev, dtype=torch.float64), 0
     say = print if cfg.verbose else (lambda *a, **k: None)
     say('[epoch {:03d}] training ...'.format(epoch))
     say('[epoch {:03d}] # batches = {}'.format(epoch, len(dloader)))
     st = time.time()
     fused = isinstance(optim, FusedAdam)
-    window_tokens, exchange = None, None
+    exchange = None
+    rng = cfg.shared_rng()
     for batch_idx, batch_samples in enumerate(dloader):
         if cfg.faithful_accum or (cfg.train_steps % cfg.accum_steps) == 0:
             optim.zero_grad() if fused else model.zero_grad()
@@ -95,7 +114,7 @@ def train_model(epoch, model, dloader, optim, sched, pad_token, model_type="perf
         cfg.train_steps += 1
         train_steps = cfg.train_steps
         if model_type == "performer":
-            omit_feature_map_draw = random.random() > cfg.redraw_prob
+            omit_feature_map_draw = rng.random() > cfg.redraw_prob
             dec_logits = model(batch_dec_inp, seg_inp=batch_track_mask, chord_inp=None, attn_kwargs={'omit_feature_map_draw': omit_feature_map_draw})
         else:
             omit_feature_map_draw = True
@@ -112,16 +131,16 @@ def train_model(epoch, model, dloader, optim, sched, pad_token, model_type="perf
             if (train_steps % cfg.accum_steps) == 0:
                 exchange.arm()                                        # the late layers' all-reduce starts inside this backward
             if cfg.faithful_accum or cfg.accum_steps == 1:            # (reference quirk F11: only the window's last micro-batch survives, scaled 1/accum)
-                window_tokens = n_tok
+                cfg.window_tokens = n_tok
                 (total_loss * n_tok).backward()
             else:                                                     # real accumulation: token-weighted mean over the whole window
-                window_tokens = n_tok if (train_steps - 1) % cfg.accum_steps == 0 else window_tokens + n_tok
+                cfg.window_tokens = n_tok if (train_steps - 1) % cfg.accum_steps == 0 or cfg.window_tokens is None else cfg.window_tokens + n_tok
                 (losses['total_loss'] * n_tok).backward()
         else:
             total_loss.backward()
         if (train_steps % cfg.accum_steps) == 0:
             if cfg.world_size > 1:
-                exchange.finish(window_tokens)                       # the one exchange per optimizer step, in up to 3 pieces
+                exchange.finish(cfg.window_tokens)                       # the one exchange per optimizer step, in up to 3 pieces
             if fused:
                 optim.step()                                         # clip(0.5) + 1/sum(tokens) folded into the fused Adam
             else:
@@ -133,14 +152,15 @@ def train_model(epoch, model, dloader, optim, sched, pad_token, model_type="perf
                 optim.zero_grad()
             n_b = batch_samples['id'].size(0)
             # (the reference's bookkeeping, quirks included: recons_loss was divided in place by accum_steps when accum>1)
-            recons = losses['recons_loss'].item() / (cfg.accum_steps if cfg.accum_steps > 1 else 1)
+            recons = losses['recons_loss'].detach().double() / (cfg.accum_steps if cfg.accum_steps > 1 else 1)
             recons_loss_rec += n_b * recons * cfg.accum_steps * cfg.accum_steps
             accum_samples += n_b * cfg.accum_steps
-            total_acc, chord_acc, melody_acc, others_acc = compute_accuracy(dec_logits, batch_dec_tgt, batch_chord_idx, batch_melody_idx, pad_token)
-            say(' -- epoch {:03d} | batch {:03d}/{:03d}: len: {}\n   * loss = {:.4f}, total_acc = {:.4f}, chord_acc = {:.4f}, '
-                'melody_acc = {:.4f}, others_acc = {:.4f}, step = {}, time_elapsed = {:.2f} secs | redraw: {}'.format(
-                    epoch, batch_idx + 1, len(dloader), batch_inp_lens, recons_loss_rec / accum_samples, total_acc, chord_acc, melody_acc,
-                    others_acc, train_steps, time.time() - st, (not omit_feature_map_draw)))
+            if cfg.verbose:
+                total_acc, chord_acc, melody_acc, others_acc = compute_accuracy(dec_logits, batch_dec_tgt, batch_chord_idx, batch_melody_idx, pad_token)
+                say(' -- epoch {:03d} | batch {:03d}/{:03d}: len: {}\n   * loss = {:.4f}, total_acc = {:.4f}, chord_acc = {:.4f}, '
+                    'melody_acc = {:.4f}, others_acc = {:.4f}, step = {}, time_elapsed = {:.2f} secs | redraw: {}'.format(
+                        epoch, batch_idx + 1, len(dloader), batch_inp_lens, float(recons_loss_rec) / accum_samples, total_acc, chord_acc, melody_acc,
+                        others_acc, train_steps, time.time() - st, (not omit_feature_map_draw)))
         if (train_steps // cfg.accum_steps) < cfg.warmup_steps:
             optim.param_groups[0]['lr'] = cfg.max_lr * train_steps / (cfg.warmup_steps * cfg.accum_steps)
         elif sched is not None:
@@ -148,14 +168,15 @@ def train_model(epoch, model, dloader, optim, sched, pad_token, model_type="perf
         else:
             optim.param_groups[0]['lr'] = lr_after_step(train_steps, cfg)
         if not train_steps % cfg.log_interval:
-            log_data = {'ep': epoch, 'steps': train_steps, 'recons_loss': recons_loss_rec / accum_samples, 'time': time.time() - st}
+            log_data = {'ep': epoch, 'steps': train_steps, 'recons_loss': float(recons_loss_rec) / accum_samples, 'time': time.time() - st}
             lf = os.path.join(cfg.ckpt_dir, 'log.txt')
             log_epoch(lf, log_data, is_init=not os.path.exists(lf))
-    say('[epoch {:03d}] training completed\n  -- loss = {:.4f}\n  -- time elapsed = {:.2f} secs.'.format(epoch, recons_loss_rec / accum_samples, time.time() - st))
-    log_data = {'ep': epoch, 'steps': cfg.train_steps, 'recons_loss': recons_loss_rec / accum_samples, 'time': time.time() - st}
+    ep_loss = float(recons_loss_rec) / accum_samples
+    say('[epoch {:03d}] training completed\n  -- loss = {:.4f}\n  -- time elapsed = {:.2f} secs.'.format(epoch, ep_loss, time.time() - st))
+    log_data = {'ep': epoch, 'steps': cfg.train_steps, 'recons_loss': ep_loss, 'time': time.time() - st}
     lf = os.path.join(cfg.ckpt_dir, 'log.txt')
     log_epoch(lf, log_data, is_init=not os.path.exists(lf))
-    return recons_loss_rec / accum_samples
+    return ep_loss
 
 
 def validate(model, dloader, pad_token, rounds=1, model_type="performer", cfg=None):
@@ -167,7 +188,7 @@ def validate(model, dloader, pad_token, rounds=1, model_type="performer", cfg=No
         for r in range(rounds):
             for batch_idx, bs in enumerate(dloader):
                 inp, tgt, seg = _to_dev(bs['dec_input'], dev), _to_dev(bs['dec_target'], dev), _to_dev(bs['track_mask'], dev)
-                kw = {'attn_kwargs': {'omit_feature_map_draw': random.random() > cfg.redraw_prob}} if model_type == 'performer' else {}
+                kw = {'attn_kwargs': {'omit_feature_map_draw': cfg.shared_rng().random() > cfg.redraw_prob}} if model_type == 'performer' else {}
                 dec_logits = model(inp, seg_inp=seg, chord_inp=None, **kw)
                 losses = model.compute_loss(dec_logits, tgt)
                 loss_rec.append(losses['recons_loss'].item())
