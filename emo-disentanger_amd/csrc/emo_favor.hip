@@ -1242,6 +1242,11 @@ template <typename CT, int DH, int MF, int C> static size_t dkv_lds() {
 
 #define EMO_MAX_LDS (160 * 1024)
 
+// emo_favor_fs.hip: the bf16 / d_head 64 / 128-feature "slice" kernels (false: shape or mode not covered -> the generic kernels below)
+bool emo_favor_fs_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const float* omega, bf16_t* out, int64_t ld_out, float* den,
+                      float* sS, float* sz, const bf16_t* dout, bf16_t* dq, bf16_t* dk, bf16_t* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, float eps,
+                      hipStream_t st);
+
 // ---- segment-parallel scan geometry (see favor_fwd_kernel).  One workgroup per (b, h, segment); segments only when B*H alone cannot
 // fill the 256 CUs.  Ts is a multiple of 64 (every chunk size divides it) and at least 2 chunks long.
 #define EMO_FAVOR_SEG_ALIGN 64
@@ -1284,6 +1289,14 @@ static int run_favor(int which, const void* q, const void* k, const void* v, int
         EMO_CHECK(((uintptr_t)workspace & 15) == 0, "favor attention: workspace must be 16-B aligned");
     }
     if (P <= 1) { P = 1; Ts = T > 0 ? T : 1; }
+    if constexpr (sizeof(CT) == 2 && DH == 64 && MF == 64) {
+        if (P == 1 && emo_favor_fs_try(which, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, omega, (bf16_t*)out, ld_out, den, sS, sz,
+                                       (const bf16_t*)dout, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, ld_d, B, T, H, eps, st)) {
+            EMO_LAUNCH_CHECK();
+            return EMO_OK;
+        }
+    }
+    { const char* e = getenv("EMO_FAVOR_FS"); EMO_CHECK(!(e && atoi(e) == 2 && which == 0), "favor attention: EMO_FAVOR_FS=2 but the slice kernels do not cover this call"); }
     float* wsS = (float*)workspace;
     float* wsz = wsS ? wsS + B * H * P * (int64_t)F * DH : nullptr;
     dim3 grid((unsigned)(B * H * P));

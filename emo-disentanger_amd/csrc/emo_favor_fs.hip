@@ -1,0 +1,366 @@
+// FAVOR+ causal linear attention, bf16, d_head 64, 128 features — "slice" kernels (r03).
+//
+// Why a second set of kernels: the generic kernels of emo_favor.hip give one (b, h) scan to an 8-wave workgroup and run every contraction of
+// a 64-token chunk as a barrier-delimited phase over LDS images (7-8 barriers per chunk; r02 PMC: ~2000-2500 cycles per phase for ~200
+// cycles of MFMA issue, 42-49 % of the LDS cycles bank conflicts, forward 0.28 / backward 0.13 of the HBM roofline).  Here a (b, h) scan
+// belongs to FOUR waves that each own a SLICE of the problem and keep their whole chain in registers:
+//   * the feature map is split by feature index m (wave w: m in [16w, 16w+16), i.e. features f = m and 64 + m);
+//   * every product is arranged so that an MFMA accumulator tile is directly the operand of the next MFMA: a 16x16 accumulator has
+//     lane l <-> column l%16 and rows 4*(l/16) .. +3, which IS the A (or B) operand layout for row (column) l%16 with the contraction
+//     index running over the accumulator rows — provided the OTHER operand is read in the same permuted k order
+//     (k-step s, element e <-> k = 32 s + 16 (e/4) + 4 (l/16) + e%4; emo_lds_mma.h load_perm / load_perm_tr);
+//   * what the waves must exchange is only bf16 operand data (feature rows, dU rows: 16-32 KB per 32-token chunk), never fp32 partial
+//     sums; the running state is split by output column d (forward, dV) or by feature f (dq, dk) so that no state is ever reduced
+//     across waves;
+//   * the normaliser (row sums of the masked A matrix, q'.z) and the z / r vectors come out of the same MFMAs through a 65th "ones"
+//     column of V (an extra 16-column tile whose column 0 is 1): no VALU reductions, no atomics;
+//   * ONE workgroup barrier per 32-token chunk (the LDS images are double buffered), 45-66 KB of LDS => 2-3 workgroups per CU, each
+//     wave runs 40-75 MFMAs per chunk between barriers.
+// Numerics = the generic bf16 kernels' (bf16 operands, fp32 accumulation and state, features exp2((c log2e) u - off)).
+// Requirements: bf16, d_head 64, n_feat 128, T % 32 == 0, single-segment scan; everything else stays on emo_favor.hip.
+#include "emo_common.h"
+
+#include "emo_lds_mma.h"
+
+namespace {
+constexpr int FS_NT = 256;                     // 4 waves
+constexpr int FS_C = 32;                       // tokens per chunk
+constexpr int FS_LDF = 136;                    // feature image row stride (128 f + 8): perm 8-B reads conflict-free
+constexpr float FS_LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ f32x4 mma32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ bf16x8 pack8(const f32x4& lo, const f32x4& hi) {
+    return (bf16x8){(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3], (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+}
+__device__ __forceinline__ void st4(bf16_t* p, float a, float b, float c, float d) {
+    const bf16x4 t = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+    *(bf16x4*)p = t;
+}
+
+// sum over the four 16-lane rows of a wave, result in every lane: two VALU lane swaps instead of two LDS round trips (ds_bpermute):
+// permlane32_swap(u, u) = {[lo, lo], [hi, hi]}, permlane16_swap(u, u) = {[r0, r0, r2, r2], [r1, r1, r3, r3]}
+__device__ __forceinline__ float fs_sum_rows(float x) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, x);
+    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float y = __builtin_bit_cast(float, (uint32_t)a[0]) + __builtin_bit_cast(float, (uint32_t)a[1]);
+    const uint32_t w = __builtin_bit_cast(uint32_t, y);
+    const auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+    return __builtin_bit_cast(float, (uint32_t)b[0]) + __builtin_bit_cast(float, (uint32_t)b[1]);
+}
+// |x_t|^2 of the 16 tokens of a tile, in every lane of column t: the diagonal of the Gram matrix X X^T from two MFMAs (the tile's
+// operand registers serve as A AND B operand), instead of 16 unpack + 16 FMA VALU instructions per lane — r03 PMC: the first version of
+// the forward kernel issued 456 VALU instructions per 32-token chunk and wave, 160 of them for these sums, and VALU issue was 33 % of
+// every wave's cycles (82 % of a SIMD's issue time with two waves).  Accumulator (g, c) register r = G[4 g + r][c]: the diagonal element
+// of column c sits in row group g = c / 4, register c % 4; fs_sum_rows then spreads it over the four row groups.
+__device__ __forceinline__ float fs_sumsq_gram(const bf16x8& x0, const bf16x8& x1, int g, int c) {
+    f32x4 gm = mma32(x0, x0, zero4());
+    gm = mma32(x1, x1, gm);
+    const int r = c & 3;
+    const float d = r == 0 ? gm[0] : r == 1 ? gm[1] : r == 2 ? gm[2] : gm[3];
+    return fs_sum_rows(g == (c >> 2) ? d : 0.f);
+}
+// FAVOR+ features of NT 16-token tiles for the wave's 16 projections, all tiles side by side (independent chains: the first version ran
+// one tile after the other — operand reads -> 2 MFMAs -> 16-deep |x|^2 chain -> two LDS shuffles -> 8 exps -> stores — and a chunk's four
+// tiles took 3000 cycles for ~900 cycles of issue).  Lane (g = l/16, c = l%16) gets, for token c of tile j, the features of
+// m = 16 w + 4 g + r: p[j][r] = exp(u - off), n[j][r] = exp(-u - off), u = c_s x.w_m, off = c_s^2 |x|^2 / 2 + ln(F) / 2.
+// x[j][s]: the token's row as B operand (lane: 8 consecutive d at 32 s + 8 g), wop[s]: omega^T rows of the slice as A operand.
+template <int NT>
+__device__ __forceinline__ void fs_features(const bf16x8 (&wop)[2], const bf16x8 (&x)[NT][2], float cs2, float c2h, float hl, int g, int c,
+                                            float (&p)[NT][4], float (&n)[NT][4]) {
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = mma32(wop[0], x[j][0], zero4());
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = mma32(wop[1], x[j][1], acc[j]);
+    float o[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) o[j] = c2h * fs_sumsq_gram(x[j][0], x[j][1], g, c) + hl;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float u = cs2 * acc[j][r];
+            p[j][r] = __builtin_amdgcn_exp2f(u - o[j]);
+            n[j][r] = __builtin_amdgcn_exp2f(-u - o[j]);
+        }
+}
+
+// =============================================================================================== forward
+// Operand stream: the chunk's q / k / v rows arrive by LDS-DMA (`global_load_lds`, 1 KB per wave instruction, three per wave and chunk)
+// into rings — q, k: 3 slots, v: 4 slots (v is still read while the q / k slot of the same chunk is being refilled) — issued THREE
+// chunks ahead, so that two chunks (24 KB per workgroup) are in flight at any time: with 512 scans on 256 CUs the kernel is a latency
+// problem (the first register-prefetch version waited one full HBM round trip + the store acknowledgements per 32-token chunk and ran
+// at the generic kernel's 0.27 ms).  Ring rows are 128 B with the 16-B pieces XOR-swizzled by (row & 7) on the DMA *source* address
+// and on the read (fragment reads of 16 rows x one piece would otherwise be 8-way bank conflicted).  The output rows of chunk i are
+// stored one iteration later, right after the counted wait, so that a `s_waitcnt vmcnt(3)` never has young stores in front of it.
+// Phase A (per chunk): the wave computes the features of its 16 projections for the chunk's q and k rows and writes them into the
+// shared row-major images QF / KF [32][128] (double buffered).  Barrier.  Phase B: the wave owns the output columns d in [16w, 16w+16)
+// and the state slice S[all f][16w..] (+ the "ones" tile S[f][64] = z[f]): A^T = masked Kf Qf^T (full f), num^T = V^T A^T + S^T Qf^T,
+// S += Kf^T V.
+constexpr int FS_ROWB = 128;                           // ring row: 64 bf16
+constexpr int FS_TILEB = FS_C * FS_ROWB;               // one tensor of one chunk: 4 KB
+
+template <int N> __device__ __forceinline__ void fs_wait();
+template <> __device__ __forceinline__ void fs_wait<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <> __device__ __forceinline__ void fs_wait<3>() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+template <> __device__ __forceinline__ void fs_wait<5>() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+template <> __device__ __forceinline__ void fs_wait<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+template <> __device__ __forceinline__ void fs_wait<10>() { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+__device__ __forceinline__ void fs_barrier() {         // LDS writes of this wave visible, then the workgroup barrier; DMA stays in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// LDS-DMA as INLINE ASM (guide 5.7): with the builtin, hipcc answers every later transpose read (ds_read_b64_tr_b16 builtin) of ANY LDS
+// address with `s_waitcnt vmcnt(0)` — it cannot prove that the read does not alias the LDS-DMA it has seen issued — which drained the
+// operand ring once per chunk.  The compiler never sees this DMA; its completion is counted by hand (fs_wait).  lds_dst: wave-uniform
+// LDS byte address of the 1 KB the wave's 64 lanes fill; M0 is saved / restored inside the statement.
+__device__ __forceinline__ void fs_dma16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// B (or A) operand fragment of a ring tile: row = row0 + c, the 8 elements at 32 s + 8 g
+__device__ __forceinline__ bf16x8 fs_ring_frag(const char* tile, int row0, int s, int g, int c) {
+    return *(const bf16x8*)(tile + (row0 + c) * FS_ROWB + (((4 * s + g) ^ (c & 7)) << 4));
+}
+// load_perm_tr (emo_lds_mma.h) on a swizzled ring tile: permuted-k fragment of the transpose, operand rows = columns col0 .. col0 + 15
+__device__ __forceinline__ bf16x8 fs_ring_perm_tr(const char* tile, int col0, int lane) {
+    const int i = lane & 15, kc = lane >> 4;
+    bf16x8 v;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = h * 16 + kc * 4 + (i >> 2), col = col0 + (i & 3) * 4;
+        const char* p = tile + row * FS_ROWB + ((((col >> 3)) ^ (row & 7)) << 4) + (col & 7) * 2;
+        const short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
+        const bf16x4 tb = __builtin_bit_cast(bf16x4, t);
+        v[h * 4 + 0] = tb[0]; v[h * 4 + 1] = tb[1]; v[h * 4 + 2] = tb[2]; v[h * 4 + 3] = tb[3];
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t fs_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
+
+__global__ __launch_bounds__(FS_NT, 2) void favor_fs_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                                int64_t ld, const float* __restrict__ omega, bf16_t* __restrict__ out, int64_t ld_out,
+                                                                float* __restrict__ den_g, float* __restrict__ state_S, float* __restrict__ state_z,
+                                                                int64_t T, int64_t H, float eps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* QKr = smem;                                  // [3 slots][q, k][32 rows][128 B]
+    char* Vr = QKr + 3 * 2 * FS_TILEB;                 // [4 slots][32 rows][128 B]
+    bf16_t* QFb = (bf16_t*)(Vr + 4 * FS_TILEB);        // [2][32][LDF]
+    bf16_t* KFb = QFb + 2 * FS_C * FS_LDF;             // [2][32][LDF]
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;
+    const bf16_t* qb = q + (b * T) * ld + h * 64;
+    const bf16_t* kb = k + (b * T) * ld + h * 64;
+    const bf16_t* vb = v + (b * T) * ld + h * 64;
+    bf16_t* ob = out + (b * T) * ld_out + h * 64;
+    float* dg = den_g + bh * T;
+    const float cs = rsqrtf(sqrtf(64.f));
+    const float cs2 = cs * FS_LOG2E, c2h = 0.5f * cs * cs * FS_LOG2E, hl = 0.5f * logf(128.f) * FS_LOG2E;
+
+    bf16x8 wop[2];                                     // omega^T rows m = 16 w + c, k = d
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wop[s][e] = (bf16_t)omega[(32 * s + 8 * g + e) * 64 + 16 * w + c];
+    bf16x8 oneop;                                      // the "ones" tile of V' (columns 64..79, column 64 = 1) as A / B operand
+#pragma unroll
+    for (int e = 0; e < 8; ++e) oneop[e] = (bf16_t)(c == 0 ? 1.f : 0.f);
+
+    f32x4 S[8][2];                                     // S[ft][0]: rows f = 16 ft + 4 g + r, column d = 16 w + c;  S[ft][1]: the ones tile (c == 0: z[f])
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft) { S[ft][0] = zero4(); S[ft][1] = zero4(); }
+
+    const int nch = (int)(T / FS_C);
+    const uint32_t qk_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(QKr)), vr_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(Vr));
+    // DMA: this wave moves rows 8 w .. 8 w + 7 of q, k and v (lane: row 8 w + lane / 8, physical piece lane % 8 <- logical piece ^ (row & 7))
+    const int64_t src_off = (int64_t)(8 * w + (lane >> 3)) * ld + (((lane & 7) ^ (lane >> 3)) << 3);
+    auto issue = [&](int n) {
+        const int64_t o = (int64_t)n * FS_C * ld + src_off;
+        const uint32_t qk = qk_lds + (n % 3) * 2 * FS_TILEB + w * 1024;
+        fs_dma16(qb + o, qk);
+        fs_dma16(kb + o, qk + FS_TILEB);
+        fs_dma16(vb + o, vr_lds + (n & 3) * FS_TILEB + w * 1024);
+    };
+    issue(0);
+    if (nch > 1) issue(1);
+    if (nch > 2) issue(2);
+    if (nch > 2) fs_wait<6>(); else if (nch > 1) fs_wait<3>(); else fs_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    bf16x4 o_prev[2] = {};                             // chunk i - 1's output rows, stored during iteration i
+    float d_prev[2] = {0.f, 0.f};
+#ifdef EMO_DIAG
+    uint64_t tc[8] = {}, ts = __builtin_readcyclecounter(), tstart = ts;
+#define FS_STAMP(k) do { const uint64_t tn_ = __builtin_readcyclecounter(); tc[k] += tn_ - ts; ts = tn_; } while (0)
+#else
+#define FS_STAMP(k) do {} while (0)
+#endif
+    for (int i = 0; i < nch; ++i) {
+        const int64_t t0 = (int64_t)i * FS_C;
+        bf16_t* QF = QFb + (i & 1) * FS_C * FS_LDF;
+        bf16_t* KF = KFb + (i & 1) * FS_C * FS_LDF;
+        const char* Xq = QKr + (i % 3) * 2 * FS_TILEB;
+        const char* Xk = Xq + FS_TILEB;
+        const char* VB = Vr + (i & 3) * FS_TILEB;
+        // ---------------- phase A: tiles 0, 1 = q rows 0-15, 16-31; tiles 2, 3 = k rows
+        {
+            bf16x8 x[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) x[j][s] = fs_ring_frag(j < 2 ? Xq : Xk, 16 * (j & 1), s, g, c);
+            float p[4][4], n[4][4];
+            fs_features<4>(wop, x, cs2, c2h, hl, g, c, p, n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16_t* dst = (j < 2 ? QF : KF) + (16 * (j & 1) + c) * FS_LDF + 16 * w + 4 * g;
+                st4(dst, p[j][0], p[j][1], p[j][2], p[j][3]);
+                st4(dst + 64, n[j][0], n[j][1], n[j][2], n[j][3]);
+            }
+        }
+        FS_STAMP(0);
+        // chunk i + 1 landed (this wave's pieces; the barrier below covers the other waves'); chunk i + 2 stays in flight
+        if (i + 2 < nch) fs_wait<3>(); else fs_wait<0>();
+        FS_STAMP(1);
+        if (i > 0) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                *(bf16x4*)(ob + (t0 - FS_C + 16 * tt + c) * ld_out + 16 * w + 4 * g) = o_prev[tt];
+                if (w == 0 && g == 0) dg[t0 - FS_C + 16 * tt + c] = d_prev[tt];
+            }
+        }
+        fs_barrier();
+        FS_STAMP(2);
+        if (i + 3 < nch) issue(i + 3);                     // q / k slot of chunk i and v slot of chunk i - 1 are free
+#ifdef EMO_DIAG
+        FS_STAMP(6);
+#endif
+        // ---------------- phase B
+        bf16x8 qf[2][4], kf[2][4];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { qf[tt][s] = load_perm<bf16_t>(QF, FS_LDF, 16 * tt, s, lane); kf[tt][s] = load_perm<bf16_t>(KF, FS_LDF, 16 * tt, s, lane); }
+        const bf16x8 vop = fs_ring_perm_tr(VB, 16 * w, lane);
+#ifdef EMO_DIAG
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" :: "v"(vop), "v"(qf[0][0]), "v"(qf[1][3]), "v"(kf[0][0]), "v"(kf[1][3]));
+        FS_STAMP(7);
+#endif
+        // A^T(jt, tt): rows j = 16 jt + 4 g + r, column t = 16 tt + c.  Six independent accumulator chains (even / odd k steps of the three tiles)
+        f32x4 aa[3][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            aa[0][u] = mma32(kf[0][u], qf[0][u], zero4());
+            aa[1][u] = mma32(kf[0][u], qf[1][u], zero4());
+            aa[2][u] = mma32(kf[1][u], qf[1][u], zero4());
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            aa[0][u] = mma32(kf[0][2 + u], qf[0][2 + u], aa[0][u]);
+            aa[1][u] = mma32(kf[0][2 + u], qf[1][2 + u], aa[1][u]);
+            aa[2][u] = mma32(kf[1][2 + u], qf[1][2 + u], aa[2][u]);
+        }
+        f32x4 a00 = aa[0][0] + aa[0][1], a11 = aa[2][0] + aa[2][1];
+        const f32x4 a01 = aa[1][0] + aa[1][1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                      // causal mask inside the diagonal tiles
+            const bool keep = (4 * g + r) <= c;
+            a00[r] = keep ? a00[r] : 0.f;
+            a11[r] = keep ? a11[r] : 0.f;
+        }
+        bf16x8 at[2];
+        at[0] = pack8(a00, zero4());
+        at[1] = pack8(a01, a11);
+#ifdef EMO_DIAG
+        asm volatile("" :: "v"(at[0]), "v"(at[1]));
+#endif
+        FS_STAMP(3);
+        // num^T = V^T A^T + S^T Qf^T for the wave's d columns (nm[tt][0]) and the ones tile (nm[tt][1]): four independent chains
+        f32x4 nm[2][2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) { nm[tt][0] = mma32(vop, at[tt], zero4()); nm[tt][1] = mma32(oneop, at[tt], zero4()); }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 s0 = pack8(S[2 * s][0], S[2 * s + 1][0]), s1 = pack8(S[2 * s][1], S[2 * s + 1][1]);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) { nm[tt][0] = mma32(s0, qf[tt][s], nm[tt][0]); nm[tt][1] = mma32(s1, qf[tt][s], nm[tt][1]); }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const float dn = __shfl(nm[tt][1][0], c, 64) + eps;   // row d' = 64 of the ones tile lives in lanes 0..15, register 0
+            const float inv = 1.f / dn;
+            o_prev[tt] = (bf16x4){(bf16_t)(nm[tt][0][0] * inv), (bf16_t)(nm[tt][0][1] * inv), (bf16_t)(nm[tt][0][2] * inv), (bf16_t)(nm[tt][0][3] * inv)};
+            d_prev[tt] = dn;
+        }
+#ifdef EMO_DIAG
+        asm volatile("" :: "v"(o_prev[0]), "v"(o_prev[1]));
+#endif
+        FS_STAMP(4);
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft) {
+            const bf16x8 kT = load_perm_tr(KF, FS_LDF, 16 * ft, 0, lane);
+            S[ft][0] = mma32(kT, vop, S[ft][0]);
+            S[ft][1] = mma32(kT, oneop, S[ft][1]);
+        }
+#ifdef EMO_DIAG
+        asm volatile("" :: "v"(S[0][0]), "v"(S[7][1]), "v"(S[3][0]), "v"(S[5][1]));
+#endif
+        FS_STAMP(5);
+    }
+#ifdef EMO_DIAG
+    if (state_S && lane == 0) {                        // diagnostics: the state pointer receives the cycle counters instead of the state
+        unsigned long long* dgp = (unsigned long long*)state_S;
+        for (int k_ = 0; k_ < 8; ++k_) atomicAdd(dgp + k_, (unsigned long long)tc[k_]);
+        atomicAdd(dgp + 8, (unsigned long long)(__builtin_readcyclecounter() - tstart));
+        atomicAdd(dgp + 9, 1ull);
+    }
+    if (state_S) return;
+#endif
+    {
+        const int64_t t0 = (int64_t)nch * FS_C;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            *(bf16x4*)(ob + (t0 - FS_C + 16 * tt + c) * ld_out + 16 * w + 4 * g) = o_prev[tt];
+            if (w == 0 && g == 0) dg[t0 - FS_C + 16 * tt + c] = d_prev[tt];
+        }
+    }
+    if (state_S) {
+        float* So = state_S + bh * (int64_t)(128 * 64);
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) So[(16 * ft + 4 * g + r) * 64 + 16 * w + c] = S[ft][0][r];
+        if (w == 0 && c == 0) {
+            float* zo = state_z + bh * 128;
+#pragma unroll
+            for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zo[16 * ft + 4 * g + r] = S[ft][1][r];
+        }
+    }
+}
+}  // namespace
+
+// which: 0 forward, 1 backward.  Returns false when the shape / mode is not covered (the caller then runs the generic kernels).
+bool emo_favor_fs_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const float* omega, bf16_t* out, int64_t ld_out, float* den,
+                      float* sS, float* sz, const bf16_t* dout, bf16_t* dq, bf16_t* dk, bf16_t* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, float eps,
+                      hipStream_t st) {
+    const char* e = getenv("EMO_FAVOR_FS");                // (read per call: tests toggle it in-process)  "0": generic kernels only
+    if (e && atoi(e) == 0) return false;
+    if (T < FS_C || (T % FS_C) != 0 || B * H <= 0) return false;
+    if ((ld & 7) || (ld_out & 3)) return false;
+    dim3 grid((unsigned)(B * H));
+    if (which == 0) {
+        const size_t lds = (size_t)(3 * 2 + 4) * FS_TILEB + sizeof(bf16_t) * (size_t)(4 * FS_C * FS_LDF);
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)favor_fs_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        hipLaunchKernelGGL(favor_fs_fwd_kernel, grid, dim3(FS_NT), lds, st, q, k, v, ld, omega, out, ld_out, den, sS, sz, T, H, eps);
+        return true;
+    }
+    return false;
+}

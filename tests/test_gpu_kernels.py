@@ -444,6 +444,39 @@ def test_favor_attention_fwd_bwd_vs_oracle(dt, B, T, H, dh, nf):
     _close(dk.reshape(B, T, H, dh), k.grad, dt, scale=gscale, mult=4)
 
 
+# the bf16 / d_head 64 / 128-feature "slice" kernels (emo_favor_fs.hip): against the oracle AND against the generic kernels
+@pytest.mark.parametrize('B,T,H', [(2, 256, 2), (1, 32, 1), (3, 96, 3), (1, 1024, 4), (2, 2048, 1)])
+def test_favor_slice_kernels_vs_oracle_and_generic(B, T, H, monkeypatch):
+    ops = _ops()
+    from oracle import model_ref
+    from oracle.weights import orthogonal_omega
+    dt, dh, nf = torch.bfloat16, 64, 128
+    monkeypatch.setenv('EMO_FAVOR_SEGMENTS', '1')           # single-segment scan (what B*H >= 256 gets by itself)
+    om = orthogonal_omega(dh, nf, np.random.default_rng(5))
+    qkv = _r(B * T, 3 * H * dh, seed=21, dt=dt, scale=0.8)
+    q, k, v = [qkv[:, i * H * dh:(i + 1) * H * dh].double().view(B, T, H, dh).requires_grad_(True) for i in range(3)]
+    ref = model_ref.causal_linear_attention(q, k, v, om.double(), form='quadratic')
+    dout = _r(B, T, H, dh, seed=22, dt=dt)
+    ref.backward(dout.double())
+    qc, HD = qkv.cuda(), H * dh
+    res = {}
+    for mode in ('2', '0'):                                 # 2: slice kernels REQUIRED (the call fails if they do not run), 0: generic kernels
+        monkeypatch.setenv('EMO_FAVOR_FS', mode)
+        out, den, S, z = ops.favor_attn_fwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], om.cuda(), B, T, H, want_state=True)
+        _close(out.view(B, T, H, dh), ref, dt, mult=3)
+        Kf = model_ref.favor_features(k.detach(), om.double())
+        _close(S, torch.einsum('nlhf,nlhd->nhfd', Kf, v.detach()), dt, mult=3)
+        _close(z, Kf.sum(1), dt, mult=3)
+        dq, dk, dv = ops.favor_attn_bwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], om.cuda(), out, dout.view(B * T, HD).cuda(), den, B, T, H)
+        gscale = max(float(q.grad.abs().max()), float(k.grad.abs().max()), float(v.grad.abs().max()))
+        _close(dv.reshape(B, T, H, dh), v.grad, dt, scale=gscale, mult=4)
+        _close(dq.reshape(B, T, H, dh), q.grad, dt, scale=gscale, mult=4)
+        _close(dk.reshape(B, T, H, dh), k.grad, dt, scale=gscale, mult=4)
+        res[mode] = [x.float().cpu() for x in (out, den, dq, dk, dv)]
+    for a, b_ in zip(res['2'], res['0']):                    # the two implementations round differently but compute the same thing
+        assert float((a - b_).abs().max()) <= 3e-2 * max(float(b_.abs().max()), 1e-6)
+
+
 # segment-parallel scan (B*H < 256 workgroups): automatic segment count, forced counts, ragged last segment, empty tail segments
 @pytest.mark.parametrize('dt', DT)
 @pytest.mark.parametrize('B,T,H,dh,nf,segs', [(1, 700, 2, 64, 128, None), (1, 512, 2, 32, 64, 4), (2, 330, 1, 16, 32, 3), (1, 1000, 1, 32, 128, 16),
