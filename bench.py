@@ -90,21 +90,21 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
 
     serial = instrumented(False)
     overlapped = instrumented(True) if engine._SIDE['on'] else {}
-    pmc_files = {'TN': os.path.join(ROOT, 'profiles', 'r01_pmc_wgrad.json'), 'NN': os.path.join(ROOT, 'profiles', 'r01_pmc_dgrad.json'),
-                 'NT/K=512': os.path.join(ROOT, 'profiles', 'r02_pmc_astat.json')}
+    # PMC counters of THIS round's kernels inside the training step (tools/pmc_step.py under rocprofv3 --pmc, one counter group per pass,
+    # summarised by tools/pmc_classes.py): HBM bytes per launch and the MFMA pipe's busy fraction per kernel class
+    pmc_path = os.path.join(ROOT, 'profiles', 'r03_pmc_step.json')
+    pmc_all = json.load(open(pmc_path))['classes'] if os.path.exists(pmc_path) else {}
 
     def entry(kind):
         d = serial[kind]
         achieved = d['flops'] / d['ms'] / 1e9
-        traffic = None      # HBM bytes per launch from rocprofv3 PMC passes (collected offline, committed under profiles/)
-        pmc = pmc_files.get(kind)
-        if pmc and os.path.exists(pmc) and B * T == 131072:
-            j = json.load(open(pmc))
-            traffic = j.get('traffic_bytes_per_launch')
-            if 'ratio' in j:         # counters were collected on ONE shape of the class: scale the class's algorithmic bytes by its measured ratio
-                traffic = round(j['ratio'] * d['bytes'] / d['n'])
+        pmc = pmc_all.get(kind, {}) if B * T == 131072 else {}     # (collected at the bench shape only)
+        traffic = pmc.get('traffic_bytes_per_launch')
+        if kind == 'TN' and traffic is not None and 'TN-reduce' in pmc_all:     # split-K partial sums + their reduce launch belong to the wgrad class
+            traffic += pmc_all['TN-reduce'].get('traffic_bytes_per_launch', 0)
         return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+                'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic, 'mfma_busy': pmc.get('mfma_busy'),
+                'waves_parked': pmc.get('waves_parked'), 'waves_issue_stalled': pmc.get('waves_issue_stalled'),
                 'kernel': '%s (%s)' % GEMM_KERNELS.get(kind, (kind, 'other GEMM')), 'launches_timed': d['n'], 'avg_launch_ms': round(d['ms'] / d['n'], 4),
                 'total_ms_per_step': round(d['ms'] / n_steps, 2),
                 'avg_launch_ms_overlapped_in_step': round(overlapped[kind]['ms'] / overlapped[kind]['n'], 4) if kind in overlapped else None,
@@ -113,20 +113,23 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
     order = sorted(serial, key=lambda k: -serial[k]['ms'])
     roof = entry(order[0])
     roof['timing'] = 'HIP events on the launch stream around every GEMM launch in %d real training steps (kernels serialized on one stream)' % n_steps
-    roof['rocprof_summary'] = ('profiles/r02_bench_train_rocprof_stats.txt = rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3 --no-cpu-baseline '
-                               '--no-gen --no-stage1 --no-gpt2 --no-step0-check` (training kernels only); PMC traffic: profiles/r02_pmc_astat.json, r01_pmc_dgrad.json, r01_pmc_wgrad.json')
-    roof['roofline_others'] = [entry(k) for k in order[1:]] + [attn_entry(k, v, n_steps) for k, v in sorted(extra.items())]
+    roof['rocprof_summary'] = ('profiles/r03_bench_train_rocprof_stats.txt = rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3 --no-cpu-baseline '
+                               '--no-gen --no-stage1 --no-gpt2 --no-step0-check --no-b4` (training kernels only); PMC (traffic, mfma_busy): profiles/r03_pmc_step.json')
+    roof['roofline_others'] = [entry(k) for k in order[1:]] + [attn_entry(k, v, n_steps, pmc_all if B * T == 131072 else {}) for k, v in sorted(extra.items())]
     return roof
 
 
-ATTN_KERNELS = {'favor_fwd': ('favor_fwd_kernel', 'hbm', 'FAVOR+ causal linear attention forward: features + chunked prefix-sum scan; bytes = q, k, v read + out written (4*512*e per token*layer)'),
+ATTN_KERNELS = {'favor_fwd': ('favor_fs_fwd_kernel (bf16 slice kernel; generic: favor_fwd_kernel)', 'hbm', 'FAVOR+ causal linear attention forward: features + chunked prefix-sum scan; bytes = q, k, v read + out written (4*512*e per token*layer)'),
                 'favor_bwd': ('favor_bwd_dq_kernel + favor_bwd_dkv_kernel', 'hbm', 'FAVOR+ backward (forward sweep dq, reverse sweep dk/dv); bytes = 7*512*e per token*layer'),
                 'sattn_fwd': ('sattn_fwd_kernel', 'mfma', 'GPT-2 causal softmax attention forward (flash tiles): 2 matmuls, causal half'),
                 'sattn_bwd': ('sattn_bwd_dq_kernel + sattn_bwd_dkv_kernel', 'mfma', 'GPT-2 attention backward: 7 matmuls, causal half')}
 
 
-def attn_entry(kind, rec, n_steps):
+def attn_entry(kind, rec, n_steps, pmc_all=None):
     """roofline entry of an attention kernel class from in-situ HIP-event brackets (ops._timed)."""
+    pmc_all = pmc_all or {}
+    parts = [pmc_all[k] for k in ((kind,) if kind != 'favor_bwd' else ('favor_bwd_dq', 'favor_bwd_dkv')) if k in pmc_all]
+    traffic = sum(p.get('traffic_bytes_per_launch', 0) for p in parts) if parts and all('traffic_bytes_per_launch' in p for p in parts) else None
     ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rec)
     fl, by = sum(r[2] for r in rec), sum(r[3] for r in rec)
     name, bound, what = ATTN_KERNELS[kind]
@@ -134,7 +137,9 @@ def attn_entry(kind, rec, n_steps):
         ach, peak, unit = by / ms / 1e6, PEAK_HBM_GBS, 'GB/s'
     else:
         ach, peak, unit = fl / ms / 1e9, PEAK_BF16_TFLOPS, 'TFLOP/s'
-    return {'bound': bound, 'achieved': round(ach, 1), 'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4), 'traffic': None, 'kernel': '%s (%s)' % (name, what),
+    return {'bound': bound, 'achieved': round(ach, 1), 'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4), 'traffic': traffic,
+            'mfma_busy': [p.get('mfma_busy') for p in parts] if parts else None, 'lds_conflict_share': [p.get('lds_conflict_share') for p in parts] if parts else None,
+            'kernel': '%s (%s)' % (name, what),
             'launches_timed': len(rec), 'avg_launch_ms': round(ms / len(rec), 4), 'total_ms_per_step': round(ms / n_steps, 2),
             'algorithmic_flops_per_launch': round(fl / len(rec)), 'algorithmic_bytes_per_launch': round(by / len(rec))}
 
@@ -301,18 +306,86 @@ def cpu_baseline(T, steps=2):
     for _ in range(steps):
         one_step()
     dt = (time.time() - t0) / steps
-    out = {'value': round(T / dt, 1), 'unit': 'tokens/s', 'cores': cores, 'kind': 'port',
-           'sample': 'oracle Performer L12 d512 fwd + bwd + clip + Adam, B=1 x T=%d, %d timed steps, torch fp32 eager + C causal product' % (T, steps)}
-    if cores > 8:
-        torch.set_num_threads(8)
-        os.environ['OMP_NUM_THREADS'] = '8'
-        try:
-            t0 = time.time()
-            one_step()
-            out['value_8_threads'] = round(T / (time.time() - t0), 1)
-        finally:
-            torch.set_num_threads(cores)
+    tried = {cores: round(T / dt, 1)}
+    for nt in (32, 16, 8):                                              # the box oversubscribes at all cores (r02: 369 tok/s at 128 threads, 1359 at 8)
+        if nt < cores:
+            torch.set_num_threads(nt)
+            os.environ['OMP_NUM_THREADS'] = str(nt)
+            try:
+                t0 = time.time()
+                one_step()
+                tried[nt] = round(T / (time.time() - t0), 1)
+            finally:
+                torch.set_num_threads(cores)
+    best = max(tried, key=tried.get)
+    return {'value': tried[best], 'unit': 'tokens/s', 'cores': best, 'kind': 'port', 'tokens_per_s_by_threads': {str(k): v for k, v in sorted(tried.items())},
+            'sample': 'oracle Performer L12 d512 fwd + bwd + clip + Adam, B=1 x T=%d, torch fp32 eager + C causal product; %d timed steps at all %d '
+                      'threads, one step at each smaller count; value = the best thread count tried' % (T, steps, cores)}
+
+
+def dp_selftest(model, rank, world):
+    """The gradient exchange of one optimizer step on a rank-stamped buffer: the flat gradient (152.7 MB fp32 at the bench config) is
+    filled with (rank + 1) * pattern(i), sent through dp.GradExchange exactly as a training step does (late-layer range on the
+    communication stream while the compute stream is busy, the rest + the token-count tail afterwards) and EVERY element is compared
+    with world (world + 1) / 2 * pattern(i).  A broken overlap (missing stream dependency, wrong range) shows up as a wrong element
+    here, not as a slightly wrong loss later.  Also times the exchange with HIP events (comm stream)."""
+    from emo_disentanger_amd import dp
+    ps = model._ensure_store()
+    n = ps.total
+    idx = torch.arange(n, device=ps.device, dtype=torch.float32)
+    pattern = (idx % 251.0) * 0.5 + 1.0                         # exact in fp32, sums of <= 8 multiples stay exact
+    ps.ensure_grads()
+    ex = dp.GradExchange(model, ps)
+    out = {'elements': int(n), 'bytes': int(4 * n), 'split': bool(ex.range is not None), 'plane': dp.data_plane()}
+    times = []
+    for rep in range(3):
+        ps.flat_grad.copy_(pattern * float(rank + 1))
+        busy = torch.randn(4096, 4096, device=ps.device)        # keeps the compute stream busy while the first piece is in flight
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        dp.barrier()
+        e0.record()
+        ex.arm()
+        if ex.range is not None and ex._enabled():
+            ex._on_layer(ex.range[2])                           # what DecoderStackFn.backward calls half-way through the sweep
+        busy = busy @ busy
+        ex.finish(torch.tensor(float(100 + rank), device=ps.device))
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1))
+        want_sum = world * (world + 1) / 2.0
+        bad = int((ps.flat_grad != pattern * want_sum).sum())
+        tail = float(ps.flat_grad_ext[ps.total])
+        tail_want = float(sum(100 + r for r in range(world)))
+        out.update(bad_elements=bad, tail=tail, tail_expected=tail_want)
+        if bad or tail != tail_want:
+            break
+    ps.flat_grad.zero_()
+    out['ok'] = bool(out['bad_elements'] == 0 and out['tail'] == out['tail_expected'])
+    out['exchange_ms'] = round(min(times), 3)
+    out['allreduce_GBps_per_gpu'] = round(4 * n / (min(times) * 1e-3) / 1e9, 1)
     return out
+
+
+def b4_bench(model, opt_cls, tr, steps=10, warm=3):
+    """SURVEY 8(d) cfg2 second batch size: the reference YAML's batch_size 4 (pop1k7_pretrain.yaml) through the same product loop."""
+    import tempfile
+    from emo_disentanger_amd.data import synthetic_batch
+    B, T = 4, CFG['seq']
+    dev = next(model.parameters()).device
+    bs = [synthetic_batch(CFG['n_token'], B, T, seed=4321 + i, device=dev) for i in range(2)]
+    cfg = tr.TrainConfig(warmup_steps=200, max_lr=1e-4, min_lr=1e-5, lr_decay_steps=500000, redraw_prob=1.0, log_interval=10 ** 9,
+                         ckpt_dir=tempfile.mkdtemp(prefix='emo_bench_b4_'), verbose=False)
+    opt = opt_cls(model, lr=1e-4, max_grad_norm=0.5)
+    tr.train_model(1, model, [bs[i % 2] for i in range(warm)], opt, None, CFG['n_token'] - 1, cfg=cfg)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = tr.train_model(1, model, [bs[i % 2] for i in range(steps)], opt, None, CFG['n_token'] - 1, cfg=cfg)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {'metric': 'train tokens/sec at the reference YAML batch size', 'value': round(B * T / dt, 1), 'unit': 'tokens/s', 'ms_per_step': round(dt * 1e3, 3),
+            'config': {'workload': 'stage2 Performer d512 L12 H8 F128 seq=%d, B=%d (pop1k7_pretrain.yaml batch_size), bf16, dropout 0.1, omega redraw every forward' % (T, B)},
+            'mean_loss': round(loss, 4)}
 
 
 def launch_ranks(n):
@@ -345,6 +418,8 @@ def main():
     ap.add_argument('--no-stage1', action='store_true')
     ap.add_argument('--no-gpt2', action='store_true')
     ap.add_argument('--no-step0-check', action='store_true')
+    ap.add_argument('--no-b4', action='store_true')
+    ap.add_argument('--dp-selftest', action='store_true', help='N > 1: run only the gradient-exchange self-test and exit')
     args = ap.parse_args()
 
     want = max(args.gpus, 1)
@@ -360,7 +435,7 @@ def main():
                  '`python -m torch.distributed.run --nproc-per-node %d ... bench.py --gpus %d`' % (want, world, want, want, want))
     if torch.cuda.device_count() < (local_rank + 1 if world > 1 else 1):
         sys.exit('bench.py: rank %d needs GPU %d but only %d visible: one process per GPU, no sharing' % (rank, local_rank, torch.cuda.device_count()))
-    dp.init_distributed()
+    dp.init_distributed(strict=True)                         # the N > 1 line measures emo_comm_* (RCCL behind the C-ABI) or fails
     local_dev = local_rank if world > 1 else 0
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
@@ -372,52 +447,76 @@ def main():
                                favor_feature_dims=CFG['n_feat'], use_segment_emb=True, n_segment_types=2, dropout=0.1,
                                compute_dtype='bf16', redraw=args.redraw).to(dev)
     model.train()
+    selftest = None
     if world > 1:
+        if dp.data_plane() != 'rccl' and os.environ.get('EMO_COMM') is None:
+            sys.exit('bench.py: data plane is %r, expected the C-ABI RCCL plane' % dp.data_plane())
+        if dp.data_plane() == 'rccl' and ops.lib.emo_comm_world() != want:
+            sys.exit('bench.py: emo_comm_world() = %d but --gpus %d' % (ops.lib.emo_comm_world(), want))
         dp.sync_model_from_rank0(model)
+        selftest = dp_selftest(model, rank, world)
+        if not selftest['ok']:
+            sys.exit('bench.py: data-parallel self-test failed on rank %d: %s' % (rank, selftest))
+        if args.dp_selftest:
+            if rank == 0:
+                print(json.dumps({'dp_selftest': selftest, 'n_gpus': world, 'comm': dp.data_plane()}), flush=True)
+            dp.barrier()
+            dp.shutdown()
+            return
     max_lr, eta_min, warmup_steps, T_max = 1e-4, 1e-5, 200, 500000      # pop1k7_pretrain.yaml
     opt = FusedAdam(model, lr=max_lr, max_grad_norm=0.5, world_size=world, token_weighted=True)
     batches = [synthetic_batch(CFG['n_token'], B, T, seed=dp.shard_seed(1234, rank) + 100 * i, device=dev) for i in range(2)]
     for b in batches:                                        # non-pad target count of the rank's batch (token-weighted DP mean)
         b['n_tok'] = (b['dec_target'] != CFG['n_token'] - 1).sum().to(torch.float32)
     s0 = step0_check(model, batches[1]) if (world == 1 and not args.no_step0_check) else None     # batches[1] = the batch of step 1
-    ps = model._ensure_store()
-    counts = torch.zeros(6, device=dev, dtype=torch.int64)
-    loss_acc = torch.zeros((), device=dev)
-    state = {'step': 0}
-    exchange = dp.GradExchange(model, ps) if world > 1 else None
+    # The timed step IS the product loop: train.train_model (zero_grad, forward with the omega redraw, loss, backward with the
+    # overlapped gradient exchange at N > 1, clip(0.5) + Adam fused, LR schedule, loss bookkeeping on the device) over K synthetic
+    # batches that are already resident in HBM, verbose off (= no per-step host sync; the reference's per-step print would add one).
+    import tempfile
+    from emo_disentanger_amd import train as tr
+    tcfg = tr.TrainConfig(warmup_steps=warmup_steps, max_lr=max_lr, min_lr=eta_min, lr_decay_steps=T_max, redraw_prob=1.0, log_interval=10 ** 9,
+                          ckpt_dir=tempfile.mkdtemp(prefix='emo_bench_'), world_size=world, verbose=False)
+    pad = CFG['n_token'] - 1
+
+    class Loader:
+        """n synthetic batches; a HIP event is recorded on the compute stream every time the loop fetches a batch (= step boundaries)."""
+
+        def __init__(self, n, record=False):
+            self.n, self.events = n, [] if record else None
+
+        def __len__(self):
+            return self.n
+
+        def __iter__(self):
+            for i in range(self.n):
+                if self.events is not None:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    self.events.append(e)
+                yield batches[i % len(batches)]
+
+    def run_steps(n, record=False):
+        ld = Loader(n, record)
+        loss = tr.train_model(1, model, ld, opt, None, pad, model_type='performer', cfg=tcfg)
+        return loss, ld.events
 
     def step():
-        state['step'] += 1
-        b = batches[state['step'] % len(batches)]
-        opt.zero_grad()
-        logits = model(b['dec_input'], seg_inp=b['track_mask'], attn_kwargs={'omit_feature_map_draw': False})
-        losses = model.compute_loss(logits, b['dec_target'])
-        if world > 1:
-            exchange.arm()                                   # the late layers' all-reduce overlaps the rest of the backward (dp.GradExchange)
-            (losses['total_loss'] * b['n_tok']).backward()
-            exchange.finish(b['n_tok'])                      # flat fp32 gradient + token count in up to 3 pieces (emo_comm_allreduce)
-        else:
-            losses['total_loss'].backward()
-        opt.step()
-        loss_acc.add_(losses['recons_loss'].detach())
-        counts.add_(ops.accuracy_counts(logits.detach().view(-1, logits.shape[-1]), b['dec_target'].view(-1), b['chord_idx'].view(-1),
-                                        b['melody_idx'].view(-1), CFG['n_token'] - 1))
-        s = state['step']
-        opt.param_groups[0]['lr'] = max_lr * s / warmup_steps if s < warmup_steps else \
-            eta_min + (max_lr - eta_min) * (1 + math.cos(math.pi * (s - warmup_steps) / T_max)) / 2
+        run_steps(1)
 
-    for _ in range(args.warmup):
-        step()
+    if args.warmup > 0:
+        run_steps(args.warmup)
     torch.cuda.synchronize()
     dp.barrier()
-    loss_acc.zero_()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    mean_loss, evs = run_steps(args.steps, record=True)
+    end_ev = torch.cuda.Event(enable_timing=True)
+    end_ev.record()
     torch.cuda.synchronize()
     dp.barrier()
-    elapsed = dp.max_over_ranks(time.perf_counter() - t0)
-    mean_loss = float(loss_acc) / max(args.steps, 1)
+    my_elapsed = time.perf_counter() - t0
+    elapsed = dp.max_over_ranks(my_elapsed)
+    per_step = [a.elapsed_time(b_) for a, b_ in zip(evs, evs[1:] + [end_ev])]       # ms, device timeline of this rank
+    median_ms = sorted(per_step)[len(per_step) // 2] if per_step else float('nan')
     tokens = world * B * T * args.steps
     value = tokens / elapsed
     out = {'metric': 'train tokens/sec (+ AR gen tokens/sec in "gen"), stage2 Performer d512 L12 seq%d' % T, 'value': round(value, 1), 'unit': 'tokens/s', 'n_gpus': world,
@@ -427,11 +526,20 @@ def main():
            'config': {'workload': 'BASELINE configs[%d]: stage2 Performer d_model=512 n_layer=12 n_head=8 favor_dims=128 seq=%d, B=%d/GPU, '
                                   'dropout 0.1, omega redraw %s, fwd+bwd+allreduce+clip+Adam' % (1 if world == 1 else 2, T, B, args.redraw),
                       'global_batch': world * B, 'seq_len': T, 'parallelism': 'dp%d' % world, 'n_token': CFG['n_token']},
-           'mean_loss': round(mean_loss, 4), 'gemm_tflops_model': round(value * gemm_flops_per_token() / 1e12, 1)}
+           'mean_loss': round(mean_loss, 4), 'gemm_tflops_model': round(value * gemm_flops_per_token() / 1e12, 1),
+           'timed_loop': 'emo_disentanger_amd.train.train_model (the product loop), verbose off',
+           'median_ms_per_step': round(median_ms, 3), 'median_tokens_per_s': round(world * B * T / (median_ms / 1e3), 1) if median_ms == median_ms else None}
     if not args.no_roofline:                 # every rank runs the instrumented steps (they contain the all-reduce)
         roof = dominant_kernel_roofline(step, B, T)
         if rank == 0:
             out['roofline'] = roof
+    if world > 1:
+        # per-rank view of the timed region + the exchange measured by the self-test (HIP events, communication stream included)
+        allt = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        import torch.distributed as dist
+        dist.all_gather(allt, torch.tensor([my_elapsed / args.steps * 1e3], dtype=torch.float64))
+        out['per_rank_ms_per_step'] = [round(float(t), 3) for t in allt]
+        out['dp_selftest'] = selftest
     if rank == 0:
         if s0 is not None:
             out['step0_check'] = s0
@@ -439,6 +547,8 @@ def main():
             out['gen'] = generation_bench(model)
             if not args.no_cpu_baseline:
                 out['gen']['cpu_baseline'] = cpu_generation_baseline()
+        if world == 1 and not args.no_b4:
+            out['b4'] = b4_bench(model, FusedAdam, tr)
         if world == 1 and not args.no_stage1:
             out['stage1'] = stage1_bench()
         if world == 1 and not args.no_gpt2:
