@@ -156,6 +156,18 @@ int emo_favor_decode_step(const void* q, const void* k, const void* v, int64_t l
                           float* state_S, float* state_z, void* out, int64_t ld_out, int dtype,
                           int64_t n_streams, int64_t H, int64_t dh, int64_t n_feat, float eps,
                           emo_stream_t stream);
+/* The same step in two launches (the decode loop of inference.py:250-277 is a chain of ~60 small dependent launches per token, so what is
+ * not needed by the NEXT launch is taken off the chain): _readout computes the step's output from the OLD state without writing anything
+ * back (out = phi(q)^T (S + phi(k) (x) v) / (phi(q).(z + phi(k)) + eps)); _update applies S += phi(k) (x) v, z += phi(k) and may run on
+ * another stream AFTER the read-out of the same token (it overwrites what the read-out reads) and before the next token's.
+ * Built for the (d_head, n_feat) pairs of emo_favor_attn_fwd with a 16-B aligned state. */
+int emo_favor_decode_readout(const void* q, const void* k, const void* v, int64_t ld, const float* omega,
+                             const float* state_S, const float* state_z, void* out, int64_t ld_out, int dtype,
+                             int64_t n_streams, int64_t H, int64_t dh, int64_t n_feat, float eps,
+                             emo_stream_t stream);
+int emo_favor_decode_update(const void* k, const void* v, int64_t ld, const float* omega, float* state_S,
+                            float* state_z, int dtype, int64_t n_streams, int64_t H, int64_t dh,
+                            int64_t n_feat, emo_stream_t stream);
 
 /* FAVOR+ omega draw (fast-transformers orthogonal_random_matrix_, called from new_feature_map() on every
  * forward — SURVEY F8): gauss [n_layers, ceil((n_feat/2)/dh), dh, dh] ~ N(0,1) from the caller's RNG ->
