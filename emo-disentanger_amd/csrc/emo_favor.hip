@@ -1247,7 +1247,7 @@ template <typename CT, int DH, int MF, int C> static size_t dkv_lds() {
 #define EMO_MAX_LDS (160 * 1024)
 
 // emo_favor_fs.hip: the bf16 / d_head 64 / 128-feature "slice" kernels (false: shape or mode not covered -> the generic kernels below)
-bool emo_favor_fs_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const float* omega, bf16_t* out, int64_t ld_out, float* den,
+int emo_favor_fs_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const float* omega, bf16_t* out, int64_t ld_out, float* den,
                       float* sS, float* sz, const bf16_t* dout, bf16_t* dq, bf16_t* dk, bf16_t* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, float eps,
                       hipStream_t st);
 
@@ -1293,14 +1293,16 @@ static int run_favor(int which, const void* q, const void* k, const void* v, int
         EMO_CHECK(((uintptr_t)workspace & 15) == 0, "favor attention: workspace must be 16-B aligned");
     }
     if (P <= 1) { P = 1; Ts = T > 0 ? T : 1; }
+    int fs = 0;                  // 1: served by the slice kernels; 2: dq done there, dk / dv below
     if constexpr (sizeof(CT) == 2 && DH == 64 && MF == 64) {
-        if (P == 1 && emo_favor_fs_try(which, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, omega, (bf16_t*)out, ld_out, den, sS, sz,
-                                       (const bf16_t*)dout, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, ld_d, B, T, H, eps, st)) {
+        if (P == 1) fs = emo_favor_fs_try(which, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, omega, (bf16_t*)out, ld_out, den, sS, sz,
+                                          (const bf16_t*)dout, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, ld_d, B, T, H, eps, st);
+        if (fs == 1) {
             EMO_LAUNCH_CHECK();
             return EMO_OK;
         }
     }
-    { const char* e = getenv("EMO_FAVOR_FS"); EMO_CHECK(!(e && atoi(e) == 2 && which == 0), "favor attention: EMO_FAVOR_FS=2 but the slice kernels do not cover this call"); }
+    { const char* e = getenv("EMO_FAVOR_FS"); EMO_CHECK(!(e && atoi(e) == 2 && fs != 1), "favor attention: EMO_FAVOR_FS=2 but the slice kernels do not cover this call"); }
     float* wsS = (float*)workspace;
     float* wsz = wsS ? wsS + B * H * P * (int64_t)F * DH : nullptr;
     dim3 grid((unsigned)(B * H * P));
@@ -1340,8 +1342,9 @@ static int run_favor(int which, const void* q, const void* k, const void* v, int
         if (P > 1)
             hipLaunchKernelGGL(k0, grid, dim3(FT), l0, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (CT*)nullptr, ld_out, (float*)nullptr,
                                (float*)nullptr, (float*)nullptr, T, H, eps, wsS, wsz, P, Ts);
-        hipLaunchKernelGGL(k1, grid, dim3(FT), l1, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
-                           (CT*)dq, ld_d, T, H, (const float*)wsS, (const float*)wsz, P | (getenv("EMO_FAVOR_ABLATE_DQ") ? atoi(getenv("EMO_FAVOR_ABLATE_DQ")) << 8 : 0), Ts);
+        if (fs != 2)
+            hipLaunchKernelGGL(k1, grid, dim3(FT), l1, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
+                               (CT*)dq, ld_d, T, H, (const float*)wsS, (const float*)wsz, P | (getenv("EMO_FAVOR_ABLATE_DQ") ? atoi(getenv("EMO_FAVOR_ABLATE_DQ")) << 8 : 0), Ts);
         if (P > 1)
             hipLaunchKernelGGL(k2s, grid, dim3(FT), l2, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
                                (CT*)dk, (CT*)dv, ld_d, T, H, wsS, wsz, P, Ts);

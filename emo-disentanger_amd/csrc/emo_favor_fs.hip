@@ -344,23 +344,577 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_fwd_kernel(const bf16_t* __
         }
     }
 }
+
+// =============================================================================================== backward: dq (forward sweep)
+// Per (b, h): dPhi_q[t][f] = sum_{j<=t} P[t][j] Kf[j][f] + sum_d' G'[t][d'] S'[f][d'],  P[t][j] = dN_t.v_j + dD_t,  G' = [dN | dD],
+// S' = running sum of Kf_j (x) [v_j | 1];  dU = dPhi+ Phi+ - dPhi- Phi-;  dq = c (W dU - c q sum_f dPhi Phi).
+// Wave w owns the feature slice f in {16w..16w+15} u {64+16w..} for everything up to dU (state S'^T[all d'][slice] in accumulators, its
+// own K features transposed through a PRIVATE 2-KB LDS image, its own Q features in registers for the Jacobian); the waves then exchange
+// dU (bf16, [32 t][64 m]) and their partial row sums, and each computes the dq columns d in [16w, 16w+16).  The P matrix and dN / dD are
+// computed by every wave (6 + 4 MFMAs: cheaper than another barrier).  dD_t = -(dout_t.out_t)/den_t is the diagonal of an MFMA Gram
+// product of the out and dout fragments; z.dD enters through the ones column of V' (16x16x16 MFMA against the z tile of the state).
+// q, k, v, dout, out rows and den arrive through a 3-slot LDS-DMA ring (6 DMA instructions per wave and chunk).  One barrier per chunk.
+constexpr int FS_SLOTB = 5 * FS_TILEB;                 // q, k, v, dout, out of one chunk
+template <> __device__ __forceinline__ void fs_wait<12>() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+__device__ __forceinline__ void fs_dma4(const void* gsrc, uint32_t lds_dst) {   // 4 B per lane (den): 256 B per wave instruction
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ f32x4 mma16(bf16x4 a, bf16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4v, a), __builtin_bit_cast(short4v, b), c, 0, 0, 0);
+}
+// permuted-k fragment (k-step s: elements 32 s + 4 g .. +3 and 32 s + 16 + 4 g .. +3) of row row0 + c of a swizzled ring tile
+__device__ __forceinline__ bf16x8 fs_ring_perm(const char* tile, int row0, int s, int g, int c) {
+    const int row = row0 + c, ch = 4 * s + (g >> 1), sw = row & 7;
+    const char* base = tile + row * FS_ROWB + (g & 1) * 8;
+    const bf16x4 lo = *(const bf16x4*)(base + ((ch ^ sw) << 4)), hi = *(const bf16x4*)(base + (((ch + 2) ^ sw) << 4));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ float fs_diag_sum_rows(const f32x4& gm, int g, int c) {   // diagonal element of column c, in every row group
+    const int r = c & 3;
+    const float d = r == 0 ? gm[0] : r == 1 ? gm[1] : r == 2 ? gm[2] : gm[3];
+    return fs_sum_rows(g == (c >> 2) ? d : 0.f);
+}
+__device__ __forceinline__ bf16x8 fs_scale8(const bf16x8& x, float a) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (bf16_t)((float)x[e] * a);
+    return r;
+}
+
+__global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                               int64_t ld, const float* __restrict__ omega, const bf16_t* __restrict__ out,
+                                                               const bf16_t* __restrict__ dout, int64_t ld_out, const float* __restrict__ den_g,
+                                                               bf16_t* __restrict__ dq, int64_t ld_d, int64_t T, int64_t H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* RING = smem;                                 // [3 slots][q, k, v, dout, out][32 rows][128 B]
+    char* DEN = RING + 3 * FS_SLOTB;                   // [3 slots][64 floats]
+    char* KP = DEN + 3 * 256;                          // [4 waves][32 rows][64 B]   private K-feature images (8-B pieces XOR-swizzled)
+    char* DU = KP + 4 * 2048;                          // [2][32 rows][128 B]        dU rows (16-B pieces XOR-swizzled)
+    float* SA = (float*)(DU + 2 * FS_TILEB);           // [2][4 waves][32]           partial sum_f dPhi Phi
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;
+    const bf16_t* qb = q + (b * T) * ld + h * 64;
+    const bf16_t* kb = k + (b * T) * ld + h * 64;
+    const bf16_t* vb = v + (b * T) * ld + h * 64;
+    const bf16_t* ob = out + (b * T) * ld_out + h * 64;
+    const bf16_t* gb = dout + (b * T) * ld_out + h * 64;
+    bf16_t* dqb = dq + (b * T) * ld_d + h * 64;
+    const float* dnb = den_g + bh * T;
+    const float cs = rsqrtf(sqrtf(64.f));
+    const float cs2 = cs * FS_LOG2E, c2h = 0.5f * cs * cs * FS_LOG2E, hl = 0.5f * logf(128.f) * FS_LOG2E;
+
+    bf16x8 wop[2], wrow[2];                            // omega^T rows m = 16 w + c (k = d);  omega rows d = 16 w + c (k = m)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            wop[s][e] = (bf16_t)omega[(32 * s + 8 * g + e) * 64 + 16 * w + c];
+            wrow[s][e] = (bf16_t)omega[(16 * w + c) * 64 + 32 * s + 8 * g + e];
+        }
+    bf16x8 oneop;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) oneop[e] = (bf16_t)(c == 0 ? 1.f : 0.f);
+
+    f32x4 ST[5][2];                                    // S'^T tiles: rows d' = 16 dl + 4 g + r (dl = 4: row 64 = z), column f = slice element c (plus / minus)
+#pragma unroll
+    for (int dl = 0; dl < 5; ++dl) { ST[dl][0] = zero4(); ST[dl][1] = zero4(); }
+
+    const int nch = (int)(T / FS_C);
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(RING)), den_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(DEN));
+    const int srow = 8 * w + (lane >> 3), spc = ((lane & 7) ^ (lane >> 3)) << 3;
+    const int64_t so_qkv = (int64_t)srow * ld + spc, so_o = (int64_t)srow * ld_out + spc;
+    auto issue = [&](int n) {
+        const int64_t t0n = (int64_t)n * FS_C;
+        const uint32_t dst = ring_lds + (n % 3) * FS_SLOTB + w * 1024;
+        fs_dma16(qb + t0n * ld + so_qkv, dst);
+        fs_dma16(kb + t0n * ld + so_qkv, dst + FS_TILEB);
+        fs_dma16(vb + t0n * ld + so_qkv, dst + 2 * FS_TILEB);
+        fs_dma16(gb + t0n * ld_out + so_o, dst + 3 * FS_TILEB);
+        fs_dma16(ob + t0n * ld_out + so_o, dst + 4 * FS_TILEB);
+        const int64_t tl = t0n + lane;
+        fs_dma4(dnb + (tl < T ? tl : T - 1), den_lds + (n % 3) * 256);      // (every wave writes the same 256 B: keeps the DMA count uniform)
+    };
+    issue(0);
+    if (nch > 1) issue(1);
+    if (nch > 2) issue(2);
+    if (nch > 2) fs_wait<12>(); else if (nch > 1) fs_wait<6>(); else fs_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    char* KPw = KP + w * 2048;
+    bf16x4 o_prev[2] = {};
+    for (int i = 0; i < nch; ++i) {
+        const int64_t t0 = (int64_t)i * FS_C;
+        const char* Xq = RING + (i % 3) * FS_SLOTB;
+        const char* Xk = Xq + FS_TILEB;
+        const char* Xv = Xq + 2 * FS_TILEB;
+        const char* Xg = Xq + 3 * FS_TILEB;
+        const char* Xo = Xq + 4 * FS_TILEB;
+        const float* dens = (const float*)(DEN + (i % 3) * 256);
+        char* DUb = DU + (i & 1) * FS_TILEB;
+        float* SAb = SA + (i & 1) * 128;
+        // ---------------- phase A: features of the slice
+        float pq[2][4], nq[2][4];
+        {
+            bf16x8 x[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) x[j][s] = fs_ring_frag(j < 2 ? Xq : Xk, 16 * (j & 1), s, g, c);
+            float p[4][4], n[4][4];
+            fs_features<4>(wop, x, cs2, c2h, hl, g, c, p, n);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pq[tt][r] = p[tt][r]; nq[tt][r] = n[tt][r]; }
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {           // K features -> private image row j: pieces g (plus) and 4 + g (minus), swizzled by bit 2 of the row
+                const int row = 16 * jt + c, sw = ((row >> 2) & 1) << 2;
+                st4((bf16_t*)(KPw + row * 64 + ((g ^ sw) << 3)), p[2 + jt][0], p[2 + jt][1], p[2 + jt][2], p[2 + jt][3]);
+                st4((bf16_t*)(KPw + row * 64 + (((4 + g) ^ sw) << 3)), n[2 + jt][0], n[2 + jt][1], n[2 + jt][2], n[2 + jt][3]);
+            }
+        }
+        bf16x4 xown[2];                                // q[t][16 w + 4 g ..] for the last line of dq
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int row = 16 * tt + c;
+            xown[tt] = *(const bf16x4*)(Xq + row * FS_ROWB + (((2 * w + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8);
+        }
+        // dN = dout / den (B operands, permuted k), dD = -(dout . out) / den
+        bf16x8 gop[2][2];
+        float dD[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const bf16x8 d0 = fs_ring_perm(Xg, 16 * tt, 0, g, c), d1 = fs_ring_perm(Xg, 16 * tt, 1, g, c);
+            const bf16x8 o0 = fs_ring_perm(Xo, 16 * tt, 0, g, c), o1 = fs_ring_perm(Xo, 16 * tt, 1, g, c);
+            f32x4 gm = mma32(o0, d0, zero4());
+            gm = mma32(o1, d1, gm);
+            const float inv = 1.f / dens[16 * tt + c];
+            dD[tt] = -fs_diag_sum_rows(gm, g, c) * inv;
+            gop[tt][0] = fs_scale8(d0, inv);
+            gop[tt][1] = fs_scale8(d1, inv);
+        }
+        // P^T(jt, tt) = V G^T + dD, masked j <= t
+        bf16x8 at[2];
+        {
+            bf16x8 vr[2][2];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) vr[jt][s] = fs_ring_perm(Xv, 16 * jt, s, g, c);
+            f32x4 p00 = mma32(vr[0][0], gop[0][0], zero4()), p01 = mma32(vr[0][0], gop[1][0], zero4()), p11 = mma32(vr[1][0], gop[1][0], zero4());
+            p00 = mma32(vr[0][1], gop[0][1], p00);
+            p01 = mma32(vr[0][1], gop[1][1], p01);
+            p11 = mma32(vr[1][1], gop[1][1], p11);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool keep = (4 * g + r) <= c;
+                p00[r] = keep ? p00[r] + dD[0] : 0.f;
+                p01[r] = p01[r] + dD[1];
+                p11[r] = keep ? p11[r] + dD[1] : 0.f;
+            }
+            at[0] = pack8(p00, zero4());
+            at[1] = pack8(p01, p11);
+        }
+        // K features of the slice, transposed (rows f, permuted k = j)
+        bf16x8 kfT[2];
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int row = hh * 16 + g * 4 + (c >> 2), pc = (4 * ph + (c & 3)) ^ (((row >> 2) & 1) << 2);
+                const short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(KPw + row * 64 + (pc << 3)));
+                const bf16x4 tb = __builtin_bit_cast(bf16x4, t);
+                kfT[ph][hh * 4 + 0] = tb[0]; kfT[ph][hh * 4 + 1] = tb[1]; kfT[ph][hh * 4 + 2] = tb[2]; kfT[ph][hh * 4 + 3] = tb[3];
+            }
+        }
+        // dPhi_q^T(ph, tt) = Kf^T P^T + S' G'^T (state BEFORE this chunk), then the Jacobian
+        {
+            bf16x8 sop[2][2];
+            bf16x4 szop[2];
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                sop[ph][0] = pack8(ST[0][ph], ST[1][ph]);
+                sop[ph][1] = pack8(ST[2][ph], ST[3][ph]);
+                szop[ph] = (bf16x4){(bf16_t)ST[4][ph][0], (bf16_t)ST[4][ph][1], (bf16_t)ST[4][ph][2], (bf16_t)ST[4][ph][3]};
+            }
+            f32x4 dph[2][2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const bf16x4 ddop = {(bf16_t)(g == 0 ? dD[tt] : 0.f), (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    f32x4 a = mma32(kfT[ph], at[tt], zero4());
+                    a = mma32(sop[ph][0], gop[tt][0], a);
+                    a = mma32(sop[ph][1], gop[tt][1], a);
+                    dph[ph][tt] = mma16(szop[ph], ddop, a);
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                float du[4], sa = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ap = dph[0][tt][r] * pq[tt][r], am = dph[1][tt][r] * nq[tt][r];
+                    du[r] = ap - am;
+                    sa += ap + am;
+                }
+                sa = fs_sum_rows(sa);
+                const int row = 16 * tt + c;
+                st4((bf16_t*)(DUb + row * FS_ROWB + (((2 * w + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8), du[0], du[1], du[2], du[3]);
+                if (g == 0) SAb[w * 32 + row] = sa;
+            }
+        }
+        // state: S'^T[d'][f] += sum_j V'^T[d'][j] Kf[j][f]
+#pragma unroll
+        for (int dl = 0; dl < 4; ++dl) {
+            const bf16x8 vT = fs_ring_perm_tr(Xv, 16 * dl, lane);
+            ST[dl][0] = mma32(vT, kfT[0], ST[dl][0]);
+            ST[dl][1] = mma32(vT, kfT[1], ST[dl][1]);
+        }
+        ST[4][0] = mma32(oneop, kfT[0], ST[4][0]);
+        ST[4][1] = mma32(oneop, kfT[1], ST[4][1]);
+        if (i + 2 < nch) fs_wait<6>(); else fs_wait<0>();
+        if (i > 0) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) *(bf16x4*)(dqb + (t0 - FS_C + 16 * tt + c) * ld_d + 16 * w + 4 * g) = o_prev[tt];
+        }
+        fs_barrier();
+        if (i + 3 < nch) issue(i + 3);
+        // ---------------- phase C: dq columns d in [16 w, 16 w + 16)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int row = 16 * tt + c;
+            const bf16x8 u0 = *(const bf16x8*)(DUb + row * FS_ROWB + (((g) ^ (row & 7)) << 4)), u1 = *(const bf16x8*)(DUb + row * FS_ROWB + (((4 + g) ^ (row & 7)) << 4));
+            f32x4 dx = mma32(wrow[0], u0, zero4());
+            dx = mma32(wrow[1], u1, dx);
+            const float sa = (SAb[row] + SAb[32 + row]) + (SAb[64 + row] + SAb[96 + row]);
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = cs * (dx[r] - cs * (float)xown[tt][r] * sa);
+            o_prev[tt] = (bf16x4){(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+        }
+    }
+    {
+        const int64_t t0 = (int64_t)nch * FS_C;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) *(bf16x4*)(dqb + (t0 - FS_C + 16 * tt + c) * ld_d + 16 * w + 4 * g) = o_prev[tt];
+    }
+}
+
+// =============================================================================================== backward: dk, dv (reverse sweep)
+// Chunks are walked from the last to the first; state = sums over the LATER tokens t of Qf_t (x) G'_t, kept twice:
+//   RT  = R'^T[all d' (+ the dD column)][feature slice of the wave]   -> dPhi_k (split by feature, like dq)
+//   RD  = R[all f][d in 16w..16w+15]                                  -> dV      (split by output column, like the forward)
+// dPhi_k[j][f] = sum_{t>=j} P[t][j] Qf[t][f] + sum_d' V'[j][d'] R'[f][d'];  dV[j][d] = sum_{t>=j} A[t][j] dN[t][d] + sum_f Kf[j][f] R[f][d].
+// Two barriers per chunk: after the features went to the shared QF / KF images (the A matrix and RD need every feature), and after dU / the
+// row sums were published (dk columns need every m).  1 / den is folded into the OPERAND that is indexed by t (Qf^T for RT, the wave's own
+// dN^T fragment for RD / dV), so the dout rows are used raw from the ring (transpose reads) and no scaled dN image is built.
+// q, k, v, dout, out, den: 2-slot LDS-DMA ring (an iteration is long enough to cover the HBM round trip of the next-but-one chunk).
+__global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                                int64_t ld, const float* __restrict__ omega, const bf16_t* __restrict__ out,
+                                                                const bf16_t* __restrict__ dout, int64_t ld_out, const float* __restrict__ den_g,
+                                                                bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t ld_d, int64_t T, int64_t H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* RING = smem;                                 // [2 slots][q, k, v, dout, out][32 rows][128 B]
+    char* DEN = RING + 2 * FS_SLOTB;                   // [2 slots][64 floats]
+    bf16_t* QF = (bf16_t*)(DEN + 2 * 256);             // [32][LDF]  shared feature images (single buffer: two barriers per chunk)
+    bf16_t* KF = QF + FS_C * FS_LDF;
+    char* DU = (char*)(KF + FS_C * FS_LDF);            // [32 rows][128 B]  dU rows (16-B pieces XOR-swizzled)
+    float* SA = (float*)(DU + FS_TILEB);               // [4 waves][32]
+    float* PV = SA + 128;                              // [4 waves][dD 32 | -dot 32 | 1/den 32]   private
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;
+    const bf16_t* qb = q + (b * T) * ld + h * 64;
+    const bf16_t* kb = k + (b * T) * ld + h * 64;
+    const bf16_t* vb = v + (b * T) * ld + h * 64;
+    const bf16_t* ob = out + (b * T) * ld_out + h * 64;
+    const bf16_t* gb = dout + (b * T) * ld_out + h * 64;
+    bf16_t* dkb = dk + (b * T) * ld_d + h * 64;
+    bf16_t* dvb = dv + (b * T) * ld_d + h * 64;
+    const float* dnb = den_g + bh * T;
+    const float cs = rsqrtf(sqrtf(64.f));
+    const float cs2 = cs * FS_LOG2E, c2h = 0.5f * cs * cs * FS_LOG2E, hl = 0.5f * logf(128.f) * FS_LOG2E;
+
+    bf16x8 wop[2], wrow[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            wop[s][e] = (bf16_t)omega[(32 * s + 8 * g + e) * 64 + 16 * w + c];
+            wrow[s][e] = (bf16_t)omega[(16 * w + c) * 64 + 32 * s + 8 * g + e];
+        }
+    const bf16x4 onecol = {(bf16_t)(g == 0 ? 1.f : 0.f), (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};   // V' column 64 = 1 as 16x16x16 B operand
+
+    f32x4 RT[5][2], RD[8];
+#pragma unroll
+    for (int dl = 0; dl < 5; ++dl) { RT[dl][0] = zero4(); RT[dl][1] = zero4(); }
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft) RD[ft] = zero4();
+
+    const int nch = (int)(T / FS_C);
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(RING)), den_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(DEN));
+    const int srow = 8 * w + (lane >> 3), spc = ((lane & 7) ^ (lane >> 3)) << 3;
+    const int64_t so_qkv = (int64_t)srow * ld + spc, so_o = (int64_t)srow * ld_out + spc;
+    auto issue = [&](int n) {                          // n-th chunk of the reverse walk = chunk nch - 1 - n
+        const int64_t t0n = (int64_t)(nch - 1 - n) * FS_C;
+        const uint32_t dst = ring_lds + (n & 1) * FS_SLOTB + w * 1024;
+        fs_dma16(qb + t0n * ld + so_qkv, dst);
+        fs_dma16(kb + t0n * ld + so_qkv, dst + FS_TILEB);
+        fs_dma16(vb + t0n * ld + so_qkv, dst + 2 * FS_TILEB);
+        fs_dma16(gb + t0n * ld_out + so_o, dst + 3 * FS_TILEB);
+        fs_dma16(ob + t0n * ld_out + so_o, dst + 4 * FS_TILEB);
+        const int64_t tl = t0n + lane;
+        fs_dma4(dnb + (tl < T ? tl : T - 1), den_lds + (n & 1) * 256);
+    };
+    issue(0);
+    if (nch > 1) issue(1);
+    if (nch > 1) fs_wait<6>(); else fs_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    float* PVw = PV + w * 96;
+    bf16x4 dk_prev[2] = {}, dv_prev[2] = {};
+    for (int n = 0; n < nch; ++n) {
+        const int64_t t0 = (int64_t)(nch - 1 - n) * FS_C;
+        const char* Xq = RING + (n & 1) * FS_SLOTB;
+        const char* Xk = Xq + FS_TILEB;
+        const char* Xv = Xq + 2 * FS_TILEB;
+        const char* Xg = Xq + 3 * FS_TILEB;
+        const char* Xo = Xq + 4 * FS_TILEB;
+        const float* dens = (const float*)(DEN + (n & 1) * 256);
+        // ---------------- phase A1: features -> shared images; dN, dD; P
+        {
+            bf16x8 x[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) x[j][s] = fs_ring_frag(j < 2 ? Xq : Xk, 16 * (j & 1), s, g, c);
+            float p[4][4], nn[4][4];
+            fs_features<4>(wop, x, cs2, c2h, hl, g, c, p, nn);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16_t* dst = (j < 2 ? QF : KF) + (16 * (j & 1) + c) * FS_LDF + 16 * w + 4 * g;
+                st4(dst, p[j][0], p[j][1], p[j][2], p[j][3]);
+                st4(dst + 64, nn[j][0], nn[j][1], nn[j][2], nn[j][3]);
+            }
+        }
+        bf16x4 xown[2];                                // k[j][16 w + 4 g ..]
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const int row = 16 * jt + c;
+            xown[jt] = *(const bf16x4*)(Xk + row * FS_ROWB + (((2 * w + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8);
+        }
+        bf16x8 gA[2][2];                               // dN rows t as A operand (permuted k = d)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const bf16x8 d0 = fs_ring_perm(Xg, 16 * tt, 0, g, c), d1 = fs_ring_perm(Xg, 16 * tt, 1, g, c);
+            const bf16x8 o0 = fs_ring_perm(Xo, 16 * tt, 0, g, c), o1 = fs_ring_perm(Xo, 16 * tt, 1, g, c);
+            f32x4 gm = mma32(o0, d0, zero4());
+            gm = mma32(o1, d1, gm);
+            const float inv = 1.f / dens[16 * tt + c];
+            const float dot = fs_diag_sum_rows(gm, g, c);
+            if (g == 0) { PVw[16 * tt + c] = -dot * inv; PVw[32 + 16 * tt + c] = -dot; PVw[64 + 16 * tt + c] = inv; }
+            gA[tt][0] = fs_scale8(d0, inv);
+            gA[tt][1] = fs_scale8(d1, inv);
+        }
+        bf16x8 pb[2];                                  // P[t][j] = dN_t.v_j + dD_t, t >= j: rows t = 16 tt + 4 g + r, column j
+        {
+            bf16x8 vB[2][2];                           // V rows j as B operand (permuted k = d)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) vB[jt][s] = fs_ring_perm(Xv, 16 * jt, s, g, c);
+            f32x4 p00 = mma32(gA[0][0], vB[0][0], zero4()), p10 = mma32(gA[1][0], vB[0][0], zero4()), p11 = mma32(gA[1][0], vB[1][0], zero4());
+            p00 = mma32(gA[0][1], vB[0][1], p00);
+            p10 = mma32(gA[1][1], vB[0][1], p10);
+            p11 = mma32(gA[1][1], vB[1][1], p11);
+            const f32x4 dd0 = *(const f32x4*)(PVw + 4 * g), dd1 = *(const f32x4*)(PVw + 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool keep = (4 * g + r) >= c;
+                p00[r] = keep ? p00[r] + dd0[r] : 0.f;
+                p10[r] = p10[r] + dd1[r];
+                p11[r] = keep ? p11[r] + dd1[r] : 0.f;
+            }
+            pb[0] = pack8(p00, p10);
+            pb[1] = pack8(zero4(), p11);
+        }
+        fs_barrier();                                  // X: the shared feature images are complete
+        // ---------------- phase B (operands are re-read from LDS where that shortens a live range: the kernel sits at the 256-register edge)
+        bf16x8 ab[2];                                  // A[t][j] = Qf_t.Kf_j, t >= j
+        {
+            bf16x8 qfA[2][4], kfB[2][4];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { qfA[tt][s] = load_perm<bf16_t>(QF, FS_LDF, 16 * tt, s, lane); kfB[tt][s] = load_perm<bf16_t>(KF, FS_LDF, 16 * tt, s, lane); }
+            f32x4 aa[3][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                aa[0][u] = mma32(qfA[0][u], kfB[0][u], zero4());
+                aa[1][u] = mma32(qfA[1][u], kfB[0][u], zero4());
+                aa[2][u] = mma32(qfA[1][u], kfB[1][u], zero4());
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                aa[0][u] = mma32(qfA[0][2 + u], kfB[0][2 + u], aa[0][u]);
+                aa[1][u] = mma32(qfA[1][2 + u], kfB[0][2 + u], aa[1][u]);
+                aa[2][u] = mma32(qfA[1][2 + u], kfB[1][2 + u], aa[2][u]);
+            }
+            f32x4 a00 = aa[0][0] + aa[0][1], a11 = aa[2][0] + aa[2][1];
+            const f32x4 a10 = aa[1][0] + aa[1][1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool keep = (4 * g + r) >= c;
+                a00[r] = keep ? a00[r] : 0.f;
+                a11[r] = keep ? a11[r] : 0.f;
+            }
+            ab[0] = pack8(a00, a10);
+            ab[1] = pack8(zero4(), a11);
+        }
+        // 1 / den of the lane's eight t positions (permuted k = t), the slice's Qf^T plain and scaled
+        const f32x4 iv0 = *(const f32x4*)(PVw + 64 + 4 * g), iv1 = *(const f32x4*)(PVw + 64 + 16 + 4 * g);
+        auto scale_t = [&](const bf16x8& x) {
+            return (bf16x8){(bf16_t)((float)x[0] * iv0[0]), (bf16_t)((float)x[1] * iv0[1]), (bf16_t)((float)x[2] * iv0[2]), (bf16_t)((float)x[3] * iv0[3]),
+                            (bf16_t)((float)x[4] * iv1[0]), (bf16_t)((float)x[5] * iv1[1]), (bf16_t)((float)x[6] * iv1[2]), (bf16_t)((float)x[7] * iv1[3])};
+        };
+        bf16x8 qfTs[2];
+        // dPhi_k^T(ph, jt) = Qf^T P + R' V'^T (state of the LATER chunks): four independent chains, then the Jacobian with the slice's K features
+        {
+            bf16x8 qfT[2], vB[2][2];
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                qfT[ph] = load_perm_tr(QF, FS_LDF, 16 * w + 64 * ph, 0, lane);
+                qfTs[ph] = scale_t(qfT[ph]);
+            }
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) vB[jt][s] = fs_ring_perm(Xv, 16 * jt, s, g, c);
+            f32x4 dph[2][2];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) dph[jt][ph] = mma32(qfT[ph], pb[jt], zero4());
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    const bf16x8 rop = pack8(RT[2 * s][ph], RT[2 * s + 1][ph]);
+#pragma unroll
+                    for (int jt = 0; jt < 2; ++jt) dph[jt][ph] = mma32(rop, vB[jt][s], dph[jt][ph]);
+                }
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const bf16x4 rzop = {(bf16_t)RT[4][ph][0], (bf16_t)RT[4][ph][1], (bf16_t)RT[4][ph][2], (bf16_t)RT[4][ph][3]};
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) dph[jt][ph] = mma16(rzop, onecol, dph[jt][ph]);
+            }
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const int row = 16 * jt + c;
+                const bf16x4 kp = *(const bf16x4*)(KF + row * FS_LDF + 16 * w + 4 * g), kn = *(const bf16x4*)(KF + row * FS_LDF + 64 + 16 * w + 4 * g);
+                float du[4], sa = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ap = dph[jt][0][r] * (float)kp[r], am = dph[jt][1][r] * (float)kn[r];
+                    du[r] = ap - am;
+                    sa += ap + am;
+                }
+                sa = fs_sum_rows(sa);
+                st4((bf16_t*)(DU + row * FS_ROWB + (((2 * w + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8), du[0], du[1], du[2], du[3]);
+                if (g == 0) SA[w * 32 + row] = sa;
+            }
+        }
+        // dV^T for the wave's columns: dN^T A + R^T Kf^T  (two independent chains)
+        const bf16x8 gTs = scale_t(fs_ring_perm_tr(Xg, 16 * w, lane));       // dN^T rows d = 16 w + i, permuted k = t
+        {
+            f32x4 a0 = mma32(gTs, ab[0], zero4()), a1 = mma32(gTs, ab[1], zero4());
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 rd = pack8(RD[2 * s], RD[2 * s + 1]);
+                a0 = mma32(rd, load_perm<bf16_t>(KF, FS_LDF, 0, s, lane), a0);
+                a1 = mma32(rd, load_perm<bf16_t>(KF, FS_LDF, 16, s, lane), a1);
+            }
+            dv_prev[0] = (bf16x4){(bf16_t)a0[0], (bf16_t)a0[1], (bf16_t)a0[2], (bf16_t)a0[3]};
+            dv_prev[1] = (bf16x4){(bf16_t)a1[0], (bf16_t)a1[1], (bf16_t)a1[2], (bf16_t)a1[3]};
+        }
+        // states
+#pragma unroll
+        for (int dl = 0; dl < 4; ++dl) {
+            const bf16x8 gT = fs_ring_perm_tr(Xg, 16 * dl, lane);             // raw dout^T: 1 / den sits in qfTs
+            RT[dl][0] = mma32(gT, qfTs[0], RT[dl][0]);
+            RT[dl][1] = mma32(gT, qfTs[1], RT[dl][1]);
+        }
+        {
+            const f32x4 nd0 = *(const f32x4*)(PVw + 32 + 4 * g), nd1 = *(const f32x4*)(PVw + 32 + 16 + 4 * g);
+            bf16x8 ndop = pack8(nd0, nd1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ndop[e] = c == 0 ? ndop[e] : (bf16_t)0.f;  // row d' = 64 of G'^T: dD_t = -dot_t / den_t, 1 / den again in qfTs
+            RT[4][0] = mma32(ndop, qfTs[0], RT[4][0]);
+            RT[4][1] = mma32(ndop, qfTs[1], RT[4][1]);
+        }
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft) RD[ft] = mma32(load_perm_tr(QF, FS_LDF, 16 * ft, 0, lane), gTs, RD[ft]);
+        fs_wait<0>();                                   // chunk n + 1 landed (issued one iteration ago); older stores drained
+        if (n > 0) {
+            const int64_t tp = t0 + FS_C;               // the previous iteration's chunk
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) *(bf16x4*)(dkb + (tp + 16 * jt + c) * ld_d + 16 * w + 4 * g) = dk_prev[jt];
+        }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) *(bf16x4*)(dvb + (t0 + 16 * jt + c) * ld_d + 16 * w + 4 * g) = dv_prev[jt];
+        fs_barrier();                                  // Y: dU / row sums published, ring slot and feature images free
+        if (n + 2 < nch) issue(n + 2);
+        // ---------------- phase C: dk columns d in [16 w, 16 w + 16)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const int row = 16 * jt + c;
+            const bf16x8 u0 = *(const bf16x8*)(DU + row * FS_ROWB + ((g ^ (row & 7)) << 4)), u1 = *(const bf16x8*)(DU + row * FS_ROWB + (((4 + g) ^ (row & 7)) << 4));
+            f32x4 dx = mma32(wrow[0], u0, zero4());
+            dx = mma32(wrow[1], u1, dx);
+            const float sa = (SA[row] + SA[32 + row]) + (SA[64 + row] + SA[96 + row]);
+            dk_prev[jt] = (bf16x4){(bf16_t)(cs * (dx[0] - cs * (float)xown[jt][0] * sa)), (bf16_t)(cs * (dx[1] - cs * (float)xown[jt][1] * sa)),
+                                   (bf16_t)(cs * (dx[2] - cs * (float)xown[jt][2] * sa)), (bf16_t)(cs * (dx[3] - cs * (float)xown[jt][3] * sa))};
+        }
+    }
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) *(bf16x4*)(dkb + (16 * jt + c) * ld_d + 16 * w + 4 * g) = dk_prev[jt];     // chunk 0 was the last one
+}
 }  // namespace
 
-// which: 0 forward, 1 backward.  Returns false when the shape / mode is not covered (the caller then runs the generic kernels).
-bool emo_favor_fs_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const float* omega, bf16_t* out, int64_t ld_out, float* den,
+// which: 0 forward, 1 backward.  Returns 0 when the shape / mode is not covered (the caller then runs the generic kernels), 1 when the call
+// was served completely, 2 when dq was written and the caller still has to run the generic dk / dv kernel.
+int emo_favor_fs_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const float* omega, bf16_t* out, int64_t ld_out, float* den,
                       float* sS, float* sz, const bf16_t* dout, bf16_t* dq, bf16_t* dk, bf16_t* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, float eps,
                       hipStream_t st) {
     const char* e = getenv("EMO_FAVOR_FS");                // (read per call: tests toggle it in-process)  "0": generic kernels only
-    if (e && atoi(e) == 0) return false;
-    if (T < FS_C || (T % FS_C) != 0 || B * H <= 0) return false;
-    if ((ld & 7) || (ld_out & 3)) return false;
+    if (e && atoi(e) == 0) return 0;
+    if (T < FS_C || (T % FS_C) != 0 || B * H <= 0) return 0;
+    if ((ld & 7) || (ld_out & 7) || (ld_d & 3)) return 0;
     dim3 grid((unsigned)(B * H));
     if (which == 0) {
         const size_t lds = (size_t)(3 * 2 + 4) * FS_TILEB + sizeof(bf16_t) * (size_t)(4 * FS_C * FS_LDF);
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)favor_fs_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
         hipLaunchKernelGGL(favor_fs_fwd_kernel, grid, dim3(FS_NT), lds, st, q, k, v, ld, omega, out, ld_out, den, sS, sz, T, H, eps);
-        return true;
+        return 1;
     }
-    return false;
+    {
+        const char* e2 = getenv("EMO_FAVOR_FS_BWD");           // "0": generic backward kernels
+        if (e2 && atoi(e2) == 0) return 0;
+        const size_t lds = (size_t)3 * FS_SLOTB + 3 * 256 + 4 * 2048 + 2 * FS_TILEB + 2 * 4 * 32 * sizeof(float);
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)favor_fs_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        hipLaunchKernelGGL(favor_fs_dq_kernel, grid, dim3(FS_NT), lds, st, q, k, v, ld, omega, (const bf16_t*)out, dout, ld_out, (const float*)den, dq, ld_d, T, H);
+        if (e2 && atoi(e2) == 1) return 2;                     // "1": slice dq + generic dk / dv
+        const size_t lds2 = (size_t)2 * FS_SLOTB + 2 * 256 + sizeof(bf16_t) * (size_t)(2 * FS_C * FS_LDF) + FS_TILEB + sizeof(float) * (128 + 4 * 96);
+        static bool attr2 = false;
+        if (!attr2) { (void)hipFuncSetAttribute((const void*)favor_fs_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr2 = true; }
+        hipLaunchKernelGGL(favor_fs_dkv_kernel, grid, dim3(FS_NT), lds2, st, q, k, v, ld, omega, (const bf16_t*)out, dout, ld_out, (const float*)den, dk, dv, ld_d, T, H);
+        return 1;
+    }
 }

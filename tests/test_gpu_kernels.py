@@ -460,7 +460,7 @@ def test_favor_slice_kernels_vs_oracle_and_generic(B, T, H, monkeypatch):
     ref.backward(dout.double())
     qc, HD = qkv.cuda(), H * dh
     res = {}
-    for mode in ('2', '0'):                                 # 2: slice kernels REQUIRED (the call fails if they do not run), 0: generic kernels
+    for mode in ('2', '0'):                                 # 2: slice kernels REQUIRED, forward and backward (the call fails if they do not run), 0: generic kernels
         monkeypatch.setenv('EMO_FAVOR_FS', mode)
         out, den, S, z = ops.favor_attn_fwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], om.cuda(), B, T, H, want_state=True)
         _close(out.view(B, T, H, dh), ref, dt, mult=3)
