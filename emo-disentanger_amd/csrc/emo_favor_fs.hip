@@ -22,6 +22,23 @@
 
 #include "emo_lds_mma.h"
 
+#ifdef EMO_DIAG
+__device__ unsigned long long emo_fs_diag[64];             // diagnostics build only: per-phase cycle sums (tools/fs_cycles.py)
+extern "C" int emo_diag_fetch(unsigned long long* host, int n, int reset) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(emo_fs_diag), sizeof(unsigned long long) * n) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[64] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(emo_fs_diag), z, sizeof(z)); }
+    return 0;
+}
+#define FSD_BEGIN uint64_t tc_[16] = {}, ts_ = __builtin_readcyclecounter(), tstart_ = ts_;
+#define FSD(k) do { const uint64_t tn_ = __builtin_readcyclecounter(); tc_[k] += tn_ - ts_; ts_ = tn_; } while (0)
+#define FSD_END(base, nk) do { if (lane == 0) { for (int k_ = 0; k_ < nk; ++k_) atomicAdd(&emo_fs_diag[base + k_], (unsigned long long)tc_[k_]); \
+    atomicAdd(&emo_fs_diag[base + 14], (unsigned long long)(__builtin_readcyclecounter() - tstart_)); atomicAdd(&emo_fs_diag[base + 15], 1ull); } } while (0)
+#else
+#define FSD_BEGIN
+#define FSD(k) do {} while (0)
+#define FSD_END(base, nk) do {} while (0)
+#endif
+
 namespace {
 constexpr int FS_NT = 256;                     // 4 waves
 constexpr int FS_C = 32;                       // tokens per chunk
@@ -117,6 +134,13 @@ __device__ __forceinline__ void fs_barrier() {         // LDS writes of this wav
 // operand ring once per chunk.  The compiler never sees this DMA; its completion is counted by hand (fs_wait).  lds_dst: wave-uniform
 // LDS byte address of the 1 KB the wave's 64 lanes fill; M0 is saved / restored inside the statement.
 __device__ __forceinline__ void fs_dma16(const void* gsrc, uint32_t lds_dst) {
+#ifdef FS_NO_DMA
+    return;                                            // timing ablation only: the kernels then compute on whatever the LDS holds
+#endif
+#ifdef FS_NO_M0SAVE
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory");
+    return;
+#endif
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
@@ -426,16 +450,26 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(RING)), den_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(DEN));
     const int srow = 8 * w + (lane >> 3), spc = ((lane & 7) ^ (lane >> 3)) << 3;
     const int64_t so_qkv = (int64_t)srow * ld + spc, so_o = (int64_t)srow * ld_out + spc;
-    auto issue = [&](int n) {
+    // One DMA instruction of chunk n (part 0..5: q, k, v, dout, out, den).  The six parts of a chunk are issued at six different points of
+    // the following iteration instead of back to back: right after a barrier all eight waves of the CU used to push their six 1-KB requests
+    // at once and the burst cost ~1300 cycles per wave and chunk (15 % of the kernel, s_memtime stamps).
+    auto issue_part = [&](int n, int part) {
+        if (n >= nch) return;
         const int64_t t0n = (int64_t)n * FS_C;
         const uint32_t dst = ring_lds + (n % 3) * FS_SLOTB + w * 1024;
-        fs_dma16(qb + t0n * ld + so_qkv, dst);
-        fs_dma16(kb + t0n * ld + so_qkv, dst + FS_TILEB);
-        fs_dma16(vb + t0n * ld + so_qkv, dst + 2 * FS_TILEB);
-        fs_dma16(gb + t0n * ld_out + so_o, dst + 3 * FS_TILEB);
-        fs_dma16(ob + t0n * ld_out + so_o, dst + 4 * FS_TILEB);
-        const int64_t tl = t0n + lane;
-        fs_dma4(dnb + (tl < T ? tl : T - 1), den_lds + (n % 3) * 256);      // (every wave writes the same 256 B: keeps the DMA count uniform)
+        if (part == 0) fs_dma16(qb + t0n * ld + so_qkv, dst);
+        else if (part == 1) fs_dma16(kb + t0n * ld + so_qkv, dst + FS_TILEB);
+        else if (part == 2) fs_dma16(vb + t0n * ld + so_qkv, dst + 2 * FS_TILEB);
+        else if (part == 3) fs_dma16(gb + t0n * ld_out + so_o, dst + 3 * FS_TILEB);
+        else if (part == 4) fs_dma16(ob + t0n * ld_out + so_o, dst + 4 * FS_TILEB);
+        else {
+            const int64_t tl = t0n + lane;
+            fs_dma4(dnb + (tl < T ? tl : T - 1), den_lds + (n % 3) * 256);  // (every wave writes the same 256 B: keeps the DMA count uniform)
+        }
+    };
+    auto issue = [&](int n) {
+#pragma unroll
+        for (int part = 0; part < 6; ++part) issue_part(n, part);
     };
     issue(0);
     if (nch > 1) issue(1);
@@ -445,6 +479,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
     asm volatile("" ::: "memory");
     char* KPw = KP + w * 2048;
     bf16x4 o_prev[2] = {};
+    FSD_BEGIN
     for (int i = 0; i < nch; ++i) {
         const int64_t t0 = (int64_t)i * FS_C;
         const char* Xq = RING + (i % 3) * FS_SLOTB;
@@ -455,6 +490,16 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
         const float* dens = (const float*)(DEN + (i % 3) * 256);
         char* DUb = DU + (i & 1) * FS_TILEB;
         float* SAb = SA + (i & 1) * 128;
+        // dN / dD operands first (ring reads + the Gram MFMAs), so that their latency runs under the feature phase's exponentials
+        bf16x8 dfr[2][2];
+        f32x4 gmm[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            dfr[tt][0] = fs_ring_perm(Xg, 16 * tt, 0, g, c); dfr[tt][1] = fs_ring_perm(Xg, 16 * tt, 1, g, c);
+            const bf16x8 o0 = fs_ring_perm(Xo, 16 * tt, 0, g, c), o1 = fs_ring_perm(Xo, 16 * tt, 1, g, c);
+            gmm[tt] = mma32(o0, dfr[tt][0], zero4());
+            gmm[tt] = mma32(o1, dfr[tt][1], gmm[tt]);
+        }
         // ---------------- phase A: features of the slice
         float pq[2][4], nq[2][4];
         {
@@ -476,6 +521,8 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
                 st4((bf16_t*)(KPw + row * 64 + (((4 + g) ^ sw) << 3)), n[2 + jt][0], n[2 + jt][1], n[2 + jt][2], n[2 + jt][3]);
             }
         }
+        FSD(0);
+        if (i > 0) issue_part(i + 2, 3);
         bf16x4 xown[2];                                // q[t][16 w + 4 g ..] for the last line of dq
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -487,15 +534,13 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
         float dD[2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            const bf16x8 d0 = fs_ring_perm(Xg, 16 * tt, 0, g, c), d1 = fs_ring_perm(Xg, 16 * tt, 1, g, c);
-            const bf16x8 o0 = fs_ring_perm(Xo, 16 * tt, 0, g, c), o1 = fs_ring_perm(Xo, 16 * tt, 1, g, c);
-            f32x4 gm = mma32(o0, d0, zero4());
-            gm = mma32(o1, d1, gm);
             const float inv = 1.f / dens[16 * tt + c];
-            dD[tt] = -fs_diag_sum_rows(gm, g, c) * inv;
-            gop[tt][0] = fs_scale8(d0, inv);
-            gop[tt][1] = fs_scale8(d1, inv);
+            dD[tt] = -fs_diag_sum_rows(gmm[tt], g, c) * inv;
+            gop[tt][0] = fs_scale8(dfr[tt][0], inv);
+            gop[tt][1] = fs_scale8(dfr[tt][1], inv);
         }
+        FSD(1);
+        if (i > 0) issue_part(i + 2, 4);
         // P^T(jt, tt) = V G^T + dD, masked j <= t
         bf16x8 at[2];
         {
@@ -518,6 +563,8 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
             at[0] = pack8(p00, zero4());
             at[1] = pack8(p01, p11);
         }
+        FSD(2);
+        if (i > 0) issue_part(i + 2, 5);
         // K features of the slice, transposed (rows f, permuted k = j)
         bf16x8 kfT[2];
 #pragma unroll
@@ -567,6 +614,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
                 if (g == 0) SAb[w * 32 + row] = sa;
             }
         }
+        FSD(3);
         // state: S'^T[d'][f] += sum_j V'^T[d'][j] Kf[j][f]
 #pragma unroll
         for (int dl = 0; dl < 4; ++dl) {
@@ -576,16 +624,21 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
         }
         ST[4][0] = mma32(oneop, kfT[0], ST[4][0]);
         ST[4][1] = mma32(oneop, kfT[1], ST[4][1]);
+        FSD(4);
         if (i + 2 < nch) fs_wait<6>(); else fs_wait<0>();
+        FSD(5);
         if (i > 0) {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) *(bf16x4*)(dqb + (t0 - FS_C + 16 * tt + c) * ld_d + 16 * w + 4 * g) = o_prev[tt];
         }
         fs_barrier();
-        if (i + 3 < nch) issue(i + 3);
+        FSD(6);
+        issue_part(i + 3, 0);                              // ring slot of chunk i is free; parts 3..5 follow in the next iteration's phase A
+        FSD(7);
         // ---------------- phase C: dq columns d in [16 w, 16 w + 16)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
+            issue_part(i + 3, 1 + tt);
             const int row = 16 * tt + c;
             const bf16x8 u0 = *(const bf16x8*)(DUb + row * FS_ROWB + (((g) ^ (row & 7)) << 4)), u1 = *(const bf16x8*)(DUb + row * FS_ROWB + (((4 + g) ^ (row & 7)) << 4));
             f32x4 dx = mma32(wrow[0], u0, zero4());
@@ -596,7 +649,9 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
             for (int r = 0; r < 4; ++r) o[r] = cs * (dx[r] - cs * (float)xown[tt][r] * sa);
             o_prev[tt] = (bf16x4){(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
         }
+        FSD(8);
     }
+    FSD_END(16, 9);
     {
         const int64_t t0 = (int64_t)nch * FS_C;
 #pragma unroll
@@ -677,6 +732,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
     asm volatile("" ::: "memory");
     float* PVw = PV + w * 96;
     bf16x4 dk_prev[2] = {}, dv_prev[2] = {};
+    FSD_BEGIN
     for (int n = 0; n < nch; ++n) {
         const int64_t t0 = (int64_t)(nch - 1 - n) * FS_C;
         const char* Xq = RING + (n & 1) * FS_SLOTB;
@@ -701,6 +757,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
                 st4(dst + 64, nn[j][0], nn[j][1], nn[j][2], nn[j][3]);
             }
         }
+        FSD(0);
         bf16x4 xown[2];                                // k[j][16 w + 4 g ..]
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
@@ -720,6 +777,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
             gA[tt][0] = fs_scale8(d0, inv);
             gA[tt][1] = fs_scale8(d1, inv);
         }
+        FSD(1);
         bf16x8 pb[2];                                  // P[t][j] = dN_t.v_j + dD_t, t >= j: rows t = 16 tt + 4 g + r, column j
         {
             bf16x8 vB[2][2];                           // V rows j as B operand (permuted k = d)
@@ -742,7 +800,9 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
             pb[0] = pack8(p00, p10);
             pb[1] = pack8(zero4(), p11);
         }
+        FSD(2);
         fs_barrier();                                  // X: the shared feature images are complete
+        FSD(3);
         // ---------------- phase B (operands are re-read from LDS where that shortens a live range: the kernel sits at the 256-register edge)
         bf16x8 ab[2];                                  // A[t][j] = Qf_t.Kf_j, t >= j
         {
@@ -775,6 +835,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
             ab[0] = pack8(a00, a10);
             ab[1] = pack8(zero4(), a11);
         }
+        FSD(4);
         // 1 / den of the lane's eight t positions (permuted k = t), the slice's Qf^T plain and scaled
         const f32x4 iv0 = *(const f32x4*)(PVw + 64 + 4 * g), iv1 = *(const f32x4*)(PVw + 64 + 16 + 4 * g);
         auto scale_t = [&](const bf16x8& x) {
@@ -829,6 +890,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
                 if (g == 0) SA[w * 32 + row] = sa;
             }
         }
+        FSD(5);
         // dV^T for the wave's columns: dN^T A + R^T Kf^T  (two independent chains)
         const bf16x8 gTs = scale_t(fs_ring_perm_tr(Xg, 16 * w, lane));       // dN^T rows d = 16 w + i, permuted k = t
         {
@@ -842,6 +904,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
             dv_prev[0] = (bf16x4){(bf16_t)a0[0], (bf16_t)a0[1], (bf16_t)a0[2], (bf16_t)a0[3]};
             dv_prev[1] = (bf16x4){(bf16_t)a1[0], (bf16_t)a1[1], (bf16_t)a1[2], (bf16_t)a1[3]};
         }
+        FSD(6);
         // states
 #pragma unroll
         for (int dl = 0; dl < 4; ++dl) {
@@ -859,7 +922,9 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
         }
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) RD[ft] = mma32(load_perm_tr(QF, FS_LDF, 16 * ft, 0, lane), gTs, RD[ft]);
+        FSD(7);
         fs_wait<0>();                                   // chunk n + 1 landed (issued one iteration ago); older stores drained
+        FSD(8);
         if (n > 0) {
             const int64_t tp = t0 + FS_C;               // the previous iteration's chunk
 #pragma unroll
@@ -868,7 +933,9 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) *(bf16x4*)(dvb + (t0 + 16 * jt + c) * ld_d + 16 * w + 4 * g) = dv_prev[jt];
         fs_barrier();                                  // Y: dU / row sums published, ring slot and feature images free
+        FSD(9);
         if (n + 2 < nch) issue(n + 2);
+        FSD(10);
         // ---------------- phase C: dk columns d in [16 w, 16 w + 16)
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
@@ -880,7 +947,9 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
             dk_prev[jt] = (bf16x4){(bf16_t)(cs * (dx[0] - cs * (float)xown[jt][0] * sa)), (bf16_t)(cs * (dx[1] - cs * (float)xown[jt][1] * sa)),
                                    (bf16_t)(cs * (dx[2] - cs * (float)xown[jt][2] * sa)), (bf16_t)(cs * (dx[3] - cs * (float)xown[jt][3] * sa))};
         }
+        FSD(11);
     }
+    FSD_END(32, 12);
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) *(bf16x4*)(dkb + (16 * jt + c) * ld_d + 16 * w + 4 * g) = dk_prev[jt];     // chunk 0 was the last one
 }
