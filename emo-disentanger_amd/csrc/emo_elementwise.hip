@@ -904,12 +904,21 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
         last = (t == gridDim.x - 1);
     }
     __syncthreads();
-    if (last && threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        float tot = 0.f;
-        for (unsigned b = 0; b < gridDim.x; ++b) tot += __hip_atomic_load(acc + 1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        acc[0] = tot;
-        __hip_atomic_store((unsigned*)(acc + 1025), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (last) {
+        // the last block adds the partials in a FIXED tree (thread t: partials t, t + 256, ...; xor-shuffle tree; four wave sums in index order):
+        // the same bits on every rank, and 4 loads in flight per thread instead of one thread walking 1024 dependent L2 round trips (r03: the
+        // serial walk was ~100 us of the kernel's 150 us)
+        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        float t = 0.f;
+        for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) t += __hip_atomic_load(acc + 1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = wave_sum(t);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            acc[0] = (red[0] + red[1]) + (red[2] + red[3]);
+            __hip_atomic_store((unsigned*)(acc + 1025), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 extern "C" int emo_sumsq(const float* x, int64_t n, float* acc, emo_stream_t stream) {
