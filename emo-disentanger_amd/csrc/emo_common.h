@@ -153,6 +153,26 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Reductions over the FOUR 16-lane rows of a wave (lanes l, l^16, l^32, l^48), result in every lane: two VALU lane swaps
+// (v_permlane32_swap(u, u) = {[lo, lo], [hi, hi]}, v_permlane16_swap(u, u) = {[r0, r0, r2, r2], [r1, r1, r3, r3]}) instead of two
+// ds_bpermute round trips through the LDS crossbar (r03: the shuffles of the FAVOR+ feature offsets serialised a 700-cycle chain per tile).
+__device__ __forceinline__ float rows4_sum(float x) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, x);
+    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float y = __builtin_bit_cast(float, (uint32_t)a[0]) + __builtin_bit_cast(float, (uint32_t)a[1]);
+    const uint32_t w = __builtin_bit_cast(uint32_t, y);
+    const auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+    return __builtin_bit_cast(float, (uint32_t)b[0]) + __builtin_bit_cast(float, (uint32_t)b[1]);
+}
+__device__ __forceinline__ float rows4_max(float x) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, x);
+    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float y = fmaxf(__builtin_bit_cast(float, (uint32_t)a[0]), __builtin_bit_cast(float, (uint32_t)a[1]));
+    const uint32_t w = __builtin_bit_cast(uint32_t, y);
+    const auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+    return fmaxf(__builtin_bit_cast(float, (uint32_t)b[0]), __builtin_bit_cast(float, (uint32_t)b[1]));
+}
+
 __device__ __forceinline__ float gelu_new_f(float x) {
     const float c = 0.7978845608028654f;  // sqrt(2/pi)
     return 0.5f * x * (1.f + tanhf(c * (x + 0.044715f * x * x * x)));

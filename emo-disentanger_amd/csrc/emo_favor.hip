@@ -526,8 +526,7 @@ __device__ __forceinline__ void jac_epilogue(const f32x4& accP, const f32x4& acc
         s += ap + am;
     }
     Img<CT>::store4(Adiff + t * lda + m0, ad[0], ad[1], ad[2], ad[3]);
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
+    s = rows4_sum(s);
     if ((lane >> 4) == 0) atomicAdd(&sumA[t], s);
 }
 

@@ -675,10 +675,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_skinny_kernel(const bf16_t*
         __builtin_amdgcn_wave_barrier();
     }
     if (ln) {                                                // the 4 lane groups hold different k slices of the same row
-        s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
-        q0 += __shfl_xor(q0, 16, 64); q0 += __shfl_xor(q0, 32, 64);
-        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-        q1 += __shfl_xor(q1, 16, 64); q1 += __shfl_xor(q1, 32, 64);
+        s0 = rows4_sum(s0); q0 = rows4_sum(q0); s1 = rows4_sum(s1); q1 = rows4_sum(q1);    // lane swaps, not 8 LDS shuffles (decode chain)
         if (lane < 16) { st[wave][0][lane][0] = s0; st[wave][0][lane][1] = q0; st[wave][1][lane][0] = s1; st[wave][1][lane][1] = q1; }
     }
     if (wave > 0) { red[wave - 1][0][lane] = acc0; red[wave - 1][1][lane] = acc1; }

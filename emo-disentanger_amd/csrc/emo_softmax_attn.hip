@@ -108,8 +108,7 @@ __global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 4 : 1)) void sattn_fwd_kern
                 mx = fmaxf(mx, val);
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = rows4_max(mx);
         float m_new = fmaxf(m_run, mx);
         if (m_new == -INFINITY) m_new = 0.f;
         const float alpha = sizeof(CT) == 2 ? __builtin_amdgcn_exp2f(m_run - m_new) : __expf(m_run - m_new);
@@ -125,9 +124,7 @@ __global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 4 : 1)) void sattn_fwd_kern
                 s[jt][r] = p * dm[r];
             }
         }
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
+        l_run = l_run * alpha + psum;              // per-lane partial row sum: the four row groups are added once, after the sweep
         m_run = m_new;
 #pragma unroll
         for (int i = 0; i < ND; ++i) oacc[i] *= alpha;
@@ -142,6 +139,7 @@ __global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 4 : 1)) void sattn_fwd_kern
             }
         }
     }
+    l_run = rows4_sum(l_run);
     if (tg < T) {
         const float inv = 1.f / l_run;
         CT* ob = out + (b * T + tg) * ld_out + h * DH;
@@ -723,8 +721,7 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const CT* __restrict__
             }
         }
         __builtin_amdgcn_wave_barrier();
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = rows4_max(mx);
         float m_new = fmaxf(m_run, mx);
         if (m_new == -INFINITY) m_new = 0.f;
         const float alpha = sizeof(CT) == 2 ? __builtin_amdgcn_exp2f(m_run - m_new) : __expf(m_run - m_new);
@@ -741,9 +738,7 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const CT* __restrict__
                 esum += s[jt][r];
             }
         }
-        psum += __shfl_xor(psum, 16, 64); psum += __shfl_xor(psum, 32, 64);
-        esum += __shfl_xor(esum, 16, 64); esum += __shfl_xor(esum, 32, 64);
-        l_run = l_run * alpha + psum;
+        l_run = l_run * alpha + psum;              // per-lane partial sums: the four row groups are added once, after the sweep
         e_run = e_run * alpha + esum;
         m_run = m_new;
 #pragma unroll
@@ -758,6 +753,8 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const CT* __restrict__
             }
         }
     }
+    l_run = rows4_sum(l_run);
+    e_run = rows4_sum(e_run);
     if (tg < T) {
         const float inv = 1.f / (e_run + 1e-8f * l_run);
         CT* ob = out + (b * T + tg) * ld_out + h * DH;
