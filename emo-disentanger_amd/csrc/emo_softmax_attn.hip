@@ -477,9 +477,19 @@ template <typename CT, int DH> static size_t sa_fwd_lds() { typedef SaDims<CT, D
 template <typename CT, int DH> static size_t sa_dq_lds() { typedef SaDims<CT, DH> D; return sizeof(CT) * (size_t)(4 * 64 * D::LDX + (sizeof(CT) == 2 ? 0 : DH * D::LDC)) + 64 * sizeof(float); }
 template <typename CT, int DH> static size_t sa_dkv_lds() { typedef SaDims<CT, DH> D; return sizeof(CT) * (size_t)(4 * 64 * D::LDX + (sizeof(CT) == 2 ? 0 : 2 * DH * D::LDC)) + 128 * sizeof(float); }
 
+// emo_softmax_attn32.hip: bf16 / d_head 64 / T % 128 == 0 kernels on 32 x 32 x 16 tiles (false: not covered -> the kernels of this file)
+bool emo_sattn32_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ld_out, float* lse, int64_t B, int64_t T,
+                     int64_t H, DropCtx drop, hipStream_t st);
+
 template <typename CT, int DH>
 static int run_sattn(int which, const void* q, const void* k, const void* v, int64_t ld, const void* out, const void* dout, int64_t ld_out, float* lse,
                      float* delta, void* dq, void* dk, void* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, DropCtx drop, hipStream_t st) {
+    if constexpr (sizeof(CT) == 2 && DH == 64) {
+        if (which == 0 && emo_sattn32_try(0, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, (bf16_t*)out, ld_out, lse, B, T, H, drop, st)) {
+            EMO_LAUNCH_CHECK();
+            return EMO_OK;
+        }
+    }
     dim3 grid((unsigned)((T + 63) / 64), (unsigned)(B * H));
     static bool attr = false;
     const size_t lfwd = sa_fwd_lds<CT, DH>(), ldq = sa_dq_lds<CT, DH>(), ldkv = sa_dkv_lds<CT, DH>();

@@ -1,0 +1,184 @@
+// Causal softmax attention of the GPT-2 backbone (HF GPT2Attention._attn), bf16, d_head 64, T % 128 == 0 — 32 x 32 x 16 MFMA kernels (r03).
+//
+// The generic kernels of emo_softmax_attn.hip give a wave 16 query rows on 16 x 16 tiles: a row's 64 scores of a key tile sit in FOUR lanes,
+// so every key tile pays cross-lane reductions, and a lane carries only 16 scores between two dependent MFMA stages (r02: latency-bound,
+// 0.09 of the MFMA peak, "only more resident waves hide it").  Here a wave owns 32 query rows on 32 x 32 x 16 tiles with the swapped product
+// S^T = K Q^T: the accumulator layout is lane <-> query (lane % 32), 16 keys per lane and tile half (key = (i & 3) + 8 (i >> 2) + 4 (lane / 32)),
+// i.e. a query's 64 scores of a key tile sit in TWO lanes (l, l + 32): row maximum = 31 v_max + one v_permlane32_swap, the row sum stays a
+// per-lane partial until the sweep ends, and 32 independent scores per lane give the softmax VALU work its instruction-level parallelism.
+// P goes from the score registers straight into the P V product (O^T = V^T P^T) as B operand in the permuted key order
+// k-slot e of lane half hi <-> key 16 u + (e & 3) + 8 (e >> 2) + 4 hi; the A operand V^T is read from the row-major V tile with
+// ds_read_b64_tr_b16 in the same order.  K / V tiles (64 keys) arrive by LDS-DMA (inline asm: see emo_favor_fs.hip) into a 2-slot ring, 128-B
+// rows with the 16-B pieces XOR-swizzled by (row & 7); one workgroup barrier per key tile; 4 waves = 128 query rows per workgroup.
+// Numerics = the generic bf16 kernel's: base-2 domain (scores scaled by log2(e)/sqrt(dh)), fp32 statistics, dropout regenerated from
+// (seed, offset, ((b H + h) T + t) T + j) with one keyed hash per 4 consecutive keys, lse = m ln 2 + ln(l).
+#include "emo_common.h"
+
+namespace {
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+constexpr float A32_LOG2E = 1.4426950408889634f, A32_LN2 = 0.6931471805599453f;
+constexpr int A32_ROWB = 128, A32_TILEB = 64 * A32_ROWB;   // one K or V tile: 64 keys x 64 bf16
+
+__device__ __forceinline__ f32x16 mma3216(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void a32_dma16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ uint32_t a32_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
+__device__ __forceinline__ float a32_pair_max(float x) {       // max over the two lanes (l, l ^ 32) that share a query row
+    const uint32_t u = __builtin_bit_cast(uint32_t, x);
+    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (uint32_t)a[0]), __builtin_bit_cast(float, (uint32_t)a[1]));
+}
+__device__ __forceinline__ float a32_pair_sum(float x) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, x);
+    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (uint32_t)a[0]) + __builtin_bit_cast(float, (uint32_t)a[1]);
+}
+
+// =============================================================================================== forward
+__global__ __launch_bounds__(256, 2) void sattn32_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t ld,
+                                                             bf16_t* __restrict__ out, int64_t ld_out, float* __restrict__ lse_g, int64_t T, int64_t H,
+                                                             DropCtx drop) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2 slots][K tile | V tile]
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, ql = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t qt = (int64_t)gridDim.x - 1 - blockIdx.x;           // longest sweeps first
+    const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int64_t q0 = qt * 128, qrow = q0 + 32 * w + ql;
+    const bf16_t* qb = q + (b * T) * ld + h * 64;
+    const bf16_t* kb = k + (b * T) * ld + h * 64;
+    const bf16_t* vb = v + (b * T) * ld + h * 64;
+    const int nkt = (int)(2 * (qt + 1));                              // key tiles 0 .. (q0 + 127) / 64
+    const int64_t wq_max = q0 + 32 * w + 31, wq_min = q0 + 32 * w;    // query range of this wave
+
+    bf16x8 qf[4];                                                     // Q rows as B operand: column = query ql, k = d = 16 s + 8 hi ..
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qb + qrow * ld + 16 * s + 8 * hi);
+
+    const uint32_t ring = __builtin_amdgcn_readfirstlane(a32_lds_addr(smem));
+    // DMA: wave w moves key rows 16 w .. 16 w + 15 of K and of V (two 1-KB pieces each); lane: row + lane / 8, physical piece lane % 8
+    const int64_t so0 = (int64_t)(16 * w + (lane >> 3)) * ld + (((lane & 7) ^ (lane >> 3)) << 3);
+    const int64_t so1 = so0 + 8 * ld;                                 // rows + 8: same (row & 7), same swizzle
+    auto issue = [&](int kt) {
+        const int64_t o = (int64_t)kt * 64 * ld;
+        const uint32_t dst = ring + (kt & 1) * 2 * A32_TILEB + w * 2048;
+        a32_dma16(kb + o + so0, dst);
+        a32_dma16(kb + o + so1, dst + 1024);
+        a32_dma16(vb + o + so0, dst + A32_TILEB);
+        a32_dma16(vb + o + so1, dst + A32_TILEB + 1024);
+    };
+    issue(0);
+    const float c2 = rsqrtf(64.f) * A32_LOG2E;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    // lane-constant LDS offsets: K fragment (row ql of a 32-key half, piece 2 s + hi), V transposed fragments (see the header)
+    const int vg = lane >> 4, vi = lane & 15;                         // 16-lane group / lane inside it for the transpose reads
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of tile kt landed
+        __builtin_amdgcn_s_barrier();                                 // ... everyone's did; everyone is done with the other slot
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nkt) issue(kt + 1);
+        const int64_t k0 = (int64_t)kt * 64;
+        if (k0 > wq_max) continue;                                    // key tile entirely above this wave's rows (wave-uniform)
+        const char* Kt = smem + (kt & 1) * 2 * A32_TILEB;
+        const char* Vt = Kt + A32_TILEB;
+        f32x16 s0, s1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 ka = *(const bf16x8*)(Kt + ql * A32_ROWB + (((2 * s + hi) ^ (ql & 7)) << 4));
+            const bf16x8 kc = *(const bf16x8*)(Kt + (32 + ql) * A32_ROWB + (((2 * s + hi) ^ (ql & 7)) << 4));
+            s0 = mma3216(ka, qf[s], s0);
+            s1 = mma3216(kc, qf[s], s1);
+        }
+        const bool diag = k0 + 63 > wq_min;                           // some key of the tile lies above some row of the wave
+        // statistics in the RAW score domain (max commutes with the positive scale): p = exp2(fma(s, c2, -c2 m)) is one FMA + one v_exp per score
+        float mx = -INFINITY;
+        if (diag) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kl = (i & 3) + 8 * (i >> 2) + 4 * hi;
+                if (k0 + kl > qrow) s0[i] = -INFINITY;
+                if (k0 + 32 + kl > qrow) s1[i] = -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
+        mx = a32_pair_max(mx);
+        float m_new = fmaxf(m_run, mx);                               // (key 0 is visible to every row: never -inf)
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+        const float nm = -m_new * c2;
+        float psum = 0.f;
+#pragma unroll
+        for (int a4 = 0; a4 < 4; ++a4) {
+            float d0[4] = {1.f, 1.f, 1.f, 1.f}, d1[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop.thr16) {
+                const uint64_t base = (uint64_t)((bh * T + qrow) * T + k0 + 8 * a4 + 4 * hi);
+                drop_mult4(drop, base, d0);
+                drop_mult4(drop, base + 32, d1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(s0[4 * a4 + r], c2, nm)), p1 = __builtin_amdgcn_exp2f(fmaf(s1[4 * a4 + r], c2, nm));
+                psum += p0 + p1;
+                s0[4 * a4 + r] = p0 * d0[r];
+                s1[4 * a4 + r] = p1 * d1[r];
+            }
+        }
+        l_run = l_run * alpha + psum;                                 // per-lane partial (this lane's 32 of the row's 64 keys)
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        // O^T[d][q] += sum_key V^T[d][key] P^T[key][q]: four 16-key steps, two 32-row d halves
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bf16x8 pb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pb[e] = (bf16_t)((u < 2 ? s0 : s1)[8 * (u & 1) + e]);
+#pragma unroll
+            for (int dh2 = 0; dh2 < 2; ++dh2) {
+                bf16x8 va;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int row = 16 * u + 8 * hh + 4 * (vg >> 1) + (vi >> 2), col = 32 * dh2 + 16 * (vg & 1) + 4 * (vi & 3);
+                    const char* p = Vt + row * A32_ROWB + (((col >> 3) ^ (row & 7)) << 4) + (col & 7) * 2;
+                    const short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
+                    const bf16x4 tb = __builtin_bit_cast(bf16x4, t);
+                    va[4 * hh + 0] = tb[0]; va[4 * hh + 1] = tb[1]; va[4 * hh + 2] = tb[2]; va[4 * hh + 3] = tb[3];
+                }
+                if (dh2 == 0) o0 = mma3216(va, pb, o0); else o1 = mma3216(va, pb, o1);
+            }
+        }
+    }
+    const float l_tot = a32_pair_sum(l_run);
+    const float inv = 1.f / l_tot;
+    bf16_t* ob = out + (b * T + qrow) * ld_out + h * 64;
+#pragma unroll
+    for (int a4 = 0; a4 < 4; ++a4) {
+        const bf16x4 x0 = {(bf16_t)(o0[4 * a4] * inv), (bf16_t)(o0[4 * a4 + 1] * inv), (bf16_t)(o0[4 * a4 + 2] * inv), (bf16_t)(o0[4 * a4 + 3] * inv)};
+        const bf16x4 x1 = {(bf16_t)(o1[4 * a4] * inv), (bf16_t)(o1[4 * a4 + 1] * inv), (bf16_t)(o1[4 * a4 + 2] * inv), (bf16_t)(o1[4 * a4 + 3] * inv)};
+        *(bf16x4*)(ob + 8 * a4 + 4 * hi) = x0;
+        *(bf16x4*)(ob + 32 + 8 * a4 + 4 * hi) = x1;
+    }
+    if (hi == 0) lse_g[bh * T + qrow] = m_run * c2 * A32_LN2 + logf(l_tot);
+}
+}  // namespace
+
+// which: 0 forward.  Returns false when the call is not covered (the caller then runs the generic kernels).
+bool emo_sattn32_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ld_out, float* lse, int64_t B, int64_t T,
+                     int64_t H, DropCtx drop, hipStream_t st) {
+    const char* e = getenv("EMO_SATTN32");                   // "0": generic kernels only (read per call: tests toggle it)
+    if (e && atoi(e) == 0) return false;
+    if (which != 0 || T < 128 || (T % 128) != 0 || (ld & 7) || (ld_out & 3)) return false;
+    dim3 grid((unsigned)(T / 128), (unsigned)(B * H));
+    const size_t lds = 4 * A32_TILEB;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)sattn32_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(sattn32_fwd_kernel, grid, dim3(256), lds, st, q, k, v, ld, out, ld_out, lse, T, H, drop);
+    return true;
+}

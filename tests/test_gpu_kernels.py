@@ -609,6 +609,34 @@ def test_softmax_attention_fwd_bwd(dt, B, T, H, dh):
     _close(od, ref.view(B, T, HD)[:, -1], dt)
 
 
+@pytest.mark.parametrize('B,T,H,p', [(2, 256, 2, 0.0), (1, 128, 1, 0.0), (1, 640, 3, 0.0), (2, 384, 2, 0.2)])
+def test_softmax_attention_32x32_kernels_vs_reference_and_generic(B, T, H, p, monkeypatch):
+    """bf16 / d_head 64 / T % 128 == 0 runs on the 32 x 32 x 16 kernels (emo_softmax_attn32.hip): against the fp64 reference (p = 0) and against
+    the generic kernels, with dropout too (same mask: the element -> hash mapping is shared), forward output, lse, and the backward fed with
+    either forward's statistics."""
+    ops = _ops()
+    dt, dh = torch.bfloat16, 64
+    HD = H * dh
+    qkv = _r(B * T, 3 * HD, seed=41, dt=dt)
+    dout = _r(B * T, HD, seed=42, dt=dt)
+    qc = qkv.cuda()
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('EMO_SATTN32', mode)
+        out, lse = ops.softmax_attn_fwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], B, T, H, p_drop=p, seed=3, offset=9)
+        dq, dk, dv = ops.softmax_attn_bwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], out, dout.cuda(), lse, B, T, H, p_drop=p, seed=3, offset=9)
+        res[mode] = [x.float().cpu() for x in (out, lse, dq, dk, dv)]
+    for a, b_ in zip(res['1'], res['0']):
+        assert float((a - b_).abs().max()) <= 3e-2 * max(float(b_.abs().max()), 1e-6)
+    if p == 0.0:
+        q, k, v = [qkv[:, i * HD:(i + 1) * HD].double().view(B, T, H, dh).permute(0, 2, 1, 3) for i in range(3)]
+        wts = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+        wts = wts.masked_fill(~torch.tril(torch.ones(T, T, dtype=torch.bool)), float('-inf'))
+        ref = (wts.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B * T, HD)
+        _close(res['1'][0], ref, dt)
+        _close(res['1'][1].view(B, H, T), torch.logsumexp(wts, -1), dt, mult=0.3)
+
+
 def test_softmax_attention_dropout_consistency():
     # with dropout the backward must use the same mask as the forward: finite-difference-free check via linearity in v
     ops = _ops()
