@@ -172,7 +172,11 @@ extern "C" int emo_embed_bwd(const int64_t* tok, const int64_t* seg, const void*
     const size_t lds = (size_t)(V + n_seg) * 64 * sizeof(float);
     EMO_CHECK(lds <= 160 * 1024, "emo_embed_bwd: vocabulary of %lld rows does not fit the LDS table", (long long)(V + n_seg));
     const int64_t M = B * T;
-    int64_t rpb = 4096;      // 8 column slices x 32 chunks = 256 blocks at the bench shape (one 84-KB block per CU)
+    // 8 column slices x 32 token chunks = 256 blocks (one 84-KB block per CU) at the bench shape; smaller token counts keep the 32 chunks
+    // (r03: with the fixed 4096-row chunk the reference's batch size 4 ran 16 blocks and took the same 335 us as batch 64)
+    int64_t rpb = cdiv64(cdiv64(M, 32), 64) * 64;
+    if (rpb < 256) rpb = 256;
+    if (rpb > 4096) rpb = 4096;
     { const char* e = getenv("EMO_EMBED_RPB"); if (e && atoi(e) > 0) rpb = atoi(e); }
     if (rpb > M) rpb = M;
     dim3 grid((unsigned)cdiv64(D, 64), (unsigned)cdiv64(M, rpb));
