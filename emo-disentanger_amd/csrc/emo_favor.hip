@@ -1246,9 +1246,9 @@ template <typename CT, int DH, int MF, int C> static size_t dkv_lds() {
 #define EMO_MAX_LDS (160 * 1024)
 
 // emo_favor_fs.hip: the bf16 / d_head 64 / 128-feature "slice" kernels (false: shape or mode not covered -> the generic kernels below)
-int emo_favor_fs_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const float* omega, bf16_t* out, int64_t ld_out, float* den,
-                      float* sS, float* sz, const bf16_t* dout, bf16_t* dq, bf16_t* dk, bf16_t* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, float eps,
-                      hipStream_t st);
+int emo_favor_fs_try(int which, int stage, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const float* omega, bf16_t* out, int64_t ld_out,
+                     float* den, float* sS, float* sz, const bf16_t* dout, bf16_t* dq, bf16_t* dk, bf16_t* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H,
+                     float eps, const float* ws_S, const float* ws_z, int P, int64_t Ts, hipStream_t st);
 
 // ---- segment-parallel scan geometry (see favor_fwd_kernel).  One workgroup per (b, h, segment); segments only when B*H alone cannot
 // fill the 256 CUs.  Ts is a multiple of 64 (every chunk size divides it) and at least 2 chunks long.
@@ -1292,19 +1292,23 @@ static int run_favor(int which, const void* q, const void* k, const void* v, int
         EMO_CHECK(((uintptr_t)workspace & 15) == 0, "favor attention: workspace must be 16-B aligned");
     }
     if (P <= 1) { P = 1; Ts = T > 0 ? T : 1; }
-    int fs = 0;                  // 1: served by the slice kernels; 2: dq done there, dk / dv below
-    if constexpr (sizeof(CT) == 2 && DH == 64 && MF == 64) {
-        if (P == 1) fs = emo_favor_fs_try(which, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, omega, (bf16_t*)out, ld_out, den, sS, sz,
-                                          (const bf16_t*)dout, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, ld_d, B, T, H, eps, st);
-        if (fs == 1) {
-            EMO_LAUNCH_CHECK();
-            return EMO_OK;
-        }
-    }
-    { const char* e = getenv("EMO_FAVOR_FS"); EMO_CHECK(!(e && atoi(e) == 2 && fs != 1), "favor attention: EMO_FAVOR_FS=2 but the slice kernels do not cover this call"); }
     float* wsS = (float*)workspace;
     float* wsz = wsS ? wsS + B * H * P * (int64_t)F * DH : nullptr;
     dim3 grid((unsigned)(B * H * P));
+    // bf16 / d_head 64 / 128 features: the main passes run on the slice kernels (emo_favor_fs.hip); with P > 1 they start every segment from the
+    // increments that the generic state-only passes below leave in the workspace
+    constexpr bool FS = sizeof(CT) == 2 && DH == 64 && MF == 64;
+    auto fs_try = [&](int stage) -> bool {
+        if constexpr (FS) {
+            if (emo_favor_fs_try(which, stage, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, omega, (bf16_t*)out, ld_out, den, sS, sz, (const bf16_t*)dout,
+                                 (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, ld_d, B, T, H, eps, wsS, wsz, P, Ts, st))
+                return true;
+        }
+        const char* e = getenv("EMO_FAVOR_FS");
+        if (e && atoi(e) == 2) emo_set_error("favor attention: EMO_FAVOR_FS=2 but the slice kernels do not cover this call");
+        return false;
+    };
+    auto fs_required_failed = [&]() { const char* e = getenv("EMO_FAVOR_FS"); return e && atoi(e) == 2; };
     if (which == 0) {
         const size_t lds = fwd_lds<CT, DH, MF, CF>();
         EMO_CHECK(lds <= EMO_MAX_LDS, "favor fwd: LDS %zu too large", lds);
@@ -1320,8 +1324,11 @@ static int run_favor(int which, const void* q, const void* k, const void* v, int
             hipLaunchKernelGGL(ks, grid, dim3(FT), lds, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (CT*)out, ld_out, den, sS, sz, T, H, eps, wsS,
                                wsz, P, Ts);
         const char* ab = getenv("EMO_FAVOR_ABLATE");   // diagnostics only
-        hipLaunchKernelGGL(kf, grid, dim3(FT), lds, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (CT*)out, ld_out, den, sS, sz, T, H, eps, wsS, wsz,
-                           P | (ab ? atoi(ab) << 8 : 0), Ts);
+        if (!fs_try(0)) {
+            if (fs_required_failed()) return EMO_ERR_INVALID;
+            hipLaunchKernelGGL(kf, grid, dim3(FT), lds, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (CT*)out, ld_out, den, sS, sz, T, H, eps, wsS, wsz,
+                               P | (ab ? atoi(ab) << 8 : 0), Ts);
+        }
     } else {
         const size_t l0 = fwd_lds<CT, DH, MF, CF>(), l1 = dq_lds<CT, DH, MF, CQ>(), l2 = dkv_lds<CT, DH, MF, CK>();
         EMO_CHECK(l0 <= EMO_MAX_LDS && l1 <= EMO_MAX_LDS && l2 <= EMO_MAX_LDS, "favor bwd: LDS %zu / %zu / %zu too large", l0, l1, l2);
@@ -1341,14 +1348,19 @@ static int run_favor(int which, const void* q, const void* k, const void* v, int
         if (P > 1)
             hipLaunchKernelGGL(k0, grid, dim3(FT), l0, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (CT*)nullptr, ld_out, (float*)nullptr,
                                (float*)nullptr, (float*)nullptr, T, H, eps, wsS, wsz, P, Ts);
-        if (fs != 2)
+        if (!fs_try(1)) {
+            if (fs_required_failed()) return EMO_ERR_INVALID;
             hipLaunchKernelGGL(k1, grid, dim3(FT), l1, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
                                (CT*)dq, ld_d, T, H, (const float*)wsS, (const float*)wsz, P | (getenv("EMO_FAVOR_ABLATE_DQ") ? atoi(getenv("EMO_FAVOR_ABLATE_DQ")) << 8 : 0), Ts);
+        }
         if (P > 1)
             hipLaunchKernelGGL(k2s, grid, dim3(FT), l2, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
                                (CT*)dk, (CT*)dv, ld_d, T, H, wsS, wsz, P, Ts);
-        hipLaunchKernelGGL(k2, grid, dim3(FT), l2, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
-                           (CT*)dk, (CT*)dv, ld_d, T, H, wsS, wsz, P | (getenv("EMO_FAVOR_ABLATE_DKV") ? atoi(getenv("EMO_FAVOR_ABLATE_DKV")) << 8 : 0), Ts);
+        if (!fs_try(2)) {
+            if (fs_required_failed()) return EMO_ERR_INVALID;
+            hipLaunchKernelGGL(k2, grid, dim3(FT), l2, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (const CT*)out, (const CT*)dout, ld_out, den,
+                               (CT*)dk, (CT*)dv, ld_d, T, H, wsS, wsz, P | (getenv("EMO_FAVOR_ABLATE_DKV") ? atoi(getenv("EMO_FAVOR_ABLATE_DKV")) << 8 : 0), Ts);
+        }
     }
     EMO_LAUNCH_CHECK();
     return EMO_OK;

@@ -168,7 +168,8 @@ __device__ __forceinline__ uint32_t fs_lds_addr(const void* p) { return (uint32_
 __global__ __launch_bounds__(FS_NT, 2) void favor_fs_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                 int64_t ld, const float* __restrict__ omega, bf16_t* __restrict__ out, int64_t ld_out,
                                                                 float* __restrict__ den_g, float* __restrict__ state_S, float* __restrict__ state_z,
-                                                                int64_t T, int64_t H, float eps) {
+                                                                int64_t Tfull, int64_t H, float eps, const float* __restrict__ S_ws,
+                                                                const float* __restrict__ z_ws, int P, int64_t Ts) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* QKr = smem;                                  // [3 slots][q, k][32 rows][128 B]
     char* Vr = QKr + 3 * 2 * FS_TILEB;                 // [4 slots][32 rows][128 B]
@@ -176,12 +177,16 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_fwd_kernel(const bf16_t* __
     bf16_t* KFb = QFb + 2 * FS_C * FS_LDF;             // [2][32][LDF]
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;
-    const bf16_t* qb = q + (b * T) * ld + h * 64;
-    const bf16_t* kb = k + (b * T) * ld + h * 64;
-    const bf16_t* vb = v + (b * T) * ld + h * 64;
-    bf16_t* ob = out + (b * T) * ld_out + h * 64;
-    float* dg = den_g + bh * T;
+    // segment-parallel scan (P > 1, B*H < 256): block = (b, h, segment); the segment starts from the sum of the state increments of the
+    // segments before it (workspace written by the generic state-only pass, emo_favor.hip) and is otherwise a scan of T = its own length
+    const int64_t bh = blockIdx.x / P, b = bh / H, h = bh % H;
+    const int p_seg = (int)(blockIdx.x % P);
+    const int64_t tbeg = (int64_t)p_seg * Ts, T = (tbeg + Ts < Tfull) ? Ts : Tfull - tbeg;
+    const bf16_t* qb = q + (b * Tfull + tbeg) * ld + h * 64;
+    const bf16_t* kb = k + (b * Tfull + tbeg) * ld + h * 64;
+    const bf16_t* vb = v + (b * Tfull + tbeg) * ld + h * 64;
+    bf16_t* ob = out + (b * Tfull + tbeg) * ld_out + h * 64;
+    float* dg = den_g + bh * Tfull + tbeg;
     const float cs = rsqrtf(sqrtf(64.f));
     const float cs2 = cs * FS_LOG2E, c2h = 0.5f * cs * cs * FS_LOG2E, hl = 0.5f * logf(128.f) * FS_LOG2E;
 
@@ -197,6 +202,17 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_fwd_kernel(const bf16_t* __
     f32x4 S[8][2];                                     // S[ft][0]: rows f = 16 ft + 4 g + r, column d = 16 w + c;  S[ft][1]: the ones tile (c == 0: z[f])
 #pragma unroll
     for (int ft = 0; ft < 8; ++ft) { S[ft][0] = zero4(); S[ft][1] = zero4(); }
+    for (int pp = 0; pp < p_seg; ++pp) {               // carried-in state
+        const float* Sp = S_ws + (bh * P + pp) * (int64_t)(128 * 64);
+        const float* zp = z_ws + (bh * P + pp) * (int64_t)128;
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                S[ft][0][r] += Sp[(16 * ft + 4 * g + r) * 64 + 16 * w + c];
+                if (c == 0) S[ft][1][r] += zp[16 * ft + 4 * g + r];
+            }
+    }
 
     const int nch = (int)(T / FS_C);
     const uint32_t qk_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(QKr)), vr_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(Vr));
@@ -353,7 +369,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_fwd_kernel(const bf16_t* __
             if (w == 0 && g == 0) dg[t0 - FS_C + 16 * tt + c] = d_prev[tt];
         }
     }
-    if (state_S) {
+    if (state_S && p_seg == P - 1) {
         float* So = state_S + bh * (int64_t)(128 * 64);
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft)
@@ -410,7 +426,8 @@ __device__ __forceinline__ bf16x8 fs_scale8(const bf16x8& x, float a) {
 __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                int64_t ld, const float* __restrict__ omega, const bf16_t* __restrict__ out,
                                                                const bf16_t* __restrict__ dout, int64_t ld_out, const float* __restrict__ den_g,
-                                                               bf16_t* __restrict__ dq, int64_t ld_d, int64_t T, int64_t H) {
+                                                               bf16_t* __restrict__ dq, int64_t ld_d, int64_t Tfull, int64_t H,
+                                                               const float* __restrict__ S_ws, const float* __restrict__ z_ws, int P, int64_t Ts) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* RING = smem;                                 // [3 slots][q, k, v, dout, out][32 rows][128 B]
     char* DEN = RING + 3 * FS_SLOTB;                   // [3 slots][64 floats]
@@ -419,14 +436,16 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
     float* SA = (float*)(DU + 2 * FS_TILEB);           // [2][4 waves][32]           partial sum_f dPhi Phi
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;
-    const bf16_t* qb = q + (b * T) * ld + h * 64;
-    const bf16_t* kb = k + (b * T) * ld + h * 64;
-    const bf16_t* vb = v + (b * T) * ld + h * 64;
-    const bf16_t* ob = out + (b * T) * ld_out + h * 64;
-    const bf16_t* gb = dout + (b * T) * ld_out + h * 64;
-    bf16_t* dqb = dq + (b * T) * ld_d + h * 64;
-    const float* dnb = den_g + bh * T;
+    const int64_t bh = blockIdx.x / P, b = bh / H, h = bh % H;   // (b, h, segment): see the forward kernel
+    const int p_seg = (int)(blockIdx.x % P);
+    const int64_t tbeg = (int64_t)p_seg * Ts, T = (tbeg + Ts < Tfull) ? Ts : Tfull - tbeg;
+    const bf16_t* qb = q + (b * Tfull + tbeg) * ld + h * 64;
+    const bf16_t* kb = k + (b * Tfull + tbeg) * ld + h * 64;
+    const bf16_t* vb = v + (b * Tfull + tbeg) * ld + h * 64;
+    const bf16_t* ob = out + (b * Tfull + tbeg) * ld_out + h * 64;
+    const bf16_t* gb = dout + (b * Tfull + tbeg) * ld_out + h * 64;
+    bf16_t* dqb = dq + (b * Tfull + tbeg) * ld_d + h * 64;
+    const float* dnb = den_g + bh * Tfull + tbeg;
     const float cs = rsqrtf(sqrtf(64.f));
     const float cs2 = cs * FS_LOG2E, c2h = 0.5f * cs * cs * FS_LOG2E, hl = 0.5f * logf(128.f) * FS_LOG2E;
 
@@ -445,6 +464,19 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
     f32x4 ST[5][2];                                    // S'^T tiles: rows d' = 16 dl + 4 g + r (dl = 4: row 64 = z), column f = slice element c (plus / minus)
 #pragma unroll
     for (int dl = 0; dl < 5; ++dl) { ST[dl][0] = zero4(); ST[dl][1] = zero4(); }
+    for (int pp = 0; pp < p_seg; ++pp) {               // K-state carried in from the earlier segments: S'^T[d'][f] (+ row 64 = z)
+        const float* Sp = S_ws + (bh * P + pp) * (int64_t)(128 * 64);
+        const float* zp = z_ws + (bh * P + pp) * (int64_t)128;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const int f = 64 * ph + 16 * w + c;
+#pragma unroll
+            for (int dl = 0; dl < 4; ++dl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ST[dl][ph][r] += Sp[f * 64 + 16 * dl + 4 * g + r];
+            if (g == 0) ST[4][ph][0] += zp[f];
+        }
+    }
 
     const int nch = (int)(T / FS_C);
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(RING)), den_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(DEN));
@@ -671,7 +703,8 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
 __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                 int64_t ld, const float* __restrict__ omega, const bf16_t* __restrict__ out,
                                                                 const bf16_t* __restrict__ dout, int64_t ld_out, const float* __restrict__ den_g,
-                                                                bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t ld_d, int64_t T, int64_t H) {
+                                                                bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t ld_d, int64_t Tfull, int64_t H,
+                                                                const float* __restrict__ R_ws, const float* __restrict__ r_ws, int P, int64_t Ts) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* RING = smem;                                 // [2 slots][q, k, v, dout, out][32 rows][128 B]
     char* DEN = RING + 2 * FS_SLOTB;                   // [2 slots][64 floats]
@@ -682,15 +715,17 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
     float* PV = SA + 128;                              // [4 waves][dD 32 | -dot 32 | 1/den 32]   private
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;
-    const bf16_t* qb = q + (b * T) * ld + h * 64;
-    const bf16_t* kb = k + (b * T) * ld + h * 64;
-    const bf16_t* vb = v + (b * T) * ld + h * 64;
-    const bf16_t* ob = out + (b * T) * ld_out + h * 64;
-    const bf16_t* gb = dout + (b * T) * ld_out + h * 64;
-    bf16_t* dkb = dk + (b * T) * ld_d + h * 64;
-    bf16_t* dvb = dv + (b * T) * ld_d + h * 64;
-    const float* dnb = den_g + bh * T;
+    const int64_t bh = blockIdx.x / P, b = bh / H, h = bh % H;   // (b, h, segment): the R state comes from the LATER segments
+    const int p_seg = (int)(blockIdx.x % P);
+    const int64_t tbeg = (int64_t)p_seg * Ts, T = (tbeg + Ts < Tfull) ? Ts : Tfull - tbeg;
+    const bf16_t* qb = q + (b * Tfull + tbeg) * ld + h * 64;
+    const bf16_t* kb = k + (b * Tfull + tbeg) * ld + h * 64;
+    const bf16_t* vb = v + (b * Tfull + tbeg) * ld + h * 64;
+    const bf16_t* ob = out + (b * Tfull + tbeg) * ld_out + h * 64;
+    const bf16_t* gb = dout + (b * Tfull + tbeg) * ld_out + h * 64;
+    bf16_t* dkb = dk + (b * Tfull + tbeg) * ld_d + h * 64;
+    bf16_t* dvb = dv + (b * Tfull + tbeg) * ld_d + h * 64;
+    const float* dnb = den_g + bh * Tfull + tbeg;
     const float cs = rsqrtf(sqrtf(64.f));
     const float cs2 = cs * FS_LOG2E, c2h = 0.5f * cs * cs * FS_LOG2E, hl = 0.5f * logf(128.f) * FS_LOG2E;
 
@@ -709,6 +744,23 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
     for (int dl = 0; dl < 5; ++dl) { RT[dl][0] = zero4(); RT[dl][1] = zero4(); }
 #pragma unroll
     for (int ft = 0; ft < 8; ++ft) RD[ft] = zero4();
+    for (int pp = p_seg + 1; pp < P; ++pp) {
+        const float* Rp = R_ws + (bh * P + pp) * (int64_t)(128 * 64);
+        const float* rp = r_ws + (bh * P + pp) * (int64_t)128;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const int f = 64 * ph + 16 * w + c;
+#pragma unroll
+            for (int dl = 0; dl < 4; ++dl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) RT[dl][ph][r] += Rp[f * 64 + 16 * dl + 4 * g + r];
+            if (g == 0) RT[4][ph][0] += rp[f];
+        }
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) RD[ft][r] += Rp[(16 * ft + 4 * g + r) * 64 + 16 * w + c];
+    }
 
     const int nch = (int)(T / FS_C);
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(RING)), den_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(DEN));
@@ -955,35 +1007,43 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
 }
 }  // namespace
 
-// which: 0 forward, 1 backward.  Returns 0 when the shape / mode is not covered (the caller then runs the generic kernels), 1 when the call
-// was served completely, 2 when dq was written and the caller still has to run the generic dk / dv kernel.
-int emo_favor_fs_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const float* omega, bf16_t* out, int64_t ld_out, float* den,
-                      float* sS, float* sz, const bf16_t* dout, bf16_t* dq, bf16_t* dk, bf16_t* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, float eps,
-                      hipStream_t st) {
+// which: 0 forward, 1 backward main passes (P > 1: the caller has run the generic state-only pass into S_ws / z_ws — for the backward the
+// K-state increments before `stage` 1 (dq) and the R-state increments before `stage` 2 (dk, dv)).  stage: 0 = whole call (P == 1 only),
+// 1 = dq, 2 = dk / dv.  Returns 0 when the shape / mode is not covered (the caller then runs the generic kernels), 1 when it was served.
+int emo_favor_fs_try(int which, int stage, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const float* omega, bf16_t* out, int64_t ld_out,
+                     float* den, float* sS, float* sz, const bf16_t* dout, bf16_t* dq, bf16_t* dk, bf16_t* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H,
+                     float eps, const float* ws_S, const float* ws_z, int P, int64_t Ts, hipStream_t st) {
     const char* e = getenv("EMO_FAVOR_FS");                // (read per call: tests toggle it in-process)  "0": generic kernels only
     if (e && atoi(e) == 0) return 0;
-    if (T < FS_C || (T % FS_C) != 0 || B * H <= 0) return 0;
+    if (T < FS_C || (T % FS_C) != 0 || B * H <= 0 || P < 1 || (P > 1 && (Ts % FS_C) != 0)) return 0;
     if ((ld & 7) || (ld_out & 7) || (ld_d & 3)) return 0;
-    dim3 grid((unsigned)(B * H));
+    if (P == 1) Ts = T;
+    // short segments (B*H < 256): the forward's generic kernel is faster (r03, B=4 x T=2048, 8 segments: 66 vs 89 us per layer), the backward's
+    // slice kernels still win (114 vs 159 us) -> the segmented forward runs here only on request (EMO_FAVOR_FS=2: tests)
+    if (which == 0 && P > 1 && !(e && atoi(e) == 2)) return 0;
+    dim3 grid((unsigned)(B * H * P));
     if (which == 0) {
         const size_t lds = (size_t)(3 * 2 + 4) * FS_TILEB + sizeof(bf16_t) * (size_t)(4 * FS_C * FS_LDF);
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)favor_fs_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-        hipLaunchKernelGGL(favor_fs_fwd_kernel, grid, dim3(FS_NT), lds, st, q, k, v, ld, omega, out, ld_out, den, sS, sz, T, H, eps);
+        hipLaunchKernelGGL(favor_fs_fwd_kernel, grid, dim3(FS_NT), lds, st, q, k, v, ld, omega, out, ld_out, den, sS, sz, T, H, eps, ws_S, ws_z, P, Ts);
         return 1;
     }
-    {
-        const char* e2 = getenv("EMO_FAVOR_FS_BWD");           // "0": generic backward kernels
-        if (e2 && atoi(e2) == 0) return 0;
+    const char* e2 = getenv("EMO_FAVOR_FS_BWD");               // "0": generic backward kernels
+    if (e2 && atoi(e2) == 0) return 0;
+    if (stage == 0 || stage == 1) {
         const size_t lds = (size_t)3 * FS_SLOTB + 3 * 256 + 4 * 2048 + 2 * FS_TILEB + 2 * 4 * 32 * sizeof(float);
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)favor_fs_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-        hipLaunchKernelGGL(favor_fs_dq_kernel, grid, dim3(FS_NT), lds, st, q, k, v, ld, omega, (const bf16_t*)out, dout, ld_out, (const float*)den, dq, ld_d, T, H);
-        if (e2 && atoi(e2) == 1) return 2;                     // "1": slice dq + generic dk / dv
+        hipLaunchKernelGGL(favor_fs_dq_kernel, grid, dim3(FS_NT), lds, st, q, k, v, ld, omega, (const bf16_t*)out, dout, ld_out, (const float*)den, dq, ld_d, T, H,
+                           ws_S, ws_z, P, Ts);
+    }
+    if (stage == 0 || stage == 2) {
         const size_t lds2 = (size_t)2 * FS_SLOTB + 2 * 256 + sizeof(bf16_t) * (size_t)(2 * FS_C * FS_LDF) + FS_TILEB + sizeof(float) * (128 + 4 * 96);
         static bool attr2 = false;
         if (!attr2) { (void)hipFuncSetAttribute((const void*)favor_fs_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr2 = true; }
-        hipLaunchKernelGGL(favor_fs_dkv_kernel, grid, dim3(FS_NT), lds2, st, q, k, v, ld, omega, (const bf16_t*)out, dout, ld_out, (const float*)den, dk, dv, ld_d, T, H);
-        return 1;
+        hipLaunchKernelGGL(favor_fs_dkv_kernel, grid, dim3(FS_NT), lds2, st, q, k, v, ld, omega, (const bf16_t*)out, dout, ld_out, (const float*)den, dk, dv, ld_d, T, H,
+                           ws_S, ws_z, P, Ts);
     }
+    return 1;
 }

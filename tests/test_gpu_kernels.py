@@ -445,13 +445,13 @@ def test_favor_attention_fwd_bwd_vs_oracle(dt, B, T, H, dh, nf):
 
 
 # the bf16 / d_head 64 / 128-feature "slice" kernels (emo_favor_fs.hip): against the oracle AND against the generic kernels
-@pytest.mark.parametrize('B,T,H', [(2, 256, 2), (1, 32, 1), (3, 96, 3), (1, 1024, 4), (2, 2048, 1)])
-def test_favor_slice_kernels_vs_oracle_and_generic(B, T, H, monkeypatch):
+@pytest.mark.parametrize('B,T,H,segs', [(2, 256, 2, 1), (1, 32, 1, 1), (3, 96, 3, 1), (1, 1024, 4, 1), (2, 2048, 1, 1), (1, 1024, 2, 4), (2, 2048, 1, 3), (1, 2048, 2, 16)])
+def test_favor_slice_kernels_vs_oracle_and_generic(B, T, H, segs, monkeypatch):
     ops = _ops()
     from oracle import model_ref
     from oracle.weights import orthogonal_omega
     dt, dh, nf = torch.bfloat16, 64, 128
-    monkeypatch.setenv('EMO_FAVOR_SEGMENTS', '1')           # single-segment scan (what B*H >= 256 gets by itself)
+    monkeypatch.setenv('EMO_FAVOR_SEGMENTS', str(segs))     # 1: single-segment scan (what B*H >= 256 gets by itself); > 1: segment-parallel, slice main passes
     om = orthogonal_omega(dh, nf, np.random.default_rng(5))
     qkv = _r(B * T, 3 * H * dh, seed=21, dt=dt, scale=0.8)
     q, k, v = [qkv[:, i * H * dh:(i + 1) * H * dh].double().view(B, T, H, dh).requires_grad_(True) for i in range(3)]
