@@ -394,7 +394,7 @@ def launch_ranks(n):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and os.environ.get('EMO_BENCH_SHARE_GPU') != '1':
         sys.exit('bench.py: --gpus %d requested but %d GPU(s) visible: refusing to run (one process per GPU, no oversubscription)' % (n, have))
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
@@ -433,10 +433,11 @@ def main():
     if world != want:
         sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d: launch with `python bench.py --gpus %d` (it starts the ranks itself) or '
                  '`python -m torch.distributed.run --nproc-per-node %d ... bench.py --gpus %d`' % (want, world, want, want, want))
-    if torch.cuda.device_count() < (local_rank + 1 if world > 1 else 1):
+    share = os.environ.get('EMO_BENCH_SHARE_GPU') == '1'     # TEST ONLY: several ranks on one GPU (host-staged gloo plane) to exercise the N > 1 code path
+    if torch.cuda.device_count() < (local_rank + 1 if world > 1 else 1) and not share:
         sys.exit('bench.py: rank %d needs GPU %d but only %d visible: one process per GPU, no sharing' % (rank, local_rank, torch.cuda.device_count()))
     dp.init_distributed(strict=True)                         # the N > 1 line measures emo_comm_* (RCCL behind the C-ABI) or fails
-    local_dev = local_rank if world > 1 else 0
+    local_dev = (local_rank % max(torch.cuda.device_count(), 1)) if world > 1 else 0
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
     torch.manual_seed(0)
