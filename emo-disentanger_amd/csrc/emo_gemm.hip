@@ -988,6 +988,11 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         EMO_LAUNCH_CHECK();
         return EMO_OK;
     }
+    if (big && !a_trans && !b_trans && !ln_fused && !accumulate &&
+        emo_gemm_w128_try((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, dtype_out, M, N, K, ep, st)) {    // long-K NT products on 256 x 256 tiles (opt-in)
+        EMO_LAUNCH_CHECK();
+        return EMO_OK;
+    }
     EMO_CHECK(!ep.mask_out && ep.mul_mode != EMO_MUL_BITMASK, "emo_gemm: mask_out / EMO_MUL_BITMASK need bf16 in/out, NT, K = 512, M %% 128 == 0, M >= 32768, N %% 64 == 0, N <= 2048");
     EMO_CHECK(!ln_fused, "emo_gemm: the LayerNorm-folded epilogue (ln_c1 / rln_x) exists only on the skinny path (bf16, M <= 32, NT, K %% 32 == 0)");
     const int64_t BMt = big ? GB_M : 64, BNt = big ? GB_N : 64;

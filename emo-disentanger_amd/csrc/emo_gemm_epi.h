@@ -203,3 +203,6 @@ __device__ __forceinline__ void epi_row8(const EpiParams& ep, OutT* __restrict__
 // A-stationary K = 512 kernel (emo_gemm_astat.hip): true when the shape / epilogue is eligible and the launch was queued.
 bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int dtype_out, int64_t M, int64_t N, int64_t K,
                         const EpiParams& ep, hipStream_t st);
+// 256 x 256 tile, one wave per SIMD (emo_gemm_w128.hip): long-K NT products; true when eligible and queued.
+bool emo_gemm_w128_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int dtype_out, int64_t M, int64_t N, int64_t K,
+                       const EpiParams& ep, hipStream_t st);

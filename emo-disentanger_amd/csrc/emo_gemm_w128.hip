@@ -1,0 +1,227 @@
+// 256 x 256 x 64 bf16 GEMM tile with ONE wave per SIMD: 4 waves, each owning a 128 x 128 quadrant (64 accumulator fragments = 256 registers,
+// which hipcc places in the accumulation VGPRs at this occupancy), for the long-K products of the layer (K >= 1024: FFN2 forward, QKV / FFN1
+// dgrad).  Why this shape: under load the package sits at its 1400 W limit and the shader clock is pulled down (tools/sustained_gemm.py), so
+// what a GEMM holds is set by the energy per flop, and the 128 x 128 tile with 64 x 64 wave quadrants spends twice the LDS-read bytes and
+// twice the L2 -> LDS bytes per flop of this one (0.031 / 0.0156 B per flop against 0.0156 / 0.0078).
+//   * operands: K-contiguous rows (A [M,K]; B [N,K] = nn.Linear weights), LDS image [256 rows][8 x 16-B chunks], chunk ^= row & 7, filled by
+//     LDS-DMA issued as inline asm (SGPR base + 32-bit lane offset; behind the builtin hipcc answers later fragment reads with full waits);
+//     the B rows a fragment reads are permuted (as in the A-stationary kernel) so that a lane owns 8 CONSECUTIVE output columns per fragment
+//     pair -> 16-B stores / residual loads straight from the accumulators; B's chunk swizzle is ((row >> 1) & 1) | ((row >> 3) & 3) << 1,
+//     the one that is conflict-free for those permuted rows (A: row & 7);
+//   * rings: A 3 slots, B 2 slots (160 KB): at the sync point in the middle of K-tile t (between its two 32-deep steps) a wave waits for
+//     tile t+1 with a counted vmcnt (tile t+2's A stays in flight), one s_barrier, then re-stages B(t+2) / A(t+3) into the slots tile t no
+//     longer reads (its second-step fragments are already in registers);
+//   * fragments are double-buffered in registers: the reads of the NEXT 32-deep step are spread over the first six MFMA groups of the
+//     current one (pinned with sched_barrier: left alone the scheduler sinks them next to their uses), so neither an LDS round trip nor a
+//     DMA wait sits in front of an MFMA in steady state: per K-tile 128 MFMAs per wave, one barrier.
+#include "emo_gemm_epi.h"
+
+namespace {
+constexpr int W_BM = 256, W_BN = 256, W_BK = 64;
+constexpr int W_TILE = 256 * W_BK * 2;                        // one operand tile: 32 KB
+constexpr int W_NA = 3, W_NB = 2;
+constexpr int W_LDS = (W_NA + W_NB) * W_TILE;                 // 160 KB
+
+__device__ __forceinline__ uint32_t w_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
+
+// two 1-KB LDS-DMA pieces (wave-uniform 64-bit base + per-lane 32-bit byte offsets) to lds_dst, lds_dst + 1024
+__device__ __forceinline__ void w_dma2(const char* sbase, uint32_t o0, uint32_t o1, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(o0), "v"(o1), "s"(sbase), "s"(lds_dst) : "memory", "scc");
+}
+// MFMA with the accumulator PINNED to the accumulation registers: with the builtin hipcc splits the 256 accumulator registers of a wave between
+// both register files and rotates them through copies on the loop back-edge (264 v_accvgpr moves per K-tile).  The statement is opaque to the
+// hazard recogniser: the same accumulator is never touched again within 63 MFMAs, and the epilogue waits out the last results (w_mma_drain).
+__device__ __forceinline__ void w_mma(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void w_mma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+// dropout multipliers of 8 consecutive elements whose linear index is a multiple of 8: two hashes, bit-identical to drop_mult()
+__device__ __forceinline__ void w_drop8(const DropCtx& d, uint64_t idx0, float (&v)[8]) {
+    const uint32_t lo = (uint32_t)(idx0 >> 2), hi = (uint32_t)(idx0 >> 34) * 0x9E3779B1u;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t h = emo_drop_hash(d, (lo + q) ^ hi), h2 = emo_xs32(h);
+        v[4 * q] *= (h & 0xFFFFu) >= d.thr16 ? d.scale : 0.f;
+        v[4 * q + 1] *= (h >> 16) >= d.thr16 ? d.scale : 0.f;
+        v[4 * q + 2] *= (h2 & 0xFFFFu) >= d.thr16 ? d.scale : 0.f;
+        v[4 * q + 3] *= (h2 >> 16) >= d.thr16 ? d.scale : 0.f;
+    }
+}
+template <int N> __device__ __forceinline__ void w_wait();
+template <> __device__ __forceinline__ void w_wait<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <> __device__ __forceinline__ void w_wait<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+template <> __device__ __forceinline__ void w_wait<24>() { asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); }
+
+template <typename OutT>
+__global__ __launch_bounds__(256, 1) void gemm_w128_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                          OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, EpiParams ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t tiles_n = N / W_BN, tiles_m = M / W_BM;
+    const int64_t bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
+    const int64_t tn = local % tiles_n, tm = (local / tiles_n) * 8 + xcd;      // the column tiles of one row panel back-to-back on one XCD
+    if (tm >= tiles_m) return;
+    const int64_t m0 = tm * W_BM, n0 = tn * W_BN;
+    const int nk = (int)(K / W_BK);
+
+    uint32_t offA[8], offB[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = (wave * 8 + i) * 8 + (lane >> 3);
+        offA[i] = (uint32_t)((r * lda + ((lane & 7) ^ (r & 7)) * 8) * 2);
+        offB[i] = (uint32_t)((r * ldb + ((lane & 7) ^ (((r >> 1) & 1) | (((r >> 3) & 3) << 1))) * 8) * 2);
+    }
+    const char* gA = (const char*)(A + m0 * lda);              // wave-uniform; K-tile t at + t * 128 bytes
+    const char* gB = (const char*)(B + n0 * ldb);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(w_lds_addr(smem));
+    const uint32_t dstw = lds0 + wave * 8192;                   // this wave's 8 KB of a tile slot
+    // fragment addressing: row = rbase + (lane & 15) (rbase % 16 == 0 -> row & 7 == lane & 7), 32-deep step ks: chunk (4 ks + lane / 16) ^ (lane & 7)
+    // B: fragment j, N-index i reads tile row 32 (j >> 1) + 8 (i >> 2) + 4 (j & 1) + (i & 3); its swizzle depends on the lane only
+    const uint32_t foA = (uint32_t)((lane & 15) * 128 + ((((lane >> 4)) ^ (lane & 7)) << 4)) + wr * 128 * 128;     // step 1: ^ 64
+    const uint32_t foB = (uint32_t)((8 * ((lane & 15) >> 2) + (lane & 3)) * 128 + (((lane >> 4) ^ (((lane >> 1) & 1) | (((lane >> 2) & 3) << 1))) << 4)) +
+                         W_NA * W_TILE + wc * 128 * 128;
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int sa_issue = 0, sb_issue = 0;                             // ring slots of the next A / B tile to issue
+    int t_issueA = 0, t_issueB = 0;
+    auto issueA_part = [&](int g) { w_dma2(gA + (int64_t)t_issueA * (W_BK * 2), offA[2 * g], offA[2 * g + 1], dstw + sa_issue * W_TILE + g * 2048); };
+    auto issueB_part = [&](int g) { w_dma2(gB + (int64_t)t_issueB * (W_BK * 2), offB[2 * g], offB[2 * g + 1], dstw + (W_NA + sb_issue) * W_TILE + g * 2048); };
+    auto doneA = [&]() { ++t_issueA; sa_issue = sa_issue == W_NA - 1 ? 0 : sa_issue + 1; };
+    auto doneB = [&]() { ++t_issueB; sb_issue ^= 1; };
+    // prologue: A0 B0 A1 B1 A2 (tiles past the end re-fetch the last one: every count below is a constant; drained before exit)
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const bool isA = (s & 1) == 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { if (isA) issueA_part(g); else issueB_part(g); }
+        if (isA) { doneA(); if (t_issueA > nk - 1) t_issueA = nk - 1; } else { doneB(); if (t_issueB > nk - 1) t_issueB = nk - 1; }
+    }
+    w_wait<24>();                                               // A0, B0 landed (A1, B1, A2 may be in flight)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    bf16x8 fa[2][8], fb[2][8];
+    int sa = 0, sb = 0;                                         // slots of the K-tile being computed
+    const char* ldsb = smem;
+    // read number q (0..15) of a fragment set: B fragments first (the first MFMA group needs all eight), then A
+    // (a_off / b_off: lane offsets with the step's chunk flip already applied: the fragment index is then an immediate offset)
+    auto rd = [&](int set, int q, uint32_t a_off, uint32_t b_off) {
+        if (q < 8) fb[set][q] = *(const bf16x8*)(ldsb + b_off + (32 * (q >> 1) + 4 * (q & 1)) * 128);
+        else fa[set][q - 8] = *(const bf16x8*)(ldsb + a_off + (q - 8) * 2048);
+    };
+    {
+        const uint32_t a_off = foA, b_off = foB;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rd(0, q, a_off, b_off);
+    }
+    constexpr int RQ[9] = {0, 3, 6, 9, 12, 14, 16, 16, 16};      // reads issued before MFMA group i: RQ[i] .. RQ[i+1]-1
+    for (int t = 0; t < nk; ++t) {
+        const uint32_t a_off = (foA + sa * W_TILE) ^ 64u, b_off = (foB + sb * W_TILE) ^ 64u;
+        // ---- step 0 of K-tile t (set 0), reading step 1 (set 1)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int q = RQ[i]; q < RQ[i + 1]; ++q) rd(1, q, a_off, b_off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w_mma(acc[i][j], fb[0][j], fa[0][i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- sync point: K-tile t+1 landed for every wave; every wave's reads of tile t are in registers
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        w_wait<8>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        sa = sa == W_NA - 1 ? 0 : sa + 1;
+        sb ^= 1;
+        const uint32_t a_nx = foA + sa * W_TILE, b_nx = foB + sb * W_TILE;
+        // ---- step 1 of K-tile t (set 1), reading step 0 of tile t+1 (set 0), re-staging B(t+2) then A(t+3)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int q = RQ[i]; q < RQ[i + 1]; ++q) rd(0, q, a_nx, b_nx);
+            if (i < 4) issueB_part(i); else issueA_part(i - 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w_mma(acc[i][j], fb[1][j], fa[1][i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        doneB(); if (t_issueB > nk - 1) t_issueB = nk - 1;
+        doneA(); if (t_issueA > nk - 1) t_issueA = nk - 1;
+    }
+    w_wait<0>();
+    w_mma_drain();
+    // ---- epilogue straight from the accumulators: lane = row .. + (lane & 15), columns 32 h + 8 (lane / 16) .. + 7 of fragment pair h
+    const int ecol = 8 * (lane >> 4);
+    {                                                             // (the launcher admits bias / dropout / residual epilogues only)
+        f32x4 bv[4][2];
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) bv[h][q] = ep.bias ? *(const f32x4*)(ep.bias + n0 + wc * 128 + 32 * h + ecol + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const OutT* rp = (const OutT*)ep.residual;
+#pragma clang loop unroll(full)
+        for (int i2 = 0; i2 < 4; ++i2) {                          // two row fragments at a time: their eight residual pieces are requested together
+            bf16x8 res[2][4];
+            if (rp) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int h = 0; h < 4; ++h)
+                        res[u][h] = *(const bf16x8*)(rp + (m0 + wr * 128 + (2 * i2 + u) * 16 + (lane & 15)) * ep.ldc + n0 + wc * 128 + 32 * h + ecol);
+            }
+#pragma clang loop unroll(full)
+            for (int u = 0; u < 2; ++u) {
+                const int i = 2 * i2 + u;
+                const int64_t m = m0 + wr * 128 + i * 16 + (lane & 15);
+#pragma clang loop unroll(full)
+                for (int h = 0; h < 4; ++h) {
+                    const int64_t n = n0 + wc * 128 + 32 * h + ecol;
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * h][r] + bv[h][0][r]; v[4 + r] = acc[i][2 * h + 1][r] + bv[h][1][r]; }
+                    if (ep.drop.thr16) w_drop8(ep.drop, (uint64_t)(m * N + n), v);
+                    if (rp) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += (float)res[u][h][r];
+                    }
+                    bf16x8 o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
+                    *(bf16x8*)(C + m * ep.ldc + n) = o;
+                }
+            }
+        }
+    }
+}
+}  // namespace
+
+// NT bf16 product on 256 x 256 tiles; true when the shape is eligible and the launch was queued.  Default: long reductions (K >= 1024) with at
+// least one tile per CU; EMO_GEMM_W128=0 switches it off, =1 admits every eligible shape (tests).
+bool emo_gemm_w128_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int dtype_out, int64_t M, int64_t N, int64_t K,
+                       const EpiParams& ep, hipStream_t st) {
+    const char* e = getenv("EMO_GEMM_W128");                   // (read per call: tests toggle it in-process)
+    const int mode = e ? atoi(e) : -1;
+    if (mode == 0) return false;
+    if ((M % W_BM) || (N % W_BN) || (K % W_BK) || K < 4 * W_BK || dtype_out != EMO_BF16) return false;
+    if (mode < 0 && (K < 1024 || (M / W_BM) * (N / W_BN) < 256)) return false;
+    if (ep.atomic || ep.accumulate || ep.ws_stride || ep.a_rowsum || ep.b_rowsum || ep.ln_c1 || ep.rln_x || ep.mask_out) return false;
+    if (ep.aux_out || ep.mul_mode != EMO_MUL_NONE || ep.act != EMO_ACT_NONE) return false;       // register epilogue: bias, dropout, residual
+    if ((lda & 7) || (ldb & 7) || (ep.ldc & 7) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return false;
+    if ((uint64_t)(256 * (lda > ldb ? lda : ldb) + 64) * 2 >= 0xFFFF0000ull) return false;
+    const int64_t tiles_m = M / W_BM, tiles_n = N / W_BN;
+    dim3 grid((unsigned)(((tiles_m + 7) / 8) * 8 * tiles_n));
+    auto k = gemm_w128_kernel<bf16_t>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS); attr = true; }
+    hipLaunchKernelGGL(k, grid, dim3(256), W_LDS, st, A, lda, B, ldb, (bf16_t*)C, M, N, K, ep);
+    return true;
+}
