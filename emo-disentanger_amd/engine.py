@@ -99,14 +99,17 @@ class ParamStore:
         self._mirror_version = self._write_signal()
         self._mirror_epoch += 1
 
-    def wT(self, name):
-        """bf16 TRANSPOSED copy [in, out] of the nn.Linear weight `name` ([out, in]), refreshed when the mirror changes: the dgrad
-        dX = dY W then is the same k-contiguous NT product as a forward (the K = 512 dgrads run on the A-stationary kernel)."""
-        ent = self._wT.get(name)
+    def wT(self, name, fused_rows=None):
+        """bf16 TRANSPOSED copy [in, out] of the nn.Linear weight `name` ([out, in]; fused_rows: the [3D, D] q/k/v view), refreshed when the
+        mirror changes: the dgrad dX = dY W then is the same k-contiguous NT product as a forward (K = 512: the A-stationary kernel; the
+        long reductions: the 256 x 256 tile kernel)."""
+        key = (name, fused_rows)
+        ent = self._wT.get(key)
         if ent is None:
-            ent = self._wT[name] = [torch.empty(self.shapes[name][::-1], device=self.device, dtype=torch.bfloat16), -1]
+            shape = self.shapes[name] if fused_rows is None else (fused_rows, self.shapes[name][1])
+            ent = self._wT[key] = [torch.empty(shape[::-1], device=self.device, dtype=torch.bfloat16), -1]
         if ent[1] != self._mirror_epoch:
-            ent[0].copy_(self.w(name).t())
+            ent[0].copy_(self.w(name, fused_rows).t())
             ent[1] = self._mirror_epoch
         return ent[0]
 
@@ -280,7 +283,9 @@ def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
     else:
         df = ops.gemm(dyd, ps.w(pfx + 'linear2.weight'), b_trans=True, mul_aux=s['f'], mul_mode=ops.MUL_NONZERO, mul_scale=inv)
     _wgrad(ps, pfx + 'linear1.weight', pfx + 'linear1.bias', df, s['h1'])
-    dh1 = ops.gemm(df, ps.w(pfx + 'linear1.weight'), b_trans=True, residual=g2)
+    # the long-reduction dgrads (K = 2048 / 1536) as NT products against transposed mirrors too: 256 x 256 tile kernel (emo_gemm_w128.hip)
+    nt_long = bf and dout.shape[0] % 256 == 0 and _os.environ.get('EMO_DGRAD_NT', '1') != '0'
+    dh1 = ops.gemm(df, ps.wT(pfx + 'linear1.weight'), residual=g2) if nt_long else ops.gemm(df, ps.w(pfx + 'linear1.weight'), b_trans=True, residual=g2)
     g1, da = ops.layernorm_bwd(dh1, s['x1'], ps.f32(pfx + 'norm1.weight'), s['m1'], s['r1'], ps.g(pfx + 'norm1.weight'), ps.g(pfx + 'norm1.bias'),
                                want_drop=p > 0, p_drop=p, seed=seed, offset=off + 1, dcol=ps.g(pfx + 'attention.out_projection.bias'))
     if da is None:
@@ -292,6 +297,8 @@ def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
     dqkv = dq._base if dq._base is not None else torch.cat([dq, dk, dv], 1)
     q = pfx + 'attention.query_projection.'
     _wgrad(ps, q + 'weight', q + 'bias', dqkv, s['x'], fused_rows=3 * D)
+    if nt_long:
+        return ops.gemm(dqkv, ps.wT(q + 'weight', 3 * D), residual=g1)
     return ops.gemm(dqkv, ps.w(q + 'weight', 3 * D), b_trans=True, residual=g1)
 
 
