@@ -865,6 +865,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     ((f32x4*)out)[i] = (a + b) + (c + d);
 }
 
+void emo_splitk_reduce_launch(const float* ws, int64_t stride, int splits, float* out, int64_t n4, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, st, ws, stride, splits, out, n4, accumulate);
+}
+
 // number of K-splits for a plain fp32-output GEMM (wgrad).  max_ws_splits > 0: partials go to a caller workspace (plain stores +
 // splitk_reduce_kernel); 0: fp32 atomics into C.
 static int64_t choose_splits(int64_t M, int64_t N, int64_t K, bool big, bool has_epi, int dtype_out, int64_t BMt, int64_t BNt, int64_t BKt,
@@ -909,6 +913,7 @@ extern "C" int64_t emo_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int
     const bool big = dtype_in == EMO_BF16;
     const int64_t BMt = big ? GB_M : 64, BNt = big ? GB_N : 64, BKt = big ? (gemm_variant() >= 2 ? G2_BK : GB_K) : 16;
     int64_t splits = choose_splits(M, N, K, big, false, dtype_out, BMt, BNt, BKt, EMO_GEMM_MAX_SPLITS);
+    if (big) { const int64_t s2 = emo_gemm_w128_tn_splits(M, N, K); if (s2 > splits) splits = s2; }     // (layout unknown here: sized for the wgrad kernel too)
     return splits > 1 ? splits * M * N * (int64_t)sizeof(float) : 0;
 }
 
@@ -985,6 +990,11 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     }
     if (big && !a_trans && !b_trans && !ln_fused && !use_safe_tr() &&
         emo_gemm_astat_try((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, dtype_out, M, N, K, ep, st)) {   // K = 512, A stationary in registers
+        EMO_LAUNCH_CHECK();
+        return EMO_OK;
+    }
+    if (big && a_trans && b_trans && dtype_out == EMO_F32 && !has_epi && !ep.b_rowsum && !ln_fused && !use_safe_tr() && e &&
+        emo_gemm_w128_tn_try((const bf16_t*)A, lda, (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, accumulate, ep.a_rowsum, e->workspace, e->workspace_bytes, st)) {
         EMO_LAUNCH_CHECK();
         return EMO_OK;
     }

@@ -37,6 +37,13 @@ __device__ __forceinline__ void w_dma2(const char* sbase, uint32_t o0, uint32_t 
 __device__ __forceinline__ void w_mma(f32x4& c, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
+// the same with the accumulator in ordinary VGPRs (the bias-gradient sums): as a builtin, hipcc also wants these in the accumulation registers,
+// evicts accumulators of w_mma to make room and reads them back right behind an MFMA it cannot see (no wait states): wrong sums
+__device__ __forceinline__ void w_mma_v(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    // (s_nop: hipcc rebuilds the constant all-ones operand with v_mov right in front of the statement, and a VALU write needs wait states
+    // before an MFMA reads the register — the hazard recogniser does not look inside an asm statement)
+    asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
 __device__ __forceinline__ void w_mma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 // dropout multipliers of 8 consecutive elements whose linear index is a multiple of 8: two hashes, bit-identical to drop_mult()
 __device__ __forceinline__ void w_drop8(const DropCtx& d, uint64_t idx0, float (&v)[8]) {
@@ -202,6 +209,151 @@ __global__ __launch_bounds__(256, 1) void gemm_w128_kernel(const bf16_t* __restr
         }
     }
 }
+
+// ================================================================================================ TN: dW[M,N] (+)= A[K,M]^T B[K,N]  (wgrad)
+// Both operands are stored token-major (K = the B*T tokens, rows of dY / X), so a K-tile of an operand is 64 rows x 256 columns: LDS image =
+// two halves of [64 k][128 columns] with the 32-B granule swizzle of the 128 x 128 wgrad kernel, fragments by `ds_read_b64_tr_b16` (two per
+// fragment).  Split-K over the tokens: all output tiles of one split run on ONE XCD (its token range is fetched from HBM once into that L2),
+// the fp32 partial tiles go to the caller's workspace with plain 16-B stores and splitk_reduce_kernel sums them in a fixed order.
+// RS = 1: a_rowsum[m] += sum_k A[k][m] (the bias gradient) as MFMAs against an all-ones operand: the two waves that hold the same A rows
+// take alternate fragments, and of the tiles_n blocks that read the same A columns block tn takes the K-tiles with index % tiles_n == tn.
+__device__ __forceinline__ int w_swz_k(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+template <int RS>
+__global__ __launch_bounds__(256, 1) void gemm_w128_tn_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                             float* __restrict__ Cws, int64_t M, int64_t N, int64_t K, int64_t kps, float* __restrict__ a_rowsum) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t tiles_n = N / W_BN, ntile = (M / W_BM) * tiles_n;
+    const int64_t bid = blockIdx.x, xcd = bid & 7, q = bid >> 3;
+    const int64_t split = xcd + 8 * (q / ntile), t_id = q % ntile;
+    const int64_t tm = t_id / tiles_n, tn = t_id % tiles_n;
+    const int64_t m0 = tm * W_BM, n0 = tn * W_BN;
+    const int64_t kbeg = split * kps;
+    const int64_t kend = (kbeg + kps < K) ? kbeg + kps : K;
+    float* C = Cws + split * M * N;
+    const int nk = kbeg < kend ? (int)((kend - kbeg) / W_BK) : 0;
+    if (nk == 0) {                                              // (a split past the end: its partial tile is zeros)
+#pragma unroll 4
+        for (int e = tid; e < 256 * 64; e += 256) *(f32x4*)(C + (m0 + (e >> 6)) * N + n0 + (e & 63) * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    uint32_t offA[8], offB[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int J = wave * 8 + i, half = J >> 4, j = J & 15;
+        const int k = j * 4 + (lane >> 4), p16 = lane & 15, g = (p16 >> 1) ^ w_swz_k(k);
+        offA[i] = (uint32_t)((k * lda + half * 128 + (g * 2 + (p16 & 1)) * 8) * 2);
+        offB[i] = (uint32_t)((k * ldb + half * 128 + (g * 2 + (p16 & 1)) * 8) * 2);
+    }
+    const char* gA = (const char*)(A + kbeg * lda + m0);         // wave-uniform; K-tile t at + t * 64 rows
+    const char* gB = (const char*)(B + kbeg * ldb + n0);
+    const int64_t stepA = 64 * lda * 2, stepB = 64 * ldb * 2;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(w_lds_addr(smem));
+    const uint32_t dstw = lds0 + wave * 8192;
+    // fragment addressing (see lfrag2<false, 64> of the 128 x 128 kernel): k = 32 ks + 8 (lane / 16) + 4 h + (lane & 15) / 4, swizzle = lane constant
+    const int li = lane & 15;
+    const uint32_t fo = (uint32_t)((((lane >> 4) * 8 + (li >> 2)) * 256) | ((((li >> 2) & 3) | (((lane >> 4) & 1) << 2)) << 5) | ((li & 3) << 3));
+    const uint32_t foA = fo + wr * 16384, foB = fo + W_NA * W_TILE + wc * 16384;
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 rs[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rs[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16_t one_b = (bf16_t)1.f;
+    bf16x8 ones = {one_b, one_b, one_b, one_b, one_b, one_b, one_b, one_b};
+    asm volatile("" : "+v"(ones));                              // opaque: one live register tuple instead of a rematerialised constant
+    int rs_phase = RS ? (int)((kbeg / W_BK) % tiles_n) : 0;      // K-tile index modulo tiles_n
+
+    int sa_issue = 0, sb_issue = 0, t_issueA = 0, t_issueB = 0;
+    auto issueA_part = [&](int g) { w_dma2(gA + (int64_t)t_issueA * stepA, offA[2 * g], offA[2 * g + 1], dstw + sa_issue * W_TILE + g * 2048); };
+    auto issueB_part = [&](int g) { w_dma2(gB + (int64_t)t_issueB * stepB, offB[2 * g], offB[2 * g + 1], dstw + (W_NA + sb_issue) * W_TILE + g * 2048); };
+    auto doneA = [&]() { ++t_issueA; sa_issue = sa_issue == W_NA - 1 ? 0 : sa_issue + 1; if (t_issueA > nk - 1) t_issueA = nk - 1; };
+    auto doneB = [&]() { ++t_issueB; sb_issue ^= 1; if (t_issueB > nk - 1) t_issueB = nk - 1; };
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const bool isA = (s & 1) == 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { if (isA) issueA_part(g); else issueB_part(g); }
+        if (isA) doneA(); else doneB();
+    }
+    w_wait<24>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    bf16x8 fa[2][8], fb[2][8];
+    int sa = 0, sb = 0;
+    const char* ldsb = smem;
+    auto rd1 = [&](uint32_t off) -> bf16x8 {                     // off: lane offset with slot / half / fragment / step already applied
+        bf16x8 v;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(ldsb + off + h * 1024));
+            const bf16x4 tb = __builtin_bit_cast(bf16x4, t);
+            v[4 * h] = tb[0]; v[4 * h + 1] = tb[1]; v[4 * h + 2] = tb[2]; v[4 * h + 3] = tb[3];
+        }
+        return v;
+    };
+    // read number q (0..15) of a fragment set (B first); ks8 = 8192 * step
+    auto rd = [&](int set, int q2, uint32_t a_off, uint32_t b_off, int ks8) {
+        if (q2 < 8) fb[set][q2] = rd1((b_off ^ (uint32_t)(q2 << 5)) + ks8);
+        else fa[set][q2 - 8] = rd1((a_off ^ (uint32_t)((q2 - 8) << 5)) + ks8);
+    };
+#pragma unroll
+    for (int q2 = 0; q2 < 16; ++q2) rd(0, q2, foA, foB, 0);
+    constexpr int RQ[9] = {0, 3, 6, 9, 12, 14, 16, 16, 16};
+    for (int t = 0; t < nk; ++t) {
+        const uint32_t a_off = foA + sa * W_TILE, b_off = foB + sb * W_TILE;
+        const bool rs_on = RS && rs_phase == (int)tn;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int q2 = RQ[i]; q2 < RQ[i + 1]; ++q2) rd(1, q2, a_off, b_off, 8192);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w_mma(acc[i][j], fb[0][j], fa[0][i]);
+            if (RS && rs_on && (i & 1) == wc) w_mma_v(rs[i >> 1], ones, fa[0][i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        w_wait<8>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        sa = sa == W_NA - 1 ? 0 : sa + 1;
+        sb ^= 1;
+        const uint32_t a_nx = foA + sa * W_TILE, b_nx = foB + sb * W_TILE;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int q2 = RQ[i]; q2 < RQ[i + 1]; ++q2) rd(0, q2, a_nx, b_nx, 0);
+            if (i < 4) issueB_part(i); else issueA_part(i - 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w_mma(acc[i][j], fb[1][j], fa[1][i]);
+            if (RS && rs_on && (i & 1) == wc) w_mma_v(rs[i >> 1], ones, fa[1][i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        doneB();
+        doneA();
+        if (RS) { if (++rs_phase == (int)tiles_n) rs_phase = 0; }
+    }
+    w_wait<0>();
+    w_mma_drain();
+    if (RS && (lane >> 4) == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) atomicAdd(a_rowsum + m0 + wr * 128 + (2 * u + wc) * 16 + lane, rs[u][0]);
+    }
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 8; ++i) {
+        float* crow = C + (m0 + wr * 128 + i * 16 + (lane & 15)) * N + n0 + wc * 128 + (lane >> 4) * 4;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < 8; ++j) *(f32x4*)(crow + j * 16) = acc[i][j];
+    }
+}
 }  // namespace
 
 // NT bf16 product on 256 x 256 tiles; true when the shape is eligible and the launch was queued.  Default: long reductions (K >= 1024) with at
@@ -223,5 +375,46 @@ bool emo_gemm_w128_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ld
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS); attr = true; }
     hipLaunchKernelGGL(k, grid, dim3(256), W_LDS, st, A, lda, B, ldb, (bf16_t*)C, M, N, K, ep);
+    return true;
+}
+
+// K-splits of the TN (wgrad) product on 256 x 256 tiles: a multiple of 8 (one split per XCD per round) that puts at most one block on
+// every CU; 0 = shape not taken by this kernel.
+int64_t emo_gemm_w128_tn_splits(int64_t M, int64_t N, int64_t K) {
+    const char* e = getenv("EMO_GEMM_W128");
+    if (e && atoi(e) == 0) return 0;
+    const char* e2 = getenv("EMO_GEMM_W128_TN");
+    if (e2 && atoi(e2) == 0) return 0;
+    if ((M % W_BM) || (N % W_BN) || (K % W_BK)) return 0;
+    const int64_t ntile = (M / W_BM) * (N / W_BN);
+    int64_t splits = (256 / ntile) / 8 * 8;
+    if (splits < 8 || splits > 32 || ntile * splits < 160) return 0;
+    while (splits > 8 && K / W_BK / splits < 8) splits -= 8;     // at least 8 K-tiles per split
+    if (K / W_BK / splits < 8) return 0;
+    return splits;
+}
+
+void emo_splitk_reduce_launch(const float* ws, int64_t stride, int splits, float* out, int64_t n4, int accumulate, hipStream_t st);
+
+// dW[M,N] (+)= A[K,M]^T B[K,N], fp32 out, contiguous C, workspace of >= splits * M * N floats; rowsum: optional a_rowsum[M] += column sums of A
+bool emo_gemm_w128_tn_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate,
+                          float* a_rowsum, void* ws, int64_t ws_bytes, hipStream_t st) {
+    const int64_t splits0 = emo_gemm_w128_tn_splits(M, N, K);
+    if (!splits0 || ldc != N || !ws || ((uintptr_t)ws & 15) || ws_bytes < splits0 * M * N * (int64_t)sizeof(float)) return false;
+    if ((lda & 7) || (ldb & 7) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return false;
+    if ((uint64_t)(64 * (lda > ldb ? lda : ldb) + 256) * 2 >= 0xFFFF0000ull) return false;
+    const int64_t kps = ((K / W_BK + splits0 - 1) / splits0) * W_BK;
+    const int64_t ntile = (M / W_BM) * (N / W_BN);
+    dim3 grid((unsigned)(ntile * splits0));
+#define W_TN_LAUNCH(RSv)                                                                                                                     \
+    do {                                                                                                                                     \
+        auto k = gemm_w128_tn_kernel<RSv>;                                                                                                   \
+        static bool attr = false;                                                                                                            \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS); attr = true; }            \
+        hipLaunchKernelGGL(k, grid, dim3(256), W_LDS, st, A, lda, B, ldb, (float*)ws, M, N, K, kps, a_rowsum);                               \
+    } while (0)
+    if (a_rowsum) W_TN_LAUNCH(1); else W_TN_LAUNCH(0);
+#undef W_TN_LAUNCH
+    emo_splitk_reduce_launch((const float*)ws, M * N, (int)splits0, C, (M * N) >> 2, accumulate, st);
     return true;
 }
