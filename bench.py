@@ -45,19 +45,20 @@ def time_kernel(fn, iters=10, warm=3):
 
 
 GEMM_KERNELS = {   # layout class of ops.gemm -> the kernel instance it launches at the bench shapes (names as in the rocprofv3 summary)
-    'TN': ('gemm_bf16_kernel<false,false,false,float,64,RS> (RS=1: with the bias gradient, RS=0: without) + splitk_reduce_kernel',
-           'wgrad dW = dY^T X, reduction over the B*T tokens'),
+    'TN': ('gemm_w128_tn_kernel<RS> (256x256 tile, one wave per SIMD; RS=1: with the bias gradient; the 512x512 projection and the logits layer stay on '
+           'gemm_bf16_kernel<false,false,false,float,64,RS>) + splitk_reduce_kernel', 'wgrad dW = dY^T X, reduction over the B*T tokens'),
     'NN': ('gemm_bf16_glds_kernel<true,false,bf16,32,2>', 'dgrad dX = dY W'),
     'NT': ('gemm_bf16_glds_kernel<true,true,bf16,32,3>', 'forward Y = X W^T + fused epilogue, K = 512 (shapes outside the A-stationary class)'),
     'NT/K=512': ('gemm_astat_kernel<bf16,BITS> (A stationary in registers, weights through the LDS ring)',
                  'K = 512 products: QKV / out-projection / FFN1 forward, FFN2 / out-projection dgrad against transposed weight mirrors'),
-    'NT/K>1024': ('gemm_bf16_glds_kernel<true,true,bf16,64,2>', 'forward Y = X W^T + fused epilogue, K = 2048'),
+    'NT/K>1024': ('gemm_w128_kernel<bf16> (256x256 tile, one wave per SIMD, 128x128 quadrant per wave)',
+                  'long reductions: FFN2 forward (K = 2048, bias + dropout + residual) and the FFN1 / QKV dgrads (K = 2048 / 1536) as NT products against transposed weight mirrors'),
 }
 
 
 def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
     """Every GEMM launch inside `n_steps` real training steps is bracketed by HIP events on its launch stream (in situ: same data,
-    same cache state as the timed region).  The four GEMM kernel instances (wgrad TN, dgrad NN, forward NT at K=512 and K=2048) take ~65 % of the
+    same cache state as the timed region).  The GEMM kernel classes (wgrad TN, A-stationary NT at K=512, long-reduction NT: FFN2 forward + dgrads) take ~65 % of the
     step; `roofline` is the class with the largest total time (the dominant kernel of the rocprofv3 summary under profiles/),
     the others are listed in `roofline_others`.  achieved = sum(algorithmic FLOPs = 2*M*N*K) / sum(durations).
 
@@ -120,7 +121,7 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
 
 
 ATTN_KERNELS = {'favor_fwd': ('favor_fs_fwd_kernel (bf16 slice kernel; generic: favor_fwd_kernel)', 'hbm', 'FAVOR+ causal linear attention forward: features + chunked prefix-sum scan; bytes = q, k, v read + out written (4*512*e per token*layer)'),
-                'favor_bwd': ('favor_bwd_dq_kernel + favor_bwd_dkv_kernel', 'hbm', 'FAVOR+ backward (forward sweep dq, reverse sweep dk/dv); bytes = 7*512*e per token*layer'),
+                'favor_bwd': ('favor_fs_dq_kernel + favor_fs_dkv_kernel (bf16 slice kernels; generic: favor_bwd_dq_kernel / favor_bwd_dkv_kernel)', 'hbm', 'FAVOR+ backward (forward sweep dq, reverse sweep dk/dv); bytes = 7*512*e per token*layer'),
                 'sattn_fwd': ('sattn_fwd_kernel', 'mfma', 'GPT-2 causal softmax attention forward (flash tiles): 2 matmuls, causal half'),
                 'sattn_bwd': ('sattn_bwd_dq_kernel + sattn_bwd_dkv_kernel', 'mfma', 'GPT-2 attention backward: 7 matmuls, causal half')}
 

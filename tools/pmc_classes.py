@@ -5,9 +5,9 @@
 SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES).  usage: pmc_classes.py out.json db1 db2 ..."""
 import collections, json, sqlite3, sys
 
-CLASSES = [('NT/K=512', ('gemm_astat_kernel',)), ('TN', ('gemm_bf16_kernelILb0ELb0', 'gemm_bf16_kernel<false, false')), ('TN-reduce', ('splitk_reduce_kernel',)),
+CLASSES = [('NT/K=512', ('gemm_astat_kernel',)), ('TN', ('gemm_w128_tn_kernel', 'gemm_bf16_kernelILb0ELb0', 'gemm_bf16_kernel<false, false')), ('TN-reduce', ('splitk_reduce_kernel',)),
            ('NN', ('gemm_bf16_glds_kernelILb1ELb0', 'gemm_bf16_glds_kernel<true, false')),
-           ('NT/K>1024', ('gemm_bf16_glds_kernelILb1ELb1EDF16bLi64ELi2', 'gemm_bf16_glds_kernel<true, true, __bf16, 64, 2')),
+           ('NT/K>1024', ('gemm_w128_kernel', 'gemm_bf16_glds_kernelILb1ELb1EDF16bLi64ELi2', 'gemm_bf16_glds_kernel<true, true, __bf16, 64, 2')),
            ('NT', ('gemm_bf16_glds_kernelILb1ELb1',  'gemm_bf16_glds_kernel<true, true')),
            ('favor_fwd', ('favor_fs_fwd_kernel', 'favor_fwd_kernel')), ('favor_bwd_dq', ('favor_bwd_dq_kernel', 'favor_fs_dq_kernel')),
            ('favor_bwd_dkv', ('favor_bwd_dkv_kernel', 'favor_fs_dkv_kernel')), ('layernorm_fwd', ('layernorm_fwd',)), ('layernorm_bwd', ('layernorm_bwd',))]
