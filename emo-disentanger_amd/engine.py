@@ -312,7 +312,11 @@ def gpt2_block_fwd(ps, pfx, x, B, T, H, p, seed, off, save):
     n2, m2, r2 = ops.layernorm_fwd(h, ps.f32(pfx + 'ln_2.weight'), ps.f32(pfx + 'ln_2.bias'))
     z = torch.empty(x.shape[0], ps.shapes[pfx + 'mlp.c_fc.weight'][1], device=x.device, dtype=x.dtype) if save is not None else None
     f = ops.gemm(n2, ps.w(pfx + 'mlp.c_fc.weight'), b_trans=True, bias=ps.f32(pfx + 'mlp.c_fc.bias'), act=ops.ACT_GELU_NEW, aux_out=z)
-    out = ops.gemm(f, ps.w(pfx + 'mlp.c_proj.weight'), b_trans=True, bias=ps.f32(pfx + 'mlp.c_proj.bias'), p_drop=p, seed=seed, offset=off + 3, residual=h)
+    if ps.flat16 is not None and x.shape[0] % 256 == 0 and x.shape[0] >= 32768 and _os.environ.get('EMO_DGRAD_NT', '1') != '0':
+        # K = 2048 reduction as an NT product against the transposed mirror ([out, in] of the Conv1D weight): the 256 x 256 tile kernel
+        out = ops.gemm(f, ps.wT(pfx + 'mlp.c_proj.weight'), bias=ps.f32(pfx + 'mlp.c_proj.bias'), p_drop=p, seed=seed, offset=off + 3, residual=h)
+    else:
+        out = ops.gemm(f, ps.w(pfx + 'mlp.c_proj.weight'), b_trans=True, bias=ps.f32(pfx + 'mlp.c_proj.bias'), p_drop=p, seed=seed, offset=off + 3, residual=h)
     if save is not None:
         save.t = dict(x=x, m1=m1, r1=r1, n1=n1, qkv=qkv, a=a, lse=lse, h=h, m2=m2, r2=r2, n2=n2, z=z, f=f)
     return out

@@ -166,8 +166,7 @@ def test_gemm_splitk_workspace_stays_inside_its_bounds(splits, monkeypatch):
 
 
 def test_gemm_large_wgrad_matches_torch_and_is_deterministic():
-    # 12 output tiles of 256^2, 32768 tokens: split-K with a workspace and the fused bias gradient (128^2 kernel by default, the 256^2
-    # four-phase kernel with EMO_GEMM_G6=2)
+    # 12 output tiles of 256^2, 32768 tokens: split-K with a workspace and the fused bias gradient (the 256^2 one-wave-per-SIMD tile)
     ops = _ops()
     M, N, K = 1024, 768, 32768
     dy, x = (_r(K, M, seed=1) * 0.5).to(torch.bfloat16).cuda(), (_r(K, N, seed=2) * 0.5).to(torch.bfloat16).cuda()
@@ -181,6 +180,48 @@ def test_gemm_large_wgrad_matches_torch_and_is_deterministic():
     assert float((outs[0].double() - ref).abs().max() / ref.abs().max()) < 1e-4
     want = dy.double().sum(0)
     assert float((db.double() - want).abs().max() / want.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize('shape', [(512, 256, 320), (1024, 512, 2048), (2048, 768, 1024), (256, 1024, 4096)])
+def test_gemm_256_tile_nt_matches_reference_and_128_tile(shape, monkeypatch):
+    # emo_gemm_w128.hip: 256 x 256 tile, one wave per SIMD (default for K >= 1024 with >= 256 tiles; EMO_GEMM_W128=1 admits every eligible shape).
+    # Against fp64 and BIT-identical to the 128 x 128 kernel (same k order, same dropout hash) for every epilogue it takes.
+    ops = _ops()
+    M, N, K = shape
+    A, W = _r(M, K, seed=1).to(torch.bfloat16).cuda(), _r(N, K, seed=2, scale=0.1).to(torch.bfloat16).cuda()
+    bias, res = _r(N, seed=3).cuda(), _r(M, N, seed=4).to(torch.bfloat16).cuda()
+    for kw in ({}, dict(bias=bias), dict(residual=res), dict(bias=bias, p_drop=0.1, seed=5, offset=7, residual=res)):
+        monkeypatch.setenv('EMO_GEMM_W128', '1')
+        y1, y2 = ops.gemm(A, W, **kw), ops.gemm(A, W, **kw)
+        monkeypatch.setenv('EMO_GEMM_W128', '0')
+        y0 = ops.gemm(A, W, **kw)
+        assert torch.equal(y1, y2) and torch.equal(y1, y0), kw.keys()
+        if 'p_drop' not in kw:
+            ref = A.double() @ W.double().T + (bias.double() if 'bias' in kw else 0.0) + (res.double() if 'residual' in kw else 0.0)
+            _close(y1, ref, torch.bfloat16, mult=1.0)
+
+
+@pytest.mark.parametrize('shape', [(8192, 2048, 512), (16384, 512, 2048), (8192, 1536, 512)])
+def test_gemm_256_tile_wgrad_matches_reference_with_bias_gradient(shape, monkeypatch):
+    # the wgrad instance of the same tile: token-major operands, split-K through the workspace, bias gradient by ones-MFMAs; with and
+    # without the bias gradient the weight gradient must be the SAME bits (the r03 compiler trap: see the kernel source), and deterministic
+    ops = _ops()
+    K, M, N = shape
+    dy, x = _r(K, M, seed=1).to(torch.bfloat16).cuda(), _r(K, N, seed=2).to(torch.bfloat16).cuda()
+    ref, want = dy.double().T @ x.double(), dy.double().sum(0)
+    for acc in (False, True):
+        got = {}
+        for mode in ('1', '0'):
+            monkeypatch.setenv('EMO_GEMM_W128_TN', mode)
+            dw, db, dw2 = torch.full((M, N), 0.5, device='cuda'), torch.full((M,), 0.25, device='cuda'), torch.full((M, N), 0.5, device='cuda')
+            ops.gemm(dy, x, a_trans=True, b_trans=True, out=dw, accumulate=acc, a_rowsum=db)
+            ops.gemm(dy, x, a_trans=True, b_trans=True, out=dw2, accumulate=acc)
+            got[mode] = (dw, db, dw2)
+        dw, db, dw2 = got['1']
+        assert torch.equal(dw, dw2)
+        assert float((dw.double() - (ref + (0.5 if acc else 0.0))).abs().max() / ref.abs().max()) < 2e-5
+        assert float((db.double() - (want + 0.25)).abs().max() / want.abs().max()) < 1e-4
+        assert float((dw - got['0'][0]).abs().max() / ref.abs().max()) < 2e-5      # the 128 x 128 kernel (other split count: not the same bits)
 
 
 @pytest.mark.parametrize('M', [1, 7, 32])
