@@ -991,3 +991,52 @@ extern "C" int emo_cast(const void* src, int sd, void* dst, int dd, int64_t n, e
     EMO_LAUNCH_CHECK();
     return EMO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Batched bf16 transposes (the transposed weight mirrors of engine.ParamStore.wT: 4 per Performer layer, refreshed after every optimizer
+// step): ONE launch for all matrices instead of one ATen copy kernel each (48 x 7.6 us per training step).  desc: n records of six int64
+// {src, dst, rows, cols, first tile, tiles per row}; a block transposes one 64 x 64 tile through LDS (16-B global accesses on both sides).
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const int64_t* __restrict__ desc, int n) {
+    __shared__ bf16_t tile[64][64 + 2];
+    const int64_t b = blockIdx.x;
+    int d = 0;
+    while (d + 1 < n && desc[(d + 1) * 6 + 4] <= b) ++d;
+    const bf16_t* src = (const bf16_t*)desc[d * 6];
+    bf16_t* dst = (bf16_t*)desc[d * 6 + 1];
+    const int64_t rows = desc[d * 6 + 2], cols = desc[d * 6 + 3], t = b - desc[d * 6 + 4], tpr = desc[d * 6 + 5];
+    const int64_t r0 = (t / tpr) * 64, c0 = (t % tpr) * 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {                       // 64 rows x 8 chunks of 8 columns
+        const int idx = tid + 256 * it, r = idx >> 3, c = (idx & 7) * 8;
+        if (r0 + r < rows && c0 + c + 7 < cols && (cols & 7) == 0) {
+            const bf16x8 v = *(const bf16x8*)(src + (r0 + r) * cols + c0 + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tile[r][c + e] = v[e];
+        } else {
+            for (int e = 0; e < 8; ++e) tile[r][c + e] = (r0 + r < rows && c0 + c + e < cols) ? src[(r0 + r) * cols + c0 + c + e] : (bf16_t)0.f;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {                       // output row = source column
+        const int idx = tid + 256 * it, c = idx >> 3, r = (idx & 7) * 8;
+        if (c0 + c >= cols) continue;
+        if (r0 + r + 7 < rows && (rows & 7) == 0) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[r + e][c];
+            *(bf16x8*)(dst + (c0 + c) * rows + r0 + r) = v;
+        } else {
+            for (int e = 0; e < 8; ++e)
+                if (r0 + r + e < rows) dst[(c0 + c) * rows + r0 + r + e] = tile[r + e][c];
+        }
+    }
+}
+
+extern "C" int emo_transpose_batch(const int64_t* desc, int n, int64_t total_tiles, emo_stream_t stream) {
+    EMO_CHECK(desc && n > 0 && total_tiles > 0, "emo_transpose_batch: bad args");
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, desc, n);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}

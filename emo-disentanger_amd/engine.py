@@ -102,16 +102,31 @@ class ParamStore:
     def wT(self, name, fused_rows=None):
         """bf16 TRANSPOSED copy [in, out] of the nn.Linear weight `name` ([out, in]; fused_rows: the [3D, D] q/k/v view), refreshed when the
         mirror changes: the dgrad dX = dY W then is the same k-contiguous NT product as a forward (K = 512: the A-stationary kernel; the
-        long reductions: the 256 x 256 tile kernel)."""
+        long reductions: the 256 x 256 tile kernel).  All registered mirrors are refreshed by ONE batched transpose launch per mirror epoch
+        (emo_transpose_batch) instead of one copy kernel each."""
         key = (name, fused_rows)
         ent = self._wT.get(key)
         if ent is None:
             shape = self.shapes[name] if fused_rows is None else (fused_rows, self.shapes[name][1])
-            ent = self._wT[key] = [torch.empty(shape[::-1], device=self.device, dtype=torch.bfloat16), -1]
+            ent = self._wT[key] = [torch.empty(shape[::-1], device=self.device, dtype=torch.bfloat16), -1, shape]
+            self._wT_desc = None                                  # table rebuilt with the new record
         if ent[1] != self._mirror_epoch:
-            ent[0].copy_(self.w(name, fused_rows).t())
-            ent[1] = self._mirror_epoch
+            self._refresh_wT()
         return ent[0]
+
+    def _refresh_wT(self):
+        if getattr(self, '_wT_desc', None) is None:
+            rec, tile = [], 0
+            for (name, fused_rows), (buf, _, shape) in self._wT.items():
+                rows, cols = shape
+                tpr = (cols + 63) // 64
+                rec.append([self.w(name, fused_rows).data_ptr(), buf.data_ptr(), rows, cols, tile, tpr])
+                tile += ((rows + 63) // 64) * tpr
+            self._wT_desc = (torch.tensor(rec, dtype=torch.int64, device=self.device), len(rec), tile)
+        desc, n, tiles = self._wT_desc
+        ops.transpose_batch(desc, n, tiles)
+        for ent in self._wT.values():
+            ent[1] = self._mirror_epoch
 
     def invalidate_mirror(self):
         self._mirror_version = -1

@@ -418,6 +418,11 @@ def adam_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, step, gscale):
     check(lib.emo_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(p_bf16), p.numel(), lr, beta1, beta2, eps, step, ptr(gscale), stream()))
 
 
+def transpose_batch(desc, n, total_tiles):
+    """desc: device int64 [n, 6] = {src ptr, dst ptr, rows, cols, first tile, tiles per row} (include/emo_hip.h); one launch."""
+    check(lib.emo_transpose_batch(ptr(desc), n, total_tiles, stream()))
+
+
 def cast(src, dst):
     assert src.numel() == dst.numel() and src.is_contiguous() and dst.is_contiguous()
     check(lib.emo_cast(ptr(src), dtype_code(src.dtype), ptr(dst), dtype_code(dst.dtype), src.numel(), stream()))

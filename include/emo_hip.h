@@ -290,6 +290,11 @@ int emo_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, in
                   float beta1, float beta2, float eps, int64_t step, const float* gscale,
                   emo_stream_t stream);
 int emo_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, emo_stream_t stream);
+/* n bf16 transposes in one launch (no reference counterpart: the transposed weight mirrors that let every dgrad run as a k-contiguous NT
+ * product, refreshed after an optimizer step).  desc: DEVICE array of n records of six int64 {src pointer, dst pointer, rows, cols, index of
+ * the record's first 64 x 64 tile, tiles per row = ceil(cols / 64)}; src is [rows, cols] row-major, dst [cols, rows]; total_tiles = sum over
+ * records of ceil(rows / 64) * ceil(cols / 64); rows and the pointers must allow 16-B accesses (rows % 8 == 0, cols % 8 == 0 fast path). */
+int emo_transpose_batch(const int64_t* desc, int n, int64_t total_tiles, emo_stream_t stream);
 
 /* ------------------------------------------------------------------ data-parallel exchange (RCCL over xGMI)
  * The reference trains on one GPU; the build shards the batch over one process per GPU and adds ONE exchange per optimizer

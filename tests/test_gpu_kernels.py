@@ -892,3 +892,20 @@ def test_gemm_astat_bitmask_epilogue_equals_the_activation_mask():
     assert torch.equal(a, b)
     with pytest.raises((EmoError, AssertionError)):                 # outside the A-stationary shape class: refused, never ignored
         ops.gemm(h[:100], W1, mask_out=fmask[:100])
+
+
+def test_transpose_batch_matches_torch():
+    # emo_transpose_batch: the transposed weight mirrors of one optimizer step in ONE launch (fast 16-B path and ragged shapes)
+    ops = _ops()
+    shapes = [(512, 512), (2048, 512), (1536, 512), (512, 2048), (72, 40), (130, 67), (8, 8)]
+    srcs = [_r(r, c, seed=i).to(torch.bfloat16).cuda() for i, (r, c) in enumerate(shapes)]
+    dsts = [torch.full((c, r), -7.0, device='cuda', dtype=torch.bfloat16) for r, c in shapes]
+    rec, tile = [], 0
+    for (r, c), a, b in zip(shapes, srcs, dsts):
+        tpr = (c + 63) // 64
+        rec.append([a.data_ptr(), b.data_ptr(), r, c, tile, tpr])
+        tile += ((r + 63) // 64) * tpr
+    desc = torch.tensor(rec, dtype=torch.int64, device='cuda')
+    ops.transpose_batch(desc, len(rec), tile)
+    for a, b in zip(srcs, dsts):
+        assert torch.equal(b, a.t().contiguous())
