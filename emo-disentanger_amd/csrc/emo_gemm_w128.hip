@@ -14,6 +14,14 @@
 //   * fragments are double-buffered in registers: the reads of the NEXT 32-deep step are spread over the first six MFMA groups of the
 //     current one (pinned with sched_barrier: left alone the scheduler sinks them next to their uses), so neither an LDS round trip nor a
 //     DMA wait sits in front of an MFMA in steady state: per K-tile 128 MFMAs per wave, one barrier.
+// Where a block's cycles go (-DEMO_DIAG, tools/w128_cycles.py, FFN2-forward shape): first DMA round trip 7 %, K loop 68 % (the mid-tile sync is 6 %
+// of it), epilogue 25 % (output stores of all CUs at once = an HBM write burst: 10 %; dropout hashes 5 %; residual loads 8 % cold).
+// Tried and dropped (r03, same-box A/B of the training step): (i) residual rows by LDS-DMA into the idle operand ring under the last 64 MFMAs
+// (wave-private 32-KB region, swizzled): epilogue 38 -> 26 thousand cycles on cold operands, but inside the step the residual is L2 / MALL-hot
+// and nothing changed (8.72 vs 8.79 ms per step for the class); (ii) one block per CU walking several output tiles so that a tile's first DMA
+// round trip overlaps the previous tile's store drain: 1142 -> 1086 TFLOP/s sustained, 1038 -> 981 in the step (loop-invariant lane offsets
+// spill across the epilogue, their scratch reloads wait for the output stores; a contiguous run of tiles per block was worse still, 871: every
+// row panel re-read from beyond the L2).
 #include "emo_gemm_epi.h"
 
 namespace {
@@ -66,6 +74,10 @@ template <typename OutT>
 __global__ __launch_bounds__(256, 1) void gemm_w128_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                           OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, EpiParams ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef EMO_DIAG
+    const uint64_t dg_t0 = __builtin_readcyclecounter();
+    uint64_t dg_sync = 0, dg_loop0 = 0, dg_loop1 = 0;
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -132,6 +144,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w128_kernel(const bf16_t* __restr
         for (int q = 0; q < 16; ++q) rd(0, q, a_off, b_off);
     }
     constexpr int RQ[9] = {0, 3, 6, 9, 12, 14, 16, 16, 16};      // reads issued before MFMA group i: RQ[i] .. RQ[i+1]-1
+#ifdef EMO_DIAG
+    dg_loop0 = __builtin_readcyclecounter();
+#endif
     for (int t = 0; t < nk; ++t) {
         const uint32_t a_off = (foA + sa * W_TILE) ^ 64u, b_off = (foB + sb * W_TILE) ^ 64u;
         // ---- step 0 of K-tile t (set 0), reading step 1 (set 1)
@@ -144,10 +159,16 @@ __global__ __launch_bounds__(256, 1) void gemm_w128_kernel(const bf16_t* __restr
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- sync point: K-tile t+1 landed for every wave; every wave's reads of tile t are in registers
+#ifdef EMO_DIAG
+        const uint64_t dg_s0 = __builtin_readcyclecounter();
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         w_wait<8>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifdef EMO_DIAG
+        dg_sync += __builtin_readcyclecounter() - dg_s0;
+#endif
         sa = sa == W_NA - 1 ? 0 : sa + 1;
         sb ^= 1;
         const uint32_t a_nx = foA + sa * W_TILE, b_nx = foB + sb * W_TILE;
@@ -164,6 +185,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w128_kernel(const bf16_t* __restr
         doneB(); if (t_issueB > nk - 1) t_issueB = nk - 1;
         doneA(); if (t_issueA > nk - 1) t_issueA = nk - 1;
     }
+#ifdef EMO_DIAG
+    dg_loop1 = __builtin_readcyclecounter();
+#endif
     w_wait<0>();
     w_mma_drain();
     // ---- epilogue straight from the accumulators: lane = row .. + (lane & 15), columns 32 h + 8 (lane / 16) .. + 7 of fragment pair h
@@ -208,6 +232,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w128_kernel(const bf16_t* __restr
             }
         }
     }
+#ifdef EMO_DIAG
+    if (ep.ablate == 8 && ep.rln_stats && lane == 0) {            // (diagnostics, tools/w128_cycles.py: the otherwise unused rln_stats pointer carries the counter buffer)
+        unsigned long long* dg = (unsigned long long*)ep.rln_stats;
+        const uint64_t t1 = __builtin_readcyclecounter();
+        atomicAdd(dg + 0, (unsigned long long)(dg_loop0 - dg_t0));        // prologue
+        atomicAdd(dg + 1, (unsigned long long)(dg_loop1 - dg_loop0));     // K loop
+        atomicAdd(dg + 2, (unsigned long long)dg_sync);                   // of it: lgkmcnt + vmcnt + barrier at the mid-tile sync
+        atomicAdd(dg + 3, (unsigned long long)(t1 - dg_loop1));           // epilogue
+        atomicAdd(dg + 4, 1ull);
+    }
+#endif
 }
 
 // ================================================================================================ TN: dW[M,N] (+)= A[K,M]^T B[K,N]  (wgrad)
