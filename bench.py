@@ -13,6 +13,7 @@ import json
 import math
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -54,6 +55,44 @@ GEMM_KERNELS = {   # layout class of ops.gemm -> the kernel instance it launches
     'NT/K>1024': ('gemm_w128_kernel<bf16> (256x256 tile, one wave per SIMD, 128x128 quadrant per wave)',
                   'long reductions: FFN2 forward (K = 2048, bias + dropout + residual) and the FFN1 / QKV dgrads (K = 2048 / 1536) as NT products against transposed weight mirrors'),
 }
+
+
+class PowerSampler(threading.Thread):
+    """Package power (W) and shader clock (MHz) of the busiest amdgpu card the process can see, from the hwmon files, ~50 Hz: the GEMM phases of
+    the step run at the package power limit with the clock pulled down, so the datasheet MFMA peak is not what a kernel can hold."""
+
+    def __init__(self):
+        super().__init__(daemon=True)
+        import glob
+        self.hw = []
+        for h in glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*'):
+            pw = next((q for q in (h + '/power1_average', h + '/power1_input') if os.path.exists(q)), None)
+            if pw and os.path.exists(h + '/freq1_input'):
+                self.hw.append((pw, h + '/freq1_input', h + '/power1_cap'))
+        self.rows, self.alive = [], True
+
+    def run(self):
+        while self.alive:
+            best = None
+            for pw, ck, cap in self.hw:
+                try:
+                    v = (int(open(pw).read()) / 1e6, int(open(ck).read()) / 1e6, int(open(cap).read()) / 1e6 if os.path.exists(cap) else None)
+                except Exception:
+                    continue
+                if best is None or v[0] > best[0]:
+                    best = v
+            if best:
+                self.rows.append(best)
+            time.sleep(0.02)
+
+    def result(self):
+        self.alive = False
+        r = self.rows[len(self.rows) // 4:]                      # (the first quarter of the window: clocks still settling)
+        if not r:
+            return None
+        return {'package_w_avg': round(sum(x[0] for x in r) / len(r), 1), 'package_w_max': round(max(x[0] for x in r), 1), 'cap_w': r[0][2],
+                'sclk_mhz_avg': round(sum(x[1] for x in r) / len(r)), 'samples': len(r),
+                'note': 'hwmon power1_average / freq1_input sampled over the timed steps; sustained single-GEMM runs sit at the cap with sclk 1.65-2.0 GHz (tools/sustained_gemm.py)'}
 
 
 def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
@@ -509,6 +548,9 @@ def main():
         run_steps(args.warmup)
     torch.cuda.synchronize()
     dp.barrier()
+    sampler = PowerSampler() if rank == 0 else None
+    if sampler is not None:
+        sampler.start()
     t0 = time.perf_counter()
     mean_loss, evs = run_steps(args.steps, record=True)
     end_ev = torch.cuda.Event(enable_timing=True)
@@ -516,6 +558,7 @@ def main():
     torch.cuda.synchronize()
     dp.barrier()
     my_elapsed = time.perf_counter() - t0
+    power = sampler.result() if sampler is not None else None
     elapsed = dp.max_over_ranks(my_elapsed)
     per_step = [a.elapsed_time(b_) for a, b_ in zip(evs, evs[1:] + [end_ev])]       # ms, device timeline of this rank
     median_ms = sorted(per_step)[len(per_step) // 2] if per_step else float('nan')
@@ -530,7 +573,8 @@ def main():
                       'global_batch': world * B, 'seq_len': T, 'parallelism': 'dp%d' % world, 'n_token': CFG['n_token']},
            'mean_loss': round(mean_loss, 4), 'gemm_tflops_model': round(value * gemm_flops_per_token() / 1e12, 1),
            'timed_loop': 'emo_disentanger_amd.train.train_model (the product loop), verbose off',
-           'median_ms_per_step': round(median_ms, 3), 'median_tokens_per_s': round(world * B * T / (median_ms / 1e3), 1) if median_ms == median_ms else None}
+           'median_ms_per_step': round(median_ms, 3), 'median_tokens_per_s': round(world * B * T / (median_ms / 1e3), 1) if median_ms == median_ms else None,
+           'power': power}
     if not args.no_roofline:                 # every rank runs the instrumented steps (they contain the all-reduce)
         roof = dominant_kernel_roofline(step, B, T)
         if rank == 0:
