@@ -993,8 +993,9 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         EMO_LAUNCH_CHECK();
         return EMO_OK;
     }
-    if (big && a_trans && b_trans && dtype_out == EMO_F32 && !has_epi && !ep.b_rowsum && !ln_fused && !use_safe_tr() && e &&
-        emo_gemm_w128_tn_try((const bf16_t*)A, lda, (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, accumulate, ep.a_rowsum, e->workspace, e->workspace_bytes, st)) {
+    if (big && a_trans && b_trans && dtype_out == EMO_F32 && !has_epi && !ln_fused && !use_safe_tr() && e &&
+        emo_gemm_w128_tn_try((const bf16_t*)A, lda, (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, accumulate, ep.a_rowsum, ep.b_rowsum, e->workspace,
+                             e->workspace_bytes, st)) {
         EMO_LAUNCH_CHECK();
         return EMO_OK;
     }

@@ -252,11 +252,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w128_kernel(const bf16_t* __restr
 // the fp32 partial tiles go to the caller's workspace with plain 16-B stores and splitk_reduce_kernel sums them in a fixed order.
 // RS = 1: a_rowsum[m] += sum_k A[k][m] (the bias gradient) as MFMAs against an all-ones operand: the two waves that hold the same A rows
 // take alternate fragments, and of the tiles_n blocks that read the same A columns block tn takes the K-tiles with index % tiles_n == tn.
+// RS = 2: b_rowsum[n] += sum_k B[k][n] (HF Conv1D layout, where dY is the B operand): the same with the roles of m and n exchanged.
 __device__ __forceinline__ int w_swz_k(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
 template <int RS>
 __global__ __launch_bounds__(256, 1) void gemm_w128_tn_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
-                                                             float* __restrict__ Cws, int64_t M, int64_t N, int64_t K, int64_t kps, float* __restrict__ a_rowsum) {
+                                                             float* __restrict__ Cws, int64_t M, int64_t N, int64_t K, int64_t kps, float* __restrict__ a_rowsum, float* __restrict__ b_rowsum) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -304,7 +305,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w128_tn_kernel(const bf16_t* __re
     const bf16_t one_b = (bf16_t)1.f;
     bf16x8 ones = {one_b, one_b, one_b, one_b, one_b, one_b, one_b, one_b};
     asm volatile("" : "+v"(ones));                              // opaque: one live register tuple instead of a rematerialised constant
-    int rs_phase = RS ? (int)((kbeg / W_BK) % tiles_n) : 0;      // K-tile index modulo tiles_n
+    const int rs_mod = RS == 2 ? (int)(M / W_BM) : (int)tiles_n, rs_me = RS == 2 ? (int)tm : (int)tn;
+    int rs_phase = RS ? (int)((kbeg / W_BK) % rs_mod) : 0;      // K-tile index modulo the number of blocks that share the summed operand
 
     int sa_issue = 0, sb_issue = 0, t_issueA = 0, t_issueB = 0;
     auto issueA_part = [&](int g) { w_dma2(gA + (int64_t)t_issueA * stepA, offA[2 * g], offA[2 * g + 1], dstw + sa_issue * W_TILE + g * 2048); };
@@ -345,14 +347,15 @@ __global__ __launch_bounds__(256, 1) void gemm_w128_tn_kernel(const bf16_t* __re
     constexpr int RQ[9] = {0, 3, 6, 9, 12, 14, 16, 16, 16};
     for (int t = 0; t < nk; ++t) {
         const uint32_t a_off = foA + sa * W_TILE, b_off = foB + sb * W_TILE;
-        const bool rs_on = RS && rs_phase == (int)tn;
+        const bool rs_on = RS && rs_phase == rs_me;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
 #pragma unroll
             for (int q2 = RQ[i]; q2 < RQ[i + 1]; ++q2) rd(1, q2, a_off, b_off, 8192);
 #pragma unroll
             for (int j = 0; j < 8; ++j) w_mma(acc[i][j], fb[0][j], fa[0][i]);
-            if (RS && rs_on && (i & 1) == wc) w_mma_v(rs[i >> 1], ones, fa[0][i]);
+            if (RS == 1 && rs_on && (i & 1) == wc) w_mma_v(rs[i >> 1], ones, fa[0][i]);
+            if (RS == 2 && rs_on && (i & 1) == wr) w_mma_v(rs[i >> 1], fb[0][i], ones);
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -369,18 +372,25 @@ __global__ __launch_bounds__(256, 1) void gemm_w128_tn_kernel(const bf16_t* __re
             if (i < 4) issueB_part(i); else issueA_part(i - 4);
 #pragma unroll
             for (int j = 0; j < 8; ++j) w_mma(acc[i][j], fb[1][j], fa[1][i]);
-            if (RS && rs_on && (i & 1) == wc) w_mma_v(rs[i >> 1], ones, fa[1][i]);
+            if (RS == 1 && rs_on && (i & 1) == wc) w_mma_v(rs[i >> 1], ones, fa[1][i]);
+            if (RS == 2 && rs_on && (i & 1) == wr) w_mma_v(rs[i >> 1], fb[1][i], ones);
             __builtin_amdgcn_sched_barrier(0);
         }
         doneB();
         doneA();
-        if (RS) { if (++rs_phase == (int)tiles_n) rs_phase = 0; }
+        if (RS) { if (++rs_phase == rs_mod) rs_phase = 0; }
     }
     w_wait<0>();
     w_mma_drain();
-    if (RS && (lane >> 4) == 0) {
+    if (RS == 1 && (lane >> 4) == 0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) atomicAdd(a_rowsum + m0 + wr * 128 + (2 * u + wc) * 16 + lane, rs[u][0]);
+    }
+    if (RS == 2 && (lane & 15) == 0) {                            // D[n][*]: a lane holds the sums of n = 4 (lane / 16) .. + 3 of its fragment
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(b_rowsum + n0 + wc * 128 + (2 * u + wr) * 16 + (lane >> 4) * 4 + r, rs[u][r]);
     }
 #pragma clang loop unroll(full)
     for (int i = 0; i < 8; ++i) {
@@ -431,9 +441,10 @@ int64_t emo_gemm_w128_tn_splits(int64_t M, int64_t N, int64_t K) {
 
 void emo_splitk_reduce_launch(const float* ws, int64_t stride, int splits, float* out, int64_t n4, int accumulate, hipStream_t st);
 
-// dW[M,N] (+)= A[K,M]^T B[K,N], fp32 out, contiguous C, workspace of >= splits * M * N floats; rowsum: optional a_rowsum[M] += column sums of A
+// dW[M,N] (+)= A[K,M]^T B[K,N], fp32 out, contiguous C, workspace of >= splits * M * N floats; optional a_rowsum[M] += column sums of A or
+// b_rowsum[N] += column sums of B (one of them)
 bool emo_gemm_w128_tn_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate,
-                          float* a_rowsum, void* ws, int64_t ws_bytes, hipStream_t st) {
+                          float* a_rowsum, float* b_rowsum, void* ws, int64_t ws_bytes, hipStream_t st) {
     const int64_t splits0 = emo_gemm_w128_tn_splits(M, N, K);
     if (!splits0 || ldc != N || !ws || ((uintptr_t)ws & 15) || ws_bytes < splits0 * M * N * (int64_t)sizeof(float)) return false;
     if ((lda & 7) || (ldb & 7) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return false;
@@ -446,9 +457,9 @@ bool emo_gemm_w128_tn_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t
         auto k = gemm_w128_tn_kernel<RSv>;                                                                                                   \
         static bool attr = false;                                                                                                            \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS); attr = true; }            \
-        hipLaunchKernelGGL(k, grid, dim3(256), W_LDS, st, A, lda, B, ldb, (float*)ws, M, N, K, kps, a_rowsum);                               \
+        hipLaunchKernelGGL(k, grid, dim3(256), W_LDS, st, A, lda, B, ldb, (float*)ws, M, N, K, kps, a_rowsum, b_rowsum);                     \
     } while (0)
-    if (a_rowsum) W_TN_LAUNCH(1); else W_TN_LAUNCH(0);
+    if (a_rowsum) W_TN_LAUNCH(1); else if (b_rowsum) W_TN_LAUNCH(2); else W_TN_LAUNCH(0);
 #undef W_TN_LAUNCH
     emo_splitk_reduce_launch((const float*)ws, M * N, (int)splits0, C, (M * N) >> 2, accumulate, st);
     return true;

@@ -222,6 +222,13 @@ def test_gemm_256_tile_wgrad_matches_reference_with_bias_gradient(shape, monkeyp
         assert float((dw.double() - (ref + (0.5 if acc else 0.0))).abs().max() / ref.abs().max()) < 2e-5
         assert float((db.double() - (want + 0.25)).abs().max() / want.abs().max()) < 1e-4
         assert float((dw - got['0'][0]).abs().max() / ref.abs().max()) < 2e-5      # the 128 x 128 kernel (other split count: not the same bits)
+    # Conv1D layout: the bias gradient is the column sum of the B operand
+    monkeypatch.setenv('EMO_GEMM_W128_TN', '1')
+    dw3, dbn = torch.zeros(M, N, device='cuda'), torch.full((N,), 0.25, device='cuda')
+    ops.gemm(dy, x, a_trans=True, b_trans=True, out=dw3, b_rowsum=dbn)
+    wantn = x.double().sum(0)
+    assert float((dw3.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert float((dbn.double() - (wantn + 0.25)).abs().max() / wantn.abs().max()) < 1e-4
 
 
 @pytest.mark.parametrize('M', [1, 7, 32])
