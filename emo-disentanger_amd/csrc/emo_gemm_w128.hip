@@ -433,9 +433,10 @@ int64_t emo_gemm_w128_tn_splits(int64_t M, int64_t N, int64_t K) {
     if ((M % W_BM) || (N % W_BN) || (K % W_BK)) return 0;
     const int64_t ntile = (M / W_BM) * (N / W_BN);
     int64_t splits = (256 / ntile) / 8 * 8;
-    if (splits < 8 || splits > 32 || ntile * splits < 160) return 0;
+    if (splits < 8) return 0;
+    if (splits > 64) splits = 64;
     while (splits > 8 && K / W_BK / splits < 8) splits -= 8;     // at least 8 K-tiles per split
-    if (K / W_BK / splits < 8) return 0;
+    if (K / W_BK / splits < 8 || ntile * splits < 160) return 0; // (too few blocks for the chip: the 128 x 128 kernel's finer tiles win)
     return splits;
 }
 
