@@ -257,14 +257,25 @@ __device__ __forceinline__ int w_swz_k(int k) { return (k & 3) | (((k >> 3) & 1)
 
 template <int RS>
 __global__ __launch_bounds__(256, 1) void gemm_w128_tn_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
-                                                             float* __restrict__ Cws, int64_t M, int64_t N, int64_t K, int64_t kps, float* __restrict__ a_rowsum, float* __restrict__ b_rowsum) {
+                                                             float* __restrict__ Cws, int64_t M, int64_t N, int64_t K, int64_t kps, float* __restrict__ a_rowsum, float* __restrict__ b_rowsum,
+                                                             int full, int extra) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int64_t tiles_n = N / W_BN, ntile = (M / W_BM) * tiles_n;
+    // 32 blocks per XCD: `full` complete K-splits (all their output tiles: the split's token range is fetched once into that L2), and the
+    // 32 - full * ntile slots left over on every XCD are filled with the tiles of `extra` more splits, each spread over as few XCDs as
+    // possible (fused QKV: 12 tiles -> 2 full splits per XCD + 5 shared ones = 21 splits on 252 CUs instead of 16 on 192)
     const int64_t bid = blockIdx.x, xcd = bid & 7, q = bid >> 3;
-    const int64_t split = xcd + 8 * (q / ntile), t_id = q % ntile;
+    int64_t split, t_id;
+    if (q < (int64_t)full * ntile) { split = xcd * full + q / ntile; t_id = q % ntile; }
+    else {
+        const int64_t left = 32 - (int64_t)full * ntile, slot = xcd * left + (q - (int64_t)full * ntile);
+        if (slot >= (int64_t)extra * ntile) return;
+        split = 8 * full + slot / ntile;
+        t_id = slot % ntile;
+    }
     const int64_t tm = t_id / tiles_n, tn = t_id % tiles_n;
     const int64_t m0 = tm * W_BM, n0 = tn * W_BN;
     const int64_t kbeg = split * kps;
@@ -423,21 +434,33 @@ bool emo_gemm_w128_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ld
     return true;
 }
 
-// K-splits of the TN (wgrad) product on 256 x 256 tiles: a multiple of 8 (one split per XCD per round) that puts at most one block on
-// every CU; 0 = shape not taken by this kernel.
-int64_t emo_gemm_w128_tn_splits(int64_t M, int64_t N, int64_t K) {
+// K-splits of the TN (wgrad) product on 256 x 256 tiles (at most one block per CU, see the kernel's block mapping); 0 = shape not taken.
+static int64_t w_tn_plan(int64_t M, int64_t N, int64_t K, int& full, int& extra) {
+    full = extra = 0;
     const char* e = getenv("EMO_GEMM_W128");
     if (e && atoi(e) == 0) return 0;
     const char* e2 = getenv("EMO_GEMM_W128_TN");
     if (e2 && atoi(e2) == 0) return 0;
     if ((M % W_BM) || (N % W_BN) || (K % W_BK)) return 0;
-    const int64_t ntile = (M / W_BM) * (N / W_BN);
-    int64_t splits = (256 / ntile) / 8 * 8;
-    if (splits < 8) return 0;
-    if (splits > 64) splits = 64;
-    while (splits > 8 && K / W_BK / splits < 8) splits -= 8;     // at least 8 K-tiles per split
-    if (K / W_BK / splits < 8 || ntile * splits < 160) return 0; // (too few blocks for the chip: the 128 x 128 kernel's finer tiles win)
-    return splits;
+    const int64_t ntile = (M / W_BM) * (N / W_BN), nkt = K / W_BK;
+    if (ntile > 32) return 0;
+    int64_t f = 32 / ntile;
+    if (f > 8) f = 8;                                          // at most 64 splits
+    int64_t x = f < 8 ? (8 * (32 - f * ntile)) / ntile : 0;
+    if (e2 && atoi(e2) == 2) x = 0;                            // (diagnostics: whole splits per XCD only)
+    while (nkt / (8 * f + x) < 8) {                            // at least 8 K-tiles per split
+        if (x) x = 0;
+        else if (f > 1) --f;
+        else return 0;
+    }
+    if (ntile * (8 * f + x) < 160) return 0;                   // (too few blocks for the chip: the 128 x 128 kernel's finer tiles win)
+    full = (int)f;
+    extra = (int)x;
+    return 8 * f + x;
+}
+int64_t emo_gemm_w128_tn_splits(int64_t M, int64_t N, int64_t K) {
+    int full, extra;
+    return w_tn_plan(M, N, K, full, extra);
 }
 
 void emo_splitk_reduce_launch(const float* ws, int64_t stride, int splits, float* out, int64_t n4, int accumulate, hipStream_t st);
@@ -446,19 +469,20 @@ void emo_splitk_reduce_launch(const float* ws, int64_t stride, int splits, float
 // b_rowsum[N] += column sums of B (one of them)
 bool emo_gemm_w128_tn_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate,
                           float* a_rowsum, float* b_rowsum, void* ws, int64_t ws_bytes, hipStream_t st) {
-    const int64_t splits0 = emo_gemm_w128_tn_splits(M, N, K);
+    int full, extra;
+    const int64_t splits0 = w_tn_plan(M, N, K, full, extra);
     if (!splits0 || ldc != N || !ws || ((uintptr_t)ws & 15) || ws_bytes < splits0 * M * N * (int64_t)sizeof(float)) return false;
     if ((lda & 7) || (ldb & 7) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return false;
     if ((uint64_t)(64 * (lda > ldb ? lda : ldb) + 256) * 2 >= 0xFFFF0000ull) return false;
     const int64_t kps = ((K / W_BK + splits0 - 1) / splits0) * W_BK;
     const int64_t ntile = (M / W_BM) * (N / W_BN);
-    dim3 grid((unsigned)(ntile * splits0));
+    dim3 grid(256);                                            // 32 block slots per XCD (w_tn_plan)
 #define W_TN_LAUNCH(RSv)                                                                                                                     \
     do {                                                                                                                                     \
         auto k = gemm_w128_tn_kernel<RSv>;                                                                                                   \
         static bool attr = false;                                                                                                            \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS); attr = true; }            \
-        hipLaunchKernelGGL(k, grid, dim3(256), W_LDS, st, A, lda, B, ldb, (float*)ws, M, N, K, kps, a_rowsum, b_rowsum);                     \
+        hipLaunchKernelGGL(k, grid, dim3(256), W_LDS, st, A, lda, B, ldb, (float*)ws, M, N, K, kps, a_rowsum, b_rowsum, full, extra);        \
     } while (0)
     if (a_rowsum) W_TN_LAUNCH(1); else if (b_rowsum) W_TN_LAUNCH(2); else W_TN_LAUNCH(0);
 #undef W_TN_LAUNCH
