@@ -33,6 +33,25 @@ __global__ __launch_bounds__(256, 1) void k(const bf16x8* __restrict__ src, floa
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += acc[i][j][0];
+    } else if (KIND == 2) {
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int rep = 0; rep < 4; ++rep)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(b[j + 4 * (rep & 1)]), "a"(a[i + 4 * (rep >> 1)]));
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += acc[i][j][0];
     } else {
         f32x16 acc[4][4];
 #pragma unroll
@@ -67,17 +86,18 @@ int main() {
     hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 4000, blocks = 1024;
-    for (int kind = 0; kind < 2; ++kind)
+    for (int kind = 0; kind < 3; ++kind)
         for (int rep = 0; rep < 12; ++rep) {
             hipEventRecord(e0);
             for (int l = 0; l < 20; ++l) {
                 if (kind == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, d, o, iters);
-                else hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, d, o, iters);
+                else if (kind == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, d, o, iters);
+                else hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, d, o, iters);
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             const double flops = 20.0 * blocks * 4 * iters * 64.0 * 16 * 16 * 32 * 2;
-            if (rep % 3 == 2) printf("%s rep %d: %.0f TFLOP/s\n", kind == 0 ? "16x16x32" : "32x32x16", rep, flops / (ms * 1e-3) / 1e12);
+            if (rep % 3 == 2) printf("%s rep %d: %.0f TFLOP/s\n", kind == 0 ? "16x16x32 (acc in AGPR)" : kind == 1 ? "32x32x16" : "16x16x32 (source in AGPR, acc in VGPR, 16 accumulators)", rep, flops / (ms * 1e-3) / 1e12);
         }
     return 0;
 }
