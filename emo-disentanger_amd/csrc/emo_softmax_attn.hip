@@ -478,6 +478,8 @@ template <typename CT, int DH> static size_t sa_dq_lds() { typedef SaDims<CT, DH
 template <typename CT, int DH> static size_t sa_dkv_lds() { typedef SaDims<CT, DH> D; return sizeof(CT) * (size_t)(4 * 64 * D::LDX + (sizeof(CT) == 2 ? 0 : 2 * DH * D::LDC)) + 128 * sizeof(float); }
 
 // emo_softmax_attn32.hip: bf16 / d_head 64 / T % 128 == 0 kernels on 32 x 32 x 16 tiles (false: not covered -> the kernels of this file)
+bool emo_sattn32_dkv_try(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const bf16_t* dout, int64_t ld_out, const float* lse, const float* delta,
+                         bf16_t* dk, bf16_t* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, DropCtx drop, hipStream_t st);
 bool emo_sattn32_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ld_out, float* lse, int64_t B, int64_t T,
                      int64_t H, DropCtx drop, hipStream_t st);
 
@@ -508,8 +510,13 @@ static int run_sattn(int which, const void* q, const void* k, const void* v, int
     } else {
         hipLaunchKernelGGL(kdq, grid, dim3(256), ldq, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, (const CT*)out,
                            (const CT*)dout, ld_out, lse, delta, (CT*)dq, ld_d, T, H, drop);
-        hipLaunchKernelGGL(kdkv, grid, dim3(256), ldkv, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, (const CT*)dout, ld_out, lse, delta, (CT*)dk,
-                           (CT*)dv, ld_d, T, H, drop);
+        bool dkv32 = false;
+        if constexpr (sizeof(CT) == 2 && DH == 64)
+            dkv32 = emo_sattn32_dkv_try((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, (const bf16_t*)dout, ld_out, lse, delta, (bf16_t*)dk, (bf16_t*)dv, ld_d,
+                                        B, T, H, drop, st);
+        if (!dkv32)
+            hipLaunchKernelGGL(kdkv, grid, dim3(256), ldkv, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, (const CT*)dout, ld_out, lse, delta, (CT*)dk,
+                               (CT*)dv, ld_d, T, H, drop);
     }
     EMO_LAUNCH_CHECK();
     return EMO_OK;

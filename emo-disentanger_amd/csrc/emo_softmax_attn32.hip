@@ -167,6 +167,152 @@ __global__ __launch_bounds__(256, 2) void sattn32_fwd_kernel(const bf16_t* __res
     }
     if (hi == 0) lse_g[bh * T + qrow] = m_run * c2 * A32_LN2 + logf(l_tot);
 }
+
+// =============================================================================================== backward: dK, dV
+// Key-stationary: a wave owns 32 keys (K / V rows as MFMA B operands in registers), the workgroup 128; query tiles of 64 rows (Q and dO, plus
+// the rows' lse and delta) stream through a 2-slot LDS ring.  Products S = Q K^T and dP = dO V^T land in the layout lane <-> key, registers <->
+// query (row 8 a + 4 (lane / 32) + r of a 32-row half), so Pd = P * dropout and dS = P (dP * dropout - delta) are element-wise with the row
+// statistics read from LDS (broadcast reads), and both go straight back into dV^T += dO^T Pd and dK^T += Q^T dS as B operands in the
+// permuted row order — the A operands dO^T / Q^T come from the row-major tiles by ds_read_b64_tr_b16 in the same order (the forward's V^T
+// recipe).  Dropout: one keyed hash per 4 consecutive keys of a row, shared by the four lanes of a quad (drop_mult_col4).  No cross-lane
+// reduction anywhere; dK^T / dV^T stay in registers for the whole sweep.  The generic kernel (16-row query tiles, P and dS through LDS
+// transposes, 168 VGPR spills) took 2.2 x the dQ pass.
+__device__ __forceinline__ void a32_dma16s(const char* sbase, uint32_t voff, uint32_t lds_dst) {       // wave-uniform base + 32-bit lane offset
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void a32_dma4s(const char* sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+constexpr int A32_QSLOT = 2 * A32_TILEB + 512;                 // Q tile | dO tile | lse[64] | delta[64]
+
+__global__ __launch_bounds__(256, 2) void sattn32_dkv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t ld,
+                                                             const bf16_t* __restrict__ dout, int64_t ld_out, const float* __restrict__ lse_g,
+                                                             const float* __restrict__ delta_g, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t ld_d,
+                                                             int64_t T, int64_t H, DropCtx drop) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2 slots][Q tile | dO tile | lse | delta]
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, kl = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t ktile = blockIdx.x;                                 // key tile 0 has the longest sweep and is dispatched first
+    const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int64_t kw0 = ktile * 128 + 32 * w, key = kw0 + kl;
+    const bf16_t* qb = q + (b * T) * ld + h * 64;
+    const bf16_t* kb = k + (b * T) * ld + h * 64;
+    const bf16_t* vb = v + (b * T) * ld + h * 64;
+    const bf16_t* gb = dout + (b * T) * ld_out + h * 64;
+    const int qt0 = (int)(2 * ktile), nqt = (int)(T / 64);            // query tiles qt0 .. nqt - 1 see this key tile
+
+    bf16x8 kB[4], vB[4];                                              // K / V rows as B operands: column = key kl, k = d = 16 s + 8 hi ..
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        kB[s] = *(const bf16x8*)(kb + key * ld + 16 * s + 8 * hi);
+        vB[s] = *(const bf16x8*)(vb + key * ld + 16 * s + 8 * hi);
+    }
+    const uint32_t ring = __builtin_amdgcn_readfirstlane(a32_lds_addr(smem));
+    // DMA sources as (wave-uniform base) + (32-bit lane byte offset): no per-lane 64-bit pointers live across the sweep
+    const uint32_t so0 = (uint32_t)(((16 * w + (lane >> 3)) * ld + (((lane & 7) ^ (lane >> 3)) << 3)) * 2), so1 = so0 + (uint32_t)(16 * ld);
+    const uint32_t go0 = (uint32_t)(((16 * w + (lane >> 3)) * ld_out + (((lane & 7) ^ (lane >> 3)) << 3)) * 2), go1 = go0 + (uint32_t)(16 * ld_out);
+    const uint32_t lo4 = (uint32_t)(lane * 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the plain loads above are the compiler's; keep them out of the DMA count)
+    auto issue = [&](int qt) {
+        const uint32_t dst = ring + (qt & 1) * A32_QSLOT;
+        const char* qs = (const char*)(qb + (int64_t)qt * 64 * ld);
+        const char* gs = (const char*)(gb + (int64_t)qt * 64 * ld_out);
+        a32_dma16s(qs, so0, dst + w * 2048);
+        a32_dma16s(qs, so1, dst + w * 2048 + 1024);
+        a32_dma16s(gs, go0, dst + A32_TILEB + w * 2048);
+        a32_dma16s(gs, go1, dst + A32_TILEB + w * 2048 + 1024);
+        if (w == 0) a32_dma4s((const char*)(lse_g + bh * T + (int64_t)qt * 64), lo4, dst + 2 * A32_TILEB);
+        if (w == 1) a32_dma4s((const char*)(delta_g + bh * T + (int64_t)qt * 64), lo4, dst + 2 * A32_TILEB + 256);
+    };
+    issue(qt0);
+    const float c2 = rsqrtf(64.f) * A32_LOG2E;
+    f32x16 dv0, dv1, dk0, dk1;                                        // dV^T / dK^T: rows d (0-31 / 32-63), column = key
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dv0[i] = 0.f; dv1[i] = 0.f; dk0[i] = 0.f; dk1[i] = 0.f; }
+    const int vg = lane >> 4, vi = lane & 15;
+    for (int qt = qt0; qt < nqt; ++qt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (qt + 1 < nqt) issue(qt + 1);
+        const int64_t q0 = (int64_t)qt * 64;
+        if (q0 + 63 < kw0) continue;                                  // every row of the tile lies before this wave's keys (wave-uniform)
+        const char* Qt = smem + (qt & 1) * A32_QSLOT;
+        const char* Gt = Qt + A32_TILEB;
+        const float* lse_l = (const float*)(Gt + A32_TILEB);
+        const float* del_l = lse_l + 64;
+        const bool diag = q0 < kw0 + 31;                              // some row of the tile lies before some key of the wave
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+            f32x16 sa, pa;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sa[i] = 0.f; pa[i] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int off = (32 * hq + kl) * A32_ROWB + (((2 * s + hi) ^ (kl & 7)) << 4);
+                sa = mma3216(*(const bf16x8*)(Qt + off), kB[s], sa);  // S[row][key]
+                pa = mma3216(*(const bf16x8*)(Gt + off), vB[s], pa);  // dP[row][key]
+            }
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+                const int rl = 32 * hq + 8 * a4 + 4 * hi;             // rows rl .. rl + 3 of the tile
+                const f32x4 ls = *(const f32x4*)(lse_l + rl), dl = *(const f32x4*)(del_l + rl);
+                float dm[4] = {1.f, 1.f, 1.f, 1.f};
+                if (drop.thr16) drop_mult_col4(drop, (uint64_t)((bh * T + q0 + rl + (lane & 3)) * T + (key & ~(int64_t)3)), lane, dm);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 4 * a4 + r;
+                    float p = __builtin_amdgcn_exp2f(fmaf(sa[i], c2, -ls[r] * A32_LOG2E));
+                    if (diag && q0 + rl + r < key) p = 0.f;
+                    sa[i] = p * dm[r];                                // Pd
+                    pa[i] = p * (pa[i] * dm[r] - dl[r]);              // dS
+                }
+            }
+            // the half's 32 rows as two 16-row B operands (permuted row order), straight into dV^T += dO^T Pd and dK^T += Q^T dS
+#pragma unroll
+            for (int u2 = 0; u2 < 2; ++u2) {
+                bf16x8 pb, sb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { pb[e] = (bf16_t)sa[8 * u2 + e]; sb[e] = (bf16_t)pa[8 * u2 + e]; }
+                const int u = 2 * hq + u2;
+#pragma unroll
+                for (int dh2 = 0; dh2 < 2; ++dh2) {
+                    bf16x8 gt, qt_;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int row = 16 * u + 8 * hh + 4 * (vg >> 1) + (vi >> 2), col = 32 * dh2 + 16 * (vg & 1) + 4 * (vi & 3);
+                        const int o = row * A32_ROWB + (((col >> 3) ^ (row & 7)) << 4) + (col & 7) * 2;
+                        const bf16x4 tg = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(Gt + o)));
+                        const bf16x4 tq = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(Qt + o)));
+                        gt[4 * hh + 0] = tg[0]; gt[4 * hh + 1] = tg[1]; gt[4 * hh + 2] = tg[2]; gt[4 * hh + 3] = tg[3];
+                        qt_[4 * hh + 0] = tq[0]; qt_[4 * hh + 1] = tq[1]; qt_[4 * hh + 2] = tq[2]; qt_[4 * hh + 3] = tq[3];
+                    }
+                    if (dh2 == 0) { dv0 = mma3216(gt, pb, dv0); dk0 = mma3216(qt_, sb, dk0); }
+                    else { dv1 = mma3216(gt, pb, dv1); dk1 = mma3216(qt_, sb, dk1); }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                        // one 32-row half at a time (register peak)
+        }
+    }
+    const float inv = rsqrtf(64.f);
+    bf16_t* dkp = dk + (b * T + key) * ld_d + h * 64;
+    bf16_t* dvp = dv + (b * T + key) * ld_d + h * 64;
+#pragma unroll
+    for (int a4 = 0; a4 < 4; ++a4) {
+        const bf16x4 k0v = {(bf16_t)(dk0[4 * a4] * inv), (bf16_t)(dk0[4 * a4 + 1] * inv), (bf16_t)(dk0[4 * a4 + 2] * inv), (bf16_t)(dk0[4 * a4 + 3] * inv)};
+        const bf16x4 k1v = {(bf16_t)(dk1[4 * a4] * inv), (bf16_t)(dk1[4 * a4 + 1] * inv), (bf16_t)(dk1[4 * a4 + 2] * inv), (bf16_t)(dk1[4 * a4 + 3] * inv)};
+        const bf16x4 v0v = {(bf16_t)dv0[4 * a4], (bf16_t)dv0[4 * a4 + 1], (bf16_t)dv0[4 * a4 + 2], (bf16_t)dv0[4 * a4 + 3]};
+        const bf16x4 v1v = {(bf16_t)dv1[4 * a4], (bf16_t)dv1[4 * a4 + 1], (bf16_t)dv1[4 * a4 + 2], (bf16_t)dv1[4 * a4 + 3]};
+        *(bf16x4*)(dkp + 8 * a4 + 4 * hi) = k0v;
+        *(bf16x4*)(dkp + 32 + 8 * a4 + 4 * hi) = k1v;
+        *(bf16x4*)(dvp + 8 * a4 + 4 * hi) = v0v;
+        *(bf16x4*)(dvp + 32 + 8 * a4 + 4 * hi) = v1v;
+    }
+}
 }  // namespace
 
 // which: 0 forward.  Returns false when the call is not covered (the caller then runs the generic kernels).
@@ -180,5 +326,21 @@ bool emo_sattn32_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* 
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)sattn32_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     hipLaunchKernelGGL(sattn32_fwd_kernel, grid, dim3(256), lds, st, q, k, v, ld, out, ld_out, lse, T, H, drop);
+    return true;
+}
+
+// dK / dV pass of the backward (after the dQ pass has written delta); false: not covered, the caller runs the generic kernel
+bool emo_sattn32_dkv_try(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const bf16_t* dout, int64_t ld_out, const float* lse, const float* delta,
+                         bf16_t* dk, bf16_t* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, DropCtx drop, hipStream_t st) {
+    const char* e = getenv("EMO_SATTN32");
+    if (e && atoi(e) == 0) return false;
+    const char* e2 = getenv("EMO_SATTN32_BWD");
+    if (e2 && atoi(e2) == 0) return false;
+    if (T < 128 || (T % 128) != 0 || (ld & 7) || (ld_out & 7) || (ld_d & 3) || !delta) return false;
+    dim3 grid((unsigned)(T / 128), (unsigned)(B * H));
+    const size_t lds = 2 * A32_QSLOT;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)sattn32_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(sattn32_dkv_kernel, grid, dim3(256), lds, st, q, k, v, ld, dout, ld_out, lse, delta, dk, dv, ld_d, T, H, drop);
     return true;
 }
