@@ -714,7 +714,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_skinny_kernel(const bf16_t*
                 if (ep.rln_x) x += (p_res[h][i] - p_st[h][0]) * p_st[h][1] * p_gam[i] + p_bet[i];     // (same order as the general path: LN'd residual, bias, act)
                 x += p_bias[i];
                 if (ep.act == EMO_ACT_RELU) x = fmaxf(x, 0.f);
-                else if (ep.act == EMO_ACT_GELU_NEW) x = gelu_new_f(x);
+                else if (ep.act == EMO_ACT_GELU_NEW) x = gelu_new_o<OutT>(x);
                 if (ep.residual) x += p_res[h][i];
                 v[h][i] = x;
             }

@@ -114,7 +114,7 @@ __device__ __forceinline__ void as_unpack8(const u32x4& r, float (&t)[8]) {
 // The epilogue is specialised at COMPILE time (FL = feature flags): with run-time `ep.*` tests the column-tile epilogue was ~650 lines of
 // branchy code per tile (dead mul / residual / aux paths with their own `s_waitcnt vmcnt(0)`, per-lane parity branches of the dropout
 // hash) and took 35-52 % of a wave's cycles (s_memtime, tools/astat_cycles.py); the flag sets the Performer step uses are straight-line.
-enum { AF_RELU = 1, AF_DROP = 2, AF_RES = 4, AF_BITS = 8, AF_MASKOUT = 16, AF_GENERIC = 32 };
+enum { AF_RELU = 1, AF_DROP = 2, AF_RES = 4, AF_BITS = 8, AF_MASKOUT = 16, AF_GENERIC = 32, AF_DGELU = 64, AF_GELUAUX = 128 };   // (the last two: GPT-2's MLP)
 
 // 8 consecutive elements starting at a multiple of 8 of a 32-bit linear index: two hashes + two xorshifts, no parity branch, no 64-bit
 // arithmetic (bit-identical to drop_mult(); the launcher sends outputs of 2^32 elements or more to the generic epilogue)
@@ -134,17 +134,26 @@ __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ 
                                         int64_t mb, uint32_t ml, float (&v)[8], const float* bias_lds, uint32_t pre_bits) {
     // (the bias is already in the accumulators: they START from it)
     constexpr bool G = (FL & AF_GENERIC) != 0;
-    if (G && ep.aux_out) as_store_row8<OutT>((const OutT*)ep.aux_out + ub, lo, v);
+    if ((FL & AF_GELUAUX) || (G && ep.aux_out)) as_store_row8<OutT>((const OutT*)ep.aux_out + ub, lo, v);      // the pre-activation (gelu backward)
     if ((FL & AF_RELU) || (G && ep.act == EMO_ACT_RELU)) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+    } else if (FL & AF_GELUAUX) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = gelu_new_fast(v[i]);
     } else if (G && ep.act == EMO_ACT_GELU_NEW) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = gelu_new_f(v[i]);
+        for (int i = 0; i < 8; ++i) v[i] = gelu_new_o<OutT>(v[i]);
     }
     if (FL & AF_BITS) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] *= ((pre_bits >> i) & 1u) ? ep.mul_scale : 0.f;
+    } else if (FL & AF_DGELU) {                                   // *= gelu_new'(pre-activation): straight-line (the generic instance ran this at 250 TFLOP/s)
+        float t0[4], t1[4];
+        Out4<OutT>::load((const OutT*)ep.mul_aux + ub + lo, t0);
+        Out4<OutT>::load((const OutT*)ep.mul_aux + ub + lo + 4, t1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] *= dgelu_new_fast(t0[i]); v[4 + i] *= dgelu_new_fast(t1[i]); }
     } else if (G && ep.mul_mode == EMO_MUL_BITMASK) {
         const uint32_t bits = (uint32_t)((const uint8_t*)ep.mul_aux)[mb + ml];
 #pragma unroll
@@ -155,8 +164,8 @@ __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ 
         Out4<OutT>::load((const OutT*)ep.mul_aux + ub + lo + 4, t1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            v[i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (t0[i] != 0.f ? ep.mul_scale : 0.f) : dgelu_new_f(t0[i]);
-            v[4 + i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (t1[i] != 0.f ? ep.mul_scale : 0.f) : dgelu_new_f(t1[i]);
+            v[i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (t0[i] != 0.f ? ep.mul_scale : 0.f) : dgelu_new_o<OutT>(t0[i]);
+            v[4 + i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (t1[i] != 0.f ? ep.mul_scale : 0.f) : dgelu_new_o<OutT>(t1[i]);
         }
     }
     if (FL & AF_DROP) as_drop8(ep.drop, (uint32_t)db + dl, v);
@@ -385,9 +394,10 @@ bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t l
         hipLaunchKernelGGL(k, grid, dim3(256), lds, st, A, lda, B, ldb, (OutT*)C, M, N, ep);                                              \
     } while (0)
     // feature flags of this launch; the sets the Performer layer uses have their own straight-line instantiation, the rest runs the generic one
+    const bool gelu_aux = ep.act == EMO_ACT_GELU_NEW && ep.aux_out;
     int fl = (ep.act == EMO_ACT_RELU ? AF_RELU : 0) | (ep.drop.thr16 ? AF_DROP : 0) | (ep.residual ? AF_RES : 0) | (ep.mul_mode == EMO_MUL_BITMASK ? AF_BITS : 0) |
-             (ep.mask_out ? AF_MASKOUT : 0);
-    const bool other = ep.aux_out || ep.act == EMO_ACT_GELU_NEW || (ep.mul_mode != EMO_MUL_NONE && ep.mul_mode != EMO_MUL_BITMASK) ||
+             (ep.mask_out ? AF_MASKOUT : 0) | (ep.mul_mode == EMO_MUL_DGELU_NEW ? AF_DGELU : 0) | (gelu_aux ? AF_GELUAUX : 0);
+    const bool other = (!gelu_aux && (ep.aux_out || ep.act == EMO_ACT_GELU_NEW)) || ep.mul_mode == EMO_MUL_NONZERO ||
                        (ep.drop.thr16 && (uint64_t)M * (uint64_t)N >= (1ull << 32));
     if (dtype_out == EMO_F32) AS_LAUNCH(float, AF_GENERIC);
     else if (other) AS_LAUNCH(bf16_t, AF_GENERIC);
@@ -398,6 +408,8 @@ bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t l
     else if (fl == AF_RES) AS_LAUNCH(bf16_t, AF_RES);
     else if (fl == (AF_DROP | AF_RES)) AS_LAUNCH(bf16_t, AF_DROP | AF_RES);
     else if (fl == AF_BITS) AS_LAUNCH(bf16_t, AF_BITS);
+    else if (fl == AF_DGELU) AS_LAUNCH(bf16_t, AF_DGELU);
+    else if (fl == AF_GELUAUX) AS_LAUNCH(bf16_t, AF_GELUAUX);
     else AS_LAUNCH(bf16_t, AF_GENERIC);
 #undef AS_LAUNCH
     return true;

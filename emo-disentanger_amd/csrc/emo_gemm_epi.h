@@ -61,13 +61,13 @@ __device__ __forceinline__ void epi_store4(const EpiParams& ep, OutT* __restrict
             for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
         } else if (ep.act == EMO_ACT_GELU_NEW) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = gelu_new_f(v[i]);
+            for (int i = 0; i < 4; ++i) v[i] = gelu_new_o<OutT>(v[i]);
         }
         if (ep.mul_mode != EMO_MUL_NONE) {
             float a[4];
             Out4<OutT>::load((const OutT*)ep.mul_aux + off, a);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (a[i] != 0.f ? ep.mul_scale : 0.f) : dgelu_new_f(a[i]);
+            for (int i = 0; i < 4; ++i) v[i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (a[i] != 0.f ? ep.mul_scale : 0.f) : dgelu_new_o<OutT>(a[i]);
         }
         if (ep.drop.thr16) {
             float dm[4];
@@ -105,10 +105,10 @@ __device__ __forceinline__ void epi_store4(const EpiParams& ep, OutT* __restrict
         if (ep.bias) x += ep.bias[n + i];
         if (ep.aux_out) ((OutT*)ep.aux_out)[off + i] = from_f32<OutT>(x);
         if (ep.act == EMO_ACT_RELU) x = fmaxf(x, 0.f);
-        else if (ep.act == EMO_ACT_GELU_NEW) x = gelu_new_f(x);
+        else if (ep.act == EMO_ACT_GELU_NEW) x = gelu_new_o<OutT>(x);
         if (ep.mul_mode != EMO_MUL_NONE) {
             const float a = to_f32<OutT>(((const OutT*)ep.mul_aux)[off + i]);
-            x *= (ep.mul_mode == EMO_MUL_NONZERO) ? (a != 0.f ? ep.mul_scale : 0.f) : dgelu_new_f(a);
+            x *= (ep.mul_mode == EMO_MUL_NONZERO) ? (a != 0.f ? ep.mul_scale : 0.f) : dgelu_new_o<OutT>(a);
         }
         if (ep.drop.thr16) x *= drop_mult(ep.drop, (uint64_t)(m * N + n + i));
         if (ep.residual) x += to_f32<OutT>(((const OutT*)ep.residual)[off + i]);
@@ -145,7 +145,7 @@ __device__ __forceinline__ void epi_row8(const EpiParams& ep, OutT* __restrict__
             for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
         } else if (ep.act == EMO_ACT_GELU_NEW) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = gelu_new_f(v[i]);
+            for (int i = 0; i < 8; ++i) v[i] = gelu_new_o<OutT>(v[i]);
         }
         if (ep.mul_mode != EMO_MUL_NONE) {
             float a[8];
@@ -153,7 +153,7 @@ __device__ __forceinline__ void epi_row8(const EpiParams& ep, OutT* __restrict__
 #pragma unroll
               for (int i = 0; i < 4; ++i) { a[i] = t0[i]; a[4 + i] = t1[i]; } }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (a[i] != 0.f ? ep.mul_scale : 0.f) : dgelu_new_f(a[i]);
+            for (int i = 0; i < 8; ++i) v[i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (a[i] != 0.f ? ep.mul_scale : 0.f) : dgelu_new_o<OutT>(a[i]);
         }
         if (ep.drop.thr16) {
             float d0[4], d1[4];

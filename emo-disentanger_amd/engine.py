@@ -320,18 +320,23 @@ def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
 def gpt2_block_fwd(ps, pfx, x, B, T, H, p, seed, off, save):
     """HF GPT2Block (pre-LN, Conv1D weights [in,out], gelu_new, no final ln_f) — SURVEY App. B/C."""
     D = x.shape[1]
+    # at >= 32768 tokens the Conv1D products run as k-contiguous NT products against transposed mirrors ([out, in], ParamStore.wT): the K = 512
+    # ones on the A-stationary kernel (the [in, out] layout only has the 128 x 128 tiled kernel), the K = 2048 one on the 256 x 256 tile
+    nt = ps.flat16 is not None and D == 512 and x.shape[0] % 256 == 0 and x.shape[0] >= 32768 and _os.environ.get('EMO_DGRAD_NT', '1') != '0'
+
+    def lin(inp, wname, **kw):
+        if nt:
+            return ops.gemm(inp, ps.wT(wname), **kw)
+        return ops.gemm(inp, ps.w(wname), b_trans=True, **kw)
+
     n1, m1, r1 = ops.layernorm_fwd(x, ps.f32(pfx + 'ln_1.weight'), ps.f32(pfx + 'ln_1.bias'))
-    qkv = ops.gemm(n1, ps.w(pfx + 'attn.c_attn.weight'), b_trans=True, bias=ps.f32(pfx + 'attn.c_attn.bias'))
+    qkv = lin(n1, pfx + 'attn.c_attn.weight', bias=ps.f32(pfx + 'attn.c_attn.bias'))
     a, lse = ops.softmax_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, T, H, p_drop=p, seed=seed, offset=off + 1)
-    h = ops.gemm(a, ps.w(pfx + 'attn.c_proj.weight'), b_trans=True, bias=ps.f32(pfx + 'attn.c_proj.bias'), p_drop=p, seed=seed, offset=off + 2, residual=x)
+    h = lin(a, pfx + 'attn.c_proj.weight', bias=ps.f32(pfx + 'attn.c_proj.bias'), p_drop=p, seed=seed, offset=off + 2, residual=x)
     n2, m2, r2 = ops.layernorm_fwd(h, ps.f32(pfx + 'ln_2.weight'), ps.f32(pfx + 'ln_2.bias'))
     z = torch.empty(x.shape[0], ps.shapes[pfx + 'mlp.c_fc.weight'][1], device=x.device, dtype=x.dtype) if save is not None else None
-    f = ops.gemm(n2, ps.w(pfx + 'mlp.c_fc.weight'), b_trans=True, bias=ps.f32(pfx + 'mlp.c_fc.bias'), act=ops.ACT_GELU_NEW, aux_out=z)
-    if ps.flat16 is not None and x.shape[0] % 256 == 0 and x.shape[0] >= 32768 and _os.environ.get('EMO_DGRAD_NT', '1') != '0':
-        # K = 2048 reduction as an NT product against the transposed mirror ([out, in] of the Conv1D weight): the 256 x 256 tile kernel
-        out = ops.gemm(f, ps.wT(pfx + 'mlp.c_proj.weight'), bias=ps.f32(pfx + 'mlp.c_proj.bias'), p_drop=p, seed=seed, offset=off + 3, residual=h)
-    else:
-        out = ops.gemm(f, ps.w(pfx + 'mlp.c_proj.weight'), b_trans=True, bias=ps.f32(pfx + 'mlp.c_proj.bias'), p_drop=p, seed=seed, offset=off + 3, residual=h)
+    f = lin(n2, pfx + 'mlp.c_fc.weight', bias=ps.f32(pfx + 'mlp.c_fc.bias'), act=ops.ACT_GELU_NEW, aux_out=z)
+    out = lin(f, pfx + 'mlp.c_proj.weight', bias=ps.f32(pfx + 'mlp.c_proj.bias'), p_drop=p, seed=seed, offset=off + 3, residual=h)
     if save is not None:
         save.t = dict(x=x, m1=m1, r1=r1, n1=n1, qkv=qkv, a=a, lse=lse, h=h, m2=m2, r2=r2, n2=n2, z=z, f=f)
     return out
