@@ -45,16 +45,29 @@ def time_kernel(fn, iters=10, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
-GEMM_KERNELS = {   # layout class of ops.gemm -> the kernel instance it launches at the bench shapes (names as in the rocprofv3 summary)
-    'TN': ('gemm_w128_tn_kernel<RS> (256x256 tile, one wave per SIMD; RS=1: with the bias gradient; the 512x512 projection and the logits layer stay on '
-           'gemm_bf16_kernel<false,false,false,float,64,RS>) + splitk_reduce_kernel', 'wgrad dW = dY^T X, reduction over the B*T tokens'),
-    'NN': ('gemm_bf16_glds_kernel<true,false,bf16,32,2>', 'dgrad dX = dY W'),
+GEMM_KERNELS = {   # class of ops.gemm (one per kernel INSTANCE of the rocprofv3 summary) -> (kernel name, what it computes)
+    'TN/rs': ('gemm_w128_tn_kernel<1> (256x256 tile, one wave per SIMD, bias gradient by ones-MFMAs) + splitk_reduce_kernel',
+              'wgrad dW = dY^T X with the bias gradient, reduction over the B*T tokens: FFN1 and the fused QKV projection'),
+    'TN/plain': ('gemm_w128_tn_kernel<0> (256x256 tile, one wave per SIMD) + splitk_reduce_kernel',
+                 'wgrad dW = dY^T X (bias gradient taken by the LayerNorm backward): FFN2 and the 512x512 out-projection'),
+    'TN/128': ('gemm_bf16_kernel<false,false,false,float,64,RS> + splitk_reduce_kernel', 'wgrad of outputs that are not multiples of 256 (the logits layer)'),
+    'NN': ('gemm_bf16_glds_kernel<true,false,bf16,32,2>', 'dgrad dX = dY W (shapes outside the NT classes)'),
     'NT': ('gemm_bf16_glds_kernel<true,true,bf16,32,3>', 'forward Y = X W^T + fused epilogue, K = 512 (shapes outside the A-stationary class)'),
-    'NT/K=512': ('gemm_astat_kernel<bf16,BITS> (A stationary in registers, weights through the LDS ring)',
-                 'K = 512 products: QKV / out-projection / FFN1 forward, FFN2 / out-projection dgrad against transposed weight mirrors'),
+    'NT/K=512/plain': ('gemm_astat_kernel<bf16,0> (A stationary in registers, weights through the LDS ring)', 'K = 512, bias-only epilogue: QKV forward, out-projection dgrad'),
+    'NT/K=512/relu+drop+mask': ('gemm_astat_kernel<bf16,19>', 'K = 512: FFN1 forward with ReLU + dropout + 1-bit mask output'),
+    'NT/K=512/bits': ('gemm_astat_kernel<bf16,8>', 'K = 512: FFN2 dgrad through the 1-bit relu.dropout mask'),
+    'NT/K=512/drop+res': ('gemm_astat_kernel<bf16,6>', 'K = 512, N = 512: out-projection forward with dropout + residual (HBM-bound)'),
+    'NT/K=512': ('gemm_astat_kernel<bf16,FL> (other epilogue instances)', 'K = 512 products'),
     'NT/K>1024': ('gemm_w128_kernel<bf16> (256x256 tile, one wave per SIMD, 128x128 quadrant per wave)',
                   'long reductions: FFN2 forward (K = 2048, bias + dropout + residual) and the FFN1 / QKV dgrads (K = 2048 / 1536) as NT products against transposed weight mirrors'),
 }
+
+
+def gemm_kernel_label(kind):
+    k = kind
+    while k and k not in GEMM_KERNELS:
+        k = k.rsplit('/', 1)[0] if '/' in k else ''
+    return GEMM_KERNELS.get(k, (kind, 'other GEMM'))
 
 
 class PowerSampler(threading.Thread):
@@ -98,7 +111,7 @@ class PowerSampler(threading.Thread):
 def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
     """Every GEMM launch inside `n_steps` real training steps is bracketed by HIP events on its launch stream (in situ: same data,
     same cache state as the timed region).  The GEMM kernel classes (wgrad TN, A-stationary NT at K=512, long-reduction NT: FFN2 forward + dgrads) take ~65 % of the
-    step; `roofline` is the class with the largest total time (the dominant kernel of the rocprofv3 summary under profiles/),
+    step; `roofline` is the kernel INSTANCE with the largest total time (= the first line of the rocprofv3 summary under profiles/),
     the others are listed in `roofline_others`.  achieved = sum(algorithmic FLOPs = 2*M*N*K) / sum(durations).
 
     Kernel durations only mean something when kernels do not share the CUs: the optional second HIP stream for wgrad
@@ -138,20 +151,26 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
     def entry(kind):
         d = serial[kind]
         achieved = d['flops'] / d['ms'] / 1e9
-        pmc = pmc_all.get(kind, {}) if B * T == 131072 else {}     # (collected at the bench shape only)
+        pmc = (pmc_all.get(kind) or pmc_all.get(kind.rsplit('/', 1)[0], {})) if B * T == 131072 else {}     # (collected at the bench shape only)
         traffic = pmc.get('traffic_bytes_per_launch')
-        if kind == 'TN' and traffic is not None and 'TN-reduce' in pmc_all:     # split-K partial sums + their reduce launch belong to the wgrad class
+        if kind.startswith('TN') and traffic is not None and 'TN-reduce' in pmc_all:     # split-K partial sums + their reduce launch belong to the wgrad class
             traffic += pmc_all['TN-reduce'].get('traffic_bytes_per_launch', 0)
         return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic, 'mfma_busy': pmc.get('mfma_busy'),
                 'waves_parked': pmc.get('waves_parked'), 'waves_issue_stalled': pmc.get('waves_issue_stalled'),
-                'kernel': '%s (%s)' % GEMM_KERNELS.get(kind, (kind, 'other GEMM')), 'launches_timed': d['n'], 'avg_launch_ms': round(d['ms'] / d['n'], 4),
+                'kernel': '%s (%s)' % gemm_kernel_label(kind), 'launches_timed': d['n'], 'avg_launch_ms': round(d['ms'] / d['n'], 4),
                 'total_ms_per_step': round(d['ms'] / n_steps, 2),
                 'avg_launch_ms_overlapped_in_step': round(overlapped[kind]['ms'] / overlapped[kind]['n'], 4) if kind in overlapped else None,
                 'algorithmic_flops_per_launch': round(d['flops'] / d['n']), 'algorithmic_bytes_per_launch': round(d['bytes'] / d['n'])}
 
     order = sorted(serial, key=lambda k: -serial[k]['ms'])
     roof = entry(order[0])
+    fam = {}
+    for k_, d_ in serial.items():                       # the instances of one kernel family taken together (A-stationary: 4 epilogue instances; wgrad: 3 kernels)
+        f_ = fam.setdefault('/'.join(k_.split('/')[:2]) if k_.startswith('NT') else k_.split('/')[0], {'ms': 0.0, 'flops': 0.0})
+        f_['ms'] += d_['ms']; f_['flops'] += d_['flops']
+    roof['gemm_families'] = {k_: {'achieved_tflops': round(f_['flops'] / f_['ms'] / 1e9, 1), 'frac': round(f_['flops'] / f_['ms'] / 1e9 / PEAK_BF16_TFLOPS, 4),
+                                  'total_ms_per_step': round(f_['ms'] / n_steps, 2)} for k_, f_ in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])}
     roof['timing'] = 'HIP events on the launch stream around every GEMM launch in %d real training steps (kernels serialized on one stream)' % n_steps
     roof['rocprof_summary'] = ('profiles/r03_bench_train_rocprof_stats.txt = rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3 --no-cpu-baseline '
                                '--no-gen --no-stage1 --no-gpt2 --no-step0-check --no-b4` (training kernels only); PMC (traffic, mfma_busy): profiles/r03_pmc_step.json')

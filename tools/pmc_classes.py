@@ -5,7 +5,10 @@
 SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES).  usage: pmc_classes.py out.json db1 db2 ..."""
 import collections, json, sqlite3, sys
 
-CLASSES = [('NT/K=512', ('gemm_astat_kernel',)), ('TN', ('gemm_w128_tn_kernel', 'gemm_bf16_kernelILb0ELb0', 'gemm_bf16_kernel<false, false')), ('TN-reduce', ('splitk_reduce_kernel',)),
+CLASSES = [('NT/K=512/relu+drop+mask', ('gemm_astat_kernelIDF16bLi19E',)), ('NT/K=512/bits', ('gemm_astat_kernelIDF16bLi8E',)), ('NT/K=512/plain', ('gemm_astat_kernelIDF16bLi0E',)),
+           ('NT/K=512/drop+res', ('gemm_astat_kernelIDF16bLi6E',)), ('NT/K=512', ('gemm_astat_kernel',)),
+           ('TN/rs', ('gemm_w128_tn_kernel<1>', 'gemm_w128_tn_kernelILi1E')), ('TN/plain', ('gemm_w128_tn_kernel<0>', 'gemm_w128_tn_kernelILi0E')),
+           ('TN/128', ('gemm_bf16_kernelILb0ELb0', 'gemm_bf16_kernel<false, false')), ('TN-reduce', ('splitk_reduce_kernel',)),
            ('NN', ('gemm_bf16_glds_kernelILb1ELb0', 'gemm_bf16_glds_kernel<true, false')),
            ('NT/K>1024', ('gemm_w128_kernel', 'gemm_bf16_glds_kernelILb1ELb1EDF16bLi64ELi2', 'gemm_bf16_glds_kernel<true, true, __bf16, 64, 2')),
            ('NT', ('gemm_bf16_glds_kernelILb1ELb1',  'gemm_bf16_glds_kernel<true, true')),
