@@ -122,8 +122,9 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
     extra = {}
 
     def instrumented(side_on):
-        was = engine._SIDE['on']
+        was, was_auto = engine._SIDE['on'], engine._SIDE['auto']
         engine._SIDE['on'] = side_on and was
+        engine._SIDE['auto'] = side_on and was_auto            # (kernel durations only mean something when kernels do not share the CUs)
         ops.GEMM_TIMING, ops.KERNEL_TIMING = [], {}
         try:
             for _ in range(n_steps):
@@ -132,7 +133,7 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
         finally:
             rec, ops.GEMM_TIMING = ops.GEMM_TIMING, None
             other, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
-            engine._SIDE['on'] = was
+            engine._SIDE['on'], engine._SIDE['auto'] = was, was_auto
         extra.clear()
         extra.update(other)
         by = {}

@@ -231,9 +231,18 @@ def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save):
 # Weight-gradient GEMMs (and the remaining bias column sums) only feed the optimizer, so they CAN run on a second HIP stream
 # next to the dgrad / attention-backward chain of the main stream (EMO_WGRAD_STREAM=1).  Measured r01: worth 3.5 % while the
 # wgrad kernel still paid for split-K atomics (79.9 -> 77.1 ms/step); with the workspace split-K the kernels no longer leave
-# gaps to fill and sharing the CUs costs more than it hides (72.9 ms with, 70.8 ms without) -> off by default.
+# gaps to fill and sharing the CUs costs more than it hides (72.9 ms with, 70.8 ms without) -> off at the benchmark batch.  At small token
+# counts (the reference YAML's batch size 4: 8192 tokens, GEMM grids of 64-256 blocks on 256 CUs) the chip is underfilled and the second stream
+# wins (r03, same box: 9.08 -> 8.84 ms/step) -> EMO_WGRAD_STREAM unset = on below 32768 tokens; =1 always, =0 never.
 import os as _os
-_SIDE = {'stream': None, 'on': _os.environ.get('EMO_WGRAD_STREAM', '0') == '1'}
+_SIDE = {'stream': None, 'on': _os.environ.get('EMO_WGRAD_STREAM', '') == '1', 'auto': _os.environ.get('EMO_WGRAD_STREAM', '') == '', 'used': False}
+
+
+def _side_on(tensors):
+    if _SIDE['on']:
+        return True
+    t = next((x for x in tensors if x is not None), None)
+    return bool(_SIDE['auto'] and t is not None and t.is_cuda and t.shape[0] < 32768)
 
 
 class _side_stream:
@@ -244,8 +253,10 @@ class _side_stream:
         self.tensors = tensors
 
     def __enter__(self):
-        if not _SIDE['on']:
+        self.on = _side_on(self.tensors)
+        if not self.on:
             return self
+        _SIDE['used'] = True
         main = torch.cuda.current_stream()
         if _SIDE['stream'] is None or _SIDE['stream'].device != main.device:
             _SIDE['stream'] = torch.cuda.Stream(device=main.device)
@@ -259,14 +270,15 @@ class _side_stream:
         return self
 
     def __exit__(self, *a):
-        if _SIDE['on']:
+        if self.on:
             self.ctx.__exit__(*a)
         return False
 
 
 def join_side_stream():
-    if _SIDE['on'] and _SIDE['stream'] is not None:
+    if _SIDE['used'] and _SIDE['stream'] is not None:
         torch.cuda.current_stream().wait_stream(_SIDE['stream'])
+        _SIDE['used'] = False
 
 
 def _timed_wgrad(a, b, out, a_rowsum=None, b_rowsum=None):

@@ -57,7 +57,9 @@ class _timed:
 
 def _workspace(kind, device, need):
     """Caller-owned kernel scratch (the library never allocates): one buffer per (kind, device, stream), grown on demand.  Consumers on one
-    stream run in launch order, so consecutive launches can share it."""
+    stream run in launch order, so consecutive launches can share it.  The size REPORTED to the kernel is the size it asked for, not the
+    (possibly larger) cached buffer: the GEMM's split-K count depends on the workspace it is offered, and a result must not depend on which
+    shapes the process happened to run before (r03: a trace test passed alone and failed after other tests by 1e-4 of a parameter sum)."""
     if need == 0:
         return None, 0
     key = (kind, device, stream())
@@ -65,7 +67,7 @@ def _workspace(kind, device, need):
     if buf is None or buf.numel() < need:
         buf = torch.empty(need, device=device, dtype=torch.uint8)
         _ws_cache[key] = buf
-    return buf, buf.numel()
+    return buf, need
 
 
 def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumulate=False, bias=None, act=ACT_NONE,
