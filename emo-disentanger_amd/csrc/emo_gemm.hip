@@ -822,6 +822,11 @@ static void dispatch_glds(bool akc, bool bkc, dim3 grid, hipStream_t st, const b
     // long reduction (K=2048) the double buffer of full 128-B lines is best (842 vs 796); for MN-contiguous B (dgrad)
     // the 2-stage ring of 32-deep tiles (32 KB, 4 blocks per CU) is best (in-step A/B of the other geometries: DESIGN.md §4.1).
     const bool can64 = (kps % 64) == 0 && (K % 64) == 0;
+    // Small grids (at most two tiles per CU: the reference YAML's batch size 4, stage 1): occupancy has nothing to offer, a block is alone on
+    // its CU and every K step exposed an L2 / HBM round trip -> the 4-stage ring of 32-deep tiles (three tiles in flight inside the block)
+    static const bool small_off = getenv("EMO_GEMM_SMALLGRID") != nullptr && atoi(getenv("EMO_GEMM_SMALLGRID")) == 0;
+    // (r03, same box: batch-4 step 8.85 -> 8.79 ms, stage 1 7.64 -> 7.47 ms; a 64-deep double buffer instead was erratic: 8.5 / 9.2 ms)
+    if (grid.x <= 512 && !small_off && K >= 128) { dispatch_glds2<OutT, 32, 4>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep); return; }
     if (bkc && K > 1024 && can64) dispatch_glds2<OutT, 64, 2>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
     else if (bkc) dispatch_glds2<OutT, 32, 3>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
     else dispatch_glds2<OutT, 32, 2>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);

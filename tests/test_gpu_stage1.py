@@ -233,9 +233,13 @@ def test_stage1_train_loop_reproduces_reference_trace(tmp_path):
     # accuracies are argmax counts over a handful of tokens: allow one flipped near-tie per segment
     for a, b in zip(accs, g['accs']):
         assert abs(a[0] - b[0]) <= 1.0 / (c['B'] * (c['T'] - 5)) + 1e-9
+    # Parameter sums after the 7 Adam steps.  Six gradient tensors of this path are reduced with float atomics (embedding rows, r_w_bias / r_r_bias,
+    # LayerNorm weight / bias, the output bias: 1e-7 relative run-to-run differences), and Adam's normalised update turns that into a visible
+    # spread on the most sensitive tensor (layers.1 r_net.weight: 1.8e-3 .. 2.8e-3 from the reference over six runs in one process, r03) —
+    # a 2e-3 bound passed or failed with the launch timing.
     for k, v in m.state_dict().items():
         ref = g['final_param_sums'][k]
-        assert abs(float(v.double().sum()) - ref) <= 2e-3 * max(abs(ref), 1.0), (k, float(v.double().sum()), ref)
+        assert abs(float(v.double().sum()) - ref) <= 5e-3 * max(abs(ref), 1.0), (k, float(v.double().sum()), ref)
 
 
 @pytest.mark.parametrize('name', ['txl_mems_shared', 'txl_mems_persample'])
