@@ -382,10 +382,14 @@ bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t l
     if ((uint64_t)(AS_BN * ldb + AS_K) * 2 >= 0xFFFF0000ull) return false;
     const size_t lds = AS_RING + AS_MAXN * sizeof(float);
     dim3 grid((unsigned)(M / AS_BM));
-    // outputs beyond the 256-MB MALL are streamed with non-temporal stores (r02 in-step A/B: leaves L2 / MALL to the operands of the
-    // kernels around it, 61.1 -> 60.5 ms/step); smaller outputs are read back by the next kernel and stay cacheable
-    ep.nt_store = (M * N * 2 >= (int64_t)256 << 20) ? 1 : 0;
+    // Non-temporal output stores only for the FFN1 forward (the mask-out instance: 537 MB + the mask, read back once by the FFN2 forward).  r02
+    // streamed every output beyond the 256-MB MALL; r03 per-instance sweep inside the step (EMO_ASTAT_NT_MASK, same box, 3 alternations):
+    // all three large outputs 46.40 ms/step, FFN1 only 46.15, none 46.45 (the A-stationary kernels then run 0.9 ms faster and the kernels that
+    // read the outputs 0.7 ms slower).  PMC: with nt stores WRITE_SIZE is 1.31 x the algorithmic bytes.
+    ep.nt_store = (M * N * 2 >= (int64_t)256 << 20 && ep.mask_out) ? 1 : 0;
     { const char* e = getenv("EMO_ASTAT_NT"); if (e) ep.nt_store = atoi(e); }
+    { const char* e = getenv("EMO_ASTAT_NT_MASK");                 // diagnostics: 1 = mask-out instance, 2 = bit-mask instance, 4 = the others (outputs >= 256 MB)
+      if (e && M * N * 2 >= (int64_t)256 << 20) { const int m = atoi(e); ep.nt_store = (m & (ep.mask_out ? 1 : (ep.mul_mode == EMO_MUL_BITMASK ? 2 : 4))) ? 1 : 0; } }
 #define AS_LAUNCH(OutT, FLv)                                                                                                              \
     do {                                                                                                                                  \
         auto k = gemm_astat_kernel<OutT, FLv>;                                                                                            \
