@@ -221,7 +221,8 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) a[i][ks] = *(const bf16x8*)(ap + (int64_t)i * 16 * lda + ks * 32);
+            for (int ks = 0; ks < 16; ++ks)
+                a[i][ks] = ep.a_nt ? __builtin_nontemporal_load((const bf16x8*)(ap + (int64_t)i * 16 * lda + ks * 32)) : *(const bf16x8*)(ap + (int64_t)i * 16 * lda + ks * 32);
     }
     // ---- per-lane constants of the weight stream
     uint32_t src[4];                                              // byte offsets of this lane's four 16-B pieces of a slot (source side, swizzled)
@@ -388,6 +389,7 @@ bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t l
     // read the outputs 0.7 ms slower).  PMC: with nt stores WRITE_SIZE is 1.31 x the algorithmic bytes.
     ep.nt_store = (M * N * 2 >= (int64_t)256 << 20 && ep.mask_out) ? 1 : 0;
     { const char* e = getenv("EMO_ASTAT_NT"); if (e) ep.nt_store = atoi(e); }
+    { const char* e = getenv("EMO_ASTAT_A_NT"); ep.a_nt = e ? atoi(e) : 0; }
     { const char* e = getenv("EMO_ASTAT_NT_MASK");                 // diagnostics: 1 = mask-out instance, 2 = bit-mask instance, 4 = the others (outputs >= 256 MB)
       if (e && M * N * 2 >= (int64_t)256 << 20) { const int m = atoi(e); ep.nt_store = (m & (ep.mask_out ? 1 : (ep.mul_mode == EMO_MUL_BITMASK ? 2 : 4))) ? 1 : 0; } }
 #define AS_LAUNCH(OutT, FLv)                                                                                                              \

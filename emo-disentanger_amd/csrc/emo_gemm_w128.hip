@@ -39,6 +39,12 @@ __device__ __forceinline__ void w_dma2(const char* sbase, uint32_t o0, uint32_t 
                  "global_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(o0), "v"(o1), "s"(sbase), "s"(lds_dst) : "memory", "scc");
 }
+__device__ __forceinline__ void w_dma2_nt(const char* sbase, uint32_t o0, uint32_t o1, uint32_t lds_dst) {      // the same with the streaming (nt) cache hint
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %3 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(o0), "v"(o1), "s"(sbase), "s"(lds_dst) : "memory", "scc");
+}
 // MFMA with the accumulator PINNED to the accumulation registers: with the builtin hipcc splits the 256 accumulator registers of a wave between
 // both register files and rotates them through copies on the loop back-edge (264 v_accvgpr moves per K-tile).  The statement is opaque to the
 // hazard recogniser: the same accumulator is never touched again within 63 MFMAs, and the epilogue waits out the last results (w_mma_drain).
@@ -113,7 +119,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w128_kernel(const bf16_t* __restr
 
     int sa_issue = 0, sb_issue = 0;                             // ring slots of the next A / B tile to issue
     int t_issueA = 0, t_issueB = 0;
-    auto issueA_part = [&](int g) { w_dma2(gA + (int64_t)t_issueA * (W_BK * 2), offA[2 * g], offA[2 * g + 1], dstw + sa_issue * W_TILE + g * 2048); };
+    const bool a_nt = ep.a_nt != 0;                            // streaming hint on the A tiles
+    auto issueA_part = [&](int g) {
+        if (a_nt) w_dma2_nt(gA + (int64_t)t_issueA * (W_BK * 2), offA[2 * g], offA[2 * g + 1], dstw + sa_issue * W_TILE + g * 2048);
+        else w_dma2(gA + (int64_t)t_issueA * (W_BK * 2), offA[2 * g], offA[2 * g + 1], dstw + sa_issue * W_TILE + g * 2048);
+    };
     auto issueB_part = [&](int g) { w_dma2(gB + (int64_t)t_issueB * (W_BK * 2), offB[2 * g], offB[2 * g + 1], dstw + (W_NA + sb_issue) * W_TILE + g * 2048); };
     auto doneA = [&]() { ++t_issueA; sa_issue = sa_issue == W_NA - 1 ? 0 : sa_issue + 1; };
     auto doneB = [&]() { ++t_issueB; sb_issue ^= 1; };
@@ -258,7 +268,7 @@ __device__ __forceinline__ int w_swz_k(int k) { return (k & 3) | (((k >> 3) & 1)
 template <int RS>
 __global__ __launch_bounds__(256, 1) void gemm_w128_tn_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                              float* __restrict__ Cws, int64_t M, int64_t N, int64_t K, int64_t kps, float* __restrict__ a_rowsum, float* __restrict__ b_rowsum,
-                                                             int full, int extra) {
+                                                             int full, int extra, int nt_mask) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -320,8 +330,15 @@ __global__ __launch_bounds__(256, 1) void gemm_w128_tn_kernel(const bf16_t* __re
     int rs_phase = RS ? (int)((kbeg / W_BK) % rs_mod) : 0;      // K-tile index modulo the number of blocks that share the summed operand
 
     int sa_issue = 0, sb_issue = 0, t_issueA = 0, t_issueB = 0;
-    auto issueA_part = [&](int g) { w_dma2(gA + (int64_t)t_issueA * stepA, offA[2 * g], offA[2 * g + 1], dstw + sa_issue * W_TILE + g * 2048); };
-    auto issueB_part = [&](int g) { w_dma2(gB + (int64_t)t_issueB * stepB, offB[2 * g], offB[2 * g + 1], dstw + (W_NA + sb_issue) * W_TILE + g * 2048); };
+    const bool a_nt = (nt_mask & 1) != 0, b_nt = (nt_mask & 2) != 0;     // streaming hint on the operand tiles
+    auto issueA_part = [&](int g) {
+        if (a_nt) w_dma2_nt(gA + (int64_t)t_issueA * stepA, offA[2 * g], offA[2 * g + 1], dstw + sa_issue * W_TILE + g * 2048);
+        else w_dma2(gA + (int64_t)t_issueA * stepA, offA[2 * g], offA[2 * g + 1], dstw + sa_issue * W_TILE + g * 2048);
+    };
+    auto issueB_part = [&](int g) {
+        if (b_nt) w_dma2_nt(gB + (int64_t)t_issueB * stepB, offB[2 * g], offB[2 * g + 1], dstw + (W_NA + sb_issue) * W_TILE + g * 2048);
+        else w_dma2(gB + (int64_t)t_issueB * stepB, offB[2 * g], offB[2 * g + 1], dstw + (W_NA + sb_issue) * W_TILE + g * 2048);
+    };
     auto doneA = [&]() { ++t_issueA; sa_issue = sa_issue == W_NA - 1 ? 0 : sa_issue + 1; if (t_issueA > nk - 1) t_issueA = nk - 1; };
     auto doneB = [&]() { ++t_issueB; sb_issue ^= 1; if (t_issueB > nk - 1) t_issueB = nk - 1; };
 #pragma unroll
@@ -427,10 +444,12 @@ bool emo_gemm_w128_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ld
     if ((uint64_t)(256 * (lda > ldb ? lda : ldb) + 64) * 2 >= 0xFFFF0000ull) return false;
     const int64_t tiles_m = M / W_BM, tiles_n = N / W_BN;
     dim3 grid((unsigned)(((tiles_m + 7) / 8) * 8 * tiles_n));
+    EpiParams ep2 = ep;
+    { const char* e3 = getenv("EMO_W128_A_NT"); ep2.a_nt = e3 ? atoi(e3) : 1; }     // default on (r03: -0.4 .. -0.55 ms/step; the wgrad kernel loses with it)
     auto k = gemm_w128_kernel<bf16_t>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS); attr = true; }
-    hipLaunchKernelGGL(k, grid, dim3(256), W_LDS, st, A, lda, B, ldb, (bf16_t*)C, M, N, K, ep);
+    hipLaunchKernelGGL(k, grid, dim3(256), W_LDS, st, A, lda, B, ldb, (bf16_t*)C, M, N, K, ep2);
     return true;
 }
 
@@ -477,12 +496,14 @@ bool emo_gemm_w128_tn_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t
     const int64_t kps = ((K / W_BK + splits0 - 1) / splits0) * W_BK;
     const int64_t ntile = (M / W_BM) * (N / W_BN);
     dim3 grid(256);                                            // 32 block slots per XCD (w_tn_plan)
+    int nt_mask = 0;
+    { const char* e3 = getenv("EMO_W128_TN_NT"); if (e3) nt_mask = atoi(e3); }
 #define W_TN_LAUNCH(RSv)                                                                                                                     \
     do {                                                                                                                                     \
         auto k = gemm_w128_tn_kernel<RSv>;                                                                                                   \
         static bool attr = false;                                                                                                            \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS); attr = true; }            \
-        hipLaunchKernelGGL(k, grid, dim3(256), W_LDS, st, A, lda, B, ldb, (float*)ws, M, N, K, kps, a_rowsum, b_rowsum, full, extra);        \
+        hipLaunchKernelGGL(k, grid, dim3(256), W_LDS, st, A, lda, B, ldb, (float*)ws, M, N, K, kps, a_rowsum, b_rowsum, full, extra, nt_mask); \
     } while (0)
     if (a_rowsum) W_TN_LAUNCH(1); else if (b_rowsum) W_TN_LAUNCH(2); else W_TN_LAUNCH(0);
 #undef W_TN_LAUNCH
