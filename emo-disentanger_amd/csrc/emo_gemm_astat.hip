@@ -53,16 +53,14 @@ template <> __device__ __forceinline__ u32x4 as_load16<64>(const char* sbase, ui
     return r;
 }
 template <int IMM> __device__ __forceinline__ uint32_t as_load1(const char* sbase, uint32_t voff);
-template <> __device__ __forceinline__ uint32_t as_load1<0>(const char* sbase, uint32_t voff) {
-    uint32_t r;
-    asm volatile("global_load_ubyte %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
-    return r;
-}
-template <> __device__ __forceinline__ uint32_t as_load1<4>(const char* sbase, uint32_t voff) {
-    uint32_t r;
-    asm volatile("global_load_ubyte %0, %1, %2 offset:4" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
-    return r;
-}
+#define AS_LOAD1(IMMv)                                                                                                                    \
+    template <> __device__ __forceinline__ uint32_t as_load1<IMMv>(const char* sbase, uint32_t voff) {                                   \
+        uint32_t r;                                                                                                                       \
+        asm volatile("global_load_ubyte %0, %1, %2 offset:" #IMMv : "=v"(r) : "v"(voff), "s"(sbase) : "memory");                         \
+        return r;                                                                                                                         \
+    }
+AS_LOAD1(0) AS_LOAD1(64) AS_LOAD1(128) AS_LOAD1(192)
+#undef AS_LOAD1
 // (every asm store ends with `s_nop 1`: a VALU write to the data registers of a > 8-byte VMEM store needs one wait state after it, and hipcc's
 // hazard recogniser does not look inside an asm statement — without it one row in ~30000 came out with garbage in its first dword.)
 // Stores with an SGPR base + 32-bit per-lane offset (hipcc otherwise keeps one 64-bit per-lane pointer per output tensor live across the
@@ -137,7 +135,7 @@ __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ 
     if ((FL & AF_GELUAUX) || (G && ep.aux_out)) as_store_row8<OutT>((const OutT*)ep.aux_out + ub, lo, v);      // the pre-activation (gelu backward)
     if ((FL & AF_RELU) || (G && ep.act == EMO_ACT_RELU)) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        for (int i = 0; i < 8; ++i) v[i] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v[i]), 0));   // one v_max_i32: same bits as fmaxf(v, 0) for every non-NaN v (fmaxf = canonicalise + v_max_f32)
     } else if (FL & AF_GELUAUX) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = gelu_new_fast(v[i]);
@@ -274,9 +272,15 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
     // The body is branch-free: past the last stage the refill re-fetches the last column tile (harmless, drained before exit) so that
     // every wait count is a constant.
     const int ecol = 8 * (lane >> 4);
-    const uint32_t boff[2] = {(uint32_t)((lane & 15) * (N >> 3) + (lane >> 4)), (uint32_t)(((lane & 15) + 16) * (N >> 3) + (lane >> 4))};
-    const uint32_t eoff2[2] = {(uint32_t)((lane & 15) * ep.ldc + ecol), (uint32_t)(((lane & 15) + 16) * ep.ldc + ecol)};          // elements
-    const uint32_t doff[2] = {(uint32_t)((lane & 15) * N + ecol), (uint32_t)(((lane & 15) + 16) * N + ecol)};
+    // 1-bit mask (mask_out / EMO_MUL_BITMASK), TILED layout private to this kernel: the 256 mask bytes of a wave's 32-row x 64-column tile are
+    // contiguous — block ((m / 32) * (N / 64) + n / 64) * 256, byte (2 i + h) * 64 + lane for row 16 i + (lane & 15), columns 32 h + 8 (lane >> 4) .. +7
+    // — so each of the four byte stores / loads of a tile covers ONE 64-byte run (row-major [M][N/8]: 16 rows = 16 lines per instruction,
+    // 4 useful bytes per 32-byte sector).  ops.bitmask_rows() converts to the row-major view for tests.
+    const int64_t mtile0 = (m0 >> 5) * (int64_t)n_tiles * 256;
+    // per-lane offsets of row (lane & 15) only: the 16-row step of the second row fragment goes into the wave-uniform (scalar) part of the
+    // address — two loop-invariant VGPRs fewer (at 256 VGPRs a spilled one comes back as scratch_load + s_waitcnt vmcnt(0) = a drained DMA ring)
+    const uint32_t eoff0 = (uint32_t)((lane & 15) * ep.ldc + ecol);                                                              // elements
+    const uint32_t doff0 = (uint32_t)((lane & 15) * N + ecol);
 #ifdef EMO_DIAG
     uint64_t t_wait = 0, t_epi = 0, t_loop0 = __builtin_readcyclecounter();
 #endif
@@ -298,12 +302,11 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                     const uint64_t tw0 = __builtin_readcyclecounter();
 #endif
                     if (BITS && kc == 3) {                        // the four mask bytes of this column tile: youngest VMEM ops at the wait below
-                        const char* op = (const char*)ep.mul_aux + m0 * (N >> 3) + nt * (AS_BN / 8);          // wave-uniform
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            preb[i * 2 + 0] = as_load1<0>(op, boff[i]);
-                            preb[i * 2 + 1] = as_load1<4>(op, boff[i]);
-                        }
+                        const char* op = (const char*)ep.mul_aux + mtile0 + nt * 256;                          // wave-uniform
+                        preb[0] = as_load1<0>(op, (uint32_t)lane);
+                        preb[1] = as_load1<64>(op, (uint32_t)lane);
+                        preb[2] = as_load1<128>(op, (uint32_t)lane);
+                        preb[3] = as_load1<192>(op, (uint32_t)lane);
                         as_wait<8>();
                     } else {
 #ifdef EMO_DIAG
@@ -347,9 +350,9 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                 float v[8] = {acc[i][2 * h][0], acc[i][2 * h][1], acc[i][2 * h][2], acc[i][2 * h][3],
                               acc[i][2 * h + 1][0], acc[i][2 * h + 1][1], acc[i][2 * h + 1][2], acc[i][2 * h + 1][3]};
                 const int nb = nt * AS_BN + 32 * h;
-                uint32_t lo = eoff2[i];
+                uint32_t lo = eoff0;
                 asm volatile("" : "+v"(lo));                     // opaque per tile: keeps (base + lane offset) out of loop-invariant 64-bit VGPR pointers
-                as_epi8<OutT, FL>(ep, C, m0 * ep.ldc + nb, lo, nb, ecol, m0 * N + nb, doff[i], m0 * (N >> 3) + (nb >> 3), boff[i], v, bias_lds,
+                as_epi8<OutT, FL>(ep, C, (m0 + 16 * i) * ep.ldc + nb, lo, nb, ecol, (m0 + 16 * i) * N + nb, doff0, mtile0 + nt * 256 + (i * 2 + h) * 64, (uint32_t)lane, v, bias_lds,
                                     preb[i * 2 + h]);
                 __builtin_amdgcn_sched_barrier(0);               // one 8-column group at a time: keeps the epilogue's temporaries out of the register peak
             }

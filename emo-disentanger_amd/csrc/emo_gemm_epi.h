@@ -26,7 +26,7 @@ struct EpiParams {
     float* a_rowsum;     // [M] += sum_k op(A)[m][k] (bias gradient riding on the wgrad GEMM), TN bf16 kernel only
     float* b_rowsum;     // [N] += sum_k op(B)[n][k] (same for the Conv1D layout, where dY is the B operand)
     int64_t ws_stride;   // > 0: split-K partials go to C + split * ws_stride with plain stores (splitk_reduce_kernel sums them)
-    uint8_t* mask_out;   // [M, N/8] bit mask of (value != 0) after act / dropout; mul_mode EMO_MUL_BITMASK reads one (A-stationary kernel only)
+    uint8_t* mask_out;   // M*N/8 bytes, tiled (emo_hip.h): bit mask of (value != 0) after act / dropout; mul_mode EMO_MUL_BITMASK reads one (A-stationary kernel only)
     int nt_store;        // A-stationary kernel: non-temporal output stores (set by its launcher for outputs too large to stay cached)
     int a_nt;            // streaming (non-temporal) hint on the A operand loads (A-stationary panel loads / 256 x 256 tile A tiles)
     int ablate;   // diagnostics only (EMO_GEMM_ABLATE): 1 = skip tile loads, 2 = skip MFMAs

@@ -14,7 +14,7 @@ from ._lib import (ACT_GELU_NEW, ACT_NONE, ACT_RELU, BF16, F32, MUL_BITMASK, MUL
 __all__ = ['gemm', 'colsum', 'embed_fwd', 'embed_bwd', 'layernorm_fwd', 'layernorm_bwd', 'dropout_apply', 'favor_attn_fwd',
            'favor_attn_bwd', 'favor_decode_step', 'favor_decode_readout', 'favor_decode_update', 'favor_draw_omega', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'relpos_attn_fwd', 'relpos_attn_bwd', 'relpos_attn_decode', 'xent_fwd',
            'xent_bwd', 'argmax', 'sample_nucleus', 'sample_nucleus_step', 'accuracy_counts', 'sumsq', 'clip_coef', 'adam_step', 'cast',
-           'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW', 'MUL_BITMASK', 'gemm_bitmask_ok']
+           'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW', 'MUL_BITMASK', 'gemm_bitmask_ok', 'bitmask_rows']
 
 
 def _c(t):
@@ -120,6 +120,12 @@ ASTAT_MIN_ROWS = 128 * 256      # emo_gemm_astat.hip: one 128-row panel per bloc
 def gemm_bitmask_ok(M, N, K, in_dtype, out_dtype):
     """Shape class in which emo_gemm writes / reads the 1-bit epilogue mask (mask_out / MUL_BITMASK): the A-stationary K = 512 kernel."""
     return in_dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and K == 512 and M % 128 == 0 and M >= ASTAT_MIN_ROWS and N % 64 == 0 and 64 <= N <= 2048
+
+
+def bitmask_rows(mask, M, N):
+    """Row-major view [M, N/8] (byte (m, n/8), bit j = column 8 (n/8) + j) of a mask in emo_gemm's tiled layout (emo_hip.h: mask_out) — tests / diagnostics."""
+    t = mask.reshape(M // 32, N // 64, 2, 2, 4, 16)           # [row panel, column tile, i = row / 16, h = column / 32, g = column group, r = row % 16]
+    return t.permute(0, 2, 5, 1, 3, 4).reshape(M, N // 8)
 
 
 def colsum(X, out=None, accumulate=False):

@@ -56,7 +56,7 @@ typedef struct {
     void* aux_out;        /* NULL or [M,N] (dtype_out, ld=ldc): value before the activation */
     const void* mul_aux;  /* NULL or [M,N] (dtype_out, ld=ldc), see mul_mode */
     int mul_mode;         /* EMO_MUL_NONZERO: *= (mul_aux!=0)*mul_scale ; EMO_MUL_DGELU_NEW: *= gelu_new'(mul_aux) ;
-                           * EMO_MUL_BITMASK: mul_aux is a uint8 bit mask [M, N/8] as written by mask_out, *= bit ? mul_scale : 0 */
+                           * EMO_MUL_BITMASK: mul_aux is the uint8 bit mask (M*N/8 bytes, tiled layout) written by mask_out, *= bit ? mul_scale : 0 */
     float mul_scale;
     float p_drop;         /* dropout after the activation; element index = m*N+n */
     uint64_t seed, offset;
@@ -77,8 +77,11 @@ typedef struct {
     float* a_rowsum;      /* NULL or [M] fp32: += sum_k op(A)[m][k]; needs a_trans.  For a weight gradient dW = dY^T X this is the bias
                            * gradient (column sums of dY), taken inside the GEMM from the operand fragments instead of a second pass. */
     float* b_rowsum;      /* NULL or [N] fp32: += sum_k op(B)[n][k]; needs a_trans and b_trans (HF Conv1D layout, where dY is the B operand) */
-    uint8_t* mask_out;    /* NULL or [M, N/8] bytes: bit j of byte (m, n/8) = (value after act and dropout != 0) for column 8*(n/8)+j — the 1-bit
-                           * relu.dropout mask the FFN2 dgrad needs (instead of re-reading the [M,N] activation).  Only with EMO_MUL_BITMASK's
+    uint8_t* mask_out;    /* NULL or M*N/8 bytes: one bit per output = (value after act and dropout != 0) — the 1-bit relu.dropout mask the FFN2
+                           * dgrad needs (instead of re-reading the [M,N] activation).  TILED layout (r03; only emo_gemm reads it back): the 256
+                           * bytes of a 32-row x 64-column tile are contiguous at ((m/32)*(N/64) + n/64)*256; inside, byte
+                           * ((m%32)/16*2 + (n%64)/32)*64 + (n%32)/8*16 + m%16 holds columns 8*(n/8) .. +7 of row m, bit j = column 8*(n/8)+j
+                           * (one 64-byte run per store / load instruction of the A-stationary kernel).  Only with EMO_MUL_BITMASK's
                            * shape class: bf16 in/out, NT, K = 512, M % 128 == 0, M >= 32768, N % 64 == 0, N <= 2048 (the A-stationary kernel); refused elsewhere. */
     void* workspace;      /* NULL or caller scratch for split-K partial sums (plain fp32-output GEMMs = weight gradients): */
     int64_t workspace_bytes; /* with it the splits are summed in a fixed order by a reduce kernel (deterministic, no atomics);

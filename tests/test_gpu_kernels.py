@@ -891,7 +891,7 @@ def test_gemm_astat_bitmask_epilogue_equals_the_activation_mask():
     f = ops.gemm(h, W1, bias=b1, act=ops.ACT_RELU, p_drop=0.1, seed=5, offset=2, mask_out=fmask)
     f_plain = ops.gemm(h, W1, bias=b1, act=ops.ACT_RELU, p_drop=0.1, seed=5, offset=2)
     assert torch.equal(f, f_plain)                                  # writing the mask does not change the output
-    bits = (fmask[:, :, None] >> torch.arange(8, device='cuda', dtype=torch.uint8)) & 1
+    bits = (ops.bitmask_rows(fmask, M, N)[:, :, None] >> torch.arange(8, device='cuda', dtype=torch.uint8)) & 1   # (the mask is stored tile by tile)
     assert torch.equal(bits.reshape(M, N).bool(), f != 0) and 0.3 < float((f != 0).float().mean()) < 0.6
     dy, W2t = _r(M, K, seed=6, dt=torch.bfloat16).cuda(), _r(N, K, seed=7, dt=torch.bfloat16, scale=0.05).cuda()
     a = ops.gemm(dy, W2t, mul_aux=fmask, mul_mode=ops.MUL_BITMASK, mul_scale=1.0 / 0.9)
