@@ -67,6 +67,7 @@ _SIG = {
     'emo_clip_coef': (c_i, [c_p, c_f, c_f, c_p, c_p, c_p]),
     'emo_adam_step': (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_l, c_p, c_p]),
     'emo_cast': (c_i, [c_p, c_i, c_p, c_i, c_l, c_p]),
+    'emo_add_bias2': (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_i, c_l, c_l, c_p]),
     'emo_transpose_batch': (c_i, [c_p, c_i, c_l, c_p]),
     'emo_comm_unique_id': (c_i, [c_p]),
     'emo_comm_init': (c_i, [c_p, c_i, c_i]),

@@ -992,6 +992,35 @@ extern "C" int emo_cast(const void* src, int sd, void* dst, int dd, int64_t n, e
     return EMO_OK;
 }
 
+// qu = x + b1, qv = x + b2 (per-column fp32 biases, the sum rounded once to the storage type): the two biased query copies the key-tile
+// and distance-window passes of the relative-position attention backward read (emo_relpos_attn_bwd_kv / _r), in ONE launch instead of a
+// float copy, two adds and two casts (ATen, 5 launches per layer in the stage-1 step).  x: [M, D] view with row pitch ld; outputs contiguous.
+template <typename T>
+__global__ __launch_bounds__(256) void add_bias2_kernel(const T* __restrict__ x, int64_t ld, const float* __restrict__ b1, const float* __restrict__ b2,
+                                                        T* __restrict__ o1, T* __restrict__ o2, int64_t M, int64_t D) {
+    const int64_t n4 = M * (D >> 2);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / (D >> 2), c = (i % (D >> 2)) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = to_f32<T>(x[m * ld + c + e]);
+            o1[m * D + c + e] = from_f32<T>(v + b1[c + e]);
+            o2[m * D + c + e] = from_f32<T>(v + b2[c + e]);
+        }
+    }
+}
+extern "C" int emo_add_bias2(const void* x, int64_t ld, const float* b1, const float* b2, void* o1, void* o2, int dtype, int64_t M, int64_t D,
+                             emo_stream_t stream) {
+    EMO_CHECK(x && b1 && b2 && o1 && o2 && M > 0 && D > 0 && (D & 3) == 0 && ld >= D, "emo_add_bias2: bad args (D %% 4 == 0, ld >= D)");
+    int64_t blocks = cdiv64(M * (D >> 2), 256);
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EMO_F32) hipLaunchKernelGGL(add_bias2_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, ld, b1, b2, (float*)o1, (float*)o2, M, D);
+    else hipLaunchKernelGGL(add_bias2_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, ld, b1, b2, (bf16_t*)o1, (bf16_t*)o2, M, D);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Batched bf16 transposes (the transposed weight mirrors of engine.ParamStore.wT: 4 per Performer layer, refreshed after every optimizer
 // step): ONE launch for all matrices instead of one ATen copy kernel each (48 x 7.6 us per training step).  desc: n records of six int64

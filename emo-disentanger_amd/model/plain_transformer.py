@@ -121,7 +121,7 @@ def _txl_layer_fwd(ps, p, x, r_dist, B, T, H, pd, seed, off, pre, save, mem=None
     return o
 
 
-def _txl_layer_bwd(ps, p, dout, pe_d, B, T, H, pd, seed, off, s):
+def _txl_layer_bwd(ps, p, dout, pe_d, B, T, H, pd, seed, off, s, acc):
     D = dout.shape[1]
     a, f = p + 'dec_attn.', p + 'pos_ff.'
     inv = 1.0 / (1.0 - pd) if pd > 0 else 1.0
@@ -144,10 +144,9 @@ def _txl_layer_bwd(ps, p, dout, pe_d, B, T, H, pd, seed, off, s):
         dvec, dh_res = pad(dvec), pad(dh)
     else:
         dh_res = dh
-    dqkv, dR, d_rw, d_rr = ops.relpos_attn_bwd(s['qkv'], s['r_dist'], ps.f32('decoder.r_w_bias'), ps.f32('decoder.r_r_bias'), s['vec'], dvec, s['lse'],
-                                               s['zden'], B, K, H, p_drop=pd, seed=seed, offset=off + 1)
-    ps.g('decoder.r_w_bias').add_(d_rw)
-    ps.g('decoder.r_r_bias').add_(d_rr)
+    # (the column sums behind d r_w_bias / d r_r_bias — parameters shared by all layers — accumulate into `acc`; TXLStackFn.backward adds them once)
+    dqkv, dR, _, _ = ops.relpos_attn_bwd(s['qkv'], s['r_dist'], ps.f32('decoder.r_w_bias'), ps.f32('decoder.r_r_bias'), s['vec'], dvec, s['lse'],
+                                         s['zden'], B, K, H, p_drop=pd, seed=seed, offset=off + 1, acc_dq=acc[0], acc_rr=acc[1])
     wg(dR.to(ps.compute_dtype), pe_d, a + 'r_net.weight')                     # R = r_net(dropout(pos_emb)): dW_r += dR^T pos_emb
     wg(dqkv, s['n'], a + 'qkv_net.weight')
     dn = ops.gemm(dqkv, ps.w(a + 'qkv_net.weight'), b_trans=True)
@@ -203,9 +202,12 @@ class TXLStackFn(torch.autograd.Function):
             dx = dx.to(ps.compute_dtype).contiguous()
         if pd > 0:
             dx = ops.dropout_apply(dx, pd, seed, base + 2)
+        acc = torch.zeros(2, D, device=dx.device, dtype=torch.float32)        # [colsum(dq), colsum(dq_relative)] summed over the layers
         for l in reversed(range(L)):
-            dx = _txl_layer_bwd(ps, 'decoder.layers.%d.' % l, dx, ctx.pe_d, B, T, H, pd, seed, base + 8 * (l + 1), ctx.saves[l])
+            dx = _txl_layer_bwd(ps, 'decoder.layers.%d.' % l, dx, ctx.pe_d, B, T, H, pd, seed, base + 8 * (l + 1), ctx.saves[l], acc)
             ctx.saves[l] = None
+        ps.g('decoder.r_r_bias').add_(acc[1].view(H, D // H))                  # d r_r_bias = colsum(dq_relative)
+        ps.g('decoder.r_w_bias').add_((acc[0] - acc[1]).view(H, D // H))       # d r_w_bias = colsum(dq) - colsum(dq_relative)
         if pd > 0:
             dx = ops.dropout_apply(dx, pd, seed, base + 1)
         gE = ps.g('word_emb.emb_lookup.weight')

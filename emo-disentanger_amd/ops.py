@@ -313,7 +313,7 @@ def relpos_attn_fwd(q, k, v, r_dist, r_w_bias, r_r_bias, B, T, H, p_drop=0.0, se
     return out, lse, zden
 
 
-def relpos_attn_bwd(qkv, r_dist, r_w_bias, r_r_bias, out, dout, lse, zden, B, T, H, p_drop=0.0, seed=0, offset=0):
+def relpos_attn_bwd(qkv, r_dist, r_w_bias, r_r_bias, out, dout, lse, zden, B, T, H, p_drop=0.0, seed=0, offset=0, acc_dq=None, acc_rr=None):
     """Backward of relpos_attn_fwd.  qkv [B*T, 3*H*dh] (the fused projection).  Returns dqkv [B*T, 3*H*dh], dR [T, H*dh] fp32 (gradient of
     r_dist rows 0..T-1), d r_w_bias [H, dh], d r_r_bias [H, dh] fp32.  Three kernels, each recomputing the probabilities of its tiles:
     query-tile pass (dq = content + relative part), key-tile pass (dk, dv), distance-window pass (dR) — include/emo_hip.h."""
@@ -329,10 +329,16 @@ def relpos_attn_bwd(qkv, r_dist, r_w_bias, r_r_bias, out, dout, lse, zden, B, T,
     check(lib.emo_relpos_attn_bwd(ptr(q), ptr(k), ptr(v), D3, ptr(r_dist), _rows(r_dist), r_dist.shape[0], ptr(r_w_bias), ptr(r_r_bias), ptr(out),
                                   ptr(dout), D, ptr(lse), ptr(zden), ptr(dqkv), D3, ptr(dq_rel), D, ptr(delta), dtype_code(dt), B, T, H, dh, p_drop,
                                   seed, offset, stream()))
-    d_rr = colsum(dq_rel)                                       # sum over (b, i) of the relative part of dq = d r_r_bias
-    d_rw = (colsum(dqkv[:, :D]) - d_rr).view(H, dh)             # ... of the content part = d r_w_bias
-    qf = q.float()
-    qu, qv = (qf + r_w_bias.view(1, D)).to(dt), (qf + r_r_bias.view(1, D)).to(dt)
+    if acc_dq is not None:                                      # training stack: column sums accumulated over the layers, no per-layer ATen ops —
+        colsum(dqkv[:, :D], out=acc_dq, accumulate=True)        # acc_dq += colsum(dq), acc_rr += colsum(dq_rel); the caller forms
+        colsum(dq_rel, out=acc_rr, accumulate=True)             # d r_r_bias = acc_rr, d r_w_bias = acc_dq - acc_rr once per backward
+        d_rr = d_rw = None
+    else:
+        d_rr = colsum(dq_rel)                                   # sum over (b, i) of the relative part of dq = d r_r_bias
+        d_rw = (colsum(dqkv[:, :D]) - d_rr).view(H, dh)         # ... of the content part = d r_w_bias
+        d_rr = d_rr.view(H, dh)
+    qu, qv = torch.empty(M, D, device=dev, dtype=dt), torch.empty(M, D, device=dev, dtype=dt)
+    check(lib.emo_add_bias2(ptr(q), D3, ptr(r_w_bias), ptr(r_r_bias), ptr(qu), ptr(qv), dtype_code(dt), M, D, stream()))   # q + r_w_bias, q + r_r_bias
     check(lib.emo_relpos_attn_bwd_kv(ptr(qu), ptr(qv), D, ptr(k), ptr(v), D3, ptr(r_dist), _rows(r_dist), r_dist.shape[0], ptr(dout), D, ptr(lse),
                                      ptr(zden), ptr(delta), ptr(dqkv[:, D:2 * D]), ptr(dqkv[:, 2 * D:]), D3, dtype_code(dt), B, T, H, dh, p_drop, seed,
                                      offset, stream()))
@@ -340,7 +346,7 @@ def relpos_attn_bwd(qkv, r_dist, r_w_bias, r_r_bias, out, dout, lse, zden, B, T,
     ws, ws_bytes = _workspace('relpos_dr', dev, lib.emo_relpos_attn_bwd_r_workspace_bytes(B, T, H, dh))
     check(lib.emo_relpos_attn_bwd_r(ptr(qu), ptr(qv), D, ptr(k), ptr(v), D3, ptr(r_dist), _rows(r_dist), r_dist.shape[0], ptr(dout), D, ptr(lse),
                                     ptr(zden), ptr(delta), ptr(dR), D, ptr(ws), ws_bytes, dtype_code(dt), B, T, H, dh, p_drop, seed, offset, stream()))
-    return dqkv, dR, d_rw, d_rr.view(H, dh)
+    return dqkv, dR, d_rw, d_rr
 
 
 def relpos_attn_decode(q, kcache, vcache, lens, H, r_dist, r_w_bias, r_r_bias, mem_len=0, lens_off=0, k_new=None, v_new=None):

@@ -293,6 +293,11 @@ int emo_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, in
                   float beta1, float beta2, float eps, int64_t step, const float* gscale,
                   emo_stream_t stream);
 int emo_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, emo_stream_t stream);
+/* o1 = x + b1, o2 = x + b2 with per-column fp32 biases [D]; x [M, D] (row pitch ld), o1 / o2 contiguous [M, D], same dtype.  The biased
+ * query copies qu = q + r_w_bias, qv = q + r_r_bias of the relative-position attention (stage1_compose/model/optimus_txl_decoder.py:331-341:
+ * rw_head_q / rr_head_q) for emo_relpos_attn_bwd_kv / _r, in one launch. */
+int emo_add_bias2(const void* x, int64_t ld, const float* b1, const float* b2, void* o1, void* o2, int dtype,
+                  int64_t M, int64_t D, emo_stream_t stream);
 /* n bf16 transposes in one launch (no reference counterpart: the transposed weight mirrors that let every dgrad run as a k-contiguous NT
  * product, refreshed after an optimizer step).  desc: DEVICE array of n records of six int64 {src pointer, dst pointer, rows, cols, index of
  * the record's first 64 x 64 tile, tiles per row = ceil(cols / 64)}; src is [rows, cols] row-major, dst [cols, rows]; total_tiles = sum over
