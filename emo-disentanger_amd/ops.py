@@ -13,7 +13,7 @@ from ._lib import (ACT_GELU_NEW, ACT_NONE, ACT_RELU, BF16, F32, MUL_BITMASK, MUL
 
 __all__ = ['gemm', 'colsum', 'embed_fwd', 'embed_bwd', 'layernorm_fwd', 'layernorm_bwd', 'dropout_apply', 'favor_attn_fwd',
            'favor_attn_bwd', 'favor_decode_step', 'favor_decode_readout', 'favor_decode_update', 'favor_draw_omega', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'relpos_attn_fwd', 'relpos_attn_bwd', 'relpos_attn_decode', 'xent_fwd',
-           'xent_bwd', 'argmax', 'sample_nucleus', 'sample_nucleus_step', 'accuracy_counts', 'sumsq', 'clip_coef', 'adam_step', 'cast',
+           'xent_bwd', 'argmax', 'sample_nucleus', 'sample_nucleus_step', 'accuracy_counts', 'sumsq', 'clip_coef', 'adam_step', 'cast', 'add_bias2',
            'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW', 'MUL_BITMASK', 'gemm_bitmask_ok', 'bitmask_rows']
 
 
@@ -337,8 +337,7 @@ def relpos_attn_bwd(qkv, r_dist, r_w_bias, r_r_bias, out, dout, lse, zden, B, T,
         d_rr = colsum(dq_rel)                                   # sum over (b, i) of the relative part of dq = d r_r_bias
         d_rw = (colsum(dqkv[:, :D]) - d_rr).view(H, dh)         # ... of the content part = d r_w_bias
         d_rr = d_rr.view(H, dh)
-    qu, qv = torch.empty(M, D, device=dev, dtype=dt), torch.empty(M, D, device=dev, dtype=dt)
-    check(lib.emo_add_bias2(ptr(q), D3, ptr(r_w_bias), ptr(r_r_bias), ptr(qu), ptr(qv), dtype_code(dt), M, D, stream()))   # q + r_w_bias, q + r_r_bias
+    qu, qv = add_bias2(q, r_w_bias, r_r_bias)                   # q + r_w_bias, q + r_r_bias
     check(lib.emo_relpos_attn_bwd_kv(ptr(qu), ptr(qv), D, ptr(k), ptr(v), D3, ptr(r_dist), _rows(r_dist), r_dist.shape[0], ptr(dout), D, ptr(lse),
                                      ptr(zden), ptr(delta), ptr(dqkv[:, D:2 * D]), ptr(dqkv[:, 2 * D:]), D3, dtype_code(dt), B, T, H, dh, p_drop, seed,
                                      offset, stream()))
@@ -441,6 +440,15 @@ def adam_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, step, gscale):
 def transpose_batch(desc, n, total_tiles):
     """desc: device int64 [n, 6] = {src ptr, dst ptr, rows, cols, first tile, tiles per row} (include/emo_hip.h); one launch."""
     check(lib.emo_transpose_batch(ptr(desc), n, total_tiles, stream()))
+
+
+def add_bias2(x, b1, b2):
+    """(x + b1, x + b2): x [M, D] (row-strided view allowed), fp32 biases of D elements (any shape); contiguous outputs in x's dtype, one launch."""
+    M, D = x.shape
+    assert b1.dtype == torch.float32 and b2.dtype == torch.float32 and b1.numel() == D and b2.numel() == D and b1.is_contiguous() and b2.is_contiguous()
+    o1, o2 = torch.empty(M, D, device=x.device, dtype=x.dtype), torch.empty(M, D, device=x.device, dtype=x.dtype)
+    check(lib.emo_add_bias2(ptr(x), _rows(x), ptr(b1), ptr(b2), ptr(o1), ptr(o2), dtype_code(x.dtype), M, D, stream()))
+    return o1, o2
 
 
 def cast(src, dst):

@@ -901,6 +901,18 @@ def test_gemm_astat_bitmask_epilogue_equals_the_activation_mask():
         ops.gemm(h[:100], W1, mask_out=fmask[:100])
 
 
+@pytest.mark.parametrize('dt', DT)
+def test_add_bias2_matches_torch(dt):
+    # emo_add_bias2: the biased query copies q + r_w_bias, q + r_r_bias of the stage-1 attention backward in one launch (fp32 sum, rounded once)
+    ops = _ops()
+    M, D = 777, 512
+    qkv = _r(M, 3 * D, seed=1, dt=dt).cuda()
+    b1, b2 = _r(8, 64, seed=2).cuda(), _r(8, 64, seed=3).cuda()
+    q = qkv[:, D:2 * D]                                              # a column block of the fused projection (row pitch 3 D)
+    o1, o2 = ops.add_bias2(q, b1, b2)
+    assert torch.equal(o1, (q.float() + b1.view(1, D)).to(dt)) and torch.equal(o2, (q.float() + b2.view(1, D)).to(dt))
+
+
 def test_transpose_batch_matches_torch():
     # emo_transpose_batch: the transposed weight mirrors of one optimizer step in ONE launch (fast 16-B path and ragged shapes)
     ops = _ops()
