@@ -182,6 +182,23 @@ def test_bench_refuses_more_ranks_than_gpus():
     assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr and '"value"' not in r.stdout
 
 
+def test_bench_two_rank_line_on_one_gpu():
+    """The N > 1 leg of bench.py end to end (rank launch, strict plane check, replica broadcast, rank-stamped exchange self-test, timed product
+    loop with the overlapped exchange, per-rank gather, ONE JSON line from rank 0) with two ranks sharing the test GPU on the host-staged gloo
+    plane (EMO_BENCH_SHARE_GPU is test-only; RCCL refuses two ranks on one device)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '4', '--no-roofline'],
+                       env=_env(EMO_BENCH_SHARE_GPU='1', EMO_COMM='gloo'), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['comm'] == 'gloo' and d['scaling'] == 'weak' and d['config']['global_batch'] == 8 and d['config']['parallelism'] == 'dp2'
+    assert d['dp_selftest']['ok'] and d['dp_selftest']['bad_elements'] == 0 and d['dp_selftest']['split'] and len(d['per_rank_ms_per_step']) == 2
+    assert abs(d['value'] - 2 * 4 * d['config']['seq_len'] * d['steps'] / (d['ms_per_step'] * d['steps'] / 1e3)) <= 1e-3 * d['value']   # whole-job tokens / max-over-ranks time
+    assert 3.0 < d['mean_loss'] < 8.0
+
+
 @pytest.mark.parametrize('opt', ['fused', 'adam'])
 def test_stage1_two_rank_step_equals_one_rank(tmp_path, opt):
     """BASELINE configs[4] (stage-1 lead-sheet LM, data parallel): stage1_train.train with 2 ranks (token-count-weighted exchange, fused
