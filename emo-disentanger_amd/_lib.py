@@ -45,8 +45,6 @@ _SIG = {
     'emo_favor_attn_fwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_l, c_l, c_l, c_l, c_l, c_f, c_p, c_l, c_p]),
     'emo_favor_attn_bwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_l, c_f, c_p, c_l, c_p]),
     'emo_favor_decode_step': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_f, c_p]),
-    'emo_favor_decode_readout': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_f, c_p]),
-    'emo_favor_decode_update': (c_i, [c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_l, c_l, c_l, c_l, c_p]),
     'emo_favor_draw_omega': (c_i, [c_p, c_p, c_l, c_l, c_l, c_p]),
     'emo_softmax_attn_fwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p]),
     'emo_softmax_attn_bwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p]),
@@ -69,6 +67,7 @@ _SIG = {
     'emo_cast': (c_i, [c_p, c_i, c_p, c_i, c_l, c_p]),
     'emo_add_bias2': (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_i, c_l, c_l, c_p]),
     'emo_transpose_batch': (c_i, [c_p, c_i, c_l, c_p]),
+    'emo_comm_bind': (c_i, []),
     'emo_comm_unique_id': (c_i, [c_p]),
     'emo_comm_init': (c_i, [c_p, c_i, c_i]),
     'emo_comm_world': (c_i, []),

@@ -67,6 +67,8 @@ int nccl_dtype(int dtype) { return dtype == EMO_F32 ? NCCL_F32 : dtype == EMO_BF
     } while (0)
 }  // namespace
 
+extern "C" int emo_comm_bind(void) { return bind_rccl() ? EMO_OK : EMO_ERR_UNSUPPORTED; }
+
 extern "C" int emo_comm_unique_id(void* id128) {
     EMO_CHECK(id128, "emo_comm_unique_id: null pointer");
     if (!bind_rccl()) return EMO_ERR_UNSUPPORTED;

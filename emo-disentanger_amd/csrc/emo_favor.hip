@@ -1093,10 +1093,7 @@ __global__ __launch_bounds__(256) void favor_decode_kernel(const CT* __restrict_
 // Compile-time (dh, mf) variant of the decode step: the whole state slice of the block (F x dh fp32 = 32 KB at 128 x 64) is requested
 // with 16-B loads BEFORE the feature phase, so the HBM round trip overlaps the phi(q), phi(k) computation; everything is unrolled
 // (r01: the generic kernel took 18 us per layer for 16.8 MB of state traffic = 0.9 TB/s, latency-bound on 32 dependent 4-B accesses).
-// MODE 0: the whole step.  MODE 1: READOUT only — out = phi(q)^T (S + phi(k) (x) v) / (phi(q).(z + phi(k)) + eps) from the OLD state, nothing
-// is written back (half the state traffic, and the only part of the step the next kernel waits for).  MODE 2: UPDATE only — S += phi(k) (x) v,
-// z += phi(k), no output: launched on a second stream after the read-out, off the token's critical path (inference.py).
-template <typename CT, int DH, int MF, int MODE = 0>
+template <typename CT, int DH, int MF>
 __global__ __launch_bounds__(256) void favor_decode_fast_kernel(const CT* __restrict__ q, const CT* __restrict__ k, const CT* __restrict__ v, int64_t ld,
                                                                 const float* __restrict__ omega, float* __restrict__ state_S,
                                                                 float* __restrict__ state_z, CT* __restrict__ out, int64_t ld_out, int64_t H, float eps) {
@@ -1142,7 +1139,7 @@ __global__ __launch_bounds__(256) void favor_decode_fast_kernel(const CT* __rest
         fq[tid] = pq;
         fk[tid] = pk;
         const float z = zold + pk;
-        if (MODE != 1) state_z[sh * F + tid] = z;
+        state_z[sh * F + tid] = z;
         dn = pq * z;
     }
     dn = wave_sum(dn);
@@ -1155,11 +1152,10 @@ __global__ __launch_bounds__(256) void favor_decode_fast_kernel(const CT* __rest
         const int f = g + R * i;
         if (f < F) {
             const f32x4 sv = st[i] + fk[f] * vd;
-            if (MODE != 1) *(f32x4*)(Sb + f * DH + d4) = sv;
+            *(f32x4*)(Sb + f * DH + d4) = sv;
             acc += fq[f] * sv;
         }
     }
-    if (MODE == 2) return;
     num[g][tid % TPRW] = acc;
     __syncthreads();
     if (tid < DH) {
@@ -1422,26 +1418,22 @@ extern "C" int emo_favor_attn_bwd(const void* q, const void* k, const void* v, i
                           eps, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-static int favor_decode_any(int mode, const void* q, const void* k, const void* v, int64_t ld, const float* omega, float* state_S, float* state_z, void* out,
-                            int64_t ld_out, int dtype, int64_t n_streams, int64_t H, int64_t dh, int64_t n_feat, float eps, emo_stream_t stream) {
-    EMO_CHECK(q && k && v && omega && state_S && state_z && (out || mode == 2), "emo_favor_decode_step: null pointer");
+extern "C" int emo_favor_decode_step(const void* q, const void* k, const void* v, int64_t ld, const float* omega, float* state_S, float* state_z, void* out,
+                                     int64_t ld_out, int dtype, int64_t n_streams, int64_t H, int64_t dh, int64_t n_feat, float eps, emo_stream_t stream) {
+    EMO_CHECK(q && k && v && omega && state_S && state_z && out, "emo_favor_decode_step: null pointer");
     EMO_CHECK(dh <= 64 && dh >= 16 && 256 % dh == 0 && n_feat <= 128 && n_feat % 2 == 0, "emo_favor_decode_step: needs 16<=d_head<=64 dividing 256, n_feat<=128");
     dim3 grid((unsigned)(n_streams * H));
     hipStream_t st = (hipStream_t)stream;
-#define DECODE_LAUNCH(CTv, DHv, MFv, MODEv)                                                                                                     \
-    hipLaunchKernelGGL((favor_decode_fast_kernel<CTv, DHv, MFv, MODEv>), grid, dim3(256), 0, st, (const CTv*)q, (const CTv*)k, (const CTv*)v, ld, omega,      \
+#define DECODE_LAUNCH(CTv, DHv, MFv)                                                                                                            \
+    hipLaunchKernelGGL((favor_decode_fast_kernel<CTv, DHv, MFv>), grid, dim3(256), 0, st, (const CTv*)q, (const CTv*)k, (const CTv*)v, ld, omega,             \
                        state_S, state_z, (CTv*)out, ld_out, H, eps)
 #define DECODE_CASE(DHv, MFv)                                                                                                                   \
     if (dh == DHv && n_feat == 2 * MFv) {                                                                                                       \
-        if (dtype == EMO_F32) {                                                                                                                 \
-            if (mode == 0) DECODE_LAUNCH(float, DHv, MFv, 0); else if (mode == 1) DECODE_LAUNCH(float, DHv, MFv, 1); else DECODE_LAUNCH(float, DHv, MFv, 2);   \
-        } else {                                                                                                                                \
-            if (mode == 0) DECODE_LAUNCH(bf16_t, DHv, MFv, 0); else if (mode == 1) DECODE_LAUNCH(bf16_t, DHv, MFv, 1); else DECODE_LAUNCH(bf16_t, DHv, MFv, 2); \
-        }                                                                                                                                       \
+        if (dtype == EMO_F32) DECODE_LAUNCH(float, DHv, MFv); else DECODE_LAUNCH(bf16_t, DHv, MFv);                                             \
         EMO_LAUNCH_CHECK();                                                                                                                     \
         return EMO_OK;                                                                                                                          \
     }
-    if ((mode != 0 || getenv("EMO_FAVOR_DECODE_GENERIC") == nullptr) && (((uintptr_t)state_S) & 15) == 0) {
+    if (getenv("EMO_FAVOR_DECODE_GENERIC") == nullptr && (((uintptr_t)state_S) & 15) == 0) {
         DECODE_CASE(64, 64)
         DECODE_CASE(32, 64)
         DECODE_CASE(32, 32)
@@ -1450,7 +1442,6 @@ static int favor_decode_any(int mode, const void* q, const void* k, const void* 
     }
 #undef DECODE_CASE
 #undef DECODE_LAUNCH
-    EMO_CHECK(mode == 0, "emo_favor_decode_readout / _update: unsupported (d_head, n_feat) or unaligned state (built: (64,128) (32,128) (32,64) (16,32) (16,64))");
     if (dtype == EMO_F32)
         hipLaunchKernelGGL(favor_decode_kernel<float>, grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, ld, omega, state_S, state_z,
                            (float*)out, ld_out, H, (int)dh, (int)(n_feat / 2), eps);
@@ -1459,18 +1450,4 @@ static int favor_decode_any(int mode, const void* q, const void* k, const void* 
                            state_z, (bf16_t*)out, ld_out, H, (int)dh, (int)(n_feat / 2), eps);
     EMO_LAUNCH_CHECK();
     return EMO_OK;
-}
-
-extern "C" int emo_favor_decode_step(const void* q, const void* k, const void* v, int64_t ld, const float* omega, float* state_S, float* state_z, void* out,
-                                     int64_t ld_out, int dtype, int64_t n_streams, int64_t H, int64_t dh, int64_t n_feat, float eps, emo_stream_t stream) {
-    return favor_decode_any(0, q, k, v, ld, omega, state_S, state_z, out, ld_out, dtype, n_streams, H, dh, n_feat, eps, stream);
-}
-extern "C" int emo_favor_decode_readout(const void* q, const void* k, const void* v, int64_t ld, const float* omega, const float* state_S, const float* state_z,
-                                        void* out, int64_t ld_out, int dtype, int64_t n_streams, int64_t H, int64_t dh, int64_t n_feat, float eps,
-                                        emo_stream_t stream) {
-    return favor_decode_any(1, q, k, v, ld, omega, (float*)state_S, (float*)state_z, out, ld_out, dtype, n_streams, H, dh, n_feat, eps, stream);
-}
-extern "C" int emo_favor_decode_update(const void* k, const void* v, int64_t ld, const float* omega, float* state_S, float* state_z, int dtype,
-                                       int64_t n_streams, int64_t H, int64_t dh, int64_t n_feat, emo_stream_t stream) {
-    return favor_decode_any(2, k, k, v, ld, omega, state_S, state_z, nullptr, 0, dtype, n_streams, H, dh, n_feat, 0.f, stream);
 }

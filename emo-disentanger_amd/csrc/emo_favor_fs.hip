@@ -1017,6 +1017,8 @@ int emo_favor_fs_try(int which, int stage, const bf16_t* q, const bf16_t* k, con
     if (e && atoi(e) == 0) return 0;
     if (T < FS_C || (T % FS_C) != 0 || B * H <= 0 || P < 1 || (P > 1 && (Ts % FS_C) != 0)) return 0;
     if ((ld & 7) || (ld_out & 7) || (ld_d & 3)) return 0;
+    // 16-B LDS-DMA pieces of q / k / v / out / dout rows and 8-/16-B output stores: unaligned views fall back to the generic kernels
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)dout) & 15) || (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15)) return 0;
     if (P == 1) Ts = T;
     // short segments (B*H < 256): the forward's generic kernel is faster (r03, B=4 x T=2048, 8 segments: 66 vs 89 us per layer), the backward's
     // slice kernels still win (114 vs 159 us) -> the segmented forward runs here only on request (EMO_FAVOR_FS=2: tests)

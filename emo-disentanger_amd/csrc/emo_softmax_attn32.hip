@@ -321,6 +321,8 @@ bool emo_sattn32_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* 
     const char* e = getenv("EMO_SATTN32");                   // "0": generic kernels only (read per call: tests toggle it)
     if (e && atoi(e) == 0) return false;
     if (which != 0 || T < 128 || (T % 128) != 0 || (ld & 7) || (ld_out & 3)) return false;
+    // 16-B LDS-DMA pieces and bf16x8 row accesses: an unaligned view (a C-ABI caller's column-offset slice) falls back to the generic kernels
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) || ((uintptr_t)lse & 3)) return false;
     dim3 grid((unsigned)(T / 128), (unsigned)(B * H));
     const size_t lds = 4 * A32_TILEB;
     static bool attr = false;
@@ -337,6 +339,7 @@ bool emo_sattn32_dkv_try(const bf16_t* q, const bf16_t* k, const bf16_t* v, int6
     const char* e2 = getenv("EMO_SATTN32_BWD");
     if (e2 && atoi(e2) == 0) return false;
     if (T < 128 || (T % 128) != 0 || (ld & 7) || (ld_out & 7) || (ld_d & 3) || !delta) return false;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)dk | (uintptr_t)dv) & 15) return false;
     dim3 grid((unsigned)(T / 128), (unsigned)(B * H));
     const size_t lds = 2 * A32_QSLOT;
     static bool attr = false;

@@ -34,29 +34,41 @@ def data_plane():
 
 
 def _init_rccl(rank, world):
-    """Two steps, so that a rank that cannot even bind RCCL never leaves the others blocked inside ncclCommInitRank:
-    (1) LOCAL — every rank dlopen()s RCCL and resolves its symbols (emo_comm_unique_id does both; the id a non-zero rank draws is
-    thrown away) and the ranks agree on the outcome over the gloo control plane; (2) only if ALL ranks could bind: rank 0's id is
-    shipped and the collective ncclCommInitRank + a probe all-reduce run.  Raises the same exception on every rank."""
+    """Three steps, each ending in an agreement over the gloo control plane, so that every rank raises the SAME outcome and none is left
+    blocked in a collective the others never enter: (1) LOCAL — every rank dlopen()s RCCL and resolves its symbols (emo_comm_bind: no
+    unique id is drawn, so no bootstrap listener thread / socket is started on the ranks that do not need one); (2) only if ALL ranks
+    could bind: rank 0 draws the id, it is shipped, and the collective ncclCommInitRank + a probe all-reduce run; (3) the ranks agree on
+    the outcome of (2) — an init error, a probe mismatch or an asynchronous RCCL error on ONE rank is raised on ALL of them."""
     from ._lib import I64, check, lib
-    buf = (ctypes.c_char * 128)()
-    bound = lib.emo_comm_unique_id(buf) == 0
+    bound = lib.emo_comm_bind() == 0
     ok = torch.tensor([1 if bound else 0])
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)                         # control plane (gloo, host memory)
     if int(ok) == 0:
         raise RuntimeError('RCCL could not be bound on every rank (rank %d: %s)' % (rank, 'ok' if bound else lib.emo_last_error().decode()))
     msg = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
-        msg[:] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+        buf = (ctypes.c_char * 128)()
+        if lib.emo_comm_unique_id(buf) == 0:
+            msg[:] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+        # (a failed draw ships zeros: ncclCommInitRank then fails on every rank and step (3) reports it)
     dist.broadcast(msg, src=0)
-    torch.empty(1, device='cuda')                                     # the HIP context of this thread is on the rank's device before RCCL binds it
-    torch.cuda.synchronize()
-    check(lib.emo_comm_init(ctypes.c_char_p(bytes(msg.numpy().tobytes())), rank, world))
-    probe = torch.full((4,), rank + 1, device='cuda', dtype=torch.int64)
-    check(lib.emo_comm_allreduce(probe.data_ptr(), 4, I64, torch.cuda.current_stream().cuda_stream))
-    torch.cuda.synchronize()                                          # an asynchronous RCCL error surfaces here, not as a wrong sum
-    if int(probe[0].item()) != world * (world + 1) // 2:
-        raise RuntimeError('emo_comm self-check failed: all-reduce of rank+1 gave %d for world %d' % (int(probe[0]), world))
+    err = None
+    try:
+        torch.empty(1, device='cuda')                                 # the HIP context of this thread is on the rank's device before RCCL binds it
+        torch.cuda.synchronize()
+        check(lib.emo_comm_init(ctypes.c_char_p(bytes(msg.numpy().tobytes())), rank, world))
+        probe = torch.full((4,), rank + 1, device='cuda', dtype=torch.int64)
+        check(lib.emo_comm_allreduce(probe.data_ptr(), 4, I64, torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()                                      # an asynchronous RCCL error surfaces here, not as a wrong sum
+        if int(probe[0].item()) != world * (world + 1) // 2:
+            raise RuntimeError('emo_comm self-check failed: all-reduce of rank+1 gave %d for world %d' % (int(probe[0]), world))
+    except Exception as e:   # noqa: BLE001 — reported after the agreement below
+        err = e
+    ok = torch.tensor([0 if err is not None else 1])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok) == 0:
+        lib.emo_comm_destroy()
+        raise RuntimeError('RCCL plane failed to initialise (rank %d: %s)' % (rank, err if err is not None else 'ok here, failed on another rank'))
 
 
 def init_distributed(backend=None, strict=None):

@@ -84,38 +84,6 @@ class PerformerDecodeEngine(_EngineBase):
         self.fold = None
         if self.dt == torch.bfloat16 and n_streams <= 32 and os.environ.get('EMO_DECODE_LN_FOLD', '1') != '0':
             self._prepare_folds()
-        # OPT-IN experiment (EMO_DECODE_SPLIT=1), a measured negative result (r03): the state update S += phi(k) (x) v is not needed by anything
-        # later in the SAME token step, so the chain could wait only for the read-out (emo_favor_decode_readout: half the state traffic) with the
-        # update (emo_favor_decode_update) on a second stream joined at the end of the step.  Under hipGraph replay the 12 fork / join pairs cost
-        # far more than the ~3 us per layer they take off the chain: 0.663 ms per token step against 0.382 ms for the single-stream graph, and the
-        # full-size teacher-forcing check did not pass on the forked graph — the default stays the fused emo_favor_decode_step.
-        self.split = os.environ.get('EMO_DECODE_SPLIT', '0') == '1'
-        self._side, self._qkv = None, None
-
-    def _attend(self, l, qkv, D, H):
-        """FAVOR+ recurrent step of layer l on q / k / v = column blocks of qkv [n, 3 D]."""
-        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
-        if not self.split:
-            return ops.favor_decode_step(q, k, v, self.omegas[l], self.S[l], self.z[l], H)
-        main = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.dev)
-        attn = ops.favor_decode_readout(q, k, v, self.omegas[l], self.S[l], self.z[l], H)
-        self._side.wait_stream(main)                         # the update overwrites what the read-out reads: strictly after it
-        with torch.cuda.stream(self._side):
-            ops.favor_decode_update(k, v, self.omegas[l], self.S[l], self.z[l], H)
-        return attn
-
-    def _qkv_buf(self, l, D):
-        if not self.split:
-            return None
-        if self._qkv is None:
-            self._qkv = [torch.empty(self.n, 3 * D, device=self.dev, dtype=self.dt) for _ in range(self.model.n_layer)]
-        return self._qkv[l]
-
-    def _join(self):
-        if self.split and self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
 
     def _prepare_folds(self):
         """gamma-scaled weights, c1[n] = sum_k gamma_k W[n,k] (of the ROUNDED bf16 product, the one the MFMA sees) and bias + W.beta for every
@@ -148,11 +116,11 @@ class PerformerDecodeEngine(_EngineBase):
             pfx = m._layer_prefix(l)
             q = pfx + 'attention.query_projection.'
             if res is None:
-                qkv = ops.gemm(x, ps.w(q + 'weight', 3 * D), bias=ps.f32(q + 'bias', 3 * D), out=self._qkv_buf(l, D))
+                qkv = ops.gemm(x, ps.w(q + 'weight', 3 * D), bias=ps.f32(q + 'bias', 3 * D))
             else:
                 Wg, c1, bb = fd['qkv'][l]
-                qkv = ops.gemm(res[0], Wg, bias=bb, ln_c1=c1, ln_stats_out=self.stats2, out=self._qkv_buf(l, D))
-            attn = self._attend(l, qkv, D, H)
+                qkv = ops.gemm(res[0], Wg, bias=bb, ln_c1=c1, ln_stats_out=self.stats2)
+            attn = ops.favor_decode_step(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], self.omegas[l], self.S[l], self.z[l], H)
             ow, ob = ps.w(pfx + 'attention.out_projection.weight'), ps.f32(pfx + 'attention.out_projection.bias')
             x1 = ops.gemm(attn, ow, bias=ob, residual=x) if res is None else ops.gemm(attn, ow, bias=ob, rln=res)
             Wg, c1, bb = fd['ffn1'][l]
@@ -161,9 +129,7 @@ class PerformerDecodeEngine(_EngineBase):
                           rln=(x1, self.stats1, ps.f32(pfx + 'norm1.weight'), ps.f32(pfx + 'norm1.bias')))
             res = (x2, self.stats2, ps.f32(pfx + 'norm2.weight'), ps.f32(pfx + 'norm2.bias'))
         Wg, c1, bb = fd['out']
-        out = ops.gemm(res[0], Wg, bias=bb, ln_c1=c1, out=logits_out, out_dtype=torch.float32)
-        self._join()
-        return out
+        return ops.gemm(res[0], Wg, bias=bb, ln_c1=c1, out=logits_out, out_dtype=torch.float32)
 
     @torch.no_grad()
     def prefill(self, tok, seg):
@@ -208,17 +174,15 @@ class PerformerDecodeEngine(_EngineBase):
         for l in range(m.n_layer):
             pfx = m._layer_prefix(l)
             q = pfx + 'attention.query_projection.'
-            qkv = ops.gemm(x, ps.w(q + 'weight', 3 * D), bias=ps.f32(q + 'bias', 3 * D), out=self._qkv_buf(l, D))
-            attn = self._attend(l, qkv, D, H)
+            qkv = ops.gemm(x, ps.w(q + 'weight', 3 * D), bias=ps.f32(q + 'bias', 3 * D))
+            attn = ops.favor_decode_step(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], self.omegas[l], self.S[l], self.z[l], H)
             x = self._tail(pfx, x, attn)
         if dev_pos:
             if self.pos_auto:
                 self.pos_dev.add_(1)
         else:
             self.pos += 1
-        out = self._logits(x, logits_out)
-        self._join()
-        return out
+        return self._logits(x, logits_out)
 
 
 class GPT2DecodeEngine(_EngineBase):

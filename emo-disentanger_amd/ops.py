@@ -12,7 +12,7 @@ from ._lib import (ACT_GELU_NEW, ACT_NONE, ACT_RELU, BF16, F32, MUL_BITMASK, MUL
                    dtype_code, lib, ptr, stream)
 
 __all__ = ['gemm', 'colsum', 'embed_fwd', 'embed_bwd', 'layernorm_fwd', 'layernorm_bwd', 'dropout_apply', 'favor_attn_fwd',
-           'favor_attn_bwd', 'favor_decode_step', 'favor_decode_readout', 'favor_decode_update', 'favor_draw_omega', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'relpos_attn_fwd', 'relpos_attn_bwd', 'relpos_attn_decode', 'xent_fwd',
+           'favor_attn_bwd', 'favor_decode_step', 'favor_draw_omega', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'relpos_attn_fwd', 'relpos_attn_bwd', 'relpos_attn_decode', 'xent_fwd',
            'xent_bwd', 'argmax', 'sample_nucleus', 'sample_nucleus_step', 'accuracy_counts', 'sumsq', 'clip_coef', 'adam_step', 'cast', 'add_bias2',
            'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW', 'MUL_BITMASK', 'gemm_bitmask_ok', 'bitmask_rows']
 
@@ -233,22 +233,6 @@ def favor_decode_step(q, k, v, omega, state_S, state_z, H, eps=1e-6):
     check(lib.emo_favor_decode_step(ptr(q), ptr(k), ptr(v), _rows(q), ptr(omega), ptr(state_S), ptr(state_z), ptr(out), HD,
                                     dtype_code(q.dtype), n, H, dh, 2 * omega.shape[1], eps, stream()))
     return out
-
-
-def favor_decode_readout(q, k, v, omega, state_S, state_z, H, eps=1e-6):
-    """The step's output from the OLD state (nothing written back); pair with favor_decode_update AFTER it."""
-    n, HD = q.shape
-    dh = HD // H
-    out = torch.empty(n, HD, device=q.device, dtype=q.dtype)
-    check(lib.emo_favor_decode_readout(ptr(q), ptr(k), ptr(v), _rows(q), ptr(omega), ptr(state_S), ptr(state_z), ptr(out), HD,
-                                       dtype_code(q.dtype), n, H, dh, 2 * omega.shape[1], eps, stream()))
-    return out
-
-
-def favor_decode_update(k, v, omega, state_S, state_z, H):
-    n, HD = k.shape
-    check(lib.emo_favor_decode_update(ptr(k), ptr(v), _rows(k), ptr(omega), ptr(state_S), ptr(state_z), dtype_code(k.dtype), n, H, HD // H,
-                                      2 * omega.shape[1], stream()))
 
 
 def favor_draw_omega(gauss, omega):

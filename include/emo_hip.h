@@ -159,19 +159,6 @@ int emo_favor_decode_step(const void* q, const void* k, const void* v, int64_t l
                           float* state_S, float* state_z, void* out, int64_t ld_out, int dtype,
                           int64_t n_streams, int64_t H, int64_t dh, int64_t n_feat, float eps,
                           emo_stream_t stream);
-/* The same step in two launches (the decode loop of inference.py:250-277 is a chain of ~60 small dependent launches per token, so what is
- * not needed by the NEXT launch is taken off the chain): _readout computes the step's output from the OLD state without writing anything
- * back (out = phi(q)^T (S + phi(k) (x) v) / (phi(q).(z + phi(k)) + eps)); _update applies S += phi(k) (x) v, z += phi(k) and may run on
- * another stream AFTER the read-out of the same token (it overwrites what the read-out reads) and before the next token's.
- * Built for the (d_head, n_feat) pairs of emo_favor_attn_fwd with a 16-B aligned state. */
-int emo_favor_decode_readout(const void* q, const void* k, const void* v, int64_t ld, const float* omega,
-                             const float* state_S, const float* state_z, void* out, int64_t ld_out, int dtype,
-                             int64_t n_streams, int64_t H, int64_t dh, int64_t n_feat, float eps,
-                             emo_stream_t stream);
-int emo_favor_decode_update(const void* k, const void* v, int64_t ld, const float* omega, float* state_S,
-                            float* state_z, int dtype, int64_t n_streams, int64_t H, int64_t dh,
-                            int64_t n_feat, emo_stream_t stream);
-
 /* FAVOR+ omega draw (fast-transformers orthogonal_random_matrix_, called from new_feature_map() on every
  * forward — SURVEY F8): gauss [n_layers, ceil((n_feat/2)/dh), dh, dh] ~ N(0,1) from the caller's RNG ->
  * omega [n_layers, dh, n_feat/2] with orthogonal columns per block scaled by the row norms of the block. */
@@ -310,12 +297,14 @@ int emo_transpose_batch(const int64_t* desc, int n, int64_t total_tiles, emo_str
  * gradient buffer (+ the non-pad token count in its last slot), and one broadcast of parameters / omega at start-up.
  * RCCL is bound with dlopen at the first call (no link-time dependency).  One communicator per process, bound to the
  * CURRENT HIP device at emo_comm_init; all transfers are in place, asynchronous on `stream`.
+ *   emo_comm_bind      : dlopen RCCL and resolve its symbols, nothing else (every rank can test locally that the plane is usable)
  *   emo_comm_unique_id : rank 0 creates the 128-byte rendezvous id; the caller ships it to the other ranks (any side channel)
  *   emo_comm_init      : collective over all ranks (ncclCommInitRank)
  *   emo_comm_allreduce : buf[i] = sum over ranks (dtype EMO_F32 / EMO_BF16 / EMO_I64)
  *   emo_comm_broadcast : buf <- root's buf
  *   emo_comm_world/rank: 0 / -1 before init
  */
+int emo_comm_bind(void);
 int emo_comm_unique_id(void* id128);
 int emo_comm_init(const void* id128, int rank, int world);
 int emo_comm_world(void);

@@ -124,8 +124,22 @@ def causal_linear_attention(q, k, v, omega, eps=1e-6, form='prefix'):
     raise ValueError(form)
 
 
+# ----------------------------------------------------------------------------- dropout with a GIVEN mask
+def _drop(x, p_drop, training, masks=None, site=None):
+    """F.dropout(x, p, training) is x * keep / (1 - p) with keep ~ Bernoulli(1 - p) (torch nn/functional.py dropout).  `masks` (dict site ->
+    MULTIPLIER tensor keep / (1 - p), broadcastable to x) replaces the draw by a given one, so that a run of the HIP path with dropout ON can be
+    compared element for element: tests export the multipliers the product's kernels used (tests/dropmask.py).  Sites: 'emb'; Performer layer l:
+    'L<l>.attn_out', 'L<l>.ffn_hidden', 'L<l>.ffn_out' (upstream TransformerEncoderLayer.forward: the three self.dropout calls); GPT-2 block l:
+    'L<l>.attn_prob' (HF GPT2Attention._attn attn_dropout), 'L<l>.attn_out' (resid_dropout after c_proj), 'L<l>.mlp_out' (GPT2MLP dropout)."""
+    if masks is None:
+        return F.dropout(x, p_drop, training)
+    if not training or p_drop == 0.0:
+        return x
+    return x * masks[site].to(x.dtype).view(x.shape)
+
+
 # ----------------------------------------------------------------------------- prologue / epilogue
-def prologue(sd, x, seg_inp, d_model, p_drop=0.0, training=False, chord_inp=None):
+def prologue(sd, x, seg_inp, d_model, p_drop=0.0, training=False, chord_inp=None, masks=None):
     """music_performer.py:51-62: (E[x] (*proj))*sqrt(d) + (S[seg])*sqrt(d) (+ chord_emb(chord_inp), :56-57) + PE[:T] -> dropout."""
     emb = F.embedding(x, sd['token_emb.emb_lookup.weight'])
     if 'token_emb.emb_proj.weight' in sd:
@@ -140,7 +154,7 @@ def prologue(sd, x, seg_inp, d_model, p_drop=0.0, training=False, chord_inp=None
         emb = emb + F.linear(chord_inp, sd['chord_emb.weight'], sd['chord_emb.bias'])
     T = x.size(1)
     h = emb + sd['pe.pe'][:T].permute(1, 0, 2)
-    return F.dropout(h, p_drop, training)
+    return _drop(h, p_drop, training, masks, 'emb')
 
 
 def logits_head(sd, h, keep_last_only=False):
@@ -155,7 +169,7 @@ def compute_loss(logits, tgt, n_token, reduction='mean'):
 
 
 # ----------------------------------------------------------------------------- Performer
-def performer_layer(sd, p, h, n_head, omega, p_drop=0.0, training=False, form='prefix'):
+def performer_layer(sd, p, h, n_head, omega, p_drop=0.0, training=False, form='prefix', masks=None, site=''):
     """upstream transformers.py TransformerEncoderLayer.forward (post-LN, ReLU) around
     attention_layer.py AttentionLayer.forward."""
     N, L, D = h.shape
@@ -165,22 +179,22 @@ def performer_layer(sd, p, h, n_head, omega, p_drop=0.0, training=False, form='p
     v = F.linear(h, sd[p + 'attention.value_projection.weight'], sd[p + 'attention.value_projection.bias']).view(N, L, n_head, dh)
     a = causal_linear_attention(q, k, v, omega, form=form).reshape(N, L, D)
     a = F.linear(a, sd[p + 'attention.out_projection.weight'], sd[p + 'attention.out_projection.bias'])
-    x = h + F.dropout(a, p_drop, training)
+    x = h + _drop(a, p_drop, training, masks, site + 'attn_out')
     y = x = F.layer_norm(x, (D,), sd[p + 'norm1.weight'], sd[p + 'norm1.bias'], 1e-5)
-    y = F.dropout(F.relu(F.linear(y, sd[p + 'linear1.weight'], sd[p + 'linear1.bias'])), p_drop, training)
-    y = F.dropout(F.linear(y, sd[p + 'linear2.weight'], sd[p + 'linear2.bias']), p_drop, training)
+    y = _drop(F.relu(F.linear(y, sd[p + 'linear1.weight'], sd[p + 'linear1.bias'])), p_drop, training, masks, site + 'ffn_hidden')
+    y = _drop(F.linear(y, sd[p + 'linear2.weight'], sd[p + 'linear2.bias']), p_drop, training, masks, site + 'ffn_out')
     return F.layer_norm(x + y, (D,), sd[p + 'norm2.weight'], sd[p + 'norm2.bias'], 1e-5)
 
 
 def performer_forward(sd, x, seg_inp, n_layer, n_head, d_model, omegas=None, keep_last_only=False,
-                      p_drop=0.0, training=False, form='prefix', chord_inp=None):
+                      p_drop=0.0, training=False, form='prefix', chord_inp=None, masks=None):
     """MusicPerformer.forward (music_performer.py:50-70). `omegas`: list of [dh,F/2]
     (the reference redraws omega every forward — SURVEY F8 — so parity runs inject it)."""
-    h = prologue(sd, x, seg_inp, d_model, p_drop, training, chord_inp)
+    h = prologue(sd, x, seg_inp, d_model, p_drop, training, chord_inp, masks)
     for l in range(n_layer):
         p = 'transformer_decoder.decoder_layers.%d.' % l
         om = omegas[l] if omegas is not None else sd[p + 'attention.inner_attention.feature_map.omega']
-        h = performer_layer(sd, p, h, n_head, om, p_drop, training, form)
+        h = performer_layer(sd, p, h, n_head, om, p_drop, training, form, masks, 'L%d.' % l)
     return logits_head(sd, h, keep_last_only)
 
 
@@ -189,7 +203,7 @@ def gelu_new(x):
     return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
 
 
-def gpt2_block(sd, p, h, n_head, p_drop=0.0, training=False):
+def gpt2_block(sd, p, h, n_head, p_drop=0.0, training=False, masks=None, site=''):
     """HF 4.28 GPT2Block.forward (pre-LN) with GPT2Attention._attn eager math."""
     N, L, D = h.shape
     dh = D // n_head
@@ -203,22 +217,22 @@ def gpt2_block(sd, p, h, n_head, p_drop=0.0, training=False):
     w = w / torch.full([], dh ** 0.5, dtype=w.dtype)
     causal = torch.tril(torch.ones(L, L, dtype=torch.bool))[None, None]
     w = torch.where(causal, w, torch.full([], torch.finfo(w.dtype).min, dtype=w.dtype))
-    w = F.dropout(F.softmax(w, dim=-1), p_drop, training)
+    w = _drop(F.softmax(w, dim=-1), p_drop, training, masks, site + 'attn_prob')
     a = torch.matmul(w, v).permute(0, 2, 1, 3).contiguous().view(N, L, D)
     a = torch.addmm(sd[p + 'attn.c_proj.bias'], a.view(-1, D), sd[p + 'attn.c_proj.weight']).view(N, L, D)
-    h = h + F.dropout(a, p_drop, training)
+    h = h + _drop(a, p_drop, training, masks, site + 'attn_out')
     m = F.layer_norm(h, (D,), sd[p + 'ln_2.weight'], sd[p + 'ln_2.bias'], 1e-5)
     f = torch.addmm(sd[p + 'mlp.c_fc.bias'], m.view(-1, D), sd[p + 'mlp.c_fc.weight'])
     f = gelu_new(f)
     f = torch.addmm(sd[p + 'mlp.c_proj.bias'], f, sd[p + 'mlp.c_proj.weight']).view(N, L, D)
-    return h + F.dropout(f, p_drop, training)
+    return h + _drop(f, p_drop, training, masks, site + 'mlp_out')
 
 
-def gpt2_forward(sd, x, seg_inp, n_layer, n_head, d_model, keep_last_only=False, p_drop=0.0, training=False, chord_inp=None):
+def gpt2_forward(sd, x, seg_inp, n_layer, n_head, d_model, keep_last_only=False, p_drop=0.0, training=False, chord_inp=None, masks=None):
     """MusicGPT2.forward (music_gpt2.py:70-92): no final ln_f."""
-    h = prologue(sd, x, seg_inp, d_model, p_drop, training, chord_inp)
+    h = prologue(sd, x, seg_inp, d_model, p_drop, training, chord_inp, masks)
     for i in range(n_layer):
-        h = gpt2_block(sd, 'transformer_decoder.%d.' % i, h, n_head, p_drop, training)
+        h = gpt2_block(sd, 'transformer_decoder.%d.' % i, h, n_head, p_drop, training, masks, 'L%d.' % i)
     return logits_head(sd, h, keep_last_only)
 
 

@@ -606,27 +606,6 @@ def test_favor_decode_step_matches_prefill(dt):
     _close(o, full.view(B, T, HD)[:, T - 1], dt, mult=3)
 
 
-@pytest.mark.parametrize('dt', DT)
-def test_favor_decode_readout_plus_update_equals_step(dt):
-    """emo_favor_decode_readout (output from the old state, nothing written) followed by emo_favor_decode_update == emo_favor_decode_step."""
-    ops = _ops()
-    from oracle.weights import orthogonal_omega
-    n, H, dh, nf = 5, 8, 64, 128
-    om = orthogonal_omega(dh, nf, np.random.default_rng(6)).cuda()
-    HD = H * dh
-    S0 = torch.rand(n, H, nf, dh, device='cuda') * 3
-    z0 = torch.rand(n, H, nf, device='cuda') * 5
-    qkv = _r(n, 3 * HD, seed=31, dt=dt, scale=0.8).cuda()
-    q, k, v = qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:]
-    S1, z1 = S0.clone(), z0.clone()
-    ref = ops.favor_decode_step(q, k, v, om, S1, z1, H)
-    S2, z2 = S0.clone(), z0.clone()
-    out = ops.favor_decode_readout(q, k, v, om, S2, z2, H)
-    assert torch.equal(S2, S0) and torch.equal(z2, z0)          # the read-out writes nothing back
-    ops.favor_decode_update(k, v, om, S2, z2, H)
-    assert torch.equal(out, ref) and torch.equal(S2, S1) and torch.equal(z2, z1)
-
-
 # ------------------------------------------------------------------------------------------- softmax attention
 @pytest.mark.parametrize('dt', DT)
 @pytest.mark.parametrize('B,T,H,dh', [(2, 150, 2, 64), (1, 70, 3, 32), (2, 33, 2, 16), (1, 256, 1, 64)])
