@@ -155,7 +155,7 @@ def _step_and_compare(kind, c, dtype, b, n_fwd=1):
     # the draw matters: the same oracle WITHOUT dropout is far away
     nloss, nlogits, _ = model_ref.loss_and_grads(kind, sd, b, c['V'], c['L'], c['H'], c['d'], **kw)
     assert float((nlogits - rlogits).abs().max()) > 0.05
-    return m, float(loss), logits.detach().cpu(), float(rloss), rlogits, rgrads
+    return m, float(loss.detach()), logits.detach().cpu(), float(rloss), rlogits, rgrads
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
@@ -185,7 +185,7 @@ def test_gpt2_dropout_on_matches_oracle_with_exported_masks(ci, dtype):
     """All four GPT-2 dropout sites, incl. the attention probabilities (case 2 = d512 / d_head 64 / T % 128 == 0: the 32 x 32 kernels in bf16)."""
     from oracle.weights import synthetic_batch
     c = GPT2_CASES[ci]
-    b = synthetic_batch(c['V'], c['B'], c['T'], seed=78, realistic_targets=True)
+    b = synthetic_batch(c['V'], c['B'], c['T'], seed=78, realistic_targets=c['T'] >= 64)      # (T = 16: one segment run would pad every target)
     m, loss, logits, rloss, rlogits, rgrads = _step_and_compare('gpt2', c, dtype, b, n_fwd=2)
     lt, gt = (1e-4, 2e-3) if dtype == 'fp32' else (3e-2, 6e-2)
     assert abs(loss - rloss) <= lt
