@@ -1,0 +1,428 @@
+// One-launch Performer decode step (BASELINE configs[3]: 32 streams x 2048 tokens): embedding -> 12 post-LN FAVOR+ layers -> logits for every
+// stream in ONE persistent kernel.  Replaces the per-token chain of ~62 dependent launches of inference.py (reference loop:
+// stage2_accompaniment/inference.py:250-277 -> MusicPerformer.forward with keep_last_only, music_performer.py:50-70), whose every launch sat
+// on the ~5-6 us launch floor with < 2 MB of work (r03: 0.383 ms per token step = 0.09 of the HBM roofline).
+//
+// Structure (DESIGN.md "persistent decode"): 256 workgroups = 8 GROUPS x 32 members; group g = blockIdx % 8 — the XCD the dispatcher puts the
+// block on, so a group's traffic normally stays inside one XCD, but NOTHING depends on that placement — owns streams 4g .. 4g+3 for the whole
+// token step and never talks to another group.  Inside a group every GEMM of the layer is split by OUTPUT COLUMN over the 32 members (each
+// member streams 1/32 of every weight matrix: 197 KB per layer, pre-packed on the host in MFMA fragment order so that a wave's load
+// instruction is one contiguous KB that goes straight into the B-operand registers — no LDS staging, each weight byte is used once), the 4
+// streams are rows 0-3 of a 16-row MFMA A operand, and the five dependent products of a layer are separated by five all-gather EDGES:
+//   P1 q/k/v columns of head h (member = (h, j): dims 16j..16j+15 of q_h, k_h, v_h)        -> E2 (gathered by the 4 members of head h)
+//   P2 FAVOR+ recurrent step of (head h, stream j): S += phi(k) (x) v, out = phi(q)^T S / ..  -> E3
+//   P3 out-projection + bias + residual (pre-LN row)                                        -> E4
+//   P4 LayerNorm1 (every member normalises the gathered rows itself) + FFN1 + ReLU         -> E5
+//   P5 FFN2 + bias + residual (pre-LN row)                                                  -> E1 (next layer's P1 applies LayerNorm2)
+// An edge is a buffer of 8-byte GRANULES {tag = epoch, value = 2 bf16} written by single agent-scope (sc1) stores and polled with agent-scope
+// loads: the data is the flag, no fences, correct for any workgroup -> XCD placement (MI355X guide, Guideline 16 form R2).  Epochs count
+// launches (a per-group counter the group's member 0 bumps when it is done) x phases, so nothing is zeroed per launch and hipGraph replay
+// works.  A buffer is rewritten one layer later; between two uses lies at least one all-to-all edge, so every reader of the old contents has
+// finished.  Every poll is bounded: a group that cannot make progress (a member not resident) writes an error code and leaves.
+//
+// Arithmetic mirrors the launch path's bf16 mode (emo_gemm skinny kernel, favor_decode_fast_kernel, layernorm_fwd_bf16_d512_kernel): bf16
+// activations between products, fp32 accumulation, fp32 FAVOR+ state, LayerNorm statistics in fp32 from the bf16 row.
+#include "emo_common.h"
+
+namespace {
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) unsigned long long gu64;      // every word another workgroup reads: GLOBAL address space, never flat
+constexpr int PD_D = 512, PD_H = 8, PD_DH = 64, PD_MF = 64, PD_F = 128, PD_FF = 2048;
+constexpr int PD_GS = 4, PD_GM = 32, PD_NG = 8, PD_NT = 512, PD_NW = 8;
+constexpr int PD_XS = PD_D + 8, PD_FS = PD_FF + 8;              // LDS row strides (bf16 elements): +16 B shifts the rows' banks
+constexpr int OFF_CNT = 0, OFF_E1 = 8, OFF_E2 = OFF_E1 + PD_GS * PD_D / 2, OFF_E3 = OFF_E2 + PD_H * PD_GS * 96, OFF_E4 = OFF_E3 + PD_GS * PD_D / 2,
+              OFF_E5 = OFF_E4 + PD_GS * PD_D / 2, PD_GSTRIDE = OFF_E5 + PD_GS * PD_FF / 2;
+constexpr int PD_WS_WORDS = PD_NG * PD_GSTRIDE + 8;             // last 8 words: [0] = error code
+constexpr int PD_MAX_LAYERS = 15;                               // epoch = launch * 128 + layer * 8 + phase
+constexpr int PD_SERR_OFF = (3 * PD_GS * PD_XS + PD_GS * PD_FS) * 2 + (PD_NW * 4 * 64 + 3 * PD_DH + 2 * PD_F + 8 + PD_NW * PD_DH) * 4;   // = s_misc
+constexpr long long PD_TIMEOUT = 5000000;                       // wall_clock64 ticks (100 MHz): 50 ms for the whole launch
+
+struct PdLayer {            // one row of the caller's device table: 16 pointers
+    const bf16_t* wqkv; const float* bqkv; const bf16_t* wo; const float* bo; const float* g1; const float* be1; const bf16_t* w1; const float* b1;
+    const bf16_t* w2; const float* b2; const float* g2; const float* be2; const float* omega; float* S; float* z; void* pad;
+};
+struct PdArgs {
+    const PdLayer* layers; int n_layers;
+    const int64_t* tok; const int64_t* seg; const float* E; const float* Sg; const float* pe; float emb_scale; int64_t pos0; const int64_t* pos_ids;
+    const bf16_t* wout; const float* bout; int n_token; float* logits; int n_streams; u64* sync; float eps, ln_eps;
+};
+struct PdCtx { int tid, lane, wave; long long t0; gu64* err; };
+
+extern __shared__ __attribute__((aligned(16))) char pd_smem[];     // (file scope: device functions reach the error flag as an LDS address,
+#define PD_SERR (*(int*)(pd_smem + PD_SERR_OFF))                        //  not through a generic pointer kept in a struct)
+
+#define PD_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define PD_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+// wave-uniform: true = give up (the launch is over its time budget, or another workgroup already reported a failure)
+__device__ __forceinline__ bool pd_spin_fail(unsigned& spins, const PdCtx& c, unsigned code) {
+    ++spins;
+    if ((spins & 63) == 0) {
+        bool bad = (long long)wall_clock64() - c.t0 > PD_TIMEOUT;
+        if (!bad && (spins & 1023) == 0) bad = PD_LOAD(c.err) != 0;
+        if (bad) {
+            if (c.lane == 0) {
+                if (PD_LOAD(c.err) == 0) PD_STORE(c.err, (u64)code);       // (first reporter wins, approximately: the code is a diagnostic)
+                PD_SERR = 1;
+            }
+            return true;
+        }
+    }
+    __builtin_amdgcn_s_sleep(1);
+    return false;
+}
+
+// All-gather of GS rows of W bf16 values (W / 2 granules per row) into LDS rows of `stride` elements.  Every thread owns NP pairs of granules.
+template <int W>
+__device__ __forceinline__ void pd_gather_rows(const gu64* buf, unsigned ep, bf16_t* dst, int stride, const PdCtx& c, unsigned code) {
+    constexpr int NP = PD_GS * W / 4 / PD_NT;
+    static_assert(NP >= 1, "row too short");
+    u64 g[NP][2];
+    unsigned spins = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int p = c.tid + i * PD_NT;
+            g[i][0] = PD_LOAD(buf + 2 * p);
+            g[i][1] = PD_LOAD(buf + 2 * p + 1);
+            ok = ok && (unsigned)(g[i][0] >> 32) == ep && (unsigned)(g[i][1] >> 32) == ep;
+        }
+        if (__all(ok)) break;
+        if (pd_spin_fail(spins, c, code)) return;
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int p = c.tid + i * PD_NT, s = p / (W / 4), c4 = p % (W / 4);
+        *(u64*)(dst + s * stride + 4 * c4) = (g[i][0] & 0xffffffffull) | (g[i][1] << 32);
+    }
+}
+
+// The wave's share of a member's packed weights: T column tiles x KPW k-steps, one KB (64 lanes x 8 bf16) per fragment, straight into registers.
+template <int T, int KPW>
+__device__ __forceinline__ void pd_load_w(bf16x8 (&w)[T][KPW], const bf16_t* member_base, const PdCtx& c) {
+    const bf16_t* p = member_base + (size_t)c.wave * (T * KPW * 512) + c.lane * 8;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KPW; ++ks) w[t][ks] = __builtin_nontemporal_load((const bf16x8*)(p + (t * KPW + ks) * 512));
+}
+
+// part[wave][t][stream][col] = x[stream, k-slice of the wave] . W[col, k-slice]   (x rows = rows 0..3 of the MFMA A operand, the rest zero)
+template <int T, int KPW>
+__device__ __forceinline__ void pd_gemv(const bf16x8 (&w)[T][KPW], const bf16_t* xs, int stride, float* part, const PdCtx& c) {
+    f32x4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int r = c.lane & 15, kg = c.lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < KPW; ++ks) {
+        bf16x8 a;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = (bf16_t)0.f;
+        if (r < PD_GS) a = *(const bf16x8*)(xs + r * stride + (c.wave * KPW + ks) * 32 + kg * 8);
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w[t][ks], acc[t], 0, 0, 0);
+    }
+    if (c.lane < 16) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[((c.wave * T + t) * 4 + i) * 16 + c.lane] = acc[t][i];
+    }
+}
+template <int T>
+__device__ __forceinline__ float pd_part_sum(const float* part, int t, int s, int col) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < PD_NW; ++w) v += part[((w * T + t) * 4 + s) * 16 + col];
+    return v;
+}
+// Two neighbouring columns (even lane + the next lane) -> one granule, stored by the even lane.  Executed by whole waves.
+__device__ __forceinline__ void pd_publish_pair(gu64* buf, int granule, unsigned ep, float v, int col) {
+    const bf16_t b = (bf16_t)v;
+    const unsigned mine = (unsigned)__builtin_bit_cast(unsigned short, b);
+    const unsigned next = (unsigned)__shfl_down((int)mine, 1, 64);
+    if ((col & 1) == 0) PD_STORE(buf + granule, ((u64)ep << 32) | (u64)(mine | (next << 16)));
+}
+__device__ __forceinline__ void pd_ln_load(float (&g)[8], float (&b)[8], const float* gamma, const float* beta, const PdCtx& c) {
+    if (c.wave < PD_GS) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { g[i] = gamma[c.lane * 8 + i]; b[i] = beta[c.lane * 8 + i]; }
+    }
+}
+// LayerNorm of LDS row `wave` (waves 0..3), in place, the arithmetic of layernorm_fwd_bf16_d512_kernel
+__device__ __forceinline__ void pd_ln_rows(bf16_t* xs, const float (&g)[8], const float (&b)[8], float eps, const PdCtx& c) {
+    if (c.wave < PD_GS) {
+        bf16_t* row = xs + c.wave * PD_XS + c.lane * 8;
+        const bf16x8 a = *(const bf16x8*)row;
+        float v[8], s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] = (float)a[i]; s += v[i]; }
+        const float mu = wave_sum(s) * (1.f / 512.f);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = v[i] - mu; q += d * d; }
+        const float rs = rsqrtf(wave_sum(q) * (1.f / 512.f) + eps);
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (bf16_t)((v[i] - mu) * rs * g[i] + b[i]);
+        *(bf16x8*)row = o;
+    }
+}
+
+#define PD_SYNC_OR_LEAVE()          \
+    do {                            \
+        __syncthreads();            \
+        if (PD_SERR) return;        \
+    } while (0)
+
+__global__ __launch_bounds__(PD_NT, 2) void pd_step_kernel(PdArgs a) {
+    bf16_t* xin = (bf16_t*)pd_smem;                       // layer input (post-LN2 / embedding), kept for the out-projection's residual
+    bf16_t* xa = xin + PD_GS * PD_XS;                  // attention output rows
+    bf16_t* x1 = xa + PD_GS * PD_XS;                   // post-LN1 rows, kept for the FFN2 residual
+    bf16_t* fh = x1 + PD_GS * PD_XS;                   // FFN hidden rows
+    float* part = (float*)(fh + PD_GS * PD_FS);        // [8 waves][<= 4 tiles][4 streams][16 columns]
+    float* xq = part + PD_NW * 4 * 64;                 // attention scratch
+    float* xk = xq + PD_DH;
+    float* xv = xk + PD_DH;
+    float* fq = xv + PD_DH;
+    float* fk = fq + PD_F;
+    float* dpart = fk + PD_F;                          // [8]
+    float* num = dpart + 8;                            // [8 waves][64]
+    int* s_misc = (int*)(num + PD_NW * PD_DH);         // [0] error flag, [1] launch counter
+    float* oml = (float*)(s_misc + 4);                 // omega of the layer [64][64]
+
+    PdCtx c;
+    c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6);
+    c.t0 = (long long)wall_clock64();
+    c.err = (gu64*)a.sync + (size_t)PD_NG * PD_GSTRIDE;
+    const int g = blockIdx.x % PD_NG, m = blockIdx.x / PD_NG;
+    if (g * PD_GS >= a.n_streams) return;
+    gu64* gs = (gu64*)a.sync + (size_t)g * PD_GSTRIDE;
+    if (c.tid == 0) { s_misc[0] = 0; s_misc[1] = (int)(unsigned)PD_LOAD(gs + OFF_CNT); }
+    __syncthreads();
+    const unsigned lc = (unsigned)s_misc[1], ep0 = lc * 128u;
+    const int hm = m >> 2, jm = m & 3;                                // P1: head / 16-dim slice; P2: head / stream
+
+    // ---------------------------------------------------------------- embedding (every member builds its group's 4 rows itself)
+    {
+        const int s = c.tid >> 7, c4 = (c.tid & 127) * 4;
+        const int64_t stream = (int64_t)g * PD_GS + s;
+        const int64_t tk = a.tok[stream], sg = a.seg ? a.seg[stream] : 0, pos = a.pos0 + (a.pos_ids ? a.pos_ids[stream] : 0);
+        const f32x4 e = *(const f32x4*)(a.E + tk * PD_D + c4);
+        f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+        if (a.seg) sv = *(const f32x4*)(a.Sg + sg * PD_D + c4);
+        const f32x4 p = *(const f32x4*)(a.pe + pos * PD_D + c4);
+        bf16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = e[i] * a.emb_scale;                             // reference order: emb.mul_(scale); emb += seg.mul_(scale); + pe
+            v += sv[i] * a.emb_scale;
+            v += p[i];
+            o[i] = (bf16_t)v;
+        }
+        *(bf16x4*)(xin + s * PD_XS + c4) = o;
+    }
+    __syncthreads();
+
+    float lg[8], lb[8];
+    for (int l = 0; l < a.n_layers; ++l) {
+        const PdLayer L = a.layers[l];
+        const unsigned ep = ep0 + (unsigned)l * 8u;
+        // ============================================================ P1: q / k / v columns of (head hm, dims 16 jm ..)
+        {
+            bf16x8 w[3][2];
+            pd_load_w<3, 2>(w, L.wqkv + (size_t)m * (PD_NW * 3 * 2 * 512), c);
+            if (l > 0) {
+                pd_ln_load(lg, lb, a.layers[l - 1].g2, a.layers[l - 1].be2, c);
+                pd_gather_rows<PD_D>(gs + OFF_E1, ep - 8u + 5u, xin, PD_XS, c, 0x100u + l);
+                PD_SYNC_OR_LEAVE();
+                pd_ln_rows(xin, lg, lb, a.ln_eps, c);
+                __syncthreads();
+            }
+            pd_gemv<3, 2>(w, xin, PD_XS, part, c);
+            __syncthreads();
+            if (c.tid < 192) {
+                const int t = c.tid >> 6, s = (c.tid >> 4) & 3, col = c.tid & 15;
+                const float v = pd_part_sum<3>(part, t, s, col) + L.bqkv[t * PD_D + hm * PD_DH + jm * 16 + col];
+                pd_publish_pair(gs + OFF_E2, ((hm * PD_GS + s) * 3 + t) * 32 + ((jm * 16 + col) >> 1), ep + 1u, v, col);
+            }
+        }
+        // ============================================================ P2: FAVOR+ recurrent step of (head hm, stream jm)
+        {
+            const int64_t stream = (int64_t)g * PD_GS + jm, sh = stream * PD_H + hm;
+            float* Sb = L.S + sh * (PD_F * PD_DH);
+            const int d4 = (c.tid & 15) * 4, fg = c.tid >> 4;            // 16 threads per state row, 32 rows per pass, 4 passes
+            f32x4 st[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st[i] = *(const f32x4*)(Sb + (fg + 32 * i) * PD_DH + d4);
+            // omega [64 d][64 m] fp32 = 16 KB goes to LDS through 8 registers per thread (kept per thread as a 64-register column, the kernel spilled)
+            const f32x4 om0 = *(const f32x4*)(L.omega + c.tid * 8), om1 = *(const f32x4*)(L.omega + c.tid * 8 + 4);
+            float zold = 0.f;
+            if (c.tid < PD_F) zold = L.z[sh * PD_F + c.tid];
+            if (c.wave == 0) {                                            // 96 granules = 48 pairs: q_h | k_h | v_h of the stream
+                const gu64* buf = gs + OFF_E2 + (hm * PD_GS + jm) * 96;
+                u64 g0 = 0, g1 = 0;
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+                    if (c.lane < 48) {
+                        g0 = PD_LOAD(buf + 2 * c.lane);
+                        g1 = PD_LOAD(buf + 2 * c.lane + 1);
+                        ok = (unsigned)(g0 >> 32) == ep + 1u && (unsigned)(g1 >> 32) == ep + 1u;
+                    }
+                    if (__all(ok)) break;
+                    if (pd_spin_fail(spins, c, 0x200u + l)) break;
+                }
+                if (c.lane < 48) {
+                    float* dst = xq + (c.lane >> 4) * PD_DH + (c.lane & 15) * 4;      // xq, xk, xv are contiguous
+                    const unsigned lo = (unsigned)g0, hi = (unsigned)g1;
+                    dst[0] = __builtin_bit_cast(float, lo << 16);
+                    dst[1] = __builtin_bit_cast(float, lo & 0xffff0000u);
+                    dst[2] = __builtin_bit_cast(float, hi << 16);
+                    dst[3] = __builtin_bit_cast(float, hi & 0xffff0000u);
+                }
+            }
+            *(f32x4*)(oml + c.tid * 8) = om0;
+            *(f32x4*)(oml + c.tid * 8 + 4) = om1;
+            PD_SYNC_OR_LEAVE();
+            const float cs = rsqrtf(sqrtf((float)PD_DH)), half_ln_f = 0.5f * logf((float)PD_F);
+            float dn = 0.f;
+            if (c.tid < PD_F) {                                           // the arithmetic of favor_decode_fast_kernel
+                const float sgn = c.tid < PD_MF ? 1.f : -1.f;
+                float uq = 0.f, uk = 0.f, nq = 0.f, nk = 0.f;
+#pragma unroll
+                for (int d = 0; d < PD_DH; ++d) {
+                    const float wv = oml[d * PD_MF + (c.tid & (PD_MF - 1))];
+                    uq += xq[d] * wv; uk += xk[d] * wv;
+                    nq += xq[d] * xq[d]; nk += xk[d] * xk[d];
+                }
+                const float pq = __expf(sgn * cs * uq - (0.5f * cs * cs * nq + half_ln_f));
+                const float pk = __expf(sgn * cs * uk - (0.5f * cs * cs * nk + half_ln_f));
+                fq[c.tid] = pq;
+                fk[c.tid] = pk;
+                const float z = zold + pk;
+                L.z[sh * PD_F + c.tid] = z;
+                dn = pq * z;
+            }
+            dn = wave_sum(dn);
+            if (c.lane == 0) dpart[c.wave] = dn;
+            __syncthreads();
+            const f32x4 vd = {xv[d4], xv[d4 + 1], xv[d4 + 2], xv[d4 + 3]};
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = fg + 32 * i;
+                const f32x4 sv = st[i] + fk[f] * vd;
+                *(f32x4*)(Sb + f * PD_DH + d4) = sv;
+                acc += fq[f] * sv;
+            }
+            // the wave's 4 rows per pass sit in lanes l, l^16, l^32, l^48
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = rows4_sum(acc[i]);
+            if (c.lane < 16) *(f32x4*)(num + c.wave * PD_DH + d4) = acc;
+            __syncthreads();
+            if (c.tid < PD_DH) {
+                float o = 0.f;
+#pragma unroll
+                for (int w = 0; w < PD_NW; ++w) o += num[w * PD_DH + c.tid];
+                o = o / (dpart[0] + dpart[1] + a.eps);                             // (waves 2..7 hold no features)
+                pd_publish_pair(gs + OFF_E3, jm * (PD_D / 2) + ((hm * PD_DH + c.tid) >> 1), ep + 2u, o, c.tid);
+            }
+        }
+        // ============================================================ P3: out-projection columns 16 m .. (+ bias + residual)
+        {
+            bf16x8 w[1][2];
+            pd_load_w<1, 2>(w, L.wo + (size_t)m * (PD_NW * 1 * 2 * 512), c);
+            pd_gather_rows<PD_D>(gs + OFF_E3, ep + 2u, xa, PD_XS, c, 0x300u + l);
+            PD_SYNC_OR_LEAVE();
+            pd_gemv<1, 2>(w, xa, PD_XS, part, c);
+            __syncthreads();
+            if (c.tid < 64) {
+                const int s = c.tid >> 4, col = c.tid & 15, gc = m * 16 + col;
+                const float v = pd_part_sum<1>(part, 0, s, col) + L.bo[gc] + (float)xin[s * PD_XS + gc];
+                pd_publish_pair(gs + OFF_E4, s * (PD_D / 2) + (gc >> 1), ep + 3u, v, col);
+            }
+        }
+        // ============================================================ P4: LayerNorm1 + FFN1 columns 64 m .. + ReLU
+        {
+            bf16x8 w[4][2];
+            pd_load_w<4, 2>(w, L.w1 + (size_t)m * (PD_NW * 4 * 2 * 512), c);
+            pd_ln_load(lg, lb, L.g1, L.be1, c);
+            pd_gather_rows<PD_D>(gs + OFF_E4, ep + 3u, x1, PD_XS, c, 0x400u + l);
+            PD_SYNC_OR_LEAVE();
+            pd_ln_rows(x1, lg, lb, a.ln_eps, c);
+            __syncthreads();
+            pd_gemv<4, 2>(w, x1, PD_XS, part, c);
+            __syncthreads();
+            if (c.tid < 256) {
+                const int t = c.tid >> 6, s = (c.tid >> 4) & 3, col = c.tid & 15, gc = m * 64 + t * 16 + col;
+                const float v = fmaxf(pd_part_sum<4>(part, t, s, col) + L.b1[gc], 0.f);
+                pd_publish_pair(gs + OFF_E5, s * (PD_FF / 2) + (gc >> 1), ep + 4u, v, col);
+            }
+        }
+        // ============================================================ P5: FFN2 columns 16 m .. (+ bias + residual)
+        {
+            bf16x8 w[1][8];
+            pd_load_w<1, 8>(w, L.w2 + (size_t)m * (PD_NW * 1 * 8 * 512), c);
+            pd_gather_rows<PD_FF>(gs + OFF_E5, ep + 4u, fh, PD_FS, c, 0x500u + l);
+            PD_SYNC_OR_LEAVE();
+            pd_gemv<1, 8>(w, fh, PD_FS, part, c);
+            __syncthreads();
+            if (c.tid < 64) {
+                const int s = c.tid >> 4, col = c.tid & 15, gc = m * 16 + col;
+                const float v = pd_part_sum<1>(part, 0, s, col) + L.b2[gc] + (float)x1[s * PD_XS + gc];
+                pd_publish_pair(gs + OFF_E1, s * (PD_D / 2) + (gc >> 1), ep + 5u, v, col);
+            }
+        }
+    }
+    // ---------------------------------------------------------------- LayerNorm2 of the last layer + logits tile m (21 tiles of 16 columns)
+    if (m < (a.n_token + 15) / 16) {                                      // (m is uniform over the workgroup; the other members are done)
+        bf16x8 w[1][2];
+        pd_load_w<1, 2>(w, a.wout + (size_t)m * (PD_NW * 1 * 2 * 512), c);
+        pd_ln_load(lg, lb, a.layers[a.n_layers - 1].g2, a.layers[a.n_layers - 1].be2, c);
+        pd_gather_rows<PD_D>(gs + OFF_E1, ep0 + (unsigned)(a.n_layers - 1) * 8u + 5u, xin, PD_XS, c, 0x600u);
+        PD_SYNC_OR_LEAVE();
+        pd_ln_rows(xin, lg, lb, a.ln_eps, c);
+        __syncthreads();
+        pd_gemv<1, 2>(w, xin, PD_XS, part, c);
+        __syncthreads();
+        if (c.tid < 64) {
+            const int s = c.tid >> 4, col = c.tid & 15, gc = m * 16 + col;
+            if (gc < a.n_token) a.logits[((int64_t)g * PD_GS + s) * a.n_token + gc] = pd_part_sum<1>(part, 0, s, col) + a.bout[gc];
+        }
+        // member 0 gathered the last edge from EVERY member of the group, so all of them have long read the counter
+        if (m == 0 && c.tid == 0) PD_STORE(gs + OFF_CNT, (u64)(lc + 1u));
+    }
+}
+}  // namespace
+
+extern "C" int64_t emo_performer_decode_step_workspace_bytes(void) { return (int64_t)PD_WS_WORDS * 8; }
+
+extern "C" int emo_performer_decode_step(const void* layer_table, int64_t n_layers, const int64_t* tok, const int64_t* seg, const float* E, const float* Sg,
+                                         const float* pe, float emb_scale, int64_t pos0, const int64_t* pos_ids, const void* wout_packed,
+                                         const float* bout, int64_t n_token, float* logits, int64_t n_streams, int64_t d_model, int64_t n_head,
+                                         int64_t n_feat, int64_t d_ff, void* sync_ws, int64_t sync_ws_bytes, float eps, float ln_eps,
+                                         emo_stream_t stream) {
+    EMO_CHECK(layer_table && tok && E && pe && wout_packed && bout && logits && sync_ws, "emo_performer_decode_step: null pointer");
+    EMO_CHECK(d_model == PD_D && n_head == PD_H && n_feat == PD_F && d_ff == PD_FF,
+              "emo_performer_decode_step: built for d_model 512 / 8 heads / 128 features / d_ff 2048 (got %lld / %lld / %lld / %lld)", (long long)d_model,
+              (long long)n_head, (long long)n_feat, (long long)d_ff);
+    EMO_CHECK(n_layers >= 1 && n_layers <= PD_MAX_LAYERS, "emo_performer_decode_step: 1 <= n_layers <= %d", PD_MAX_LAYERS);
+    EMO_CHECK(n_streams >= PD_GS && n_streams <= PD_GS * PD_NG && n_streams % PD_GS == 0, "emo_performer_decode_step: n_streams must be a multiple of 4, <= 32");
+    EMO_CHECK(n_token >= 1 && n_token <= 16 * PD_GM, "emo_performer_decode_step: n_token <= 512");
+    EMO_CHECK(!(seg && !Sg), "emo_performer_decode_step: seg ids without a segment table");
+    EMO_CHECK(sync_ws_bytes >= (int64_t)PD_WS_WORDS * 8 && ((uintptr_t)sync_ws & 15) == 0, "emo_performer_decode_step: workspace too small / unaligned");
+    PdArgs a;
+    a.layers = (const PdLayer*)layer_table; a.n_layers = (int)n_layers;
+    a.tok = tok; a.seg = seg; a.E = E; a.Sg = Sg; a.pe = pe; a.emb_scale = emb_scale; a.pos0 = pos0; a.pos_ids = pos_ids;
+    a.wout = (const bf16_t*)wout_packed; a.bout = bout; a.n_token = (int)n_token; a.logits = logits; a.n_streams = (int)n_streams;
+    a.sync = (u64*)sync_ws; a.eps = eps; a.ln_eps = ln_eps;
+    const size_t lds = 96 * 1024;                                         // > half of the CU's LDS: one workgroup per CU
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)pd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(pd_step_kernel, dim3(PD_NG * PD_GM), dim3(PD_NT), lds, (hipStream_t)stream, a);
+    EMO_LAUNCH_CHECK();
+    return EMO_OK;
+}

@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from . import engine, ops
+from ._lib import EmoError
 
 max_dec_inp_len = 2048
 
@@ -84,6 +85,90 @@ class PerformerDecodeEngine(_EngineBase):
         self.fold = None
         if self.dt == torch.bfloat16 and n_streams <= 32 and os.environ.get('EMO_DECODE_LN_FOLD', '1') != '0':
             self._prepare_folds()
+        # the whole token step as ONE persistent launch (emo_performer_decode_step) for the benchmark architecture: bf16, d_model 512, 8 heads,
+        # 128 features, d_ff 2048, a multiple of 4 streams up to 32.  EMO_DECODE_PERSISTENT=0 keeps the chain of launches (tests compare the two).
+        self.persist = None
+        ff = model.transformer_decoder.decoder_layers[0].linear1.weight.shape[0]
+        nf = 2 * self.omegas[0].shape[1]
+        if (self.dt == torch.bfloat16 and n_streams % 4 == 0 and 4 <= n_streams <= 32 and model.d_model == 512 and model.n_head == 8 and nf == 128
+                and ff == 2048 and model.n_layer <= 15 and model.n_token <= 512 and os.environ.get('EMO_DECODE_PERSISTENT', '1') != '0'):
+            self._prepare_persist()
+
+    # ------------------------------------------------------------------------------------------ one-launch step
+    @staticmethod
+    def _pack_fragments(W, tile_idx, kpw):
+        """bf16 nn.Linear weight [N, K] -> [members][8 waves][tiles per member][kpw][64 lanes x 8]: the MFMA B fragment (16 output columns x 32 k)
+        of column tile t and k step ks holds, in lane l, W[16 t + l % 16][32 ks + 8 (l // 16) .. + 8]; wave w of a member owns the k steps
+        [w kpw, (w + 1) kpw) of all of the member's tiles (emo_hip.h: emo_performer_decode_step)."""
+        N, K = W.shape
+        assert N % 16 == 0 and K == 32 * 8 * kpw
+        frags = W.reshape(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(N // 16, K // 32, 512)      # [tile][k step][lane * 8 + j]
+        sel = frags[tile_idx]                                                                                  # [members, tiles per member, k steps, 512]
+        members, tpm = tile_idx.shape
+        return sel.reshape(members, tpm, 8, kpw, 512).permute(0, 2, 1, 3, 4).contiguous()
+
+    def _prepare_persist(self):
+        m, ps, dev = self.model, self.ps, self.dev
+        D, L = m.d_model, m.n_layer
+        mem = torch.arange(32, device=dev)
+        t_qkv = torch.stack([mem, 32 + mem, 64 + mem], 1)            # member (h, j) = 4 h + j: rows 64 h + 16 j .. of q, of k (+ 512), of v (+ 1024)
+        t_one = mem.view(32, 1)                                      # member m: output columns 16 m ..
+        t_ffn = (4 * mem).view(32, 1) + torch.arange(4, device=dev).view(1, 4)
+        pk = self._pack_fragments
+        self.persist = {'w': [], 'table': None}
+        for l in range(L):
+            pfx = m._layer_prefix(l)
+            q = pfx + 'attention.query_projection.'
+            self.persist['w'].append(dict(
+                wqkv=pk(ps.w(q + 'weight', 3 * D), t_qkv, 2), bqkv=ps.f32(q + 'bias', 3 * D),
+                wo=pk(ps.w(pfx + 'attention.out_projection.weight'), t_one, 2), bo=ps.f32(pfx + 'attention.out_projection.bias'),
+                g1=ps.f32(pfx + 'norm1.weight'), be1=ps.f32(pfx + 'norm1.bias'),
+                w1=pk(ps.w(pfx + 'linear1.weight'), t_ffn, 2), b1=ps.f32(pfx + 'linear1.bias'),
+                w2=pk(ps.w(pfx + 'linear2.weight'), t_one, 8), b2=ps.f32(pfx + 'linear2.bias'),
+                g2=ps.f32(pfx + 'norm2.weight'), be2=ps.f32(pfx + 'norm2.bias')))
+        V = m.n_token
+        Vp = (V + 15) // 16 * 16
+        wout = torch.zeros(Vp, D, device=dev, dtype=torch.bfloat16)
+        wout[:V] = ps.w('dec_out_proj.weight')
+        self.persist['wout'] = pk(wout, torch.arange(Vp // 16, device=dev).view(-1, 1), 2)
+        self.persist['bout'] = ps.f32('dec_out_proj.bias')
+        self.persist['sync'] = torch.zeros(ops.lib.emo_performer_decode_step_workspace_bytes() // 8, device=dev, dtype=torch.int64)   # zeroed ONCE
+        self.persist['logits'] = torch.empty(self.n, V, device=dev, dtype=torch.float32)
+
+    def _persist_table(self):
+        """[L][16] device pointers (emo_hip.h); built once the recurrent state exists (prefill)."""
+        pp = self.persist
+        if pp['table'] is None:
+            rows = []
+            for l, w in enumerate(pp['w']):
+                assert self.S[l].is_contiguous() and self.z[l].is_contiguous() and self.omegas[l].is_contiguous()
+                rows.append([w['wqkv'].data_ptr(), w['bqkv'].data_ptr(), w['wo'].data_ptr(), w['bo'].data_ptr(), w['g1'].data_ptr(), w['be1'].data_ptr(),
+                             w['w1'].data_ptr(), w['b1'].data_ptr(), w['w2'].data_ptr(), w['b2'].data_ptr(), w['g2'].data_ptr(), w['be2'].data_ptr(),
+                             self.omegas[l].data_ptr(), self.S[l].data_ptr(), self.z[l].data_ptr(), 0])
+            pp['table'] = torch.tensor(rows, dtype=torch.int64, device=self.dev)
+        return pp['table']
+
+    def _step_persistent(self, tok, seg, dev_pos, logits_out):
+        m, pp = self.model, self.persist
+        if self._tables is None:
+            self._tables = (engine.embedding_table(self.ps, 'token_emb.'), engine.embedding_table(self.ps, 'segemb.') if m.use_segment_emb else None)
+        E, Sg = self._tables
+        seg = seg if (Sg is not None and seg is not None) else None
+        pe = m.pe.pe if m.use_pe else m._zero_pe(self.max_len, m.d_model)
+        out = logits_out if logits_out is not None else pp['logits']
+        nf = 2 * self.omegas[0].shape[1]
+        ops.performer_decode_step(self._persist_table(), m.n_layer, tok, seg, E, Sg if seg is not None else None, pe, float(m.token_emb.emb_scale),
+                                  self.dev_pos0 if dev_pos else self.pos, self.pos_dev if dev_pos else None, pp['wout'], pp['bout'], m.n_token, out,
+                                  self.n, m.d_model, m.n_head, nf, 2048, pp['sync'])
+        return out
+
+    def check_persistent(self):
+        """Raises if a one-launch step gave up (synchronises; call it where the caller reads results anyway)."""
+        if self.persist is not None:
+            code = int(self.persist['sync'][-8].item())
+            if code != 0:
+                raise EmoError('emo_performer_decode_step gave up (code 0x%x): a workgroup of the persistent launch did not get a compute unit next to the '
+                               'others within 50 ms (is another process using the GPU?); set EMO_DECODE_PERSISTENT=0 for the chain of launches' % code)
 
     def _prepare_folds(self):
         """gamma-scaled weights, c1[n] = sum_k gamma_k W[n,k] (of the ROUNDED bf16 product, the one the MFMA sees) and bias + W.beta for every
@@ -143,6 +228,8 @@ class PerformerDecodeEngine(_EngineBase):
             qkv = ops.gemm(x, ps.w(q + 'weight', 3 * D), bias=ps.f32(q + 'bias', 3 * D))
             attn, _, self.S[l], self.z[l] = ops.favor_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], self.omegas[l], B, T, H, want_state=True)
             x = self._tail(pfx, x, attn)
+        if self.persist is not None:
+            self.persist['table'] = None                         # new state tensors: the pointer table is rebuilt at the next step
         self.pos = T
         self.pos_dev.fill_(T)
         return self._logits(x.view(B, T, D)[:, -1].contiguous())
@@ -162,6 +249,14 @@ class PerformerDecodeEngine(_EngineBase):
         capturable in a hipGraph and replayable.  logits_out: write the logits into this static buffer (no copy kernel)."""
         m, ps = self.model, self.ps
         D, H = m.d_model, m.n_head
+        if self.persist is not None:
+            out = self._step_persistent(tok.reshape(-1), None if seg is None else seg.reshape(-1), dev_pos, logits_out)
+            if dev_pos:
+                if self.pos_auto:
+                    self.pos_dev.add_(1)
+            else:
+                self.pos += 1
+            return out
         x = self._embed(tok.view(-1, 1), None if seg is None else seg.view(-1, 1), self.pos, dev_pos)
         if self.fold is not None:
             out = self._step_folded(x, logits_out)
@@ -446,6 +541,8 @@ def generate_conditional_batch(model, event2idx, idx2event, lead_sheets, primers
                         continue
                     if logits_np is None:
                         logits_np = logits.cpu().numpy()
+                        if getattr(eng, 'persist', None) is not None:
+                            eng.check_persistent()
                     while True:                                  # a rejected sample re-derives probs from the same logits (reference: `continue`)
                         probs = temperature(logits_np[i].copy(), temp, inadmissibles=inadmissibles)
                         if s.offer(int(samplers[i](probs)), event2idx, idx2event, skip_check, max_events):
@@ -579,6 +676,9 @@ def generate_streams(model, prompt_tok, prompt_seg, n_new, temp=1.1, top_p=0.9, 
                 print('[gen timing] enqueue %.3f ms/step, total %.3f ms/step' % (1e3 * t_enq / (n_new - 1), 1e3 * (time.perf_counter() - t_host) / (n_new - 1)))
             for ch in cs:
                 main.wait_stream(ch.stream)
+    for ch in cs:
+        if getattr(ch.eng, 'persist', None) is not None:
+            ch.eng.check_persistent()
     return cs[0].out if chains == 1 else torch.cat([ch.out for ch in cs], 0)
 
 

@@ -12,7 +12,7 @@ from ._lib import (ACT_GELU_NEW, ACT_NONE, ACT_RELU, BF16, F32, MUL_BITMASK, MUL
                    dtype_code, lib, ptr, stream)
 
 __all__ = ['gemm', 'colsum', 'embed_fwd', 'embed_bwd', 'layernorm_fwd', 'layernorm_bwd', 'dropout_apply', 'favor_attn_fwd',
-           'favor_attn_bwd', 'favor_decode_step', 'favor_draw_omega', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'relpos_attn_fwd', 'relpos_attn_bwd', 'relpos_attn_decode', 'xent_fwd',
+           'favor_attn_bwd', 'favor_decode_step', 'performer_decode_step', 'favor_draw_omega', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'relpos_attn_fwd', 'relpos_attn_bwd', 'relpos_attn_decode', 'xent_fwd',
            'xent_bwd', 'argmax', 'sample_nucleus', 'sample_nucleus_step', 'accuracy_counts', 'sumsq', 'clip_coef', 'adam_step', 'cast', 'add_bias2',
            'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW', 'MUL_BITMASK', 'gemm_bitmask_ok', 'bitmask_rows']
 
@@ -233,6 +233,17 @@ def favor_decode_step(q, k, v, omega, state_S, state_z, H, eps=1e-6):
     check(lib.emo_favor_decode_step(ptr(q), ptr(k), ptr(v), _rows(q), ptr(omega), ptr(state_S), ptr(state_z), ptr(out), HD,
                                     dtype_code(q.dtype), n, H, dh, 2 * omega.shape[1], eps, stream()))
     return out
+
+
+def performer_decode_step(layer_table, n_layers, tok, seg, E, Sg, pe, emb_scale, pos0, pos_ids, wout_packed, bout, n_token, logits, n_streams,
+                          d_model, n_head, n_feat, d_ff, sync_ws, eps=1e-6, ln_eps=1e-5):
+    """One token step of every stream in ONE persistent launch (emo_hip.h: emo_performer_decode_step)."""
+    tok, seg, pos_ids = _c(tok), _c(seg), _c(pos_ids)
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.shape == (n_streams, n_token)
+    check(lib.emo_performer_decode_step(ptr(layer_table), n_layers, ptr(tok), ptr(seg), ptr(E), ptr(Sg), ptr(pe), emb_scale, pos0, ptr(pos_ids),
+                                        ptr(wout_packed), ptr(bout), n_token, ptr(logits), n_streams, d_model, n_head, n_feat, d_ff,
+                                        ptr(sync_ws), sync_ws.numel() * sync_ws.element_size(), eps, ln_eps, stream()))
+    return logits
 
 
 def favor_draw_omega(gauss, omega):

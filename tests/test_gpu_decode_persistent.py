@@ -1,0 +1,78 @@
+"""GPU: the one-launch Performer decode step (emo_performer_decode_step, csrc/emo_decode_persist.hip) against (a) the chain of launches it
+replaces (same bf16 arithmetic up to the LayerNorm fold and the reduction order: logits within 2 % of the logit range, recurrent state within
+1e-3 relative) and (b) the fp32 parity-mode engine, which is itself tied to the oracle's recurrent form (tests/test_gpu_generate.py) — bf16
+tolerance 5 % of the logit range.  Reference: the token loop of stage2_accompaniment/inference.py:250-277."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(L, dtype, seed=0, scale=2.5):
+    from emo_disentanger_amd.model.music_performer import MusicPerformer
+    from oracle.weights import make_state_dict
+    V, H, d, dff, nf = 327, 8, 512, 2048, 128
+    sd = make_state_dict('performer', V, L, H, d, dff, favor_feature_dims=nf, seed=seed, scale=scale)
+    m = MusicPerformer(V, L, H, d, dff, d, favor_feature_dims=nf, use_segment_emb=True, n_segment_types=2, compute_dtype=dtype, redraw='fixed')
+    m.load_state_dict(sd)
+    return m.cuda().eval()
+
+
+def _run(model, ptok, pseg, toks, segs, persistent, monkeypatch):
+    from emo_disentanger_amd import inference as inf
+    monkeypatch.setenv('EMO_DECODE_PERSISTENT', '1' if persistent else '0')
+    eng = inf.make_engine(model, ptok.shape[0], redraw=False)
+    assert (eng.persist is not None) == (persistent and model.compute_dtype == torch.bfloat16)
+    out = [eng.prefill(ptok, pseg).float().clone()]
+    for t in range(toks.shape[1]):
+        out.append(eng.step(toks[:, t], segs[:, t]).float().clone())
+    if eng.persist is not None:
+        eng.check_persistent()
+    return torch.stack(out, 1), [s.clone() for s in eng.S], [z.clone() for z in eng.z]
+
+
+@pytest.mark.parametrize('n,L', [(4, 1), (8, 3), (32, 12)])
+def test_one_launch_step_matches_launch_chain_and_fp32(n, L, monkeypatch):
+    g = torch.Generator().manual_seed(5 + n)
+    V, T0, K = 327, 24, 6
+    ptok = torch.randint(0, V - 1, (n, T0), generator=g).cuda()
+    pseg = torch.randint(0, 2, (n, T0), generator=g).cuda()
+    toks = torch.randint(0, V - 1, (n, K), generator=g).cuda()
+    segs = torch.randint(0, 2, (n, K), generator=g).cuda()
+    mb = _model(L, 'bf16')
+    one, S1, z1 = _run(mb, ptok, pseg, toks, segs, True, monkeypatch)
+    chain, S0, z0 = _run(mb, ptok, pseg, toks, segs, False, monkeypatch)
+    ref, _, _ = _run(_model(L, 'fp32'), ptok, pseg, toks, segs, False, monkeypatch)
+    rng = float(ref.max() - ref.min())
+    assert torch.equal(one[:, 0], chain[:, 0])                       # the prefill is shared
+    e_chain = float((one - chain).abs().max()) / rng
+    e_ref = float((one - ref).abs().max()) / rng
+    e_chain_ref = float((chain - ref).abs().max()) / rng
+    print('[one-launch decode] n=%d L=%d: vs launch chain %.4f, vs fp32 %.4f (launch chain vs fp32 %.4f) of the logit range' % (n, L, e_chain, e_ref, e_chain_ref))
+    assert e_chain <= 0.02 and e_ref <= 0.05
+    for a, b in zip(S1 + z1, S0 + z0):
+        assert float((a - b).norm() / b.norm().clamp_min(1e-12)) <= 1e-3
+    # graph replay of the step = eager launches, bit for bit (the launch counter in the workspace advances on the device)
+    from emo_disentanger_amd import inference as inf
+    monkeypatch.setenv('EMO_DECODE_PERSISTENT', '1')
+    a = inf.generate_streams(mb, ptok, pseg, 12, greedy=True, use_graph=False)
+    b = inf.generate_streams(mb, ptok, pseg, 12, greedy=True, use_graph=True)
+    c = inf.generate_streams(mb, ptok, pseg, 12, greedy=False, seed=3, use_graph=True)
+    d = inf.generate_streams(mb, ptok, pseg, 12, greedy=False, seed=3, use_graph=False)
+    assert torch.equal(a, b) and torch.equal(c, d)
+
+
+def test_one_launch_step_refuses_what_it_was_not_built_for():
+    from emo_disentanger_amd import ops
+    from emo_disentanger_amd._lib import EmoError
+    z = torch.zeros(16, device='cuda')
+    zi = torch.zeros(16, dtype=torch.int64, device='cuda')
+    ws = torch.zeros(ops.lib.emo_performer_decode_step_workspace_bytes() // 8, dtype=torch.int64, device='cuda')
+    lg = torch.zeros(4, 327, device='cuda')
+    with pytest.raises(EmoError, match='built for d_model 512'):
+        ops.performer_decode_step(zi, 1, zi, None, z, None, z, 1.0, 0, None, z, z, 327, lg, 4, 256, 8, 128, 2048, ws)
+    lg6 = torch.zeros(6, 327, device='cuda')
+    with pytest.raises(EmoError, match='multiple of 4'):
+        ops.performer_decode_step(zi, 1, zi, None, z, None, z, 1.0, 0, None, z, z, 327, lg6, 6, 512, 8, 128, 2048, ws)
