@@ -159,7 +159,7 @@ class PerformerDecodeEngine(_EngineBase):
         nf = 2 * self.omegas[0].shape[1]
         ops.performer_decode_step(self._persist_table(), m.n_layer, tok, seg, E, Sg if seg is not None else None, pe, float(m.token_emb.emb_scale),
                                   self.dev_pos0 if dev_pos else self.pos, self.pos_dev if dev_pos else None, pp['wout'], pp['bout'], m.n_token, out,
-                                  self.n, m.d_model, m.n_head, nf, 2048, pp['sync'])
+                                  self.n, m.d_model, m.n_head, nf, 2048, pp['sync'], diag=pp.get('diag'))
         return out
 
     def check_persistent(self):

@@ -236,13 +236,13 @@ def favor_decode_step(q, k, v, omega, state_S, state_z, H, eps=1e-6):
 
 
 def performer_decode_step(layer_table, n_layers, tok, seg, E, Sg, pe, emb_scale, pos0, pos_ids, wout_packed, bout, n_token, logits, n_streams,
-                          d_model, n_head, n_feat, d_ff, sync_ws, eps=1e-6, ln_eps=1e-5):
+                          d_model, n_head, n_feat, d_ff, sync_ws, eps=1e-6, ln_eps=1e-5, diag=None):
     """One token step of every stream in ONE persistent launch (emo_hip.h: emo_performer_decode_step)."""
     tok, seg, pos_ids = _c(tok), _c(seg), _c(pos_ids)
     assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.shape == (n_streams, n_token)
     check(lib.emo_performer_decode_step(ptr(layer_table), n_layers, ptr(tok), ptr(seg), ptr(E), ptr(Sg), ptr(pe), emb_scale, pos0, ptr(pos_ids),
                                         ptr(wout_packed), ptr(bout), n_token, ptr(logits), n_streams, d_model, n_head, n_feat, d_ff,
-                                        ptr(sync_ws), sync_ws.numel() * sync_ws.element_size(), eps, ln_eps, stream()))
+                                        ptr(sync_ws), sync_ws.numel() * sync_ws.element_size(), eps, ln_eps, ptr(diag), stream()))
     return logits
 
 

@@ -173,13 +173,14 @@ int emo_favor_decode_step(const void* q, const void* k, const void* v, int64_t l
  *   logits      : f32 [n_streams][n_token]
  *   sync_ws     : emo_performer_decode_step_workspace_bytes() bytes, ZEROED ONCE by the caller before the first step and then left alone
  *                 (it carries the launch counter the granule tags are derived from); its last 8 words: [0] != 0 after a step that gave up
- *                 (a workgroup could not be scheduled next to the others within 50 ms) - the caller must check it before trusting the logits. */
+ *                 (a workgroup could not be scheduled next to the others within 50 ms) - the caller must check it before trusting the logits.
+ *   diag        : NULL, or int64 [32][16][8][4] device words that receive group 0's per-phase time stamps (tools/pd_diag.py). */
 int64_t emo_performer_decode_step_workspace_bytes(void);
 int emo_performer_decode_step(const void* layer_table, int64_t n_layers, const int64_t* tok, const int64_t* seg, const float* E,
                               const float* Sg, const float* pe, float emb_scale, int64_t pos0, const int64_t* pos_ids,
                               const void* wout_packed, const float* bout, int64_t n_token, float* logits, int64_t n_streams,
                               int64_t d_model, int64_t n_head, int64_t n_feat, int64_t d_ff, void* sync_ws, int64_t sync_ws_bytes,
-                              float eps, float ln_eps, emo_stream_t stream);
+                              float eps, float ln_eps, int64_t* diag, emo_stream_t stream);
 
 /* FAVOR+ omega draw (fast-transformers orthogonal_random_matrix_, called from new_feature_map() on every
  * forward — SURVEY F8): gauss [n_layers, ceil((n_feat/2)/dh), dh, dh] ~ N(0,1) from the caller's RNG ->
