@@ -146,8 +146,9 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
     overlapped = instrumented(True) if engine._SIDE['on'] else {}
     # PMC counters of THIS round's kernels inside the training step (tools/pmc_step.py under rocprofv3 --pmc, one counter group per pass,
     # summarised by tools/pmc_classes.py): HBM bytes per launch and the MFMA pipe's busy fraction per kernel class
-    pmc_path = os.path.join(ROOT, 'profiles', 'r03_pmc_step.json')
-    pmc_all = json.load(open(pmc_path))['classes'] if os.path.exists(pmc_path) else {}
+    # — printed ONLY while the file's stamp (hash of the kernel sources it was collected with) matches the sources of this run: stale counters
+    # are dropped, not shown (r02 printed counters of kernels that no longer existed)
+    pmc_all, pmc_note = load_pmc()
 
     def entry(kind):
         d = serial[kind]
@@ -158,7 +159,7 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
             traffic += pmc_all['TN-reduce'].get('traffic_bytes_per_launch', 0)
         return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic, 'mfma_busy': pmc.get('mfma_busy'),
-                'waves_parked': pmc.get('waves_parked'), 'waves_issue_stalled': pmc.get('waves_issue_stalled'),
+                'waves_parked': pmc.get('waves_parked'), 'waves_issue_stalled': pmc.get('waves_issue_stalled'), 'effective_clock_ghz': pmc.get('effective_clock_ghz'),
                 'kernel': '%s (%s)' % gemm_kernel_label(kind), 'launches_timed': d['n'], 'avg_launch_ms': round(d['ms'] / d['n'], 4),
                 'total_ms_per_step': round(d['ms'] / n_steps, 2),
                 'avg_launch_ms_overlapped_in_step': round(overlapped[kind]['ms'] / overlapped[kind]['n'], 4) if kind in overlapped else None,
@@ -174,7 +175,7 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
                                   'total_ms_per_step': round(f_['ms'] / n_steps, 2)} for k_, f_ in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])}
     roof['timing'] = 'HIP events on the launch stream around every GEMM launch in %d real training steps (kernels serialized on one stream)' % n_steps
     roof['rocprof_summary'] = ('profiles/r03_bench_train_rocprof_stats.txt = rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3 --no-cpu-baseline '
-                               '--no-gen --no-stage1 --no-gpt2 --no-step0-check --no-b4` (training kernels only); PMC (traffic, mfma_busy): profiles/r03_pmc_step.json')
+                               '--no-gen --no-stage1 --no-gpt2 --no-step0-check --no-b4` (training kernels only); PMC (traffic, mfma_busy, effective clock): ' + pmc_note)
     roof['roofline_others'] = [entry(k) for k in order[1:]] + [attn_entry(k, v, n_steps, pmc_all if B * T == 131072 else {}) for k, v in sorted(extra.items())]
     return roof
 
@@ -183,6 +184,22 @@ ATTN_KERNELS = {'favor_fwd': ('favor_fs_fwd_kernel (bf16 slice kernel; generic: 
                 'favor_bwd': ('favor_fs_dq_kernel + favor_fs_dkv_kernel (bf16 slice kernels; generic: favor_bwd_dq_kernel / favor_bwd_dkv_kernel)', 'hbm', 'FAVOR+ backward (forward sweep dq, reverse sweep dk/dv); bytes = 7*512*e per token*layer'),
                 'sattn_fwd': ('sattn32_fwd_kernel (32x32x16 tiles; generic: sattn_fwd_kernel)', 'mfma', 'GPT-2 causal softmax attention forward (flash tiles): 2 matmuls, causal half'),
                 'sattn_bwd': ('sattn_bwd_dq_kernel + sattn32_dkv_kernel (32x32x16 tiles; generic: sattn_bwd_dkv_kernel)', 'mfma', 'GPT-2 attention backward: 7 matmuls, causal half')}
+
+
+def load_pmc():
+    """(classes, note): the newest profiles/r*_pmc_step.json whose csrc_hash equals the hash of the kernel sources in this tree."""
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        from pmc_classes import csrc_hash
+        now = csrc_hash()
+    except Exception as e:   # noqa: BLE001
+        return {}, 'no PMC file used (%s)' % e
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_step.json')), reverse=True):
+        j = json.load(open(path))
+        if j.get('csrc_hash') == now:
+            return j['classes'], '%s (stamp %s = the kernel sources of this run)' % (os.path.relpath(path, ROOT), now)
+    return {}, 'no PMC file matches the kernel sources of this run (hash %s): traffic / mfma_busy / clock omitted — re-run tools/collect_profiles.sh' % now
 
 
 def attn_entry(kind, rec, n_steps, pmc_all=None):
@@ -198,7 +215,7 @@ def attn_entry(kind, rec, n_steps, pmc_all=None):
     else:
         ach, peak, unit = fl / ms / 1e9, PEAK_BF16_TFLOPS, 'TFLOP/s'
     return {'bound': bound, 'achieved': round(ach, 1), 'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4), 'traffic': traffic,
-            'mfma_busy': [p.get('mfma_busy') for p in parts] if parts else None, 'lds_conflict_share': [p.get('lds_conflict_share') for p in parts] if parts else None,
+            'mfma_busy': [p.get('mfma_busy') for p in parts] if parts else None, 'effective_clock_ghz': [p.get('effective_clock_ghz') for p in parts] if parts else None, 'lds_conflict_share': [p.get('lds_conflict_share') for p in parts] if parts else None,
             'kernel': '%s (%s)' % (name, what),
             'launches_timed': len(rec), 'avg_launch_ms': round(ms / len(rec), 4), 'total_ms_per_step': round(ms / n_steps, 2),
             'algorithmic_flops_per_launch': round(fl / len(rec)), 'algorithmic_bytes_per_launch': round(by / len(rec))}

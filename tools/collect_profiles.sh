@@ -3,7 +3,7 @@
 # passes over the training step (one counter group per pass; --pmc is never combined with other trace domains).  Outputs -> gpurun_out/,
 # copy what is to be judged into profiles/.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 rocprofv3 --kernel-trace --stats -d gpurun_out/${R}_stats -o x -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-gen --no-stage1 --no-gpt2 --no-step0-check --no-b4 > gpurun_out/${R}_stats_bench.json 2> gpurun_out/${R}_stats.log

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel-trace summaries of the secondary paths (decode step, stage-1 step, GPT-2 step) -> gpurun_out/<round>_*_rocprof_stats.txt
 set -u
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for job in "decode_step tools/gen_prof.py" "stage1 tools/bench_stage1.py" "gpt2_step tools/bench_gpt2.py"; do
   set -- $job
