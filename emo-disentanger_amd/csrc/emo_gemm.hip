@@ -870,6 +870,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     ((f32x4*)out)[i] = (a + b) + (c + d);
 }
 
+// The same sum followed by the FULL fused epilogue (bias -> aux -> act -> mul -> dropout -> residual, emo_gemm_epi.h) and the store in the output
+// dtype: split-K for products WITH an epilogue whose tile grid leaves the chip empty (r04: stage-1 / batch-4 dgrads and FFN2 forwards with
+// 64-256 tiles ran at the ~25-32 GB/s one block's 4-stage DMA ring can keep in flight; two to four K-splits put 2 blocks on every CU).
+// A thread owns 8 consecutive columns of a row (N % 8 == 0).
+template <typename OutT>
+__global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(const float* __restrict__ ws, int64_t stride, int splits, OutT* __restrict__ C, int64_t M,
+                                                                int64_t N, EpiParams ep) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i * 8 >= M * N) return;
+    const float* p = ws + 8 * i;
+    f32x4 a0 = *(const f32x4*)p, a1 = *(const f32x4*)(p + 4);
+    for (int s = 1; s < splits; ++s) {
+        a0 += *(const f32x4*)(p + (int64_t)s * stride);
+        a1 += *(const f32x4*)(p + (int64_t)s * stride + 4);
+    }
+    float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    const int64_t m = (8 * i) / N, n = (8 * i) - m * N;
+    epi_row8<OutT>(ep, C, m, n, v, N);
+}
+
+// K-splits of a bf16-output product with an epilogue (0 / 1 = none): a tile grid of at most 256 blocks and a long reduction
+static int64_t choose_epi_splits(int64_t M, int64_t N, int64_t K) {
+    static const bool off = getenv("EMO_GEMM_EPI_SPLIT") != nullptr && atoi(getenv("EMO_GEMM_EPI_SPLIT")) == 0;
+    if (off || (N & 7) || K < 1024 || (K % (4 * G2_BK)) != 0) return 1;
+    const int64_t tiles = cdiv64(M, GB_M) * cdiv64(N, GB_N);
+    if (tiles > 256) return 1;
+    return tiles > 128 ? 2 : 4;
+}
+
 void emo_splitk_reduce_launch(const float* ws, int64_t stride, int splits, float* out, int64_t n4, int accumulate, hipStream_t st) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, st, ws, stride, splits, out, n4, accumulate);
 }
@@ -914,7 +943,12 @@ static int64_t choose_splits(int64_t M, int64_t N, int64_t K, bool big, bool has
 
 #define EMO_GEMM_MAX_SPLITS 32
 extern "C" int64_t emo_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype_in, int dtype_out) {
-    if (dtype_out != EMO_F32 || M <= 0 || N <= 0 || K <= 0) return 0;
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if (dtype_in == EMO_BF16 && dtype_out == EMO_BF16) {               // split-K + reduce-with-epilogue of the small-grid long-K products
+        const int64_t es = choose_epi_splits(M, N, K);
+        return es > 1 ? es * M * N * (int64_t)sizeof(float) : 0;
+    }
+    if (dtype_out != EMO_F32) return 0;
     const bool big = dtype_in == EMO_BF16;
     const int64_t BMt = big ? GB_M : 64, BNt = big ? GB_N : 64, BKt = big ? (gemm_variant() >= 2 ? G2_BK : GB_K) : 16;
     int64_t splits = choose_splits(M, N, K, big, false, dtype_out, BMt, BNt, BKt, EMO_GEMM_MAX_SPLITS);
@@ -1022,6 +1056,19 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     int64_t max_ws_splits = ws_ok ? ws_bytes / (M * N * (int64_t)sizeof(float)) : 0;
     int64_t splits = choose_splits(M, N, K, big, has_epi, dtype_out, BMt, BNt, BKt, max_ws_splits >= 2 ? max_ws_splits : 0);
     if (ldc != N) splits = 1;                                // split-K partials need a contiguous C: a strided output view runs unsplit
+    // bf16 outputs (with or without an epilogue) on a small tile grid: split-K through the workspace + splitk_reduce_epi_kernel
+    EpiParams ep_final = ep;
+    bool epi_split = false;
+    if (big && dtype_out == EMO_BF16 && !accumulate && ldc == N && ws_ok && variant >= 2 && !use_safe_tr() && (!a_trans || variant >= 3) && !ep.a_rowsum && !ep.b_rowsum) {
+        const int64_t es = choose_epi_splits(M, N, K);
+        if (es > 1 && max_ws_splits >= es) {
+            splits = es;
+            epi_split = true;
+            ep.bias = nullptr; ep.act = EMO_ACT_NONE; ep.aux_out = nullptr; ep.mul_aux = nullptr; ep.mul_mode = EMO_MUL_NONE; ep.mul_scale = 1.f;
+            ep.drop = make_drop(0.f, 0, 0); ep.residual = nullptr;
+        }
+    }
+    const int kdt = epi_split ? EMO_F32 : dtype_out;         // the GEMM pass of an epilogue split writes raw fp32 partial sums
     int64_t kps = cdiv64(cdiv64(K, splits), BKt) * BKt;
     splits = cdiv64(K, kps);
     const bool use_ws = splits > 1 && max_ws_splits >= splits;
@@ -1061,9 +1108,9 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         const bool span_ok = spanA < (int64_t)0xFFFF0000 && spanB < (int64_t)0xFFFF0000;
         const bool glds_ok = !safe && variant >= 2 && (akc || variant >= 3) && (K % G2_BK) == 0 && (kps % G2_BK) == 0 && M >= 8 && N >= 8 && span_ok;
         if (glds_ok) {
-            if (dtype_out == EMO_F32) dispatch_glds<float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
+            if (kdt == EMO_F32) dispatch_glds<float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
             else dispatch_glds<bf16_t>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
-        } else if (dtype_out == EMO_F32) {   // register-staged v1 (same 128^2 grid; any K, predicated edges)
+        } else if (kdt == EMO_F32) {   // register-staged v1 (same 128^2 grid; any K, predicated edges)
             if (safe) dispatch_bf16<true, float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
             else dispatch_bf16<false, float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
         } else {
@@ -1072,7 +1119,12 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         }
     }
     EMO_LAUNCH_CHECK();
-    if (use_ws) {
+    if (use_ws && epi_split) {
+        ep_final.atomic = 0; ep_final.ws_stride = 0; ep_final.accumulate = 0; ep_final.ldc = N;
+        hipLaunchKernelGGL(splitk_reduce_epi_kernel<bf16_t>, dim3((unsigned)cdiv64(M * N / 8, 256)), dim3(256), 0, st, (const float*)ws, M * N, (int)splits,
+                           (bf16_t*)C_final, M, N, ep_final);
+        EMO_LAUNCH_CHECK();
+    } else if (use_ws) {
         const int64_t n4 = (M * N) >> 2;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, st, (const float*)ws, M * N, (int)splits, (float*)C_final, n4,
                            accumulate_final);

@@ -82,7 +82,9 @@ def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumu
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=out_dtype or A.dtype)
     ws, ws_bytes = None, 0
-    if out.dtype == torch.float32 and bias is None and residual is None and aux_out is None and mul_aux is None and act == ACT_NONE and p_drop == 0.0:
+    plain = bias is None and residual is None and aux_out is None and mul_aux is None and act == ACT_NONE and p_drop == 0.0
+    if (out.dtype == torch.float32 and plain) or (out.dtype == torch.bfloat16 and not accumulate and M > 32):
+        # fp32 plain outputs (wgrad): split-K partial sums; bf16 outputs on a small tile grid with a long reduction: split-K + reduce-with-epilogue
         ws, ws_bytes = _workspace('gemm', A.device, lib.emo_gemm_workspace_bytes(M, N, K, dtype_code(A.dtype), dtype_code(out.dtype)))
     rx, rstats, rgamma, rbeta = rln if rln is not None else (None, None, None, None)     # residual = LayerNorm(rx) from exported statistics
     assert rx is None or (rx.dtype == out.dtype and _rows(rx) == _rows(out))

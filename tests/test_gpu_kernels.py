@@ -101,6 +101,35 @@ def test_gemm_epilogue_mul_modes_and_dropout(dt):
     _close(o1[keep], (plain.double() / 0.9)[keep], dt, mult=2.0)
 
 
+@pytest.mark.parametrize('M,N,K,b_trans', [(2048, 512, 2048, False), (2048, 512, 2048, True), (8192, 512, 1536, True), (4096, 1024, 1024, False)])
+def test_gemm_small_grid_long_k_split_with_epilogue(M, N, K, b_trans):
+    """bf16 products whose 128 x 128 tile grid leaves the chip empty (<= 256 tiles: stage 1, batch-size-4 steps) and whose reduction is long run
+    split-K through the workspace + splitk_reduce_epi_kernel, which applies the whole fused epilogue: against fp64, dropout against
+    emo_dropout_apply of the plain product (same element indexing), the multiplicative mask mode, and the pre-activation side output."""
+    ops = _ops()
+    dt = torch.bfloat16
+    from emo_disentanger_amd._lib import lib, dtype_code
+    assert lib.emo_gemm_workspace_bytes(M, N, K, dtype_code(dt), dtype_code(dt)) > 0          # this shape takes the split path
+    A = _r(M, K, seed=21, dt=dt)
+    W = _r(K, N, seed=22, dt=dt, scale=0.05) if b_trans else _r(N, K, seed=22, dt=dt, scale=0.05)
+    bias, res = _r(N, seed=23), _r(M, N, seed=24, dt=dt)
+    z = A.double() @ (W.double() if b_trans else W.double().T)
+    Ac, Wc = A.cuda(), W.cuda()
+    plain = ops.gemm(Ac, Wc, b_trans=b_trans)
+    _close(plain, z, dt)
+    aux = torch.empty(M, N, device='cuda', dtype=dt)
+    out = ops.gemm(Ac, Wc, b_trans=b_trans, bias=bias.cuda(), act=ops.ACT_RELU, residual=res.cuda(), aux_out=aux)
+    _close(aux, z + bias.double(), dt)
+    _close(out, torch.relu(z + bias.double()) + res.double(), dt)
+    o1 = ops.gemm(Ac, Wc, b_trans=b_trans, p_drop=0.1, seed=11, offset=3, residual=res.cuda())
+    masked = ops.dropout_apply(plain, 0.1, 11, 3)
+    _close(o1, masked.double().cpu() + res.double(), dt, mult=2.0)
+    mask = _r(M, N, seed=25, dt=dt)
+    mask[mask.abs() < 0.6] = 0
+    o2 = ops.gemm(Ac, Wc, b_trans=b_trans, mul_aux=mask.cuda(), mul_mode=ops.MUL_NONZERO, mul_scale=1.25)
+    _close(o2, z * (mask.double() != 0) * 1.25, dt)
+
+
 def test_gemm_splitk_wgrad_accumulate():
     ops = _ops()
     for dt in DT:
