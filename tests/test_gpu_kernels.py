@@ -216,6 +216,7 @@ def test_gemm_256_tile_nt_matches_reference_and_128_tile(shape, monkeypatch):
     # emo_gemm_w128.hip: 256 x 256 tile, one wave per SIMD (default for K >= 1024 with >= 256 tiles; EMO_GEMM_W128=1 admits every eligible shape).
     # Against fp64 and BIT-identical to the 128 x 128 kernel (same k order, same dropout hash) for every epilogue it takes.
     ops = _ops()
+    monkeypatch.setenv('EMO_GEMM_EPI_SPLIT', '0')        # (the 128 x 128 kernel unsplit: split-K sums in another order)
     M, N, K = shape
     A, W = _r(M, K, seed=1).to(torch.bfloat16).cuda(), _r(N, K, seed=2, scale=0.1).to(torch.bfloat16).cuda()
     bias, res = _r(N, seed=3).cuda(), _r(M, N, seed=4).to(torch.bfloat16).cuda()
