@@ -3,12 +3,12 @@
 // stage2_accompaniment/inference.py:250-277 -> MusicPerformer.forward with keep_last_only, music_performer.py:50-70), whose every launch sat
 // on the ~5-6 us launch floor with < 2 MB of work (r03: 0.383 ms per token step = 0.09 of the HBM roofline).
 //
-// Structure (DESIGN.md "persistent decode"): 256 workgroups = 8 GROUPS x 32 members; group g = blockIdx % 8 — the XCD the dispatcher puts the
-// block on, so a group's traffic normally stays inside one XCD, but NOTHING depends on that placement — owns streams 4g .. 4g+3 for the whole
-// token step and never talks to another group.  Inside a group every GEMM of the layer is split by OUTPUT COLUMN over the 32 members (each
-// member streams 1/32 of every weight matrix: 197 KB per layer, pre-packed on the host in MFMA fragment order so that a wave's load
-// instruction is one contiguous KB that goes straight into the B-operand registers — no LDS staging, each weight byte is used once), the 4
-// streams are rows 0-3 of a 16-row MFMA A operand, and the five dependent products of a layer are separated by five all-gather EDGES:
+// Structure: 256 workgroups = 8 GROUPS x 32 members; group g = blockIdx % 8 — the XCD the dispatcher puts the block on, so a group's traffic
+// normally stays inside one XCD, but NOTHING depends on that placement — owns streams 4g .. 4g+3 for the whole token step and never talks to
+// another group.  Inside a group every GEMM of the layer is split by OUTPUT COLUMN over the 32 members (each member streams 1/32 of every
+// weight matrix: 197 KB per layer, pre-packed on the host in MFMA fragment order so that a wave's load instruction is one contiguous KB that
+// goes straight into the B-operand registers — no LDS staging, each weight byte is used once), the 4 streams are rows 0-3 of a 16-row MFMA A
+// operand, and the five dependent products of a layer are separated by five all-gather EDGES:
 //   P1 q/k/v columns of head h (member = (h, j): dims 16j..16j+15 of q_h, k_h, v_h)        -> E2 (gathered by the 4 members of head h)
 //   P2 FAVOR+ recurrent step of (head h, stream j): S += phi(k) (x) v, out = phi(q)^T S / ..  -> E3
 //   P3 out-projection + bias + residual (pre-LN row)                                        -> E4
@@ -23,19 +23,25 @@
 // Same-XCD fast path (measured r04, tools/pd_diag.py: a write-through granule costs the reader a fabric round trip of ~1.5 us per poll, two per
 // edge): every launch starts with a CENSUS — each member publishes its XCC id through the placement-independent form, gathers the 32 ids of
 // its group, and only if all are equal the group's producers switch to PLAIN stores, which stay in that XCD's L2 where the agent-scope (L1
-// bypassing) polls of the other members hit.  A group that is spread over several XCDs keeps the write-through stores: speed depends on the
-// placement, the result never does.
-// Latency plan: a wave's loads return in order, so a poll cannot overtake an older weight load; everything a phase needs from HBM (its weight
-// fragments, the recurrent-state slice, biases, LayerNorm parameters) is therefore requested TWO PHASES AHEAD (right after the gather of phase p - 2:
-// measured r04, an HBM fetch takes 2-2.5 us here, a phase 1-1.5), and workgroup barriers are raw s_barrier + lgkmcnt (no vmcnt(0) fence).
+// bypassing) polls of the other members hit (~0.5 us per edge).  A group that is spread over several XCDs keeps the write-through stores:
+// speed depends on the placement, the result never does.
 //
-// What bounds it (r04, tools/pd_diag.py, profiles/r04_pd_diag_v*.txt): 0.244 ms per token step of which ~0.21 in this kernel = 60 phases x ~3.3 us.
-// A phase's own work (barrier -> MFMAs -> partial sums -> publish) is 0.3-0.9 us and an L2-local poll 0.2 us; the rest is the CU's memory queue:
-// every XCD streams ALL weights for its 4 streams (8 x 76 MB + 200 MB of state = 0.8 GB per token step, ~4 TB/s), a phase's 16-64 KB weight
-// burst takes 2-3 us to drain at ~25 GB/s per CU, and polls — from ANY wave of the CU — queue behind it.  A 12-wave variant with dedicated
-// poller waves and two compute halves that prefetch 2-3 phases ahead (git history: "Persistent decode v6") moved the waiting from the compute
-// side to the pollers' first poll (2.0 us behind a burst vs 0.2 us without) and measured 0.251 ms: not kept.  Next step: stop
-// re-streaming the weights — layer-pipelined groups that keep 1/8 of the model resident in registers / LDS across tokens.
+// Wave roles (12 waves per workgroup).  A wave's loads return IN ORDER and hipcc waits for its own loads with s_waitcnt vmcnt(0), so a poll — or
+// the first use of anything — waits for every older AND every newer outstanding load of that wave: in the first versions (all waves did
+// everything) each gather waited ~2 us for the HBM weight loads issued just before it, however far ahead they were requested (r04
+// diagnostics: 0.26 -> 0.24 ms per token with 1- and 2-phase-ahead loads).  Therefore:
+//   * waves 8-11 = POLLERS: gather the edges into LDS (poller wave s owns row s, so it also applies the LayerNorm without a barrier), sum the
+//     partial products, add the residual, publish.  They issue NO other global loads: a poll never queues behind HBM.
+//   * waves 0-3 = compute half A: the P1 and P4 products;  waves 4-7 = half B: the attention step P2 and the P3 and P5 products.  A half
+//     requests its NEXT operand set (weight fragments + bias; B: state slice; A: omega and the LayerNorm parameters, which it hands to B / the
+//     pollers through LDS) after it has published the current product, in SLICES of 8-21 KB — one after each barrier it passes while idle — and
+//     has nothing to wait for until its next turn, two to three phases later.  (Requested as one 48-64 KB burst the set sat in the CU's memory
+//     queue in front of the pollers' loads: first poll 2.0 us instead of 0.2, and the burst's issue stalled its own wave for ~2 us.)
+// Measured r04 (tools/pd_diag.py, profiles/r04_pd_diag_v*.txt; bench `gen`): chain of launches 0.383 ms per token step; all-waves-do-everything
+// persistent kernel 0.325 (write-through granules) -> 0.257 (census + L2-local granules) -> 0.244 (raw barriers, loads two phases ahead);
+// wave roles with burst loads 0.251-0.283; wave roles with sliced loads 0.221 (kernel 181 us = 60 phases x 3.0 us: 0.5-0.9 us of work each, the
+// rest is the wait for the edge behind the CU's weight stream: every XCD streams ALL weights for its 4 streams, 0.8 GB per token step).
+// Workgroup barriers are raw s_barrier + lgkmcnt(0): __syncthreads() carries a vmcnt(0) fence and would drain the HBM loads at every barrier.
 //
 // Arithmetic mirrors the launch path's bf16 mode (emo_gemm skinny kernel, favor_decode_fast_kernel, layernorm_fwd_bf16_d512_kernel): bf16
 // activations between products, fp32 accumulation, fp32 FAVOR+ state, LayerNorm statistics in fp32 from the bf16 row.
@@ -45,7 +51,7 @@ namespace {
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) unsigned long long gu64;      // every word another workgroup reads: GLOBAL address space, never flat
 constexpr int PD_D = 512, PD_H = 8, PD_DH = 64, PD_MF = 64, PD_F = 128, PD_FF = 2048;
-constexpr int PD_GS = 4, PD_GM = 32, PD_NG = 8, PD_NT = 512, PD_NW = 8;
+constexpr int PD_GS = 4, PD_GM = 32, PD_NG = 8, PD_NT = 768, PD_HW = 4, PD_HT = 256;    // threads; waves / threads per role (A, B, pollers)
 constexpr int PD_XS = PD_D + 8, PD_FS = PD_FF + 8;              // LDS row strides (bf16 elements): +16 B shifts the rows' banks
 constexpr int OFF_CNT = 0, OFF_E1 = 8, OFF_E2 = OFF_E1 + PD_GS * PD_D / 2, OFF_E3 = OFF_E2 + PD_H * PD_GS * 96, OFF_E4 = OFF_E3 + PD_GS * PD_D / 2,
               OFF_E5 = OFF_E4 + PD_GS * PD_D / 2, OFF_CEN = OFF_E5 + PD_GS * PD_FF / 2, PD_GSTRIDE = OFF_CEN + PD_GM;
@@ -64,23 +70,32 @@ struct PdArgs {
     int flags;      // bit 0: non-temporal weight loads
     u64* diag;      // optional [32 members][16 layers][8 phases][4]: {t_start, t_gathered, t_published, failed poll passes} of GROUP 0, 10-ns ticks (tools/pd_diag.py)
 };
-struct PdCtx { int tid, lane, wave; long long t0; gu64* err; bool local; };
-#define PD_NTW ((a.flags & 1) != 0)      // weight loads non-temporal (EMO_PD_NT=1) or default policy: the 8 groups read the same 76 MB within microseconds
+// t = thread index INSIDE the role (0..255), hw = wave inside the role (0..3)
+struct PdCtx { int t, lane, hw; long long t0; gu64* err; bool local; };
+#define PD_NTW ((a.flags & 1) != 0)      // weight loads non-temporal (EMO_PD_NT=1) or default policy (r04: no measurable difference)
 
 // LDS carve (bytes from the dynamic base; device functions reach the error flag as an LDS address, not through a generic pointer kept in a struct)
 constexpr int LDS_XIN = 0, LDS_XA = LDS_XIN + PD_GS * PD_XS * 2, LDS_X1 = LDS_XA + PD_GS * PD_XS * 2, LDS_FH = LDS_X1 + PD_GS * PD_XS * 2,
-              LDS_PART = LDS_FH + PD_GS * PD_FS * 2, LDS_ATT = LDS_PART + PD_NW * 4 * 64 * 4,
-              LDS_MISC = LDS_ATT + (3 * PD_DH + 2 * PD_F + 8 + PD_NW * PD_DH + 4 * 2 * 64 + 8) * 4, LDS_OM = LDS_MISC + 16, LDS_TOTAL = LDS_OM + PD_DH * PD_MF * 4;
+              LDS_PART = LDS_FH + PD_GS * PD_FS * 2, LDS_ATT = LDS_PART + PD_HW * 4 * 64 * 4,
+              LDS_LN = LDS_ATT + (3 * PD_DH + 2 * PD_F + 8 + PD_HW * PD_DH + 2 * 2 * 64 + 8) * 4, LDS_MISC = LDS_LN + 2 * 2 * PD_D * 4, LDS_OM = LDS_MISC + 16,
+              LDS_TOTAL = LDS_OM + PD_DH * PD_MF * 4;
 extern __shared__ __attribute__((aligned(16))) char pd_smem[];
 #define PD_SERR (*(int*)(pd_smem + LDS_MISC))
 
 #define PD_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define PD_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-// a granule: write-through (sc1) unless the census found the whole group on one XCD — then a plain store, which stays in that XCD's L2
+// a granule: write-through (sc1) unless the census found the whole group on one XCD — then a workgroup-scope (sc0) store, which stays in that XCD's L2
 #define PD_PUBLISH(p, v)                                                                   \
     do {                                                                                   \
         if (c.local) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
         else PD_STORE((p), (v));                                                           \
+    } while (0)
+// Workgroup barrier for LDS traffic ONLY (see the header): all 12 waves execute the same sequence of these.
+#define PD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define PD_SYNC_OR_LEAVE()          \
+    do {                            \
+        PD_BARRIER();               \
+        if (PD_SERR) return;        \
     } while (0)
 
 // wave-uniform: true = give up (the launch is over its time budget, or another workgroup already reported a failure)
@@ -102,27 +117,35 @@ __device__ __forceinline__ bool pd_spin_fail(unsigned& spins, const PdCtx& c, un
 }
 
 // NP x 16 B = NP pairs of granules per thread, agent scope (sc1: past the L1), ONE asm statement with its own wait: hipcc must not touch a
-// destination register before the data is there.  (vmcnt(0) also covers the phase-ahead loads issued before: in-order return anyway.)
+// destination register before the data is there.
 template <int NP> __device__ __forceinline__ void pd_poll(u32x4 (&v)[NP], const gu64* p);
 template <> __device__ __forceinline__ void pd_poll<1>(u32x4 (&v)[1], const gu64* p) {
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(p) : "memory");
 }
-template <> __device__ __forceinline__ void pd_poll<4>(u32x4 (&v)[4], const gu64* p) {
-    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
-                 "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p) : "memory");
+template <> __device__ __forceinline__ void pd_poll<2>(u32x4 (&v)[2], const gu64* p) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]) : "v"(p) : "memory");
+}
+template <> __device__ __forceinline__ void pd_poll<8>(u32x4 (&v)[8], const gu64* p) {
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %8, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:48 sc1\n\t"
+                 "global_load_dwordx4 %4, %8, off offset:64 sc1\n\tglobal_load_dwordx4 %5, %8, off offset:80 sc1\n\t"
+                 "global_load_dwordx4 %6, %8, off offset:96 sc1\n\tglobal_load_dwordx4 %7, %8, off offset:112 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]) : "v"(p) : "memory");
 }
 
-// All-gather of GS rows of W bf16 values (W / 2 granules per row) into LDS rows of `stride` elements.  Thread t owns the NP consecutive pairs
-// NP t .. of the buffer (a pair = 2 granules = 16 B = 4 values).  Returns the number of failed passes.
+// POLLERS: all-gather of GS rows of W bf16 values (W / 2 granules per row) into LDS rows of `stride` elements.  Poller thread t owns the NP
+// consecutive pairs NP t .. of the buffer (a pair = 2 granules = 16 B = 4 values); for W = 512 poller wave s owns exactly row s.
 template <int W>
-__device__ __forceinline__ unsigned pd_gather_rows(const gu64* buf, unsigned ep, bf16_t* dst, int stride, const PdCtx& c, unsigned code) {
-    constexpr int NP = PD_GS * W / 4 / PD_NT;
-    static_assert(NP == 1 || NP == 4, "pairs per thread");
+__device__ __forceinline__ unsigned pd_gather_rows(const gu64* buf, unsigned ep, bf16_t* dst, int stride, const PdCtx& c, unsigned code, u64* first_poll = nullptr) {
+    constexpr int NP = PD_GS * W / 4 / PD_HT;
+    static_assert(NP == 2 || NP == 8, "pairs per thread");
     u32x4 g[NP];
     unsigned spins = 0;
     for (;;) {
-        pd_poll<NP>(g, buf + 2 * NP * c.tid);
+        const u64 tp0 = first_poll && spins == 0 ? (u64)wall_clock64() : 0;
+        pd_poll<NP>(g, buf + 2 * NP * c.t);
+        if (first_poll && spins == 0) *first_poll = (u64)wall_clock64() - tp0;
         bool ok = true;
 #pragma unroll
         for (int i = 0; i < NP; ++i) ok = ok && g[i][1] == ep && g[i][3] == ep;
@@ -131,16 +154,16 @@ __device__ __forceinline__ unsigned pd_gather_rows(const gu64* buf, unsigned ep,
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int p = NP * c.tid + i, s = p / (W / 4), c4 = p % (W / 4);
+        const int p = NP * c.t + i, s = p / (W / 4), c4 = p % (W / 4);
         *(u32x2*)(dst + s * stride + 4 * c4) = (u32x2){g[i][0], g[i][2]};
     }
     return spins;
 }
 
-// The wave's share of a member's packed weights: T column tiles x KPW k-steps, one KB (64 lanes x 8 bf16) per fragment, straight into registers.
+// COMPUTE: the wave's share of a member's packed weights: T column tiles x KPW k-steps, one KB (64 lanes x 8 bf16) per fragment, into registers.
 template <int T, int KPW>
 __device__ __forceinline__ void pd_load_w(bf16x8 (&w)[T][KPW], const bf16_t* member_base, const PdCtx& c, bool nt) {
-    const bf16_t* p = member_base + (size_t)c.wave * (T * KPW * 512) + c.lane * 8;
+    const bf16_t* p = member_base + (size_t)c.hw * (T * KPW * 512) + c.lane * 8;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -149,20 +172,36 @@ __device__ __forceinline__ void pd_load_w(bf16x8 (&w)[T][KPW], const bf16_t* mem
             w[t][ks] = nt ? __builtin_nontemporal_load(q) : *q;
         }
 }
-
-// part[wave][t][stream][col] = x[stream, k-slice of the wave] . W[col, k-slice]   (x rows = rows 0..3 of the MFMA A operand, the rest zero)
+// fragments [I0, I1) of the same set (flat index t * KPW + ks): an operand set is requested in SLICES, one after each barrier the idle half passes,
+// so that no 48-64 KB burst sits in the CU's memory queue in front of the pollers' loads (r04 diagnostics: first poll 2.0 us behind a burst, 0.2 us
+// without one; the burst's issue itself stalled its wave for ~2 us)
+template <int T, int KPW, int I0, int I1>
+__device__ __forceinline__ void pd_load_w_part(bf16x8 (&w)[T][KPW], const bf16_t* member_base, const PdCtx& c, bool nt) {
+    const bf16_t* p = member_base + (size_t)c.hw * (T * KPW * 512) + c.lane * 8;
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+        const bf16x8* q = (const bf16x8*)(p + i * 512);
+        w[i / KPW][i % KPW] = nt ? __builtin_nontemporal_load(q) : *q;
+    }
+}
+// part[hw][t][stream][col] = x[stream, k-slice of the wave] . W[col, k-slice] (+ bias[t] from the role's wave 0): x rows = rows 0..3 of the
+// MFMA A operand, the rest zero; lane l < 16 ends up with column l of the 4 streams
 template <int T, int KPW>
-__device__ __forceinline__ void pd_gemv(const bf16x8 (&w)[T][KPW], const bf16_t* xs, int stride, float* part, const PdCtx& c) {
+__device__ __forceinline__ void pd_gemv(const bf16x8 (&w)[T][KPW], const float (&bias)[T], const bf16_t* xs, int stride, float* part, const PdCtx& c) {
     f32x4 acc[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < T; ++t) {
+        const float b = c.hw == 0 ? bias[t] : 0.f;
+        acc[t] = (f32x4){b, b, b, b};
+    }
     const int r = c.lane & 15, kg = c.lane >> 4;
 #pragma unroll
     for (int ks = 0; ks < KPW; ++ks) {
+        if (ks > 0 && (ks & 3) == 0) __builtin_amdgcn_sched_barrier(0);       // at most 4 A fragments in flight (16 hoisted reads = 64 registers)
         bf16x8 a;
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = (bf16_t)0.f;
-        if (r < PD_GS) a = *(const bf16x8*)(xs + r * stride + (c.wave * KPW + ks) * 32 + kg * 8);
+        if (r < PD_GS) a = *(const bf16x8*)(xs + r * stride + (c.hw * KPW + ks) * 32 + kg * 8);
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w[t][ks], acc[t], 0, 0, 0);
     }
@@ -170,14 +209,14 @@ __device__ __forceinline__ void pd_gemv(const bf16x8 (&w)[T][KPW], const bf16_t*
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) part[((c.wave * T + t) * 4 + i) * 16 + c.lane] = acc[t][i];
+            for (int i = 0; i < 4; ++i) part[((c.hw * T + t) * 4 + i) * 16 + c.lane] = acc[t][i];
     }
 }
 template <int T>
 __device__ __forceinline__ float pd_part_sum(const float* part, int t, int s, int col) {
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < PD_NW; ++w) v += part[((w * T + t) * 4 + s) * 16 + col];
+    for (int w = 0; w < PD_HW; ++w) v += part[((w * T + t) * 4 + s) * 16 + col];
     return v;
 }
 // Two neighbouring columns (even lane + the next lane) -> one granule, stored by the even lane.  Executed by whole waves.
@@ -188,7 +227,7 @@ __device__ __forceinline__ void pd_publish_pair(gu64* buf, int granule, unsigned
     if ((col & 1) == 0) PD_PUBLISH(buf + granule, ((u64)ep << 32) | (u64)(mine | (next << 16)));
 }
 // Sum over the 64 lanes, result in every lane: 4 DPP steps inside the 16-lane rows + the two lane swaps of rows4_sum — no LDS crossbar
-// (__shfl_xor = ds_bpermute: 12 dependent ~100-cycle round trips per LayerNorm row were 0.5 us of each LayerNorm phase).
+// (__shfl_xor = ds_bpermute: 12 dependent ~100-cycle round trips per LayerNorm row).
 __device__ __forceinline__ float pd_dpp_add(float v, const int ctrl_id) {
     const int x = __builtin_bit_cast(int, v);
     int y;
@@ -207,353 +246,494 @@ __device__ __forceinline__ float pd_wave_sum(float v) {
     v = pd_dpp_add(v, 3);
     return rows4_sum(v);
 }
-__device__ __forceinline__ void pd_ln_load(float (&g)[8], float (&b)[8], const float* gamma, const float* beta, const PdCtx& c) {
-    if (c.wave < PD_GS) {
+// POLLERS: LayerNorm of LDS row `hw` (the row this poller wave gathered itself), in place, gamma / beta from LDS (ln = [gamma 512 | beta 512]);
+// the arithmetic of layernorm_fwd_bf16_d512_kernel
+__device__ __forceinline__ void pd_ln_row(bf16_t* xs, const float* ln, float eps, const PdCtx& c) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // the wave's own row is in LDS
+    bf16_t* row = xs + c.hw * PD_XS + c.lane * 8;
+    const bf16x8 a = *(const bf16x8*)row;
+    float v[8], s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { g[i] = gamma[c.lane * 8 + i]; b[i] = beta[c.lane * 8 + i]; }
+    for (int i = 0; i < 8; ++i) { v[i] = (float)a[i]; s += v[i]; }
+    const float mu = pd_wave_sum(s) * (1.f / 512.f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float d = v[i] - mu; q += d * d; }
+    const float rs = rsqrtf(pd_wave_sum(q) * (1.f / 512.f) + eps);
+    const f32x4 g0 = *(const f32x4*)(ln + c.lane * 8), g1 = *(const f32x4*)(ln + c.lane * 8 + 4);
+    const f32x4 b0 = *(const f32x4*)(ln + PD_D + c.lane * 8), b1 = *(const f32x4*)(ln + PD_D + c.lane * 8 + 4);
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[i] = (bf16_t)((v[i] - mu) * rs * g0[i] + b0[i]);
+        o[4 + i] = (bf16_t)((v[4 + i] - mu) * rs * g1[i] + b1[i]);
     }
-}
-// LayerNorm of LDS row `wave` (waves 0..3), in place, the arithmetic of layernorm_fwd_bf16_d512_kernel
-__device__ __forceinline__ void pd_ln_rows(bf16_t* xs, const float (&g)[8], const float (&b)[8], float eps, const PdCtx& c) {
-    if (c.wave < PD_GS) {
-        bf16_t* row = xs + c.wave * PD_XS + c.lane * 8;
-        const bf16x8 a = *(const bf16x8*)row;
-        float v[8], s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { v[i] = (float)a[i]; s += v[i]; }
-        const float mu = pd_wave_sum(s) * (1.f / 512.f);
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { const float d = v[i] - mu; q += d * d; }
-        const float rs = rsqrtf(pd_wave_sum(q) * (1.f / 512.f) + eps);
-        bf16x8 o;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (bf16_t)((v[i] - mu) * rs * g[i] + b[i]);
-        *(bf16x8*)row = o;
-    }
+    *(bf16x8*)row = o;
 }
 
-// A per-phase copy of the context whose thread index the optimiser cannot see through: without it every phase's per-thread addresses are
-// hoisted out of the layer loop and kept in ~100 registers, and the phase-ahead weight registers get spilled (= waited for) right after the load.
+// A per-iteration copy of the context whose thread index the optimiser cannot see through: otherwise every per-thread address of the layer loop
+// is hoisted out of it and held in (spilled) registers.
 __device__ __forceinline__ PdCtx pd_fresh(const PdCtx& c) {
     PdCtx r = c;
-    asm volatile("" : "+v"(r.tid));
-    r.lane = r.tid & 63;
+    asm volatile("" : "+v"(r.t));
+    r.lane = r.t & 63;
     return r;
 }
 
-// Workgroup barrier for LDS traffic ONLY: __syncthreads() carries a workgroup-scope fence, which on gfx950 is s_waitcnt vmcnt(0) — it would
-// wait for the phase-ahead HBM loads at every barrier (measured r04: 2-3 us per phase).  Cross-wave data here lives in LDS (lgkmcnt).
-#define PD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#define PD_SYNC_OR_LEAVE()          \
-    do {                            \
-        PD_BARRIER();               \
-        if (PD_SERR) return;        \
+// keep the next operand set's loads BEHIND the MFMAs that free its registers (hoisted above them, both sets are live and hipcc spills)
+#define PD_SCHED_FENCE()                         \
+    do {                                         \
+        asm volatile("" ::: "memory");           \
+        __builtin_amdgcn_sched_barrier(0);       \
     } while (0)
 
 #define PD_DIAG(l, ph, k, val)                                                                          \
     do {                                                                                               \
-        if (a.diag && g == 0 && c.tid == 0) a.diag[(((size_t)m * 16 + (l)) * 8 + (ph)) * 4 + (k)] = (u64)(val); \
+        if (a.diag && g == 0 && c.t == 0) a.diag[(((size_t)m * 16 + (l)) * 8 + (ph)) * 4 + (k)] = (u64)(val); \
     } while (0)
 #define PD_NOW() ((u64)wall_clock64())
 
-__global__ __launch_bounds__(PD_NT, 2) void pd_step_kernel(PdArgs a) {
+__global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
     bf16_t* xin = (bf16_t*)(pd_smem + LDS_XIN);        // layer input (post-LN2 / embedding), kept for the out-projection's residual
     bf16_t* xa = (bf16_t*)(pd_smem + LDS_XA);          // attention output rows
     bf16_t* x1 = (bf16_t*)(pd_smem + LDS_X1);          // post-LN1 rows, kept for the FFN2 residual
     bf16_t* fh = (bf16_t*)(pd_smem + LDS_FH);          // FFN hidden rows
-    float* part = (float*)(pd_smem + LDS_PART);        // [8 waves][<= 4 tiles][4 streams][16 columns]
+    float* part = (float*)(pd_smem + LDS_PART);        // [4 waves][<= 4 tiles][4 streams][16 columns]
     float* xq = (float*)(pd_smem + LDS_ATT);           // attention scratch: q | k | v rows of (head, stream) as fp32
     float* xk = xq + PD_DH;
     float* xv = xk + PD_DH;
     float* fq = xv + PD_DH;                            // phi(q), phi(k)
     float* fk = fq + PD_F;
     float* dpart = fk + PD_F;                          // [8]
-    float* num = dpart + 8;                            // [8 waves][64]
-    float* upart = num + PD_NW * PD_DH;                // [4 d-quarters][q | k][64 projections]
-    float* npart = upart + 4 * 2 * 64;                 // [4][2] partial |x|^2
+    float* num = dpart + 8;                            // [4 waves][64]
+    float* upart = num + PD_HW * PD_DH;                // [2 d-halves][q | k][64 projections]
+    float* npart = upart + 2 * 2 * 64;                 // [2][2] partial |x|^2
+    float* ln1 = (float*)(pd_smem + LDS_LN);           // [gamma | beta] of norm1 of the layer (written by half A before P2, read by the pollers in P4)
+    float* ln2 = ln1 + 2 * PD_D;                       // norm2 (written by half A in P4, read by the pollers in the next P1 / before the logits)
     int* s_misc = (int*)(pd_smem + LDS_MISC);          // [0] error flag, [1] launch counter, [2] census: group on one XCD
     float* oml = (float*)(pd_smem + LDS_OM);           // omega of the layer [64][64]
 
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), role = wave >> 2;      // 0 = A, 1 = B, 2 = pollers
     PdCtx c;
-    c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6);
+    c.t = tid & (PD_HT - 1); c.lane = tid & 63; c.hw = wave & 3;
     c.t0 = (long long)wall_clock64();
     c.err = (gu64*)a.sync + (size_t)PD_NG * PD_GSTRIDE;
     c.local = false;
     const int g = blockIdx.x % PD_NG, m = blockIdx.x / PD_NG;
     if (g * PD_GS >= a.n_streams) return;
     gu64* gs = (gu64*)a.sync + (size_t)g * PD_GSTRIDE;
-    if (c.tid == 0) { s_misc[0] = 0; s_misc[1] = (int)(unsigned)PD_LOAD(gs + OFF_CNT); s_misc[2] = 0; }
-    PD_BARRIER();
-    const unsigned lc = (unsigned)s_misc[1], ep0 = lc * 128u;
     const int hm = m >> 2, jm = m & 3;                                // P1: head / 16-dim slice; P2: head / stream
-    int xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 15;
-    if (c.tid == 0) PD_STORE(gs + OFF_CEN + m, ((u64)(ep0 + 127u) << 32) | (u64)(unsigned)xcc);       // census entry: always write-through
-    PD_DIAG(15, 0, 0, c.t0);
-    PD_DIAG(15, 0, 1, xcc);
-    PD_DIAG(15, 1, 0, (u64)clock64());                               // shader-clock cycles: with the 100-MHz stamps = the effective clock
-
-    // ---------------------------------------------------------------- phase-ahead loads of layer 0's first two phases
+    const int L_ = a.n_layers;
     const PdLayer* LY = a.layers;
-    bf16x8 wq[3][2], wo[1][2], w1[4][2], w2[1][8];
-    f32x4 st[4], om0, om1;
-    float zold = 0.f, bq = 0.f, bo = 0.f, b1 = 0.f, b2 = 0.f, lg[8], lb[8];
-    const int64_t sh = ((int64_t)g * PD_GS + jm) * PD_H + hm;         // P2: (stream, head) of this member
-    pd_load_w<3, 2>(wq, LY[0].wqkv + (size_t)m * (PD_NW * 3 * 2 * 512), c, PD_NTW);
-    if (c.tid < 192) bq = LY[0].bqkv[(c.tid >> 6) * PD_D + hm * PD_DH + jm * 16 + (c.tid & 15)];
-#define PD_LOAD_STATE(Lp, cx)     /* P2 state mapping: 16 threads per state row, 32 rows per pass, 4 passes */ \
-    do {                                                                                                   \
-        const int d4 = ((cx).tid & 15) * 4, fg = (cx).tid >> 4;                                            \
-        const float* Sb_ = (Lp).S + sh * (PD_F * PD_DH);                                                   \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) st[i] = *(const f32x4*)(Sb_ + (fg + 32 * i) * PD_DH + d4); \
-        om0 = *(const f32x4*)((Lp).omega + (cx).tid * 8);                                                  \
-        om1 = *(const f32x4*)((Lp).omega + (cx).tid * 8 + 4);                                              \
-        if ((cx).tid < PD_F) zold = (Lp).z[sh * PD_F + (cx).tid];                                          \
-    } while (0)
-    PD_LOAD_STATE(LY[0], c);
-    pd_load_w<1, 2>(wo, LY[0].wo + (size_t)m * (PD_NW * 1 * 2 * 512), c, PD_NTW);
-    if (c.tid < 64) bo = LY[0].bo[m * 16 + (c.tid & 15)];
+    const bool has_logits = m < (a.n_token + 15) / 16;                // member m owns logits tile m (uniform over the workgroup)
+    const bool nt = PD_NTW;
 
-    // ---------------------------------------------------------------- embedding (every member builds its group's 4 rows itself)
-    {
-        const int s = c.tid >> 7, c4 = (c.tid & 127) * 4;
-        const int64_t stream = (int64_t)g * PD_GS + s;
-        const int64_t tk = a.tok[stream], sg = a.seg ? a.seg[stream] : 0, pos = a.pos0 + (a.pos_ids ? a.pos_ids[stream] : 0);
-        const f32x4 e = *(const f32x4*)(a.E + tk * PD_D + c4);
-        f32x4 sv = {0.f, 0.f, 0.f, 0.f};
-        if (a.seg) sv = *(const f32x4*)(a.Sg + sg * PD_D + c4);
-        const f32x4 p = *(const f32x4*)(a.pe + pos * PD_D + c4);
-        bf16x4 o;
+    if (role == 2) {
+        // ========================================================================================== POLLERS (waves 8-11)
+        if (c.t == 0) { s_misc[0] = 0; s_misc[2] = 0; }
+        const unsigned ep0 = (unsigned)PD_LOAD(gs + OFF_CNT) * 128u;                // (every thread reads the counter itself: member 0 bumps it after the last phase)
+        int xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 15;
+        if (c.t == 0) PD_STORE(gs + OFF_CEN + m, ((u64)(ep0 + 127u) << 32) | (u64)(unsigned)xcc);       // census entry: always write-through
+        PD_DIAG(15, 0, 0, c.t0);
+        PD_DIAG(15, 0, 1, xcc);
+        PD_DIAG(15, 1, 0, (u64)clock64());                           // shader-clock cycles: with the 100-MHz stamps = the effective clock
+        {   // embedding: the group's 4 rows, 8 columns per poller thread (row s = poller wave s)
+            const int s = c.hw, c8 = c.lane * 8;
+            const int64_t stream = (int64_t)g * PD_GS + s;
+            const int64_t tk = a.tok[stream], sg = a.seg ? a.seg[stream] : 0, pos = a.pos0 + (a.pos_ids ? a.pos_ids[stream] : 0);
+            bf16x8 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float v = e[i] * a.emb_scale;                             // reference order: emb.mul_(scale); emb += seg.mul_(scale); + pe
-            v += sv[i] * a.emb_scale;
-            v += p[i];
-            o[i] = (bf16_t)v;
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const f32x4 e = *(const f32x4*)(a.E + tk * PD_D + c8 + 4 * h2);
+                f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+                if (a.seg) sv = *(const f32x4*)(a.Sg + sg * PD_D + c8 + 4 * h2);
+                const f32x4 p = *(const f32x4*)(a.pe + pos * PD_D + c8 + 4 * h2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = e[i] * a.emb_scale;                     // reference order: emb.mul_(scale); emb += seg.mul_(scale); + pe
+                    v += sv[i] * a.emb_scale;
+                    v += p[i];
+                    o[4 * h2 + i] = (bf16_t)v;
+                }
+            }
+            *(bf16x8*)(xin + s * PD_XS + c8) = o;
         }
-        *(bf16x4*)(xin + s * PD_XS + c4) = o;
-    }
-    // ---------------------------------------------------------------- census: is the whole group on one XCD?
-    if (c.wave == 0) {
-        u64 v = 0;
-        unsigned spins = 0;
-        bool got = true;
-        for (;;) {
-            bool ok = true;
-            if (c.lane < PD_GM) { v = PD_LOAD(gs + OFF_CEN + c.lane); ok = (unsigned)(v >> 32) == ep0 + 127u; }
-            if (__all(ok)) break;
-            if (pd_spin_fail(spins, c, 0x700u)) { got = false; break; }
+        if (c.hw == 0) {                                              // census: is the whole group on one XCD?
+            u64 v = 0;
+            unsigned spins = 0;
+            bool got = true;
+            for (;;) {
+                bool ok = true;
+                if (c.lane < PD_GM) { v = PD_LOAD(gs + OFF_CEN + c.lane); ok = (unsigned)(v >> 32) == ep0 + 127u; }
+                if (__all(ok)) break;
+                if (pd_spin_fail(spins, c, 0x700u)) { got = false; break; }
+            }
+            const bool same = c.lane >= PD_GM || (unsigned)v == (unsigned)xcc;
+            const bool all_same = __all(same);
+            if (c.lane == 0) s_misc[2] = (got && all_same) ? 1 : 0;
         }
-        const bool same = c.lane >= PD_GM || (unsigned)v == (unsigned)xcc;
-        if (c.lane == 0) s_misc[2] = (got && __all(same)) ? 1 : 0;
-    }
-    PD_SYNC_OR_LEAVE();
-    c.local = s_misc[2] != 0;
-    PD_DIAG(15, 0, 3, c.local ? 1 : 0);
-
-    for (int l = 0; l < a.n_layers; ++l) {
-        const PdLayer L = LY[l];
-        const bool last = l + 1 == a.n_layers;
-        const unsigned ep = ep0 + (unsigned)l * 8u;
-        // ============================================================ P1: q / k / v columns of (head hm, dims 16 jm ..)
-        {
-            const PdCtx cc = pd_fresh(c);
+        PD_SYNC_OR_LEAVE();                                           // B0
+        c.local = s_misc[2] != 0;
+        PD_DIAG(15, 0, 3, c.local ? 1 : 0);
+        for (int l = 0; l < L_; ++l) {
+            const unsigned ep = ep0 + (unsigned)l * 8u;
+            // ---- P1
             PD_DIAG(l, 1, 0, PD_NOW());
             if (l > 0) {
-                const unsigned sp = pd_gather_rows<PD_D>(gs + OFF_E1, ep - 8u + 5u, xin, PD_XS, cc, 0x100u + l);
-                PD_SYNC_OR_LEAVE();
+                const unsigned sp = pd_gather_rows<PD_D>(gs + OFF_E1, ep - 8u + 5u, xin, PD_XS, c, 0x100u + l);
+                if (!PD_SERR) pd_ln_row(xin, ln2, a.ln_eps, c);
                 PD_DIAG(l, 1, 3, sp);
-                pd_load_w<1, 2>(wo, L.wo + (size_t)m * (PD_NW * 1 * 2 * 512), cc, PD_NTW);      // two phases ahead: P3's weights and bias
-                if (cc.tid < 64) bo = L.bo[m * 16 + (cc.tid & 15)];
-                pd_ln_rows(xin, lg, lb, a.ln_eps, cc);
-                PD_BARRIER();
             }
+            PD_SYNC_OR_LEAVE();                                       // 1a: xin ready
             PD_DIAG(l, 1, 1, PD_NOW());
-            pd_gemv<3, 2>(wq, xin, PD_XS, part, cc);
-            PD_BARRIER();
-            if (cc.tid < 192) {
-                const int t = cc.tid >> 6, s = (cc.tid >> 4) & 3, col = cc.tid & 15;
-                const float v = pd_part_sum<3>(part, t, s, col) + bq;
-                pd_publish_pair(gs + OFF_E2, ((hm * PD_GS + s) * 3 + t) * 32 + ((jm * 16 + col) >> 1), ep + 1u, v, col, cc);
-            }
-            PD_DIAG(l, 1, 2, PD_NOW());
-        }
-        // ============================================================ P2: FAVOR+ recurrent step of (head hm, stream jm)
-        {
-            const PdCtx cc = pd_fresh(c);
+            PD_BARRIER();                                             // 1b: partial products ready (half A sums and publishes them)
+            // ---- P2: q_h | k_h | v_h of (head hm, stream jm): 96 granules = 48 pairs
             PD_DIAG(l, 2, 0, PD_NOW());
-            float* Sb = L.S + sh * (PD_F * PD_DH);
-            const int d4 = (cc.tid & 15) * 4, fg = cc.tid >> 4;
-            unsigned sp = 0;
-            if (cc.wave == 0) {                                            // 96 granules = 48 pairs: q_h | k_h | v_h of the stream
+            if (c.hw == 0) {
                 const gu64* buf = gs + OFF_E2 + (hm * PD_GS + jm) * 96;
                 u32x4 gq[1];
                 gq[0] = (u32x4){0u, ep + 1u, 0u, ep + 1u};
+                unsigned sp = 0;
                 for (;;) {
-                    if (cc.lane < 48) pd_poll<1>(gq, buf + 2 * cc.lane);
+                    if (c.lane < 48) pd_poll<1>(gq, buf + 2 * c.lane);
                     if (__all(gq[0][1] == ep + 1u && gq[0][3] == ep + 1u)) break;
-                    if (pd_spin_fail(sp, cc, 0x200u + l)) break;
+                    if (pd_spin_fail(sp, c, 0x200u + l)) break;
                 }
-                if (cc.lane < 48) {
-                    float* dst = xq + (cc.lane >> 4) * PD_DH + (cc.lane & 15) * 4;      // xq, xk, xv are contiguous
+                if (c.lane < 48) {
+                    float* dst = xq + (c.lane >> 4) * PD_DH + (c.lane & 15) * 4;      // xq, xk, xv are contiguous
                     dst[0] = __builtin_bit_cast(float, gq[0][0] << 16);
                     dst[1] = __builtin_bit_cast(float, gq[0][0] & 0xffff0000u);
                     dst[2] = __builtin_bit_cast(float, gq[0][2] << 16);
                     dst[3] = __builtin_bit_cast(float, gq[0][2] & 0xffff0000u);
                 }
+                PD_DIAG(l, 2, 3, sp);
             }
-            *(f32x4*)(oml + cc.tid * 8) = om0;                             // omega [64 d][64 m] of the layer -> LDS
-            *(f32x4*)(oml + cc.tid * 8 + 4) = om1;
-            PD_SYNC_OR_LEAVE();
-            PD_DIAG(l, 2, 3, sp);
+            PD_SYNC_OR_LEAVE();                                       // 2a
             PD_DIAG(l, 2, 1, PD_NOW());
-            pd_load_w<4, 2>(w1, L.w1 + (size_t)m * (PD_NW * 4 * 2 * 512), cc, PD_NTW);      // two phases ahead: P4
-            if (cc.tid < 256) b1 = L.b1[m * 64 + (cc.tid >> 6) * 16 + (cc.tid & 15)];
-            pd_ln_load(lg, lb, L.g1, L.be1, cc);
-            // projections: thread = (d-quarter, q | k, projection): 16 of the 64 terms each
+            PD_BARRIER();                                             // 2b
+            PD_BARRIER();                                             // 2c
+            PD_BARRIER();                                             // 2d
+            PD_DIAG(l, 2, 2, PD_NOW());
+            // ---- P3
+            PD_DIAG(l, 3, 0, PD_NOW());
             {
-                const int col = cc.tid & 63, which = (cc.tid >> 6) & 1, qd = cc.tid >> 7;
+                u64 fp = 0;
+                const unsigned sp = pd_gather_rows<PD_D>(gs + OFF_E3, ep + 2u, xa, PD_XS, c, 0x300u + l, a.diag ? &fp : nullptr);
+                PD_DIAG(l, 6, 2, fp);
+                PD_DIAG(l, 3, 3, sp);
+            }
+            PD_SYNC_OR_LEAVE();                                       // 3a
+            PD_DIAG(l, 3, 1, PD_NOW());
+            PD_BARRIER();                                             // 3b
+            // ---- P4
+            PD_DIAG(l, 4, 0, PD_NOW());
+            {
+                u64 fp = 0;
+                const unsigned sp = pd_gather_rows<PD_D>(gs + OFF_E4, ep + 3u, x1, PD_XS, c, 0x400u + l, a.diag ? &fp : nullptr);
+                PD_DIAG(l, 6, 1, fp);
+                if (!PD_SERR) pd_ln_row(x1, ln1, a.ln_eps, c);
+                PD_DIAG(l, 4, 3, sp);
+            }
+            PD_SYNC_OR_LEAVE();                                       // 4a
+            PD_DIAG(l, 4, 1, PD_NOW());
+            PD_BARRIER();                                             // 4b
+            // ---- P5
+            PD_DIAG(l, 5, 0, PD_NOW());
+            {
+                u64 fp = 0;
+                const unsigned sp = pd_gather_rows<PD_FF>(gs + OFF_E5, ep + 4u, fh, PD_FS, c, 0x500u + l, a.diag ? &fp : nullptr);
+                PD_DIAG(l, 6, 0, fp);
+                PD_DIAG(l, 5, 3, sp);
+            }
+            PD_SYNC_OR_LEAVE();                                       // 5a
+            PD_DIAG(l, 5, 1, PD_NOW());
+            PD_BARRIER();                                             // 5b
+        }
+        if (!has_logits) return;
+        pd_gather_rows<PD_D>(gs + OFF_E1, ep0 + (unsigned)(L_ - 1) * 8u + 5u, xin, PD_XS, c, 0x600u);
+        if (!PD_SERR) pd_ln_row(xin, ln2, a.ln_eps, c);
+        PD_SYNC_OR_LEAVE();                                           // Fa
+        PD_BARRIER();                                                 // Fb
+        PD_DIAG(15, 0, 2, PD_NOW());
+        PD_DIAG(15, 1, 1, (u64)clock64());
+        return;
+    }
+
+    if (role == 0) {
+        // ========================================================================================== HALF A (waves 0-3): P1 and P4 products
+        bf16x8 wq[3][4], w1[4][4];
+        float bq[3], b1[4];
+        f32x4 lnv, ln1v, om[4];
+        // operand set of P1 (+ what half A hands to the others through LDS before P2: omega for half B, LayerNorm1's parameters for the pollers)
+#define PD_LOAD_A0(Lp)                                                                                     \
+    do {                                                                                                   \
+        pd_load_w_part<3, 4, 0, 4>(wq, (Lp).wqkv + (size_t)m * (PD_HW * 3 * 4 * 512), cc, nt);               \
+        _Pragma("unroll") for (int t = 0; t < 3; ++t) bq[t] = (Lp).bqkv[t * PD_D + hm * PD_DH + jm * 16 + lc16]; \
+    } while (0)
+#define PD_LOAD_A1(Lp)                                                                                     \
+    do {                                                                                                   \
+        pd_load_w_part<3, 4, 4, 8>(wq, (Lp).wqkv + (size_t)m * (PD_HW * 3 * 4 * 512), cc, nt);               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) om[i] = *(const f32x4*)((Lp).omega + cc.t * 16 + 4 * i); \
+    } while (0)
+#define PD_LOAD_A2(Lp)                                                                                     \
+    do {                                                                                                   \
+        pd_load_w_part<3, 4, 8, 12>(wq, (Lp).wqkv + (size_t)m * (PD_HW * 3 * 4 * 512), cc, nt);              \
+        ln1v = *(const f32x4*)((cc.t < 128 ? (Lp).g1 : (Lp).be1) + (cc.t & 127) * 4);                      \
+    } while (0)
+#define PD_LOAD_A(Lp) do { PD_LOAD_A0(Lp); PD_LOAD_A1(Lp); PD_LOAD_A2(Lp); } while (0)
+        {
+            const PdCtx cc = c;
+            const int lc16 = cc.lane & 15;
+            PD_LOAD_A(LY[0]);
+        }
+        PD_SYNC_OR_LEAVE();                                           // B0
+        c.local = s_misc[2] != 0;
+        const unsigned lc = (unsigned)PD_LOAD(gs + OFF_CNT), ep0 = lc * 128u;
+        for (int l = 0; l < L_; ++l) {
+            const PdLayer L = LY[l];
+            const bool last = l + 1 == L_;
+            const unsigned ep = ep0 + (unsigned)l * 8u;
+            PdCtx cc = pd_fresh(c);
+            cc.local = c.local;
+            const int lc16 = cc.lane & 15;
+            PD_SYNC_OR_LEAVE();                                       // 1a
+            const u64 tg1 = a.diag ? PD_NOW() : 0;
+            pd_gemv<3, 4>(wq, bq, xin, PD_XS, part, cc);
+            PD_SCHED_FENCE();
+            if (a.diag) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PD_DIAG(l, 7, 0, PD_NOW() - tg1); }
+            PD_BARRIER();                                             // 1b
+            // the half that computed a product sums its partials and publishes: the pollers' next poll then never waits for a store's ~2-us
+            // acknowledgement (r04 diagnostics: first poll 0.19 us after a phase the pollers did not publish in, 1.8-2.0 us after one they did)
+            if (cc.t < 192) {
+                const int t = cc.t >> 6, s = (cc.t >> 4) & 3, col = cc.t & 15;
+                pd_publish_pair(gs + OFF_E2, ((hm * PD_GS + s) * 3 + t) * 32 + ((jm * 16 + col) >> 1), ep + 1u, pd_part_sum<3>(part, t, s, col), col, cc);
+            }
+            PD_DIAG(l, 1, 2, PD_NOW());
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(f32x4*)(oml + cc.t * 16 + 4 * i) = om[i];       // omega [64 d][64 m] of the layer for half B
+            *(f32x4*)(ln1 + cc.t * 4) = ln1v;                          // [gamma | beta]: threads 0..127 gamma, 128..255 beta
+            PD_SCHED_FENCE();
+            // (requested AFTER the publish: a 64-KB burst in front of it held the partial sums back by ~2 us — the issue itself stalls on the full queue)
+            // next operand set: P4's FFN1 fragments + bias, and LayerNorm2's parameters for the pollers (handed over through LDS in P4)
+            const bf16_t* w1p = L.w1 + (size_t)m * (PD_HW * 4 * 4 * 512);
+            pd_load_w_part<4, 4, 0, 2>(w1, w1p, cc, nt);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b1[t] = L.b1[m * 64 + t * 16 + lc16];
+            lnv = *(const f32x4*)((cc.t < 128 ? L.g2 : L.be2) + (cc.t & 127) * 4);
+            PD_SYNC_OR_LEAVE();                                       // 2a
+            pd_load_w_part<4, 4, 2, 4>(w1, w1p, cc, nt);
+            PD_BARRIER();                                             // 2b
+            pd_load_w_part<4, 4, 4, 6>(w1, w1p, cc, nt);
+            PD_BARRIER();                                             // 2c
+            pd_load_w_part<4, 4, 6, 8>(w1, w1p, cc, nt);
+            PD_BARRIER();                                             // 2d
+            pd_load_w_part<4, 4, 8, 10>(w1, w1p, cc, nt);
+            PD_SYNC_OR_LEAVE();                                       // 3a
+            pd_load_w_part<4, 4, 10, 13>(w1, w1p, cc, nt);
+            PD_BARRIER();                                             // 3b
+            pd_load_w_part<4, 4, 13, 16>(w1, w1p, cc, nt);
+            *(f32x4*)(ln2 + cc.t * 4) = lnv;                           // [gamma | beta]: threads 0..127 gamma, 128..255 beta
+            PD_SYNC_OR_LEAVE();                                       // 4a
+            const u64 tg4 = a.diag ? PD_NOW() : 0;
+            pd_gemv<4, 4>(w1, b1, x1, PD_XS, part, cc);
+            PD_SCHED_FENCE();
+            if (a.diag) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PD_DIAG(l, 7, 1, PD_NOW() - tg4); }
+            PD_BARRIER();                                             // 4b
+            {
+                const int t = cc.t >> 6, s = (cc.t >> 4) & 3, col = cc.t & 15, gc = m * 64 + t * 16 + col;
+                pd_publish_pair(gs + OFF_E5, s * (PD_FF / 2) + (gc >> 1), ep + 4u, fmaxf(pd_part_sum<4>(part, t, s, col), 0.f), col, cc);
+            }
+            PD_DIAG(l, 4, 2, PD_NOW());
+            PD_SCHED_FENCE();
+            if (!last) {
+                PD_LOAD_A0(LY[l + 1]);
+            } else {                                                  // (every register of the set is overwritten on both paths: the old set is dead above)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    bq[t] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) wq[t][ks][i] = (bf16_t)0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) om[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                ln1v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (has_logits) {                                     // the logits tile reuses the first q/k/v fragment set
+                    bf16x8 wl[1][4];
+                    pd_load_w<1, 4>(wl, a.wout + (size_t)m * (PD_HW * 1 * 4 * 512), cc, nt);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) wq[0][ks] = wl[0][ks];
+                    bq[0] = (m * 16 + lc16) < a.n_token ? a.bout[m * 16 + lc16] : 0.f;
+                }
+            }
+            PD_SYNC_OR_LEAVE();                                       // 5a
+            if (!last) PD_LOAD_A1(LY[l + 1]);
+            PD_BARRIER();                                             // 5b
+            if (!last) PD_LOAD_A2(LY[l + 1]);
+        }
+        if (!has_logits) return;
+        PD_SYNC_OR_LEAVE();                                           // Fa
+        {
+            bf16x8 wl[1][4];
+            float bl[1] = {bq[0]};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wl[0][ks] = wq[0][ks];
+            pd_gemv<1, 4>(wl, bl, xin, PD_XS, part, c);
+        }
+        PD_BARRIER();                                                 // Fb
+        if (c.t < 64) {
+            const int s = c.t >> 4, col = c.t & 15, gc = m * 16 + col;
+            if (gc < a.n_token) a.logits[((int64_t)g * PD_GS + s) * a.n_token + gc] = pd_part_sum<1>(part, 0, s, col);
+        }
+        // member 0 gathered the last edge from EVERY member of the group, so all of them have long read the counter
+        if (m == 0 && c.t == 0) PD_STORE(gs + OFF_CNT, (u64)(lc + 1u));
+        return;
+    }
+
+    // ============================================================================================== HALF B (waves 4-7): P2, P3, P5
+    {
+        bf16x8 wo[1][4], w2[1][16];
+        float bo[1], b2[1];
+        f32x4 st[8];
+        float zold = 0.f;
+        const int64_t sh = ((int64_t)g * PD_GS + jm) * PD_H + hm;     // (stream, head) of this member
+#define PD_LOAD_B(Lp)                                                                                      \
+    do {                                                                                                   \
+        pd_load_w<1, 4>(wo, (Lp).wo + (size_t)m * (PD_HW * 1 * 4 * 512), cc, nt);                           \
+        bo[0] = (Lp).bo[m * 16 + lc16];                                                                    \
+        const float* Sb_ = (Lp).S + sh * (PD_F * PD_DH);                                                   \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) st[i] = *(const f32x4*)(Sb_ + (fg + 16 * i) * PD_DH + d4); \
+        if (cc.t < PD_F) zold = (Lp).z[sh * PD_F + cc.t];                                                  \
+    } while (0)
+        {
+            const PdCtx cc = c;
+            const int lc16 = cc.lane & 15, d4 = (cc.t & 15) * 4, fg = cc.t >> 4;
+            PD_LOAD_B(LY[0]);
+        }
+        PD_SYNC_OR_LEAVE();                                           // B0
+        c.local = s_misc[2] != 0;
+        const unsigned ep0 = (unsigned)PD_LOAD(gs + OFF_CNT) * 128u;  // (member 0 bumps the counter only after every member's last phase)
+        for (int l = 0; l < L_; ++l) {
+            const PdLayer L = LY[l];
+            const bool last = l + 1 == L_;
+            const unsigned ep = ep0 + (unsigned)l * 8u;
+            float* Sb = L.S + sh * (PD_F * PD_DH);
+            PdCtx cc = pd_fresh(c);
+            cc.local = c.local;
+            const int lc16 = cc.lane & 15, d4 = (cc.t & 15) * 4, fg = cc.t >> 4;      // state mapping: 16 threads per state row, 16 rows per pass, 8 passes
+            PD_SYNC_OR_LEAVE();                                       // 1a
+            if (l > 0) {                                              // (layer 0's slice was requested before the loop)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st[i] = *(const f32x4*)(Sb + (fg + 16 * i) * PD_DH + d4);
+            }
+            PD_BARRIER();                                             // 1b
+            if (l > 0) {
+#pragma unroll
+                for (int i = 4; i < 8; ++i) st[i] = *(const f32x4*)(Sb + (fg + 16 * i) * PD_DH + d4);
+                if (cc.t < PD_F) zold = L.z[sh * PD_F + cc.t];
+            }
+            // ---- P2: the recurrent step
+            PD_SYNC_OR_LEAVE();                                       // 2a: q | k | v rows (poller wave 0) and omega (half A) staged
+            {   // projections: thread = (d-half, q | k, projection): 32 of the 64 terms each
+                const int col = cc.t & 63, which = (cc.t >> 6) & 1, hd = cc.t >> 7;
                 const float* xx = which ? xk : xq;
                 float u = 0.f, nn = 0.f;
-#pragma unroll
-                for (int d = 0; d < 16; ++d) {
-                    const float xv_ = xx[qd * 16 + d];
-                    u += xv_ * oml[(qd * 16 + d) * PD_MF + col];
+#pragma unroll 8
+                for (int d = 0; d < 32; ++d) {
+                    const float xv_ = xx[hd * 32 + d];
+                    u += xv_ * oml[(hd * 32 + d) * PD_MF + col];
                     nn += xv_ * xv_;
                 }
-                upart[(qd * 2 + which) * 64 + col] = u;
-                if (col == 0) npart[qd * 2 + which] = nn;
+                upart[(hd * 2 + which) * 64 + col] = u;
+                if (col == 0) npart[hd * 2 + which] = nn;
             }
-            PD_BARRIER();
+            PD_BARRIER();                                             // 2b
             const float cs = rsqrtf(sqrtf((float)PD_DH)), half_ln_f = 0.5f * logf((float)PD_F);
             float dn = 0.f;
-            if (cc.tid < PD_F) {
-                const int col = cc.tid & (PD_MF - 1);
-                const float sgn = cc.tid < PD_MF ? 1.f : -1.f;
-                const float uq = (upart[col] + upart[128 + col]) + (upart[256 + col] + upart[384 + col]);
-                const float uk = (upart[64 + col] + upart[192 + col]) + (upart[320 + col] + upart[448 + col]);
-                const float nq = (npart[0] + npart[2]) + (npart[4] + npart[6]), nk = (npart[1] + npart[3]) + (npart[5] + npart[7]);
+            if (cc.t < PD_F) {
+                const int col = cc.t & (PD_MF - 1);
+                const float sgn = cc.t < PD_MF ? 1.f : -1.f;
+                const float uq = upart[col] + upart[128 + col], uk = upart[64 + col] + upart[192 + col];
+                const float nq = npart[0] + npart[2], nk = npart[1] + npart[3];
                 const float pq = __expf(sgn * cs * uq - (0.5f * cs * cs * nq + half_ln_f));
                 const float pk = __expf(sgn * cs * uk - (0.5f * cs * cs * nk + half_ln_f));
-                fq[cc.tid] = pq;
-                fk[cc.tid] = pk;
+                fq[cc.t] = pq;
+                fk[cc.t] = pk;
                 const float z = zold + pk;
-                L.z[sh * PD_F + cc.tid] = z;
+                L.z[sh * PD_F + cc.t] = z;
                 dn = pq * z;
             }
             dn = pd_wave_sum(dn);
-            if (cc.lane == 0) dpart[cc.wave] = dn;
-            PD_BARRIER();
-            const f32x4 vd = {xv[d4], xv[d4 + 1], xv[d4 + 2], xv[d4 + 3]};
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (cc.lane == 0) dpart[cc.hw] = dn;
+            PD_BARRIER();                                             // 2c
+            {
+                const f32x4 vd = {xv[d4], xv[d4 + 1], xv[d4 + 2], xv[d4 + 3]};
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int f = fg + 32 * i;
-                const f32x4 sv = st[i] + fk[f] * vd;
-                *(f32x4*)(Sb + f * PD_DH + d4) = sv;
-                acc += fq[f] * sv;
+                for (int i = 0; i < 8; ++i) {
+                    const int f = fg + 16 * i;
+                    const f32x4 sv = st[i] + fk[f] * vd;
+                    *(f32x4*)(Sb + f * PD_DH + d4) = sv;
+                    acc += fq[f] * sv;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = rows4_sum(acc[i]);   // the wave's 4 rows per pass sit in lanes l, l^16, l^32, l^48
+                if (cc.lane < 16) *(f32x4*)(num + cc.hw * PD_DH + d4) = acc;
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = rows4_sum(acc[i]);       // the wave's 4 rows per pass sit in lanes l, l^16, l^32, l^48
-            if (cc.lane < 16) *(f32x4*)(num + cc.wave * PD_DH + d4) = acc;
-            PD_BARRIER();
-            if (cc.tid < PD_DH) {
-                float o = 0.f;
-#pragma unroll
-                for (int w = 0; w < PD_NW; ++w) o += num[w * PD_DH + cc.tid];
-                o = o / (dpart[0] + dpart[1] + a.eps);                    // (waves 2..7 hold no features)
-                pd_publish_pair(gs + OFF_E3, jm * (PD_D / 2) + ((hm * PD_DH + cc.tid) >> 1), ep + 2u, o, cc.tid, cc);
+            PD_BARRIER();                                             // 2d
+            if (cc.t < PD_DH) {
+                float o = (num[cc.t] + num[PD_DH + cc.t]) + (num[2 * PD_DH + cc.t] + num[3 * PD_DH + cc.t]);
+                o = o / (dpart[0] + dpart[1] + a.eps);                // (waves 2, 3 of the half hold no features)
+                pd_publish_pair(gs + OFF_E3, jm * (PD_D / 2) + ((hm * PD_DH + cc.t) >> 1), ep + 2u, o, c.t, cc);
             }
-            PD_DIAG(l, 2, 2, PD_NOW());
-        }
-        // ============================================================ P3: out-projection columns 16 m .. (+ bias + residual)
-        {
-            const PdCtx cc = pd_fresh(c);
-            PD_DIAG(l, 3, 0, PD_NOW());
-            const unsigned sp = pd_gather_rows<PD_D>(gs + OFF_E3, ep + 2u, xa, PD_XS, cc, 0x300u + l);
-            PD_SYNC_OR_LEAVE();
-            PD_DIAG(l, 3, 3, sp);
-            PD_DIAG(l, 3, 1, PD_NOW());
-            pd_load_w<1, 8>(w2, L.w2 + (size_t)m * (PD_NW * 1 * 8 * 512), cc, PD_NTW);      // two phases ahead: P5
-            if (cc.tid < 64) b2 = L.b2[m * 16 + (cc.tid & 15)];
-            pd_gemv<1, 2>(wo, xa, PD_XS, part, cc);
-            PD_BARRIER();
-            if (cc.tid < 64) {
-                const int s = cc.tid >> 4, col = cc.tid & 15, gc = m * 16 + col;
-                const float v = pd_part_sum<1>(part, 0, s, col) + bo + (float)xin[s * PD_XS + gc];
-                pd_publish_pair(gs + OFF_E4, s * (PD_D / 2) + (gc >> 1), ep + 3u, v, col, cc);
+            // ---- P3
+            PD_SYNC_OR_LEAVE();                                       // 3a
+            const u64 tg3 = a.diag ? PD_NOW() : 0;
+            pd_gemv<1, 4>(wo, bo, xa, PD_XS, part, cc);
+            PD_SCHED_FENCE();
+            if (a.diag) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PD_DIAG(l, 7, 2, PD_NOW() - tg3); }
+            PD_BARRIER();                                             // 3b
+            if (cc.t < 64) {
+                const int s = cc.t >> 4, col = cc.t & 15, gc = m * 16 + col;
+                pd_publish_pair(gs + OFF_E4, s * (PD_D / 2) + (gc >> 1), ep + 3u, pd_part_sum<1>(part, 0, s, col) + (float)xin[s * PD_XS + gc], col, cc);
             }
             PD_DIAG(l, 3, 2, PD_NOW());
-        }
-        // ============================================================ P4: LayerNorm1 + FFN1 columns 64 m .. + ReLU
-        {
-            const PdCtx cc = pd_fresh(c);
-            PD_DIAG(l, 4, 0, PD_NOW());
-            const unsigned sp = pd_gather_rows<PD_D>(gs + OFF_E4, ep + 3u, x1, PD_XS, cc, 0x400u + l);
-            PD_SYNC_OR_LEAVE();
-            PD_DIAG(l, 4, 3, sp);
-            PD_DIAG(l, 4, 1, PD_NOW());
-            pd_ln_rows(x1, lg, lb, a.ln_eps, cc);
-            // two phases ahead: the next layer's P1 (its q / k / v weights, LayerNorm2 of THIS layer), or the logits tile after the last layer
-            pd_ln_load(lg, lb, L.g2, L.be2, cc);
-            if (!last) {
-                pd_load_w<3, 2>(wq, LY[l + 1].wqkv + (size_t)m * (PD_NW * 3 * 2 * 512), cc, PD_NTW);
-                if (cc.tid < 192) bq = LY[l + 1].bqkv[(cc.tid >> 6) * PD_D + hm * PD_DH + jm * 16 + (cc.tid & 15)];
-            } else if (m < (a.n_token + 15) / 16) {
-                pd_load_w<1, 2>(wo, a.wout + (size_t)m * (PD_NW * 1 * 2 * 512), cc, PD_NTW);
-                if (cc.tid < 64) bo = (m * 16 + (cc.tid & 15)) < a.n_token ? a.bout[m * 16 + (cc.tid & 15)] : 0.f;
-            }
-            PD_BARRIER();
-            pd_gemv<4, 2>(w1, x1, PD_XS, part, cc);
-            PD_BARRIER();
-            if (cc.tid < 256) {
-                const int t = cc.tid >> 6, s = (cc.tid >> 4) & 3, col = cc.tid & 15, gc = m * 64 + t * 16 + col;
-                const float v = fmaxf(pd_part_sum<4>(part, t, s, col) + b1, 0.f);
-                pd_publish_pair(gs + OFF_E5, s * (PD_FF / 2) + (gc >> 1), ep + 4u, v, col, cc);
-            }
-            PD_DIAG(l, 4, 2, PD_NOW());
-        }
-        // ============================================================ P5: FFN2 columns 16 m .. (+ bias + residual)
-        {
-            const PdCtx cc = pd_fresh(c);
-            PD_DIAG(l, 5, 0, PD_NOW());
-            const unsigned sp = pd_gather_rows<PD_FF>(gs + OFF_E5, ep + 4u, fh, PD_FS, cc, 0x500u + l);
-            PD_SYNC_OR_LEAVE();
-            PD_DIAG(l, 5, 3, sp);
-            PD_DIAG(l, 5, 1, PD_NOW());
-            if (!last) PD_LOAD_STATE(LY[l + 1], cc);                   // two phases ahead: the next layer's P2 (state slice, omega, z)
-            pd_gemv<1, 8>(w2, fh, PD_FS, part, cc);
-            PD_BARRIER();
-            if (cc.tid < 64) {
-                const int s = cc.tid >> 4, col = cc.tid & 15, gc = m * 16 + col;
-                const float v = pd_part_sum<1>(part, 0, s, col) + b2 + (float)x1[s * PD_XS + gc];
-                pd_publish_pair(gs + OFF_E1, s * (PD_D / 2) + (gc >> 1), ep + 5u, v, col, cc);
+            PD_SCHED_FENCE();
+            const bf16_t* w2p = L.w2 + (size_t)m * (PD_HW * 1 * 16 * 512);                // next operand set: P5, in three slices
+            pd_load_w_part<1, 16, 0, 5>(w2, w2p, cc, nt);
+            b2[0] = L.b2[m * 16 + lc16];
+            PD_SYNC_OR_LEAVE();                                       // 4a
+            pd_load_w_part<1, 16, 5, 10>(w2, w2p, cc, nt);
+            PD_BARRIER();                                             // 4b
+            pd_load_w_part<1, 16, 10, 16>(w2, w2p, cc, nt);
+            // ---- P5
+            PD_SYNC_OR_LEAVE();                                       // 5a
+            const u64 tg5 = a.diag ? PD_NOW() : 0;
+            pd_gemv<1, 16>(w2, b2, fh, PD_FS, part, cc);
+            PD_SCHED_FENCE();
+            if (a.diag) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PD_DIAG(l, 7, 3, PD_NOW() - tg5); }
+            PD_BARRIER();                                             // 5b
+            if (cc.t < 64) {
+                const int s = cc.t >> 4, col = cc.t & 15, gc = m * 16 + col;
+                pd_publish_pair(gs + OFF_E1, s * (PD_D / 2) + (gc >> 1), ep + 5u, pd_part_sum<1>(part, 0, s, col) + (float)x1[s * PD_XS + gc], col, cc);
             }
             PD_DIAG(l, 5, 2, PD_NOW());
+            PD_SCHED_FENCE();
+            if (!last) {                                              // next operand set: the next layer's P3 fragments now, its state slice after 1a / 1b
+                pd_load_w<1, 4>(wo, LY[l + 1].wo + (size_t)m * (PD_HW * 1 * 4 * 512), cc, nt);
+                bo[0] = LY[l + 1].bo[m * 16 + lc16];
+            }
         }
-    }
-    // ---------------------------------------------------------------- LayerNorm2 of the last layer + logits tile m (21 tiles of 16 columns)
-    if (m < (a.n_token + 15) / 16) {                                      // (m is uniform over the workgroup; the other members are done)
-        const PdCtx cc = pd_fresh(c);
-        pd_gather_rows<PD_D>(gs + OFF_E1, ep0 + (unsigned)(a.n_layers - 1) * 8u + 5u, xin, PD_XS, cc, 0x600u);
-        PD_SYNC_OR_LEAVE();
-        pd_ln_rows(xin, lg, lb, a.ln_eps, cc);
-        PD_BARRIER();
-        pd_gemv<1, 2>(wo, xin, PD_XS, part, cc);
-        PD_BARRIER();
-        if (cc.tid < 64) {
-            const int s = cc.tid >> 4, col = cc.tid & 15, gc = m * 16 + col;
-            if (gc < a.n_token) a.logits[((int64_t)g * PD_GS + s) * a.n_token + gc] = pd_part_sum<1>(part, 0, s, col) + bo;
-        }
-        // member 0 gathered the last edge from EVERY member of the group, so all of them have long read the counter
-        if (m == 0 && cc.tid == 0) PD_STORE(gs + OFF_CNT, (u64)(lc + 1u));
-        PD_DIAG(15, 0, 2, PD_NOW());
-        PD_DIAG(15, 1, 1, (u64)clock64());
+        if (!has_logits) return;
+        PD_SYNC_OR_LEAVE();                                           // Fa
+        PD_BARRIER();                                                 // Fb
     }
 }
 }  // namespace
+
 extern "C" int64_t emo_performer_decode_step_workspace_bytes(void) { return (int64_t)PD_WS_WORDS * 8; }
 
 extern "C" int emo_performer_decode_step(const void* layer_table, int64_t n_layers, const int64_t* tok, const int64_t* seg, const float* E, const float* Sg,

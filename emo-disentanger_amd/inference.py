@@ -97,15 +97,15 @@ class PerformerDecodeEngine(_EngineBase):
     # ------------------------------------------------------------------------------------------ one-launch step
     @staticmethod
     def _pack_fragments(W, tile_idx, kpw):
-        """bf16 nn.Linear weight [N, K] -> [members][8 waves][tiles per member][kpw][64 lanes x 8]: the MFMA B fragment (16 output columns x 32 k)
-        of column tile t and k step ks holds, in lane l, W[16 t + l % 16][32 ks + 8 (l // 16) .. + 8]; wave w of a member owns the k steps
-        [w kpw, (w + 1) kpw) of all of the member's tiles (emo_hip.h: emo_performer_decode_step)."""
+        """bf16 nn.Linear weight [N, K] -> [members][4 waves][tiles per member][kpw][64 lanes x 8]: the MFMA B fragment (16 output columns x 32 k)
+        of column tile t and k step ks holds, in lane l, W[16 t + l % 16][32 ks + 8 (l // 16) .. + 8]; wave w of the compute half that owns the
+        product holds the k steps [w kpw, (w + 1) kpw) of all of the member's tiles (emo_hip.h: emo_performer_decode_step)."""
         N, K = W.shape
-        assert N % 16 == 0 and K == 32 * 8 * kpw
+        assert N % 16 == 0 and K == 32 * 4 * kpw
         frags = W.reshape(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(N // 16, K // 32, 512)      # [tile][k step][lane * 8 + j]
         sel = frags[tile_idx]                                                                                  # [members, tiles per member, k steps, 512]
         members, tpm = tile_idx.shape
-        return sel.reshape(members, tpm, 8, kpw, 512).permute(0, 2, 1, 3, 4).contiguous()
+        return sel.reshape(members, tpm, 4, kpw, 512).permute(0, 2, 1, 3, 4).contiguous()
 
     def _prepare_persist(self):
         m, ps, dev = self.model, self.ps, self.dev
@@ -120,17 +120,17 @@ class PerformerDecodeEngine(_EngineBase):
             pfx = m._layer_prefix(l)
             q = pfx + 'attention.query_projection.'
             self.persist['w'].append(dict(
-                wqkv=pk(ps.w(q + 'weight', 3 * D), t_qkv, 2), bqkv=ps.f32(q + 'bias', 3 * D),
-                wo=pk(ps.w(pfx + 'attention.out_projection.weight'), t_one, 2), bo=ps.f32(pfx + 'attention.out_projection.bias'),
+                wqkv=pk(ps.w(q + 'weight', 3 * D), t_qkv, 4), bqkv=ps.f32(q + 'bias', 3 * D),
+                wo=pk(ps.w(pfx + 'attention.out_projection.weight'), t_one, 4), bo=ps.f32(pfx + 'attention.out_projection.bias'),
                 g1=ps.f32(pfx + 'norm1.weight'), be1=ps.f32(pfx + 'norm1.bias'),
-                w1=pk(ps.w(pfx + 'linear1.weight'), t_ffn, 2), b1=ps.f32(pfx + 'linear1.bias'),
-                w2=pk(ps.w(pfx + 'linear2.weight'), t_one, 8), b2=ps.f32(pfx + 'linear2.bias'),
+                w1=pk(ps.w(pfx + 'linear1.weight'), t_ffn, 4), b1=ps.f32(pfx + 'linear1.bias'),
+                w2=pk(ps.w(pfx + 'linear2.weight'), t_one, 16), b2=ps.f32(pfx + 'linear2.bias'),
                 g2=ps.f32(pfx + 'norm2.weight'), be2=ps.f32(pfx + 'norm2.bias')))
         V = m.n_token
         Vp = (V + 15) // 16 * 16
         wout = torch.zeros(Vp, D, device=dev, dtype=torch.bfloat16)
         wout[:V] = ps.w('dec_out_proj.weight')
-        self.persist['wout'] = pk(wout, torch.arange(Vp // 16, device=dev).view(-1, 1), 2)
+        self.persist['wout'] = pk(wout, torch.arange(Vp // 16, device=dev).view(-1, 1), 4)
         self.persist['bout'] = ps.f32('dec_out_proj.bias')
         self.persist['sync'] = torch.zeros(ops.lib.emo_performer_decode_step_workspace_bytes() // 8, device=dev, dtype=torch.int64)   # zeroed ONCE
         self.persist['logits'] = torch.empty(self.n, V, device=dev, dtype=torch.float32)

@@ -162,12 +162,12 @@ int emo_favor_decode_step(const void* q, const void* k, const void* v, int64_t l
 /* ONE-LAUNCH Performer decode step (the token loop of inference.py:250-277 -> MusicPerformer.forward(keep_last_only), music_performer.py:50-70):
  * embedding (transformer_helpers.py:81-87 + PE) -> n_layers post-LN FAVOR+ encoder layers (fast_transformer_decoder.py:54-74: fused q/k/v projection,
  * FAVOR+ recurrent step on the fp32 state, out-projection + residual + LayerNorm, ReLU FFN + residual + LayerNorm) -> dec_out_proj logits, for
- * n_streams <= 32 streams (a multiple of 4), bf16 weights, in a single persistent kernel: 8 groups x 32 workgroups, a group owns 4 streams and
+ * n_streams <= 32 streams (a multiple of 4), bf16 weights, in a single persistent kernel: 8 groups x 32 workgroups of 12 waves (4 poller + 2 x 4 compute), a group owns 4 streams and
  * exchanges the activations of the 5 dependent products of a layer through tagged 8-byte granules (csrc/emo_decode_persist.hip).
  * Built for d_model 512 / 8 heads / 128 features / d_ff 2048, n_layers <= 15, n_token <= 512.
  *   layer_table : device array [n_layers][16] of pointers: wqkv_packed, bqkv (f32 [3 d], q|k|v), wo_packed, bo, norm1 gamma, beta, w1_packed, b1,
  *                 w2_packed, b2, norm2 gamma, beta, omega (f32 [64][64]), state_S (f32 [n][8][128][64]), state_z (f32 [n][8][128]), unused.
- *                 *_packed = the bf16 nn.Linear weight [N][K] re-ordered per (member, wave, column tile, k step) into 1-KB MFMA B fragments
+ *                 *_packed = the bf16 nn.Linear weight [N][K] re-ordered per (member, wave 0..3 of the compute half, column tile, k step) into 1-KB MFMA B fragments
  *                 (element (lane, j) = W[16 tile + lane % 16][32 kstep + 8 (lane / 16) + j]); the host mirror builds them (inference.py).
  *   tok, seg    : int64 [n_streams] (seg may be NULL); position of stream s = pos0 + (pos_ids ? pos_ids[s] : 0)
  *   logits      : f32 [n_streams][n_token]

@@ -46,6 +46,8 @@ if __name__ == '__main__':
         print('%-14s wait %.2f us (max over members %.2f)   work %.2f us (max %.2f)   poll passes %.1f' % (names[ph], w.mean(), w.max(1).values.mean() if False else w.mean(1).max(), k.mean(), k.mean(1).max(), sp.mean()))
         tot += (w.mean() + k.mean()) * L
     print('sum over phases x layers: %.1f us' % tot)
+    print('first poll of a gather (us): E5 %.2f  E4 %.2f  E3 %.2f' % tuple((d[:, :L, 6, k].mean() / 100) for k in range(3)))
+    print('barrier exit -> partial products written (us): P1 %.2f  P4 %.2f  P3 %.2f  P5 %.2f' % tuple((d[:, :L, 7, k].mean() / 100) for k in range(4)))
     # the dependency chain of member 0, layer 5
     for ph in range(1, 6):
         r = d[0, 5, ph]
