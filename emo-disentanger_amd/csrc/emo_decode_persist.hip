@@ -39,7 +39,8 @@
 //     queue in front of the pollers' loads: first poll 2.0 us instead of 0.2, and the burst's issue stalled its own wave for ~2 us.)
 // Measured r04 (tools/pd_diag.py, profiles/r04_pd_diag_v*.txt; bench `gen`): chain of launches 0.383 ms per token step; all-waves-do-everything
 // persistent kernel 0.325 (write-through granules) -> 0.257 (census + L2-local granules) -> 0.244 (raw barriers, loads two phases ahead);
-// wave roles with burst loads 0.251-0.283; wave roles with sliced loads 0.221 (kernel 181 us = 60 phases x 3.0 us: 0.5-0.9 us of work each, the
+// wave roles with burst loads 0.251-0.283; a slice schedule that packs the loads into the poll-free windows (1a, 2a-2c, 4a) 0.233 (the 32-KB E5
+// gather stays at 2.4-2.8 us whatever precedes it: it is the CU's own L2 -> CU rate); wave roles with evenly sliced loads 0.221 (kernel 181 us = 60 phases x 3.0 us: 0.5-0.9 us of work each, the
 // rest is the wait for the edge behind the CU's weight stream: every XCD streams ALL weights for its 4 streams, 0.8 GB per token step).
 // Workgroup barriers are raw s_barrier + lgkmcnt(0): __syncthreads() carries a vmcnt(0) fence and would drain the HBM loads at every barrier.
 //
