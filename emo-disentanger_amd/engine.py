@@ -310,7 +310,9 @@ def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
     else:
         df = ops.gemm(dyd, ps.w(pfx + 'linear2.weight'), b_trans=True, mul_aux=s['f'], mul_mode=ops.MUL_NONZERO, mul_scale=inv)
     _wgrad(ps, pfx + 'linear1.weight', pfx + 'linear1.bias', df, s['h1'])
-    # the long-reduction dgrads (K = 2048 / 1536) as NT products against transposed mirrors too: 256 x 256 tile kernel (emo_gemm_w128.hip)
+    # the long-reduction dgrads (K = 2048 / 1536) as NT products against transposed mirrors too: 256 x 256 tile kernel (emo_gemm_w128.hip).
+    # `bf` already requires >= ASTAT_MIN_ROWS = 32768 tokens, where M / 256 * N / 256 >= 256 tiles holds for N = 512: below that (the reference
+    # batch size 4) `nt_long` is False and the dgrads stay NN products on the 128 x 128 kernel, without mirror transposes.
     nt_long = bf and dout.shape[0] % 256 == 0 and _os.environ.get('EMO_DGRAD_NT', '1') != '0'
     dh1 = ops.gemm(df, ps.wT(pfx + 'linear1.weight'), residual=g2) if nt_long else ops.gemm(df, ps.w(pfx + 'linear1.weight'), b_trans=True, residual=g2)
     g1, da = ops.layernorm_bwd(dh1, s['x1'], ps.f32(pfx + 'norm1.weight'), s['m1'], s['r1'], ps.g(pfx + 'norm1.weight'), ps.g(pfx + 'norm1.bias'),

@@ -1,7 +1,10 @@
-"""Parameter holders of the embedding prologue — mirrors
+"""Parameter holders of the embedding prologue: the state-dict CONTRACT of
 /root/reference/stage2_accompaniment/model/transformer_helpers.py (:24-40 weights_init,
-:43-63 PositionalEncoding, :66-87 TokenEmbedding).  The arithmetic itself runs in the fused
-HIP kernel ``emo_embed_fwd`` (gather + segment gather + *sqrt(d) + PE + dropout in one pass)."""
+:43-63 PositionalEncoding, :66-87 TokenEmbedding).  Two pieces here necessarily follow the reference expression for expression and are
+not claimed as original work: the `pe` buffer of PositionalEncoding (it is part of the checkpoint — `pe.pe` — and must be bit-identical:
+tests/test_host_logic.py compares it with rows dumped from the imported reference) and the class-name dispatch of weights_init (the init
+rule IS the behaviour).  The arithmetic of the prologue runs in the fused HIP kernel ``emo_embed_fwd`` (gather + segment gather +
+*sqrt(d) + PE + dropout in one pass); nothing in this file computes on the hot path."""
 import math
 
 import torch
