@@ -770,6 +770,7 @@ __global__ __launch_bounds__(512) void nucleus_kernel(const float* __restrict__ 
                                                       int64_t* __restrict__ seq, int64_t ld_seq, int64_t col0) {
     __shared__ __attribute__((aligned(16))) float sp[1024 + 8], sq[1024 + 8], cumf[1024 + 8];
     __shared__ __attribute__((aligned(16))) double cumd[1024 + 8];
+    __shared__ __attribute__((aligned(16))) unsigned long long skey[1024 + 8];
     __shared__ int si[1024];
     __shared__ float red[8];
     __shared__ int cnt[8];
@@ -793,17 +794,25 @@ __global__ __launch_bounds__(512) void nucleus_kernel(const float* __restrict__ 
     if (lane == 0) red[wave] = s;
     __syncthreads();
     const float tot = red[0] + red[1] + red[2] + red[3] + red[4] + red[5] + red[6] + red[7];
-    for (int c = tid; c < V; c += 512) sq[c] = sp[c] / tot;
-    for (int c = (int)V + tid; c < Vp + 8; c += 512) sq[c] = -1.f;        // never greater than or equal to a probability
+    // rank sort on 64-bit keys {probability bits, ~index}: key_j > key_c  <=>  p_j > p_c, or p_j == p_c and j < c (probabilities are >= 0, so their
+    // bit patterns order like their values) - the stable descending order of the reference's argsort in ONE compare + ONE add-with-carry per pair
+    // (r04: the float version spent ~7 VALU instructions per pair, 336 x 336 pairs on 6 waves = half of the kernel's 20 us).  Pad keys are 0.
+    for (int c = tid; c < V; c += 512) {
+        const float pc = sp[c] / tot;
+        sq[c] = pc;
+        skey[c] = ((unsigned long long)__builtin_bit_cast(unsigned, pc) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)c);
+    }
+    for (int c = (int)V + tid; c < Vp + 8; c += 512) { sq[c] = -1.f; skey[c] = 0ull; }
     __syncthreads();
     for (int c = tid; c < Vp; c += 512) {
         if (c < V) {
             const float pc = sq[c];
+            const unsigned long long kc = skey[c];
             int rank = 0;
-            for (int j0 = 0; j0 < Vp; j0 += 4) {
-                const f32x4 q4 = *(const f32x4*)(sq + j0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rank += (int)(q4[e] > pc) | ((int)(q4[e] == pc) & (int)(j0 + e < c));
+            for (int j0 = 0; j0 < Vp; j0 += 2) {
+                const u32x4 k2 = *(const u32x4*)(skey + j0);
+                const unsigned long long ka = ((unsigned long long)k2[1] << 32) | k2[0], kb = ((unsigned long long)k2[3] << 32) | k2[2];
+                rank += (int)(ka > kc) + (int)(kb > kc);
             }
             sp[rank] = pc;
             si[rank] = c;
@@ -812,24 +821,34 @@ __global__ __launch_bounds__(512) void nucleus_kernel(const float* __restrict__ 
         }
     }
     __syncthreads();
+    // Both prefixes stay SEQUENTIAL (np.cumsum order: the top-p crossing and the draw are rounding-sensitive), but a chunk of 32 sorted values is
+    // fetched into registers before its dependent chain of adds runs (r04: the loops used to pay an LDS round trip per 4-8 values, and the f64 one
+    // was ~9 of the kernel's 20 us).
     if (tid == 0) {                        // np.cumsum order, fp32
         float cum = 0.f;
-        for (int i0 = 0; i0 < Vp; i0 += 8) {
-            const f32x4 a = *(const f32x4*)(sp + i0), b = *(const f32x4*)(sp + i0 + 4);
-            f32x4 ca, cb;
-            ca[0] = cum += a[0]; ca[1] = cum += a[1]; ca[2] = cum += a[2]; ca[3] = cum += a[3];
-            cb[0] = cum += b[0]; cb[1] = cum += b[1]; cb[2] = cum += b[2]; cb[3] = cum += b[3];
-            *(f32x4*)(cumf + i0) = ca;
-            *(f32x4*)(cumf + i0 + 4) = cb;
+        for (int i0 = 0; i0 < Vp; i0 += 32) {
+            f32x4 a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = (i0 + 4 * j < Vp) ? *(const f32x4*)(sp + i0 + 4 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f32x4 ca;
+                ca[0] = cum += a[j][0]; ca[1] = cum += a[j][1]; ca[2] = cum += a[j][2]; ca[3] = cum += a[j][3];
+                if (i0 + 4 * j < Vp) *(f32x4*)(cumf + i0 + 4 * j) = ca;
+            }
         }
     } else if (tid == 64) {                // sequential f64 prefix of the same sorted probabilities (candidate renormalisation + draw)
         double run = 0.0;
-        for (int i0 = 0; i0 < Vp; i0 += 4) {
-            const f32x4 a = *(const f32x4*)(sp + i0);
-            cumd[i0] = run += (double)a[0];
-            cumd[i0 + 1] = run += (double)a[1];
-            cumd[i0 + 2] = run += (double)a[2];
-            cumd[i0 + 3] = run += (double)a[3];
+        for (int i0 = 0; i0 < Vp; i0 += 32) {
+            f32x4 a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = (i0 + 4 * j < Vp) ? *(const f32x4*)(sp + i0 + 4 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                double c0, c1, c2, c3;
+                c0 = run += (double)a[j][0]; c1 = run += (double)a[j][1]; c2 = run += (double)a[j][2]; c3 = run += (double)a[j][3];
+                if (i0 + 4 * j < Vp) { cumd[i0 + 4 * j] = c0; cumd[i0 + 4 * j + 1] = c1; cumd[i0 + 4 * j + 2] = c2; cumd[i0 + 4 * j + 3] = c3; }
+            }
         }
     }
     __syncthreads();
