@@ -86,11 +86,14 @@ class PerformerDecodeEngine(_EngineBase):
         if self.dt == torch.bfloat16 and n_streams <= 32 and os.environ.get('EMO_DECODE_LN_FOLD', '1') != '0':
             self._prepare_folds()
         # the whole token step as ONE persistent launch (emo_performer_decode_step) for the benchmark architecture: bf16, d_model 512, 8 heads,
-        # 128 features, d_ff 2048, a multiple of 4 streams up to 32.  EMO_DECODE_PERSISTENT=0 keeps the chain of launches (tests compare the two).
+        # 128 features, d_ff 2048, up to 32 streams (the kernel's groups own 4 streams each: other counts — the reference's own one-piece-at-a-time
+        # loop is n = 1 — are padded with idle streams whose state is zero and whose logits nobody reads).  EMO_DECODE_PERSISTENT=0 keeps the chain
+        # of launches (tests compare the two).
         self.persist = None
         ff = model.transformer_decoder.decoder_layers[0].linear1.weight.shape[0]
         nf = 2 * self.omegas[0].shape[1]
-        if (self.dt == torch.bfloat16 and n_streams % 4 == 0 and 4 <= n_streams <= 32 and model.d_model == 512 and model.n_head == 8 and nf == 128
+        self.n_pad = (n_streams + 3) // 4 * 4
+        if (self.dt == torch.bfloat16 and 1 <= n_streams <= 32 and model.d_model == 512 and model.n_head == 8 and nf == 128
                 and ff == 2048 and model.n_layer <= 15 and model.n_token <= 512 and os.environ.get('EMO_DECODE_PERSISTENT', '1') != '0'):
             self._prepare_persist()
 
@@ -133,7 +136,11 @@ class PerformerDecodeEngine(_EngineBase):
         self.persist['wout'] = pk(wout, torch.arange(Vp // 16, device=dev).view(-1, 1), 4)
         self.persist['bout'] = ps.f32('dec_out_proj.bias')
         self.persist['sync'] = torch.zeros(ops.lib.emo_performer_decode_step_workspace_bytes() // 8, device=dev, dtype=torch.int64)   # zeroed ONCE
-        self.persist['logits'] = torch.empty(self.n, V, device=dev, dtype=torch.float32)
+        self.persist['logits'] = torch.zeros(self.n_pad, V, device=dev, dtype=torch.float32)
+        if self.n_pad != self.n:                                     # padded inputs of the idle streams: token 0, segment 0, position 0
+            self.persist['tok'] = torch.zeros(self.n_pad, dtype=torch.int64, device=dev)
+            self.persist['seg'] = torch.zeros(self.n_pad, dtype=torch.int64, device=dev)
+            self.persist['pos'] = torch.zeros(self.n_pad, dtype=torch.int64, device=dev)
 
     def _persist_table(self):
         """[L][16] device pointers (emo_hip.h); built once the recurrent state exists (prefill)."""
@@ -155,11 +162,27 @@ class PerformerDecodeEngine(_EngineBase):
         E, Sg = self._tables
         seg = seg if (Sg is not None and seg is not None) else None
         pe = m.pe.pe if m.use_pe else m._zero_pe(self.max_len, m.d_model)
-        out = logits_out if logits_out is not None else pp['logits']
         nf = 2 * self.omegas[0].shape[1]
+        pos_ids = self.pos_dev if dev_pos else None
+        padded = self.n_pad != self.n
+        if padded:
+            pp['tok'][:self.n].copy_(tok)
+            tok = pp['tok']
+            if seg is not None:
+                pp['seg'][:self.n].copy_(seg)
+                seg = pp['seg']
+            if pos_ids is not None:
+                pp['pos'][:self.n].copy_(pos_ids)
+                pos_ids = pp['pos']
+        out = logits_out if (logits_out is not None and not padded) else pp['logits']
         ops.performer_decode_step(self._persist_table(), m.n_layer, tok, seg, E, Sg if seg is not None else None, pe, float(m.token_emb.emb_scale),
-                                  self.dev_pos0 if dev_pos else self.pos, self.pos_dev if dev_pos else None, pp['wout'], pp['bout'], m.n_token, out,
-                                  self.n, m.d_model, m.n_head, nf, 2048, pp['sync'], diag=pp.get('diag'))
+                                  self.dev_pos0 if dev_pos else self.pos, pos_ids, pp['wout'], pp['bout'], m.n_token, out,
+                                  self.n_pad, m.d_model, m.n_head, nf, 2048, pp['sync'], diag=pp.get('diag'))
+        if padded:
+            if logits_out is not None:
+                logits_out.copy_(out[:self.n])
+                return logits_out
+            return out[:self.n]
         return out
 
     def check_persistent(self):
@@ -230,6 +253,13 @@ class PerformerDecodeEngine(_EngineBase):
             x = self._tail(pfx, x, attn)
         if self.persist is not None:
             self.persist['table'] = None                         # new state tensors: the pointer table is rebuilt at the next step
+            if self.n_pad != B:                                  # state of the padded (idle) streams: zero; S[l] / z[l] stay the views of the real ones
+                for l in range(m.n_layer):
+                    Sp = torch.zeros((self.n_pad,) + tuple(self.S[l].shape[1:]), device=self.dev, dtype=self.S[l].dtype)
+                    zp = torch.zeros((self.n_pad,) + tuple(self.z[l].shape[1:]), device=self.dev, dtype=self.z[l].dtype)
+                    Sp[:B].copy_(self.S[l])
+                    zp[:B].copy_(self.z[l])
+                    self.S[l], self.z[l] = Sp[:B], zp[:B]
         self.pos = T
         self.pos_dev.fill_(T)
         return self._logits(x.view(B, T, D)[:, -1].contiguous())

@@ -33,7 +33,7 @@ def _run(model, ptok, pseg, toks, segs, persistent, monkeypatch):
     return torch.stack(out, 1), [s.clone() for s in eng.S], [z.clone() for z in eng.z]
 
 
-@pytest.mark.parametrize('n,L', [(4, 1), (8, 3), (32, 12)])
+@pytest.mark.parametrize('n,L', [(4, 1), (8, 3), (32, 12), (1, 2), (5, 2)])       # (1, 5: padded to the kernel's groups of 4 streams)
 def test_one_launch_step_matches_launch_chain_and_fp32(n, L, monkeypatch):
     g = torch.Generator().manual_seed(5 + n)
     V, T0, K = 327, 24, 6
