@@ -276,11 +276,18 @@ def generation_bench(model, n_streams=32, prompt=64, n_new=2048 - 64, top_p=0.9,
     out = inf.generate_streams(model, ptok, pseg, n_new, temp=temp, top_p=top_p, seed=2)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    model.train()
     assert out.shape == (n_streams, prompt + n_new) and int(out.max()) < CFG['n_token']
+    # the reference's own use: ONE piece at a time (inference.py:231-327) — a single stream on the same engine (idle padding streams)
+    inf.generate_streams(model, ptok[:1], pseg[:1], 8, temp=temp, top_p=top_p, seed=1)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    inf.generate_streams(model, ptok[:1], pseg[:1], 512, temp=temp, top_p=top_p, seed=3)
+    torch.cuda.synchronize()
+    single_ms = 1000 * (time.perf_counter() - t1) / 512
+    model.train()
     return {'metric': 'AR gen tokens/sec, stage2 Performer d512 L12, %d streams, nucleus p=%.2f' % (n_streams, top_p),
             'value': round(n_streams * n_new / dt, 1), 'unit': 'tokens/s', 'streams': n_streams, 'prompt': prompt, 'new_tokens': n_new,
-            'ms_per_token_step': round(1000 * dt / n_new, 3), 'engine': 'FAVOR+ recurrent state in HBM; token step = nucleus sampler + ONE persistent launch (emo_performer_decode_step), hipGraph replay'}
+            'ms_per_token_step': round(1000 * dt / n_new, 3), 'single_stream_ms_per_token': round(single_ms, 3), 'engine': 'FAVOR+ recurrent state in HBM; token step = nucleus sampler + ONE persistent launch (emo_performer_decode_step), hipGraph replay'}
 
 
 def stage1_bench(n_steps=10, B=4, T=512, V=200):
