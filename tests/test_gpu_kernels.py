@@ -101,7 +101,7 @@ def test_gemm_epilogue_mul_modes_and_dropout(dt):
     _close(o1[keep], (plain.double() / 0.9)[keep], dt, mult=2.0)
 
 
-@pytest.mark.parametrize('M,N,K,b_trans', [(2048, 512, 2048, False), (2048, 512, 2048, True), (8192, 512, 1536, True), (4096, 1024, 1024, False)])
+@pytest.mark.parametrize('M,N,K,b_trans', [(2048, 512, 2048, False), (2048, 512, 2048, True), (4096, 512, 1536, True), (2048, 1024, 1024, False)])
 def test_gemm_small_grid_long_k_split_with_epilogue(M, N, K, b_trans):
     """bf16 products whose 128 x 128 tile grid leaves the chip empty (<= 256 tiles: stage 1, batch-size-4 steps) and whose reduction is long run
     split-K through the workspace + splitk_reduce_epi_kernel, which applies the whole fused epilogue: against fp64, dropout against
