@@ -39,6 +39,10 @@
 //     queue in front of the pollers' loads: first poll 2.0 us instead of 0.2, and the burst's issue stalled its own wave for ~2 us.)
 // Measured r04 (tools/pd_diag.py, profiles/r04_pd_diag_v*.txt; bench `gen`): chain of launches 0.383 ms per token step; all-waves-do-everything
 // persistent kernel 0.325 (write-through granules) -> 0.257 (census + L2-local granules) -> 0.244 (raw barriers, loads two phases ahead);
+// (timing ablation EMO_PD_NT=2 — every weight fragment read from one hot KB, results wrong — : kernel 181 -> 155 us, so the weight stream is NOT
+// the bulk of it: 60 phases x 2.6 us remain as publish -> visible -> polled latency (1.3-1.8 failed poll passes of 0.3-0.5 us per edge, the 32-KB E5
+// gather 1.6 us on its own), the HBM round trip of the state slice in P2 and 0.6-1.5 us of work; a design that keeps the weights resident would
+// gain ~15 %, not 2 x)
 // wave roles with burst loads 0.251-0.283; a slice schedule that packs the loads into the poll-free windows (1a, 2a-2c, 4a) 0.233 (the 32-KB E5
 // gather stays at 2.4-2.8 us whatever precedes it: it is the CU's own L2 -> CU rate); wave roles with evenly sliced loads 0.221 (kernel 181 us = 60 phases x 3.0 us: 0.5-0.9 us of work each, the
 // rest is the wait for the edge behind the CU's weight stream: every XCD streams ALL weights for its 4 streams, 0.8 GB per token step).
@@ -163,26 +167,27 @@ __device__ __forceinline__ unsigned pd_gather_rows(const gu64* buf, unsigned ep,
 
 // COMPUTE: the wave's share of a member's packed weights: T column tiles x KPW k-steps, one KB (64 lanes x 8 bf16) per fragment, into registers.
 template <int T, int KPW>
-__device__ __forceinline__ void pd_load_w(bf16x8 (&w)[T][KPW], const bf16_t* member_base, const PdCtx& c, bool nt) {
+__device__ __forceinline__ void pd_load_w(bf16x8 (&w)[T][KPW], const bf16_t* member_base, const PdCtx& c, int nt) {
     const bf16_t* p = member_base + (size_t)c.hw * (T * KPW * 512) + c.lane * 8;
+    if (nt == 2) p = member_base + c.lane * 8;              // TIMING ABLATION ONLY (EMO_PD_NT=2): every fragment from one hot KB — no weight stream, wrong results
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int ks = 0; ks < KPW; ++ks) {
-            const bf16x8* q = (const bf16x8*)(p + (t * KPW + ks) * 512);
-            w[t][ks] = nt ? __builtin_nontemporal_load(q) : *q;
+            const bf16x8* q = (const bf16x8*)(p + (nt == 2 ? 0 : (t * KPW + ks) * 512));
+            w[t][ks] = nt == 1 ? __builtin_nontemporal_load(q) : *q;
         }
 }
 // fragments [I0, I1) of the same set (flat index t * KPW + ks): an operand set is requested in SLICES, one after each barrier the idle half passes,
 // so that no 48-64 KB burst sits in the CU's memory queue in front of the pollers' loads (r04 diagnostics: first poll 2.0 us behind a burst, 0.2 us
 // without one; the burst's issue itself stalled its wave for ~2 us)
 template <int T, int KPW, int I0, int I1>
-__device__ __forceinline__ void pd_load_w_part(bf16x8 (&w)[T][KPW], const bf16_t* member_base, const PdCtx& c, bool nt) {
+__device__ __forceinline__ void pd_load_w_part(bf16x8 (&w)[T][KPW], const bf16_t* member_base, const PdCtx& c, int nt) {
     const bf16_t* p = member_base + (size_t)c.hw * (T * KPW * 512) + c.lane * 8;
 #pragma unroll
     for (int i = I0; i < I1; ++i) {
-        const bf16x8* q = (const bf16x8*)(p + i * 512);
-        w[i / KPW][i % KPW] = nt ? __builtin_nontemporal_load(q) : *q;
+        const bf16x8* q = (const bf16x8*)(p + (nt == 2 ? 0 : i * 512));
+        w[i / KPW][i % KPW] = nt == 1 ? __builtin_nontemporal_load(q) : *q;
     }
 }
 // part[hw][t][stream][col] = x[stream, k-slice of the wave] . W[col, k-slice] (+ bias[t] from the role's wave 0): x rows = rows 0..3 of the
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
     const int L_ = a.n_layers;
     const PdLayer* LY = a.layers;
     const bool has_logits = m < (a.n_token + 15) / 16;                // member m owns logits tile m (uniform over the workgroup)
-    const bool nt = PD_NTW;
+    const int nt = a.flags & 3;                                      // 0: default cache policy, 1: non-temporal weight loads, 2: timing ablation
 
     if (role == 2) {
         // ========================================================================================== POLLERS (waves 8-11)
@@ -756,7 +761,7 @@ extern "C" int emo_performer_decode_step(const void* layer_table, int64_t n_laye
     a.tok = tok; a.seg = seg; a.E = E; a.Sg = Sg; a.pe = pe; a.emb_scale = emb_scale; a.pos0 = pos0; a.pos_ids = pos_ids;
     a.wout = (const bf16_t*)wout_packed; a.bout = bout; a.n_token = (int)n_token; a.logits = logits; a.n_streams = (int)n_streams;
     a.sync = (u64*)sync_ws; a.eps = eps; a.ln_eps = ln_eps; a.diag = (u64*)diag;
-    { const char* e = getenv("EMO_PD_NT"); a.flags = (e && atoi(e) == 1) ? 1 : 0; }
+    { const char* e = getenv("EMO_PD_NT"); a.flags = e ? (atoi(e) & 3) : 0; }
     static_assert(LDS_TOTAL <= 96 * 1024, "LDS carve");
     const size_t lds = 96 * 1024;                                         // > half of the CU's LDS: one workgroup per CU
     static bool attr = false;
