@@ -34,6 +34,7 @@ _SIG = {
     'emo_last_error': (ctypes.c_char_p, []),
     'emo_device_cus': (c_i, []),
     'emo_gemm': (c_i, [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, ctypes.POINTER(Epilogue), c_p]),
+    'emo_gemm_last_kernel': (c_i, []),
     'emo_gemm_workspace_bytes': (c_l, [c_l, c_l, c_l, c_i, c_i]),
     'emo_colsum': (c_i, [c_p, c_i, c_l, c_l, c_l, c_p, c_i, c_p]),
     'emo_embed_fwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_l, c_l, c_l, c_l, c_l, c_p, c_f, c_f, c_u64, c_u64, c_p]),

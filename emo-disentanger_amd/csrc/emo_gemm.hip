@@ -944,6 +944,12 @@ static int64_t choose_splits(int64_t M, int64_t N, int64_t K, bool big, bool has
     return splits;
 }
 
+// which kernel family the calling thread's last emo_gemm went to (diagnostics: bench.py attributes a launch to the kernel that RAN, not to the
+// one its shape suggests): 1 skinny (M <= 32), 2 A-stationary K = 512, 3 256 x 256 tile wgrad, 4 256 x 256 tile NT, 5 128 x 128 LDS-DMA ring,
+// 6 128 x 128 register-staged, 7 exact-fp32; + 16 split-K through the workspace, + 32 split-K with the reduce-and-epilogue pass
+static thread_local int g_last_gemm_kernel = 0;
+extern "C" int emo_gemm_last_kernel(void) { return g_last_gemm_kernel; }
+
 #define EMO_GEMM_MAX_SPLITS 32
 extern "C" int64_t emo_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype_in, int dtype_out) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -1028,22 +1034,26 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         else { if (nw == 16) SKINNY_LAUNCH(bf16_t, 16, 64); else if (nw == 8) SKINNY_LAUNCH(bf16_t, 8, 128); else SKINNY_LAUNCH(bf16_t, 4, 128); }
 #undef SKINNY_LAUNCH
         EMO_LAUNCH_CHECK();
+        g_last_gemm_kernel = 1;
         return EMO_OK;
     }
     if (big && !a_trans && !b_trans && !ln_fused && !use_safe_tr() &&
         emo_gemm_astat_try((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, dtype_out, M, N, K, ep, st)) {   // K = 512, A stationary in registers
         EMO_LAUNCH_CHECK();
+        g_last_gemm_kernel = 2;
         return EMO_OK;
     }
     if (big && a_trans && b_trans && dtype_out == EMO_F32 && !has_epi && !ln_fused && !use_safe_tr() && e &&
         emo_gemm_w128_tn_try((const bf16_t*)A, lda, (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, accumulate, ep.a_rowsum, ep.b_rowsum, e->workspace,
                              e->workspace_bytes, st)) {
         EMO_LAUNCH_CHECK();
+        g_last_gemm_kernel = 3;
         return EMO_OK;
     }
     if (big && !a_trans && !b_trans && !ln_fused && !accumulate &&
         emo_gemm_w128_try((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, dtype_out, M, N, K, ep, st)) {    // long-K NT products on 256 x 256 tiles (opt-in)
         EMO_LAUNCH_CHECK();
+        g_last_gemm_kernel = 4;
         return EMO_OK;
     }
     EMO_CHECK(!ep.mask_out && ep.mul_mode != EMO_MUL_BITMASK, "emo_gemm: mask_out / EMO_MUL_BITMASK need bf16 in/out, NT, K = 512, M %% 128 == 0, M >= 32768, N %% 64 == 0, N <= 2048");
@@ -1092,6 +1102,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     dim3 grid((unsigned)(tiles_m8 * tiles_n), 1, 1);
     if (splits > 1)   // see splitk_coords()
         grid.x = ep.atomic > 1 ? (unsigned)(8 * cdiv64(tiles_m * tiles_n, ep.atomic)) : (unsigned)(tiles_m * tiles_n * (cdiv64(splits, 8) * 8));
+    g_last_gemm_kernel = (dtype_in == EMO_F32 ? 7 : 6) + (use_ws ? (epi_split ? 32 : 16) : 0);
     if (dtype_in == EMO_F32) {
         const float* a = (const float*)A;
         const float* b = (const float*)B;
@@ -1111,6 +1122,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         const bool span_ok = spanA < (int64_t)0xFFFF0000 && spanB < (int64_t)0xFFFF0000;
         const bool glds_ok = !safe && variant >= 2 && (akc || variant >= 3) && (K % G2_BK) == 0 && (kps % G2_BK) == 0 && M >= 8 && N >= 8 && span_ok;
         if (glds_ok) {
+            g_last_gemm_kernel += 5 - 6;
             if (kdt == EMO_F32) dispatch_glds<float>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
             else dispatch_glds<bf16_t>(akc, bkc, grid, st, a, lda, b, ldb, C, M, N, K, kps, ep);
         } else if (kdt == EMO_F32) {   // register-staged v1 (same 128^2 grid; any K, predicated edges)

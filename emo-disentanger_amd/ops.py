@@ -103,14 +103,19 @@ def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumu
     if GEMM_TIMING is not None:
         e1.record()
         kind = ('T' if a_trans else 'N') + ('N' if b_trans else 'T')
-        if kind == 'NT':
-            kind += '/K>1024' if K > 1024 else ('/K=512' if (K == 512 and A.dtype == torch.bfloat16 and M % 128 == 0 and M >= ASTAT_MIN_ROWS and N % 64 == 0 and 64 <= N <= 2048) else '')
-            if kind.endswith('/K=512'):       # one class per kernel INSTANCE (template argument = epilogue flags), as the rocprofv3 summary lists them
-                tag = [t for t, on in (('relu', act == ACT_RELU), ('gelu', act == ACT_GELU_NEW), ('drop', p_drop > 0), ('res', residual is not None),
-                                       ('bits', mul_mode == MUL_BITMASK), ('mul', mul_aux is not None and mul_mode != MUL_BITMASK), ('mask', mask_out is not None)) if on]
-                kind += '/' + ('+'.join(tag) if tag else 'plain')
-        elif kind == 'TN':                    # 256 x 256 tile (with / without the bias gradient) or the 128 x 128 kernel (outputs that are not multiples of 256)
-            kind += '/128' if (M % 256 or N % 256) else ('/rs' if (a_rowsum is not None or b_rowsum is not None) else '/plain')
+        fam = lib.emo_gemm_last_kernel() & 15          # the kernel family that RAN (emo_hip.h), not the one the shape suggests
+        if fam == 4:
+            kind += '/K>1024'
+        elif fam == 2:       # one class per kernel INSTANCE (template argument = epilogue flags), as the rocprofv3 summary lists them
+            tag = [t for t, on in (('relu', act == ACT_RELU), ('gelu', act == ACT_GELU_NEW), ('drop', p_drop > 0), ('res', residual is not None),
+                                   ('bits', mul_mode == MUL_BITMASK), ('mul', mul_aux is not None and mul_mode != MUL_BITMASK), ('mask', mask_out is not None)) if on]
+            kind += '/K=512/' + ('+'.join(tag) if tag else 'plain')
+        elif fam == 3:       # 256 x 256 tile wgrad (with / without the bias gradient)
+            kind += '/rs' if (a_rowsum is not None or b_rowsum is not None) else '/plain'
+        elif kind == 'TN':
+            kind += '/128'
+        elif fam == 1:
+            kind += '/skinny'
         GEMM_TIMING.append((kind, e0, e1, 2.0 * M * N * K,
                             (M * K + N * K) * A.element_size() + M * N * out.element_size(), (M, N, K)))
     return out
