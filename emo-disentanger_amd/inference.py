@@ -650,14 +650,20 @@ class _Chain:
         self.one_step = one_step
         self.graph, self.stream = None, None
 
-    def capture(self):
+    def capture(self, steps=1):
+        """One graph of `steps` consecutive token steps (all loop state lives on the device, so a replay continues wherever the streams are):
+        a replay costs the device a fixed ~10 us of idle time whatever it holds, so several token steps per replay amortise it (r04:
+        EMO_GEN_GRAPH_STEPS, default 16; the single-step graph serves the remainder)."""
         dev = self.out.device
-        self.graph = torch.cuda.CUDAGraph()
-        self.stream = torch.cuda.Stream(device=dev)
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=dev)
+        g = torch.cuda.CUDAGraph()
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
-            with torch.cuda.graph(self.graph, stream=self.stream):
-                self.one_step()
+            with torch.cuda.graph(g, stream=self.stream):
+                for _ in range(steps):
+                    self.one_step()
+        return g
 
 
 @torch.no_grad()
@@ -692,14 +698,19 @@ def generate_streams(model, prompt_tok, prompt_seg, n_new, temp=1.1, top_p=0.9, 
                 cs[0].one_step()
         elif n_new > 1:
             torch.cuda.synchronize()
+            left = n_new - 1
+            k = max(1, int(os.environ.get('EMO_GEN_GRAPH_STEPS', 16)))
             for ch in cs:
-                ch.capture()
+                ch.graph = ch.capture(1)
+                ch.graph_k = ch.capture(k) if (k > 1 and left >= 2 * k) else None
             main = torch.cuda.current_stream()
             t_host = time.perf_counter()
-            for _ in range(n_new - 1):
+            while left > 0:
+                many = cs[0].graph_k is not None and left >= k
                 for ch in cs:
                     with torch.cuda.stream(ch.stream):
-                        ch.graph.replay()
+                        (ch.graph_k if many else ch.graph).replay()
+                left -= k if many else 1
             if os.environ.get('EMO_GEN_TIMING'):            # diagnostics: host time to ENQUEUE the replays vs time until the GPU is done
                 t_enq = time.perf_counter() - t_host
                 torch.cuda.synchronize()
