@@ -287,7 +287,7 @@ def generation_bench(model, n_streams=32, prompt=64, n_new=2048 - 64, top_p=0.9,
     model.train()
     return {'metric': 'AR gen tokens/sec, stage2 Performer d512 L12, %d streams, nucleus p=%.2f' % (n_streams, top_p),
             'value': round(n_streams * n_new / dt, 1), 'unit': 'tokens/s', 'streams': n_streams, 'prompt': prompt, 'new_tokens': n_new,
-            'ms_per_token_step': round(1000 * dt / n_new, 3), 'single_stream_ms_per_token': round(single_ms, 3), 'engine': 'FAVOR+ recurrent state in HBM; token step = nucleus sampler + ONE persistent launch (emo_performer_decode_step), hipGraph replay'}
+            'ms_per_token_step': round(1000 * dt / n_new, 3), 'single_stream_ms_per_token': round(single_ms, 3), 'engine': 'FAVOR+ recurrent state in HBM; token step = ONE persistent launch (emo_performer_decode_step_sampled: nucleus draw + embedding + 12 layers + logits), hipGraph replay'}
 
 
 def stage1_bench(n_steps=10, B=4, T=512, V=200):

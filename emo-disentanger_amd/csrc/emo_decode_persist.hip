@@ -51,6 +51,7 @@
 // Arithmetic mirrors the launch path's bf16 mode (emo_gemm skinny kernel, favor_decode_fast_kernel, layernorm_fwd_bf16_d512_kernel): bf16
 // activations between products, fp32 accumulation, fp32 FAVOR+ state, LayerNorm statistics in fp32 from the bf16 row.
 #include "emo_common.h"
+#include "emo_nucleus.h"
 
 namespace {
 typedef unsigned long long u64;
@@ -59,7 +60,8 @@ constexpr int PD_D = 512, PD_H = 8, PD_DH = 64, PD_MF = 64, PD_F = 128, PD_FF = 
 constexpr int PD_GS = 4, PD_GM = 32, PD_NG = 8, PD_NT = 768, PD_HW = 4, PD_HT = 256;    // threads; waves / threads per role (A, B, pollers)
 constexpr int PD_XS = PD_D + 8, PD_FS = PD_FF + 8;              // LDS row strides (bf16 elements): +16 B shifts the rows' banks
 constexpr int OFF_CNT = 0, OFF_E1 = 8, OFF_E2 = OFF_E1 + PD_GS * PD_D / 2, OFF_E3 = OFF_E2 + PD_H * PD_GS * 96, OFF_E4 = OFF_E3 + PD_GS * PD_D / 2,
-              OFF_E5 = OFF_E4 + PD_GS * PD_D / 2, OFF_CEN = OFF_E5 + PD_GS * PD_FF / 2, PD_GSTRIDE = OFF_CEN + PD_GM;
+              OFF_E5 = OFF_E4 + PD_GS * PD_D / 2, OFF_CEN = OFF_E5 + PD_GS * PD_FF / 2, OFF_TOK = OFF_CEN + PD_GM,
+              PD_GSTRIDE = OFF_TOK + 8;
 constexpr int PD_WS_WORDS = PD_NG * PD_GSTRIDE + 8;             // last 8 words: [0] = error code
 constexpr int PD_MAX_LAYERS = 15;                               // epoch = launch * 128 + layer * 8 + phase (census: + 127)
 constexpr long long PD_TIMEOUT = 5000000;                       // wall_clock64 ticks (100 MHz): 50 ms for the whole launch
@@ -72,6 +74,9 @@ struct PdArgs {
     const PdLayer* layers; int n_layers;
     const int64_t* tok; const int64_t* seg; const float* E; const float* Sg; const float* pe; float emb_scale; int64_t pos0; const int64_t* pos_ids;
     const bf16_t* wout; const float* bout; int n_token; float* logits; int n_streams; u64* sync; float eps, ln_eps;
+    // in-kernel nucleus draw (samp_mode 1): member s < 4 of a group draws the next token of stream 4 g + s from logits_in (the previous step's
+    // logits) exactly as emo_sample_nucleus_step does, writes it to tok_out / seq and hands it to the group through 4 granules; tok is ignored
+    int samp_mode; float temp, top_p; const float* u_steps; int64_t* step; int64_t* seq; int64_t ld_seq, col0; int64_t* tok_out; const float* logits_in; int n_real;
     int flags;      // bit 0: non-temporal weight loads
     u64* diag;      // optional [32 members][16 layers][8 phases][4]: {t_start, t_gathered, t_published, failed poll passes} of GROUP 0, 10-ns ticks (tools/pd_diag.py)
 };
@@ -82,8 +87,8 @@ struct PdCtx { int t, lane, hw; long long t0; gu64* err; bool local; };
 // LDS carve (bytes from the dynamic base; device functions reach the error flag as an LDS address, not through a generic pointer kept in a struct)
 constexpr int LDS_XIN = 0, LDS_XA = LDS_XIN + PD_GS * PD_XS * 2, LDS_X1 = LDS_XA + PD_GS * PD_XS * 2, LDS_FH = LDS_X1 + PD_GS * PD_XS * 2,
               LDS_PART = LDS_FH + PD_GS * PD_FS * 2, LDS_ATT = LDS_PART + PD_HW * 4 * 64 * 4,
-              LDS_LN = LDS_ATT + (3 * PD_DH + 2 * PD_F + 8 + PD_HW * PD_DH + 2 * 2 * 64 + 8) * 4, LDS_MISC = LDS_LN + 2 * 2 * PD_D * 4, LDS_OM = LDS_MISC + 16,
-              LDS_TOTAL = LDS_OM + PD_DH * PD_MF * 4;
+              LDS_LN = LDS_ATT + (3 * PD_DH + 2 * PD_F + 8 + PD_HW * PD_DH + 2 * 2 * 64 + 8) * 4, LDS_MISC = LDS_LN + 2 * 2 * PD_D * 4, LDS_OM = LDS_MISC + 64,
+              LDS_SAMP = LDS_OM + PD_DH * PD_MF * 4, LDS_TOTAL = LDS_SAMP + EMO_NUCLEUS_LDS;
 extern __shared__ __attribute__((aligned(16))) char pd_smem[];
 #define PD_SERR (*(int*)(pd_smem + LDS_MISC))
 
@@ -299,6 +304,11 @@ __device__ __forceinline__ PdCtx pd_fresh(const PdCtx& c) {
     } while (0)
 #define PD_NOW() ((u64)wall_clock64())
 
+// out of line: nothing is live at the kernel's start, and inlined the draw's rank loop costs the layer loop a spilled weight fragment
+__device__ __noinline__ int64_t pd_draw(const float* l, int n_token, float temp, float top_p, float u, int tid) {
+    return emo_nucleus_draw(l, n_token, temp, top_p, u, pd_smem + LDS_SAMP, tid, [] { PD_BARRIER(); });
+}
+
 __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
     bf16_t* xin = (bf16_t*)(pd_smem + LDS_XIN);        // layer input (post-LN2 / embedding), kept for the out-projection's residual
     bf16_t* xa = (bf16_t*)(pd_smem + LDS_XA);          // attention output rows
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
     float* npart = upart + 2 * 2 * 64;                 // [2][2] partial |x|^2
     float* ln1 = (float*)(pd_smem + LDS_LN);           // [gamma | beta] of norm1 of the layer (written by half A before P2, read by the pollers in P4)
     float* ln2 = ln1 + 2 * PD_D;                       // norm2 (written by half A in P4, read by the pollers in the next P1 / before the logits)
-    int* s_misc = (int*)(pd_smem + LDS_MISC);          // [0] error flag, [1] launch counter, [2] census: group on one XCD
+    int* s_misc = (int*)(pd_smem + LDS_MISC);          // [0] error flag, [1] launch counter, [2] census: group on one XCD, [4..7] the group's tokens
     float* oml = (float*)(pd_smem + LDS_OM);           // omega of the layer [64][64]
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), role = wave >> 2;      // 0 = A, 1 = B, 2 = pollers
@@ -334,6 +344,31 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
     const bool has_logits = m < (a.n_token + 15) / 16;                // member m owns logits tile m (uniform over the workgroup)
     const int nt = a.flags & 3;                                      // 0: default cache policy, 1: non-temporal weight loads, 2: timing ablation
 
+    // ---------------------------------------------------------------- in-kernel nucleus draw: member s < 4 of a group draws stream 4 g + s
+    // (the arithmetic of emo_sample_nucleus_step: same header).  The 512 threads of the two compute halves draw, the pollers keep the barrier count.
+    const bool sampling = a.samp_mode == 1;
+    if (sampling && m < PD_GS) {                                      // (uniform over the workgroup)
+        const int64_t r = (int64_t)g * PD_GS + m;
+        gu64* tokg = gs + OFF_TOK + m;
+        const unsigned ept = (unsigned)PD_LOAD(gs + OFF_CNT) * 128u + 126u;
+        if (r < a.n_real) {
+            if (role < 2) {
+                const int64_t kstep = a.step[r];
+                const int64_t tk = pd_draw(a.logits_in + r * a.n_token, a.n_token, a.temp, a.top_p, a.u_steps[kstep * a.n_real + r], tid);
+                if (tid == 0) {
+                    a.tok_out[r] = tk;
+                    if (a.seq) a.seq[r * a.ld_seq + a.col0 + kstep] = tk;
+                    PD_STORE(tokg, ((u64)ept << 32) | (u64)(unsigned)tk);      // always write-through: the census has not run yet
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < EMO_NUCLEUS_BARRIERS; ++i) PD_BARRIER();
+            }
+        } else if (tid == 0) {
+            PD_STORE(tokg, (u64)ept << 32);                             // idle padding stream: token 0
+        }
+    }
+
     if (role == 2) {
         // ========================================================================================== POLLERS (waves 8-11)
         if (c.t == 0) { s_misc[0] = 0; s_misc[2] = 0; }
@@ -345,10 +380,30 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
         PD_DIAG(15, 0, 0, c.t0);
         PD_DIAG(15, 0, 1, xcc);
         PD_DIAG(15, 1, 0, (u64)clock64());                           // shader-clock cycles: with the 100-MHz stamps = the effective clock
+        if (sampling && c.hw == 0) {                                  // the group's 4 drawn tokens
+            u64 v = 0;
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+                if (c.lane < PD_GS) { v = PD_LOAD(gs + OFF_TOK + c.lane); ok = (unsigned)(v >> 32) == ep0 + 126u; }
+                if (__all(ok)) break;
+                if (pd_spin_fail(spins, c, 0x800u)) break;
+            }
+            if (c.lane < PD_GS) s_misc[4 + c.lane] = (int)(unsigned)v;
+        }
+        if (sampling) PD_SYNC_OR_LEAVE();                             // Bt (every role): s_misc[4..7] = tokens
         {   // embedding: the group's 4 rows, 8 columns per poller thread (row s = poller wave s)
             const int s = c.hw, c8 = c.lane * 8;
             const int64_t stream = (int64_t)g * PD_GS + s;
-            const int64_t tk = a.tok[stream], sg = a.seg ? a.seg[stream] : 0, pos = a.pos0 + (a.pos_ids ? a.pos_ids[stream] : 0);
+            int64_t tk, pos;
+            if (sampling) {                                           // position = pos0 + (step counter AFTER the draw); the counter is bumped at the kernel's end
+                tk = s_misc[4 + s];
+                pos = stream < a.n_real ? a.pos0 + a.step[stream] + 1 : 0;
+            } else {
+                tk = a.tok[stream];
+                pos = a.pos0 + (a.pos_ids ? a.pos_ids[stream] : 0);
+            }
+            const int64_t sg = a.seg ? a.seg[stream] : 0;
             bf16x8 o;
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
@@ -494,6 +549,7 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
             const int lc16 = cc.lane & 15;
             PD_LOAD_A(LY[0]);
         }
+        if (sampling) PD_SYNC_OR_LEAVE();                             // Bt
         PD_SYNC_OR_LEAVE();                                           // B0
         c.local = s_misc[2] != 0;
         const unsigned lc = (unsigned)PD_LOAD(gs + OFF_CNT), ep0 = lc * 128u;
@@ -580,6 +636,8 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
             PD_BARRIER();                                             // 5b
             if (!last) PD_LOAD_A2(LY[l + 1]);
         }
+        // the drawn stream's step counter: every member of the group read it for the token's position before its first edge, long ago
+        if (sampling && m < PD_GS && c.t == 0 && (int64_t)g * PD_GS + m < a.n_real) a.step[(int64_t)g * PD_GS + m] += 1;
         if (!has_logits) return;
         PD_SYNC_OR_LEAVE();                                           // Fa
         {
@@ -619,6 +677,7 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
             const int lc16 = cc.lane & 15, d4 = (cc.t & 15) * 4, fg = cc.t >> 4;
             PD_LOAD_B(LY[0]);
         }
+        if (sampling) PD_SYNC_OR_LEAVE();                             // Bt
         PD_SYNC_OR_LEAVE();                                           // B0
         c.local = s_misc[2] != 0;
         const unsigned ep0 = (unsigned)PD_LOAD(gs + OFF_CNT) * 128u;  // (member 0 bumps the counter only after every member's last phase)
@@ -742,12 +801,12 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
 
 extern "C" int64_t emo_performer_decode_step_workspace_bytes(void) { return (int64_t)PD_WS_WORDS * 8; }
 
-extern "C" int emo_performer_decode_step(const void* layer_table, int64_t n_layers, const int64_t* tok, const int64_t* seg, const float* E, const float* Sg,
-                                         const float* pe, float emb_scale, int64_t pos0, const int64_t* pos_ids, const void* wout_packed,
-                                         const float* bout, int64_t n_token, float* logits, int64_t n_streams, int64_t d_model, int64_t n_head,
-                                         int64_t n_feat, int64_t d_ff, void* sync_ws, int64_t sync_ws_bytes, float eps, float ln_eps,
-                                         int64_t* diag, emo_stream_t stream) {
-    EMO_CHECK(layer_table && tok && E && pe && wout_packed && bout && logits && sync_ws, "emo_performer_decode_step: null pointer");
+static int pd_launch(const void* layer_table, int64_t n_layers, const int64_t* tok, const int64_t* seg, const float* E, const float* Sg, const float* pe,
+                     float emb_scale, int64_t pos0, const int64_t* pos_ids, const void* wout_packed, const float* bout, int64_t n_token, float* logits,
+                     int64_t n_streams, int64_t d_model, int64_t n_head, int64_t n_feat, int64_t d_ff, void* sync_ws, int64_t sync_ws_bytes, float eps,
+                     float ln_eps, int64_t* diag, int samp_mode, float temperature, float top_p, const float* u_steps, int64_t* step, int64_t* seq,
+                     int64_t ld_seq, int64_t col0, int64_t* tok_out, const float* logits_in, int64_t n_real, emo_stream_t stream) {
+    EMO_CHECK(layer_table && E && pe && wout_packed && bout && logits && sync_ws, "emo_performer_decode_step: null pointer");
     EMO_CHECK(d_model == PD_D && n_head == PD_H && n_feat == PD_F && d_ff == PD_FF,
               "emo_performer_decode_step: built for d_model 512 / 8 heads / 128 features / d_ff 2048 (got %lld / %lld / %lld / %lld)", (long long)d_model,
               (long long)n_head, (long long)n_feat, (long long)d_ff);
@@ -756,11 +815,19 @@ extern "C" int emo_performer_decode_step(const void* layer_table, int64_t n_laye
     EMO_CHECK(n_token >= 1 && n_token <= 16 * PD_GM, "emo_performer_decode_step: n_token <= 512");
     EMO_CHECK(!(seg && !Sg), "emo_performer_decode_step: seg ids without a segment table");
     EMO_CHECK(sync_ws_bytes >= (int64_t)PD_WS_WORDS * 8 && ((uintptr_t)sync_ws & 15) == 0, "emo_performer_decode_step: workspace too small / unaligned");
+    if (samp_mode) {
+        EMO_CHECK(u_steps && step && tok_out && logits_in && n_real >= 1 && n_real <= n_streams && temperature > 0.f && n_token <= 1024,
+                  "emo_performer_decode_step_sampled: bad sampling arguments");
+    } else {
+        EMO_CHECK(tok, "emo_performer_decode_step: null token pointer");
+    }
     PdArgs a;
     a.layers = (const PdLayer*)layer_table; a.n_layers = (int)n_layers;
     a.tok = tok; a.seg = seg; a.E = E; a.Sg = Sg; a.pe = pe; a.emb_scale = emb_scale; a.pos0 = pos0; a.pos_ids = pos_ids;
     a.wout = (const bf16_t*)wout_packed; a.bout = bout; a.n_token = (int)n_token; a.logits = logits; a.n_streams = (int)n_streams;
     a.sync = (u64*)sync_ws; a.eps = eps; a.ln_eps = ln_eps; a.diag = (u64*)diag;
+    a.samp_mode = samp_mode; a.temp = temperature; a.top_p = top_p; a.u_steps = u_steps; a.step = step; a.seq = seq; a.ld_seq = ld_seq; a.col0 = col0;
+    a.tok_out = tok_out; a.logits_in = logits_in; a.n_real = (int)n_real;
     { const char* e = getenv("EMO_PD_NT"); a.flags = e ? (atoi(e) & 3) : 0; }
     static_assert(LDS_TOTAL <= 96 * 1024, "LDS carve");
     const size_t lds = 96 * 1024;                                         // > half of the CU's LDS: one workgroup per CU
@@ -769,4 +836,24 @@ extern "C" int emo_performer_decode_step(const void* layer_table, int64_t n_laye
     hipLaunchKernelGGL(pd_step_kernel, dim3(PD_NG * PD_GM), dim3(PD_NT), lds, (hipStream_t)stream, a);
     EMO_LAUNCH_CHECK();
     return EMO_OK;
+}
+
+extern "C" int emo_performer_decode_step(const void* layer_table, int64_t n_layers, const int64_t* tok, const int64_t* seg, const float* E, const float* Sg,
+                                         const float* pe, float emb_scale, int64_t pos0, const int64_t* pos_ids, const void* wout_packed,
+                                         const float* bout, int64_t n_token, float* logits, int64_t n_streams, int64_t d_model, int64_t n_head,
+                                         int64_t n_feat, int64_t d_ff, void* sync_ws, int64_t sync_ws_bytes, float eps, float ln_eps,
+                                         int64_t* diag, emo_stream_t stream) {
+    return pd_launch(layer_table, n_layers, tok, seg, E, Sg, pe, emb_scale, pos0, pos_ids, wout_packed, bout, n_token, logits, n_streams, d_model, n_head,
+                     n_feat, d_ff, sync_ws, sync_ws_bytes, eps, ln_eps, diag, 0, 1.f, 1.f, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int emo_performer_decode_step_sampled(const void* layer_table, int64_t n_layers, const int64_t* seg, const float* E, const float* Sg,
+                                                 const float* pe, float emb_scale, int64_t pos0, const void* wout_packed, const float* bout,
+                                                 int64_t n_token, float* logits, int64_t n_streams, int64_t n_real, int64_t d_model, int64_t n_head,
+                                                 int64_t n_feat, int64_t d_ff, void* sync_ws, int64_t sync_ws_bytes, float eps, float ln_eps,
+                                                 float temperature, float top_p, const float* u_steps, int64_t* step, int64_t* seq, int64_t ld_seq,
+                                                 int64_t col0, int64_t* tok_out, emo_stream_t stream) {
+    return pd_launch(layer_table, n_layers, nullptr, seg, E, Sg, pe, emb_scale, pos0, nullptr, wout_packed, bout, n_token, logits, n_streams, d_model, n_head,
+                     n_feat, d_ff, sync_ws, sync_ws_bytes, eps, ln_eps, nullptr, 1, temperature, top_p, u_steps, step, seq, ld_seq, col0, tok_out, logits,
+                     n_real, stream);
 }

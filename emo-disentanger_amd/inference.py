@@ -185,6 +185,25 @@ class PerformerDecodeEngine(_EngineBase):
             return out[:self.n]
         return out
 
+    def step_sampled(self, seg_padded, temp, top_p, U, step_ctr, seq, col0, tok_out, pos0):
+        """One token step with the nucleus draw INSIDE the launch (emo_performer_decode_step_sampled): draws from the logits the previous step (or
+        the prefill: see load_logits) left in the engine's buffer, writes token / sequence / step counter like emo_sample_nucleus_step, then runs
+        the step on the drawn tokens.  seg_padded: int64 [n_pad] (or None)."""
+        m, pp = self.model, self.persist
+        if self._tables is None:
+            self._tables = (engine.embedding_table(self.ps, 'token_emb.'), engine.embedding_table(self.ps, 'segemb.') if m.use_segment_emb else None)
+        E, Sg = self._tables
+        seg = seg_padded if Sg is not None else None
+        pe = m.pe.pe if m.use_pe else m._zero_pe(self.max_len, m.d_model)
+        ops.performer_decode_step_sampled(self._persist_table(), m.n_layer, seg, E, Sg if seg is not None else None, pe, float(m.token_emb.emb_scale), pos0,
+                                          pp['wout'], pp['bout'], m.n_token, pp['logits'], self.n_pad, self.n, m.d_model, m.n_head,
+                                          2 * self.omegas[0].shape[1], 2048, pp['sync'], temp, top_p, U, step_ctr, seq, col0, tok_out)
+        return pp['logits'][:self.n]
+
+    def load_logits(self, logits):
+        """Put externally produced logits (the prefill's) where step_sampled draws from."""
+        self.persist['logits'][:self.n].copy_(logits)
+
     def check_persistent(self):
         """Raises if a one-launch step gave up (synchronises; call it where the caller reads results anyway)."""
         if self.persist is not None:
@@ -635,9 +654,19 @@ class _Chain:
             eng.pos_dev, eng.dev_pos0, eng.pos_auto = step_ctr, T0 - 1, False
             nxt_buf = torch.empty(n, dtype=torch.long, device=dev)
 
-            def one_step():
-                ops.sample_nucleus_step(logits_buf, temp, top_p, U, step_ctr, seq=out, col0=T0, out=nxt_buf)
-                eng.step(nxt_buf, seg_col, dev_pos=True, logits_out=logits_buf)
+            if getattr(eng, 'persist', None) is not None and os.environ.get('EMO_PD_SAMPLER', '1') != '0':
+                # one launch per token: the draw runs inside the persistent step (the same device code as emo_sample_nucleus_step)
+                eng.load_logits(logits_buf)
+                seg_p = torch.zeros(eng.n_pad, dtype=torch.long, device=dev)
+                seg_p[:n] = seg_col
+                Uc = U.contiguous()
+
+                def one_step():
+                    eng.step_sampled(seg_p, temp, top_p, Uc, step_ctr, out, T0, nxt_buf, T0 - 1)
+            else:
+                def one_step():
+                    ops.sample_nucleus_step(logits_buf, temp, top_p, U, step_ctr, seq=out, col0=T0, out=nxt_buf)
+                    eng.step(nxt_buf, seg_col, dev_pos=True, logits_out=logits_buf)
         else:
             step_idx = torch.zeros(1, dtype=torch.long, device=dev)
 

@@ -12,7 +12,7 @@ from ._lib import (ACT_GELU_NEW, ACT_NONE, ACT_RELU, BF16, F32, MUL_BITMASK, MUL
                    dtype_code, lib, ptr, stream)
 
 __all__ = ['gemm', 'colsum', 'embed_fwd', 'embed_bwd', 'layernorm_fwd', 'layernorm_bwd', 'dropout_apply', 'favor_attn_fwd',
-           'favor_attn_bwd', 'favor_decode_step', 'performer_decode_step', 'favor_draw_omega', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'relpos_attn_fwd', 'relpos_attn_bwd', 'relpos_attn_decode', 'xent_fwd',
+           'favor_attn_bwd', 'favor_decode_step', 'performer_decode_step', 'performer_decode_step_sampled', 'favor_draw_omega', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'relpos_attn_fwd', 'relpos_attn_bwd', 'relpos_attn_decode', 'xent_fwd',
            'xent_bwd', 'argmax', 'sample_nucleus', 'sample_nucleus_step', 'accuracy_counts', 'sumsq', 'clip_coef', 'adam_step', 'cast', 'add_bias2',
            'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW', 'MUL_BITMASK', 'gemm_bitmask_ok', 'bitmask_rows']
 
@@ -250,6 +250,20 @@ def performer_decode_step(layer_table, n_layers, tok, seg, E, Sg, pe, emb_scale,
     check(lib.emo_performer_decode_step(ptr(layer_table), n_layers, ptr(tok), ptr(seg), ptr(E), ptr(Sg), ptr(pe), emb_scale, pos0, ptr(pos_ids),
                                         ptr(wout_packed), ptr(bout), n_token, ptr(logits), n_streams, d_model, n_head, n_feat, d_ff,
                                         ptr(sync_ws), sync_ws.numel() * sync_ws.element_size(), eps, ln_eps, ptr(diag), stream()))
+    return logits
+
+
+def performer_decode_step_sampled(layer_table, n_layers, seg, E, Sg, pe, emb_scale, pos0, wout_packed, bout, n_token, logits, n_streams, n_real,
+                                  d_model, n_head, n_feat, d_ff, sync_ws, temperature, top_p, u_steps, step, seq, col0, tok_out, eps=1e-6, ln_eps=1e-5):
+    """emo_performer_decode_step with the next token drawn inside the launch (emo_hip.h)."""
+    seg = _c(seg)
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.shape == (n_streams, n_token)
+    assert u_steps.dtype == torch.float32 and u_steps.is_contiguous() and u_steps.shape[1] == n_real and step.dtype == torch.int64 and tok_out.dtype == torch.int64
+    assert seq is None or (seq.dtype == torch.int64 and seq.stride(1) == 1)
+    check(lib.emo_performer_decode_step_sampled(ptr(layer_table), n_layers, ptr(seg), ptr(E), ptr(Sg), ptr(pe), emb_scale, pos0, ptr(wout_packed), ptr(bout),
+                                                n_token, ptr(logits), n_streams, n_real, d_model, n_head, n_feat, d_ff, ptr(sync_ws),
+                                                sync_ws.numel() * sync_ws.element_size(), eps, ln_eps, temperature, top_p, ptr(u_steps), ptr(step), ptr(seq),
+                                                0 if seq is None else seq.stride(0), col0, ptr(tok_out), stream()))
     return logits
 
 

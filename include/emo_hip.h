@@ -184,6 +184,16 @@ int emo_performer_decode_step(const void* layer_table, int64_t n_layers, const i
                               const void* wout_packed, const float* bout, int64_t n_token, float* logits, int64_t n_streams,
                               int64_t d_model, int64_t n_head, int64_t n_feat, int64_t d_ff, void* sync_ws, int64_t sync_ws_bytes,
                               float eps, float ln_eps, int64_t* diag, emo_stream_t stream);
+/* The same launch with the NEXT token drawn inside it (the sampling half of the loop of inference.py:252-277, arithmetic of emo_sample_nucleus_step:
+ * same device code): member s < 4 of a group draws stream 4 g + s from `logits` AS THE PREVIOUS STEP LEFT IT (temperature, nucleus top_p, uniform
+ * u_steps[step[r] * n_real + r]), writes the token to tok_out[r] and seq[r * ld_seq + col0 + step[r]], and the step then embeds it at position
+ * pos0 + step[r] + 1; step[r] is incremented when the launch is done.  Streams r >= n_real are idle padding (n_streams = n_real rounded up to 4). */
+int emo_performer_decode_step_sampled(const void* layer_table, int64_t n_layers, const int64_t* seg, const float* E, const float* Sg,
+                                      const float* pe, float emb_scale, int64_t pos0, const void* wout_packed, const float* bout,
+                                      int64_t n_token, float* logits, int64_t n_streams, int64_t n_real, int64_t d_model, int64_t n_head,
+                                      int64_t n_feat, int64_t d_ff, void* sync_ws, int64_t sync_ws_bytes, float eps, float ln_eps,
+                                      float temperature, float top_p, const float* u_steps, int64_t* step, int64_t* seq, int64_t ld_seq,
+                                      int64_t col0, int64_t* tok_out, emo_stream_t stream);
 
 /* FAVOR+ omega draw (fast-transformers orthogonal_random_matrix_, called from new_feature_map() on every
  * forward — SURVEY F8): gauss [n_layers, ceil((n_feat/2)/dh), dh, dh] ~ N(0,1) from the caller's RNG ->

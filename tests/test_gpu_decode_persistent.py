@@ -62,6 +62,10 @@ def test_one_launch_step_matches_launch_chain_and_fp32(n, L, monkeypatch):
     c = inf.generate_streams(mb, ptok, pseg, 12, greedy=False, seed=3, use_graph=True)
     d = inf.generate_streams(mb, ptok, pseg, 12, greedy=False, seed=3, use_graph=False)
     assert torch.equal(a, b) and torch.equal(c, d)
+    # the draw inside the launch picks the same tokens as the sampler kernel in front of it (same device code, same logits)
+    monkeypatch.setenv('EMO_PD_SAMPLER', '0')
+    e = inf.generate_streams(mb, ptok, pseg, 12, greedy=False, seed=3, use_graph=True)
+    assert torch.equal(c, e)
 
 
 def test_one_launch_step_refuses_what_it_was_not_built_for():
