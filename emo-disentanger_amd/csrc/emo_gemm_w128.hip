@@ -467,7 +467,9 @@ static int64_t w_tn_plan(int64_t M, int64_t N, int64_t K, int& full, int& extra)
     if (f > 8) f = 8;                                          // at most 64 splits
     int64_t x = f < 8 ? (8 * (32 - f * ntile)) / ntile : 0;
     if (e2 && atoi(e2) == 2) x = 0;                            // (diagnostics: whole splits per XCD only)
-    while (nkt / (8 * f + x) < 8) {                            // at least 8 K-tiles per split
+    int64_t min_kt = 16;                                       // K-tiles per split (r04: 8 let batch-size-4 steps — 512 tokens per split — onto this tile, where
+    { const char* e3 = getenv("EMO_W128_TN_MINKT"); if (e3 && atoi(e3) > 0) min_kt = atoi(e3); }      // prologue + epilogue dominate: 8.89 vs 8.39 ms per step)
+    while (nkt / (8 * f + x) < min_kt) {
         if (x) x = 0;
         else if (f > 1) --f;
         else return 0;
