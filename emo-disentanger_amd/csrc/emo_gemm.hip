@@ -826,7 +826,15 @@ static void dispatch_glds(bool akc, bool bkc, dim3 grid, hipStream_t st, const b
     // its CU and every K step exposed an L2 / HBM round trip -> the 4-stage ring of 32-deep tiles (three tiles in flight inside the block)
     static const bool small_off = getenv("EMO_GEMM_SMALLGRID") != nullptr && atoi(getenv("EMO_GEMM_SMALLGRID")) == 0;
     // (r03, same box: batch-4 step 8.85 -> 8.79 ms, stage 1 7.64 -> 7.47 ms; a 64-deep double buffer instead was erratic: 8.5 / 9.2 ms)
-    if (grid.x <= 512 && !small_off && K >= 128) { dispatch_glds2<OutT, 32, 4>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep); return; }
+    if (grid.x <= 512 && !small_off && K >= 128) {
+        // 64-deep tiles in the same 4-stage ring = twice the bytes in flight per block (128 KB of LDS, one block per CU): what bounds these products is
+        // the bytes one block keeps in flight (r04, same box, two pairs: stage 1 262 / 266 -> 284 / 283 k tokens/s, batch-size-4 steps unchanged);
+        // EMO_GEMM_SMALL64=0: the 32-deep ring
+        static const bool small64 = !(getenv("EMO_GEMM_SMALL64") != nullptr && atoi(getenv("EMO_GEMM_SMALL64")) == 0);
+        if (small64 && can64 && kps >= 512) { dispatch_glds2<OutT, 64, 4>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep); return; }
+        dispatch_glds2<OutT, 32, 4>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
+        return;
+    }
     if (bkc && K > 1024 && can64) dispatch_glds2<OutT, 64, 2>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
     else if (bkc) dispatch_glds2<OutT, 32, 3>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
     else dispatch_glds2<OutT, 32, 2>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
