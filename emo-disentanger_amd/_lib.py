@@ -41,6 +41,8 @@ _SIG = {
     'emo_embed_bwd': (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_f, c_u64, c_u64, c_p]),
     'emo_layernorm_fwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_l, c_f, c_p]),
     'emo_layernorm_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_l, c_f, c_u64, c_u64, c_p]),
+    'emo_layernorm_bwd_workspace_bytes': (c_l, [c_i, c_l, c_l]),
+    'emo_layernorm_bwd_ws': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_l, c_f, c_u64, c_u64, c_p, c_l, c_p]),
     'emo_dropout_apply': (c_i, [c_p, c_p, c_i, c_l, c_f, c_u64, c_u64, c_p]),
     'emo_favor_attn_workspace_bytes': (c_l, [c_l, c_l, c_l, c_l, c_l]),
     'emo_favor_attn_fwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_l, c_l, c_l, c_l, c_l, c_f, c_p, c_l, c_p]),

@@ -395,7 +395,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_bf16_d512_kernel(const bf16
                                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                       const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
                                                                       bf16_t* __restrict__ dx, bf16_t* __restrict__ dx_drop, float* __restrict__ dgamma,
-                                                                      float* __restrict__ dbeta, float* __restrict__ dcol, int64_t M, DropCtx drop) {
+                                                                      float* __restrict__ dbeta, float* __restrict__ dcol, int64_t M, DropCtx drop,
+                                                                      float* __restrict__ part) {
     constexpr int D = 512;
     __shared__ float red[3][4][D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -452,6 +453,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_bf16_d512_kernel(const bf16
 #pragma unroll
     for (int i = 0; i < 8; ++i) { red[0][wave][c + i] = dg[i]; red[1][wave][c + i] = db[i]; red[2][wave][c + i] = dc[i]; }
     __syncthreads();
+    if (part) {                                      // per-block partial column sums [gridDim][3][512]: ln_bwd_colsum_kernel adds them up in a fixed order
+        float* pb = part + (int64_t)blockIdx.x * 3 * D;
+        for (int cc = threadIdx.x; cc < 3 * D; cc += 256) {
+            const int w = cc >> 9, c1 = cc & (D - 1);
+            pb[cc] = red[w][0][c1] + red[w][1][c1] + red[w][2][c1] + red[w][3][c1];
+        }
+        return;
+    }
     for (int cc = threadIdx.x; cc < D; cc += 256) {
         atomicAdd(dgamma + cc, red[0][0][cc] + red[0][1][cc] + red[0][2][cc] + red[0][3][cc]);
         atomicAdd(dbeta + cc, red[1][0][cc] + red[1][1][cc] + red[1][2][cc] + red[1][3][cc]);
@@ -459,9 +468,53 @@ __global__ __launch_bounds__(256) void layernorm_bwd_bf16_d512_kernel(const bf16
     }
 }
 
-extern "C" int emo_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                                 const void* dres, void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dcol, int dtype,
-                                 int64_t M, int64_t D, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
+// dgamma / dbeta / dcol += the blocks' partial column sums, summed in block order (deterministic; r04: the 3 x 512 fp32 atomics per block were
+// ~8 us per 256 blocks — a third of the kernel at 8192 rows — and made these three gradients depend on the arrival order).
+// A block owns 32 columns of one of the three vectors: 8 column quads x 32 slices of the block list.
+__global__ __launch_bounds__(256) void ln_bwd_colsum_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ dcol) {
+    constexpr int D = 512;
+    __shared__ f32x4 red[32][8];
+    const int w = blockIdx.x / (D / 32), c0 = (blockIdx.x % (D / 32)) * 32 + (threadIdx.x & 7) * 4, sl = threadIdx.x >> 3;
+    float* out = w == 0 ? dgamma : (w == 1 ? dbeta : dcol);
+    if (!out) return;
+    const float* p = part + (int64_t)w * D + c0;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a, c = a, d = a;
+    int i = sl;
+    for (; i + 96 < nblk; i += 128) {
+        const f32x4 x0 = *(const f32x4*)(p + (int64_t)i * 3 * D), x1 = *(const f32x4*)(p + (int64_t)(i + 32) * 3 * D);
+        const f32x4 x2 = *(const f32x4*)(p + (int64_t)(i + 64) * 3 * D), x3 = *(const f32x4*)(p + (int64_t)(i + 96) * 3 * D);
+        a += x0; b += x1; c += x2; d += x3;
+    }
+    for (; i < nblk; i += 32) a += *(const f32x4*)(p + (int64_t)i * 3 * D);
+    red[sl][threadIdx.x & 7] = (a + b) + (c + d);
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        f32x4 s = red[0][threadIdx.x];
+        for (int j = 1; j < 32; ++j) s += red[j][threadIdx.x];
+        f32x4 o = *(f32x4*)(out + c0);
+        o += s;
+        *(f32x4*)(out + c0) = o;
+    }
+}
+
+// partial column sums of the bf16 / D = 512 kernel: [blocks][3][512] fp32 (0: the shape takes the generic kernel, which accumulates with atomics)
+static int64_t ln_bwd_blocks(int64_t M) {
+    int64_t b = cdiv64(M, 8);                         // two rows per wave at small M; >= 128 rows per block at the benchmark's 131072
+    if (b > 1024) b = 1024;
+    { const char* eb = getenv("EMO_LN_BWD_BLOCKS"); if (eb && atoi(eb) > 0) b = atoi(eb); }
+    return b < 1 ? 1 : b;
+}
+extern "C" int64_t emo_layernorm_bwd_workspace_bytes(int dtype, int64_t M, int64_t D) {
+    if (dtype != EMO_BF16 || D != 512 || getenv("EMO_LN_GENERIC") != nullptr) return 0;
+    { const char* e = getenv("EMO_LN_BWD_ATOMIC"); if (e && atoi(e) != 0) return 0; }
+    return ln_bwd_blocks(M) * 3 * 512 * (int64_t)sizeof(float);
+}
+
+extern "C" int emo_layernorm_bwd_ws(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                    const void* dres, void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dcol, int dtype,
+                                    int64_t M, int64_t D, float p_drop, uint64_t seed, uint64_t offset, void* workspace, int64_t workspace_bytes,
+                                    emo_stream_t stream) {
     EMO_CHECK(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "emo_layernorm_bwd: null pointer");
     EMO_CHECK((D & 3) == 0 && D <= 1024, "emo_layernorm_bwd: D must be a multiple of 4 and <= 1024 (got %lld)", (long long)D);
     hipStream_t st = (hipStream_t)stream;
@@ -471,12 +524,19 @@ extern "C" int emo_layernorm_bwd(const void* dy, const void* x, const float* gam
     DropCtx drop = make_drop(p_drop, seed, offset);
     if (dtype == EMO_BF16 && D == 512 && getenv("EMO_LN_GENERIC") == nullptr &&
         ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres | (uintptr_t)dx_drop | (uintptr_t)gamma) & 15) == 0)) {
-        // every block ends with 3 x 512 fp32 atomics (dgamma, dbeta, dcol): ~25 us per 1024 blocks (r01 sweep), so a block takes >= 32 rows
-        int64_t b8 = cdiv64(M, 32);
-        if (b8 > 1024) b8 = 1024;
-        { const char* eb = getenv("EMO_LN_BWD_BLOCKS"); if (eb && atoi(eb) > 0) b8 = atoi(eb); }
+        const int64_t need = emo_layernorm_bwd_workspace_bytes(dtype, M, D);
+        const bool use_ws = workspace && need > 0 && workspace_bytes >= need && (((uintptr_t)workspace | (uintptr_t)dgamma | (uintptr_t)dbeta | (uintptr_t)dcol) & 15) == 0;
+        int64_t b8;
+        if (use_ws) b8 = ln_bwd_blocks(M);
+        else {
+            // every block ends with 3 x 512 fp32 atomics (dgamma, dbeta, dcol): ~25 us per 1024 blocks (r01 sweep), so a block takes >= 32 rows
+            b8 = cdiv64(M, 32);
+            if (b8 > 1024) b8 = 1024;
+        }
         hipLaunchKernelGGL(layernorm_bwd_bf16_d512_kernel, dim3((unsigned)b8), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
-                           (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dx_drop, dgamma, dbeta, dcol, M, drop);
+                           (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dx_drop, dgamma, dbeta, dcol, M, drop, use_ws ? (float*)workspace : nullptr);
+        if (use_ws)
+            hipLaunchKernelGGL(ln_bwd_colsum_kernel, dim3(3 * 512 / 32), dim3(256), 0, st, (const float*)workspace, (int)b8, dgamma, dbeta, dcol);
         EMO_LAUNCH_CHECK();
         return EMO_OK;
     }
@@ -487,6 +547,12 @@ extern "C" int emo_layernorm_bwd(const void* dy, const void* x, const float* gam
 #undef LN_BWD
     EMO_LAUNCH_CHECK();
     return EMO_OK;
+}
+
+extern "C" int emo_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                 const void* dres, void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dcol, int dtype,
+                                 int64_t M, int64_t D, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
+    return emo_layernorm_bwd_ws(dy, x, gamma, mean, rstd, dres, dx, dx_drop, dgamma, dbeta, dcol, dtype, M, D, p_drop, seed, offset, nullptr, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ dropout re-apply

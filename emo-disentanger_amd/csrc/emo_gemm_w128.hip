@@ -474,7 +474,9 @@ static int64_t w_tn_plan(int64_t M, int64_t N, int64_t K, int& full, int& extra)
         else if (f > 1) --f;
         else return 0;
     }
-    if (ntile * (8 * f + x) < 160) return 0;                   // (too few blocks for the chip: the 128 x 128 kernel's finer tiles win)
+    int64_t min_blk = 96;                                      // (r04: 160 -> 96 lets the batch-size-4 FFN / QKV weight gradients on: 8.30 -> 7.97 ms per step)
+    { const char* e4 = getenv("EMO_W128_TN_MINBLK"); if (e4 && atoi(e4) > 0) min_blk = atoi(e4); }
+    if (ntile * (8 * f + x) < min_blk) return 0;                   // (too few blocks for the chip: the 128 x 128 kernel's finer tiles win)
     full = (int)f;
     extra = (int)x;
     return 8 * f + x;

@@ -180,8 +180,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, want_drop=
     assert dy.is_contiguous() and x.is_contiguous() and (dres is None or dres.is_contiguous())
     dx = torch.empty_like(x)
     dxd = torch.empty_like(x) if want_drop else None
-    check(lib.emo_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dxd), ptr(dgamma), ptr(dbeta),
-                                ptr(dcol), dtype_code(x.dtype), M, D, p_drop, seed, offset, stream()))
+    ws, ws_bytes = _workspace('ln_bwd', x.device, lib.emo_layernorm_bwd_workspace_bytes(dtype_code(x.dtype), M, D))
+    check(lib.emo_layernorm_bwd_ws(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dxd), ptr(dgamma), ptr(dbeta),
+                                   ptr(dcol), dtype_code(x.dtype), M, D, p_drop, seed, offset, ptr(ws), ws_bytes, stream()))
     return dx, dxd
 
 

@@ -447,6 +447,36 @@ def test_layernorm_fwd_bwd(dt, D):
     _close(dxd, ops.dropout_apply(dx, 0.25, 9, 2), dt)
 
 
+@pytest.mark.parametrize('M', [7, 2048, 8193, 40000])
+def test_layernorm_bwd_column_sums_without_atomics(M, monkeypatch):
+    # bf16 / D = 512: the blocks' partial dgamma / dbeta / dcol sums go through the caller's workspace and are added in block order:
+    # += semantics kept, equal to the atomic path within fp32 summation order, and bit-identical from run to run
+    ops = _ops()
+    D, dt = 512, torch.bfloat16
+    x, dy, dres = _r(M, D, seed=1, dt=dt).cuda(), _r(M, D, seed=4, dt=dt).cuda(), _r(M, D, seed=5, dt=dt).cuda()
+    gm, bt = (_r(D, seed=2) * 0.1 + 1).cuda(), _r(D, seed=3).cuda()
+    _, mean, rstd = ops.layernorm_fwd(x, gm, bt)
+
+    def run():
+        acc = [torch.full((D,), 0.5, device='cuda') for _ in range(3)]
+        dx, dxd = ops.layernorm_bwd(dy, x, gm, mean, rstd, acc[0], acc[1], dres=dres, want_drop=True, p_drop=0.1, seed=3, offset=1, dcol=acc[2])
+        return [dx, dxd] + acc
+    assert ops.lib.emo_layernorm_bwd_workspace_bytes(ops.dtype_code(dt), M, D) > 0
+    a, b = run(), run()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    monkeypatch.setenv('EMO_LN_BWD_ATOMIC', '1')
+    assert ops.lib.emo_layernorm_bwd_workspace_bytes(ops.dtype_code(dt), M, D) == 0
+    c = run()
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+    for u, v in zip(a[2:], c[2:]):
+        assert (u - v).abs().max().item() <= 2e-5 * max(1.0, v.abs().max().item())
+    xf = x.float()
+    xh = (xf - mean[:, None]) * rstd[:, None]
+    assert (a[2] - 0.5 - (dy.float() * xh).sum(0)).abs().max().item() <= 2e-3 * (M ** 0.5)
+    assert torch.allclose(a[4] - 0.5, a[1].float().sum(0), atol=1e-3 * (M ** 0.5), rtol=1e-4)
+
+
 @pytest.mark.parametrize('M', [4096, 4101, 8193])
 def test_layernorm_fwd_bf16_d512_fast_path(M):
     # >= 4096 rows of 512 bf16 columns take the one-16-B-load-per-lane kernel (two rows per wave step: odd row counts exercise the tail)

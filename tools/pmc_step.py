@@ -16,5 +16,13 @@ m = MusicPerformer(C['n_token'], C['n_layer'], C['n_head'], C['d_model'], C['d_f
 opt = FusedAdam(m, lr=1e-4, max_grad_norm=0.5)
 bs = [synthetic_batch(C['n_token'], B, C['seq'], seed=1234 + 100 * i, device='cuda') for i in range(2)]
 cfg = tr.TrainConfig(redraw_prob=1.0, log_interval=10 ** 9, ckpt_dir=tempfile.mkdtemp(), verbose=False)
-tr.train_model(1, m, [bs[i % 2] for i in range(int(os.environ.get('STEPS', 3)))], opt, None, C['n_token'] - 1, cfg=cfg)
+import time
+n = int(os.environ.get('STEPS', 3))
+if os.environ.get('TIME'):                                   # TIME=1: 3 untimed steps first, then report ms per step (same-box A/B of kernel variants)
+    tr.train_model(1, m, [bs[i % 2] for i in range(3)], opt, None, C['n_token'] - 1, cfg=cfg)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+tr.train_model(1, m, [bs[i % 2] for i in range(n)], opt, None, C['n_token'] - 1, cfg=cfg)
 torch.cuda.synchronize()
+if os.environ.get('TIME'):
+    dt = (time.perf_counter() - t0) / n
+    print('B=%d: %.3f ms/step = %.1f k tokens/s' % (B, dt * 1e3, B * C['seq'] / dt / 1e3))
