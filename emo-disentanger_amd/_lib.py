@@ -55,6 +55,9 @@ _SIG = {
     'emo_favor_draw_omega': (c_i, [c_p, c_p, c_l, c_l, c_l, c_p]),
     'emo_softmax_attn_fwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p]),
     'emo_softmax_attn_bwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p]),
+    'emo_softmax_attn_keep_bytes': (c_l, [c_i, c_l, c_l, c_l, c_l, c_f]),
+    'emo_softmax_attn_fwd_keep': (c_i, [c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p, c_l, c_p]),
+    'emo_softmax_attn_bwd_keep': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p, c_l, c_p]),
     'emo_relpos_attn_fwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p]),
     'emo_relpos_attn_bwd_kv': (c_i, [c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p]),
     'emo_relpos_attn_bwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p]),

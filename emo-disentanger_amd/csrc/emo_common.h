@@ -117,6 +117,16 @@ __device__ __forceinline__ void drop_mult4(const DropCtx& d, uint64_t idx0, floa
     m[3] = (h2 >> 16) >= d.thr16 ? d.scale : 0.f;
 }
 
+// The same for an aligned quad (idx0 % 4 == 0, dropout on), also returning the four keep decisions as bits pos .. pos + 3 OR-ed into `word`
+// (the attention forward's keep words): the compares are shared between the multiplier and the bit.
+__device__ __forceinline__ void drop_mult4_bits(const DropCtx& d, uint64_t idx0, float (&m)[4], uint32_t& word, int pos) {
+    const uint32_t quad = (uint32_t)(idx0 >> 2) ^ (uint32_t)(idx0 >> 34) * 0x9E3779B1u;
+    const uint32_t h = emo_drop_hash(d, quad), h2 = emo_xs32(h);
+    const bool c0 = (h & 0xFFFFu) >= d.thr16, c1 = (h >> 16) >= d.thr16, c2 = (h2 & 0xFFFFu) >= d.thr16, c3 = (h2 >> 16) >= d.thr16;
+    m[0] = c0 ? d.scale : 0.f; m[1] = c1 ? d.scale : 0.f; m[2] = c2 ? d.scale : 0.f; m[3] = c3 ? d.scale : 0.f;
+    word |= (c0 ? 1u << pos : 0u) | (c1 ? 2u << pos : 0u) | (c2 ? 4u << pos : 0u) | (c3 ? 8u << pos : 0u);
+}
+
 // Key-stationary layout (attention dK/dV passes): a lane owns ONE key column j and 4 query rows t0 .. t0+3, so its four elements are T apart
 // and drop_mult4 does not apply — but the 4 lanes of a quad own keys 4q .. 4q+3 of the SAME rows, i.e. the four 16-bit fields of one hash
 // per row.  Lane c of the quad hashes row t0 + c and the words travel by DPP quad broadcasts: 1 hash per lane per 4 rows instead of 4 (the

@@ -479,19 +479,22 @@ template <typename CT, int DH> static size_t sa_dkv_lds() { typedef SaDims<CT, D
 
 // emo_softmax_attn32.hip: bf16 / d_head 64 / T % 128 == 0 kernels on 32 x 32 x 16 tiles (false: not covered -> the kernels of this file)
 bool emo_sattn32_dkv_try(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const bf16_t* dout, int64_t ld_out, const float* lse, const float* delta,
-                         bf16_t* dk, bf16_t* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, DropCtx drop, hipStream_t st);
+                         bf16_t* dk, bf16_t* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, DropCtx drop, const uint32_t* keep, hipStream_t st);
 bool emo_sattn32_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ld_out, float* lse, int64_t B, int64_t T,
-                     int64_t H, DropCtx drop, hipStream_t st);
+                     int64_t H, DropCtx drop, uint32_t* keep, hipStream_t st);
+int64_t emo_sattn32_keep_bytes(int64_t B, int64_t T, int64_t H, int64_t dh, float p_drop);
 
 template <typename CT, int DH>
 static int run_sattn(int which, const void* q, const void* k, const void* v, int64_t ld, const void* out, const void* dout, int64_t ld_out, float* lse,
-                     float* delta, void* dq, void* dk, void* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, DropCtx drop, hipStream_t st) {
+                     float* delta, void* dq, void* dk, void* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, DropCtx drop, uint32_t* keep, hipStream_t st) {
     if constexpr (sizeof(CT) == 2 && DH == 64) {
-        if (which == 0 && emo_sattn32_try(0, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, (bf16_t*)out, ld_out, lse, B, T, H, drop, st)) {
+        if (which == 0 && emo_sattn32_try(0, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, (bf16_t*)out, ld_out, lse, B, T, H, drop, keep, st)) {
             EMO_LAUNCH_CHECK();
             return EMO_OK;
         }
     }
+    // keep words exist only in the 32 x 32 kernels' layout: a forward that cannot write them must not pretend to, a backward must not half-use them
+    EMO_CHECK(!(which == 0 && keep), "softmax attention: keep words requested but the call is not served by the 32 x 32 kernels (bf16, d_head 64, T %% 128 == 0, 16-B aligned views)");
     dim3 grid((unsigned)((T + 63) / 64), (unsigned)(B * H));
     static bool attr = false;
     const size_t lfwd = sa_fwd_lds<CT, DH>(), ldq = sa_dq_lds<CT, DH>(), ldkv = sa_dkv_lds<CT, DH>();
@@ -513,7 +516,8 @@ static int run_sattn(int which, const void* q, const void* k, const void* v, int
         bool dkv32 = false;
         if constexpr (sizeof(CT) == 2 && DH == 64)
             dkv32 = emo_sattn32_dkv_try((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, (const bf16_t*)dout, ld_out, lse, delta, (bf16_t*)dk, (bf16_t*)dv, ld_d,
-                                        B, T, H, drop, st);
+                                        B, T, H, drop, keep, st);
+        EMO_CHECK(dkv32 || !keep, "softmax attention backward: keep words given but the 32 x 32 dK/dV kernel does not serve the call");
         if (!dkv32)
             hipLaunchKernelGGL(kdkv, grid, dim3(256), ldkv, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, (const CT*)dout, ld_out, lse, delta, (CT*)dk,
                                (CT*)dv, ld_d, T, H, drop);
@@ -524,11 +528,11 @@ static int run_sattn(int which, const void* q, const void* k, const void* v, int
 
 static int dispatch_sattn(int which, int dtype, int64_t dh, const void* q, const void* k, const void* v, int64_t ld, const void* out, const void* dout,
                           int64_t ld_out, float* lse, float* delta, void* dq, void* dk, void* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H,
-                          DropCtx drop, hipStream_t st) {
+                          DropCtx drop, uint32_t* keep, hipStream_t st) {
 #define SA_CASE(DHv)                                                                                                                      \
     if (dh == DHv) {                                                                                                                      \
-        if (dtype == EMO_BF16) return run_sattn<bf16_t, DHv>(which, q, k, v, ld, out, dout, ld_out, lse, delta, dq, dk, dv, ld_d, B, T, H, drop, st); \
-        return run_sattn<float, DHv>(which, q, k, v, ld, out, dout, ld_out, lse, delta, dq, dk, dv, ld_d, B, T, H, drop, st);             \
+        if (dtype == EMO_BF16) return run_sattn<bf16_t, DHv>(which, q, k, v, ld, out, dout, ld_out, lse, delta, dq, dk, dv, ld_d, B, T, H, drop, keep, st); \
+        return run_sattn<float, DHv>(which, q, k, v, ld, out, dout, ld_out, lse, delta, dq, dk, dv, ld_d, B, T, H, drop, keep, st);             \
     }
     SA_CASE(64)
     SA_CASE(32)
@@ -547,25 +551,48 @@ static int sattn_check(const void* q, const void* k, const void* v, int64_t ld, 
     return EMO_OK;
 }
 
-extern "C" int emo_softmax_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, void* out, int64_t ld_out, float* lse, int dtype, int64_t B,
-                                    int64_t T, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
+extern "C" int64_t emo_softmax_attn_keep_bytes(int dtype, int64_t B, int64_t T, int64_t H, int64_t dh, float p_drop) {
+    return dtype == EMO_BF16 ? emo_sattn32_keep_bytes(B, T, H, dh, p_drop) : 0;
+}
+
+extern "C" int emo_softmax_attn_fwd_keep(const void* q, const void* k, const void* v, int64_t ld, void* out, int64_t ld_out, float* lse, int dtype, int64_t B,
+                                         int64_t T, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint64_t offset, void* keep, int64_t keep_bytes,
+                                         emo_stream_t stream) {
     int rc = sattn_check(q, k, v, ld, ld_out, dtype, dh);
     if (rc) return rc;
     EMO_CHECK(out && lse && ((uintptr_t)out & 15) == 0, "emo_softmax_attn_fwd: bad out/lse");
+    if (keep) {
+        const int64_t need = emo_softmax_attn_keep_bytes(dtype, B, T, H, dh, p_drop);
+        EMO_CHECK(need > 0 && keep_bytes >= need && ((uintptr_t)keep & 15) == 0, "emo_softmax_attn_fwd_keep: keep buffer of %lld bytes, need %lld (emo_softmax_attn_keep_bytes; 0 = not available for this call)",
+                  (long long)keep_bytes, (long long)need);
+    }
     return dispatch_sattn(0, dtype, dh, q, k, v, ld, out, nullptr, ld_out, lse, nullptr, nullptr, nullptr, nullptr, 0, B, T, H, make_drop(p_drop, seed, offset),
-                          (hipStream_t)stream);
+                          (uint32_t*)keep, (hipStream_t)stream);
+}
+extern "C" int emo_softmax_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, void* out, int64_t ld_out, float* lse, int dtype, int64_t B,
+                                    int64_t T, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
+    return emo_softmax_attn_fwd_keep(q, k, v, ld, out, ld_out, lse, dtype, B, T, H, dh, p_drop, seed, offset, nullptr, 0, stream);
 }
 
-extern "C" int emo_softmax_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* out, const void* dout, int64_t ld_out,
-                                    const float* lse, float* delta_ws, void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H,
-                                    int64_t dh, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
+extern "C" int emo_softmax_attn_bwd_keep(const void* q, const void* k, const void* v, int64_t ld, const void* out, const void* dout, int64_t ld_out,
+                                         const float* lse, float* delta_ws, void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H,
+                                         int64_t dh, float p_drop, uint64_t seed, uint64_t offset, const void* keep, int64_t keep_bytes, emo_stream_t stream) {
     int rc = sattn_check(q, k, v, ld, ld_out, dtype, dh);
     if (rc) return rc;
     EMO_CHECK(out && dout && lse && delta_ws && dq && dk && dv, "emo_softmax_attn_bwd: null pointer");
     EMO_CHECK(ld_d % 4 == 0 && (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)out | (uintptr_t)dout) & 15) == 0,
               "emo_softmax_attn_bwd: gradients must be 16-B aligned with ld_d %% 4 == 0");
+    if (keep) {
+        const int64_t need = emo_softmax_attn_keep_bytes(dtype, B, T, H, dh, p_drop);
+        EMO_CHECK(need > 0 && keep_bytes >= need && ((uintptr_t)keep & 15) == 0, "emo_softmax_attn_bwd_keep: keep buffer of %lld bytes, need %lld", (long long)keep_bytes, (long long)need);
+    }
     return dispatch_sattn(1, dtype, dh, q, k, v, ld, out, dout, ld_out, (float*)lse, delta_ws, dq, dk, dv, ld_d, B, T, H, make_drop(p_drop, seed, offset),
-                          (hipStream_t)stream);
+                          (uint32_t*)keep, (hipStream_t)stream);
+}
+extern "C" int emo_softmax_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* out, const void* dout, int64_t ld_out,
+                                    const float* lse, float* delta_ws, void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H,
+                                    int64_t dh, float p_drop, uint64_t seed, uint64_t offset, emo_stream_t stream) {
+    return emo_softmax_attn_bwd_keep(q, k, v, ld, out, dout, ld_out, lse, delta_ws, dq, dk, dv, ld_d, dtype, B, T, H, dh, p_drop, seed, offset, nullptr, 0, stream);
 }
 
 extern "C" int emo_softmax_attn_decode(const void* q, int64_t ld_q, void* kcache, void* vcache, int64_t T_max, const int64_t* lens, int64_t lens_off,

@@ -38,9 +38,14 @@ __device__ __forceinline__ float a32_pair_sum(float x) {
 }
 
 // =============================================================================================== forward
-__global__ __launch_bounds__(256, 2) void sattn32_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t ld,
+// KB: also write the dropout keep decisions, one 32-bit word per lane and key tile: word [bh][key tile kt][hi][query row], bit i + 16 half <->
+// key 64 kt + 32 half + (i & 3) + 8 (i >> 2) + 4 hi — the lane's own score registers, so the word is assembled without any cross-lane traffic
+// (a query row's 64 decisions of a key tile = the words of lanes l and l + 32).  The backward passes read the bits instead of re-evaluating the
+// keyed hash per score (r04: the hash was ~30 % of the dK/dV pass's VALU work).  Only tiles at or below the diagonal are written / read.
+template <bool KB>
+__global__ __launch_bounds__(256, 3) void sattn32_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t ld,
                                                              bf16_t* __restrict__ out, int64_t ld_out, float* __restrict__ lse_g, int64_t T, int64_t H,
-                                                             DropCtx drop) {
+                                                             DropCtx drop, uint32_t* __restrict__ keep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [2 slots][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, ql = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,13 +119,19 @@ __global__ __launch_bounds__(256, 2) void sattn32_fwd_kernel(const bf16_t* __res
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
         const float nm = -m_new * c2;
         float psum = 0.f;
+        uint32_t kw = 0u;
 #pragma unroll
         for (int a4 = 0; a4 < 4; ++a4) {
             float d0[4] = {1.f, 1.f, 1.f, 1.f}, d1[4] = {1.f, 1.f, 1.f, 1.f};
             if (drop.thr16) {
                 const uint64_t base = (uint64_t)((bh * T + qrow) * T + k0 + 8 * a4 + 4 * hi);
-                drop_mult4(drop, base, d0);
-                drop_mult4(drop, base + 32, d1);
+                if (KB) {
+                    drop_mult4_bits(drop, base, d0, kw, 4 * a4);
+                    drop_mult4_bits(drop, base + 32, d1, kw, 16 + 4 * a4);
+                } else {
+                    drop_mult4(drop, base, d0);
+                    drop_mult4(drop, base + 32, d1);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -130,6 +141,7 @@ __global__ __launch_bounds__(256, 2) void sattn32_fwd_kernel(const bf16_t* __res
                 s1[4 * a4 + r] = p1 * d1[r];
             }
         }
+        if (KB) keep[((bh * (T >> 6) + kt) * 2 + hi) * T + qrow] = kw;
         l_run = l_run * alpha + psum;                                 // per-lane partial (this lane's 32 of the row's 64 keys)
         m_run = m_new;
 #pragma unroll
@@ -187,13 +199,16 @@ __device__ __forceinline__ void a32_dma4s(const char* sbase, uint32_t voff, uint
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
-constexpr int A32_QSLOT = 2 * A32_TILEB + 512;                 // Q tile | dO tile | lse[64] | delta[64]
+constexpr int A32_QSLOT = 2 * A32_TILEB + 512 + 1024;          // Q tile | dO tile | lse[64] | delta[64] | keep words [2 key tiles][2 hi][64 rows]
 
+// KB: the dropout decisions come from the forward's keep words (a lane's key fixes the word plane and the bit, the rows index the words: four
+// consecutive rows = one ds_read_b128 of the 1-KB block that waves 2 and 3 bring in with the query tile) instead of one keyed hash per 4 scores.
+template <bool KB>
 __global__ __launch_bounds__(256, 2) void sattn32_dkv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t ld,
                                                              const bf16_t* __restrict__ dout, int64_t ld_out, const float* __restrict__ lse_g,
                                                              const float* __restrict__ delta_g, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t ld_d,
-                                                             int64_t T, int64_t H, DropCtx drop) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2 slots][Q tile | dO tile | lse | delta]
+                                                             int64_t T, int64_t H, DropCtx drop, const uint32_t* __restrict__ keep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2 slots][Q tile | dO tile | lse | delta | keep words]
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, kl = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t ktile = blockIdx.x;                                 // key tile 0 has the longest sweep and is dispatched first
@@ -227,7 +242,15 @@ __global__ __launch_bounds__(256, 2) void sattn32_dkv_kernel(const bf16_t* __res
         a32_dma16s(gs, go1, dst + A32_TILEB + w * 2048 + 1024);
         if (w == 0) a32_dma4s((const char*)(lse_g + bh * T + (int64_t)qt * 64), lo4, dst + 2 * A32_TILEB);
         if (w == 1) a32_dma4s((const char*)(delta_g + bh * T + (int64_t)qt * 64), lo4, dst + 2 * A32_TILEB + 256);
+        if (KB && w >= 2) {                                           // wave 2: key tile 2 ktile, wave 3: 2 ktile + 1; both hi planes, rows of this query tile
+            const uint32_t* kp = keep + ((bh * (T >> 6) + 2 * ktile + (w - 2)) * 2) * T + (int64_t)qt * 64;
+            a32_dma4s((const char*)kp, lo4, dst + 2 * A32_TILEB + 512 + (w - 2) * 512);
+            a32_dma4s((const char*)(kp + T), lo4, dst + 2 * A32_TILEB + 512 + (w - 2) * 512 + 256);
+        }
     };
+    // this lane's key inside its 64-key tile: word plane (tile w / 2, hi = bit 2 of the key's position in its 32-key half) and bit
+    const int kb_plane = (w >> 1) * 512 + ((kl >> 2) & 1) * 256, kb_bit = (kl & 3) + 4 * (kl >> 3) + 16 * (w & 1);
+    const uint32_t scale_bits = __builtin_bit_cast(uint32_t, drop.scale);
     issue(qt0);
     const float c2 = rsqrtf(64.f) * A32_LOG2E;
     f32x16 dv0, dv1, dk0, dk1;                                        // dV^T / dK^T: rows d (0-31 / 32-63), column = key
@@ -262,7 +285,11 @@ __global__ __launch_bounds__(256, 2) void sattn32_dkv_kernel(const bf16_t* __res
                 const int rl = 32 * hq + 8 * a4 + 4 * hi;             // rows rl .. rl + 3 of the tile
                 const f32x4 ls = *(const f32x4*)(lse_l + rl), dl = *(const f32x4*)(del_l + rl);
                 float dm[4] = {1.f, 1.f, 1.f, 1.f};
-                if (drop.thr16) drop_mult_col4(drop, (uint64_t)((bh * T + q0 + rl + (lane & 3)) * T + (key & ~(int64_t)3)), lane, dm);
+                if (KB) {
+                    const u32x4 kwv = *(const u32x4*)((const char*)del_l + 256 + kb_plane + rl * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dm[r] = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_sbfe((int)kwv[r], kb_bit, 1) & scale_bits);
+                } else if (drop.thr16) drop_mult_col4(drop, (uint64_t)((bh * T + q0 + rl + (lane & 3)) * T + (key & ~(int64_t)3)), lane, dm);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = 4 * a4 + r;
@@ -316,8 +343,20 @@ __global__ __launch_bounds__(256, 2) void sattn32_dkv_kernel(const bf16_t* __res
 }  // namespace
 
 // which: 0 forward.  Returns false when the call is not covered (the caller then runs the generic kernels).
+// bytes of the keep words of one attention call (0: the 32 x 32 kernels do not serve the shape, or dropout is off)
+int64_t emo_sattn32_keep_bytes(int64_t B, int64_t T, int64_t H, int64_t dh, float p_drop) {
+    const char* e = getenv("EMO_SATTN32");
+    if (e && atoi(e) == 0) return 0;
+    const char* e2 = getenv("EMO_SATTN32_BWD");
+    if (e2 && atoi(e2) == 0) return 0;
+    const char* e3 = getenv("EMO_SATTN_KEEP");               // "0": every pass re-evaluates the hash
+    if (e3 && atoi(e3) == 0) return 0;
+    if (dh != 64 || T < 128 || (T % 128) != 0 || !(p_drop > 0.f)) return 0;
+    return B * H * (T / 64) * 2 * T * (int64_t)sizeof(uint32_t);
+}
+
 bool emo_sattn32_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ld_out, float* lse, int64_t B, int64_t T,
-                     int64_t H, DropCtx drop, hipStream_t st) {
+                     int64_t H, DropCtx drop, uint32_t* keep, hipStream_t st) {
     const char* e = getenv("EMO_SATTN32");                   // "0": generic kernels only (read per call: tests toggle it)
     if (e && atoi(e) == 0) return false;
     if (which != 0 || T < 128 || (T % 128) != 0 || (ld & 7) || (ld_out & 3)) return false;
@@ -326,14 +365,19 @@ bool emo_sattn32_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* 
     dim3 grid((unsigned)(T / 128), (unsigned)(B * H));
     const size_t lds = 4 * A32_TILEB;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)sattn32_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL(sattn32_fwd_kernel, grid, dim3(256), lds, st, q, k, v, ld, out, ld_out, lse, T, H, drop);
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)sattn32_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)sattn32_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    if (keep && drop.thr16) hipLaunchKernelGGL(sattn32_fwd_kernel<true>, grid, dim3(256), lds, st, q, k, v, ld, out, ld_out, lse, T, H, drop, keep);
+    else hipLaunchKernelGGL(sattn32_fwd_kernel<false>, grid, dim3(256), lds, st, q, k, v, ld, out, ld_out, lse, T, H, drop, (uint32_t*)nullptr);
     return true;
 }
 
 // dK / dV pass of the backward (after the dQ pass has written delta); false: not covered, the caller runs the generic kernel
 bool emo_sattn32_dkv_try(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const bf16_t* dout, int64_t ld_out, const float* lse, const float* delta,
-                         bf16_t* dk, bf16_t* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, DropCtx drop, hipStream_t st) {
+                         bf16_t* dk, bf16_t* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, DropCtx drop, const uint32_t* keep, hipStream_t st) {
     const char* e = getenv("EMO_SATTN32");
     if (e && atoi(e) == 0) return false;
     const char* e2 = getenv("EMO_SATTN32_BWD");
@@ -343,7 +387,12 @@ bool emo_sattn32_dkv_try(const bf16_t* q, const bf16_t* k, const bf16_t* v, int6
     dim3 grid((unsigned)(T / 128), (unsigned)(B * H));
     const size_t lds = 2 * A32_QSLOT;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)sattn32_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL(sattn32_dkv_kernel, grid, dim3(256), lds, st, q, k, v, ld, dout, ld_out, lse, delta, dk, dv, ld_d, T, H, drop);
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)sattn32_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)sattn32_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    if (keep && drop.thr16) hipLaunchKernelGGL(sattn32_dkv_kernel<true>, grid, dim3(256), lds, st, q, k, v, ld, dout, ld_out, lse, delta, dk, dv, ld_d, T, H, drop, keep);
+    else hipLaunchKernelGGL(sattn32_dkv_kernel<false>, grid, dim3(256), lds, st, q, k, v, ld, dout, ld_out, lse, delta, dk, dv, ld_d, T, H, drop, (const uint32_t*)nullptr);
     return true;
 }

@@ -345,14 +345,16 @@ def gpt2_block_fwd(ps, pfx, x, B, T, H, p, seed, off, save):
 
     n1, m1, r1 = ops.layernorm_fwd(x, ps.f32(pfx + 'ln_1.weight'), ps.f32(pfx + 'ln_1.bias'))
     qkv = lin(n1, pfx + 'attn.c_attn.weight', bias=ps.f32(pfx + 'attn.c_attn.bias'))
-    a, lse = ops.softmax_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, T, H, p_drop=p, seed=seed, offset=off + 1)
+    # (training: the forward leaves the attention-dropout keep bits for the backward's dK/dV pass — one hash evaluation per score instead of two)
+    a, lse, keep = ops.softmax_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, T, H, p_drop=p, seed=seed, offset=off + 1, want_keep=True) \
+        if (save is not None and p > 0) else ops.softmax_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, T, H, p_drop=p, seed=seed, offset=off + 1) + (None,)
     h = lin(a, pfx + 'attn.c_proj.weight', bias=ps.f32(pfx + 'attn.c_proj.bias'), p_drop=p, seed=seed, offset=off + 2, residual=x)
     n2, m2, r2 = ops.layernorm_fwd(h, ps.f32(pfx + 'ln_2.weight'), ps.f32(pfx + 'ln_2.bias'))
     z = torch.empty(x.shape[0], ps.shapes[pfx + 'mlp.c_fc.weight'][1], device=x.device, dtype=x.dtype) if save is not None else None
     f = lin(n2, pfx + 'mlp.c_fc.weight', bias=ps.f32(pfx + 'mlp.c_fc.bias'), act=ops.ACT_GELU_NEW, aux_out=z)
     out = lin(f, pfx + 'mlp.c_proj.weight', bias=ps.f32(pfx + 'mlp.c_proj.bias'), p_drop=p, seed=seed, offset=off + 3, residual=h)
     if save is not None:
-        save.t = dict(x=x, m1=m1, r1=r1, n1=n1, qkv=qkv, a=a, lse=lse, h=h, m2=m2, r2=r2, n2=n2, z=z, f=f)
+        save.t = dict(x=x, m1=m1, r1=r1, n1=n1, qkv=qkv, a=a, lse=lse, keep=keep, h=h, m2=m2, r2=r2, n2=n2, z=z, f=f)
     return out
 
 
@@ -375,7 +377,7 @@ def gpt2_block_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
     _wgrad_conv1d(ps, pfx + 'attn.c_proj.weight', pfx + 'attn.c_proj.bias', s['a'], dad)
     da = ops.gemm(dad, ps.w(pfx + 'attn.c_proj.weight'))
     qkv = s['qkv']
-    dq, dk, dv = ops.softmax_attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], s['a'], da, s['lse'], B, T, H, p_drop=p, seed=seed, offset=off + 1)
+    dq, dk, dv = ops.softmax_attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], s['a'], da, s['lse'], B, T, H, p_drop=p, seed=seed, offset=off + 1, keep=s['keep'])
     dqkv = dq._base
     _wgrad_conv1d(ps, pfx + 'attn.c_attn.weight', pfx + 'attn.c_attn.bias', s['n1'], dqkv)
     dn1 = ops.gemm(dqkv, ps.w(pfx + 'attn.c_attn.weight'))

@@ -276,20 +276,26 @@ def favor_draw_omega(gauss, omega):
     return omega
 
 
-def softmax_attn_fwd(q, k, v, B, T, H, p_drop=0.0, seed=0, offset=0):
+def softmax_attn_fwd(q, k, v, B, T, H, p_drop=0.0, seed=0, offset=0, want_keep=False):
+    """want_keep: also return the dropout keep words for softmax_attn_bwd (None when the call has none: include/emo_hip.h)."""
     M, HD = q.shape
     dh = HD // H
     assert M == B * T and _rows(q) == _rows(k) == _rows(v)
     out = torch.empty(M, HD, device=q.device, dtype=q.dtype)
     lse = torch.empty(B, H, T, device=q.device, dtype=torch.float32)
+    keep, kbytes = None, 0
+    if want_keep and all(t.data_ptr() % 16 == 0 for t in (q, k, v)):
+        kbytes = lib.emo_softmax_attn_keep_bytes(dtype_code(q.dtype), B, T, H, dh, p_drop)
+        if kbytes:
+            keep = torch.empty(kbytes // 4, device=q.device, dtype=torch.int32)
     # 2 matmuls (Q K^T, P V) of 2*T*T*dh FLOP per (b, h), half of the tiles skipped by the causal mask
     with _timed('sattn_fwd', 0.5 * 2 * 2.0 * B * H * T * T * dh, 4.0 * M * HD * q.element_size()):
-        check(lib.emo_softmax_attn_fwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(out), HD, ptr(lse), dtype_code(q.dtype), B, T, H, dh, p_drop,
-                                       seed, offset, stream()))
-    return out, lse
+        check(lib.emo_softmax_attn_fwd_keep(ptr(q), ptr(k), ptr(v), _rows(q), ptr(out), HD, ptr(lse), dtype_code(q.dtype), B, T, H, dh, p_drop,
+                                            seed, offset, ptr(keep), kbytes, stream()))
+    return (out, lse, keep) if want_keep else (out, lse)
 
 
-def softmax_attn_bwd(q, k, v, out, dout, lse, B, T, H, p_drop=0.0, seed=0, offset=0, dqkv=None):
+def softmax_attn_bwd(q, k, v, out, dout, lse, B, T, H, p_drop=0.0, seed=0, offset=0, dqkv=None, keep=None):
     M, HD = q.shape
     dh = HD // H
     assert out.is_contiguous() and dout.is_contiguous()
@@ -299,8 +305,8 @@ def softmax_attn_bwd(q, k, v, out, dout, lse, B, T, H, p_drop=0.0, seed=0, offse
     delta = torch.empty(B, H, T, device=q.device, dtype=torch.float32)          # dO.O per query row, handed from the dQ to the dK/dV pass
     # dQ pass: S, dP, dQ; dK/dV pass: S, dP, dV, dK = 7 matmuls, causal half
     with _timed('sattn_bwd', 0.5 * 7 * 2.0 * B * H * T * T * dh, 8.0 * M * HD * q.element_size()):
-        check(lib.emo_softmax_attn_bwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(out), ptr(dout), HD, ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), 3 * HD,
-                                       dtype_code(q.dtype), B, T, H, dh, p_drop, seed, offset, stream()))
+        check(lib.emo_softmax_attn_bwd_keep(ptr(q), ptr(k), ptr(v), _rows(q), ptr(out), ptr(dout), HD, ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), 3 * HD,
+                                            dtype_code(q.dtype), B, T, H, dh, p_drop, seed, offset, ptr(keep), 0 if keep is None else keep.numel() * 4, stream()))
     return dq, dk, dv
 
 

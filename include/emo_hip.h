@@ -223,6 +223,20 @@ int emo_softmax_attn_bwd(const void* q, const void* k, const void* v, int64_t ld
                          void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T,
                          int64_t H, int64_t dh, float p_drop, uint64_t seed, uint64_t offset,
                          emo_stream_t stream);
+/* The same two calls with the attention-dropout keep decisions handed from the forward to the backward: the forward writes one bit per
+ * score at or below the diagonal (32-bit words [B*H][T/64 key tiles][2][T rows], emo_softmax_attn_keep_bytes() bytes — 0 when the call is
+ * not served by the 32 x 32 MFMA kernels: then pass keep = NULL), the dK/dV pass reads the bits instead of re-evaluating the keyed hash per
+ * score.  Results are bit-identical to the calls without the buffer (same hash, evaluated once).  keep = NULL: exactly the calls above. */
+int64_t emo_softmax_attn_keep_bytes(int dtype, int64_t B, int64_t T, int64_t H, int64_t dh, float p_drop);
+int emo_softmax_attn_fwd_keep(const void* q, const void* k, const void* v, int64_t ld, void* out,
+                              int64_t ld_out, float* lse, int dtype, int64_t B, int64_t T, int64_t H,
+                              int64_t dh, float p_drop, uint64_t seed, uint64_t offset, void* keep,
+                              int64_t keep_bytes, emo_stream_t stream);
+int emo_softmax_attn_bwd_keep(const void* q, const void* k, const void* v, int64_t ld, const void* out,
+                              const void* dout, int64_t ld_out, const float* lse, float* delta_ws,
+                              void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B,
+                              int64_t T, int64_t H, int64_t dh, float p_drop, uint64_t seed,
+                              uint64_t offset, const void* keep, int64_t keep_bytes, emo_stream_t stream);
 /* decode: one query row per stream against a KV cache [n_streams, T_max, H*dh]; lens[s] + lens_off = valid keys INCLUDING the new
  * token.  k_new / v_new [n_streams, H*dh] (ld_new; both or neither NULL): the new token's key / value rows, appended to the caches
  * at position len-1 by the kernel itself (the HF `past_key_values` concat of GPT2Attention). */

@@ -724,6 +724,49 @@ def test_softmax_attention_32x32_kernels_vs_reference_and_generic(B, T, H, p, mo
         _close(res['1'][1].view(B, H, T), torch.logsumexp(wts, -1), dt, mult=0.3)
 
 
+@pytest.mark.parametrize('B,T,H', [(1, 128, 1), (2, 384, 2), (1, 1024, 3)])
+def test_softmax_attention_keep_bits_equal_the_hash(B, T, H, monkeypatch):
+    """The forward's keep words (one bit per score at or below the diagonal) drive the dK/dV pass instead of the keyed hash: every output is
+    BIT-identical to the calls without the buffer, the bits equal the mask read out of the kernel with V = identity, and a call the 32 x 32
+    kernels do not serve reports no buffer instead of half-using one."""
+    ops = _ops()
+    dt, dh, p = torch.bfloat16, 64, 0.25
+    HD = H * dh
+    qc = _r(B * T, 3 * HD, seed=51, dt=dt).cuda()
+    dout = _r(B * T, HD, seed=52, dt=dt).cuda()
+    q, k, v = qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:]
+    out0, lse0 = ops.softmax_attn_fwd(q, k, v, B, T, H, p_drop=p, seed=3, offset=9)
+    g0 = ops.softmax_attn_bwd(q, k, v, out0, dout, lse0, B, T, H, p_drop=p, seed=3, offset=9)
+    out1, lse1, keep = ops.softmax_attn_fwd(q, k, v, B, T, H, p_drop=p, seed=3, offset=9, want_keep=True)
+    assert keep is not None and keep.numel() * 4 == ops.lib.emo_softmax_attn_keep_bytes(ops.dtype_code(dt), B, T, H, dh, p)
+    g1 = ops.softmax_attn_bwd(q, k, v, out1, dout, lse1, B, T, H, p_drop=p, seed=3, offset=9, keep=keep)
+    assert torch.equal(out0, out1) and torch.equal(lse0, lse1)
+    for a, b_ in zip(g0, g1):
+        assert torch.equal(a, b_)
+    # decode the words: [bh][key tile][hi][row], bit i + 16 half <-> key 64 kt + 32 half + (i & 3) + 8 (i >> 2) + 4 hi
+    w = keep.view(B * H, T // 64, 2, T).cpu().numpy().astype(np.uint32)
+    from dropmask import site_multipliers
+    m = site_multipliers((B * H * T, T), p, 3, 9).view(B * H, T, T).numpy() != 0
+    for bh in range(B * H):
+        for kt in range(T // 64):
+            for hi in range(2):
+                for bit in range(32):
+                    i, half = bit & 15, bit >> 4
+                    key = 64 * kt + 32 * half + (i & 3) + 8 * (i >> 2) + 4 * hi
+                    rows = np.arange(64 * kt, T)                          # every wave that owns one of these rows swept this key tile
+                    got = (w[bh, kt, hi, rows] >> bit) & 1
+                    assert np.array_equal(got.astype(bool), m[bh, rows, key]), (bh, kt, hi, bit)
+    # not served: fp32, d_head 32, T not a multiple of 128, dropout off
+    assert ops.lib.emo_softmax_attn_keep_bytes(ops.dtype_code(torch.float32), B, T, H, dh, p) == 0
+    assert ops.lib.emo_softmax_attn_keep_bytes(ops.dtype_code(dt), B, T, H, 32, p) == 0
+    assert ops.lib.emo_softmax_attn_keep_bytes(ops.dtype_code(dt), B, T + 64, H, dh, p) == 0
+    assert ops.lib.emo_softmax_attn_keep_bytes(ops.dtype_code(dt), B, T, H, dh, 0.0) == 0
+    monkeypatch.setenv('EMO_SATTN32', '0')
+    assert ops.softmax_attn_fwd(q, k, v, B, T, H, p_drop=p, seed=3, offset=9, want_keep=True)[2] is None
+    with pytest.raises(RuntimeError):
+        ops.softmax_attn_bwd(q, k, v, out0, dout, lse0, B, T, H, p_drop=p, seed=3, offset=9, keep=keep)
+
+
 def test_softmax_attention_dropout_consistency():
     # with dropout the backward must use the same mask as the forward: finite-difference-free check via linearity in v
     ops = _ops()
