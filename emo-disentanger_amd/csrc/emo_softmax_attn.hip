@@ -483,6 +483,8 @@ bool emo_sattn32_dkv_try(const bf16_t* q, const bf16_t* k, const bf16_t* v, int6
 bool emo_sattn32_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, bf16_t* out, int64_t ld_out, float* lse, int64_t B, int64_t T,
                      int64_t H, DropCtx drop, uint32_t* keep, hipStream_t st);
 int64_t emo_sattn32_keep_bytes(int64_t B, int64_t T, int64_t H, int64_t dh, float p_drop);
+bool emo_sattn32_dq_try(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const bf16_t* out, const bf16_t* dout, int64_t ld_out, const float* lse,
+                        float* delta, bf16_t* dq, int64_t ld_d, int64_t B, int64_t T, int64_t H, DropCtx drop, const uint32_t* keep, hipStream_t st);
 
 template <typename CT, int DH>
 static int run_sattn(int which, const void* q, const void* k, const void* v, int64_t ld, const void* out, const void* dout, int64_t ld_out, float* lse,
@@ -511,8 +513,13 @@ static int run_sattn(int which, const void* q, const void* k, const void* v, int
         hipLaunchKernelGGL(kfwd, grid, dim3(256), lfwd, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, (CT*)out, ld_out,
                            lse, T, H, drop);
     } else {
-        hipLaunchKernelGGL(kdq, grid, dim3(256), ldq, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, (const CT*)out,
-                           (const CT*)dout, ld_out, lse, delta, (CT*)dq, ld_d, T, H, drop);
+        bool dq32 = false;
+        if constexpr (sizeof(CT) == 2 && DH == 64)
+            dq32 = emo_sattn32_dq_try((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, (const bf16_t*)out, (const bf16_t*)dout, ld_out, lse, delta, (bf16_t*)dq,
+                                      ld_d, B, T, H, drop, keep, st);
+        if (!dq32)
+            hipLaunchKernelGGL(kdq, grid, dim3(256), ldq, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, (const CT*)out,
+                               (const CT*)dout, ld_out, lse, delta, (CT*)dq, ld_d, T, H, drop);
         bool dkv32 = false;
         if constexpr (sizeof(CT) == 2 && DH == 64)
             dkv32 = emo_sattn32_dkv_try((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, (const bf16_t*)dout, ld_out, lse, delta, (bf16_t*)dk, (bf16_t*)dv, ld_d,

@@ -180,6 +180,144 @@ __global__ __launch_bounds__(256, 3) void sattn32_fwd_kernel(const bf16_t* __res
     if (hi == 0) lse_g[bh * T + qrow] = m_run * c2 * A32_LN2 + logf(l_tot);
 }
 
+// =============================================================================================== backward: dQ (and delta)
+// The forward's geometry (a wave owns 32 query rows, lane <-> query, K / V tiles of 64 keys through the 2-slot ring) with two score products per
+// key tile, S^T = K Q^T and dP^T = V dO^T, both in the layout lane <-> query / registers <-> keys, so dS = P (dP * dropout - delta) is
+// element-wise with per-lane row statistics (lse, delta = dO . O of the lane's row: no LDS, no cross-lane traffic beyond one pair sum in the
+// prologue) and goes straight back as B operand into dQ^T[d][q] += K^T[d][key] dS^T[key][q] (A operand K^T by ds_read_b64_tr_b16 from the
+// row-major K tile: the forward's V^T recipe).  KB: the dropout decisions are the forward's keep word of (key tile, lane) — the lane's own
+// 32 scores, bit = register index — fetched one tile ahead; otherwise one keyed hash per 4 consecutive keys as in the forward.
+// The generic kernel (16-row tiles, P through LDS) took 304 us per layer at B = 16, T = 2048 against the forward's 271.
+template <bool KB>
+__global__ __launch_bounds__(256, KB ? 3 : 2) void sattn32_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t ld,
+                                                            const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, int64_t ld_out,
+                                                            const float* __restrict__ lse_g, float* __restrict__ delta_g, bf16_t* __restrict__ dq, int64_t ld_d,
+                                                            int64_t T, int64_t H, DropCtx drop, const uint32_t* __restrict__ keep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2 slots][K tile | V tile]
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, ql = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t qt = (int64_t)gridDim.x - 1 - blockIdx.x;           // longest sweeps first
+    const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int64_t q0 = qt * 128, qrow = q0 + 32 * w + ql;
+    const bf16_t* qb = q + (b * T) * ld + h * 64;
+    const bf16_t* kb = k + (b * T) * ld + h * 64;
+    const bf16_t* vb = v + (b * T) * ld + h * 64;
+    const int nkt = (int)(2 * (qt + 1));
+    const int64_t wq_max = q0 + 32 * w + 31, wq_min = q0 + 32 * w;
+
+    bf16x8 qf[4], gf[4];                                              // Q / dO rows as B operands: column = query ql, k = d = 16 s + 8 hi ..
+    float dl = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qf[s] = *(const bf16x8*)(qb + qrow * ld + 16 * s + 8 * hi);
+        gf[s] = *(const bf16x8*)(dout + (b * T + qrow) * ld_out + h * 64 + 16 * s + 8 * hi);
+        const bf16x8 of = *(const bf16x8*)(out + (b * T + qrow) * ld_out + h * 64 + 16 * s + 8 * hi);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)gf[s][e] * (float)of[e];
+    }
+    dl = a32_pair_sum(dl);                                            // delta = dO . O of the row (both lanes of the pair hold it)
+    if (hi == 0) delta_g[bh * T + qrow] = dl;
+    const float nl = -lse_g[bh * T + qrow] * A32_LOG2E;
+    const uint32_t* kwp = KB ? keep + ((bh * (T >> 6)) * 2 + hi) * T + qrow : nullptr;       // + kt * 2 T per key tile
+    uint32_t kw_next = KB ? kwp[0] : 0u;
+
+    const uint32_t ring = __builtin_amdgcn_readfirstlane(a32_lds_addr(smem));
+    const int64_t so0 = (int64_t)(16 * w + (lane >> 3)) * ld + (((lane & 7) ^ (lane >> 3)) << 3);
+    const int64_t so1 = so0 + 8 * ld;
+    auto issue = [&](int kt) {
+        const int64_t o = (int64_t)kt * 64 * ld;
+        const uint32_t dst = ring + (kt & 1) * 2 * A32_TILEB + w * 2048;
+        a32_dma16(kb + o + so0, dst);
+        a32_dma16(kb + o + so1, dst + 1024);
+        a32_dma16(vb + o + so0, dst + A32_TILEB);
+        a32_dma16(vb + o + so1, dst + A32_TILEB + 1024);
+    };
+    issue(0);
+    const float c2 = rsqrtf(64.f) * A32_LOG2E;
+    const uint32_t scale_bits = __builtin_bit_cast(uint32_t, drop.scale);
+    f32x16 o0, o1;                                                    // dQ^T: rows d (0-31 / 32-63), column = query
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    const int vg = lane >> 4, vi = lane & 15;
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const uint32_t kw = kw_next;
+        const int64_t k0 = (int64_t)kt * 64;
+        if (KB && kt + 1 < nkt && k0 + 64 <= wq_max) kw_next = kwp[(int64_t)(kt + 1) * 2 * T];     // (the next tile's word, if this wave will sweep it)
+        if (kt + 1 < nkt) issue(kt + 1);
+        if (k0 > wq_max) continue;
+        const char* Kt = smem + (kt & 1) * 2 * A32_TILEB;
+        const char* Vt = Kt + A32_TILEB;
+        f32x16 s0, s1, p0, p1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; p0[i] = 0.f; p1[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int oa = ql * A32_ROWB + (((2 * s + hi) ^ (ql & 7)) << 4), oc = oa + 32 * A32_ROWB;
+            s0 = mma3216(*(const bf16x8*)(Kt + oa), qf[s], s0);
+            s1 = mma3216(*(const bf16x8*)(Kt + oc), qf[s], s1);
+            p0 = mma3216(*(const bf16x8*)(Vt + oa), gf[s], p0);
+            p1 = mma3216(*(const bf16x8*)(Vt + oc), gf[s], p1);
+        }
+        const bool diag = k0 + 63 > wq_min;
+#pragma unroll
+        for (int a4 = 0; a4 < 4; ++a4) {
+            float d0[4] = {1.f, 1.f, 1.f, 1.f}, d1[4] = {1.f, 1.f, 1.f, 1.f};
+            if (KB) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    d0[r] = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_sbfe((int)kw, 4 * a4 + r, 1) & scale_bits);
+                    d1[r] = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_sbfe((int)kw, 16 + 4 * a4 + r, 1) & scale_bits);
+                }
+            } else if (drop.thr16) {
+                const uint64_t base = (uint64_t)((bh * T + qrow) * T + k0 + 8 * a4 + 4 * hi);
+                drop_mult4(drop, base, d0);
+                drop_mult4(drop, base + 32, d1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 4 * a4 + r, kl = r + 8 * a4 + 4 * hi;
+                float e0 = __builtin_amdgcn_exp2f(fmaf(s0[i], c2, nl)), e1 = __builtin_amdgcn_exp2f(fmaf(s1[i], c2, nl));
+                if (diag) {
+                    if (k0 + kl > qrow) e0 = 0.f;
+                    if (k0 + 32 + kl > qrow) e1 = 0.f;
+                }
+                s0[i] = e0 * fmaf(p0[i], d0[r], -dl);                 // dS (in units of the scaled scores)
+                s1[i] = e1 * fmaf(p1[i], d1[r], -dl);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bf16x8 sb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sb[e] = (bf16_t)((u < 2 ? s0 : s1)[8 * (u & 1) + e]);
+#pragma unroll
+            for (int dh2 = 0; dh2 < 2; ++dh2) {
+                bf16x8 ka;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int row = 16 * u + 8 * hh + 4 * (vg >> 1) + (vi >> 2), col = 32 * dh2 + 16 * (vg & 1) + 4 * (vi & 3);
+                    const char* p = Kt + row * A32_ROWB + (((col >> 3) ^ (row & 7)) << 4) + (col & 7) * 2;
+                    const bf16x4 tb = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p));
+                    ka[4 * hh + 0] = tb[0]; ka[4 * hh + 1] = tb[1]; ka[4 * hh + 2] = tb[2]; ka[4 * hh + 3] = tb[3];
+                }
+                if (dh2 == 0) o0 = mma3216(ka, sb, o0); else o1 = mma3216(ka, sb, o1);
+            }
+        }
+    }
+    const float inv = rsqrtf(64.f);
+    bf16_t* ob = dq + (b * T + qrow) * ld_d + h * 64;
+#pragma unroll
+    for (int a4 = 0; a4 < 4; ++a4) {
+        const bf16x4 x0 = {(bf16_t)(o0[4 * a4] * inv), (bf16_t)(o0[4 * a4 + 1] * inv), (bf16_t)(o0[4 * a4 + 2] * inv), (bf16_t)(o0[4 * a4 + 3] * inv)};
+        const bf16x4 x1 = {(bf16_t)(o1[4 * a4] * inv), (bf16_t)(o1[4 * a4 + 1] * inv), (bf16_t)(o1[4 * a4 + 2] * inv), (bf16_t)(o1[4 * a4 + 3] * inv)};
+        *(bf16x4*)(ob + 8 * a4 + 4 * hi) = x0;
+        *(bf16x4*)(ob + 32 + 8 * a4 + 4 * hi) = x1;
+    }
+}
+
 // =============================================================================================== backward: dK, dV
 // Key-stationary: a wave owns 32 keys (K / V rows as MFMA B operands in registers), the workgroup 128; query tiles of 64 rows (Q and dO, plus
 // the rows' lse and delta) stream through a 2-slot LDS ring.  Products S = Q K^T and dP = dO V^T land in the layout lane <-> key, registers <->
@@ -372,6 +510,30 @@ bool emo_sattn32_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* 
     }
     if (keep && drop.thr16) hipLaunchKernelGGL(sattn32_fwd_kernel<true>, grid, dim3(256), lds, st, q, k, v, ld, out, ld_out, lse, T, H, drop, keep);
     else hipLaunchKernelGGL(sattn32_fwd_kernel<false>, grid, dim3(256), lds, st, q, k, v, ld, out, ld_out, lse, T, H, drop, (uint32_t*)nullptr);
+    return true;
+}
+
+// dQ pass of the backward (writes delta for the dK / dV pass); false: not covered, the caller runs the generic kernel
+bool emo_sattn32_dq_try(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const bf16_t* out, const bf16_t* dout, int64_t ld_out, const float* lse,
+                        float* delta, bf16_t* dq, int64_t ld_d, int64_t B, int64_t T, int64_t H, DropCtx drop, const uint32_t* keep, hipStream_t st) {
+    const char* e = getenv("EMO_SATTN32");
+    if (e && atoi(e) == 0) return false;
+    const char* e2 = getenv("EMO_SATTN32_BWD");
+    if (e2 && atoi(e2) == 0) return false;
+    const char* e3 = getenv("EMO_SATTN32_DQ");                // "0": generic dQ kernel
+    if (e3 && atoi(e3) == 0) return false;
+    if (T < 128 || (T % 128) != 0 || (ld & 7) || (ld_out & 7) || (ld_d & 3) || !delta) return false;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dq) & 15) return false;
+    dim3 grid((unsigned)(T / 128), (unsigned)(B * H));
+    const size_t lds = 4 * A32_TILEB;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)sattn32_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)sattn32_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    if (keep && drop.thr16) hipLaunchKernelGGL(sattn32_dq_kernel<true>, grid, dim3(256), lds, st, q, k, v, ld, out, dout, ld_out, lse, delta, dq, ld_d, T, H, drop, keep);
+    else hipLaunchKernelGGL(sattn32_dq_kernel<false>, grid, dim3(256), lds, st, q, k, v, ld, out, dout, ld_out, lse, delta, dq, ld_d, T, H, drop, (const uint32_t*)nullptr);
     return true;
 }
 

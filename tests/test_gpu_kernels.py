@@ -761,6 +761,13 @@ def test_softmax_attention_keep_bits_equal_the_hash(B, T, H, monkeypatch):
     assert ops.lib.emo_softmax_attn_keep_bytes(ops.dtype_code(dt), B, T, H, 32, p) == 0
     assert ops.lib.emo_softmax_attn_keep_bytes(ops.dtype_code(dt), B, T + 64, H, dh, p) == 0
     assert ops.lib.emo_softmax_attn_keep_bytes(ops.dtype_code(dt), B, T, H, dh, 0.0) == 0
+    # the 32 x 32 dQ pass against the generic one (same mask, same statistics); delta feeds the dK / dV pass, which must not move
+    monkeypatch.setenv('EMO_SATTN32_DQ', '0')
+    g2 = ops.softmax_attn_bwd(q, k, v, out1, dout, lse1, B, T, H, p_drop=p, seed=3, offset=9, keep=keep)
+    monkeypatch.delenv('EMO_SATTN32_DQ')
+    assert float((g2[0].float() - g1[0].float()).abs().max()) <= 3e-2 * float(g2[0].float().abs().max())
+    for a, b_ in zip(g2[1:], g1[1:]):
+        assert float((a.float() - b_.float()).abs().max()) <= 1e-2 * float(b_.float().abs().max())
     monkeypatch.setenv('EMO_SATTN32', '0')
     assert ops.softmax_attn_fwd(q, k, v, B, T, H, p_drop=p, seed=3, offset=9, want_keep=True)[2] is None
     with pytest.raises(RuntimeError):

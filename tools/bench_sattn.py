@@ -21,9 +21,9 @@ dout = torch.randn(B * T, HD, device='cuda').to(torch.bfloat16)
 q, k, v = qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:]
 res = {}
 for p in (0.0, 0.1):
-    out, lse = ops.softmax_attn_fwd(q, k, v, B, T, H, p_drop=p, seed=5, offset=64)
-    f = t(lambda: ops.softmax_attn_fwd(q, k, v, B, T, H, p_drop=p, seed=5, offset=64))
-    b = t(lambda: ops.softmax_attn_bwd(q, k, v, out, dout, lse, B, T, H, p_drop=p, seed=5, offset=64))
+    out, lse, keep = ops.softmax_attn_fwd(q, k, v, B, T, H, p_drop=p, seed=5, offset=64, want_keep=True)     # (the training path: keep bits for the backward)
+    f = t(lambda: ops.softmax_attn_fwd(q, k, v, B, T, H, p_drop=p, seed=5, offset=64, want_keep=True))
+    b = t(lambda: ops.softmax_attn_bwd(q, k, v, out, dout, lse, B, T, H, p_drop=p, seed=5, offset=64, keep=keep))
     fl = 0.5 * 2 * 2.0 * B * H * T * T * dh
     res['p%.1f' % p] = {'fwd_ms': round(f, 4), 'fwd_tflops': round(fl / f / 1e9, 1), 'bwd_ms': round(b, 4), 'bwd_tflops': round(3.5 * fl / b / 1e9, 1)}
 print(json.dumps(res))
