@@ -241,7 +241,7 @@ def gpt2_bench(n_steps=6, B=16, T=2048):
         loss.backward()
         opt.step()
         return loss
-    for _ in range(3):
+    for _ in range(5):                       # (7-ms steps: 5 untimed + 30 timed ones, so that clocks / allocator / launch queue are in steady state)
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -290,7 +290,7 @@ def generation_bench(model, n_streams=32, prompt=64, n_new=2048 - 64, top_p=0.9,
             'ms_per_token_step': round(1000 * dt / n_new, 3), 'single_stream_ms_per_token': round(single_ms, 3), 'engine': 'FAVOR+ recurrent state in HBM; token step = ONE persistent launch (emo_performer_decode_step_sampled: nucleus draw + embedding + 12 layers + logits), hipGraph replay'}
 
 
-def stage1_bench(n_steps=10, B=4, T=512, V=200):
+def stage1_bench(n_steps=30, B=4, T=512, V=200):
     """Secondary line, BASELINE configs[4] (single GPU): the stage-1 lead-sheet LM (Transformer-XL decoder, emopia_finetune.yaml shape:
     d512 / L12 / H8 / d_ff 2048, tgt_len 512, batch 4), bf16, dropout 0.1, fwd + bwd + clip + fused Adam on synthetic tokens."""
     from emo_disentanger_amd.model.plain_transformer import PlainTransformer
@@ -306,7 +306,7 @@ def stage1_bench(n_steps=10, B=4, T=512, V=200):
         loss.backward()
         opt.step()
         return loss
-    for _ in range(3):
+    for _ in range(5):                       # (7-ms steps: 5 untimed + 30 timed ones, so that clocks / allocator / launch queue are in steady state)
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -451,7 +451,7 @@ def dp_selftest(model, rank, world):
     return out
 
 
-def b4_bench(model, opt_cls, tr, steps=10, warm=3):
+def b4_bench(model, opt_cls, tr, steps=30, warm=5):
     """SURVEY 8(d) cfg2 second batch size: the reference YAML's batch_size 4 (pop1k7_pretrain.yaml) through the same product loop."""
     import tempfile
     from emo_disentanger_amd.data import synthetic_batch

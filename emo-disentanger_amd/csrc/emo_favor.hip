@@ -1173,36 +1173,44 @@ __global__ __launch_bounds__(256) void favor_decode_fast_kernel(const CT* __rest
 // torch.qr: the two differ only by column signs, to which the feature set {exp(+u), exp(-u)} is invariant.
 // grid = (n_layers * n_blocks); one wave per block; lane = row index.
 __global__ __launch_bounds__(64) void favor_omega_kernel(const float* __restrict__ gauss, float* __restrict__ omega, int dh, int cols, int nblocks) {
-    __shared__ float Q[64 * 65];
-    __shared__ float v[64], cf[64];
+    // Q is kept twice, row-major (Qr[row][col]: the update x -= Q c reads a lane's row) and column-major (Qc[col][row]: the projections c = Q^T x
+    // read a lane's column), rows padded to 68 floats, so that both loops run on 16-B LDS reads: 32 + j / 2 LDS instructions per pass instead
+    // of 128 + 2 j one-float reads (r04: 177 -> ~65 us for the 12 x (64 x 64) blocks of the benchmark model; the kernel is a chain of 64
+    // dependent column steps on one wave per block — latency, not throughput).  Unused rows / columns (dh < 64) are zero.
+    constexpr int LD = 68;
+    __shared__ __attribute__((aligned(16))) float Qr[64 * LD];
+    __shared__ __attribute__((aligned(16))) float Qc[64 * LD];
+    __shared__ __attribute__((aligned(16))) float v[64], cf[64];
     const int lane = threadIdx.x;
     const int layer = blockIdx.x / nblocks, blk = blockIdx.x % nblocks;
     const float* G = gauss + (int64_t)blockIdx.x * dh * dh;
+    for (int e = lane; e < 64 * LD; e += 64) { Qr[e] = 0.f; Qc[e] = 0.f; }
     float rn = 0.f;
     if (lane < dh)
         for (int b = 0; b < dh; ++b) { const float g = G[lane * dh + b]; rn += g * g; }
     rn = sqrtf(rn);                                   // norm of row `lane` of G
     const int start = blk * dh;
     const int ncol = (cols - start) < dh ? (cols - start) : dh;
+    __syncthreads();
     for (int j = 0; j < ncol; ++j) {
         float x = lane < dh ? G[lane * dh + j] : 0.f; // column j, element `lane`
+        const int j4 = (j + 3) >> 2;                  // (columns >= j of Q are still zero: whole quads can be summed)
         for (int pass = 0; pass < 2; ++pass) {
             v[lane] = x;
             __syncthreads();
-            float c = 0.f;
-            if (lane < j)
-                for (int a = 0; a < dh; ++a) c += Q[a * 65 + lane] * v[a];
-            cf[lane] = lane < j ? c : 0.f;
+            f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int a = 0; a < 16; ++a) c4 += *(const f32x4*)(Qc + lane * LD + 4 * a) * *(const f32x4*)(v + 4 * a);
+            cf[lane] = (c4[0] + c4[1]) + (c4[2] + c4[3]);       // (lane >= j: column lane of Q is zero, so is the projection)
             __syncthreads();
-            float sub = 0.f;
-            if (lane < dh)
-                for (int i = 0; i < j; ++i) sub += cf[i] * Q[lane * 65 + i];
-            x -= sub;
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < j4; ++i) s4 += *(const f32x4*)(cf + 4 * i) * *(const f32x4*)(Qr + lane * LD + 4 * i);
+            x -= (s4[0] + s4[1]) + (s4[2] + s4[3]);
             __syncthreads();
         }
         const float nrm = sqrtf(wave_sum(lane < dh ? x * x : 0.f));
         const float qv = x / nrm;
-        if (lane < dh) Q[lane * 65 + j] = qv;
+        if (lane < dh) { Qr[lane * LD + j] = qv; Qc[j * LD + lane] = qv; }
         const float scale = __shfl(rn, j, 64);
         if (lane < dh) omega[((int64_t)layer * dh + lane) * cols + start + j] = qv * scale;
         __syncthreads();

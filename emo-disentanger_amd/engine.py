@@ -245,6 +245,9 @@ def _side_on(tensors):
     return bool(_SIDE['auto'] and t is not None and t.is_cuda and t.shape[0] < 32768)
 
 
+_AUX = {'stream': None}     # auxiliary stream of the omega redraw (MusicLM forward)
+
+
 class _side_stream:
     """with _side_stream(t1, t2, ...): launches go to the side stream after everything queued so far on the main stream;
     the tensors are marked as used by the side stream so the caching allocator does not recycle them early."""
@@ -409,6 +412,22 @@ class DecoderStackFn(torch.autograd.Function):
                                'as in the reference, music_performer.py:59-60)' % (D, model.d_embed))
         pe = model.pe.pe if model.use_pe else model._zero_pe(T, D)
         cp = None
+        # The omega redraw (randn + one Gram-Schmidt launch of 64 dependent column steps: ~180 us on 12 workgroups, pure latency) depends on nothing
+        # in this forward: it runs on an auxiliary stream beside the embedding / first LayerNorm / first QKV product, the main stream waits for it
+        # in front of the first layer (r04: hidden completely at the benchmark's batch, about a third of it at the YAML's batch size 4).
+        omegas, omega_ev = None, None
+        if model.kind == 'performer':
+            if tok.is_cuda and not torch.cuda.is_current_stream_capturing() and _os.environ.get('EMO_OMEGA_STREAM', '1') != '0':
+                main = torch.cuda.current_stream()
+                if _AUX['stream'] is None or _AUX['stream'].device != main.device:
+                    _AUX['stream'] = torch.cuda.Stream(device=main.device)
+                aux = _AUX['stream']
+                aux.wait_stream(main)
+                with torch.cuda.stream(aux):
+                    omegas = model._omegas()
+                    omega_ev = aux.record_event()
+            else:
+                omegas = model._omegas()
         if chord is None:
             x = ops.embed_fwd(tok, seg, E, S, pe, ps.compute_dtype, float(model.token_emb.emb_scale), p_drop=p, seed=seed, offset=base).view(B * T, D)
         else:
@@ -423,7 +442,10 @@ class DecoderStackFn(torch.autograd.Function):
             if p > 0.0:
                 x = ops.dropout_apply(x, p, seed, base)
         saves = []
-        omegas = model._omegas() if model.kind == 'performer' else None
+        if omega_ev is not None:
+            torch.cuda.current_stream().wait_event(omega_ev)
+            for t in omegas:
+                t.record_stream(torch.cuda.current_stream())
         for l in range(L):
             sv = LayerCtx() if need_bwd else None
             if model.kind == 'performer':
