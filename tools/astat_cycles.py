@@ -6,12 +6,14 @@ import torch
 from emo_disentanger_amd import ops
 os.environ['EMO_GEMM_ABLATE'] = '8'
 M, K = 131072, 512
-for name, N, kw in (('QKV', 1536, {}), ('FFN1', 2048, dict(act=ops.ACT_RELU, p_drop=0.1, seed=1, offset=2)), ('out dgrad', 512, {})):
+for name, N, kw in (('QKV', 1536, {}), ('FFN1', 2048, dict(act=ops.ACT_RELU, p_drop=0.1, seed=1, offset=2)), ('FFN1+mask', 2048, dict(act=ops.ACT_RELU, p_drop=0.1, seed=1, offset=2, mask=True)), ('FFN1 plain', 2048, {}), ('out dgrad', 512, {})):
     a = torch.randn(M, K, device='cuda').to(torch.bfloat16)
     w = (torch.randn(N, K, device='cuda') * 0.05).to(torch.bfloat16)
     b = torch.randn(N, device='cuda')
     o = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
     diag = torch.zeros(8, device='cuda', dtype=torch.int64)
+    if kw.pop('mask', False):
+        kw['mask_out'] = torch.empty(M, N // 8, device='cuda', dtype=torch.uint8)
     ops.gemm(a, w, out=o, bias=b, **kw)
     diag.zero_()
     ops.gemm(a, w, out=o, bias=b, rln=(None, diag.view(torch.float32), None, None), **kw)
