@@ -49,8 +49,10 @@ __global__ __launch_bounds__(256, 3) void sattn32_fwd_kernel(const bf16_t* __res
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [2 slots][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, ql = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t qt = (int64_t)gridDim.x - 1 - blockIdx.x;           // longest sweeps first
-    const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
+    // longest sweeps first over the WHOLE grid (blockIdx.x = (b, h) runs fastest): with the tiles of one (b, h) adjacent in dispatch order the last
+    // (b, h)'s long blocks started late and a quarter of the block slots idled through the tail (r04 PMC: 1.0 resident waves per SIMD of 2)
+    const int64_t qt = (int64_t)gridDim.y - 1 - blockIdx.y;
+    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;
     const int64_t q0 = qt * 128, qrow = q0 + 32 * w + ql;
     const bf16_t* qb = q + (b * T) * ld + h * 64;
     const bf16_t* kb = k + (b * T) * ld + h * 64;
@@ -196,8 +198,10 @@ __global__ __launch_bounds__(256, KB ? 3 : 2) void sattn32_dq_kernel(const bf16_
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [2 slots][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, ql = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t qt = (int64_t)gridDim.x - 1 - blockIdx.x;           // longest sweeps first
-    const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
+    // longest sweeps first over the WHOLE grid (blockIdx.x = (b, h) runs fastest): with the tiles of one (b, h) adjacent in dispatch order the last
+    // (b, h)'s long blocks started late and a quarter of the block slots idled through the tail (r04 PMC: 1.0 resident waves per SIMD of 2)
+    const int64_t qt = (int64_t)gridDim.y - 1 - blockIdx.y;
+    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;
     const int64_t q0 = qt * 128, qrow = q0 + 32 * w + ql;
     const bf16_t* qb = q + (b * T) * ld + h * 64;
     const bf16_t* kb = k + (b * T) * ld + h * 64;
@@ -349,8 +353,8 @@ __global__ __launch_bounds__(256, 2) void sattn32_dkv_kernel(const bf16_t* __res
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [2 slots][Q tile | dO tile | lse | delta | keep words]
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, kl = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t ktile = blockIdx.x;                                 // key tile 0 has the longest sweep and is dispatched first
-    const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int64_t ktile = blockIdx.y;                                 // key tile 0 has the longest sweep: all (b, h) of it are dispatched first
+    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;
     const int64_t kw0 = ktile * 128 + 32 * w, key = kw0 + kl;
     const bf16_t* qb = q + (b * T) * ld + h * 64;
     const bf16_t* kb = k + (b * T) * ld + h * 64;
@@ -500,7 +504,7 @@ bool emo_sattn32_try(int which, const bf16_t* q, const bf16_t* k, const bf16_t* 
     if (which != 0 || T < 128 || (T % 128) != 0 || (ld & 7) || (ld_out & 3)) return false;
     // 16-B LDS-DMA pieces and bf16x8 row accesses: an unaligned view (a C-ABI caller's column-offset slice) falls back to the generic kernels
     if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) || ((uintptr_t)lse & 3)) return false;
-    dim3 grid((unsigned)(T / 128), (unsigned)(B * H));
+    dim3 grid((unsigned)(B * H), (unsigned)(T / 128));
     const size_t lds = 4 * A32_TILEB;
     static bool attr = false;
     if (!attr) {
@@ -524,7 +528,7 @@ bool emo_sattn32_dq_try(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64
     if (e3 && atoi(e3) == 0) return false;
     if (T < 128 || (T % 128) != 0 || (ld & 7) || (ld_out & 7) || (ld_d & 3) || !delta) return false;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dq) & 15) return false;
-    dim3 grid((unsigned)(T / 128), (unsigned)(B * H));
+    dim3 grid((unsigned)(B * H), (unsigned)(T / 128));
     const size_t lds = 4 * A32_TILEB;
     static bool attr = false;
     if (!attr) {
@@ -546,7 +550,7 @@ bool emo_sattn32_dkv_try(const bf16_t* q, const bf16_t* k, const bf16_t* v, int6
     if (e2 && atoi(e2) == 0) return false;
     if (T < 128 || (T % 128) != 0 || (ld & 7) || (ld_out & 7) || (ld_d & 3) || !delta) return false;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)dk | (uintptr_t)dv) & 15) return false;
-    dim3 grid((unsigned)(T / 128), (unsigned)(B * H));
+    dim3 grid((unsigned)(B * H), (unsigned)(T / 128));
     const size_t lds = 2 * A32_QSLOT;
     static bool attr = false;
     if (!attr) {

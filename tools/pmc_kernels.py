@@ -16,6 +16,8 @@ def short(name):
 
 def main(argv):
     match = None
+    dump_all = '--all' in argv            # also list every collected counter (mean per dispatch; SQ_* additionally per SIMD-cycle = / (GRBM_GUI_ACTIVE / 8 * 1024))
+    argv = [a for a in argv if a != '--all']
     if '--match' in argv:
         i = argv.index('--match')
         match = argv[i + 1].split(',')
@@ -58,6 +60,10 @@ def main(argv):
             short(name)[:88], e['n'], e['ns'] / e['n'] / 1e3, md.get('vgpr_count', md.get('arch_vgpr_count', '-')), md.get('accum_vgpr_count', '-'),
             md.get('lds_size', md.get('lds_block_size', '-')), wg, busy, m.get('FETCH_SIZE', float('nan')) * 2 / 1024, m.get('WRITE_SIZE', float('nan')) / 1024,
             sum(clk[name]) / len(clk[name]) if clk.get(name) else float('nan')))
+        if dump_all:
+            simd_cyc = m['GRBM_GUI_ACTIVE'] / 8 * 1024 if m.get('GRBM_GUI_ACTIVE') else None
+            for k in sorted(m):
+                lines.append('    %-28s %16.0f%s' % (k, m[k], ('   %.3f per SIMD-cycle' % (m[k] / simd_cyc)) if simd_cyc and k.startswith('SQ_') else ''))
     txt = '\n'.join(lines) + '\n'
     open(out, 'w').write(txt)
     print(txt)
