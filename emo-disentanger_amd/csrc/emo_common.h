@@ -119,6 +119,14 @@ __device__ __forceinline__ void drop_mult4(const DropCtx& d, uint64_t idx0, floa
 
 // The same for an aligned quad (idx0 % 4 == 0, dropout on), also returning the four keep decisions as bits pos .. pos + 3 OR-ed into `word`
 // (the attention forward's keep words): the compares are shared between the multiplier and the bit.
+// (quad = idx0 >> 2 of an index below 2^34, where the high-word term of the general form vanishes: callers that know their tensor is that small
+// keep the quad index in 32-bit arithmetic — the 64-bit shifts and the extra quarter-rate multiply were a sixth of the hash's cost)
+__device__ __forceinline__ void drop_mult4_bits_q(const DropCtx& d, uint32_t quad, float (&m)[4], uint32_t& word, int pos) {
+    const uint32_t h = emo_drop_hash(d, quad), h2 = emo_xs32(h);
+    const bool c0 = (h & 0xFFFFu) >= d.thr16, c1 = (h >> 16) >= d.thr16, c2 = (h2 & 0xFFFFu) >= d.thr16, c3 = (h2 >> 16) >= d.thr16;
+    m[0] = c0 ? d.scale : 0.f; m[1] = c1 ? d.scale : 0.f; m[2] = c2 ? d.scale : 0.f; m[3] = c3 ? d.scale : 0.f;
+    word |= (c0 ? 1u << pos : 0u) | (c1 ? 2u << pos : 0u) | (c2 ? 4u << pos : 0u) | (c3 ? 8u << pos : 0u);
+}
 __device__ __forceinline__ void drop_mult4_bits(const DropCtx& d, uint64_t idx0, float (&m)[4], uint32_t& word, int pos) {
     const uint32_t quad = (uint32_t)(idx0 >> 2) ^ (uint32_t)(idx0 >> 34) * 0x9E3779B1u;
     const uint32_t h = emo_drop_hash(d, quad), h2 = emo_xs32(h);

@@ -108,7 +108,7 @@ __device__ __forceinline__ void fs_features(const bf16x8 (&wop)[2], const bf16x8
 // into rings — q, k: 3 slots, v: 4 slots (v is still read while the q / k slot of the same chunk is being refilled) — issued THREE
 // chunks ahead, so that two chunks (24 KB per workgroup) are in flight at any time: with 512 scans on 256 CUs the kernel is a latency
 // problem (the first register-prefetch version waited one full HBM round trip + the store acknowledgements per 32-token chunk and ran
-// at the generic kernel's 0.27 ms).  Ring rows are 128 B with the 16-B pieces XOR-swizzled by (row & 7) on the DMA *source* address
+// at the generic kernel's 0.27 ms).  Ring rows are 128 B with the 16-B pieces XOR-swizzled by fs_sw(row) on the DMA *source* address
 // and on the read (fragment reads of 16 rows x one piece would otherwise be 8-way bank conflicted).  The output rows of chunk i are
 // stored one iteration later, right after the counted wait, so that a `s_waitcnt vmcnt(3)` never has young stores in front of it.
 // Phase A (per chunk): the wave computes the features of its 16 projections for the chunk's q and k rows and writes them into the
@@ -145,9 +145,26 @@ __device__ __forceinline__ void fs_dma16(const void* gsrc, uint32_t lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// load_perm (emo_lds_mma.h) for the feature images of these kernels, with the two 8-B reads kept APART: from one base register with constant
+// offsets hipcc fuses them into ds_read2_b64 (or ds_read2st64_b64 across k-steps), which is serviced at half the rate of two ds_read_b64 and
+// banked modulo 32 — there rows c and c + 8 of the 136-element stride collide (r04: tools/ubench/lds_patterns + PMC: 8.9 LDS cycles and 4.0
+// conflict cycles per LDS instruction in the forward kernel, LDS 50 % busy, SQ_WAIT_INST_LDS on a third of the cycles).  The k-step offset goes
+// through an opaque SGPR, so every read has its own address register (one v_add each) and stays a plain ds_read_b64: 2 cycles, conflict-free.
+__device__ __forceinline__ int fs_opaque(int x) { asm volatile("" : "+s"(x)); return x; }
+__device__ __forceinline__ bf16x8 fs_load_perm(const bf16_t* img, int row0, int step, int lane) {
+    const bf16_t* p = img + (row0 + (lane & 15)) * FS_LDF + (lane >> 4) * 4;
+    const bf16x4 lo = *(const bf16x4*)(p + fs_opaque((2 * step) * 16)), hi = *(const bf16x4*)(p + fs_opaque((2 * step + 1) * 16));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// Ring-row swizzle: the 16-B piece p of row r sits at piece p ^ fs_sw(r).  r03 used r & 7, which is conflict-free for the 16-B fragment reads and
+// the transpose reads but puts rows c and c + 8 of an 8-B permuted read (fs_ring_perm, xown: 32 lanes = 16 rows x 2 halves = one full
+// 256-B bank row) on the same banks: 2-way on every such read.  This map — bit 0 = row bit 2, bit 1 = row bit 1, bit 2 = row bits 2 ^ 3 —
+// is conflict-free for all three read patterns (tools/lds_conflicts.py: the guide's lane-group model, exhaustive search over the linear
+// maps of the row bits; confirmed per pattern with SQ_LDS_BANK_CONFLICT in tools/ubench/lds_patterns.hip).
+__device__ __forceinline__ int fs_sw(int row) { return ((row >> 2) & 1) | (row & 2) | ((((row >> 2) ^ (row >> 3)) & 1) << 2); }
 // B (or A) operand fragment of a ring tile: row = row0 + c, the 8 elements at 32 s + 8 g
 __device__ __forceinline__ bf16x8 fs_ring_frag(const char* tile, int row0, int s, int g, int c) {
-    return *(const bf16x8*)(tile + (row0 + c) * FS_ROWB + (((4 * s + g) ^ (c & 7)) << 4));
+    return *(const bf16x8*)(tile + (row0 + c) * FS_ROWB + (((4 * s + g) ^ fs_sw(row0 + c)) << 4));
 }
 // load_perm_tr (emo_lds_mma.h) on a swizzled ring tile: permuted-k fragment of the transpose, operand rows = columns col0 .. col0 + 15
 __device__ __forceinline__ bf16x8 fs_ring_perm_tr(const char* tile, int col0, int lane) {
@@ -156,7 +173,7 @@ __device__ __forceinline__ bf16x8 fs_ring_perm_tr(const char* tile, int col0, in
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int row = h * 16 + kc * 4 + (i >> 2), col = col0 + (i & 3) * 4;
-        const char* p = tile + row * FS_ROWB + ((((col >> 3)) ^ (row & 7)) << 4) + (col & 7) * 2;
+        const char* p = tile + row * FS_ROWB + ((((col >> 3)) ^ fs_sw(row)) << 4) + (col & 7) * 2;
         const short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
         const bf16x4 tb = __builtin_bit_cast(bf16x4, t);
         v[h * 4 + 0] = tb[0]; v[h * 4 + 1] = tb[1]; v[h * 4 + 2] = tb[2]; v[h * 4 + 3] = tb[3];
@@ -216,8 +233,8 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_fwd_kernel(const bf16_t* __
 
     const int nch = (int)(T / FS_C);
     const uint32_t qk_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(QKr)), vr_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(Vr));
-    // DMA: this wave moves rows 8 w .. 8 w + 7 of q, k and v (lane: row 8 w + lane / 8, physical piece lane % 8 <- logical piece ^ (row & 7))
-    const int64_t src_off = (int64_t)(8 * w + (lane >> 3)) * ld + (((lane & 7) ^ (lane >> 3)) << 3);
+    // DMA: this wave moves rows 8 w .. 8 w + 7 of q, k and v (lane: row 8 w + lane / 8, physical piece lane % 8 <- logical piece ^ fs_sw(row))
+    const int64_t src_off = (int64_t)(8 * w + (lane >> 3)) * ld + (((lane & 7) ^ fs_sw(8 * w + (lane >> 3))) << 3);
     auto issue = [&](int n) {
         const int64_t o = (int64_t)n * FS_C * ld + src_off;
         const uint32_t qk = qk_lds + (n % 3) * 2 * FS_TILEB + w * 1024;
@@ -284,7 +301,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_fwd_kernel(const bf16_t* __
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) { qf[tt][s] = load_perm<bf16_t>(QF, FS_LDF, 16 * tt, s, lane); kf[tt][s] = load_perm<bf16_t>(KF, FS_LDF, 16 * tt, s, lane); }
+            for (int s = 0; s < 4; ++s) { qf[tt][s] = fs_load_perm(QF, 16 * tt, s, lane); kf[tt][s] = fs_load_perm(KF, 16 * tt, s, lane); }
         const bf16x8 vop = fs_ring_perm_tr(VB, 16 * w, lane);
 #ifdef EMO_DIAG
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -406,8 +423,10 @@ __device__ __forceinline__ f32x4 mma16(bf16x4 a, bf16x4 b, f32x4 c) {
 }
 // permuted-k fragment (k-step s: elements 32 s + 4 g .. +3 and 32 s + 16 + 4 g .. +3) of row row0 + c of a swizzled ring tile
 __device__ __forceinline__ bf16x8 fs_ring_perm(const char* tile, int row0, int s, int g, int c) {
-    const int row = row0 + c, ch = 4 * s + (g >> 1), sw = row & 7;
-    const char* base = tile + row * FS_ROWB + (g & 1) * 8;
+    // (row0 goes through an opaque SGPR: with a constant the reads of rows c and c + 16 — same lane offsets, 2048 B apart — are fused into
+    // ds_read2st64_b64, half the rate of two ds_read_b64 and banked modulo 32; see fs_load_perm)
+    const int row = row0 + c, ch = 4 * s + (g >> 1), sw = fs_sw(row);
+    const char* base = tile + fs_opaque(row0 * FS_ROWB) + c * FS_ROWB + (g & 1) * 8;
     const bf16x4 lo = *(const bf16x4*)(base + ((ch ^ sw) << 4)), hi = *(const bf16x4*)(base + (((ch + 2) ^ sw) << 4));
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
@@ -480,7 +499,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
 
     const int nch = (int)(T / FS_C);
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(RING)), den_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(DEN));
-    const int srow = 8 * w + (lane >> 3), spc = ((lane & 7) ^ (lane >> 3)) << 3;
+    const int srow = 8 * w + (lane >> 3), spc = ((lane & 7) ^ fs_sw(srow)) << 3;
     const int64_t so_qkv = (int64_t)srow * ld + spc, so_o = (int64_t)srow * ld_out + spc;
     // One DMA instruction of chunk n (part 0..5: q, k, v, dout, out, den).  The six parts of a chunk are issued at six different points of
     // the following iteration instead of back to back: right after a barrier all eight waves of the CU used to push their six 1-KB requests
@@ -559,7 +578,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int row = 16 * tt + c;
-            xown[tt] = *(const bf16x4*)(Xq + row * FS_ROWB + (((2 * w + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8);
+            xown[tt] = *(const bf16x4*)(Xq + row * FS_ROWB + (((2 * w + (g >> 1)) ^ fs_sw(row)) << 4) + (g & 1) * 8);
         }
         // dN = dout / den (B operands, permuted k), dD = -(dout . out) / den
         bf16x8 gop[2][2];
@@ -642,7 +661,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
                 }
                 sa = fs_sum_rows(sa);
                 const int row = 16 * tt + c;
-                st4((bf16_t*)(DUb + row * FS_ROWB + (((2 * w + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8), du[0], du[1], du[2], du[3]);
+                st4((bf16_t*)(DUb + row * FS_ROWB + (((2 * w + (g >> 1)) ^ fs_sw(row)) << 4) + (g & 1) * 8), du[0], du[1], du[2], du[3]);
                 if (g == 0) SAb[w * 32 + row] = sa;
             }
         }
@@ -672,7 +691,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
         for (int tt = 0; tt < 2; ++tt) {
             issue_part(i + 3, 1 + tt);
             const int row = 16 * tt + c;
-            const bf16x8 u0 = *(const bf16x8*)(DUb + row * FS_ROWB + (((g) ^ (row & 7)) << 4)), u1 = *(const bf16x8*)(DUb + row * FS_ROWB + (((4 + g) ^ (row & 7)) << 4));
+            const bf16x8 u0 = *(const bf16x8*)(DUb + row * FS_ROWB + (((g) ^ fs_sw(row)) << 4)), u1 = *(const bf16x8*)(DUb + row * FS_ROWB + (((4 + g) ^ fs_sw(row)) << 4));
             f32x4 dx = mma32(wrow[0], u0, zero4());
             dx = mma32(wrow[1], u1, dx);
             const float sa = (SAb[row] + SAb[32 + row]) + (SAb[64 + row] + SAb[96 + row]);
@@ -764,7 +783,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
 
     const int nch = (int)(T / FS_C);
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(RING)), den_lds = __builtin_amdgcn_readfirstlane(fs_lds_addr(DEN));
-    const int srow = 8 * w + (lane >> 3), spc = ((lane & 7) ^ (lane >> 3)) << 3;
+    const int srow = 8 * w + (lane >> 3), spc = ((lane & 7) ^ fs_sw(srow)) << 3;
     const int64_t so_qkv = (int64_t)srow * ld + spc, so_o = (int64_t)srow * ld_out + spc;
     auto issue = [&](int n) {                          // n-th chunk of the reverse walk = chunk nch - 1 - n
         const int64_t t0n = (int64_t)(nch - 1 - n) * FS_C;
@@ -814,7 +833,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
             const int row = 16 * jt + c;
-            xown[jt] = *(const bf16x4*)(Xk + row * FS_ROWB + (((2 * w + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8);
+            xown[jt] = *(const bf16x4*)(Xk + row * FS_ROWB + (((2 * w + (g >> 1)) ^ fs_sw(row)) << 4) + (g & 1) * 8);
         }
         bf16x8 gA[2][2];                               // dN rows t as A operand (permuted k = d)
 #pragma unroll
@@ -862,7 +881,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) { qfA[tt][s] = load_perm<bf16_t>(QF, FS_LDF, 16 * tt, s, lane); kfB[tt][s] = load_perm<bf16_t>(KF, FS_LDF, 16 * tt, s, lane); }
+                for (int s = 0; s < 4; ++s) { qfA[tt][s] = fs_load_perm(QF, 16 * tt, s, lane); kfB[tt][s] = fs_load_perm(KF, 16 * tt, s, lane); }
             f32x4 aa[3][2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -938,7 +957,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
                     sa += ap + am;
                 }
                 sa = fs_sum_rows(sa);
-                st4((bf16_t*)(DU + row * FS_ROWB + (((2 * w + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8), du[0], du[1], du[2], du[3]);
+                st4((bf16_t*)(DU + row * FS_ROWB + (((2 * w + (g >> 1)) ^ fs_sw(row)) << 4) + (g & 1) * 8), du[0], du[1], du[2], du[3]);
                 if (g == 0) SA[w * 32 + row] = sa;
             }
         }
@@ -950,8 +969,8 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const bf16x8 rd = pack8(RD[2 * s], RD[2 * s + 1]);
-                a0 = mma32(rd, load_perm<bf16_t>(KF, FS_LDF, 0, s, lane), a0);
-                a1 = mma32(rd, load_perm<bf16_t>(KF, FS_LDF, 16, s, lane), a1);
+                a0 = mma32(rd, fs_load_perm(KF, 0, s, lane), a0);
+                a1 = mma32(rd, fs_load_perm(KF, 16, s, lane), a1);
             }
             dv_prev[0] = (bf16x4){(bf16_t)a0[0], (bf16_t)a0[1], (bf16_t)a0[2], (bf16_t)a0[3]};
             dv_prev[1] = (bf16x4){(bf16_t)a1[0], (bf16_t)a1[1], (bf16_t)a1[2], (bf16_t)a1[3]};
@@ -992,7 +1011,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
             const int row = 16 * jt + c;
-            const bf16x8 u0 = *(const bf16x8*)(DU + row * FS_ROWB + ((g ^ (row & 7)) << 4)), u1 = *(const bf16x8*)(DU + row * FS_ROWB + (((4 + g) ^ (row & 7)) << 4));
+            const bf16x8 u0 = *(const bf16x8*)(DU + row * FS_ROWB + ((g ^ fs_sw(row)) << 4)), u1 = *(const bf16x8*)(DU + row * FS_ROWB + (((4 + g) ^ fs_sw(row)) << 4));
             f32x4 dx = mma32(wrow[0], u0, zero4());
             dx = mma32(wrow[1], u1, dx);
             const float sa = (SA[row] + SA[32 + row]) + (SA[64 + row] + SA[96 + row]);

@@ -78,6 +78,8 @@ __global__ __launch_bounds__(256, 3) void sattn32_fwd_kernel(const bf16_t* __res
     };
     issue(0);
     const float c2 = rsqrtf(64.f) * A32_LOG2E;
+    const bool small_idx = (int64_t)gridDim.x * T * T <= ((int64_t)1 << 34);        // every element index of the call below 2^34
+    const uint32_t rowq = (uint32_t)(((bh * T + qrow) * T) >> 2);
     float m_run = -INFINITY, l_run = 0.f;
     f32x16 o0, o1;
 #pragma unroll
@@ -127,7 +129,11 @@ __global__ __launch_bounds__(256, 3) void sattn32_fwd_kernel(const bf16_t* __res
             float d0[4] = {1.f, 1.f, 1.f, 1.f}, d1[4] = {1.f, 1.f, 1.f, 1.f};
             if (drop.thr16) {
                 const uint64_t base = (uint64_t)((bh * T + qrow) * T + k0 + 8 * a4 + 4 * hi);
-                if (KB) {
+                if (KB && small_idx) {                                // (wave-uniform) 32-bit quad index: ((bh T + qrow) T + k0 + 8 a4 + 4 hi) / 4
+                    const uint32_t quad = rowq + (uint32_t)(k0 >> 2) + 2 * a4 + hi;
+                    drop_mult4_bits_q(drop, quad, d0, kw, 4 * a4);
+                    drop_mult4_bits_q(drop, quad + 8, d1, kw, 16 + 4 * a4);
+                } else if (KB) {
                     drop_mult4_bits(drop, base, d0, kw, 4 * a4);
                     drop_mult4_bits(drop, base + 32, d1, kw, 16 + 4 * a4);
                 } else {
