@@ -51,7 +51,7 @@ template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return
 // thr16 = round(p * 65536).  Forward and backward regenerate the same mask from
 // (seed, offset, linear element index) — nothing is stored.
 // The 64-bit key (two words derived from the 64-bit seed and the per-site offset) enters the hash at two
-// points — XORed into the multiplied counter before the first round and again between the two
+// points — XORed into the counter before the first round and again between the two
 // multiply rounds — so two (seed, offset) streams are NOT index-shifted copies of one sequence (an
 // additive 32-bit key in front of a fixed hash would make them exactly that).
 __host__ __device__ __forceinline__ uint32_t emo_hash32(uint32_t x) {
@@ -65,7 +65,10 @@ struct DropCtx {
     float scale;     // 1/(1-p)
 };
 __host__ __device__ __forceinline__ uint32_t emo_drop_hash(const DropCtx& d, uint32_t pair) {
-    uint32_t x = (pair * 0x9E3779B1u) ^ d.key;
+    // (r04: the counter enters un-multiplied — the two multiply-xorshift rounds below are a full-avalanche bijection on their own, and the third
+    // quarter-rate 32-bit multiply was a sixth of the hash; keep rate, lag-1 / lag-4 / row-stride correlations, cross-stream correlations and
+    // avalanche re-checked on 2^24 samples: all at the sampling-noise level, as before)
+    uint32_t x = pair ^ d.key;
     x ^= x >> 16; x *= 0x7feb352dU; x ^= d.key2; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
