@@ -910,6 +910,43 @@ static int64_t choose_epi_splits(int64_t M, int64_t N, int64_t K) {
     return K >= 1024 ? 4 : 1;
 }
 
+// the same pass with a tail of blocks that adds up the bias-gradient partials of the 256 x 256 weight-gradient kernel: rs_out[i] += sum over
+// rs_parts vectors of length rs_stride (fixed order)
+__global__ __launch_bounds__(256) void splitk_reduce_rs_kernel(const float* __restrict__ ws, int64_t stride, int splits, float* __restrict__ out, int64_t n4,
+                                                               int accumulate, const float* __restrict__ rs_ws, int64_t rs_stride, int rs_parts,
+                                                               float* __restrict__ rs_out, int64_t main_blocks) {
+    if ((int64_t)blockIdx.x >= main_blocks) {
+        const int64_t i = ((int64_t)blockIdx.x - main_blocks) * 256 + threadIdx.x;
+        if (i * 4 >= rs_stride) return;
+        f32x4 a = ((const f32x4*)rs_out)[i], b = {0.f, 0.f, 0.f, 0.f};
+        const float* p = rs_ws + 4 * i;
+        int s = 0;
+        for (; s + 2 <= rs_parts; s += 2) { a += *(const f32x4*)(p + (int64_t)s * rs_stride); b += *(const f32x4*)(p + (int64_t)(s + 1) * rs_stride); }
+        if (s < rs_parts) a += *(const f32x4*)(p + (int64_t)s * rs_stride);
+        ((f32x4*)rs_out)[i] = a + b;
+        return;
+    }
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 a = accumulate ? ((const f32x4*)out)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 b = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+    const float* p = ws + 4 * i;
+    int s = 0;
+    for (; s + 4 <= splits; s += 4) {
+        const f32x4 x0 = *(const f32x4*)(p + (int64_t)s * stride), x1 = *(const f32x4*)(p + (int64_t)(s + 1) * stride);
+        const f32x4 x2 = *(const f32x4*)(p + (int64_t)(s + 2) * stride), x3 = *(const f32x4*)(p + (int64_t)(s + 3) * stride);
+        a += x0; b += x1; c += x2; d += x3;
+    }
+    for (; s < splits; ++s) a += *(const f32x4*)(p + (int64_t)s * stride);
+    ((f32x4*)out)[i] = (a + b) + (c + d);
+}
+void emo_splitk_reduce_rs_launch(const float* ws, int64_t stride, int splits, float* out, int64_t n4, int accumulate, const float* rs_ws, int64_t rs_stride,
+                                 int rs_parts, float* rs_out, hipStream_t st) {
+    const int64_t mb = cdiv64(n4, 256), rb = cdiv64(rs_stride >> 2, 256);
+    hipLaunchKernelGGL(splitk_reduce_rs_kernel, dim3((unsigned)(mb + rb)), dim3(256), 0, st, ws, stride, splits, out, n4, accumulate, rs_ws, rs_stride, rs_parts,
+                       rs_out, mb);
+}
+
 void emo_splitk_reduce_launch(const float* ws, int64_t stride, int splits, float* out, int64_t n4, int accumulate, hipStream_t st) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, st, ws, stride, splits, out, n4, accumulate);
 }
@@ -969,8 +1006,13 @@ extern "C" int64_t emo_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int
     const bool big = dtype_in == EMO_BF16;
     const int64_t BMt = big ? GB_M : 64, BNt = big ? GB_N : 64, BKt = big ? (gemm_variant() >= 2 ? G2_BK : GB_K) : 16;
     int64_t splits = choose_splits(M, N, K, big, false, dtype_out, BMt, BNt, BKt, EMO_GEMM_MAX_SPLITS);
-    if (big) { const int64_t s2 = emo_gemm_w128_tn_splits(M, N, K); if (s2 > splits) splits = s2; }     // (layout unknown here: sized for the wgrad kernel too)
-    return splits > 1 ? splits * M * N * (int64_t)sizeof(float) : 0;
+    int64_t rs_floats = 0;
+    if (big) {                                                  // (layout unknown here: sized for the wgrad kernel too, with its bias-gradient partials)
+        const int64_t s2 = emo_gemm_w128_tn_splits(M, N, K);
+        if (s2 > splits) splits = s2;
+        if (s2 > 0) rs_floats = emo_gemm_w128_tn_rs_floats(M, N, s2);
+    }
+    return splits > 1 ? (splits * M * N + rs_floats) * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, int b_trans, int64_t ldb, void* C,

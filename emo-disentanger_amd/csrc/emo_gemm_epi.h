@@ -209,5 +209,6 @@ bool emo_gemm_w128_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ld
                        const EpiParams& ep, hipStream_t st);
 // the same tile for the wgrad layout (A stored [K, M], B stored [K, N], fp32 out, split-K through the caller's workspace)
 int64_t emo_gemm_w128_tn_splits(int64_t M, int64_t N, int64_t K);
+int64_t emo_gemm_w128_tn_rs_floats(int64_t M, int64_t N, int64_t splits);
 bool emo_gemm_w128_tn_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate,
                           float* a_rowsum, float* b_rowsum, void* ws, int64_t ws_bytes, hipStream_t st);

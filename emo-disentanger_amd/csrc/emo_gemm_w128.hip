@@ -268,7 +268,7 @@ __device__ __forceinline__ int w_swz_k(int k) { return (k & 3) | (((k >> 3) & 1)
 template <int RS>
 __global__ __launch_bounds__(256, 1) void gemm_w128_tn_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                              float* __restrict__ Cws, int64_t M, int64_t N, int64_t K, int64_t kps, float* __restrict__ a_rowsum, float* __restrict__ b_rowsum,
-                                                             int full, int extra, int nt_mask) {
+                                                             int full, int extra, int nt_mask, float* __restrict__ rs_ws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -295,6 +295,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w128_tn_kernel(const bf16_t* __re
     if (nk == 0) {                                              // (a split past the end: its partial tile is zeros)
 #pragma unroll 4
         for (int e = tid; e < 256 * 64; e += 256) *(f32x4*)(C + (m0 + (e >> 6)) * N + n0 + (e & 63) * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (RS == 1 && rs_ws) rs_ws[(split * tiles_n + tn) * M + m0 + tid] = 0.f;
+        if (RS == 2 && rs_ws) rs_ws[(split * (M / W_BM) + tm) * N + n0 + tid] = 0.f;
         return;
     }
     uint32_t offA[8], offB[8];
@@ -410,15 +412,27 @@ __global__ __launch_bounds__(256, 1) void gemm_w128_tn_kernel(const bf16_t* __re
     }
     w_wait<0>();
     w_mma_drain();
+    // bias-gradient partials: every (split, tile) block owns its 256 rows (columns) of ONE partial vector in the workspace behind the weight
+    // partials — plain stores, summed in a fixed order by the reduce pass (r04: deterministic; without the extra workspace: fp32 atomics)
     if (RS == 1 && (lane >> 4) == 0) {
+        float* dst = rs_ws ? rs_ws + (split * tiles_n + tn) * M : nullptr;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) atomicAdd(a_rowsum + m0 + wr * 128 + (2 * u + wc) * 16 + lane, rs[u][0]);
+        for (int u = 0; u < 4; ++u) {
+            const int64_t m = m0 + wr * 128 + (2 * u + wc) * 16 + lane;
+            if (dst) dst[m] = rs[u][0]; else atomicAdd(a_rowsum + m, rs[u][0]);
+        }
     }
     if (RS == 2 && (lane & 15) == 0) {                            // D[n][*]: a lane holds the sums of n = 4 (lane / 16) .. + 3 of its fragment
+        float* dst = rs_ws ? rs_ws + (split * (M / W_BM) + tm) * N : nullptr;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4; ++u) {
+            const int64_t n = n0 + wc * 128 + (2 * u + wr) * 16 + (lane >> 4) * 4;
+            if (dst) *(f32x4*)(dst + n) = rs[u];
+            else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(b_rowsum + n0 + wc * 128 + (2 * u + wr) * 16 + (lane >> 4) * 4 + r, rs[u][r]);
+                for (int r = 0; r < 4; ++r) atomicAdd(b_rowsum + n + r, rs[u][r]);
+            }
+        }
     }
 #pragma clang loop unroll(full)
     for (int i = 0; i < 8; ++i) {
@@ -487,6 +501,13 @@ int64_t emo_gemm_w128_tn_splits(int64_t M, int64_t N, int64_t K) {
 }
 
 void emo_splitk_reduce_launch(const float* ws, int64_t stride, int splits, float* out, int64_t n4, int accumulate, hipStream_t st);
+void emo_splitk_reduce_rs_launch(const float* ws, int64_t stride, int splits, float* out, int64_t n4, int accumulate, const float* rs_ws, int64_t rs_stride,
+                                 int rs_parts, float* rs_out, hipStream_t st);
+// floats of bias-gradient partials behind the weight partials (one vector per (split, tile of the other dimension))
+int64_t emo_gemm_w128_tn_rs_floats(int64_t M, int64_t N, int64_t splits) {
+    const int64_t a = (N / W_BN) * M, b = (M / W_BM) * N;
+    return splits * (a > b ? a : b);
+}
 
 // dW[M,N] (+)= A[K,M]^T B[K,N], fp32 out, contiguous C, workspace of >= splits * M * N floats; optional a_rowsum[M] += column sums of A or
 // b_rowsum[N] += column sums of B (one of them)
@@ -502,15 +523,23 @@ bool emo_gemm_w128_tn_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t
     dim3 grid(256);                                            // 32 block slots per XCD (w_tn_plan)
     int nt_mask = 0;
     { const char* e3 = getenv("EMO_W128_TN_NT"); if (e3) nt_mask = atoi(e3); }
+    float* rs_ws = nullptr;                                     // bias-gradient partials through the workspace when it has room for them
+    if ((a_rowsum || b_rowsum) && ws_bytes >= (splits0 * M * N + emo_gemm_w128_tn_rs_floats(M, N, splits0)) * (int64_t)sizeof(float) &&
+        !(((uintptr_t)a_rowsum | (uintptr_t)b_rowsum) & 15))
+        rs_ws = (float*)ws + splits0 * M * N;
 #define W_TN_LAUNCH(RSv)                                                                                                                     \
     do {                                                                                                                                     \
         auto k = gemm_w128_tn_kernel<RSv>;                                                                                                   \
         static bool attr = false;                                                                                                            \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS); attr = true; }            \
-        hipLaunchKernelGGL(k, grid, dim3(256), W_LDS, st, A, lda, B, ldb, (float*)ws, M, N, K, kps, a_rowsum, b_rowsum, full, extra, nt_mask); \
+        hipLaunchKernelGGL(k, grid, dim3(256), W_LDS, st, A, lda, B, ldb, (float*)ws, M, N, K, kps, a_rowsum, b_rowsum, full, extra, nt_mask, rs_ws); \
     } while (0)
     if (a_rowsum) W_TN_LAUNCH(1); else if (b_rowsum) W_TN_LAUNCH(2); else W_TN_LAUNCH(0);
 #undef W_TN_LAUNCH
-    emo_splitk_reduce_launch((const float*)ws, M * N, (int)splits0, C, (M * N) >> 2, accumulate, st);
+    if (rs_ws)
+        emo_splitk_reduce_rs_launch((const float*)ws, M * N, (int)splits0, C, (M * N) >> 2, accumulate, rs_ws, a_rowsum ? M : N,
+                                    (int)(splits0 * (a_rowsum ? N / W_BN : M / W_BM)), a_rowsum ? a_rowsum : b_rowsum, st);
+    else
+        emo_splitk_reduce_launch((const float*)ws, M * N, (int)splits0, C, (M * N) >> 2, accumulate, st);
     return true;
 }

@@ -249,6 +249,12 @@ def test_gemm_256_tile_wgrad_matches_reference_with_bias_gradient(shape, monkeyp
             got[mode] = (dw, db, dw2)
         dw, db, dw2 = got['1']
         assert torch.equal(dw, dw2)
+        # the bias-gradient partials go through the workspace and are summed in a fixed order (r04): same bits on every run
+        monkeypatch.setenv('EMO_GEMM_W128_TN', '1')
+        for _ in range(3):
+            db_r = torch.full((M,), 0.25, device='cuda')
+            ops.gemm(dy, x, a_trans=True, b_trans=True, out=torch.full((M, N), 0.5, device='cuda'), accumulate=acc, a_rowsum=db_r)
+            assert torch.equal(db_r, db)
         assert float((dw.double() - (ref + (0.5 if acc else 0.0))).abs().max() / ref.abs().max()) < 2e-5
         assert float((db.double() - (want + 0.25)).abs().max() / want.abs().max()) < 1e-4
         assert float((dw - got['0'][0]).abs().max() / ref.abs().max()) < 2e-5      # the 128 x 128 kernel (other split count: not the same bits)
@@ -257,6 +263,9 @@ def test_gemm_256_tile_wgrad_matches_reference_with_bias_gradient(shape, monkeyp
     dw3, dbn = torch.zeros(M, N, device='cuda'), torch.full((N,), 0.25, device='cuda')
     ops.gemm(dy, x, a_trans=True, b_trans=True, out=dw3, b_rowsum=dbn)
     wantn = x.double().sum(0)
+    dbn2 = torch.full((N,), 0.25, device='cuda')
+    ops.gemm(dy, x, a_trans=True, b_trans=True, out=torch.zeros(M, N, device='cuda'), b_rowsum=dbn2)
+    assert torch.equal(dbn, dbn2)
     assert float((dw3.double() - ref).abs().max() / ref.abs().max()) < 2e-5
     assert float((dbn.double() - (wantn + 0.25)).abs().max() / wantn.abs().max()) < 1e-4
 
