@@ -121,7 +121,15 @@ def _txl_layer_fwd(ps, p, x, r_dist, B, T, H, pd, seed, off, pre, save, mem=None
     return o
 
 
-def _txl_layer_bwd(ps, p, dout, pe_d, B, T, H, pd, seed, off, s, acc):
+import os as _os
+_FUSE_BELOW = _os.environ.get('EMO_S1_FUSE', '1') != '0'      # (A/B switch of the cross-layer LayerNorm-backward fusion)
+
+
+def _txl_layer_bwd(ps, p, dout, pe_d, B, T, H, pd, seed, off, s, acc, dyd=None, bias3_done=False, below=None):
+    """dyd / bias3_done: dout with this layer's output dropout already re-applied and the CoreNet.3 bias gradient already accumulated — by the
+    LayerNorm backward of the layer ABOVE, which produced dout (below = (offset of the output-dropout site, CoreNet.3 bias gradient) of the
+    layer below: this layer's last LayerNorm backward does the same for it).  Saves three ~3-us launches per layer of a launch-bound step.
+    Returns (dx, dx with the lower layer's dropout, bias gradient done)."""
     D = dout.shape[1]
     a, f = p + 'dec_attn.', p + 'pos_ff.'
     inv = 1.0 / (1.0 - pd) if pd > 0 else 1.0
@@ -129,14 +137,16 @@ def _txl_layer_bwd(ps, p, dout, pe_d, B, T, H, pd, seed, off, s, acc):
                                                      a_rowsum=None if bname is None else ps.g(bname))
     # (weight gradients on the engine's side stream, as the Performer does below 32768 rows: measured late r03 on one box, 7.98 ms/step with
     # against 8.02 without — the stage-1 step is paced by its ~500 dependent launches, not by CU occupancy — so they stay on the main stream)
-    dyd = ops.dropout_apply(dout, pd, seed, off + 4) if pd > 0 else dout
-    wg(dyd, s['g'], f + 'CoreNet.3.weight', f + 'CoreNet.3.bias')
+    if dyd is None:
+        dyd = ops.dropout_apply(dout, pd, seed, off + 4) if pd > 0 else dout
+    wg(dyd, s['g'], f + 'CoreNet.3.weight', None if bias3_done else f + 'CoreNet.3.bias')
     dg = ops.gemm(dyd, ps.w(f + 'CoreNet.3.weight'), b_trans=True, mul_aux=s['g'], mul_mode=ops.MUL_NONZERO, mul_scale=inv)
     wg(dg, s['n2'], f + 'CoreNet.0.weight', f + 'CoreNet.0.bias')
     dn2 = ops.gemm(dg, ps.w(f + 'CoreNet.0.weight'), b_trans=True)
-    dh, _ = ops.layernorm_bwd(dn2, s['h'], ps.f32(f + 'layer_norm.weight'), s['m2'], s['r2'], ps.g(f + 'layer_norm.weight'), ps.g(f + 'layer_norm.bias'),
-                              dres=dout)
-    dad = ops.dropout_apply(dh, pd, seed, off + 2) if pd > 0 else dh
+    dh, dad = ops.layernorm_bwd(dn2, s['h'], ps.f32(f + 'layer_norm.weight'), s['m2'], s['r2'], ps.g(f + 'layer_norm.weight'), ps.g(f + 'layer_norm.bias'),
+                                dres=dout, want_drop=pd > 0, p_drop=pd, seed=seed, offset=off + 2)       # dad = dh re-masked with the o_net output dropout
+    if dad is None:
+        dad = dh
     wg(dad, s['vq'], a + 'o_net.weight')
     dvec = ops.gemm(dad, ps.w(a + 'o_net.weight'), b_trans=True)
     mlen = s['mlen']
@@ -148,13 +158,18 @@ def _txl_layer_bwd(ps, p, dout, pe_d, B, T, H, pd, seed, off, s, acc):
         dh_res = dh
     # (the column sums behind d r_w_bias / d r_r_bias — parameters shared by all layers — accumulate into `acc`; TXLStackFn.backward adds them once)
     dqkv, dR, _, _ = ops.relpos_attn_bwd(s['qkv'], s['r_dist'], ps.f32('decoder.r_w_bias'), ps.f32('decoder.r_r_bias'), s['vec'], dvec, s['lse'],
-                                         s['zden'], B, K, H, p_drop=pd, seed=seed, offset=off + 1, acc_dq=acc[0], acc_rr=acc[1])
+                                         s['zden'], B, K, H, p_drop=pd, seed=seed, offset=off + 1, acc_dq=None, acc_rr=acc[3 * D:])
     wg(dR.to(ps.compute_dtype), pe_d, a + 'r_net.weight')                     # R = r_net(dropout(pos_emb)): dW_r += dR^T pos_emb
-    wg(dqkv, s['n'], a + 'qkv_net.weight')
+    # (colsum(dq) = the first D entries of the column sums of dqkv, which the weight-gradient GEMM takes from its operand fragments: acc[:3D])
+    ops.gemm(dqkv, s['n'], a_trans=True, b_trans=True, out=ps.g(a + 'qkv_net.weight'), accumulate=True, a_rowsum=acc[:3 * D])
     dn = ops.gemm(dqkv, ps.w(a + 'qkv_net.weight'), b_trans=True)
+    if below is not None and not mlen:                           # the layer below wants dx * its output dropout and colsum of that (its CoreNet.3 bias)
+        dx, dxd = ops.layernorm_bwd(dn, s['x'], ps.f32(a + 'layer_norm.weight'), s['m1'], s['r1'], ps.g(a + 'layer_norm.weight'), ps.g(a + 'layer_norm.bias'),
+                                    dres=dh_res, want_drop=pd > 0, p_drop=pd, seed=seed, offset=below[0], dcol=below[1])
+        return dx, (dxd if dxd is not None else dx), True
     dx, _ = ops.layernorm_bwd(dn, s['x'], ps.f32(a + 'layer_norm.weight'), s['m1'], s['r1'], ps.g(a + 'layer_norm.weight'), ps.g(a + 'layer_norm.bias'),
                               dres=dh_res)
-    return dx.view(B, K, D)[:, mlen:].reshape(B * T, D) if mlen else dx
+    return (dx.view(B, K, D)[:, mlen:].reshape(B * T, D) if mlen else dx), None, False
 
 
 class TXLStackFn(torch.autograd.Function):
@@ -204,12 +219,15 @@ class TXLStackFn(torch.autograd.Function):
             dx = dx.to(ps.compute_dtype).contiguous()
         if pd > 0:
             dx = ops.dropout_apply(dx, pd, seed, base + 2)
-        acc = torch.zeros(2, D, device=dx.device, dtype=torch.float32)        # [colsum(dq), colsum(dq_relative)] summed over the layers
+        acc = torch.zeros(4 * D, device=dx.device, dtype=torch.float32)       # [colsum(dqkv) (3D), colsum(dq_relative) (D)] summed over the layers
+        dyd, b3 = None, False
         for l in reversed(range(L)):
-            dx = _txl_layer_bwd(ps, 'decoder.layers.%d.' % l, dx, ctx.pe_d, B, T, H, pd, seed, base + 8 * (l + 1), ctx.saves[l], acc)
+            below = (base + 8 * l + 4, ps.g('decoder.layers.%d.pos_ff.CoreNet.3.bias' % (l - 1))) if (l > 0 and _FUSE_BELOW) else None
+            dx, dyd, b3 = _txl_layer_bwd(ps, 'decoder.layers.%d.' % l, dx, ctx.pe_d, B, T, H, pd, seed, base + 8 * (l + 1), ctx.saves[l], acc,
+                                         dyd=dyd, bias3_done=b3, below=below)
             ctx.saves[l] = None
-        ps.g('decoder.r_r_bias').add_(acc[1].view(H, D // H))                  # d r_r_bias = colsum(dq_relative)
-        ps.g('decoder.r_w_bias').add_((acc[0] - acc[1]).view(H, D // H))       # d r_w_bias = colsum(dq) - colsum(dq_relative)
+        ps.g('decoder.r_r_bias').add_(acc[3 * D:].view(H, D // H))             # d r_r_bias = colsum(dq_relative)
+        ps.g('decoder.r_w_bias').add_((acc[:D] - acc[3 * D:]).view(H, D // H)) # d r_w_bias = colsum(dq) - colsum(dq_relative)
         if pd > 0:
             dx = ops.dropout_apply(dx, pd, seed, base + 1)
         gE = ps.g('word_emb.emb_lookup.weight')

@@ -352,9 +352,9 @@ def relpos_attn_bwd(qkv, r_dist, r_w_bias, r_r_bias, out, dout, lse, zden, B, T,
     check(lib.emo_relpos_attn_bwd(ptr(q), ptr(k), ptr(v), D3, ptr(r_dist), _rows(r_dist), r_dist.shape[0], ptr(r_w_bias), ptr(r_r_bias), ptr(out),
                                   ptr(dout), D, ptr(lse), ptr(zden), ptr(dqkv), D3, ptr(dq_rel), D, ptr(delta), dtype_code(dt), B, T, H, dh, p_drop,
                                   seed, offset, stream()))
-    assert (acc_dq is None) == (acc_rr is None), 'acc_dq and acc_rr go together'
-    if acc_dq is not None:                                      # training stack: column sums accumulated over the layers, no per-layer ATen ops —
-        colsum(dqkv[:, :D], out=acc_dq, accumulate=True)        # acc_dq += colsum(dq), acc_rr += colsum(dq_rel); the caller forms
+    if acc_rr is not None:                                      # training stack: column sums accumulated over the layers, no per-layer ATen ops —
+        if acc_dq is not None:                                  # acc_dq += colsum(dq) (None: the caller takes it from the qkv_net weight-gradient
+            colsum(dqkv[:, :D], out=acc_dq, accumulate=True)    # GEMM's a_rowsum, one launch fewer), acc_rr += colsum(dq_rel); the caller forms
         colsum(dq_rel, out=acc_rr, accumulate=True)             # d r_r_bias = acc_rr, d r_w_bias = acc_dq - acc_rr once per backward
         d_rr = d_rw = None
     else:
