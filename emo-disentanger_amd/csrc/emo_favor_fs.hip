@@ -222,13 +222,21 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_fwd_kernel(const bf16_t* __
     for (int pp = 0; pp < p_seg; ++pp) {               // carried-in state
         const float* Sp = S_ws + (bh * P + pp) * (int64_t)(128 * 64);
         const float* zp = z_ws + (bh * P + pp) * (int64_t)128;
+        // (all loads of an increment first, no lane-dependent branch between them: with the `if (c == 0)` inside the loop every load was
+        // followed by its own wait — 8 us per increment, 56 of the segmented forward's 90 us at eight segments, r04)
+        float ts[8][4];
+        f32x4 tz[8];
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ts[ft][r] = Sp[(16 * ft + 4 * g + r) * 64 + 16 * w + c];
+            tz[ft] = *(const f32x4*)(zp + 16 * ft + 4 * g);
+        }
+        const float zm = c == 0 ? 1.f : 0.f;
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                S[ft][0][r] += Sp[(16 * ft + 4 * g + r) * 64 + 16 * w + c];
-                if (c == 0) S[ft][1][r] += zp[16 * ft + 4 * g + r];
-            }
+            for (int r = 0; r < 4; ++r) { S[ft][0][r] += ts[ft][r]; S[ft][1][r] += zm * tz[ft][r]; }
     }
 
     const int nch = (int)(T / FS_C);
@@ -486,14 +494,21 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
     for (int pp = 0; pp < p_seg; ++pp) {               // K-state carried in from the earlier segments: S'^T[d'][f] (+ row 64 = z)
         const float* Sp = S_ws + (bh * P + pp) * (int64_t)(128 * 64);
         const float* zp = z_ws + (bh * P + pp) * (int64_t)128;
+        f32x4 t4[2][4];                                // (loads first, no lane-dependent branch between them: see the forward kernel)
+        float tz[2];
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
             const int f = 64 * ph + 16 * w + c;
 #pragma unroll
-            for (int dl = 0; dl < 4; ++dl)
+            for (int dl = 0; dl < 4; ++dl) t4[ph][dl] = *(const f32x4*)(Sp + f * 64 + 16 * dl + 4 * g);
+            tz[ph] = zp[f];
+        }
+        const float gm = g == 0 ? 1.f : 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ST[dl][ph][r] += Sp[f * 64 + 16 * dl + 4 * g + r];
-            if (g == 0) ST[4][ph][0] += zp[f];
+        for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+            for (int dl = 0; dl < 4; ++dl) ST[dl][ph] += t4[ph][dl];
+            ST[4][ph][0] += gm * tz[ph];
         }
     }
 
@@ -766,19 +781,31 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
     for (int pp = p_seg + 1; pp < P; ++pp) {
         const float* Rp = R_ws + (bh * P + pp) * (int64_t)(128 * 64);
         const float* rp = r_ws + (bh * P + pp) * (int64_t)128;
+        // (loads first, no lane-dependent branch between them: see the forward kernel)
+        f32x4 t4[2][4];
+        float tr[2], td[8][4];
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
             const int f = 64 * ph + 16 * w + c;
 #pragma unroll
-            for (int dl = 0; dl < 4; ++dl)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) RT[dl][ph][r] += Rp[f * 64 + 16 * dl + 4 * g + r];
-            if (g == 0) RT[4][ph][0] += rp[f];
+            for (int dl = 0; dl < 4; ++dl) t4[ph][dl] = *(const f32x4*)(Rp + f * 64 + 16 * dl + 4 * g);
+            tr[ph] = rp[f];
         }
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) RD[ft][r] += Rp[(16 * ft + 4 * g + r) * 64 + 16 * w + c];
+            for (int r = 0; r < 4; ++r) td[ft][r] = Rp[(16 * ft + 4 * g + r) * 64 + 16 * w + c];
+        const float gm = g == 0 ? 1.f : 0.f;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+            for (int dl = 0; dl < 4; ++dl) RT[dl][ph] += t4[ph][dl];
+            RT[4][ph][0] += gm * tr[ph];
+        }
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) RD[ft][r] += td[ft][r];
     }
 
     const int nch = (int)(T / FS_C);
@@ -1039,9 +1066,9 @@ int emo_favor_fs_try(int which, int stage, const bf16_t* q, const bf16_t* k, con
     // 16-B LDS-DMA pieces of q / k / v / out / dout rows and 8-/16-B output stores: unaligned views fall back to the generic kernels
     if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)dout) & 15) || (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15)) return 0;
     if (P == 1) Ts = T;
-    // short segments (B*H < 256): the forward's generic kernel is faster (r03, B=4 x T=2048, 8 segments: 66 vs 89 us per layer), the backward's
-    // slice kernels still win (114 vs 159 us) -> the segmented forward runs here only on request (EMO_FAVOR_FS=2: tests)
-    if (which == 0 && P > 1 && !(e && atoi(e) == 2)) return 0;
+    // short segments (B*H < 256; r03: the generic forward was faster there, 66 vs 89 us per layer at B=4 x T=2048 in 8 segments, because of the
+    // carried-in state loop below)
+    // (r04: with the carried-in state loaded without a branch between the loads the segmented forward is 44 us against the generic 66 — default on)
     dim3 grid((unsigned)(B * H * P));
     if (which == 0) {
         const size_t lds = (size_t)(3 * 2 + 4) * FS_TILEB + sizeof(bf16_t) * (size_t)(4 * FS_C * FS_LDF);
