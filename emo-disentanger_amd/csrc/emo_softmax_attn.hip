@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 4 : 1)) void sattn_fwd_kern
     CT* VT = Ki + 64 * LDX;      // fp32: V^T [DH][LDC]; bf16: V row-major [64][LDX] read through ds_read_b64_tr_b16
     constexpr bool TR = sizeof(CT) == 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t qt = (int64_t)gridDim.x - 1 - blockIdx.x;   // longest tiles first
-    const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int64_t qt = (int64_t)gridDim.y - 1 - blockIdx.y;   // longest tiles first
+    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;      // (b, h) fastest in dispatch order: the longest sweeps of the whole grid go first
     const int64_t q0 = qt * 64;
     const CT* qb = q + (b * T) * ld + h * DH;
     const CT* kb = k + (b * T) * ld + h * DH;
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 4 : 2)) void sattn_bwd_dq_k
     CT* KT = Vi + 64 * LDX;       // [DH][LDC]
     float* Dv = (float*)(KT + (sizeof(CT) == 2 ? 0 : DH * LDC));   // [64]  (bf16: no K^T image)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t qt = (int64_t)gridDim.x - 1 - blockIdx.x;
-    const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int64_t qt = (int64_t)gridDim.y - 1 - blockIdx.y;
+    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;      // (b, h) fastest in dispatch order: the longest sweeps of the whole grid go first
     const int64_t q0 = qt * 64;
     const CT* qb = q + (b * T) * ld + h * DH;
     const CT* kb = k + (b * T) * ld + h * DH;
@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 2 : 1)) void sattn_bwd_dkv_
     float* Dv = (float*)(QT + (sizeof(CT) == 2 ? 0 : 2 * DH * LDC));   // [64]  (bf16: no Q^T / dO^T images)
     float* Lv = Dv + 64;                    // [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t kt = blockIdx.x;
-    const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int64_t kt = blockIdx.y;
+    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;      // (b, h) fastest in dispatch order: the longest sweeps of the whole grid go first
     const int64_t k0 = kt * 64;
     const int64_t nqt = (T + 63) / 64;
     const CT* qb = q + (b * T) * ld + h * DH;
@@ -497,7 +497,7 @@ static int run_sattn(int which, const void* q, const void* k, const void* v, int
     }
     // keep words exist only in the 32 x 32 kernels' layout: a forward that cannot write them must not pretend to, a backward must not half-use them
     EMO_CHECK(!(which == 0 && keep), "softmax attention: keep words requested but the call is not served by the 32 x 32 kernels (bf16, d_head 64, T %% 128 == 0, 16-B aligned views)");
-    dim3 grid((unsigned)((T + 63) / 64), (unsigned)(B * H));
+    dim3 grid((unsigned)(B * H), (unsigned)((T + 63) / 64));
     static bool attr = false;
     const size_t lfwd = sa_fwd_lds<CT, DH>(), ldq = sa_dq_lds<CT, DH>(), ldkv = sa_dkv_lds<CT, DH>();
     auto kfwd = sattn_fwd_kernel<CT, DH>;
@@ -652,8 +652,8 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const CT* __restrict__
     CT* Rw = VT + CMax<DH * LDC, 64 * LDX>::v;   // [128][LDX]  R rows of the distance window d0 .. d0+127
     float* sk = (float*)(Rw + 128 * LDX);     // [4 waves][16 t][SKW]  skew buffer
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t qt = (int64_t)gridDim.x - 1 - blockIdx.x;
-    const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int64_t qt = (int64_t)gridDim.y - 1 - blockIdx.y;
+    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;      // (b, h) fastest in dispatch order: the longest sweeps of the whole grid go first
     const int64_t q0 = qt * 64;
     const CT* qb = q + (b * T) * ld + h * DH;
     const CT* kb = k + (b * T) * ld + h * DH;
@@ -849,8 +849,8 @@ __global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 2 : 1)) void relattn_bwd_ke
     float* sk = (float*)(Rw + 128 * LDX);     // [4][16][SKW]
     float* Dv = sk + 4 * 16 * SKW;            // [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t qt = (int64_t)gridDim.x - 1 - blockIdx.x;
-    const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int64_t qt = (int64_t)gridDim.y - 1 - blockIdx.y;
+    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;      // (b, h) fastest in dispatch order: the longest sweeps of the whole grid go first
     const int64_t q0 = qt * 64;
     const CT* qb = q + (b * T) * ld + h * DH;
     const CT* kb = k + (b * T) * ld + h * DH;
@@ -1073,8 +1073,8 @@ __global__ __launch_bounds__(256, 1) void relattn_bwd_dkv_kernel(
     float* Lv = Dv + 64;            // [64] lse (base-2 in bf16 mode)
     float* Zv = Lv + 64;            // [64] 1 / zden
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t kt = blockIdx.x;
-    const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int64_t kt = blockIdx.y;
+    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;      // (b, h) fastest in dispatch order: the longest sweeps of the whole grid go first
     const int64_t k0 = kt * 64;
     const int64_t nqt = (T + 63) / 64;
     const CT* qub = qu + (b * T) * ld_q + h * DH;
@@ -1257,8 +1257,8 @@ __global__ __launch_bounds__(256) void relattn_bwd_dr_kernel(const CT* __restric
     float* sk = (float*)(Rw + 128 * LDX);     // [4][16][SKW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t nt = (T + 63) / 64;
-    const int64_t dl = blockIdx.x;            // diagonal: qt = kt + dl (dl = 0 is the longest walk and starts first)
-    const int64_t bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int64_t dl = blockIdx.y;            // diagonal: qt = kt + dl (dl = 0 is the longest walk and starts first)
+    const int64_t bh = blockIdx.x, b = bh / H, h = bh % H;      // (b, h) fastest in dispatch order: the longest sweeps of the whole grid go first
     const CT* qub = qu + (b * T) * ld_q + h * DH;
     const CT* qvb = qv + (b * T) * ld_q + h * DH;
     const CT* kb = k + (b * T) * ld + h * DH;
@@ -1512,7 +1512,7 @@ template <typename CT, int DH> static size_t ra_fwd_lds() {
 template <typename CT, int DH>
 static int run_relattn(const void* q, const void* k, const void* v, int64_t ld, const void* rd, int64_t ld_r, int64_t n_dist, const float* ub, const float* vb,
                        void* out, int64_t ld_out, float* lse, float* zden, int64_t B, int64_t T, int64_t H, DropCtx drop, hipStream_t st) {
-    dim3 grid((unsigned)((T + 63) / 64), (unsigned)(B * H));
+    dim3 grid((unsigned)(B * H), (unsigned)((T + 63) / 64));
     const size_t lds = ra_fwd_lds<CT, DH>();
     auto kf = relattn_fwd_kernel<CT, DH>;
     static bool attr = false;
@@ -1555,7 +1555,7 @@ template <typename CT, int DH>
 static int run_relattn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* rd, int64_t ld_r, int64_t n_dist, const float* ub,
                            const float* vb, const void* out, const void* dout, int64_t ld_out, const float* lse, const float* zden, void* dq, int64_t ld_d,
                            void* dq_rel, int64_t ld_rel, float* delta, int64_t B, int64_t T, int64_t H, DropCtx drop, hipStream_t st) {
-    dim3 grid((unsigned)((T + 63) / 64), (unsigned)(B * H));
+    dim3 grid((unsigned)(B * H), (unsigned)((T + 63) / 64));
     const size_t lds = ra_bwd_lds<CT, DH>();
     auto kf = relattn_bwd_kernel<CT, DH>;
     static bool attr = false;
@@ -1603,7 +1603,7 @@ template <typename CT, int DH>
 static int run_relattn_dr(const void* qu, const void* qv, int64_t ld_q, const void* k, const void* v, int64_t ld, const void* rd, int64_t ld_r, int64_t n_dist,
                           const void* dout, int64_t ld_out, const float* lse, const float* zden, const float* delta, float* dR, int64_t ld_dr, float* part,
                           int64_t B, int64_t T, int64_t H, DropCtx drop, hipStream_t st) {
-    dim3 grid((unsigned)((T + 63) / 64), (unsigned)(B * H));
+    dim3 grid((unsigned)(B * H), (unsigned)((T + 63) / 64));
     const size_t lds = ra_dr_lds<CT, DH>();
     auto kf = relattn_bwd_dr_kernel<CT, DH>;
     static bool attr = false;
@@ -1659,7 +1659,7 @@ template <typename CT, int DH>
 static int run_relattn_dkv(const void* qu, const void* qv, int64_t ld_q, const void* k, const void* v, int64_t ld, const void* rd, int64_t ld_r, int64_t n_dist,
                            const void* dout, int64_t ld_out, const float* lse, const float* zden, const float* delta, void* dk, void* dv, int64_t ld_d,
                            int64_t B, int64_t T, int64_t H, DropCtx drop, hipStream_t st) {
-    dim3 grid((unsigned)((T + 63) / 64), (unsigned)(B * H));
+    dim3 grid((unsigned)(B * H), (unsigned)((T + 63) / 64));
     const size_t lds = ra_dkv_lds<CT, DH>();
     auto kf = relattn_bwd_dkv_kernel<CT, DH>;
     static bool attr = false;
