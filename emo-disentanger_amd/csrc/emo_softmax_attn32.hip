@@ -9,7 +9,7 @@
 // P goes from the score registers straight into the P V product (O^T = V^T P^T) as B operand in the permuted key order
 // k-slot e of lane half hi <-> key 16 u + (e & 3) + 8 (e >> 2) + 4 hi; the A operand V^T is read from the row-major V tile with
 // ds_read_b64_tr_b16 in the same order.  K / V tiles (64 keys) arrive by LDS-DMA (inline asm: see emo_favor_fs.hip) into a 2-slot ring, 128-B
-// rows with the 16-B pieces XOR-swizzled by (row & 7); one workgroup barrier per key tile; 4 waves = 128 query rows per workgroup.
+// rows with the 16-B pieces XOR-swizzled by a32_sw(row); one workgroup barrier per key tile; 4 waves = 128 query rows per workgroup.
 // Numerics = the generic bf16 kernel's: base-2 domain (scores scaled by log2(e)/sqrt(dh)), fp32 statistics, dropout regenerated from
 // (seed, offset, ((b H + h) T + t) T + j) with one keyed hash per 4 consecutive keys, lse = m ln 2 + ln(l).
 #include "emo_common.h"
@@ -26,6 +26,11 @@ __device__ __forceinline__ void a32_dma16(const void* gsrc, uint32_t lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ uint32_t a32_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
+// Tile-row swizzle: the 16-B piece p of row r sits at piece p ^ a32_sw(r).  r03 used r & 7: with 128-B rows every 16-B fragment read of 32
+// consecutive rows and every transpose read was 2-way bank-conflicted (rows r and r + 8 of a lane group share their banks; r04 PMC: half of
+// these kernels' LDS cycles were conflicts, the LDS 27-40 % busy).  This map (bits: row bit 2, row bit 3, row bit 1) is conflict-free for both
+// patterns (tools/lds_conflicts.py model, exhaustive search over the linear maps of the row bits).
+__device__ __forceinline__ int a32_sw(int row) { return ((row >> 2) & 3) | (((row >> 1) & 1) << 2); }
 __device__ __forceinline__ float a32_pair_max(float x) {       // max over the two lanes (l, l ^ 32) that share a query row
     const uint32_t u = __builtin_bit_cast(uint32_t, x);
     const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
@@ -66,8 +71,8 @@ __global__ __launch_bounds__(256, 3) void sattn32_fwd_kernel(const bf16_t* __res
 
     const uint32_t ring = __builtin_amdgcn_readfirstlane(a32_lds_addr(smem));
     // DMA: wave w moves key rows 16 w .. 16 w + 15 of K and of V (two 1-KB pieces each); lane: row + lane / 8, physical piece lane % 8
-    const int64_t so0 = (int64_t)(16 * w + (lane >> 3)) * ld + (((lane & 7) ^ (lane >> 3)) << 3);
-    const int64_t so1 = so0 + 8 * ld;                                 // rows + 8: same (row & 7), same swizzle
+    const int64_t so0 = (int64_t)(16 * w + (lane >> 3)) * ld + (((lane & 7) ^ a32_sw(lane >> 3)) << 3);
+    const int64_t so1 = (int64_t)(16 * w + 8 + (lane >> 3)) * ld + (((lane & 7) ^ a32_sw(8 + (lane >> 3))) << 3);   // rows + 8
     auto issue = [&](int kt) {
         const int64_t o = (int64_t)kt * 64 * ld;
         const uint32_t dst = ring + (kt & 1) * 2 * A32_TILEB + w * 2048;
@@ -100,8 +105,8 @@ __global__ __launch_bounds__(256, 3) void sattn32_fwd_kernel(const bf16_t* __res
         for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const bf16x8 ka = *(const bf16x8*)(Kt + ql * A32_ROWB + (((2 * s + hi) ^ (ql & 7)) << 4));
-            const bf16x8 kc = *(const bf16x8*)(Kt + (32 + ql) * A32_ROWB + (((2 * s + hi) ^ (ql & 7)) << 4));
+            const bf16x8 ka = *(const bf16x8*)(Kt + ql * A32_ROWB + (((2 * s + hi) ^ a32_sw(ql)) << 4));
+            const bf16x8 kc = *(const bf16x8*)(Kt + (32 + ql) * A32_ROWB + (((2 * s + hi) ^ a32_sw(ql)) << 4));
             s0 = mma3216(ka, qf[s], s0);
             s1 = mma3216(kc, qf[s], s1);
         }
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256, 3) void sattn32_fwd_kernel(const bf16_t* __res
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int row = 16 * u + 8 * hh + 4 * (vg >> 1) + (vi >> 2), col = 32 * dh2 + 16 * (vg & 1) + 4 * (vi & 3);
-                    const char* p = Vt + row * A32_ROWB + (((col >> 3) ^ (row & 7)) << 4) + (col & 7) * 2;
+                    const char* p = Vt + row * A32_ROWB + (((col >> 3) ^ a32_sw(row)) << 4) + (col & 7) * 2;
                     const short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
                     const bf16x4 tb = __builtin_bit_cast(bf16x4, t);
                     va[4 * hh + 0] = tb[0]; va[4 * hh + 1] = tb[1]; va[4 * hh + 2] = tb[2]; va[4 * hh + 3] = tb[3];
@@ -232,8 +237,8 @@ __global__ __launch_bounds__(256, KB ? 3 : 2) void sattn32_dq_kernel(const bf16_
     uint32_t kw_next = KB ? kwp[0] : 0u;
 
     const uint32_t ring = __builtin_amdgcn_readfirstlane(a32_lds_addr(smem));
-    const int64_t so0 = (int64_t)(16 * w + (lane >> 3)) * ld + (((lane & 7) ^ (lane >> 3)) << 3);
-    const int64_t so1 = so0 + 8 * ld;
+    const int64_t so0 = (int64_t)(16 * w + (lane >> 3)) * ld + (((lane & 7) ^ a32_sw(lane >> 3)) << 3);
+    const int64_t so1 = (int64_t)(16 * w + 8 + (lane >> 3)) * ld + (((lane & 7) ^ a32_sw(8 + (lane >> 3))) << 3);
     auto issue = [&](int kt) {
         const int64_t o = (int64_t)kt * 64 * ld;
         const uint32_t dst = ring + (kt & 1) * 2 * A32_TILEB + w * 2048;
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256, KB ? 3 : 2) void sattn32_dq_kernel(const bf16_
         for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; p0[i] = 0.f; p1[i] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int oa = ql * A32_ROWB + (((2 * s + hi) ^ (ql & 7)) << 4), oc = oa + 32 * A32_ROWB;
+            const int oa = ql * A32_ROWB + (((2 * s + hi) ^ a32_sw(ql)) << 4), oc = oa + 32 * A32_ROWB;
             s0 = mma3216(*(const bf16x8*)(Kt + oa), qf[s], s0);
             s1 = mma3216(*(const bf16x8*)(Kt + oc), qf[s], s1);
             p0 = mma3216(*(const bf16x8*)(Vt + oa), gf[s], p0);
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(256, KB ? 3 : 2) void sattn32_dq_kernel(const bf16_
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int row = 16 * u + 8 * hh + 4 * (vg >> 1) + (vi >> 2), col = 32 * dh2 + 16 * (vg & 1) + 4 * (vi & 3);
-                    const char* p = Kt + row * A32_ROWB + (((col >> 3) ^ (row & 7)) << 4) + (col & 7) * 2;
+                    const char* p = Kt + row * A32_ROWB + (((col >> 3) ^ a32_sw(row)) << 4) + (col & 7) * 2;
                     const bf16x4 tb = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p));
                     ka[4 * hh + 0] = tb[0]; ka[4 * hh + 1] = tb[1]; ka[4 * hh + 2] = tb[2]; ka[4 * hh + 3] = tb[3];
                 }
@@ -376,8 +381,9 @@ __global__ __launch_bounds__(256, 2) void sattn32_dkv_kernel(const bf16_t* __res
     }
     const uint32_t ring = __builtin_amdgcn_readfirstlane(a32_lds_addr(smem));
     // DMA sources as (wave-uniform base) + (32-bit lane byte offset): no per-lane 64-bit pointers live across the sweep
-    const uint32_t so0 = (uint32_t)(((16 * w + (lane >> 3)) * ld + (((lane & 7) ^ (lane >> 3)) << 3)) * 2), so1 = so0 + (uint32_t)(16 * ld);
-    const uint32_t go0 = (uint32_t)(((16 * w + (lane >> 3)) * ld_out + (((lane & 7) ^ (lane >> 3)) << 3)) * 2), go1 = go0 + (uint32_t)(16 * ld_out);
+    const int p0 = ((lane & 7) ^ a32_sw(lane >> 3)) << 3, p1 = ((lane & 7) ^ a32_sw(8 + (lane >> 3))) << 3;      // rows r and r + 8 of the wave's 16
+    const uint32_t so0 = (uint32_t)(((16 * w + (lane >> 3)) * ld + p0) * 2), so1 = (uint32_t)(((16 * w + 8 + (lane >> 3)) * ld + p1) * 2);
+    const uint32_t go0 = (uint32_t)(((16 * w + (lane >> 3)) * ld_out + p0) * 2), go1 = (uint32_t)(((16 * w + 8 + (lane >> 3)) * ld_out + p1) * 2);
     const uint32_t lo4 = (uint32_t)(lane * 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the plain loads above are the compiler's; keep them out of the DMA count)
     auto issue = [&](int qt) {
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void sattn32_dkv_kernel(const bf16_t* __res
             for (int i = 0; i < 16; ++i) { sa[i] = 0.f; pa[i] = 0.f; }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int off = (32 * hq + kl) * A32_ROWB + (((2 * s + hi) ^ (kl & 7)) << 4);
+                const int off = (32 * hq + kl) * A32_ROWB + (((2 * s + hi) ^ a32_sw(kl)) << 4);
                 sa = mma3216(*(const bf16x8*)(Qt + off), kB[s], sa);  // S[row][key]
                 pa = mma3216(*(const bf16x8*)(Gt + off), vB[s], pa);  // dP[row][key]
             }
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void sattn32_dkv_kernel(const bf16_t* __res
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh) {
                         const int row = 16 * u + 8 * hh + 4 * (vg >> 1) + (vi >> 2), col = 32 * dh2 + 16 * (vg & 1) + 4 * (vi & 3);
-                        const int o = row * A32_ROWB + (((col >> 3) ^ (row & 7)) << 4) + (col & 7) * 2;
+                        const int o = row * A32_ROWB + (((col >> 3) ^ a32_sw(row)) << 4) + (col & 7) * 2;
                         const bf16x4 tg = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(Gt + o)));
                         const bf16x4 tq = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(Qt + o)));
                         gt[4 * hh + 0] = tg[0]; gt[4 * hh + 1] = tg[1]; gt[4 * hh + 2] = tg[2]; gt[4 * hh + 3] = tg[3];
