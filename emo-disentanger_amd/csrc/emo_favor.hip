@@ -1285,7 +1285,7 @@ extern "C" int64_t emo_favor_attn_workspace_bytes(int64_t B, int64_t T, int64_t 
 template <typename CT, int DH, int MF, int CF, int CQ, int CK>
 static int run_favor(int which, const void* q, const void* k, const void* v, int64_t ld, const float* omega, void* out, int64_t ld_out, float* den,
                      float* sS, float* sz, const void* dout, void* dq, void* dk, void* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H, float eps,
-                     void* workspace, int64_t workspace_bytes, hipStream_t st) {
+                     void* workspace, int64_t workspace_bytes, hipStream_t st, bool kstate_valid = false) {
     constexpr int F = 2 * MF;
     int P = 1; int64_t Ts = T > 0 ? T : 1;
     if (workspace) {
@@ -1349,7 +1349,8 @@ static int run_favor(int which, const void* q, const void* k, const void* v, int
             attr = true;
         }
         // P > 1: the K-state increments are recomputed (state-only forward pass), then the workspace is reused for the R-state increments
-        if (P > 1)
+        // (kstate_valid: the caller kept the forward's workspace — the same increments — for this call: emo_favor_attn_bwd_kstate)
+        if (P > 1 && !kstate_valid)
             hipLaunchKernelGGL(k0, grid, dim3(FT), l0, st, (const CT*)q, (const CT*)k, (const CT*)v, ld, omega, (CT*)nullptr, ld_out, (float*)nullptr,
                                (float*)nullptr, (float*)nullptr, T, H, eps, wsS, wsz, P, Ts);
         if (!fs_try(1)) {
@@ -1372,14 +1373,14 @@ static int run_favor(int which, const void* q, const void* k, const void* v, int
 
 static int dispatch_favor(int which, int dtype, int64_t dh, int64_t mf, const void* q, const void* k, const void* v, int64_t ld, const float* omega,
                           void* out, int64_t ld_out, float* den, float* sS, float* sz, const void* dout, void* dq, void* dk, void* dv, int64_t ld_d,
-                          int64_t B, int64_t T, int64_t H, float eps, void* ws, int64_t ws_bytes, hipStream_t st) {
+                          int64_t B, int64_t T, int64_t H, float eps, void* ws, int64_t ws_bytes, hipStream_t st, bool kstate_valid = false) {
 #define FAVOR_CASE(DHv, MFv, CFb, CQb, CKb, CFf, CQf, CKf)                                                                                   \
     if (dh == DHv && mf == MFv) {                                                                                                            \
         if (dtype == EMO_BF16)                                                                                                               \
             return run_favor<bf16_t, DHv, MFv, CFb, CQb, CKb>(which, q, k, v, ld, omega, out, ld_out, den, sS, sz, dout, dq, dk, dv, ld_d, B, T, H, eps, ws, \
-                                                              ws_bytes, st);                                                                 \
+                                                              ws_bytes, st, kstate_valid);                                                   \
         return run_favor<float, DHv, MFv, CFf, CQf, CKf>(which, q, k, v, ld, omega, out, ld_out, den, sS, sz, dout, dq, dk, dv, ld_d, B, T, H, eps, ws,      \
-                                                         ws_bytes, st);                                                                      \
+                                                         ws_bytes, st, kstate_valid);                                                        \
     }
     FAVOR_CASE(64, 64, FAVOR_CFB, FAVOR_CQB, FAVOR_CKB, 32, 32, 16)
     FAVOR_CASE(32, 64, 64, 64, 64, 32, 32, 32)
@@ -1414,16 +1415,21 @@ extern "C" int emo_favor_attn_fwd(const void* q, const void* k, const void* v, i
                           eps, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-extern "C" int emo_favor_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const float* omega, const void* out, const void* dout,
-                                  int64_t ld_out, const float* den, void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H,
-                                  int64_t dh, int64_t n_feat, float eps, void* workspace, int64_t workspace_bytes, emo_stream_t stream) {
+extern "C" int emo_favor_attn_bwd_kstate(const void* q, const void* k, const void* v, int64_t ld, const float* omega, const void* out, const void* dout,
+                                         int64_t ld_out, const float* den, void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H,
+                                         int64_t dh, int64_t n_feat, float eps, void* workspace, int64_t workspace_bytes, int kstate_valid, emo_stream_t stream) {
     int rc = favor_check(q, k, v, ld, ld_out, dtype, dh, n_feat);
     if (rc) return rc;
     EMO_CHECK(omega && out && dout && den && dq && dk && dv, "emo_favor_attn_bwd: null pointer");
     EMO_CHECK(ld_d % 4 == 0, "emo_favor_attn_bwd: ld_d must be a multiple of 4");
     EMO_CHECK((((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)out | (uintptr_t)dout) & 15) == 0, "emo_favor_attn_bwd: pointers must be 16-B aligned");
     return dispatch_favor(1, dtype, dh, n_feat / 2, q, k, v, ld, omega, (void*)out, ld_out, (float*)den, nullptr, nullptr, dout, dq, dk, dv, ld_d, B, T, H,
-                          eps, workspace, workspace_bytes, (hipStream_t)stream);
+                          eps, workspace, workspace_bytes, (hipStream_t)stream, kstate_valid != 0 && workspace != nullptr);
+}
+extern "C" int emo_favor_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const float* omega, const void* out, const void* dout,
+                                  int64_t ld_out, const float* den, void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H,
+                                  int64_t dh, int64_t n_feat, float eps, void* workspace, int64_t workspace_bytes, emo_stream_t stream) {
+    return emo_favor_attn_bwd_kstate(q, k, v, ld, omega, out, dout, ld_out, den, dq, dk, dv, ld_d, dtype, B, T, H, dh, n_feat, eps, workspace, workspace_bytes, 0, stream);
 }
 
 extern "C" int emo_favor_decode_step(const void* q, const void* k, const void* v, int64_t ld, const float* omega, float* state_S, float* state_z, void* out,

@@ -212,7 +212,12 @@ def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save):
     D = x.shape[1]
     q = pfx + 'attention.query_projection.'
     qkv = ops.gemm(x, ps.w(q + 'weight', 3 * D), bias=ps.f32(q + 'bias', 3 * D))
-    attn, den = ops.favor_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], omega, B, T, H)
+    # (training with a time-segmented scan — B*H < 256: the call's workspace stays with the layer, its K-state increments serve the backward)
+    fws = None
+    if save is not None:
+        attn, den, fws = ops.favor_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], omega, B, T, H, keep_ws=True)
+    else:
+        attn, den = ops.favor_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], omega, B, T, H)
     x1 = ops.gemm(attn, ps.w(pfx + 'attention.out_projection.weight'), bias=ps.f32(pfx + 'attention.out_projection.bias'),
                   p_drop=p, seed=seed, offset=off + 1, residual=x)
     h1, m1, r1 = ops.layernorm_fwd(x1, ps.f32(pfx + 'norm1.weight'), ps.f32(pfx + 'norm1.bias'))
@@ -224,7 +229,7 @@ def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save):
     x2 = ops.gemm(f, ps.w(pfx + 'linear2.weight'), bias=ps.f32(pfx + 'linear2.bias'), p_drop=p, seed=seed, offset=off + 3, residual=h1)
     out, m2, r2 = ops.layernorm_fwd(x2, ps.f32(pfx + 'norm2.weight'), ps.f32(pfx + 'norm2.bias'))
     if save is not None:
-        save.t = dict(x=x, qkv=qkv, attn=attn, den=den, x1=x1, m1=m1, r1=r1, h1=h1, f=f, fmask=fmask, x2=x2, m2=m2, r2=r2, omega=omega)
+        save.t = dict(x=x, qkv=qkv, attn=attn, den=den, x1=x1, m1=m1, r1=r1, h1=h1, f=f, fmask=fmask, x2=x2, m2=m2, r2=r2, omega=omega, fws=fws)
     return out
 
 
@@ -325,7 +330,7 @@ def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
     _wgrad(ps, pfx + 'attention.out_projection.weight', pfx + 'attention.out_projection.bias', da, s['attn'], bias_done=True)
     dattn = ops.gemm(da, ps.wT(pfx + 'attention.out_projection.weight')) if bf else ops.gemm(da, ps.w(pfx + 'attention.out_projection.weight'), b_trans=True)
     qkv = s['qkv']
-    dq, dk, dv = ops.favor_attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], s['omega'], s['attn'], dattn, s['den'], B, T, H)
+    dq, dk, dv = ops.favor_attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], s['omega'], s['attn'], dattn, s['den'], B, T, H, ws_saved=s.get('fws'))
     dqkv = dq._base if dq._base is not None else torch.cat([dq, dk, dv], 1)
     q = pfx + 'attention.query_projection.'
     _wgrad(ps, q + 'weight', q + 'bias', dqkv, s['x'], fused_rows=3 * D)

@@ -198,8 +198,10 @@ def _favor_workspace(device, B, T, H, dh, n_feat):
     return _workspace('favor', device, lib.emo_favor_attn_workspace_bytes(B, T, H, dh, n_feat))
 
 
-def favor_attn_fwd(q, k, v, omega, B, T, H, eps=1e-6, want_state=False):
-    """q,k,v: [B*T, H*dh] (row-strided views allowed). Returns out [B*T, H*dh], den [B,H,T] (, S, z)."""
+def favor_attn_fwd(q, k, v, omega, B, T, H, eps=1e-6, want_state=False, keep_ws=False):
+    """q,k,v: [B*T, H*dh] (row-strided views allowed). Returns out [B*T, H*dh], den [B,H,T] (, S, z).
+    keep_ws: the call gets a PRIVATE workspace, returned as a third value (None when the scan is not segmented) for favor_attn_bwd(ws_saved=):
+    the backward then skips recomputing the K-state increments (include/emo_hip.h, emo_favor_attn_bwd_kstate)."""
     M, HD = q.shape
     dh = HD // H
     n_feat = 2 * omega.shape[1]
@@ -209,15 +211,22 @@ def favor_attn_fwd(q, k, v, omega, B, T, H, eps=1e-6, want_state=False):
     den = torch.empty(B, H, T, device=q.device, dtype=torch.float32)
     S = torch.empty(B, H, n_feat, dh, device=q.device, dtype=torch.float32) if want_state else None
     z = torch.empty(B, H, n_feat, device=q.device, dtype=torch.float32) if want_state else None
-    ws, ws_bytes = _favor_workspace(q.device, B, T, H, dh, n_feat)
+    if keep_ws:
+        ws_bytes = lib.emo_favor_attn_workspace_bytes(B, T, H, dh, n_feat)
+        ws = torch.empty(ws_bytes, device=q.device, dtype=torch.uint8) if ws_bytes else None
+    else:
+        ws, ws_bytes = _favor_workspace(q.device, B, T, H, dh, n_feat)
     # algorithmic HBM bytes: read q, k, v + write out = 4 * H*dh * e per token
     with _timed('favor_fwd', 0.0, 4.0 * M * HD * q.element_size()):
         check(lib.emo_favor_attn_fwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(omega), ptr(out), HD, ptr(den), ptr(S), ptr(z), dtype_code(q.dtype),
                                      B, T, H, dh, n_feat, eps, ptr(ws), ws_bytes, stream()))
+    if keep_ws:
+        assert not want_state
+        return out, den, ws
     return (out, den, S, z) if want_state else (out, den)
 
 
-def favor_attn_bwd(q, k, v, omega, out, dout, den, B, T, H, dqkv=None, eps=1e-6):
+def favor_attn_bwd(q, k, v, omega, out, dout, den, B, T, H, dqkv=None, eps=1e-6, ws_saved=None):
     """Returns (dq, dk, dv) views of one fused [B*T, 3*H*dh] buffer (ready for the fused-QKV dgrad/wgrad)."""
     M, HD = q.shape
     dh = HD // H
@@ -226,11 +235,15 @@ def favor_attn_bwd(q, k, v, omega, out, dout, den, B, T, H, dqkv=None, eps=1e-6)
     if dqkv is None:
         dqkv = torch.empty(M, 3 * HD, device=q.device, dtype=q.dtype)
     dq, dk, dv = dqkv[:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:]
-    ws, ws_bytes = _favor_workspace(q.device, B, T, H, dh, n_feat)
+    if ws_saved is not None:                                      # the forward's private workspace: its K-state increments are still there
+        ws, ws_bytes, kvalid = ws_saved, ws_saved.numel(), 1
+        assert ws_bytes == lib.emo_favor_attn_workspace_bytes(B, T, H, dh, n_feat)
+    else:
+        (ws, ws_bytes), kvalid = _favor_workspace(q.device, B, T, H, dh, n_feat), 0
     # read q, k, v, dout (+ out) + write dq, dk, dv = 7 * H*dh * e per token
     with _timed('favor_bwd', 0.0, 7.0 * M * HD * q.element_size()):
-        check(lib.emo_favor_attn_bwd(ptr(q), ptr(k), ptr(v), _rows(q), ptr(omega), ptr(out), ptr(dout), HD, ptr(den), ptr(dq), ptr(dk), ptr(dv),
-                                     3 * HD, dtype_code(q.dtype), B, T, H, dh, n_feat, eps, ptr(ws), ws_bytes, stream()))
+        check(lib.emo_favor_attn_bwd_kstate(ptr(q), ptr(k), ptr(v), _rows(q), ptr(omega), ptr(out), ptr(dout), HD, ptr(den), ptr(dq), ptr(dk), ptr(dv),
+                                            3 * HD, dtype_code(q.dtype), B, T, H, dh, n_feat, eps, ptr(ws), ws_bytes, kvalid, stream()))
     return dq, dk, dv
 
 

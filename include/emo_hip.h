@@ -167,6 +167,15 @@ int emo_favor_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, 
                        void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T,
                        int64_t H, int64_t dh, int64_t n_feat, float eps, void* workspace,
                        int64_t workspace_bytes, emo_stream_t stream);
+/* The same with the forward's workspace handed over: when the segment-parallel scan is in use (emo_favor_attn_workspace_bytes() > 0) the
+ * backward first recomputes the per-segment K-state increments that the forward call left in ITS workspace.  A caller that kept that buffer
+ * untouched for the matching backward passes it here with kstate_valid = 1 and saves the state-only pass (one launch per layer); the buffer is
+ * then reused for the R-state increments as usual.  kstate_valid = 0: exactly emo_favor_attn_bwd. */
+int emo_favor_attn_bwd_kstate(const void* q, const void* k, const void* v, int64_t ld, const float* omega,
+                              const void* out, const void* dout, int64_t ld_out, const float* den, void* dq,
+                              void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H,
+                              int64_t dh, int64_t n_feat, float eps, void* workspace, int64_t workspace_bytes,
+                              int kstate_valid, emo_stream_t stream);
 /* one recurrent step per stream: state += phi(k) (x) v ; out = phi(q)^T S / (phi(q).z + eps) */
 int emo_favor_decode_step(const void* q, const void* k, const void* v, int64_t ld, const float* omega,
                           float* state_S, float* state_z, void* out, int64_t ld_out, int dtype,

@@ -871,6 +871,26 @@ def test_adam_and_clip_match_torch():
     _close(pb, p.detach(), torch.bfloat16)
 
 
+def test_favor_backward_reuses_the_forward_workspace():
+    """Segment-parallel scan (B*H < 256): the backward normally recomputes the K-state increments the forward left in its workspace; with the
+    forward's private workspace handed over (keep_ws / ws_saved) it skips that pass — same bits."""
+    ops = _ops()
+    B, T, H, dh, F = 2, 1024, 8, 64, 128
+    HD = H * dh
+    qkv = (_r(B * T, 3 * HD, seed=3) * 0.8).to(torch.bfloat16).cuda()
+    om = _r(dh, F // 2, seed=4).cuda()
+    dout = _r(B * T, HD, seed=5).to(torch.bfloat16).cuda()
+    q, k, v = qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:]
+    assert ops.lib.emo_favor_attn_workspace_bytes(B, T, H, dh, F) > 0
+    out0, den0 = ops.favor_attn_fwd(q, k, v, om, B, T, H)
+    g0 = ops.favor_attn_bwd(q, k, v, om, out0, dout, den0, B, T, H)
+    out1, den1, ws = ops.favor_attn_fwd(q, k, v, om, B, T, H, keep_ws=True)
+    assert ws is not None and torch.equal(out0, out1) and torch.equal(den0, den1)
+    g1 = ops.favor_attn_bwd(q, k, v, om, out1, dout, den1, B, T, H, ws_saved=ws)
+    for a, b_ in zip(g0, g1):
+        assert torch.equal(a, b_)
+
+
 def test_favor_omega_draw_is_orthogonal_with_row_norm_scaling():
     ops = _ops()
     for L, dh, nf in ((3, 64, 128), (2, 32, 128), (2, 16, 32)):
