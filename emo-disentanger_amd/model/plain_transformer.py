@@ -125,7 +125,7 @@ import os as _os
 _FUSE_BELOW = _os.environ.get('EMO_S1_FUSE', '1') != '0'      # (A/B switch of the cross-layer LayerNorm-backward fusion)
 
 
-def _txl_layer_bwd(ps, p, dout, pe_d, B, T, H, pd, seed, off, s, acc, dyd=None, bias3_done=False, below=None):
+def _txl_layer_bwd(ps, p, dout, pe_d, B, T, H, pd, seed, off, s, acc, dyd=None, bias3_done=False, below=None, dR_out=None):
     """dyd / bias3_done: dout with this layer's output dropout already re-applied and the CoreNet.3 bias gradient already accumulated — by the
     LayerNorm backward of the layer ABOVE, which produced dout (below = (offset of the output-dropout site, CoreNet.3 bias gradient) of the
     layer below: this layer's last LayerNorm backward does the same for it).  Saves three ~3-us launches per layer of a launch-bound step.
@@ -158,8 +158,9 @@ def _txl_layer_bwd(ps, p, dout, pe_d, B, T, H, pd, seed, off, s, acc, dyd=None, 
         dh_res = dh
     # (the column sums behind d r_w_bias / d r_r_bias — parameters shared by all layers — accumulate into `acc`; TXLStackFn.backward adds them once)
     dqkv, dR, _, _ = ops.relpos_attn_bwd(s['qkv'], s['r_dist'], ps.f32('decoder.r_w_bias'), ps.f32('decoder.r_r_bias'), s['vec'], dvec, s['lse'],
-                                         s['zden'], B, K, H, p_drop=pd, seed=seed, offset=off + 1, acc_dq=None, acc_rr=acc[3 * D:])
-    wg(dR.to(ps.compute_dtype), pe_d, a + 'r_net.weight')                     # R = r_net(dropout(pos_emb)): dW_r += dR^T pos_emb
+                                         s['zden'], B, K, H, p_drop=pd, seed=seed, offset=off + 1, acc_dq=None, acc_rr=acc[3 * D:], dR_out=dR_out)
+    if dR_out is None:
+        wg(dR.to(ps.compute_dtype), pe_d, a + 'r_net.weight')                 # R = r_net(dropout(pos_emb)): dW_r += dR^T pos_emb
     # (colsum(dq) = the first D entries of the column sums of dqkv, which the weight-gradient GEMM takes from its operand fragments: acc[:3D])
     ops.gemm(dqkv, s['n'], a_trans=True, b_trans=True, out=ps.g(a + 'qkv_net.weight'), accumulate=True, a_rowsum=acc[:3 * D])
     dn = ops.gemm(dqkv, ps.w(a + 'qkv_net.weight'), b_trans=True)
@@ -195,9 +196,10 @@ class TXLStackFn(torch.autograd.Function):
         pe = model.decoder.pos_emb(torch.arange(mlen + T, device=ps.device, dtype=torch.float32)).to(ps.compute_dtype).contiguous()   # row d = distance d
         pe_d = ops.dropout_apply(pe, pd, seed, base + 3) if pd > 0 else pe
         saves, hids = [], [x]
+        r_all = ops.gemm(pe_d, ps.w('decoder.layers.0.dec_attn.r_net.weight', L * D))      # [n_dist, L*D]: layer l's R = columns l*D .. (l+1)*D
         for l in range(L):
             sv = {} if need_bwd else None
-            r_dist = ops.gemm(pe_d, ps.w('decoder.layers.%d.dec_attn.r_net.weight' % l))
+            r_dist = r_all[:, l * D:(l + 1) * D]
             x = _txl_layer_fwd(ps, 'decoder.layers.%d.' % l, x, r_dist, B, T, H, pd, seed, base + 8 * (l + 1), model.decoder.pre_lnorm, sv,
                                mem=None if not mlen else mems[l])
             saves.append(sv)
@@ -221,11 +223,15 @@ class TXLStackFn(torch.autograd.Function):
             dx = ops.dropout_apply(dx, pd, seed, base + 2)
         acc = torch.zeros(4 * D, device=dx.device, dtype=torch.float32)       # [colsum(dqkv) (3D), colsum(dq_relative) (D)] summed over the layers
         dyd, b3 = None, False
+        n_dist = ctx.pe_d.shape[0]
+        dR_all = torch.empty(n_dist, L * D, device=dx.device, dtype=torch.float32)       # every layer's dR (its kernel writes all n_dist rows of its block)
         for l in reversed(range(L)):
             below = (base + 8 * l + 4, ps.g('decoder.layers.%d.pos_ff.CoreNet.3.bias' % (l - 1))) if (l > 0 and _FUSE_BELOW) else None
             dx, dyd, b3 = _txl_layer_bwd(ps, 'decoder.layers.%d.' % l, dx, ctx.pe_d, B, T, H, pd, seed, base + 8 * (l + 1), ctx.saves[l], acc,
-                                         dyd=dyd, bias3_done=b3, below=below)
+                                         dyd=dyd, bias3_done=b3, below=below, dR_out=dR_all[:, l * D:(l + 1) * D])
             ctx.saves[l] = None
+        # R_l = r_net_l(dropout(pos_emb)): dW_r[l] += dR_l^T pos_emb, all layers in one product (the weights are adjacent in the store)
+        ops.gemm(dR_all.to(ps.compute_dtype), ctx.pe_d, a_trans=True, b_trans=True, out=ps.g('decoder.layers.0.dec_attn.r_net.weight', L * D), accumulate=True)
         ps.g('decoder.r_r_bias').add_(acc[3 * D:].view(H, D // H))             # d r_r_bias = colsum(dq_relative)
         ps.g('decoder.r_w_bias').add_((acc[:D] - acc[3 * D:]).view(H, D // H)) # d r_w_bias = colsum(dq) - colsum(dq_relative)
         if pd > 0:
@@ -273,7 +279,10 @@ class PlainTransformer(nn.Module):
     # ------------------------------------------------------------------ engine plumbing
     def _ensure_store(self):
         if self._store is None or not self._store.intact() or self._store.compute_dtype != self._compute_dtype:
-            self._store = engine.ParamStore(self, self._compute_dtype, [])
+            # (the r_net weights of all layers sit back to back: R of every layer is ONE [n_dist, L*D] product of the shared position embedding,
+            # and their weight gradients one product of the concatenated dR — 44 launches per training step fewer, r04)
+            rnets = ['decoder.layers.%d.dec_attn.r_net.weight' % l for l in range(self.dec_n_layer)]
+            self._store = engine.ParamStore(self, self._compute_dtype, [rnets] if len(rnets) > 1 else [])
         self._store.sync_mirror()
         return self._store
 
@@ -294,7 +303,7 @@ class PlainTransformer(nn.Module):
         reference's r_head_k[klen-1-d] (optimus_txl_decoder.py:318, 791-796)."""
         ps = self._ensure_store()
         pe = self.decoder.pos_emb(torch.arange(n_dist, device=ps.device, dtype=torch.float32)).to(ps.compute_dtype).contiguous()
-        return [ops.gemm(pe, ps.w('decoder.layers.%d.dec_attn.r_net.weight' % l)) for l in range(self.dec_n_layer)]
+        return [ops.gemm(pe, ps.w('decoder.layers.%d.dec_attn.r_net.weight' % l)) for l in range(self.dec_n_layer)]     # (contiguous per layer: the decode kernels index rows)
 
     def _embed(self, tok_bm, pos0=0):
         ps = self._store

@@ -349,7 +349,7 @@ def relpos_attn_fwd(q, k, v, r_dist, r_w_bias, r_r_bias, B, T, H, p_drop=0.0, se
     return out, lse, zden
 
 
-def relpos_attn_bwd(qkv, r_dist, r_w_bias, r_r_bias, out, dout, lse, zden, B, T, H, p_drop=0.0, seed=0, offset=0, acc_dq=None, acc_rr=None):
+def relpos_attn_bwd(qkv, r_dist, r_w_bias, r_r_bias, out, dout, lse, zden, B, T, H, p_drop=0.0, seed=0, offset=0, acc_dq=None, acc_rr=None, dR_out=None):
     """Backward of relpos_attn_fwd.  qkv [B*T, 3*H*dh] (the fused projection).  Returns dqkv [B*T, 3*H*dh], dR [T, H*dh] fp32 (gradient of
     r_dist rows 0..T-1), d r_w_bias [H, dh], d r_r_bias [H, dh] fp32.  Three kernels, each recomputing the probabilities of its tiles:
     query-tile pass (dq = content + relative part), key-tile pass (dk, dv), distance-window pass (dR) — include/emo_hip.h."""
@@ -378,10 +378,14 @@ def relpos_attn_bwd(qkv, r_dist, r_w_bias, r_r_bias, out, dout, lse, zden, B, T,
     check(lib.emo_relpos_attn_bwd_kv(ptr(qu), ptr(qv), D, ptr(k), ptr(v), D3, ptr(r_dist), _rows(r_dist), r_dist.shape[0], ptr(dout), D, ptr(lse),
                                      ptr(zden), ptr(delta), ptr(dqkv[:, D:2 * D]), ptr(dqkv[:, 2 * D:]), D3, dtype_code(dt), B, T, H, dh, p_drop, seed,
                                      offset, stream()))
-    dR = torch.empty(T, D, device=dev, dtype=torch.float32)
+    if dR_out is not None:                                      # caller's fp32 [>= T, D] view (row-strided: one column block of a buffer shared by all layers)
+        assert dR_out.dtype == torch.float32 and dR_out.shape[1] == D and dR_out.shape[0] >= T and dR_out.stride(1) == 1
+        dR = dR_out
+    else:
+        dR = torch.empty(T, D, device=dev, dtype=torch.float32)
     ws, ws_bytes = _workspace('relpos_dr', dev, lib.emo_relpos_attn_bwd_r_workspace_bytes(B, T, H, dh))
     check(lib.emo_relpos_attn_bwd_r(ptr(qu), ptr(qv), D, ptr(k), ptr(v), D3, ptr(r_dist), _rows(r_dist), r_dist.shape[0], ptr(dout), D, ptr(lse),
-                                    ptr(zden), ptr(delta), ptr(dR), D, ptr(ws), ws_bytes, dtype_code(dt), B, T, H, dh, p_drop, seed, offset, stream()))
+                                    ptr(zden), ptr(delta), ptr(dR), _rows(dR), ptr(ws), ws_bytes, dtype_code(dt), B, T, H, dh, p_drop, seed, offset, stream()))
     return dqkv, dR, d_rw, d_rr
 
 
