@@ -125,7 +125,7 @@ import os as _os
 _FUSE_BELOW = _os.environ.get('EMO_S1_FUSE', '1') != '0'      # (A/B switch of the cross-layer LayerNorm-backward fusion)
 
 
-def _txl_layer_bwd(ps, p, dout, pe_d, B, T, H, pd, seed, off, s, acc, dyd=None, bias3_done=False, below=None, dR_out=None):
+def _txl_layer_bwd(ps, p, dout, pe_d, B, T, H, pd, seed, off, s, acc, dyd=None, bias3_done=False, below=None, dR_out=None, dq_rel_out=None):
     """dyd / bias3_done: dout with this layer's output dropout already re-applied and the CoreNet.3 bias gradient already accumulated — by the
     LayerNorm backward of the layer ABOVE, which produced dout (below = (offset of the output-dropout site, CoreNet.3 bias gradient) of the
     layer below: this layer's last LayerNorm backward does the same for it).  Saves three ~3-us launches per layer of a launch-bound step.
@@ -158,7 +158,7 @@ def _txl_layer_bwd(ps, p, dout, pe_d, B, T, H, pd, seed, off, s, acc, dyd=None, 
         dh_res = dh
     # (the column sums behind d r_w_bias / d r_r_bias — parameters shared by all layers — accumulate into `acc`; TXLStackFn.backward adds them once)
     dqkv, dR, _, _ = ops.relpos_attn_bwd(s['qkv'], s['r_dist'], ps.f32('decoder.r_w_bias'), ps.f32('decoder.r_r_bias'), s['vec'], dvec, s['lse'],
-                                         s['zden'], B, K, H, p_drop=pd, seed=seed, offset=off + 1, acc_dq=None, acc_rr=acc[3 * D:], dR_out=dR_out)
+                                         s['zden'], B, K, H, p_drop=pd, seed=seed, offset=off + 1, acc_dq=None, acc_rr=acc[3 * D:], dR_out=dR_out, dq_rel_out=dq_rel_out if not mlen else None)
     if dR_out is None:
         wg(dR.to(ps.compute_dtype), pe_d, a + 'r_net.weight')                 # R = r_net(dropout(pos_emb)): dW_r += dR^T pos_emb
     # (colsum(dq) = the first D entries of the column sums of dqkv, which the weight-gradient GEMM takes from its operand fragments: acc[:3D])
@@ -225,11 +225,16 @@ class TXLStackFn(torch.autograd.Function):
         dyd, b3 = None, False
         n_dist = ctx.pe_d.shape[0]
         dR_all = torch.empty(n_dist, L * D, device=dx.device, dtype=torch.float32)       # every layer's dR (its kernel writes all n_dist rows of its block)
+        dq_rel_all = torch.empty(L, B * T, D, device=dx.device, dtype=ps.compute_dtype)   # every layer's relative part of dq: ONE column sum below
+        stacked = True
         for l in reversed(range(L)):
+            stacked = stacked and not (ctx.saves[l]['mlen'])
             below = (base + 8 * l + 4, ps.g('decoder.layers.%d.pos_ff.CoreNet.3.bias' % (l - 1))) if (l > 0 and _FUSE_BELOW) else None
             dx, dyd, b3 = _txl_layer_bwd(ps, 'decoder.layers.%d.' % l, dx, ctx.pe_d, B, T, H, pd, seed, base + 8 * (l + 1), ctx.saves[l], acc,
-                                         dyd=dyd, bias3_done=b3, below=below, dR_out=dR_all[:, l * D:(l + 1) * D])
+                                         dyd=dyd, bias3_done=b3, below=below, dR_out=dR_all[:, l * D:(l + 1) * D], dq_rel_out=dq_rel_all[l])
             ctx.saves[l] = None
+        if stacked:
+            ops.colsum(dq_rel_all.view(L * B * T, D), out=acc[3 * D:], accumulate=True)
         # R_l = r_net_l(dropout(pos_emb)): dW_r[l] += dR_l^T pos_emb, all layers in one product (the weights are adjacent in the store)
         ops.gemm(dR_all.to(ps.compute_dtype), ctx.pe_d, a_trans=True, b_trans=True, out=ps.g('decoder.layers.0.dec_attn.r_net.weight', L * D), accumulate=True)
         ps.g('decoder.r_r_bias').add_(acc[3 * D:].view(H, D // H))             # d r_r_bias = colsum(dq_relative)

@@ -349,7 +349,7 @@ def relpos_attn_fwd(q, k, v, r_dist, r_w_bias, r_r_bias, B, T, H, p_drop=0.0, se
     return out, lse, zden
 
 
-def relpos_attn_bwd(qkv, r_dist, r_w_bias, r_r_bias, out, dout, lse, zden, B, T, H, p_drop=0.0, seed=0, offset=0, acc_dq=None, acc_rr=None, dR_out=None):
+def relpos_attn_bwd(qkv, r_dist, r_w_bias, r_r_bias, out, dout, lse, zden, B, T, H, p_drop=0.0, seed=0, offset=0, acc_dq=None, acc_rr=None, dR_out=None, dq_rel_out=None):
     """Backward of relpos_attn_fwd.  qkv [B*T, 3*H*dh] (the fused projection).  Returns dqkv [B*T, 3*H*dh], dR [T, H*dh] fp32 (gradient of
     r_dist rows 0..T-1), d r_w_bias [H, dh], d r_r_bias [H, dh] fp32.  Three kernels, each recomputing the probabilities of its tiles:
     query-tile pass (dq = content + relative part), key-tile pass (dk, dv), distance-window pass (dR) — include/emo_hip.h."""
@@ -359,7 +359,9 @@ def relpos_attn_bwd(qkv, r_dist, r_w_bias, r_r_bias, out, dout, lse, zden, B, T,
     dt, dev = qkv.dtype, qkv.device
     assert M == B * T and out.is_contiguous() and dout.is_contiguous() and qkv.is_contiguous()
     dqkv = torch.empty(M, D3, device=dev, dtype=dt)
-    dq_rel = torch.empty(M, D, device=dev, dtype=dt)
+    # dq_rel_out: caller's [M, D] buffer for the relative part of dq (the training stack keeps all layers' in one tensor and takes ONE column sum)
+    dq_rel = dq_rel_out if dq_rel_out is not None else torch.empty(M, D, device=dev, dtype=dt)
+    assert dq_rel.shape == (M, D) and dq_rel.dtype == dt and dq_rel.is_contiguous()
     delta = torch.empty(B, H, T, device=dev, dtype=torch.float32)
     q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
     check(lib.emo_relpos_attn_bwd(ptr(q), ptr(k), ptr(v), D3, ptr(r_dist), _rows(r_dist), r_dist.shape[0], ptr(r_w_bias), ptr(r_r_bias), ptr(out),
@@ -368,7 +370,8 @@ def relpos_attn_bwd(qkv, r_dist, r_w_bias, r_r_bias, out, dout, lse, zden, B, T,
     if acc_rr is not None:                                      # training stack: column sums accumulated over the layers, no per-layer ATen ops —
         if acc_dq is not None:                                  # acc_dq += colsum(dq) (None: the caller takes it from the qkv_net weight-gradient
             colsum(dqkv[:, :D], out=acc_dq, accumulate=True)    # GEMM's a_rowsum, one launch fewer), acc_rr += colsum(dq_rel); the caller forms
-        colsum(dq_rel, out=acc_rr, accumulate=True)             # d r_r_bias = acc_rr, d r_w_bias = acc_dq - acc_rr once per backward
+        if dq_rel_out is None:
+            colsum(dq_rel, out=acc_rr, accumulate=True)         # d r_r_bias = acc_rr, d r_w_bias = acc_dq - acc_rr once per backward
         d_rr = d_rw = None
     else:
         d_rr = colsum(dq_rel)                                   # sum over (b, i) of the relative part of dq = d r_r_bias
