@@ -36,3 +36,39 @@ def export_masks(kind, p, seed, base, B, T, D, d_ff, H, L):
 def slice_batch(masks, b):
     """The masks of sequence b alone (batch dimension kept, size 1)."""
     return {k: v[b:b + 1] for k, v in masks.items()}
+
+
+# ---------------------------------------------------------------------------------------------------- stage 1 (Transformer-XL)
+def load_txl_dropout_fixture(path, c):
+    """tests/golden/txl_dropout_*.npz (tools/make_golden_stage1_dropout.py: the IMPORTED reference run in training mode, torch's Bernoulli
+    draws stored as packed keep-bits) -> (npz, masks) with masks = the oracle's `masks=` dict (multipliers, reference time-major shapes)."""
+    import numpy as np
+    g = np.load(path)
+    T, B, D, dff, H, L, p = c['T'], c['B'], c['d'], c['dff'], c['H'], c['L'], c['p']
+    shapes = {'emb': (T, B, D), 'emb2': (T, B, D), 'pos': (T, 1, D), 'final': (T, B, D)}
+    for l in range(L):
+        shapes.update({'L%d.attn_prob' % l: (T, T, B, H), 'L%d.attn_out' % l: (T, B, D), 'L%d.ffn_hidden' % l: (T, B, dff), 'L%d.ffn_out' % l: (T, B, D)})
+    inv = float(torch.tensor(1.0) / (1.0 - p))
+    masks = {}
+    for k, shp in shapes.items():
+        n = int(np.prod(shp))
+        masks[k] = torch.from_numpy(np.unpackbits(g['keep_' + k])[:n].astype(np.float32).reshape(shp)) * inv
+    return g, masks
+
+
+def export_txl_masks(p, seed, base, B, T, D, d_ff, H, L, attn_keep):
+    """Multipliers of every dropout site of ONE training forward of the product's PlainTransformer (model/plain_transformer.py: TXLStackFn —
+    embedding = base, decoder.drop on it = base + 1, final = base + 2, pos_emb = base + 3, layer l = base + 8 (l + 1) + {1 attention
+    probabilities, 2 o_net output, 3 CoreNet hidden, 4 CoreNet output}), converted to the oracle's (= the reference's) time-major shapes.
+    The product indexes batch-major ([B, T, ...]) and keeps pos_emb by DISTANCE (row d = distance d; the reference's row i is distance
+    klen - 1 - i).  attn_keep(l) -> [B, H, T, T] multipliers of layer l's attention probabilities, read out of the attention kernel itself."""
+    tm = lambda shape, off: site_multipliers(shape, p, seed, off).transpose(0, 1).contiguous()          # [B, T, X] -> [T, B, X]
+    m = {'emb': tm((B, T, D), base), 'emb2': tm((B, T, D), base + 1), 'final': tm((B, T, D), base + 2),
+         'pos': site_multipliers((T, D), p, seed, base + 3).flip(0)[:, None, :].contiguous()}
+    for l in range(L):
+        off = base + 8 * (l + 1)
+        m['L%d.attn_prob' % l] = attn_keep(l).permute(2, 3, 0, 1).contiguous()                          # [B, H, Tq, Tk] -> [Tq, Tk, B, H]
+        m['L%d.attn_out' % l] = tm((B, T, D), off + 2)
+        m['L%d.ffn_hidden' % l] = tm((B, T, d_ff), off + 3)
+        m['L%d.ffn_out' % l] = tm((B, T, D), off + 4)
+    return m

@@ -68,6 +68,50 @@ def test_one_launch_step_matches_launch_chain_and_fp32(n, L, monkeypatch):
     assert torch.equal(c, e)
 
 
+@pytest.mark.parametrize('n', [4, 32])
+def test_one_launch_step_matches_oracle_recurrent_form(n, monkeypatch):
+    """The launch `gen` times, directly against the ORACLE: teacher-force 64 tokens on 4 / 32 streams at d512 / L12 / H8 / F128 and compare
+    every step's logits of emo_performer_decode_step with oracle.model_ref.performer_forward(form='recurrent') — the token recurrence
+    S += phi(k) v^T, z += phi(k), out = phi(q) S / (phi(q) z + eps) that the cached loop of stage2_accompaniment/inference.py:250-277 runs —
+    on the same tokens.  bf16 bound: 5 % of the logit range (the bound of the bf16 training-parity tests); greedy ids must agree wherever the
+    oracle's top-2 margin exceeds twice that bound's measured counterpart."""
+    from oracle import model_ref
+    from oracle.weights import make_state_dict
+    from emo_disentanger_amd import inference as inf
+    from emo_disentanger_amd.model.music_performer import MusicPerformer
+    V, L, H, d, dff, nf, T0, K = 327, 12, 8, 512, 2048, 128, 24, 64
+    sd = make_state_dict('performer', V, L, H, d, dff, favor_feature_dims=nf, seed=3, scale=2.5)
+    m = MusicPerformer(V, L, H, d, dff, d, favor_feature_dims=nf, use_segment_emb=True, n_segment_types=2, compute_dtype='bf16', redraw='fixed')
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(50 + n)
+    tok = torch.randint(0, V - 1, (n, T0 + K), generator=g)
+    seg = torch.randint(0, 2, (n, T0 + K), generator=g)
+    with torch.no_grad():
+        ref = model_ref.performer_forward(sd, tok, seg, L, H, d, form='recurrent')[:, T0 - 1:]          # [n, K + 1, V]: positions T0-1 .. T0+K-1
+    monkeypatch.setenv('EMO_DECODE_PERSISTENT', '1')
+    eng = inf.make_engine(m, n, redraw=False)
+    assert eng.persist is not None                                   # the one-launch step, not the launch chain
+    tc, sc = tok.cuda(), seg.cuda()
+    out = [eng.prefill(tc[:, :T0], sc[:, :T0]).float().clone()]
+    for t in range(K):
+        out.append(eng.step(tc[:, T0 + t], sc[:, T0 + t]).float().clone())
+    eng.check_persistent()
+    got = torch.stack(out, 1).cpu()
+    rng = float(ref.max() - ref.min())
+    err = (got - ref).abs()
+    e_max, e_steps = float(err.max()), err.amax(dim=(0, 2))
+    top2 = ref.topk(2, -1).values
+    margin = top2[..., 0] - top2[..., 1]
+    safe = margin > 2 * e_max
+    print('[one-launch decode vs oracle recurrent] n=%d: max |dlogit| %.4f = %.4f of the logit range (step 1: %.4f, step %d: %.4f); greedy ids compared at %.0f %% of positions'
+          % (n, e_max, e_max / rng, float(e_steps[1]), K, float(e_steps[-1]), 100 * float(safe.float().mean())))
+    assert e_max <= 0.05 * rng
+    assert float(e_steps[-8:].max()) <= 3 * float(e_steps[1:9].max()) + 0.01 * rng        # the recurrent state does not drift over the 64 steps
+    assert float(safe.float().mean()) > 0.05
+    assert torch.equal(got.argmax(-1)[safe], ref.argmax(-1)[safe])
+
+
 def test_one_launch_step_refuses_what_it_was_not_built_for():
     from emo_disentanger_amd import ops
     from emo_disentanger_amd._lib import EmoError

@@ -83,3 +83,35 @@ def test_oracle_segment_recurrence_matches_reference(name):
     for n, want in zip(g['grad_names'], g['grad_norms']):
         got = float(leaf[str(n)].grad.norm()) if leaf[str(n)].grad is not None else 0.0
         assert abs(got - want) <= 1e-4 * max(1.0, want), n
+
+
+DROP_CASES = sorted(json.load(open(os.path.join(G, 'txl_dropout_manifest.json'))).items())
+
+
+@pytest.mark.parametrize('name,c', DROP_CASES)
+def test_txl_oracle_with_dropout_masks_matches_reference_training_run(name, c):
+    # the fixture is the IMPORTED reference in training mode (dropout 0.1, all eight sites incl. the attention-probability dropout followed
+    # by the renormalisation p / (sum p + 1e-8), optimus_txl_decoder.py:361-363) with its Bernoulli draws stored as keep-bits: the masked
+    # restatement must land on the reference's logits, loss and every gradient — this pins the oracle the dropout-ON GPU tests use
+    from oracle import txl_ref
+    from dropmask import load_txl_dropout_fixture
+    g, masks = load_txl_dropout_fixture(os.path.join(G, name + '.npz'), c)
+    sd = txl_ref.make_state_dict_txl(c['V'], c['L'], c['H'], c['d'], c['dff'], seed=c['seed'], scale=c['scale'])
+    x, tgt = torch.from_numpy(g['x']), torch.from_numpy(g['tgt'])
+    loss, logits, grads = txl_ref.loss_and_grads(sd, x, tgt, c['L'], c['H'], masks=masks)
+    scale = float(np.abs(g['logits']).max())
+    np.testing.assert_allclose(logits.numpy(), g['logits'], rtol=0, atol=2e-5 * scale)
+    assert abs(float(loss) - float(g['loss'])) < 1e-5
+    names = [str(n) for n in g['grad_names']]
+    assert names == list(grads.keys())
+    for n, ref in zip(names, g['grad_norms']):
+        got = float(grads[n].norm())
+        assert abs(got - ref) <= 2e-4 * max(ref, 1e-3), (n, got, ref)
+    for i, n in enumerate(str(k) for k in g['full_names']):
+        ref = g['grad_%d' % i]
+        np.testing.assert_allclose(grads[n].numpy(), ref, rtol=0, atol=1e-4 * float(np.abs(ref).max()))
+    # sanity of the fixture itself: the keep rate is 1 - p, the masks matter, and dropping the renormalisation is detected
+    keep = np.concatenate([(m != 0).numpy().reshape(-1) for m in masks.values()])
+    assert abs(keep.mean() - (1 - c['p'])) < 0.01
+    off, _ = txl_ref.forward(sd, x, c['L'], c['H'])
+    assert float((off - logits).abs().max()) > 1e-2 * scale
