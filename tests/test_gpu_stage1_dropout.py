@@ -45,7 +45,7 @@ def relattn_keep_from_kernel(B, T, H, dh, p, seed, offset, dt):
     return keep.float() / (1.0 - p)
 
 
-def _relattn_ref_masked(q, k, v, R, u, vb, mult):
+def _relattn_ref_masked(q, k, v, R, u, vb, mult, renorm=True):
     """fp64 RelPartialLearnableMultiHeadAttn core (:340-366) with explicit distances and the GIVEN dropout multipliers [B, H, T, T]."""
     B, T, H, dh = q.shape
     AC = torch.einsum('bihd,bjhd->bhij', q + u, k)
@@ -56,7 +56,8 @@ def _relattn_ref_masked(q, k, v, R, u, vb, mult):
     p = torch.softmax(sc, -1)
     if mult is not None:
         p = p * mult.double()                                                        # dropatt (:361)
-    p = p / (p.sum(-1, keepdim=True) + 1e-8)                                         # renormalisation (:363)
+    if renorm:
+        p = p / (p.sum(-1, keepdim=True) + 1e-8)                                     # renormalisation (:363)
     return torch.einsum('bhij,bjhd->bihd', p, v)
 
 
@@ -99,10 +100,10 @@ def test_relattn_kernels_with_dropout_and_renormalisation_vs_fp64(B, T, H, dh, d
     close(dR, leaf[1].grad, float(leaf[1].grad.abs().max()), 6, 'dR')
     close(du, leaf[2].grad, float(leaf[2].grad.abs().max()), 8, 'd r_w_bias')
     close(dvb, leaf[3].grad, float(leaf[3].grad.abs().max()), 8, 'd r_r_bias')
-    # the renormalisation is not a no-op here and the test sees it: without it the reference output differs by far more than the tolerance
+    # the renormalisation is not a no-op here and the test sees it: plain inverted dropout (no renormalisation) is far outside the tolerance
     with torch.no_grad():
-        sc_ref = _relattn_ref_masked(q, k, v, leaf[1].view(T, H, dh), leaf[2], leaf[3], None)
-    assert float((sc_ref - ref).abs().max()) > 20 * tol * float(ref.abs().max())
+        plain = _relattn_ref_masked(q, k, v, leaf[1].view(T, H, dh), leaf[2], leaf[3], mult, renorm=False)
+    assert float((plain - ref).abs().max()) > 0.1 * float(ref.abs().max()) > 3 * tol * float(ref.abs().max())
 
 
 def _step(c, dtype, x, tgt, p, seed, fuse, monkeypatch):
@@ -144,8 +145,11 @@ def _oracle(c, sd, x, tgt, p, seed, dtype):
     return _ORACLE[key]
 
 
-def _compare(m, loss, logits, rloss, rlogits, rgrads, dtype):
-    lt, gt = (1e-4, 2e-3) if dtype == 'fp32' else (3e-2, 6e-2)
+def _compare(m, loss, logits, rloss, rlogits, rgrads, dtype, gt32=2e-3):
+    # gradient bounds: fp32 2e-3 of the largest gradient element; bf16 1e-1 — measured on MI355X with dropout OFF the bf16 path is already at
+    # 0.033 / 0.067 on the two fixture shapes (word_emb: every layer's bf16 backward rounding ends in it, times emb_scale) and with dropout ON at
+    # 0.047 / 0.073 (tools/diag_s1_dropout.py prints both): the masks add nothing measurable, which is what this test is about
+    lt, gt = (1e-4, gt32) if dtype == 'fp32' else (3e-2, 1e-1)
     assert abs(loss - float(rloss)) <= lt, (loss, float(rloss))
     scale = float(rlogits.abs().max())
     lerr = float((logits - rlogits).abs().max())
@@ -189,7 +193,10 @@ def test_stage1_dropout_on_at_bench_shape_matches_oracle(dtype, fuse, monkeypatc
     tgt[-37:, 1] = c['V'] - 1
     m, sd, loss, logits = _step(c, dtype, x, tgt, p, seed, fuse, monkeypatch)
     rloss, rlogits, rgrads = _oracle(c, sd, x, tgt, p, seed, dtype)
-    dl, lerr, worst = _compare(m, loss, logits, rloss, rlogits, rgrads, dtype)
+    # fp32 gradient bound 4e-3 here: with dropout OFF this shape measures 2.5e-3 (loss 2e-6, logits 4e-6: the forward is exact; the backward
+    # differs where a ReLU pre-activation of the 12 x 4 M hidden units lies within rounding of 0 and the two sides disagree on its sign), with
+    # dropout ON 2.2e-3 (tools/diag_s1_dropout.py)
+    dl, lerr, worst = _compare(m, loss, logits, rloss, rlogits, rgrads, dtype, gt32=4e-3)
     print('[stage-1 dropout-on bench-shape parity] %s fuse=%d: |dloss| %.3g  max|dlogit| %.3g  worst grad %s %.3g of max|g|' % (dtype, fuse, dl, lerr, worst[0], worst[1]))
 
 
@@ -202,7 +209,7 @@ def test_stage1_fused_and_unfused_backward_agree_bf16(monkeypatch):
     tgt = torch.from_numpy(rng.integers(0, c['V'] - 1, size=(c['T'], 4), dtype=np.int64))
     m1, _, l1, _ = _step(c, 'bf16', x, tgt, 0.1, 3, 1, monkeypatch)
     m0, _, l0, _ = _step(c, 'bf16', x, tgt, 0.1, 3, 0, monkeypatch)
-    assert l1 == l0
+    assert abs(l1 - l0) < 1e-5                                                       # (same forward; the loss reduction's summation order is free)
     gmax = max(float(p.grad.abs().max()) for p in m0.parameters())
     for (k, a), (_, b) in zip(m1.named_parameters(), m0.named_parameters()):
         assert float((a.grad - b.grad).abs().max()) <= 2e-3 * gmax, k
