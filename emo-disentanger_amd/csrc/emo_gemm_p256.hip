@@ -1,0 +1,436 @@
+// Persistent 256 x 256 bf16 NT GEMM (C[M,N] = A[M,K] B[N,K]^T + epilogue) for the big products of the layer — r05, OPT-IN (EMO_GEMM_P256=1).
+// Replaces upstream F.linear of the FFN / projection GEMMs reached from stage2_accompaniment/model/fast_transformer_decoder.py:28-51.
+//
+// Built from the instruction-level comparison with the vendor's 256 x 256 x 64 kernel (profiles/r05_gemm_isa_diff.txt): same tile, same wave
+// count, same fragment-read and LDS-DMA counts per K — but the vendor's loop never puts more than two non-MFMA instructions into one MFMA gap and
+// spreads its LDS-DMA pieces over the whole tile, where gemm_w128_kernel issues 2 pieces + 3 reads + 6 scalar m0 operations in FRONT of every
+// group of eight MFMAs during one half of the tile, and pays prologue + epilogue once per tile (32 % of a block's life).  This kernel:
+//   * one workgroup per CU for the whole launch (grid = 256), walking its output tiles (column tiles of a row panel on one XCD); the operand
+//     stream does not stop at a tile boundary: slabs of the next tile are already in the ring when the epilogue of this one runs, so there is
+//     no prologue after the first tile;
+//   * v_mfma_f32_32x32x16_bf16 (32 cycles per issue, 5 hidden issue slots per gap; a wave owns a 128 x 128 quadrant = 16 accumulator tiles
+//     = 256 accumulation registers), operands swapped (D = Bfrag Afrag^T) and the B rows permuted inside a 32-column block so that a lane owns
+//     16 CONSECUTIVE output columns of one row per accumulator tile: 2 x 16-B stores / residual loads straight from the registers;
+//   * K in 32-deep slabs (16 KB per operand), ring of 5 + 5 slabs = 160 KB: every slab is requested five slabs (~5000 cycles) ahead for BOTH
+//     operands; a slab = 2 k-steps of 16 MFMAs; per k-step 8 ds_read_b128 (fragments of the next k-step, two per gap in gaps 0/2/4/6) and
+//     4 LDS-DMA pieces of 1 KB (gaps 3/7/11/15: one piece per 128 cycles per wave), m0 updates in the odd gaps between; ONE barrier per slab;
+//   * LDS image of a slab: [256 rows][4 chunks of 16 B], chunk ^= (row >> 2) & 3: conflict-free for ds_read_b128's lane groups both for the A
+//     rows (lane & 31) and for the permuted B rows; the swizzle is applied on the DMA source side (a lane fetches the chunk its LDS slot wants);
+//   * the whole K loop is inline asm in program order (MFMA, ds_read, buffer_load ... lds, s_waitcnt): hipcc schedules nothing inside it.
+//     Counters by hand: every k-step ends with lgkmcnt(0) (fragments are complete at every point where the compiler could touch their
+//     registers), the slab sync waits with a counted vmcnt (24 newer pieces may be in flight); the epilogue's loads / stores are the compiler's;
+//     the first slab behind an epilogue waits for everything but the four newest pieces (stores retire out of order with respect to loads).
+// Measured (profiles/r05_gemm_isa_diff.txt): slab syncs 4-7 % of the K loop (the five-slab lead hides HBM), k-steps 1240 cycles per slab with the
+// A rows in L2 and 1300-1330 from HBM against the MFMA bound of 1024: what is left is the ISSUE of the LDS-DMA pieces (18-29 cycles each: one
+// address unit per CU, four waves arriving in the same gap).  With A out of L2 the kernel runs at 0.50 (FFN2 forward) - 0.60 (plain) of the
+// MFMA peak, 5-10 % ahead of gemm_w128_kernel; with A from HBM it is on par in isolation and BEHIND inside the training step (47.4 vs 45.9 ms):
+// the 256 CUs walk their four tiles in lock step, so every tile round ends in a 32-MB store burst (+ 32 MB of residual loads) during which no
+// MFMA runs (22 k / 48 k cycles per tile against 84 k of K loop), where the tile-per-block launch drifts apart and overlaps epilogues with
+// other CUs' K loops.  What would have to change for the persistent walk to win: CUs out of phase without idle time (a stream-K split of each
+// CU's first tile costs 128 MB of fp32 partials per launch on a product that is already bound by its HBM stream), or output tiles staged in
+// registers and stored during the next tile's K loop (needs 128 more VGPRs per wave than the 256-register accumulator leaves).
+#include "emo_gemm_epi.h"
+
+namespace {
+constexpr int P_BM = 256, P_BN = 256, P_BK = 32;
+constexpr int P_SLAB = 256 * P_BK * 2;                       // one operand slab: 16 KB
+constexpr int P_NS = 5;                                       // slabs per operand in the ring
+constexpr int P_LDS = 2 * P_NS * P_SLAB;                      // 160 KB
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+__device__ __forceinline__ uint32_t p_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
+__device__ __forceinline__ void p_mma(f32x16& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// first k-step of a tile: C = 0 (no zeroing pass).  Declared read-write like p_mma although it only writes: both arms of the branch around
+// it then have the same data flow, and the accumulators stay pinned (as an output-only operand the two arms meet in 16 phi nodes that hipcc
+// resolves with copies — and, out of accumulation registers, with scratch spills inside the K loop)
+__device__ __forceinline__ void p_mma0(f32x16& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "+a"(c) : "v"(a), "v"(b));
+}
+template <int OFF> __device__ __forceinline__ void p_rd(bf16x8& f, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void p_m0_set(uint32_t v) { asm volatile("s_mov_b32 m0, %0" ::"s"(v)); }
+__device__ __forceinline__ void p_m0_add() { asm volatile("s_add_u32 m0, m0, 0x400" ::: "scc"); }
+// one LDS-DMA piece: 64 lanes x 16 B from (descriptor base + soff + per-lane voff) to LDS m0 + 16 lane
+__device__ __forceinline__ void p_dma(uint32_t voff, i32x4 rs, uint32_t soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rs), "s"(soff));
+}
+template <int N> __device__ __forceinline__ void p_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N)); }
+__device__ __forceinline__ void p_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)"); }
+__device__ __forceinline__ void p_barrier() { asm volatile("s_barrier"); }
+
+// dropout multipliers of 8 consecutive elements whose linear index is a multiple of 8: two hashes, bit-identical to drop_mult()
+__device__ __forceinline__ void p_drop8(const DropCtx& d, uint64_t idx0, float* v) {
+    const uint32_t lo = (uint32_t)(idx0 >> 2), hi = (uint32_t)(idx0 >> 34) * 0x9E3779B1u;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t h = emo_drop_hash(d, (lo + q) ^ hi), h2 = emo_xs32(h);
+        v[4 * q] *= (h & 0xFFFFu) >= d.thr16 ? d.scale : 0.f;
+        v[4 * q + 1] *= (h >> 16) >= d.thr16 ? d.scale : 0.f;
+        v[4 * q + 2] *= (h2 & 0xFFFFu) >= d.thr16 ? d.scale : 0.f;
+        v[4 * q + 3] *= (h2 >> 16) >= d.thr16 ? d.scale : 0.f;
+    }
+}
+
+// One k-step: 16 MFMAs on fragment set CUR (= KS), the 8 fragment reads of the next k-step into set CUR ^ 1 from (rdA, rdB), and one group of
+// four LDS-DMA pieces (voff, rs, soff[0..3]) to LDS address m0dst .. + 4 KB.  At most two fillers per MFMA gap; ends with lgkmcnt(0).
+template <bool INIT, int KS, bool READ = true, int SCHED = 0>
+__device__ __forceinline__ void p_kstep(f32x16 (&acc)[4][4], bf16x8 (&fa)[2][4], bf16x8 (&fb)[2][4], uint32_t rdA, uint32_t rdB, uint32_t voff, i32x4 rs,
+                                        const uint32_t (&soff)[4], uint32_t m0dst, int wave) {
+    constexpr int CUR = KS, NXT = KS ^ 1;
+    // SCHED (experiments, EMO_P256_SCHED): 0 = reads in gaps 0/2/4/6, pieces in 3/7/11/15; 1 = reads in gaps 0-3, pieces in 7/10/13/15;
+    // 2 = no pieces (wrong results: timing only); 3 = neither reads nor pieces; 4 = pieces only
+    // 5 = pieces without the m0 updates between them (timing only); 6 = plain buffer loads to registers instead of LDS-DMA (timing only);
+    // 7 = the four pieces back to back in the last gap
+    constexpr bool RD = READ && SCHED != 3 && SCHED != 4, DM = SCHED != 2 && SCHED != 3;
+#define P_MMA(i, j)                                              \
+    do {                                                         \
+        if (INIT) p_mma0(acc[i][j], fb[CUR][j], fa[CUR][i]);     \
+        else p_mma(acc[i][j], fb[CUR][j], fa[CUR][i]);           \
+    } while (0)
+#define P_RB01 if (RD) { p_rd<0>(fb[NXT][0], rdB); p_rd<2048>(fb[NXT][1], rdB); }
+#define P_RB23 if (RD) { p_rd<4096>(fb[NXT][2], rdB); p_rd<6144>(fb[NXT][3], rdB); }
+#define P_RA01 if (RD) { p_rd<0>(fa[NXT][0], rdA); p_rd<2048>(fa[NXT][1], rdA); }
+#define P_RA23 if (RD) { p_rd<4096>(fa[NXT][2], rdA); p_rd<6144>(fa[NXT][3], rdA); }
+#define P_M0S if (DM && SCHED != 6) p_m0_set(m0dst)
+#define P_M0A if (DM && SCHED != 5 && SCHED != 6) p_m0_add()
+#define P_DMA(p) if (DM) { if (SCHED == 6) { u32x4 t_; asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(t_) : "v"(voff), "s"(rs), "s"(soff[p])); } else p_dma(voff, rs, soff[p]); }
+    // 8 = the four waves request in DIFFERENT gaps (wave w: gaps w, 4 + w, 8 + w, 12 + w): the CU has one address unit, 16 cycles per piece; four
+    // waves that hit it in the same gap wait for each other (measured: 18-29 cycles per piece per wave)
+#define P_GAP(G) asm volatile("s_cmp_eq_u32 %0, %5\n\ts_cbranch_scc0 1f\n\ts_add_u32 m0, %1, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n1:" \
+                              ::"s"(wave), "s"(m0dst), "v"(voff), "s"(rs), "s"(soff[(G) >> 2]), "n"((G) & 3), "n"(((G) >> 2) * 0x400) : "scc")
+    if (SCHED == 8) {
+        P_MMA(0, 0); P_RB01; P_GAP(0);
+        P_MMA(0, 1); P_GAP(1);
+        P_MMA(0, 2); P_RB23; P_GAP(2);
+        P_MMA(0, 3); P_GAP(3);
+        P_MMA(1, 0); P_RA01; P_GAP(4);
+        P_MMA(1, 1); P_GAP(5);
+        P_MMA(1, 2); P_RA23; P_GAP(6);
+        P_MMA(1, 3); P_GAP(7);
+        P_MMA(2, 0); P_GAP(8);
+        P_MMA(2, 1); P_GAP(9);
+        P_MMA(2, 2); P_GAP(10);
+        P_MMA(2, 3); P_GAP(11);
+        P_MMA(3, 0); P_GAP(12);
+        P_MMA(3, 1); P_GAP(13);
+        P_MMA(3, 2); P_GAP(14);
+        P_MMA(3, 3); P_GAP(15);
+    } else if (SCHED == 7) {
+        P_MMA(0, 0); P_RB01;
+        P_MMA(0, 1);
+        P_MMA(0, 2); P_RB23;
+        P_MMA(0, 3);
+        P_MMA(1, 0); P_RA01;
+        P_MMA(1, 1);
+        P_MMA(1, 2); P_RA23;
+        P_MMA(1, 3);
+        P_MMA(2, 0);
+        P_MMA(2, 1);
+        P_MMA(2, 2);
+        P_MMA(2, 3);
+        P_MMA(3, 0);
+        P_MMA(3, 1);
+        P_MMA(3, 2); P_M0S;
+        P_MMA(3, 3); P_DMA(0); P_M0A; asm volatile("s_nop 0"); P_DMA(1); P_M0A; asm volatile("s_nop 0"); P_DMA(2); P_M0A; asm volatile("s_nop 0"); P_DMA(3);
+    } else if (SCHED == 1) {
+        P_MMA(0, 0); P_RB01;
+        P_MMA(0, 1); P_RB23;
+        P_MMA(0, 2); P_RA01;
+        P_MMA(0, 3); P_RA23;
+        P_MMA(1, 0);
+        P_MMA(1, 1); P_M0S;
+        P_MMA(1, 2);
+        P_MMA(1, 3); P_DMA(0);
+        P_MMA(2, 0); P_M0A;
+        P_MMA(2, 1);
+        P_MMA(2, 2); P_DMA(1);
+        P_MMA(2, 3); P_M0A;
+        P_MMA(3, 0);
+        P_MMA(3, 1); P_DMA(2);
+        P_MMA(3, 2); P_M0A;
+        P_MMA(3, 3); P_DMA(3);
+    } else {
+        P_MMA(0, 0); P_RB01;
+        P_MMA(0, 1); P_M0S;
+        P_MMA(0, 2); P_RB23;
+        P_MMA(0, 3); P_DMA(0);
+        P_MMA(1, 0); P_RA01;
+        P_MMA(1, 1); P_M0A;
+        P_MMA(1, 2); P_RA23;
+        P_MMA(1, 3); P_DMA(1);
+        P_MMA(2, 0);
+        P_MMA(2, 1); P_M0A;
+        P_MMA(2, 2);
+        P_MMA(2, 3); P_DMA(2);
+        P_MMA(3, 0);
+        P_MMA(3, 1); P_M0A;
+        P_MMA(3, 2);
+        P_MMA(3, 3); P_DMA(3);
+    }
+#undef P_GAP
+#undef P_MMA
+#undef P_RB01
+#undef P_RB23
+#undef P_RA01
+#undef P_RA23
+#undef P_M0S
+#undef P_M0A
+#undef P_DMA
+    if (READ) p_lgkm0();
+}
+// the eight fragments of a slab's first k-step (the stream's start, and behind every epilogue: nothing of the K loop is live across one)
+__device__ __forceinline__ void p_read_set0(bf16x8 (&fa)[2][4], bf16x8 (&fb)[2][4], uint32_t rdA, uint32_t rdB) {
+    p_rd<0>(fb[0][0], rdB); p_rd<2048>(fb[0][1], rdB); p_rd<4096>(fb[0][2], rdB); p_rd<6144>(fb[0][3], rdB);
+    p_rd<0>(fa[0][0], rdA); p_rd<2048>(fa[0][1], rdA); p_rd<4096>(fa[0][2], rdA); p_rd<6144>(fa[0][3], rdA);
+    p_lgkm0();
+}
+
+// source side of one operand's slab stream: buffer descriptor of the slab to request next + where that slab is in the block's tile walk
+struct PStream {
+    i32x4 rs;          // descriptor: base = first row of the tile, current k
+    int it, k;         // tile iteration of the block, slab inside the tile
+};
+
+template <typename OutT, int SCHED>
+__global__ __launch_bounds__(256, 1) void gemm_p256_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                          OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, EpiParams ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef EMO_DIAG
+    const uint64_t dg_t0 = __builtin_readcyclecounter();
+    uint64_t dg_sync = 0, dg_epi = 0, dg_pro = 0;
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = (int)(N / P_BN), tiles_m = (int)(M / P_BM), nk = (int)(K / P_BK);
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3, nslot = (int)(gridDim.x >> 3);
+    // tile walk of this block: iteration it -> local = slot + nslot * it; tn = local % tiles_n, tm = (local / tiles_n) * 8 + xcd
+    // (the column tiles of a row panel run side by side on ONE XCD: the panel comes from HBM once into that L2)
+    const int panels = tiles_m > xcd ? (tiles_m - xcd + 7) / 8 : 0;               // row panels of this XCD
+    const int n_local = panels * tiles_n;
+    const int n_mine = n_local > slot ? (n_local - slot + nslot - 1) / nslot : 0;
+    if (n_mine == 0) return;
+    const int S = n_mine * nk;                                                    // slabs of this block's stream
+
+    // ---- per-lane constants
+    // DMA piece = 16 rows x 64 B; lane L -> row L / 4, LDS chunk L % 4, which holds global chunk (L % 4) ^ ((row >> 2) & 3) = (L % 4) ^ ((L >> 4) & 3)
+    const uint32_t voffA = (uint32_t)(((lane >> 2) * lda + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2);
+    const uint32_t voffB = (uint32_t)(((lane >> 2) * ldb + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2);
+    uint32_t soffA[4], soffB[4];                                                  // this wave's four pieces of a slab: rows 16 (4 wave + p) ..
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        soffA[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(16 * (4 * wave + p) * lda * 2));
+        soffB[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(16 * (4 * wave + p) * ldb * 2));
+    }
+    const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p_lds_addr(smem));
+    const uint32_t dstA0 = lds0 + wave * 4096, dstB0 = lds0 + P_NS * P_SLAB + wave * 4096;   // + ring slot * P_SLAB
+    // fragment reads (k-step 0; k-step 1 = ^ 32): A rows wr 128 + 32 i + (lane & 31), chunk (lane >> 5) ^ ((lane >> 2) & 3);
+    // B rows wc 128 + 32 j + pi(lane & 31), pi(m) = 16 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3), chunk (lane >> 5) ^ ((lane >> 3) & 3)
+    const int ml = lane & 31;
+    const int pi = 16 * ((ml >> 2) & 1) + 4 * (ml >> 3) + (ml & 3);
+    const uint32_t foA = lds0 + (uint32_t)(wr * 8192 + ml * 64 + ((((lane >> 5) ^ ((lane >> 2) & 3))) << 4));
+    const uint32_t foB = lds0 + (uint32_t)(P_NS * P_SLAB + wc * 8192 + pi * 64 + ((((lane >> 5) ^ ((lane >> 3) & 3))) << 4));
+
+    // ---- the two request streams
+    auto set_tile = [&](PStream& s, const bf16_t* base, int64_t ld, bool is_a) {
+        const int local = slot + nslot * s.it;
+        const int tn = local % tiles_n, tm = (local / tiles_n) * 8 + xcd;
+        const uint64_t p = (uint64_t)(uintptr_t)(base + (int64_t)(is_a ? tm : tn) * 256 * ld);
+        s.rs[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)p);
+        s.rs[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(p >> 32));      // stride 0 (raw buffer)
+        s.rs[2] = 0x7FFFFFFE;                                                     // num_records: the launcher checked the shapes
+        s.rs[3] = 0x00020000;                                                     // DATA_FORMAT = 32 (raw dword buffer, gfx9 encoding)
+    };
+    PStream sA, sB;
+    sA.it = sA.k = sB.it = sB.k = 0;
+    set_tile(sA, A, lda, true);
+    set_tile(sB, B, ldb, false);
+    // next slab of a stream.  Past the block's last tile the walk stays on that tile (its first slabs are requested again: valid addresses,
+    // constant counts; nobody reads them)
+    auto advance = [&](PStream& s, const bf16_t* base, int64_t ld, bool is_a) {
+        if (__builtin_expect(++s.k == nk, 0)) {
+            s.k = 0;
+            s.it = s.it + 1 < n_mine ? s.it + 1 : n_mine - 1;
+            set_tile(s, base, ld, is_a);
+        } else {
+            const uint64_t b = (((uint64_t)(uint32_t)s.rs[1] << 32) | (uint32_t)s.rs[0]) + P_BK * 2;      // (stride bits of word 1 are 0)
+            s.rs[0] = (int)(uint32_t)b;
+            s.rs[1] = (int)(uint32_t)(b >> 32);
+        }
+    };
+    int isA = 0, isB = 0;                                                         // ring slots of the next A / B slab to request
+    auto issue_group_plain = [&](uint32_t voff, const PStream& s, const uint32_t (&so)[4], uint32_t dst) {
+        p_m0_set(dst);
+        asm volatile("s_nop 0");
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            p_dma(voff, s.rs, so[p]);
+            if (p < 3) { p_m0_add(); asm volatile("s_nop 0"); }
+        }
+    };
+    // ---- prologue: A0 B0 A1 B1 A2 B2 A3 B3 A4 (B4 is the first k-step's group)
+#pragma unroll 1
+    for (int s = 0; s < 9; ++s) {
+        if ((s & 1) == 0) { issue_group_plain(voffA, sA, soffA, dstA0 + isA * P_SLAB); advance(sA, A, lda, true); isA = isA == P_NS - 1 ? 0 : isA + 1; }
+        else { issue_group_plain(voffB, sB, soffB, dstB0 + isB * P_SLAB); advance(sB, B, ldb, false); isB = isB == P_NS - 1 ? 0 : isB + 1; }
+    }
+    f32x16 acc[4][4];
+    bf16x8 fa[2][4], fb[2][4];
+    p_vmwait<28>();                                                               // A0, B0 landed
+    p_barrier();
+    p_read_set0(fa, fb, foA, foB);
+#ifdef EMO_DIAG
+    dg_pro = __builtin_readcyclecounter() - dg_t0;
+#endif
+    int sc = 0;                                                                   // ring slot of the slab being multiplied
+    const int skew = wave * ep.nt_store;                                          // (experiment) wave w runs w * nt_store short loop turns behind after every barrier
+    // One slab = k-step 0 (+ the B request four slabs ahead), the slab sync, k-step 1 (+ the A request five slabs ahead).  The sync lets the 24
+    // newest pieces stay in flight — except in the first slab behind an epilogue: stores retire out of order with respect to loads, so there
+    // everything but the four pieces requested since the stores is waited for (the slabs in question were requested before the epilogue and have
+    // long landed; what is really waited for is the acknowledgement of the last output stores); from then on only loads are in flight again.  FIRST: the tile's
+    // first slab (accumulators start from 0); LAST: its last one (no fragment reads across the epilogue).  The three instances sit in
+    // straight-line order inside the tile loop — first, loop over the middle slabs, last — so that every accumulator is one chain of tied asm
+    // operands without control-flow joins between different instances (hipcc resolves such joins with copies, i.e. here with scratch spills).
+#ifdef EMO_DIAG
+#define P_DG_T(x) const uint64_t x = __builtin_readcyclecounter()
+#define P_DG_ADD(acc_, x) acc_ += __builtin_readcyclecounter() - x
+#else
+#define P_DG_T(x)
+#define P_DG_ADD(acc_, x)
+#endif
+#define P_SLAB_BODY(FIRST, LAST)                                                                                                       \
+    do {                                                                                                                               \
+        {                                                                                                                              \
+            const uint32_t rdA = (foA + sc * P_SLAB) ^ 32u, rdB = (foB + sc * P_SLAB) ^ 32u;                                           \
+            p_kstep<FIRST, 0, true, SCHED>(acc, fa, fb, rdA, rdB, voffB, sB.rs, soffB, dstB0 + isB * P_SLAB, wave);                                 \
+            advance(sB, B, ldb, false);                                                                                            \
+            isB = isB == P_NS - 1 ? 0 : isB + 1;                                                                                       \
+        }                                                                                                                              \
+        P_DG_T(dg_s0);                                                                                                                 \
+        if ((FIRST) && itC > 0) p_vmwait<4>();                                                                                         \
+        else p_vmwait<24>();                                                                                                           \
+        p_barrier();                                                                                                                   \
+        for (int q_ = 0; q_ < skew; ++q_) asm volatile("s_nop 0");                                                                     \
+        P_DG_ADD(dg_sync, dg_s0);                                                                                                                   \
+        {                                                                                                                              \
+            const int sn = sc == P_NS - 1 ? 0 : sc + 1;                                                                                \
+            p_kstep<false, 1, !(LAST), SCHED>(acc, fa, fb, foA + sn * P_SLAB, foB + sn * P_SLAB, voffA, sA.rs, soffA, dstA0 + isA * P_SLAB, wave);  \
+            advance(sA, A, lda, true);                                                                                             \
+            isA = isA == P_NS - 1 ? 0 : isA + 1;                                                                                       \
+            sc = sn;                                                                                                                   \
+        }                                                                                                                              \
+    } while (0)
+#pragma unroll 1
+    for (int itC = 0; itC < n_mine; ++itC) {
+        P_SLAB_BODY(true, false);
+#pragma unroll 1
+        for (int kC = 2; kC < nk; ++kC) P_SLAB_BODY(false, false);
+        P_SLAB_BODY(false, true);
+        {
+            // ---- epilogue of tile itC straight from the accumulators (the next tile's first slabs are already in the ring)
+            P_DG_T(dg_e0);
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            const int local = slot + nslot * itC;
+            const int64_t n0 = (int64_t)(local % tiles_n) * P_BN, m0 = (int64_t)((local / tiles_n) * 8 + xcd) * P_BM;
+            const int h = lane >> 5;
+            const OutT* rp = (const OutT*)ep.residual;
+            // sixteen 32 x 32 accumulator tiles one after the other (a lane: 16 consecutive columns of one row), the residual of the next one
+            // requested before this one is converted; fences keep hipcc from interleaving the blocks (256 live values otherwise)
+            auto rload = [&](int b, bf16x8 (&r)[2]) {
+                const int64_t m = m0 + wr * 128 + 32 * (b >> 2) + ml, n = n0 + wc * 128 + 32 * (b & 3) + 16 * h;
+                r[0] = *(const bf16x8*)(rp + m * ep.ldc + n);
+                r[1] = *(const bf16x8*)(rp + m * ep.ldc + n + 8);
+            };
+            bf16x8 rcur[2], rnxt[2];
+            if (rp) rload(0, rcur);
+#pragma clang loop unroll(full)
+            for (int b = 0; b < 16; ++b) {
+                const int i = b >> 2, j = b & 3;
+                const int64_t m = m0 + wr * 128 + 32 * i + ml, n = n0 + wc * 128 + 32 * j + 16 * h;
+                if (rp && b < 15) rload(b + 1, rnxt);
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+                if (ep.bias) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 bq = *(const f32x4*)(ep.bias + n + 4 * q);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[4 * q + r] += bq[r];
+                    }
+                }
+                if (ep.drop.thr16) {
+                    p_drop8(ep.drop, (uint64_t)(m * N + n), v);
+                    p_drop8(ep.drop, (uint64_t)(m * N + n + 8), v + 8);
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[r] = (bf16_t)(rp ? v[8 * q + r] + (float)rcur[q][r] : v[8 * q + r]);
+                    *(bf16x8*)(C + m * ep.ldc + n + 8 * q) = o;
+                }
+                rcur[0] = rnxt[0];
+                rcur[1] = rnxt[1];
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("" ::: "memory");
+            if (itC + 1 < n_mine) p_read_set0(fa, fb, foA + sc * P_SLAB, foB + sc * P_SLAB);      // (sc already points at the next tile's first slab)
+            P_DG_ADD(dg_epi, dg_e0);
+        }
+    }
+#undef P_SLAB_BODY
+#ifdef EMO_DIAG
+    if (ep.rln_stats && !ep.rln_x && lane == 0) {                 // (diagnostics, tools/p256_cycles.py: the otherwise unused rln_stats pointer carries the counter buffer)
+        unsigned long long* dg = (unsigned long long*)ep.rln_stats;
+        atomicAdd(dg + 0, (unsigned long long)dg_pro);
+        atomicAdd(dg + 1, (unsigned long long)(__builtin_readcyclecounter() - dg_t0));
+        atomicAdd(dg + 2, (unsigned long long)dg_sync);
+        atomicAdd(dg + 3, (unsigned long long)dg_epi);
+        atomicAdd(dg + 4, 1ull);
+        atomicAdd(dg + 5, (unsigned long long)n_mine);
+    }
+#endif
+    p_vmwait<0>();
+}
+}  // namespace
+
+// NT bf16 product on the persistent 256 x 256 kernel; true when the shape is eligible and the launch was queued.
+// EMO_GEMM_P256: 1 = every eligible shape (tests, tools/bench_p256.py), 2 = long reductions with at least one tile per CU; unset / 0 = off
+// (r05: behind the tile-per-block kernel inside the training step, see the header and profiles/r05_gemm_isa_diff.txt).
+bool emo_gemm_p256_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int dtype_out, int64_t M, int64_t N, int64_t K,
+                       const EpiParams& ep, hipStream_t st) {
+    const char* e = getenv("EMO_GEMM_P256");                   // (read per call: tests toggle it in-process)
+    const int mode = e ? atoi(e) : 0;
+    if (mode <= 0) return false;
+    if ((M % P_BM) || (N % P_BN) || (K % P_BK) || K < 2 * P_BK || dtype_out != EMO_BF16) return false;
+    if (mode == 2 && (K < 1024 || (M / P_BM) * (N / P_BN) < 256)) return false;
+    if (ep.atomic || ep.accumulate || ep.ws_stride || ep.a_rowsum || ep.b_rowsum || ep.ln_c1 || ep.rln_x || ep.mask_out) return false;
+    if (ep.aux_out || ep.mul_mode != EMO_MUL_NONE || ep.act != EMO_ACT_NONE) return false;       // register epilogue: bias, dropout, residual
+    if ((lda & 7) || (ldb & 7) || (ep.ldc & 7) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return false;
+    if (ep.residual && ((uintptr_t)ep.residual & 15)) return false;
+    if (ep.bias && ((uintptr_t)ep.bias & 15)) return false;
+    if ((uint64_t)(256 * (lda > ldb ? lda : ldb) + 64) * 2 >= 0x7FFF0000ull) return false;
+    const int64_t tiles = (M / P_BM) * (N / P_BN);
+    int64_t nslot = (tiles + 7) / 8;
+    if (nslot > 32) nslot = 32;                                // one workgroup per CU
+    EpiParams ep2 = ep;
+    { const char* e3 = getenv("EMO_P256_SKEW"); ep2.nt_store = e3 ? atoi(e3) : 0; }
+    int sched = 0;
+    { const char* e4 = getenv("EMO_P256_SCHED"); if (e4) sched = atoi(e4); }
+#define P_LAUNCH(Sv)                                                                                                                   \
+    do {                                                                                                                               \
+        auto k = gemm_p256_kernel<bf16_t, Sv>;                                                                                         \
+        static bool attr = false;                                                                                                      \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS); attr = true; }     \
+        hipLaunchKernelGGL(k, dim3((unsigned)(8 * nslot)), dim3(256), P_LDS, st, A, lda, B, ldb, (bf16_t*)C, M, N, K, ep2);           \
+    } while (0)
+    switch (sched) { case 1: P_LAUNCH(1); break; case 2: P_LAUNCH(2); break; case 3: P_LAUNCH(3); break; case 4: P_LAUNCH(4); break; case 5: P_LAUNCH(5); break; case 6: P_LAUNCH(6); break; case 7: P_LAUNCH(7); break; case 8: P_LAUNCH(8); break; default: P_LAUNCH(0); }
+#undef P_LAUNCH
+    return true;
+}

@@ -1,8 +1,9 @@
 // 256 x 256 x 64 bf16 GEMM tile with ONE wave per SIMD: 4 waves, each owning a 128 x 128 quadrant (64 accumulator fragments = 256 registers,
 // which hipcc places in the accumulation VGPRs at this occupancy), for the long-K products of the layer (K >= 1024: FFN2 forward, QKV / FFN1
-// dgrad).  Why this shape: under load the package sits at its 1400 W limit and the shader clock is pulled down (tools/sustained_gemm.py), so
-// what a GEMM holds is set by the energy per flop, and the 128 x 128 tile with 64 x 64 wave quadrants spends twice the LDS-read bytes and
-// twice the L2 -> LDS bytes per flop of this one (0.031 / 0.0156 B per flop against 0.0156 / 0.0078).
+// dgrad).  Why this shape: the 128 x 128 tile with 64 x 64 wave quadrants spends twice the LDS-read bytes and twice the L2 -> LDS bytes per flop
+// of this one (0.031 / 0.0156 B per flop against 0.0156 / 0.0078).  (r03 gave the 1400-W package limit as the reason; r04 measured 2.18-2.43 GHz
+// per kernel class inside the training step, i.e. no cap there; r05: what couples these products to the clock is their HBM stream — the same
+// kernel runs at 2.10 GHz with the A rows in L2 and at 1.79 GHz with A from HBM, profiles/r05_gemm_isa_diff.txt.)
 //   * operands: K-contiguous rows (A [M,K]; B [N,K] = nn.Linear weights), LDS image [256 rows][8 x 16-B chunks], chunk ^= row & 7, filled by
 //     LDS-DMA issued as inline asm (SGPR base + 32-bit lane offset; behind the builtin hipcc answers later fragment reads with full waits);
 //     the B rows a fragment reads are permuted (as in the A-stationary kernel) so that a lane owns 8 CONSECUTIVE output columns per fragment
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w128_kernel(const bf16_t* __restr
                     bf16x8 o;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
-                    *(bf16x8*)(C + m * ep.ldc + n) = o;
+                    if (ep.nt_store) __builtin_nontemporal_store(o, (bf16x8*)(C + m * ep.ldc + n));
+                    else *(bf16x8*)(C + m * ep.ldc + n) = o;
                 }
             }
         }
@@ -459,6 +461,7 @@ bool emo_gemm_w128_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ld
     const int64_t tiles_m = M / W_BM, tiles_n = N / W_BN;
     dim3 grid((unsigned)(((tiles_m + 7) / 8) * 8 * tiles_n));
     EpiParams ep2 = ep;
+    { const char* e4 = getenv("EMO_W128_NT_STORE"); ep2.nt_store = e4 ? atoi(e4) : 0; }
     { const char* e3 = getenv("EMO_W128_A_NT"); ep2.a_nt = e3 ? atoi(e3) : 1; }     // default on (r03: -0.4 .. -0.55 ms/step; the wgrad kernel loses with it)
     auto k = gemm_w128_kernel<bf16_t>;
     static bool attr = false;

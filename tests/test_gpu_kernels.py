@@ -231,6 +231,39 @@ def test_gemm_256_tile_nt_matches_reference_and_128_tile(shape, monkeypatch):
             _close(y1, ref, torch.bfloat16, mult=1.0)
 
 
+@pytest.mark.parametrize('shape', [(512, 256, 320), (1024, 512, 2048), (2048, 768, 1024), (256, 1024, 4096), (8192, 512, 64), (2304, 256, 96), (131072, 512, 1536)])
+def test_gemm_persistent_256_tile_matches_reference(shape, monkeypatch):
+    # emo_gemm_p256.hip (r05, opt-in EMO_GEMM_P256=1): persistent tile walk, 32 x 32 x 16 MFMA, 32-deep slabs in a 5 + 5 ring.  Shapes cover
+    # one tile per block (no walk), fewer blocks than CUs, several tiles per block with the operand stream crossing tile boundaries (2304 x 256 =
+    # 9 tiles on 8 blocks; the last shape = the QKV dgrad of the benchmark: 4 tiles per CU), K = 64 (first slab is also the last), every
+    # epilogue it takes; deterministic; the dropout mask is the one every other kernel applies.
+    ops = _ops()
+    monkeypatch.setenv('EMO_GEMM_EPI_SPLIT', '0')
+    M, N, K = shape
+    A, W = _r(M, K, seed=1).to(torch.bfloat16).cuda(), _r(N, K, seed=2, scale=0.1).to(torch.bfloat16).cuda()
+    bias, res = _r(N, seed=3).cuda(), _r(M, N, seed=4).to(torch.bfloat16).cuda()
+    for kw in ({}, dict(bias=bias), dict(residual=res), dict(bias=bias, p_drop=0.1, seed=5, offset=7, residual=res)):
+        monkeypatch.setenv('EMO_GEMM_P256', '1')
+        y1 = ops.gemm(A, W, **kw)
+        assert ops.lib.emo_gemm_last_kernel() == 8
+        y2 = ops.gemm(A, W, **kw)
+        monkeypatch.setenv('EMO_GEMM_P256', '0')
+        y0 = ops.gemm(A, W, **kw)
+        assert ops.lib.emo_gemm_last_kernel() != 8
+        assert torch.equal(y1, y2), kw.keys()
+        if 'p_drop' not in kw:
+            rows = slice(0, M) if M <= 8192 else slice(M - 4096, M)
+            ref = A[rows].double() @ W.double().T + (bias.double() if 'bias' in kw else 0.0) + (res[rows].double() if 'residual' in kw else 0.0)
+            _close(y1[rows], ref, torch.bfloat16, mult=1.0)
+        # same products, another summation order inside a dot product: equal up to one bf16 rounding of the output; a dropped element is dropped in both
+        assert float((y1.float() - y0.float()).abs().max()) <= 0.02 * float(y0.float().abs().max())
+        if 'p_drop' in kw:
+            base = ops.gemm(A, W, bias=bias).float()
+            kept = (y1.float() - res.float()).abs() > 1e-6 * (1 + base.abs())
+            kept0 = (y0.float() - res.float()).abs() > 1e-6 * (1 + base.abs())
+            assert float((kept != kept0).float().mean()) < 1e-3
+
+
 @pytest.mark.parametrize('shape', [(8192, 2048, 512), (16384, 512, 2048), (8192, 1536, 512)])
 def test_gemm_256_tile_wgrad_matches_reference_with_bias_gradient(shape, monkeypatch):
     # the wgrad instance of the same tile: token-major operands, split-K through the workspace, bias gradient by ones-MFMAs; with and
