@@ -290,6 +290,39 @@ def generation_bench(model, n_streams=32, prompt=64, n_new=2048 - 64, top_p=0.9,
             'ms_per_token_step': round(1000 * dt / n_new, 3), 'single_stream_ms_per_token': round(single_ms, 3), 'engine': 'FAVOR+ recurrent state in HBM; token step = ONE persistent launch (emo_performer_decode_step_sampled: nucleus draw + embedding + 12 layers + logits), hipGraph replay'}
 
 
+def gpt2_generation_bench(n_streams=32, prompt=64, n_new=2048 - 64, top_p=0.9, temp=1.1):
+    """BASELINE configs[3] names a KV cache: the same 32 x 2048 nucleus generation on the GPT-2 backbone (d512 / L12 / H8) — KV cache
+    [n, 2048, 512] x 2 per layer in HBM (bf16), token step = hipGraph-replayed chain of launches (skinny GEMMs with the LayerNorms folded in,
+    sattn_decode over the cache, nucleus sampler).  Roofline: HBM bytes a token step must move = the bf16 weights once + every stream's keys and
+    values of all layers at the step's context length (12 x 2 x ctx x 512 x 2 B), averaged over the generated positions."""
+    import contextlib
+    from emo_disentanger_amd import inference as inf
+    from emo_disentanger_amd.model.music_gpt2 import MusicGPT2
+    with contextlib.redirect_stdout(sys.stderr):
+        m = MusicGPT2(CFG['n_token'], 12, 8, 512, 2048, 512, use_segment_emb=True, n_segment_types=2, dropout=0.1, compute_dtype='bf16').cuda().eval()
+    g = torch.Generator().manual_seed(7)
+    ptok = torch.randint(0, CFG['n_token'] - 1, (n_streams, prompt), generator=g).cuda()
+    pseg = torch.ones(n_streams, prompt, dtype=torch.long, device='cuda')
+    inf.generate_streams(m, ptok, pseg, 8, temp=temp, top_p=top_p, seed=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = inf.generate_streams(m, ptok, pseg, n_new, temp=temp, top_p=top_p, seed=2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert out.shape == (n_streams, prompt + n_new) and int(out.max()) < CFG['n_token']
+    wbytes = 2 * sum(p.numel() for n_, p in m.named_parameters() if p.dim() == 2 and 'emb' not in n_)      # bf16 matrices read by a step
+    ctx = prompt + (n_new + 1) / 2.0                                                                       # mean context length of a generated token
+    kv = n_streams * 12 * 2 * ctx * 512 * 2
+    step_s = dt / n_new
+    ach = (wbytes + kv) / step_s / 1e9
+    return {'metric': 'AR gen tokens/sec, stage2 GPT-2 d512 L12, %d streams, nucleus p=%.2f, KV cache in HBM' % (n_streams, top_p),
+            'value': round(n_streams * n_new / dt, 1), 'unit': 'tokens/s', 'streams': n_streams, 'prompt': prompt, 'new_tokens': n_new,
+            'ms_per_token_step': round(1000 * step_s, 3),
+            'roofline': {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4),
+                         'algorithmic_bytes_per_step': int(wbytes + kv), 'note': 'weights %.1f MB + KV cache %.1f MB at the mean context of %d tokens' % (wbytes / 1e6, kv / 1e6, ctx)},
+            'engine': 'KV cache [n, 2048, 512] x 2 x 12 layers (bf16) in HBM; token step = hipGraph replay of the launch chain (skinny GEMMs with folded LayerNorms, sattn_decode, nucleus sampler)'}
+
+
 def stage1_bench(n_steps=30, B=4, T=512, V=200):
     """Secondary line, BASELINE configs[4] (single GPU): the stage-1 lead-sheet LM (Transformer-XL decoder, emopia_finetune.yaml shape:
     d512 / L12 / H8 / d_ff 2048, tgt_len 512, batch 4), bf16, dropout 0.1, fwd + bwd + clip + fused Adam on synthetic tokens."""
@@ -645,6 +678,9 @@ def main():
             del model, opt                                   # (the Performer's 21 GB of saved activations are not needed any more)
             torch.cuda.empty_cache()
             out['gpt2'] = gpt2_bench()
+            if not args.no_gen:
+                torch.cuda.empty_cache()
+                out['gen_gpt2'] = gpt2_generation_bench()
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(min(T, 2048))
         print(json.dumps(out), flush=True)

@@ -50,6 +50,7 @@ _SIG = {
     'emo_favor_attn_bwd_kstate': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_l, c_f, c_p, c_l, c_i, c_p]),
     'emo_favor_decode_step': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_f, c_p]),
     'emo_performer_decode_step_workspace_bytes': (c_l, []),
+    'emo_performer_decode_step_supported': (c_i, []),
     'emo_performer_decode_step': (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_f, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_l, c_p, c_l, c_f, c_f, c_p, c_p]),
     'emo_performer_decode_step_sampled': (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_f, c_l, c_p, c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_l, c_l, c_p, c_l, c_f, c_f,
                                                 c_f, c_f, c_p, c_p, c_p, c_l, c_l, c_p, c_p]),

@@ -801,6 +801,24 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
 
 extern "C" int64_t emo_performer_decode_step_workspace_bytes(void) { return (int64_t)PD_WS_WORDS * 8; }
 
+// The launch is PD_NG * PD_GM = 256 workgroups that spin-wait on each other: all of them must be resident at once, one per CU.  Checked once per
+// process: the 96-KB dynamic LDS attribute could be set, the device has at least 256 CUs (partition modes / CU masks have fewer), and the
+// occupancy query grants the kernel a workgroup per CU.  (Another process holding CUs cannot be seen from here: that case is the 50-ms give-up
+// code in the workspace, emo_performer_decode_step's documented failure mode.)
+static int pd_supported() {
+    static int cached = -1;
+    if (cached >= 0) return cached;
+    const size_t lds = 96 * 1024;
+    int dev = 0, cus = 0, per_cu = 0;
+    bool ok = hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= PD_NG * PD_GM;
+    ok = ok && hipFuncSetAttribute((const void*)pd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)pd_step_kernel, PD_NT, lds) == hipSuccess && per_cu >= 1;
+    (void)hipGetLastError();
+    cached = ok ? 1 : 0;
+    return cached;
+}
+extern "C" int emo_performer_decode_step_supported(void) { return pd_supported(); }
+
 static int pd_launch(const void* layer_table, int64_t n_layers, const int64_t* tok, const int64_t* seg, const float* E, const float* Sg, const float* pe,
                      float emb_scale, int64_t pos0, const int64_t* pos_ids, const void* wout_packed, const float* bout, int64_t n_token, float* logits,
                      int64_t n_streams, int64_t d_model, int64_t n_head, int64_t n_feat, int64_t d_ff, void* sync_ws, int64_t sync_ws_bytes, float eps,
@@ -831,8 +849,8 @@ static int pd_launch(const void* layer_table, int64_t n_layers, const int64_t* t
     { const char* e = getenv("EMO_PD_NT"); a.flags = e ? (atoi(e) & 3) : 0; }
     static_assert(LDS_TOTAL <= 96 * 1024, "LDS carve");
     const size_t lds = 96 * 1024;                                         // > half of the CU's LDS: one workgroup per CU
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)pd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    EMO_CHECK(pd_supported(), "emo_performer_decode_step: this device / partition cannot hold the launch's %d workgroups at once (needs >= %d CUs with 96 KB "
+              "of LDS each): use the chain of launches", PD_NG * PD_GM, PD_NG * PD_GM);
     hipLaunchKernelGGL(pd_step_kernel, dim3(PD_NG * PD_GM), dim3(PD_NT), lds, (hipStream_t)stream, a);
     EMO_LAUNCH_CHECK();
     return EMO_OK;

@@ -45,17 +45,29 @@ def _init_rccl(rank, world):
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)                         # control plane (gloo, host memory)
     if int(ok) == 0:
         raise RuntimeError('RCCL could not be bound on every rank (rank %d: %s)' % (rank, 'ok' if bound else lib.emo_last_error().decode()))
-    msg = torch.zeros(128, dtype=torch.uint8)
-    if rank == 0:
-        buf = (ctypes.c_char * 128)()
-        if lib.emo_comm_unique_id(buf) == 0:
-            msg[:] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
-        # (a failed draw ships zeros: ncclCommInitRank then fails on every rank and step (3) reports it)
-    dist.broadcast(msg, src=0)
-    err = None
+    # local steps that can fail on ONE rank (the device touch) happen BEFORE the collective init and are agreed on, and the id travels with a status
+    # byte: a rank never enters ncclCommInitRank alone, and a failed draw is not left to RCCL's handling of an all-zero bootstrap address
+    local_err = None
     try:
         torch.empty(1, device='cuda')                                 # the HIP context of this thread is on the rank's device before RCCL binds it
         torch.cuda.synchronize()
+    except Exception as e:   # noqa: BLE001 — reported after the agreement below
+        local_err = e
+    msg = torch.zeros(129, dtype=torch.uint8)                         # [0:128] = the id, [128] = 1 when rank 0 could draw it
+    if rank == 0:
+        buf = (ctypes.c_char * 128)()
+        if lib.emo_comm_unique_id(buf) == 0:
+            msg[:128] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+            msg[128] = 1
+    dist.broadcast(msg, src=0)
+    ok = torch.tensor([1 if (local_err is None and int(msg[128]) == 1) else 0])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok) == 0:
+        raise RuntimeError('RCCL plane not started (rank %d: %s)' % (rank, local_err if local_err is not None else
+                                                                     ('rank 0 could not draw the unique id' if int(msg[128]) == 0 else 'ok here, failed on another rank')))
+    msg = msg[:128]
+    err = None
+    try:
         check(lib.emo_comm_init(ctypes.c_char_p(bytes(msg.numpy().tobytes())), rank, world))
         probe = torch.full((4,), rank + 1, device='cuda', dtype=torch.int64)
         check(lib.emo_comm_allreduce(probe.data_ptr(), 4, I64, torch.cuda.current_stream().cuda_stream))

@@ -75,7 +75,9 @@ class PerformerDecodeEngine(_EngineBase):
     """FAVOR+ recurrent state per layer: S [n,H,F,dh], z [n,H,F] fp32 (6.4 MB / stream at the perf config).
     omega is fixed for the lifetime of the engine (the state is only meaningful under one feature map)."""
 
-    def __init__(self, model, n_streams, redraw=True):
+    def __init__(self, model, n_streams, redraw=True, persistent=True):
+        """persistent=False keeps the chain of launches (callers that run several engines side by side on different streams, and the fall-back of
+        the reference loop when a one-launch step gave up)."""
         super().__init__(model, n_streams)
         if redraw and model.redraw != 'fixed':
             model.draw_feature_maps()
@@ -94,7 +96,10 @@ class PerformerDecodeEngine(_EngineBase):
         nf = 2 * self.omegas[0].shape[1]
         self.n_pad = (n_streams + 3) // 4 * 4
         if (self.dt == torch.bfloat16 and 1 <= n_streams <= 32 and model.d_model == 512 and model.n_head == 8 and nf == 128
-                and ff == 2048 and model.n_layer <= 15 and model.n_token <= 512 and os.environ.get('EMO_DECODE_PERSISTENT', '1') != '0'):
+                and ff == 2048 and model.n_layer <= 15 and model.n_token <= 512 and persistent and os.environ.get('EMO_DECODE_PERSISTENT', '1') != '0'
+                and ops.lib.emo_performer_decode_step_supported() == 1):
+            # (emo_performer_decode_step_supported: the launch's 256 workgroups spin-wait on each other and must all be resident — >= 256 CUs,
+            # 96 KB LDS each, one per CU by the occupancy query; partitions / CU masks with fewer keep the chain of launches)
             self._prepare_persist()
 
     # ------------------------------------------------------------------------------------------ one-launch step
@@ -156,12 +161,16 @@ class PerformerDecodeEngine(_EngineBase):
         return pp['table']
 
     def _step_persistent(self, tok, seg, dev_pos, logits_out):
+        """Returns `logits_out` when given, else the engine's STATIC logits buffer (or a view of its first n rows): the next step overwrites it —
+        callers that keep logits across steps clone them (the chain of launches returns a fresh tensor; hipGraph capture needs the static one)."""
         m, pp = self.model, self.persist
         if self._tables is None:
             self._tables = (engine.embedding_table(self.ps, 'token_emb.'), engine.embedding_table(self.ps, 'segemb.') if m.use_segment_emb else None)
         E, Sg = self._tables
         seg = seg if (Sg is not None and seg is not None) else None
         pe = m.pe.pe if m.use_pe else m._zero_pe(self.max_len, m.d_model)
+        if not dev_pos and self.pos >= pe.shape[0]:                  # (ops.embed_fwd makes the same check on the launch-chain path)
+            raise EmoError('decode position %d is past the positional-encoding table (%d rows)' % (self.pos, pe.shape[0]))
         nf = 2 * self.omegas[0].shape[1]
         pos_ids = self.pos_dev if dev_pos else None
         padded = self.n_pad != self.n
@@ -480,7 +489,18 @@ def generate_conditional(model, event2idx, idx2event, lead_sheet_events, primer,
                     kw = {'attn_kwargs': {'omit_feature_map_draw': len(s.generated) > primed}} if model_type == 'performer' else {}
                     logits = model(torch.tensor([s.generated[-max_dec_inp_len:]], dtype=torch.long, device=dev),
                                    seg_inp=torch.tensor([s.seg[-max_dec_inp_len:]], dtype=torch.long, device=dev), keep_last_only=True, **kw)
-                probs = temperature(logits[0].cpu().numpy().copy(), temp, inadmissibles=inadmissibles)
+                logits_np = logits[0].cpu().numpy().copy()
+                if eng is not None and getattr(eng, 'persist', None) is not None:
+                    try:
+                        eng.check_persistent()                   # (the copy above already synchronised)
+                    except EmoError as e:
+                        # the one-launch step gave up (its workgroups were not all resident within 50 ms): logits and recurrent state of this
+                        # engine are void.  Re-run the piece so far through the chain of launches and continue there.
+                        note('[gen] %s -> falling back to the chain of launches' % e)
+                        eng = make_engine(model, 1, redraw=False, persistent=False) if model.kind == 'performer' else make_engine(model, 1)
+                        s.consumed, cached = 0, None
+                        continue
+                probs = temperature(logits_np, temp, inadmissibles=inadmissibles)
                 bars = s.generated_bars
                 if not s.offer(int(draw(probs)), event2idx, idx2event, skip_check, max_events):
                     note('[gen] sample rejected (%d in a row)' % s.failed_cnt)
@@ -636,10 +656,10 @@ def _resume_windowed(model, event2idx, idx2event, s, max_events, skip_check, tem
 class _Chain:
     """One lock-step group of streams: engine + device-side loop state + (optionally) the captured step graph on its own HIP stream."""
 
-    def __init__(self, model, ptok, pseg, n_new, U, temp, top_p, greedy, seg_value, redraw):
+    def __init__(self, model, ptok, pseg, n_new, U, temp, top_p, greedy, seg_value, redraw, persistent=True):
         self.n, self.T0 = ptok.shape
         n, T0, dev = self.n, self.T0, ptok.device
-        self.eng = make_engine(model, n, redraw=redraw) if model.kind == 'performer' else make_engine(model, n)
+        self.eng = make_engine(model, n, redraw=redraw, persistent=persistent) if model.kind == 'performer' else make_engine(model, n)
         eng = self.eng
         self.out = torch.empty(n, T0 + n_new, dtype=torch.long, device=dev)
         self.out[:, :T0] = ptok
@@ -718,7 +738,8 @@ def generate_streams(model, prompt_tok, prompt_seg, n_new, temp=1.1, top_p=0.9, 
     for c in range(chains):
         rows = slice(c * m, (c + 1) * m)
         cs.append(_Chain(model, prompt_tok[rows].contiguous(), prompt_seg[rows].contiguous(), n_new, U[:, rows].contiguous(), temp, top_p, greedy,
-                         seg_value, redraw=(c == 0)))
+                         seg_value, redraw=(c == 0), persistent=(chains == 1)))      # (two persistent launches on two streams can each be
+                                                                                      # partially resident and starve each other: one chain only)
     if n_new > 0:
         for ch in cs:
             ch.one_step()                        # eager first step (also warms every kernel / attribute cache)

@@ -198,6 +198,9 @@ int emo_favor_decode_step(const void* q, const void* k, const void* v, int64_t l
  *                 (a workgroup could not be scheduled next to the others within 50 ms) - the caller must check it before trusting the logits.
  *   diag        : NULL, or int64 [32][16][8][4] device words that receive group 0's per-phase time stamps (tools/pd_diag.py). */
 int64_t emo_performer_decode_step_workspace_bytes(void);
+/* 1 when this device can hold the launch (>= 256 CUs, 96 KB of LDS per workgroup granted, one workgroup per CU by the occupancy query), else 0:
+ * callers keep the chain of launches (emo_gemm + emo_favor_decode_step ...) of stage2_accompaniment/inference.py:250-277 then */
+int emo_performer_decode_step_supported(void);
 int emo_performer_decode_step(const void* layer_table, int64_t n_layers, const int64_t* tok, const int64_t* seg, const float* E,
                               const float* Sg, const float* pe, float emb_scale, int64_t pos0, const int64_t* pos_ids,
                               const void* wout_packed, const float* bout, int64_t n_token, float* logits, int64_t n_streams,
