@@ -816,7 +816,7 @@ static void dispatch_glds2(bool akc, bool bkc, dim3 grid, hipStream_t st, const 
 template <typename OutT>
 static void dispatch_glds(bool akc, bool bkc, dim3 grid, hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C,
                           int64_t M, int64_t N, int64_t K, int64_t kps, const EpiParams& ep) {
-    // measured r01 (tools/bench_gemm.py, MI355X): the per-tile fixed cost (prologue latency + epilogue, ~4-5 us) is what
+    // measured r01 (tools/bench_gemm.py of that round — git history — MI355X): the per-tile fixed cost (prologue latency + epilogue, ~4-5 us) is what
     // limits the K=512 GEMMs, so OCCUPANCY wins over prefetch depth: a 3-stage ring of 32-deep tiles (48 KB LDS, 3 blocks
     // per CU) beats the 4-stage ring (64 KB, 2 blocks) by 13-16 % (qkv 575 vs 509, ffn1 659 vs 568 TFLOP/s); for the
     // long reduction (K=2048) the double buffer of full 128-B lines is best (842 vs 796); for MN-contiguous B (dgrad)
@@ -960,7 +960,7 @@ static int64_t choose_splits(int64_t M, int64_t N, int64_t K, bool big, bool has
     if (dtype_out == EMO_F32 && !has_epi && tiles_m * tiles_n < 256 && K >= 8 * BKt) {
         const int64_t max_splits = K / (4 * BKt);
         if (big) {
-            // Cost model fitted to the r01 sweep (tools/bench_wgrad_splits.py, M = 8k/32k/131k tokens): a 128^2 x 64 K-step takes ~1.1 us
+            // Cost model fitted to the r01 sweep (tools/bench_wgrad_splits.py of that round — git history —, M = 8k/32k/131k tokens): a 128^2 x 64 K-step takes ~1.1 us
             // with one block per CU and ~1.4 us with two; blocks run in rounds of 512 (2 per CU); every split pays ~0.18 us per output
             // tile for its fp32 atomics (device-scope atomics from 8 XCDs resolve beyond the L2s: ~0.3 TB/s), or ~0.03 us per tile for
             // plain stores + its share of the reduce pass when a workspace is available.

@@ -34,6 +34,7 @@ __device__ __forceinline__ int as_nrow(int f, int i) { return 32 * (f >> 1) + 8 
 template <int N> __device__ __forceinline__ void as_wait();
 template <> __device__ __forceinline__ void as_wait<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <> __device__ __forceinline__ void as_wait<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+template <> __device__ __forceinline__ void as_wait<5>() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
 template <> __device__ __forceinline__ void as_wait<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 template <> __device__ __forceinline__ void as_wait<12>() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
 template <> __device__ __forceinline__ void as_wait<16>() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
@@ -77,6 +78,16 @@ __device__ __forceinline__ void as_store16_o16(const void* sbase, uint32_t boff,
 __device__ __forceinline__ void as_store1(const void* sbase, uint32_t boff, uint32_t d) {
     asm volatile("global_store_byte %0, %1, %2\n\ts_nop 1" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
 }
+__device__ __forceinline__ void as_store4(const void* sbase, uint32_t boff, uint32_t d) {
+    asm volatile("global_store_dword %0, %1, %2" :: "v"(boff), "v"(d), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ uint32_t as_load4(const char* sbase, uint32_t voff) {
+    uint32_t r;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+    return r;
+}
+template <int N> __device__ __forceinline__ void as_pinw(uint32_t& r);
+template <> __device__ __forceinline__ void as_pinw<4>(uint32_t& r) { asm volatile("s_waitcnt vmcnt(4)" : "+v"(r) :: "memory"); }
 template <typename OutT> __device__ __forceinline__ void as_store_row8(const OutT* sbase, uint32_t eoff, const float (&v)[8], bool nt = false) {
     if constexpr (sizeof(OutT) == 4) {
         as_store16(sbase, eoff * 4, (u32x4){__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1]), __builtin_bit_cast(uint32_t, v[2]), __builtin_bit_cast(uint32_t, v[3])});
@@ -129,7 +140,7 @@ __device__ __forceinline__ void as_drop8(const DropCtx& d, uint32_t idx0, float 
 
 template <typename OutT, int FL>
 __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ C, int64_t ub, uint32_t lo, int nb, int ecol, int64_t db, uint32_t dl,
-                                        int64_t mb, uint32_t ml, float (&v)[8], const float* bias_lds, uint32_t pre_bits) {
+                                        int64_t mb, uint32_t ml, float (&v)[8], const float* bias_lds, uint32_t pre_bits, uint32_t& mask_word, int mask_byte) {
     // (the bias is already in the accumulators: they START from it)
     constexpr bool G = (FL & AF_GENERIC) != 0;
     if ((FL & AF_GELUAUX) || (G && ep.aux_out)) as_store_row8<OutT>((const OutT*)ep.aux_out + ub, lo, v);      // the pre-activation (gelu backward)
@@ -153,7 +164,7 @@ __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[i] *= dgelu_new_fast(t0[i]); v[4 + i] *= dgelu_new_fast(t1[i]); }
     } else if (G && ep.mul_mode == EMO_MUL_BITMASK) {
-        const uint32_t bits = (uint32_t)((const uint8_t*)ep.mul_aux)[mb + ml];
+        const uint32_t bits = (uint32_t)((const uint8_t*)ep.mul_aux)[mb + 4 * ml + mask_byte];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] *= ((bits >> i) & 1u) ? ep.mul_scale : 0.f;
     } else if (G && ep.mul_mode != EMO_MUL_NONE) {
@@ -178,7 +189,7 @@ __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ 
         uint32_t bits = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) bits |= (v[i] != 0.f ? 1u : 0u) << i;
-        as_store1(ep.mask_out + mb, ml, bits);
+        mask_word |= bits << (8 * mask_byte);                     // the tile's four bytes of this lane leave as ONE dword (caller)
     }
     if ((FL & AF_RES) || (G && ep.residual)) {
         float t0[4], t1[4];
@@ -273,9 +284,10 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
     // every wait count is a constant.
     const int ecol = 8 * (lane >> 4);
     // 1-bit mask (mask_out / EMO_MUL_BITMASK), TILED layout private to this kernel: the 256 mask bytes of a wave's 32-row x 64-column tile are
-    // contiguous — block ((m / 32) * (N / 64) + n / 64) * 256, byte (2 i + h) * 64 + lane for row 16 i + (lane & 15), columns 32 h + 8 (lane >> 4) .. +7
-    // — so each of the four byte stores / loads of a tile covers ONE 64-byte run (row-major [M][N/8]: 16 rows = 16 lines per instruction,
-    // 4 useful bytes per 32-byte sector).  ops.bitmask_rows() converts to the row-major view for tests.
+    // contiguous — block ((m / 32) * (N / 64) + n / 64) * 256, byte 4 lane + (2 i + h) for row 16 i + (lane & 15), columns 32 h + 8 (lane >> 4) .. +7
+    // — so a lane's four bytes of a tile are ONE dword and the wave writes / reads the tile's 256 bytes with ONE store / load instruction
+    // (r05; r03-r04: byte (2 i + h) * 64 + lane, four byte stores of 64-byte runs per tile — PMC r04: 135 MB of write traffic over the 570 MB
+    // the FFN1 forward has to write, four times the mask's size).  ops.bitmask_rows() converts to the row-major view for tests.
     const int64_t mtile0 = (m0 >> 5) * (int64_t)n_tiles * 256;
     // per-lane offsets of row (lane & 15) only: the 16-row step of the second row fragment goes into the wave-uniform (scalar) part of the
     // address — two loop-invariant VGPRs fewer (at 256 VGPRs a spilled one comes back as scratch_load + s_waitcnt vmcnt(0) = a drained DMA ring)
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
             acc[0][f] = b4;
             acc[1][f] = b4;
         }
-        uint32_t preb[4];
+        uint32_t prew = 0;
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
 #pragma unroll
@@ -301,13 +313,10 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
 #ifdef EMO_DIAG
                     const uint64_t tw0 = __builtin_readcyclecounter();
 #endif
-                    if (BITS && kc == 3) {                        // the four mask bytes of this column tile: youngest VMEM ops at the wait below
+                    if (BITS && kc == 3) {                        // the mask word of this column tile: youngest VMEM op at the wait below
                         const char* op = (const char*)ep.mul_aux + mtile0 + nt * 256;                          // wave-uniform
-                        preb[0] = as_load1<0>(op, (uint32_t)lane);
-                        preb[1] = as_load1<64>(op, (uint32_t)lane);
-                        preb[2] = as_load1<128>(op, (uint32_t)lane);
-                        preb[3] = as_load1<192>(op, (uint32_t)lane);
-                        as_wait<8>();
+                        prew = as_load4(op, (uint32_t)lane * 4);
+                        as_wait<5>();
                     } else {
 #ifdef EMO_DIAG
                         if (ep.ablate != 2)
@@ -342,7 +351,8 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
 #ifdef EMO_DIAG
         const uint64_t te0 = __builtin_readcyclecounter();
 #endif
-        if (BITS) as_pin1<4>(preb);                               // one refill (4 DMA ops) was issued after the mask bytes
+        if (BITS) as_pinw<4>(prew);                               // one refill (4 DMA ops) was issued after the mask word
+        uint32_t mask_word = 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -352,10 +362,11 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                 const int nb = nt * AS_BN + 32 * h;
                 uint32_t lo = eoff0;
                 asm volatile("" : "+v"(lo));                     // opaque per tile: keeps (base + lane offset) out of loop-invariant 64-bit VGPR pointers
-                as_epi8<OutT, FL>(ep, C, (m0 + 16 * i) * ep.ldc + nb, lo, nb, ecol, (m0 + 16 * i) * N + nb, doff0, mtile0 + nt * 256 + (i * 2 + h) * 64, (uint32_t)lane, v, bias_lds,
-                                    preb[i * 2 + h]);
+                as_epi8<OutT, FL>(ep, C, (m0 + 16 * i) * ep.ldc + nb, lo, nb, ecol, (m0 + 16 * i) * N + nb, doff0, mtile0 + nt * 256, (uint32_t)lane, v, bias_lds,
+                                    (prew >> (8 * (i * 2 + h))) & 0xFFu, mask_word, i * 2 + h);
                 __builtin_amdgcn_sched_barrier(0);               // one 8-column group at a time: keeps the epilogue's temporaries out of the register peak
             }
+        if ((FL & AF_MASKOUT) || ((FL & AF_GENERIC) && ep.mask_out)) as_store4(ep.mask_out + mtile0 + nt * 256, (uint32_t)lane * 4, mask_word);
 #ifdef EMO_DIAG
         t_epi += __builtin_readcyclecounter() - te0;
 #endif

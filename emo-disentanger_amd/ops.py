@@ -131,8 +131,8 @@ def gemm_bitmask_ok(M, N, K, in_dtype, out_dtype):
 
 def bitmask_rows(mask, M, N):
     """Row-major view [M, N/8] (byte (m, n/8), bit j = column 8 (n/8) + j) of a mask in emo_gemm's tiled layout (emo_hip.h: mask_out) — tests / diagnostics."""
-    t = mask.reshape(M // 32, N // 64, 2, 2, 4, 16)           # [row panel, column tile, i = row / 16, h = column / 32, g = column group, r = row % 16]
-    return t.permute(0, 2, 5, 1, 3, 4).reshape(M, N // 8)
+    t = mask.reshape(M // 32, N // 64, 4, 16, 2, 2)           # [row panel, column tile, g = column group, r = row % 16, i = row / 16, h = column / 32]
+    return t.permute(0, 4, 3, 1, 5, 2).reshape(M, N // 8)
 
 
 def colsum(X, out=None, accumulate=False):

@@ -78,10 +78,10 @@ typedef struct {
                            * gradient (column sums of dY), taken inside the GEMM from the operand fragments instead of a second pass. */
     float* b_rowsum;      /* NULL or [N] fp32: += sum_k op(B)[n][k]; needs a_trans and b_trans (HF Conv1D layout, where dY is the B operand) */
     uint8_t* mask_out;    /* NULL or M*N/8 bytes: one bit per output = (value after act and dropout != 0) — the 1-bit relu.dropout mask the FFN2
-                           * dgrad needs (instead of re-reading the [M,N] activation).  TILED layout (r03; only emo_gemm reads it back): the 256
+                           * dgrad needs (instead of re-reading the [M,N] activation).  TILED layout (r03, byte order r05; only emo_gemm reads it back): the 256
                            * bytes of a 32-row x 64-column tile are contiguous at ((m/32)*(N/64) + n/64)*256; inside, byte
-                           * ((m%32)/16*2 + (n%64)/32)*64 + (n%32)/8*16 + m%16 holds columns 8*(n/8) .. +7 of row m, bit j = column 8*(n/8)+j
-                           * (one 64-byte run per store / load instruction of the A-stationary kernel).  Only with EMO_MUL_BITMASK's
+                           * ((n%32)/8*16 + m%16)*4 + (m%32)/16*2 + (n%64)/32 holds columns 8*(n/8) .. +7 of row m, bit j = column 8*(n/8)+j
+                           * (a lane's four bytes of a tile are one dword: ONE 256-byte store / load per wave of the A-stationary kernel).  Only with EMO_MUL_BITMASK's
                            * shape class: bf16 in/out, NT, K = 512, M % 128 == 0, M >= 32768, N % 64 == 0, N <= 2048 (the A-stationary kernel); refused elsewhere. */
     void* workspace;      /* NULL or caller scratch for split-K partial sums (plain fp32-output GEMMs = weight gradients): */
     int64_t workspace_bytes; /* with it the splits are summed in a fixed order by a reduce kernel (deterministic, no atomics);
