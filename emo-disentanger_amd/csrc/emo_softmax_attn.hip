@@ -391,15 +391,15 @@ __global__ __launch_bounds__(256, (sizeof(CT) == 2 ? 2 : 1)) void sattn_bwd_dkv_
 // One workgroup per (stream, head).  len = lens[s] + lens_off keys are valid INCLUDING the new token, whose k / v rows (k_new / v_new, may be
 // NULL) the kernel appends to the cache itself at position len - 1 (saves two index_copy launches per layer).  Score pass: dh/VE lanes share
 // a key row (16-B loads, a wave reads 64/(dh/VE) whole rows per instruction), shuffle-reduced; value pass: 16-B loads, 256/(dh/VE) keys in flight.
-template <typename CT>
-__global__ __launch_bounds__(256) void sattn_decode_kernel(const CT* __restrict__ q, int64_t ld_q, CT* __restrict__ kc, CT* __restrict__ vc,
+template <typename CT, int NT>
+__global__ __launch_bounds__(NT) void sattn_decode_kernel(const CT* __restrict__ q, int64_t ld_q, CT* __restrict__ kc, CT* __restrict__ vc,
                                                            int64_t T_max, const int64_t* __restrict__ lens, int64_t lens_off,
                                                            const CT* __restrict__ k_new, const CT* __restrict__ v_new, int64_t ld_new,
                                                            CT* __restrict__ out, int64_t ld_out, int64_t H, int dh) {
     constexpr int VE = 16 / sizeof(CT);
     extern __shared__ float sc[];            // [T_max] scores
-    __shared__ float qs[128], red[4];
-    __shared__ float part[256 * VE];
+    __shared__ float qs[128], red[NT / 64];
+    __shared__ float part[NT * VE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t sh = blockIdx.x, s = sh / H, h = sh % H;
     const int64_t len = lens[s] + lens_off;
@@ -414,53 +414,68 @@ __global__ __launch_bounds__(256) void sattn_decode_kernel(const CT* __restrict_
     __syncthreads();
     const float sqrt_dh = sqrtf((float)dh);
     const int LPR = dh / VE;                 // lanes per key row (power of two: dh in {16,32,64,128})
-    const int rl = tid / LPR, cl = (tid % LPR) * VE, RPB = 256 / LPR;
+    const int rl = tid / LPR, cl = (tid % LPR) * VE, RPB = NT / LPR;
     float qv[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) qv[e] = qs[cl + e];
+    // Both sweeps keep SU key / value rows per thread in flight (r05: with one 16-B load per thread and iteration a CU had 4 KB outstanding
+    // against the ~40 KB that cover the HBM round trip at its share of the bandwidth — rocprofv3 of the GPT-2 generation: 18 us per layer at
+    // ~300 keys, 40 % of the token step).  Rows past `len` are clamped to the last valid row and discarded.
+    constexpr int SU = NT >= 1024 ? 4 : 8;
+    typedef typename std::conditional<sizeof(CT) == 2, bf16x8, f32x4>::type RowV;
     float mx = -INFINITY;
-    for (int64_t j0 = 0; j0 < len; j0 += RPB) {
-        const int64_t j = j0 + rl;
-        float a = 0.f;
-        if (j < len) {
-            const CT* kr = kc + (s * T_max + j) * HD + h * dh + cl;
-            if constexpr (sizeof(CT) == 2) { const bf16x8 kv = *(const bf16x8*)kr;
+    for (int64_t j0 = 0; j0 < len; j0 += (int64_t)RPB * SU) {
+        RowV kv[SU];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a += qv[e] * (float)kv[e]; }
-            else { const f32x4 kv = *(const f32x4*)kr;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) a += qv[e] * kv[e]; }
+        for (int u = 0; u < SU; ++u) {
+            const int64_t j = j0 + (int64_t)u * RPB + rl;
+            kv[u] = *(const RowV*)(kc + (s * T_max + (j < len ? j : len - 1)) * HD + h * dh + cl);
         }
-        for (int o = LPR >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-        a = a / sqrt_dh;
-        if (j < len) {
-            if ((tid % LPR) == 0) sc[j] = a;
-            mx = fmaxf(mx, a);
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int64_t j = j0 + (int64_t)u * RPB + rl;
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) a += qv[e] * (float)kv[u][e];
+            for (int o = LPR >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+            a = a / sqrt_dh;
+            if (j < len) {
+                if ((tid % LPR) == 0) sc[j] = a;
+                mx = fmaxf(mx, a);
+            }
         }
     }
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = red[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) mx = fmaxf(mx, red[i]);
     __syncthreads();
     float sum = 0.f;
-    for (int64_t j = tid; j < len; j += 256) { float p = expf(sc[j] - mx); sc[j] = p; sum += p; }
+    for (int64_t j = tid; j < len; j += NT) { float p = expf(sc[j] - mx); sc[j] = p; sum += p; }
     sum = wave_sum(sum);
     if (lane == 0) red[wave] = sum;
     __syncthreads();
-    const float tot = red[0] + red[1] + red[2] + red[3];
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) tot += red[i];
     float acc[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) acc[e] = 0.f;
-    for (int64_t j = rl; j < len; j += RPB) {
-        const CT* vr = vc + (s * T_max + j) * HD + h * dh + cl;
-        const float p = sc[j];
-        if constexpr (sizeof(CT) == 2) { const bf16x8 vv = *(const bf16x8*)vr;
+    for (int64_t j0 = 0; j0 < len; j0 += (int64_t)RPB * SU) {
+        RowV vv[SU];
+        float pw[SU];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += p * (float)vv[e]; }
-        else { const f32x4 vv = *(const f32x4*)vr;
+        for (int u = 0; u < SU; ++u) {
+            const int64_t j = j0 + (int64_t)u * RPB + rl;
+            vv[u] = *(const RowV*)(vc + (s * T_max + (j < len ? j : len - 1)) * HD + h * dh + cl);
+            pw[u] = j < len ? sc[j] : 0.f;
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += p * vv[e]; }
+        for (int u = 0; u < SU; ++u)
+#pragma unroll
+            for (int e = 0; e < VE; ++e) acc[e] += pw[u] * (float)vv[u][e];
     }
 #pragma unroll
     for (int e = 0; e < VE; ++e) part[rl * dh + cl + e] = acc[e];
@@ -607,24 +622,30 @@ extern "C" int emo_softmax_attn_decode(const void* q, int64_t ld_q, void* kcache
                                        int64_t H, int64_t dh, emo_stream_t stream) {
     EMO_CHECK(q && kcache && vcache && lens && out, "emo_softmax_attn_decode: null pointer");
     EMO_CHECK(dh == 16 || dh == 32 || dh == 64 || dh == 128, "emo_softmax_attn_decode: d_head must be 16, 32, 64 or 128");
-    EMO_CHECK(T_max * 4 <= 128 * 1024, "emo_softmax_attn_decode: T_max too large for the LDS score buffer");
     EMO_CHECK(!k_new == !v_new, "emo_softmax_attn_decode: k_new and v_new go together");
     const int64_t ve = dtype == EMO_BF16 ? 8 : 4;
     EMO_CHECK((((uintptr_t)kcache | (uintptr_t)vcache) & 15) == 0 && (H * dh) % ve == 0, "emo_softmax_attn_decode: caches must be 16-B aligned");
+    EMO_CHECK(T_max * 4 <= 128 * 1024, "emo_softmax_attn_decode: T_max too large for the LDS score buffer");
     dim3 grid((unsigned)(n_streams * H));
     const size_t lds = (size_t)T_max * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == EMO_F32) {
-        static bool a = false;
-        if (!a) { (void)hipFuncSetAttribute((const void*)sattn_decode_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); a = true; }
-        hipLaunchKernelGGL(sattn_decode_kernel<float>, grid, dim3(256), lds, st, (const float*)q, ld_q, (float*)kcache, (float*)vcache, T_max, lens, lens_off,
-                           (const float*)k_new, (const float*)v_new, ld_new, (float*)out, ld_out, H, (int)dh);
-    } else {
-        static bool a = false;
-        if (!a) { (void)hipFuncSetAttribute((const void*)sattn_decode_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); a = true; }
-        hipLaunchKernelGGL(sattn_decode_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)q, ld_q, (bf16_t*)kcache, (bf16_t*)vcache, T_max, lens,
-                           lens_off, (const bf16_t*)k_new, (const bf16_t*)v_new, ld_new, (bf16_t*)out, ld_out, H, (int)dh);
-    }
+    // one workgroup per (stream, head) = at most one per CU at 32 streams x 8 heads: 16 waves instead of 4 give the CU's memory pipe four
+    // times the requests in flight (r05; EMO_SATTN_DECODE_NT=256 keeps the 4-wave instance).  GPT-2 generation, 32 streams x 2048: 25 us per
+    // layer with 8 rows per thread in flight, 20 us with 16 waves (the CU's own ~10 B/clk HBM rate gives 12 us for its 270 KB at the mean
+    // context); a single-sweep online-softmax variant (K and V rows in flight together, no score buffer) measured the same 20 us and was dropped.
+    int nt = 1024;
+    { const char* e = getenv("EMO_SATTN_DECODE_NT"); if (e && atoi(e) == 256) nt = 256; }
+    if (T_max * 4 > 96 * 1024) nt = 256;                             // (two-pass kernel: score buffer + the 1024-thread instance's partial sums must fit the LDS)
+#define SD_LAUNCH(CTv, NTv)                                                                                                                \
+    do {                                                                                                                                   \
+        static bool a = false;                                                                                                             \
+        if (!a) { (void)hipFuncSetAttribute((const void*)sattn_decode_kernel<CTv, NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, (NTv == 1024 ? 96 : 128) * 1024); a = true; } \
+        hipLaunchKernelGGL((sattn_decode_kernel<CTv, NTv>), grid, dim3(NTv), lds, st, (const CTv*)q, ld_q, (CTv*)kcache, (CTv*)vcache, T_max, lens, lens_off, \
+                           (const CTv*)k_new, (const CTv*)v_new, ld_new, (CTv*)out, ld_out, H, (int)dh);                                  \
+    } while (0)
+    if (dtype == EMO_F32) { if (nt == 1024) SD_LAUNCH(float, 1024); else SD_LAUNCH(float, 256); }
+    else { if (nt == 1024) SD_LAUNCH(bf16_t, 1024); else SD_LAUNCH(bf16_t, 256); }
+#undef SD_LAUNCH
     EMO_LAUNCH_CHECK();
     return EMO_OK;
 }
@@ -1710,6 +1731,7 @@ extern "C" int emo_relpos_attn_decode(const void* q, int64_t ld_q, void* kcache,
     const int64_t ve = dtype == EMO_BF16 ? 8 : 4;
     EMO_CHECK((((uintptr_t)kcache | (uintptr_t)vcache | (uintptr_t)r_dist) & 15) == 0 && (H * dh) % ve == 0 && ld_r % ve == 0,
               "emo_relpos_attn_decode: caches / r_dist must be 16-B aligned");
+    EMO_CHECK(T_max * 4 <= 128 * 1024, "emo_softmax_attn_decode: T_max too large for the LDS score buffer");
     dim3 grid((unsigned)(n_streams * H));
     const size_t lds = (size_t)T_max * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
