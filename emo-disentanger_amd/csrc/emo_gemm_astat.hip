@@ -286,8 +286,9 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
     // 1-bit mask (mask_out / EMO_MUL_BITMASK), TILED layout private to this kernel: the 256 mask bytes of a wave's 32-row x 64-column tile are
     // contiguous — block ((m / 32) * (N / 64) + n / 64) * 256, byte 4 lane + (2 i + h) for row 16 i + (lane & 15), columns 32 h + 8 (lane >> 4) .. +7
     // — so a lane's four bytes of a tile are ONE dword and the wave writes / reads the tile's 256 bytes with ONE store / load instruction
-    // (r05; r03-r04: byte (2 i + h) * 64 + lane, four byte stores of 64-byte runs per tile — PMC r04: 135 MB of write traffic over the 570 MB
-    // the FFN1 forward has to write, four times the mask's size).  ops.bitmask_rows() converts to the row-major view for tests.
+    // (r05; r03-r04: byte (2 i + h) * 64 + lane, four byte stores / loads of 64-byte runs per tile.  The r05 counters show the same write
+    // traffic as before — 727 MB against 570 MB algorithmic — so the excess the r04 counters showed is NOT the byte stores: it comes with the
+    // non-temporal output stores this instance uses, 1.31 x on the 537-MB output, see the launcher).  ops.bitmask_rows() converts to the row-major view for tests.
     const int64_t mtile0 = (m0 >> 5) * (int64_t)n_tiles * 256;
     // per-lane offsets of row (lane & 15) only: the 16-row step of the second row fragment goes into the wave-uniform (scalar) part of the
     // address — two loop-invariant VGPRs fewer (at 256 VGPRs a spilled one comes back as scratch_load + s_waitcnt vmcnt(0) = a drained DMA ring)
