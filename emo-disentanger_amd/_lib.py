@@ -11,8 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libemo_hip.so')
 
 F32, BF16, I64 = 0, 1, 2
-ACT_NONE, ACT_RELU, ACT_GELU_NEW = 0, 1, 2
-MUL_NONE, MUL_NONZERO, MUL_DGELU_NEW, MUL_BITMASK = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_GELU_NEW, ACT_GELU = 0, 1, 2, 3
+MUL_NONE, MUL_NONZERO, MUL_DGELU_NEW, MUL_BITMASK, MUL_DGELU = 0, 1, 2, 3, 4
 
 if not os.path.exists(LIB_PATH):
     raise ImportError('libemo_hip.so not built: run `python -c "import __graft_entry__ as g; g.build()"` '

@@ -224,6 +224,10 @@ __device__ __forceinline__ float dgelu_new_fast(float x) {
 
 // bf16 outputs use the fast forms in EVERY kernel (a sequence's result must not depend on which GEMM kernel its batch size selects);
 // fp32 outputs (parity mode) keep the libm tanhf.
+// exact GELU (F.gelu: x Phi(x)) and its derivative Phi(x) + x phi(x) — the Performer stack's activation='gelu' (upstream TransformerEncoderLayer);
+// libm erff / expf: this activation only runs on the generic epilogues
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float dgelu_erf_f(float x) { return 0.5f * (1.f + erff(x * 0.7071067811865476f)) + x * 0.3989422804014327f * expf(-0.5f * x * x); }
 template <typename OutT> __device__ __forceinline__ float gelu_new_o(float x) { if constexpr (sizeof(OutT) == 2) return gelu_new_fast(x); else return gelu_new_f(x); }
 template <typename OutT> __device__ __forceinline__ float dgelu_new_o(float x) { if constexpr (sizeof(OutT) == 2) return dgelu_new_fast(x); else return dgelu_new_f(x); }
 

@@ -715,6 +715,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_skinny_kernel(const bf16_t*
                 x += p_bias[i];
                 if (ep.act == EMO_ACT_RELU) x = fmaxf(x, 0.f);
                 else if (ep.act == EMO_ACT_GELU_NEW) x = gelu_new_o<OutT>(x);
+                else if (ep.act == EMO_ACT_GELU) x = gelu_erf_f(x);
                 if (ep.residual) x += p_res[h][i];
                 v[h][i] = x;
             }

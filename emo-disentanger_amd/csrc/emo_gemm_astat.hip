@@ -394,6 +394,7 @@ bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t l
     if (off || K != AS_K || (M % AS_BM) != 0 || M < (int64_t)AS_BM * AS_MIN_BLOCKS || (N % AS_BN) != 0 || N > AS_MAXN || N < AS_BN) return false;
     if (ep.atomic || ep.accumulate || ep.ws_stride || ep.a_rowsum || ep.b_rowsum || ep.ln_c1 || ep.rln_x) return false;
     if ((ep.mask_out || ep.mul_mode == EMO_MUL_BITMASK) && dtype_out != EMO_BF16) return false;
+    if (ep.act == EMO_ACT_GELU || ep.mul_mode == EMO_MUL_DGELU) return false;          // (exact erf GELU: the generic tiled epilogue only)
     if ((lda & 7) || (ldb & 7) || (ep.ldc & 7) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return false;
     if ((uint64_t)(AS_BN * ldb + AS_K) * 2 >= 0xFFFF0000ull) return false;
     const size_t lds = AS_RING + AS_MAXN * sizeof(float);

@@ -63,12 +63,15 @@ __device__ __forceinline__ void epi_store4(const EpiParams& ep, OutT* __restrict
         } else if (ep.act == EMO_ACT_GELU_NEW) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = gelu_new_o<OutT>(v[i]);
+        } else if (ep.act == EMO_ACT_GELU) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
         }
         if (ep.mul_mode != EMO_MUL_NONE) {
             float a[4];
             Out4<OutT>::load((const OutT*)ep.mul_aux + off, a);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (a[i] != 0.f ? ep.mul_scale : 0.f) : dgelu_new_o<OutT>(a[i]);
+            for (int i = 0; i < 4; ++i) v[i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (a[i] != 0.f ? ep.mul_scale : 0.f) : (ep.mul_mode == EMO_MUL_DGELU ? dgelu_erf_f(a[i]) : dgelu_new_o<OutT>(a[i]));
         }
         if (ep.drop.thr16) {
             float dm[4];
@@ -107,9 +110,10 @@ __device__ __forceinline__ void epi_store4(const EpiParams& ep, OutT* __restrict
         if (ep.aux_out) ((OutT*)ep.aux_out)[off + i] = from_f32<OutT>(x);
         if (ep.act == EMO_ACT_RELU) x = fmaxf(x, 0.f);
         else if (ep.act == EMO_ACT_GELU_NEW) x = gelu_new_o<OutT>(x);
+        else if (ep.act == EMO_ACT_GELU) x = gelu_erf_f(x);
         if (ep.mul_mode != EMO_MUL_NONE) {
             const float a = to_f32<OutT>(((const OutT*)ep.mul_aux)[off + i]);
-            x *= (ep.mul_mode == EMO_MUL_NONZERO) ? (a != 0.f ? ep.mul_scale : 0.f) : dgelu_new_o<OutT>(a);
+            x *= (ep.mul_mode == EMO_MUL_NONZERO) ? (a != 0.f ? ep.mul_scale : 0.f) : (ep.mul_mode == EMO_MUL_DGELU ? dgelu_erf_f(a) : dgelu_new_o<OutT>(a));
         }
         if (ep.drop.thr16) x *= drop_mult(ep.drop, (uint64_t)(m * N + n + i));
         if (ep.residual) x += to_f32<OutT>(((const OutT*)ep.residual)[off + i]);
@@ -147,6 +151,9 @@ __device__ __forceinline__ void epi_row8(const EpiParams& ep, OutT* __restrict__
         } else if (ep.act == EMO_ACT_GELU_NEW) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = gelu_new_o<OutT>(v[i]);
+        } else if (ep.act == EMO_ACT_GELU) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = gelu_erf_f(v[i]);
         }
         if (ep.mul_mode != EMO_MUL_NONE) {
             float a[8];
@@ -154,7 +161,7 @@ __device__ __forceinline__ void epi_row8(const EpiParams& ep, OutT* __restrict__
 #pragma unroll
               for (int i = 0; i < 4; ++i) { a[i] = t0[i]; a[4 + i] = t1[i]; } }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (a[i] != 0.f ? ep.mul_scale : 0.f) : dgelu_new_o<OutT>(a[i]);
+            for (int i = 0; i < 8; ++i) v[i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (a[i] != 0.f ? ep.mul_scale : 0.f) : (ep.mul_mode == EMO_MUL_DGELU ? dgelu_erf_f(a[i]) : dgelu_new_o<OutT>(a[i]));
         }
         if (ep.drop.thr16) {
             float d0[4], d1[4];

@@ -207,8 +207,9 @@ class LayerCtx:
         self.t = {}
 
 
-def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save):
-    """Post-LN encoder layer with FAVOR+ causal attention.  x: [M, D]."""
+def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save, act='relu'):
+    """Post-LN encoder layer with FAVOR+ causal attention.  x: [M, D].  act: 'relu' (every YAML of the reference) or 'gelu'
+    (upstream's F.gelu, passed through at fast_transformer_decoder.py:50: exact erf form on the generic epilogue, pre-activation saved)."""
     D = x.shape[1]
     q = pfx + 'attention.query_projection.'
     qkv = ops.gemm(x, ps.w(q + 'weight', 3 * D), bias=ps.f32(q + 'bias', 3 * D))
@@ -224,12 +225,17 @@ def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save):
     W1 = ps.w(pfx + 'linear1.weight')
     # 1-bit relu.dropout mask for the FFN2 dgrad (1/16 of the bytes of re-reading f), when the shape runs on the A-stationary kernel
     fmask = torch.empty(x.shape[0], W1.shape[0] // 8, device=x.device, dtype=torch.uint8) \
-        if (save is not None and ops.gemm_bitmask_ok(x.shape[0], W1.shape[0], D, h1.dtype, h1.dtype)) else None
-    f = ops.gemm(h1, W1, bias=ps.f32(pfx + 'linear1.bias'), act=ops.ACT_RELU, p_drop=p, seed=seed, offset=off + 2, mask_out=fmask)
+        if (act == 'relu' and save is not None and ops.gemm_bitmask_ok(x.shape[0], W1.shape[0], D, h1.dtype, h1.dtype)) else None
+    z = None
+    if act == 'relu':
+        f = ops.gemm(h1, W1, bias=ps.f32(pfx + 'linear1.bias'), act=ops.ACT_RELU, p_drop=p, seed=seed, offset=off + 2, mask_out=fmask)
+    else:
+        z = torch.empty(x.shape[0], W1.shape[0], device=x.device, dtype=h1.dtype) if save is not None else None      # pre-activation for gelu'
+        f = ops.gemm(h1, W1, bias=ps.f32(pfx + 'linear1.bias'), act=ops.ACT_GELU, aux_out=z, p_drop=p, seed=seed, offset=off + 2)
     x2 = ops.gemm(f, ps.w(pfx + 'linear2.weight'), bias=ps.f32(pfx + 'linear2.bias'), p_drop=p, seed=seed, offset=off + 3, residual=h1)
     out, m2, r2 = ops.layernorm_fwd(x2, ps.f32(pfx + 'norm2.weight'), ps.f32(pfx + 'norm2.bias'))
     if save is not None:
-        save.t = dict(x=x, qkv=qkv, attn=attn, den=den, x1=x1, m1=m1, r1=r1, h1=h1, f=f, fmask=fmask, x2=x2, m2=m2, r2=r2, omega=omega, fws=fws)
+        save.t = dict(x=x, qkv=qkv, attn=attn, den=den, x1=x1, m1=m1, r1=r1, h1=h1, f=f, fmask=fmask, z=z, x2=x2, m2=m2, r2=r2, omega=omega, fws=fws)
     return out
 
 
@@ -311,7 +317,11 @@ def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
         dyd = g2
     _wgrad(ps, pfx + 'linear2.weight', pfx + 'linear2.bias', dyd, s['f'], bias_done=True)
     bf = ps.flat16 is not None and D == 512 and dout.shape[0] % 128 == 0 and dout.shape[0] >= ops.ASTAT_MIN_ROWS     # the A-stationary K = 512 class
-    if bf and s['fmask'] is not None:
+    if s.get('z') is not None:                       # activation = 'gelu': df = (dyd W2) * gelu'(z), then the hidden dropout's multipliers again
+        df = ops.gemm(dyd, ps.w(pfx + 'linear2.weight'), b_trans=True, mul_aux=s['z'], mul_mode=ops.MUL_DGELU)
+        if p > 0:
+            df = ops.dropout_apply(df, p, seed, off + 2)
+    elif bf and s['fmask'] is not None:
         df = ops.gemm(dyd, ps.wT(pfx + 'linear2.weight'), mul_aux=s['fmask'], mul_mode=ops.MUL_BITMASK, mul_scale=inv)
     elif bf:     # K = 512 dgrads against the transposed mirror (NT, A-stationary kernel)
         df = ops.gemm(dyd, ps.wT(pfx + 'linear2.weight'), mul_aux=s['f'], mul_mode=ops.MUL_NONZERO, mul_scale=inv)
@@ -454,7 +464,7 @@ class DecoderStackFn(torch.autograd.Function):
         for l in range(L):
             sv = LayerCtx() if need_bwd else None
             if model.kind == 'performer':
-                x = performer_layer_fwd(ps, model._layer_prefix(l), x, omegas[l], B, T, H, p, seed, base + 8 * (l + 1), sv)
+                x = performer_layer_fwd(ps, model._layer_prefix(l), x, omegas[l], B, T, H, p, seed, base + 8 * (l + 1), sv, act=model.activation)
             else:
                 x = gpt2_block_fwd(ps, model._layer_prefix(l), x, B, T, H, p, seed, base + 8 * (l + 1), sv)
             saves.append(sv)

@@ -82,6 +82,7 @@ class PerformerDecodeEngine(_EngineBase):
         if redraw and model.redraw != 'fixed':
             model.draw_feature_maps()
         self.omegas = [lyr.attention.inner_attention.feature_map.omega.clone() for lyr in model.transformer_decoder.decoder_layers]
+        self.act = ops.ACT_GELU if getattr(model, 'activation', 'relu') == 'gelu' else ops.ACT_RELU
         self.S, self.z = [None] * model.n_layer, [None] * model.n_layer
         # bf16 one-token steps: norm1 / norm2 are folded into the GEMMs around them (2 launches fewer per layer, see emo_hip.h: ln_c1 / rln_*)
         self.fold = None
@@ -96,7 +97,8 @@ class PerformerDecodeEngine(_EngineBase):
         nf = 2 * self.omegas[0].shape[1]
         self.n_pad = (n_streams + 3) // 4 * 4
         if (self.dt == torch.bfloat16 and 1 <= n_streams <= 32 and model.d_model == 512 and model.n_head == 8 and nf == 128
-                and ff == 2048 and model.n_layer <= 15 and model.n_token <= 512 and persistent and os.environ.get('EMO_DECODE_PERSISTENT', '1') != '0'
+                and ff == 2048 and model.n_layer <= 15 and model.n_token <= 512 and persistent and self.act == ops.ACT_RELU
+                and os.environ.get('EMO_DECODE_PERSISTENT', '1') != '0'
                 and ops.lib.emo_performer_decode_step_supported() == 1):
             # (emo_performer_decode_step_supported: the launch's 256 workgroups spin-wait on each other and must all be resident — >= 256 CUs,
             # 96 KB LDS each, one per CU by the occupancy query; partitions / CU masks with fewer keep the chain of launches)
@@ -260,7 +262,7 @@ class PerformerDecodeEngine(_EngineBase):
             ow, ob = ps.w(pfx + 'attention.out_projection.weight'), ps.f32(pfx + 'attention.out_projection.bias')
             x1 = ops.gemm(attn, ow, bias=ob, residual=x) if res is None else ops.gemm(attn, ow, bias=ob, rln=res)
             Wg, c1, bb = fd['ffn1'][l]
-            f = ops.gemm(x1, Wg, bias=bb, act=ops.ACT_RELU, ln_c1=c1, ln_stats_out=self.stats1)
+            f = ops.gemm(x1, Wg, bias=bb, act=self.act, ln_c1=c1, ln_stats_out=self.stats1)
             x2 = ops.gemm(f, ps.w(pfx + 'linear2.weight'), bias=ps.f32(pfx + 'linear2.bias'),
                           rln=(x1, self.stats1, ps.f32(pfx + 'norm1.weight'), ps.f32(pfx + 'norm1.bias')))
             res = (x2, self.stats2, ps.f32(pfx + 'norm2.weight'), ps.f32(pfx + 'norm2.bias'))
@@ -296,7 +298,7 @@ class PerformerDecodeEngine(_EngineBase):
         ps = self.ps
         x1 = ops.gemm(attn, ps.w(pfx + 'attention.out_projection.weight'), bias=ps.f32(pfx + 'attention.out_projection.bias'), residual=x)
         h1, _, _ = ops.layernorm_fwd(x1, ps.f32(pfx + 'norm1.weight'), ps.f32(pfx + 'norm1.bias'))
-        f = ops.gemm(h1, ps.w(pfx + 'linear1.weight'), bias=ps.f32(pfx + 'linear1.bias'), act=ops.ACT_RELU)
+        f = ops.gemm(h1, ps.w(pfx + 'linear1.weight'), bias=ps.f32(pfx + 'linear1.bias'), act=self.act)
         x2 = ops.gemm(f, ps.w(pfx + 'linear2.weight'), bias=ps.f32(pfx + 'linear2.bias'), residual=h1)
         out, _, _ = ops.layernorm_fwd(x2, ps.f32(pfx + 'norm2.weight'), ps.f32(pfx + 'norm2.bias'))
         return out

@@ -35,8 +35,9 @@ class AttentionLayer(nn.Module):
 class TransformerEncoderLayer(nn.Module):
     def __init__(self, attention, d_model, d_ff, dropout=0.1, activation='relu'):
         super().__init__()
-        if activation != 'relu':
-            raise NotImplementedError('the reference never overrides activation="relu" for the Performer stack')
+        if activation not in ('relu', 'gelu'):         # upstream: F.relu if activation == "relu" else F.gelu (fast_transformers/transformers.py)
+            raise ValueError('activation must be "relu" or "gelu", got %r' % (activation,))
+        self.activation = activation
         self.attention = attention
         self.linear1 = nn.Linear(d_model, d_ff)
         self.linear2 = nn.Linear(d_ff, d_model)

@@ -8,13 +8,13 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU_NEW, ACT_NONE, ACT_RELU, BF16, F32, MUL_BITMASK, MUL_DGELU_NEW, MUL_NONE, MUL_NONZERO, Epilogue, check,
+from ._lib import (ACT_GELU, ACT_GELU_NEW, ACT_NONE, ACT_RELU, BF16, F32, MUL_BITMASK, MUL_DGELU, MUL_DGELU_NEW, MUL_NONE, MUL_NONZERO, Epilogue, check,
                    dtype_code, lib, ptr, stream)
 
 __all__ = ['gemm', 'colsum', 'embed_fwd', 'embed_bwd', 'layernorm_fwd', 'layernorm_bwd', 'dropout_apply', 'favor_attn_fwd',
            'favor_attn_bwd', 'favor_decode_step', 'performer_decode_step', 'performer_decode_step_sampled', 'favor_draw_omega', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'relpos_attn_fwd', 'relpos_attn_bwd', 'relpos_attn_decode', 'xent_fwd',
            'xent_bwd', 'argmax', 'sample_nucleus', 'sample_nucleus_step', 'accuracy_counts', 'sumsq', 'clip_coef', 'adam_step', 'cast', 'add_bias2',
-           'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW', 'MUL_BITMASK', 'gemm_bitmask_ok', 'bitmask_rows']
+           'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'ACT_GELU', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW', 'MUL_DGELU', 'MUL_BITMASK', 'gemm_bitmask_ok', 'bitmask_rows']
 
 
 def _c(t):

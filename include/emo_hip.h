@@ -32,8 +32,9 @@ typedef void* emo_stream_t; /* hipStream_t */
 
 enum { EMO_OK = 0, EMO_ERR_INVALID = -1, EMO_ERR_LAUNCH = -2, EMO_ERR_UNSUPPORTED = -3 };
 enum { EMO_F32 = 0, EMO_BF16 = 1, EMO_I64 = 2 /* emo_comm_* payloads only */ };
-enum { EMO_ACT_NONE = 0, EMO_ACT_RELU = 1, EMO_ACT_GELU_NEW = 2 };
-enum { EMO_MUL_NONE = 0, EMO_MUL_NONZERO = 1, EMO_MUL_DGELU_NEW = 2, EMO_MUL_BITMASK = 3 };
+enum { EMO_ACT_NONE = 0, EMO_ACT_RELU = 1, EMO_ACT_GELU_NEW = 2, EMO_ACT_GELU = 3 };   /* GELU_NEW: HF tanh form (GPT-2); GELU: exact erf form
+                                                                                       * (F.gelu: the Performer stack's activation='gelu', fast_transformer_decoder.py:50) */
+enum { EMO_MUL_NONE = 0, EMO_MUL_NONZERO = 1, EMO_MUL_DGELU_NEW = 2, EMO_MUL_BITMASK = 3, EMO_MUL_DGELU = 4 };   /* DGELU: *= d/dx of the erf form at mul_aux */
 
 int emo_version(void);
 const char* emo_last_error(void);

@@ -169,8 +169,8 @@ def compute_loss(logits, tgt, n_token, reduction='mean'):
 
 
 # ----------------------------------------------------------------------------- Performer
-def performer_layer(sd, p, h, n_head, omega, p_drop=0.0, training=False, form='prefix', masks=None, site=''):
-    """upstream transformers.py TransformerEncoderLayer.forward (post-LN, ReLU) around
+def performer_layer(sd, p, h, n_head, omega, p_drop=0.0, training=False, form='prefix', masks=None, site='', activation='relu'):
+    """upstream transformers.py TransformerEncoderLayer.forward (post-LN; activation = F.relu if activation == "relu" else F.gelu) around
     attention_layer.py AttentionLayer.forward."""
     N, L, D = h.shape
     dh = D // n_head
@@ -181,20 +181,21 @@ def performer_layer(sd, p, h, n_head, omega, p_drop=0.0, training=False, form='p
     a = F.linear(a, sd[p + 'attention.out_projection.weight'], sd[p + 'attention.out_projection.bias'])
     x = h + _drop(a, p_drop, training, masks, site + 'attn_out')
     y = x = F.layer_norm(x, (D,), sd[p + 'norm1.weight'], sd[p + 'norm1.bias'], 1e-5)
-    y = _drop(F.relu(F.linear(y, sd[p + 'linear1.weight'], sd[p + 'linear1.bias'])), p_drop, training, masks, site + 'ffn_hidden')
+    act = F.relu if activation == 'relu' else F.gelu
+    y = _drop(act(F.linear(y, sd[p + 'linear1.weight'], sd[p + 'linear1.bias'])), p_drop, training, masks, site + 'ffn_hidden')
     y = _drop(F.linear(y, sd[p + 'linear2.weight'], sd[p + 'linear2.bias']), p_drop, training, masks, site + 'ffn_out')
     return F.layer_norm(x + y, (D,), sd[p + 'norm2.weight'], sd[p + 'norm2.bias'], 1e-5)
 
 
 def performer_forward(sd, x, seg_inp, n_layer, n_head, d_model, omegas=None, keep_last_only=False,
-                      p_drop=0.0, training=False, form='prefix', chord_inp=None, masks=None):
+                      p_drop=0.0, training=False, form='prefix', chord_inp=None, masks=None, activation='relu'):
     """MusicPerformer.forward (music_performer.py:50-70). `omegas`: list of [dh,F/2]
     (the reference redraws omega every forward — SURVEY F8 — so parity runs inject it)."""
     h = prologue(sd, x, seg_inp, d_model, p_drop, training, chord_inp, masks)
     for l in range(n_layer):
         p = 'transformer_decoder.decoder_layers.%d.' % l
         om = omegas[l] if omegas is not None else sd[p + 'attention.inner_attention.feature_map.omega']
-        h = performer_layer(sd, p, h, n_head, om, p_drop, training, form, masks, 'L%d.' % l)
+        h = performer_layer(sd, p, h, n_head, om, p_drop, training, form, masks, 'L%d.' % l, activation)
     return logits_head(sd, h, keep_last_only)
 
 
@@ -239,7 +240,7 @@ def gpt2_forward(sd, x, seg_inp, n_layer, n_head, d_model, keep_last_only=False,
 def forward(kind, sd, x, seg_inp, n_layer, n_head, d_model, **kw):
     if kind == 'performer':
         return performer_forward(sd, x, seg_inp, n_layer, n_head, d_model, **kw)
-    kw.pop('omegas', None), kw.pop('form', None)
+    kw.pop('omegas', None), kw.pop('form', None), kw.pop('activation', None)
     return gpt2_forward(sd, x, seg_inp, n_layer, n_head, d_model, **kw)
 
 

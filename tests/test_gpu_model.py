@@ -398,3 +398,55 @@ def test_chord_multi_hot_embedding(kind, p_drop):
         assert float((p.grad.cpu() - rgrads[k]).abs().max()) <= 2e-3 * gmax, k
     plain = m(b['dec_input'].cuda(), seg_inp=b['track_mask'].cuda())              # chord_inp=None: the term is skipped (:56)
     assert not torch.allclose(plain, logits)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('p_drop', [0.0, 0.1])
+def test_performer_gelu_activation_matches_oracle(dtype, p_drop):
+    """music_performer.py:11 / fast_transformer_decoder.py:50 pass `activation` through to upstream's TransformerEncoderLayer
+    (F.relu if activation == "relu" else F.gelu).  'gelu' = the exact erf form on the generic GEMM epilogue (EMO_ACT_GELU, pre-activation saved,
+    EMO_MUL_DGELU in the FFN2 dgrad + the hidden dropout's multipliers re-applied): loss, logits and every gradient against the oracle, with the
+    kernels' own exported masks when dropout is on; and the cached decode engine (launch chain) against the full forward."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from dropmask import export_masks
+    from emo_disentanger_amd import inference as inf
+    from emo_disentanger_amd.model.music_performer import MusicPerformer
+    from oracle import model_ref
+    from oracle.weights import make_state_dict, synthetic_batch
+    V, L, H, d, dff, nf, B, T = 60, 2, 4, 128, 256, 64, 2, 96
+    sd = make_state_dict('performer', V, L, H, d, dff, favor_feature_dims=nf, seed=13, scale=3.0)
+    m = MusicPerformer(V, L, H, d, dff, d, activation='gelu', dropout=p_drop, favor_feature_dims=nf, use_segment_emb=True, n_segment_types=2,
+                       compute_dtype=dtype, redraw='fixed')
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    seed = 17
+    m.set_dropout_seed(seed)
+    b = synthetic_batch(V, B, T, seed=6)
+    logits = m(b['dec_input'].cuda(), seg_inp=b['track_mask'].cuda())
+    loss = m.compute_loss(logits, b['dec_target'].cuda())['total_loss']
+    loss.backward()
+    masks = export_masks('performer', p_drop, seed, 4096, B, T, d, dff, H, L) if p_drop > 0 else None
+    rloss, rlogits, rgrads = model_ref.loss_and_grads('performer', sd, b, V, L, H, d, form='quadratic', activation='gelu',
+                                                      p_drop=p_drop, training=p_drop > 0, masks=masks)
+    relu_loss, relu_logits, _ = model_ref.loss_and_grads('performer', sd, b, V, L, H, d, form='quadratic')
+    assert float((relu_logits - rlogits).abs().max()) > 0.05                      # the activation matters at these weights
+    lt, gt = (1e-4, 2e-3) if dtype == 'fp32' else (3e-2, 6e-2)
+    assert abs(float(loss) - float(rloss)) <= lt
+    if dtype == 'fp32':
+        np.testing.assert_allclose(logits.detach().cpu().numpy(), rlogits.numpy(), rtol=3e-4, atol=3e-4)
+    gmax = max(float(g.abs().max()) for g in rgrads.values())
+    for k, p in m.named_parameters():
+        assert float((p.grad.cpu() - rgrads[k]).abs().max()) <= gt * gmax, k
+    # decode: the cached engine (not the persistent launch: it is built for ReLU) reproduces the full forward's last-position logits
+    m.eval()
+    eng = inf.make_engine(m, B, redraw=False)
+    assert eng.persist is None
+    x, sg = b['dec_input'].cuda(), b['track_mask'].cuda()
+    lg = eng.prefill(x[:, :T - 4], sg[:, :T - 4])
+    for t in range(T - 4, T):
+        lg = eng.step(x[:, t], sg[:, t])
+    with torch.no_grad():
+        full = m(x, seg_inp=sg, keep_last_only=True)
+    tol = 2e-4 if dtype == 'fp32' else 6e-2
+    assert float((lg.float() - full.float().view_as(lg)).abs().max()) <= tol * max(1.0, float(full.abs().max()))
