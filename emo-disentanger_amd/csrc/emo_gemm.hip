@@ -904,7 +904,7 @@ static int64_t choose_epi_splits(int64_t M, int64_t N, int64_t K) {
     const char* e = getenv("EMO_GEMM_EPI_SPLIT");                     // (read per call: tests toggle it in-process)
     if ((e && atoi(e) == 0) || (N & 7) || (K % (4 * G2_BK)) != 0) return 1;
     const int64_t tiles = cdiv64(M, GB_M) * cdiv64(N, GB_N);
-    // measured r04 (tools/ab_epi_split.sh, rocprofv3 per kernel): stage 1's K = 2048 dgrads on 64 tiles 48 -> 22 + 6 us with 4 splits; at 256 tiles
+    // measured r04 (same-box A/B script of that round, rocprofv3 per kernel; profiles/r04_ab_epi_split*): stage 1's K = 2048 dgrads on 64 tiles 48 -> 22 + 6 us with 4 splits; at 256 tiles
     // (batch-size-4 stage-2 dgrads) 2 splits only tie (52 -> 45 + 15 us: the 32 MB of fp32 partials cost what the second resident block gains)
     if (tiles > 128) return 1;
     // (K = 512 products on <= 64 tiles, 4 splits: 18.6 -> 13.4 + 5 us per launch, the step's kernel time unchanged at 89.9 vs 89.8 ms: not split)
