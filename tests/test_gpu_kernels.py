@@ -264,6 +264,23 @@ def test_gemm_persistent_256_tile_matches_reference(shape, monkeypatch):
             assert float((kept != kept0).float().mean()) < 1e-3
 
 
+def test_gemm_persistent_256_tile_leaves_other_shapes_to_the_other_kernels(monkeypatch):
+    # EMO_GEMM_P256=1 only takes M, N multiples of 256, K a multiple of 32 (>= 64), bf16 outputs, bias / dropout / residual epilogues: everything
+    # else must run (and be right) on the kernels it ran on before
+    ops = _ops()
+    monkeypatch.setenv('EMO_GEMM_P256', '1')
+    for (M, N, K), kw in (((300, 256, 64), {}), ((256, 200, 64), {}), ((256, 256, 48), {}), ((256, 256, 32), {}), ((512, 256, 128), dict(act=ops.ACT_RELU)),
+                          ((512, 256, 128), dict(out_dtype=torch.float32))):
+        pad = lambda n: (n + 7) // 8 * 8
+        A, W = _r(M, pad(K), seed=1).to(torch.bfloat16).cuda()[:, :K], _r(N, pad(K), seed=2, scale=0.1).to(torch.bfloat16).cuda()[:, :K]
+        y = ops.gemm(A, W, **kw)
+        assert ops.lib.emo_gemm_last_kernel() != 8, (M, N, K, kw)
+        ref = A.double() @ W.double().T
+        if kw.get('act') == ops.ACT_RELU:
+            ref = ref.clamp_min(0)
+        _close(y, ref, torch.bfloat16, mult=1.0)
+
+
 @pytest.mark.parametrize('shape', [(8192, 2048, 512), (16384, 512, 2048), (8192, 1536, 512)])
 def test_gemm_256_tile_wgrad_matches_reference_with_bias_gradient(shape, monkeypatch):
     # the wgrad instance of the same tile: token-major operands, split-K through the workspace, bias gradient by ones-MFMAs; with and
