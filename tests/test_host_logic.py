@@ -142,6 +142,45 @@ def test_data_parallel_plumbing_gloo_world2():
     assert x0 == x1 == 2.0                                 # bench timing = max over ranks
 
 
+def _rccl_init_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from emo_disentanger_amd import dp
+    dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+    try:
+        dp._init_rccl(rank, world)
+        q.put((rank, 'ok', ''))
+    except RuntimeError as e:
+        q.put((rank, 'raised', str(e)))
+    finally:
+        dist.barrier()                                     # every rank comes back out of the bring-up: nobody is left inside a collective
+        dist.destroy_process_group()
+
+
+def test_rccl_bringup_agrees_on_a_local_failure_world2():
+    """dp._init_rccl on a box without a GPU: binding RCCL or touching the device fails LOCALLY on the ranks — the steps in front of the
+    collective ncclCommInitRank end in agreements over the gloo control plane, so both ranks raise (the same outcome) and neither hangs
+    (a rank that failed before emo_comm_init used to leave the others blocked inside it)."""
+    import socket
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('needs a box without a GPU (here the bring-up would succeed or fail inside RCCL)')
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_rccl_init_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == ['raised', 'raised'], res
+    assert all('RCCL' in r[2] for r in res), res
+
+
 def test_checkpoint_contract_param_order_and_init_rule():
     """The reference resumes optimizers by PARAMETER ORDER (stock Adam.state_dict(), train.py:318-326) and loads flat state dicts
     (train.py:304-311): names, order and shapes must match the imported reference (fixture: named_parameters() of the real MusicGPT2),
