@@ -16,6 +16,7 @@ def t(f, it=10):
 b = n * 2
 tf = t(lambda: x.fill_(1.0)); print('fill  (write %.2f GB): %.1f us  = %.2f TB/s written' % (b / 1e9, tf * 1e6, b / tf / 1e12))
 tc = t(lambda: y.copy_(x)); print('copy  (read + write)  : %.1f us  = %.2f TB/s total (%.2f each way)' % (tc * 1e6, 2 * b / tc / 1e12, b / tc / 1e12))
-ts = t(lambda: x.view(torch.int16).sum()); print('sum   (read only)     : %.1f us  = %.2f TB/s read' % (ts * 1e6, b / ts / 1e12))
+xf = x.view(torch.float32)
+ts = t(lambda: xf.sum()); print('sum   (read only, fp32 view): %.1f us  = %.2f TB/s read' % (ts * 1e6, b / ts / 1e12))
 xs = x[: n // 4]
 tf2 = t(lambda: xs.fill_(2.0)); print('fill 0.5 GB           : %.1f us  = %.2f TB/s written' % (tf2 * 1e6, b / 4 / tf2 / 1e12))
