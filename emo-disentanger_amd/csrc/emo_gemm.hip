@@ -1088,11 +1088,13 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         g_last_gemm_kernel = 1;
         return EMO_OK;
     }
-    if (big && !a_trans && !b_trans && !ln_fused && !accumulate && !use_safe_tr() &&
-        emo_gemm_p256_try((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, dtype_out, M, N, K, ep, st)) {    // persistent 256 x 256 tile walk (r05)
-        EMO_LAUNCH_CHECK();
-        g_last_gemm_kernel = 8;
-        return EMO_OK;
+    if (big && !a_trans && !b_trans && !ln_fused && !accumulate && !use_safe_tr()) {
+        const int pk = emo_gemm_p256_try((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, dtype_out, M, N, K, ep, st);   // opt-in persistent tile walks (r05)
+        if (pk) {
+            EMO_LAUNCH_CHECK();
+            g_last_gemm_kernel = pk;                              // 8: 256 x 256 tile, 9: 128 x 512 tile
+            return EMO_OK;
+        }
     }
     if (big && !a_trans && !b_trans && !ln_fused && !use_safe_tr() &&
         emo_gemm_astat_try((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, dtype_out, M, N, K, ep, st)) {   // K = 512, A stationary in registers

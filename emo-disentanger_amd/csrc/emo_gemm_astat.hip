@@ -140,7 +140,8 @@ __device__ __forceinline__ void as_drop8(const DropCtx& d, uint32_t idx0, float 
 
 template <typename OutT, int FL>
 __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ C, int64_t ub, uint32_t lo, int nb, int ecol, int64_t db, uint32_t dl,
-                                        int64_t mb, uint32_t ml, float (&v)[8], const float* bias_lds, uint32_t pre_bits, uint32_t& mask_word, int mask_byte) {
+                                        int64_t mb, uint32_t ml, float (&v)[8], const float* bias_lds, uint32_t pre_bits, uint32_t& mask_word, int mask_byte,
+                                        const u32x4& pre_res) {
     // (the bias is already in the accumulators: they START from it)
     constexpr bool G = (FL & AF_GENERIC) != 0;
     if ((FL & AF_GELUAUX) || (G && ep.aux_out)) as_store_row8<OutT>((const OutT*)ep.aux_out + ub, lo, v);      // the pre-activation (gelu backward)
@@ -157,6 +158,11 @@ __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ 
     if (FL & AF_BITS) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] *= ((pre_bits >> i) & 1u) ? ep.mul_scale : 0.f;
+    } else if ((FL & AF_DGELU) && !(FL & (AF_GENERIC | AF_RES)) && sizeof(OutT) == 2) {   // *= gelu_new'(pre-activation), the row group prefetched (pre_res)
+        float t[8];
+        as_unpack8(pre_res, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= dgelu_new_fast(t[i]);
     } else if (FL & AF_DGELU) {                                   // *= gelu_new'(pre-activation): straight-line (the generic instance ran this at 250 TFLOP/s)
         float t0[4], t1[4];
         Out4<OutT>::load((const OutT*)ep.mul_aux + ub + lo, t0);
@@ -191,7 +197,12 @@ __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ 
         for (int i = 0; i < 8; ++i) bits |= (v[i] != 0.f ? 1u : 0u) << i;
         mask_word |= bits << (8 * mask_byte);                     // the tile's four bytes of this lane leave as ONE dword (caller)
     }
-    if ((FL & AF_RES) || (G && ep.residual)) {
+    if ((FL & AF_RES) && !G && sizeof(OutT) == 2) {               // the residual row group already in registers (inline-asm prefetch, r05)
+        float t[8];
+        as_unpack8(pre_res, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += t[i];
+    } else if ((FL & AF_RES) || (G && ep.residual)) {
         float t0[4], t1[4];
         Out4<OutT>::load((const OutT*)ep.residual + ub + lo, t0);
         Out4<OutT>::load((const OutT*)ep.residual + ub + lo + 4, t1);
@@ -205,18 +216,23 @@ __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ 
 }
 
 // BITS: the 1-bit mask operand (EMO_MUL_BITMASK, 1 byte per 8 columns) is prefetched by inline-asm loads half a stage before the epilogue.
-// (16-B residual / mask rows stay plain loads in the epilogue: prefetching them needs 16 more registers than the 256 the kernel has, and a
-// spilled inline-asm destination would be copied before its data arrives.)
+// RESP: the 16-B residual row groups of the bf16 straight-line instances likewise (r05: their registers are live from the last stage's middle to
+// the end of the epilogue only, where one of the four B fragment sets is dead).
 template <typename OutT, int FL>
 __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                            OutT* __restrict__ C, int64_t M, int64_t N, EpiParams ep) {
     constexpr bool BITS = (FL & AF_BITS) != 0;
+    // residual rows (AF_RES) or pre-activation rows (AF_DGELU) of the column tile prefetched like the mask word
+    constexpr bool RESP = ((FL & AF_RES) != 0 || (FL & (AF_DGELU | AF_RES)) == AF_DGELU) && (FL & AF_GENERIC) == 0 && sizeof(OutT) == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [4 slots x 16 KB ring][bias: N floats]
     float* bias_lds = (float*)(smem + AS_RING);                   // bias (or zeros): the accumulators of every column tile start from it
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t m0 = (int64_t)blockIdx.x * AS_BM + wave * 32;
     const int n_tiles = (int)(N / AS_BN), T = n_tiles * 4;
+#ifdef EMO_DIAG
+    const uint64_t t_entry = __builtin_readcyclecounter();
+#endif
 
     // bias -> registers first (oldest VMEM ops), -> LDS before the loop
     float bv[AS_MAXN / 256];
@@ -248,11 +264,14 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
     }
     const char* gB = (const char*)B;                              // wave-uniform: start of the NEXT stage to issue
     const int64_t tile_step = (int64_t)AS_BN * ldb * 2 - 3 * AS_KS * 2;
+    // LDS-DMA as inline asm with the SGPR-base addressing form (wave-uniform stage pointer + the lane's 32-bit offset): the builtin takes a
+    // per-lane 64-bit pointer, which cost two v_lshl_add_u64 per piece and kept the four offsets zero-extended in eight VGPRs (r05: the first
+    // thing hipcc spilled when the residual prefetch was added — and a reload is a scratch_load + s_waitcnt vmcnt(0) inside the ring).
+    const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem) + wave * 4096;
     auto issue = [&](int slot) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + src[jj]),
-                                             (__attribute__((address_space(3))) void*)(smem + slot * AS_SLOT + (wave * 4 + jj) * 1024), 16, 0, 0);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(src[jj]), "s"(gB), "s"(ring_lds + slot * AS_SLOT + jj * 1024) : "memory");
     };
     auto frags = [&](int slot, int ks, bf16x8 (&bf)[4]) {
 #pragma unroll
@@ -270,6 +289,12 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
         if (tid + 256 * q < (int)N) bias_lds[tid + 256 * q] = bv[q];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     as_wait<8>();                                                 // A fragments + stage 0 landed (stages 1, 2 may be in flight)
+    // (hipcc does not see the asm DMA or this wait: without the pin below it answers the FIRST use of every A fragment inside the unrolled
+    // loop body with its own countdown `s_waitcnt vmcnt(15) .. vmcnt(0)` — executed again in every column tile, draining the ring each time)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        asm volatile("" : "+v"(a[i][0]), "+v"(a[i][1]), "+v"(a[i][2]), "+v"(a[i][3]), "+v"(a[i][4]), "+v"(a[i][5]), "+v"(a[i][6]), "+v"(a[i][7]), "+v"(a[i][8]),
+                     "+v"(a[i][9]), "+v"(a[i][10]), "+v"(a[i][11]), "+v"(a[i][12]), "+v"(a[i][13]), "+v"(a[i][14]), "+v"(a[i][15]));
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     // B fragments: 4 rotating register sets (step g of a column tile computes with set g & 3 and prefetches step g + 2 into set (g + 2) & 3,
@@ -306,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
             acc[1][f] = b4;
         }
         uint32_t prew = 0;
+        u32x4 pres[4] = {};
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
 #pragma unroll
@@ -318,6 +344,16 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                         const char* op = (const char*)ep.mul_aux + mtile0 + nt * 256;                          // wave-uniform
                         prew = as_load4(op, (uint32_t)lane * 4);
                         as_wait<5>();
+                    } else if (RESP && kc == 2) {                 // the residual rows of this column tile (4 x 16 B per lane), 2.5 stages before their use
+                        const char* rp = (const char*)((FL & AF_RES) ? ep.residual : ep.mul_aux) + ((m0 * ep.ldc + (int64_t)nt * AS_BN) << 1);   // (wave-uniform).  In the epilogue each of
+                        const uint32_t vo = eoff0 * 2;            // the four plain loads was a full HBM round trip (tools/astat_cycles.py: 13.7 k cycles per
+                        pres[0] = as_load16<0>(rp, vo);           // column tile against 2 k of MFMA issue).  vmcnt retires in order, so the lead cannot
+                        pres[1] = as_load16<64>(rp, vo);          // exceed the ring: the stage issued behind these loads is needed 2 stages later
+                        pres[2] = as_load16<0>(rp + ((16 * ep.ldc) << 1), vo);
+                        pres[3] = as_load16<64>(rp + ((16 * ep.ldc) << 1), vo);
+                        as_wait<8>();
+                    } else if (RESP && kc == 3) {
+                        as_wait<8>();                             // stage s+1 landed; behind it: the residual rows and stage s+2
                     } else {
 #ifdef EMO_DIAG
                         if (ep.ablate != 2)
@@ -353,6 +389,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
         const uint64_t te0 = __builtin_readcyclecounter();
 #endif
         if (BITS) as_pinw<4>(prew);                               // one refill (4 DMA ops) was issued after the mask word
+        if (RESP) as_pin<4>(pres);
         uint32_t mask_word = 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -364,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                 uint32_t lo = eoff0;
                 asm volatile("" : "+v"(lo));                     // opaque per tile: keeps (base + lane offset) out of loop-invariant 64-bit VGPR pointers
                 as_epi8<OutT, FL>(ep, C, (m0 + 16 * i) * ep.ldc + nb, lo, nb, ecol, (m0 + 16 * i) * N + nb, doff0, mtile0 + nt * 256, (uint32_t)lane, v, bias_lds,
-                                    (prew >> (8 * (i * 2 + h))) & 0xFFu, mask_word, i * 2 + h);
+                                    (prew >> (8 * (i * 2 + h))) & 0xFFu, mask_word, i * 2 + h, pres[i * 2 + h]);
                 __builtin_amdgcn_sched_barrier(0);               // one 8-column group at a time: keeps the epilogue's temporaries out of the register peak
             }
         if ((FL & AF_MASKOUT) || ((FL & AF_GENERIC) && ep.mask_out)) as_store4(ep.mask_out + mtile0 + nt * 256, (uint32_t)lane * 4, mask_word);
@@ -379,6 +416,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
         atomicAdd(dg + 1, (unsigned long long)t_epi);
         atomicAdd(dg + 2, (unsigned long long)(__builtin_readcyclecounter() - t_loop0));
         atomicAdd(dg + 3, 1ull);
+        atomicAdd(dg + 4, (unsigned long long)(t_loop0 - t_entry));       // panel load + prologue
     }
 #endif
     as_wait<0>();                                                 // the run-ahead refills past the last stage must land before the LDS is released
@@ -425,7 +463,8 @@ bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t l
     else if (other) AS_LAUNCH(bf16_t, AF_GENERIC);
     else if (fl == 0) AS_LAUNCH(bf16_t, 0);
     else if (fl == AF_RELU) AS_LAUNCH(bf16_t, AF_RELU);
-    else if (fl == (AF_RELU | AF_DROP)) AS_LAUNCH(bf16_t, AF_RELU | AF_DROP);
+    // (relu + dropout WITHOUT the mask output — no caller in the training or decoding paths — runs the generic instance: its straight-line
+    // instantiation no longer fits 256 VGPRs without an in-loop reload, which drains the ring)
     else if (fl == (AF_RELU | AF_DROP | AF_MASKOUT)) AS_LAUNCH(bf16_t, AF_RELU | AF_DROP | AF_MASKOUT);
     else if (fl == AF_RES) AS_LAUNCH(bf16_t, AF_RES);
     else if (fl == (AF_DROP | AF_RES)) AS_LAUNCH(bf16_t, AF_DROP | AF_RES);

@@ -215,7 +215,7 @@ bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t l
 bool emo_gemm_w128_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int dtype_out, int64_t M, int64_t N, int64_t K,
                        const EpiParams& ep, hipStream_t st);
 // persistent 256 x 256 tile walk, 32 x 32 x 16 MFMA (emo_gemm_p256.hip, r05): true when eligible and queued.
-bool emo_gemm_p256_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int dtype_out, int64_t M, int64_t N, int64_t K,
+int emo_gemm_p256_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int dtype_out, int64_t M, int64_t N, int64_t K,
                        const EpiParams& ep, hipStream_t st);
 // the same tile for the wgrad layout (A stored [K, M], B stored [K, N], fp32 out, split-K through the caller's workspace)
 int64_t emo_gemm_w128_tn_splits(int64_t M, int64_t N, int64_t K);

@@ -398,24 +398,272 @@ __global__ __launch_bounds__(256, 1) void gemm_p256_kernel(const bf16_t* __restr
 #endif
     p_vmwait<0>();
 }
+
+// ================================================================================================ 128 x 512 tile ("full N"), r05
+// Same machinery, other tile: a workgroup owns 128 rows x 512 columns (wave w: all 128 rows x columns 128 w ..).  Why: with N = 512 the 256 x
+// 256 tiling reads every A row panel from TWO workgroups, which share it through the L2 only while they run in step (measured fetch 1.2-1.4 x
+// the algorithmic bytes on products that are bound by that stream); here every A byte is requested once, and a lane's two accumulator tiles of
+// a 64-column group are 32 consecutive columns, so the four 16-B stores of a row group complete a 128-B line back to back.  Price: the 2-MB
+// weight matrix is streamed from the L2 once per 128 rows instead of once per 256 (1.25 x the L2 -> LDS bytes per flop).
+// Rings: A (the HBM stream) 8 stages x 8 KB, requested 8 slabs ahead; B (L2-resident weights) 3 stages x 32 KB, requested 3 ahead.  A slab =
+// 2 A pieces + 8 B pieces per wave, five per k-step (A first) in gaps 3 / 6 / 9 / 12 / 15; the slab sync lets the 10 newest pieces in flight.
+constexpr int Q_BM = 128, Q_BN = 512, Q_NSA = 8, Q_NSB = 3, Q_SLABA = 128 * P_BK * 2, Q_SLABB = 512 * P_BK * 2;
+constexpr int Q_BOFF = Q_NSA * Q_SLABA, Q_LDS = Q_BOFF + Q_NSB * Q_SLABB;      // 64 KB + 96 KB
+static_assert(Q_LDS == 160 * 1024, "LDS carve");
+
+// k-step of the 128 x 512 tile: B fragments at rows 64 (j >> 1) + 16 (j & 1) of the wave's 128 (immediates 0 / 1024 / 4096 / 5120)
+template <bool INIT, int KS, bool READ>
+__device__ __forceinline__ void q_kstep(f32x16 (&acc)[4][4], bf16x8 (&fa)[2][4], bf16x8 (&fb)[2][4], uint32_t rdA, uint32_t rdB, uint32_t voffA, i32x4 rsA,
+                                        uint32_t soffA, uint32_t m0A, uint32_t voffB, i32x4 rsB, const uint32_t (&soffB)[4], uint32_t m0B) {
+    constexpr int CUR = KS, NXT = KS ^ 1;
+#define Q_MMA(i, j)                                              \
+    do {                                                         \
+        if (INIT) p_mma0(acc[i][j], fb[CUR][j], fa[CUR][i]);     \
+        else p_mma(acc[i][j], fb[CUR][j], fa[CUR][i]);           \
+    } while (0)
+    Q_MMA(0, 0); if (READ) { p_rd<0>(fb[NXT][0], rdB); p_rd<1024>(fb[NXT][1], rdB); }
+    Q_MMA(0, 1); p_m0_set(m0A);
+    Q_MMA(0, 2); if (READ) { p_rd<4096>(fb[NXT][2], rdB); p_rd<5120>(fb[NXT][3], rdB); }
+    Q_MMA(0, 3); p_dma(voffA, rsA, soffA);
+    Q_MMA(1, 0); if (READ) { p_rd<0>(fa[NXT][0], rdA); p_rd<2048>(fa[NXT][1], rdA); } p_m0_set(m0B);
+    Q_MMA(1, 1);
+    Q_MMA(1, 2); if (READ) { p_rd<4096>(fa[NXT][2], rdA); p_rd<6144>(fa[NXT][3], rdA); } p_dma(voffB, rsB, soffB[0]);
+    Q_MMA(1, 3); p_m0_add();
+    Q_MMA(2, 0);
+    Q_MMA(2, 1); p_dma(voffB, rsB, soffB[1]);
+    Q_MMA(2, 2); p_m0_add();
+    Q_MMA(2, 3);
+    Q_MMA(3, 0); p_dma(voffB, rsB, soffB[2]);
+    Q_MMA(3, 1); p_m0_add();
+    Q_MMA(3, 2);
+    Q_MMA(3, 3); p_dma(voffB, rsB, soffB[3]);
+#undef Q_MMA
+    if (READ) p_lgkm0();
+}
+__device__ __forceinline__ void q_read_set0(bf16x8 (&fa)[2][4], bf16x8 (&fb)[2][4], uint32_t rdA, uint32_t rdB) {
+    p_rd<0>(fb[0][0], rdB); p_rd<1024>(fb[0][1], rdB); p_rd<4096>(fb[0][2], rdB); p_rd<5120>(fb[0][3], rdB);
+    p_rd<0>(fa[0][0], rdA); p_rd<2048>(fa[0][1], rdA); p_rd<4096>(fa[0][2], rdA); p_rd<6144>(fa[0][3], rdA);
+    p_lgkm0();
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256, 1) void gemm_q512_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                          OutT* __restrict__ C, int64_t M, int64_t N, int64_t K, EpiParams ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (int)(N / Q_BN), tiles_m = (int)(M / Q_BM), nk = (int)(K / P_BK);
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3, nslot = (int)(gridDim.x >> 3);
+    const int panels = tiles_m > xcd ? (tiles_m - xcd + 7) / 8 : 0;
+    const int n_local = panels * tiles_n;
+    const int n_mine = n_local > slot ? (n_local - slot + nslot - 1) / nslot : 0;
+    if (n_mine == 0) return;
+
+    const uint32_t voffA = (uint32_t)(((lane >> 2) * lda + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2);
+    const uint32_t voffB = (uint32_t)(((lane >> 2) * ldb + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2);
+    uint32_t soffA[2], soffB[2][4];                               // this wave's pieces of a slab: A rows 16 (2 wave + p), B rows 128 wave + 16 p
+#pragma unroll
+    for (int p_ = 0; p_ < 2; ++p_) soffA[p_] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(16 * (2 * wave + p_) * lda * 2));
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) soffB[hf][p_] = (uint32_t)__builtin_amdgcn_readfirstlane((int)((128 * wave + 16 * (4 * hf + p_)) * ldb * 2));
+    const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p_lds_addr(smem));
+    const uint32_t dstA0 = lds0 + wave * 2048, dstB0 = lds0 + Q_BOFF + wave * 8192;      // + stage * slab (+ 1024 / 4096 for the second half)
+    const int ml = lane & 31;
+    const int pi2 = 32 * ((ml >> 2) & 1) + 4 * (ml >> 3) + (ml & 3);
+    const uint32_t foA = lds0 + (uint32_t)(ml * 64 + ((((lane >> 5) ^ ((lane >> 2) & 3))) << 4));
+    const uint32_t foB = lds0 + (uint32_t)(Q_BOFF + (128 * wave + pi2) * 64 + ((((lane >> 5) ^ ((lane >> 3) & 3))) << 4));
+
+    auto set_tile = [&](PStream& s_, const bf16_t* base, int64_t ld, bool is_a) {
+        const int local = slot + nslot * s_.it;
+        const int tn = local % tiles_n, tm = (local / tiles_n) * 8 + xcd;
+        const uint64_t p_ = (uint64_t)(uintptr_t)(base + (is_a ? (int64_t)tm * Q_BM : (int64_t)tn * Q_BN) * ld);
+        s_.rs[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)p_);
+        s_.rs[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(p_ >> 32));
+        s_.rs[2] = 0x7FFFFFFE;
+        s_.rs[3] = 0x00020000;
+    };
+    PStream sA, sB;
+    sA.it = sA.k = sB.it = sB.k = 0;
+    set_tile(sA, A, lda, true);
+    set_tile(sB, B, ldb, false);
+    auto advance = [&](PStream& s_, const bf16_t* base, int64_t ld, bool is_a) {
+        if (__builtin_expect(++s_.k == nk, 0)) {
+            s_.k = 0;
+            s_.it = s_.it + 1 < n_mine ? s_.it + 1 : n_mine - 1;
+            set_tile(s_, base, ld, is_a);
+        } else {
+            const uint64_t b_ = (((uint64_t)(uint32_t)s_.rs[1] << 32) | (uint32_t)s_.rs[0]) + P_BK * 2;
+            s_.rs[0] = (int)(uint32_t)b_;
+            s_.rs[1] = (int)(uint32_t)(b_ >> 32);
+        }
+    };
+    int isA = 0, isB = 0;                                         // ring stages of the next A / B slab to request
+    auto issue_half_plain = [&](int hf) {                         // prologue form of what a k-step issues: A piece hf, B pieces 4 hf .. 4 hf + 3
+        p_m0_set(dstA0 + isA * Q_SLABA + hf * 1024);
+        asm volatile("s_nop 0");
+        p_dma(voffA, sA.rs, soffA[hf]);
+        p_m0_set(dstB0 + isB * Q_SLABB + hf * 4096);
+        asm volatile("s_nop 0");
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) {
+            p_dma(voffB, sB.rs, soffB[hf][p_]);
+            if (p_ < 3) { p_m0_add(); asm volatile("s_nop 0"); }
+        }
+    };
+    // ---- prologue.  Steady state: the slab requested behind the sync of slab g is (A of g + 8, B of g + 3), first half in k-step 1 of g, second
+    // half in k-step 0 of g + 1.  The two rings have different depths, so A runs ahead first: A slabs 0 .. 4 alone, then (A 5, B 0), (A 6, B 1)
+    // in full and the first half of (A 7, B 2); k-step 0 of slab 0 issues its second half.
+    auto issue_a_plain = [&]() {
+        p_m0_set(dstA0 + isA * Q_SLABA);
+        asm volatile("s_nop 0");
+        p_dma(voffA, sA.rs, soffA[0]);
+        p_m0_add();
+        asm volatile("s_nop 0");
+        p_dma(voffA, sA.rs, soffA[1]);
+        advance(sA, A, lda, true);
+        isA = isA == Q_NSA - 1 ? 0 : isA + 1;
+    };
+    auto step_both = [&]() {
+        advance(sA, A, lda, true);
+        isA = isA == Q_NSA - 1 ? 0 : isA + 1;
+        advance(sB, B, ldb, false);
+        isB = isB == Q_NSB - 1 ? 0 : isB + 1;
+    };
+#pragma unroll 1
+    for (int s_ = 0; s_ < 5; ++s_) issue_a_plain();               // 10 pieces
+#pragma unroll 1
+    for (int s_ = 0; s_ < 2; ++s_) { issue_half_plain(0); issue_half_plain(1); step_both(); }      // 20 pieces
+    issue_half_plain(0);                                          // 5 pieces: 35 in flight
+    f32x16 acc[4][4];
+    bf16x8 fa[2][4], fb[2][4];
+    p_vmwait<15>();                                               // A 0 .. A 4 and B 0 landed (behind B 0: A 6 / B 1 in full and half of A 7 / B 2 = 15 pieces)
+    p_barrier();
+    q_read_set0(fa, fb, foA, foB);
+    int scA = 0, scB = 0;
+#define Q_SLAB_BODY(FIRST, LAST)                                                                                                       \
+    do {                                                                                                                               \
+        {                                                                                                                              \
+            const uint32_t rdA = (foA + scA * Q_SLABA) ^ 32u, rdB = (foB + scB * Q_SLABB) ^ 32u;                                       \
+            q_kstep<FIRST, 0, true>(acc, fa, fb, rdA, rdB, voffA, sA.rs, soffA[1], dstA0 + isA * Q_SLABA + 1024, voffB, sB.rs, soffB[1],  \
+                                    dstB0 + isB * Q_SLABB + 4096);                                                                     \
+            step_both();                                                                                                               \
+        }                                                                                                                              \
+        if ((FIRST) && itC > 0) p_vmwait<5>();                                                                                         \
+        else p_vmwait<10>();                                                                                                           \
+        p_barrier();                                                                                                                   \
+        {                                                                                                                              \
+            const int snA = scA == Q_NSA - 1 ? 0 : scA + 1, snB = scB == Q_NSB - 1 ? 0 : scB + 1;                                      \
+            q_kstep<false, 1, !(LAST)>(acc, fa, fb, foA + snA * Q_SLABA, foB + snB * Q_SLABB, voffA, sA.rs, soffA[0], dstA0 + isA * Q_SLABA,  \
+                                       voffB, sB.rs, soffB[0], dstB0 + isB * Q_SLABB);                                                 \
+            scA = snA;                                                                                                                 \
+            scB = snB;                                                                                                                 \
+        }                                                                                                                              \
+    } while (0)
+#pragma unroll 1
+    for (int itC = 0; itC < n_mine; ++itC) {
+        Q_SLAB_BODY(true, false);
+#pragma unroll 1
+        for (int kC = 2; kC < nk; ++kC) Q_SLAB_BODY(false, false);
+        Q_SLAB_BODY(false, true);
+        {
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            const int local = slot + nslot * itC;
+            const int64_t n0 = (int64_t)(local % tiles_n) * Q_BN + 128 * wave, m0 = (int64_t)((local / tiles_n) * 8 + xcd) * Q_BM;
+            const int h = lane >> 5;
+            const OutT* rp = (const OutT*)ep.residual;
+            // eight groups (row block i, 64-column group J): a lane holds 32 consecutive columns of one row = accumulator tiles (i, 2 J), (i, 2 J + 1)
+            auto rload = [&](int b_, bf16x8 (&r)[4]) {
+                const int64_t m = m0 + 32 * (b_ >> 1) + ml, n = n0 + 64 * (b_ & 1) + 32 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r[q] = *(const bf16x8*)(rp + m * ep.ldc + n + 8 * q);
+            };
+            bf16x8 rcur[4], rnxt[4];
+            if (rp) rload(0, rcur);
+#pragma clang loop unroll(full)
+            for (int b_ = 0; b_ < 8; ++b_) {
+                const int i = b_ >> 1, J = b_ & 1;
+                const int64_t m = m0 + 32 * i + ml, n = n0 + 64 * J + 32 * h;
+                if (rp && b_ < 7) rload(b_ + 1, rnxt);
+                float v[32];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { v[r] = acc[i][2 * J][r]; v[16 + r] = acc[i][2 * J + 1][r]; }
+                if (ep.bias) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const f32x4 bq = *(const f32x4*)(ep.bias + n + 4 * q);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[4 * q + r] += bq[r];
+                    }
+                }
+                if (ep.drop.thr16) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) p_drop8(ep.drop, (uint64_t)(m * N + n + 8 * q), v + 8 * q);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[r] = (bf16_t)(rp ? v[8 * q + r] + (float)rcur[q][r] : v[8 * q + r]);
+                    *(bf16x8*)(C + m * ep.ldc + n + 8 * q) = o;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rcur[q] = rnxt[q];
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("" ::: "memory");
+            if (itC + 1 < n_mine) q_read_set0(fa, fb, foA + scA * Q_SLABA, foB + scB * Q_SLABB);
+        }
+    }
+#undef Q_SLAB_BODY
+    p_vmwait<0>();
+}
 }  // namespace
 
 // NT bf16 product on the persistent 256 x 256 kernel; true when the shape is eligible and the launch was queued.
 // EMO_GEMM_P256: 1 = every eligible shape (tests, tools/bench_p256.py), 2 = long reductions with at least one tile per CU; unset / 0 = off
 // (r05: behind the tile-per-block kernel inside the training step, see the header and profiles/r05_gemm_isa_diff.txt).
-bool emo_gemm_p256_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int dtype_out, int64_t M, int64_t N, int64_t K,
-                       const EpiParams& ep, hipStream_t st) {
-    const char* e = getenv("EMO_GEMM_P256");                   // (read per call: tests toggle it in-process)
+// 128 x 512 tile (gemm_q512_kernel): EMO_GEMM_Q512 = 1 every eligible shape, 2 long reductions only; EMO_Q512_PERSIST=1: one workgroup per CU
+// walking its tiles instead of one tile per workgroup.
+static bool emo_gemm_q512_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int dtype_out, int64_t M, int64_t N, int64_t K,
+                              const EpiParams& ep, hipStream_t st) {
+    const char* e = getenv("EMO_GEMM_Q512");
     const int mode = e ? atoi(e) : 0;
     if (mode <= 0) return false;
-    if ((M % P_BM) || (N % P_BN) || (K % P_BK) || K < 2 * P_BK || dtype_out != EMO_BF16) return false;
-    if (mode == 2 && (K < 1024 || (M / P_BM) * (N / P_BN) < 256)) return false;
+    if ((M % Q_BM) || (N % Q_BN) || (K % P_BK) || K < 2 * P_BK || dtype_out != EMO_BF16) return false;
+    if (mode == 2 && (K < 1024 || (M / Q_BM) * (N / Q_BN) < 256)) return false;
     if (ep.atomic || ep.accumulate || ep.ws_stride || ep.a_rowsum || ep.b_rowsum || ep.ln_c1 || ep.rln_x || ep.mask_out) return false;
-    if (ep.aux_out || ep.mul_mode != EMO_MUL_NONE || ep.act != EMO_ACT_NONE) return false;       // register epilogue: bias, dropout, residual
+    if (ep.aux_out || ep.mul_mode != EMO_MUL_NONE || ep.act != EMO_ACT_NONE) return false;
     if ((lda & 7) || (ldb & 7) || (ep.ldc & 7) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return false;
     if (ep.residual && ((uintptr_t)ep.residual & 15)) return false;
     if (ep.bias && ((uintptr_t)ep.bias & 15)) return false;
-    if ((uint64_t)(256 * (lda > ldb ? lda : ldb) + 64) * 2 >= 0x7FFF0000ull) return false;
+    if ((uint64_t)(512 * (lda > ldb ? lda : ldb) + 64) * 2 >= 0x7FFF0000ull) return false;
+    const int64_t tiles = (M / Q_BM) * (N / Q_BN);
+    int64_t nslot = (tiles + 7) / 8;
+    { const char* e2 = getenv("EMO_Q512_PERSIST"); if (e2 && atoi(e2) && nslot > 32) nslot = 32; }
+    auto k = gemm_q512_kernel<bf16_t>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS); attr = true; }
+    hipLaunchKernelGGL(k, dim3((unsigned)(8 * nslot)), dim3(256), Q_LDS, st, A, lda, B, ldb, (bf16_t*)C, M, N, K, ep);
+    return true;
+}
+
+int emo_gemm_p256_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int dtype_out, int64_t M, int64_t N, int64_t K,
+                      const EpiParams& ep, hipStream_t st) {
+    if (emo_gemm_q512_try(A, lda, B, ldb, C, dtype_out, M, N, K, ep, st)) return 9;
+    const char* e = getenv("EMO_GEMM_P256");                   // (read per call: tests toggle it in-process)
+    const int mode = e ? atoi(e) : 0;
+    if (mode <= 0) return 0;
+    if ((M % P_BM) || (N % P_BN) || (K % P_BK) || K < 2 * P_BK || dtype_out != EMO_BF16) return 0;
+    if (mode == 2 && (K < 1024 || (M / P_BM) * (N / P_BN) < 256)) return 0;
+    if (ep.atomic || ep.accumulate || ep.ws_stride || ep.a_rowsum || ep.b_rowsum || ep.ln_c1 || ep.rln_x || ep.mask_out) return 0;
+    if (ep.aux_out || ep.mul_mode != EMO_MUL_NONE || ep.act != EMO_ACT_NONE) return 0;       // register epilogue: bias, dropout, residual
+    if ((lda & 7) || (ldb & 7) || (ep.ldc & 7) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return 0;
+    if (ep.residual && ((uintptr_t)ep.residual & 15)) return 0;
+    if (ep.bias && ((uintptr_t)ep.bias & 15)) return 0;
+    if ((uint64_t)(256 * (lda > ldb ? lda : ldb) + 64) * 2 >= 0x7FFF0000ull) return 0;
     const int64_t tiles = (M / P_BM) * (N / P_BN);
     int64_t nslot = (tiles + 7) / 8;
     if (nslot > 32) nslot = 32;                                // one workgroup per CU
@@ -432,5 +680,5 @@ bool emo_gemm_p256_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ld
     } while (0)
     switch (sched) { case 1: P_LAUNCH(1); break; case 2: P_LAUNCH(2); break; case 3: P_LAUNCH(3); break; case 4: P_LAUNCH(4); break; case 5: P_LAUNCH(5); break; case 6: P_LAUNCH(6); break; case 7: P_LAUNCH(7); break; case 8: P_LAUNCH(8); break; default: P_LAUNCH(0); }
 #undef P_LAUNCH
-    return true;
+    return 8;
 }

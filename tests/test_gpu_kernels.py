@@ -264,6 +264,37 @@ def test_gemm_persistent_256_tile_matches_reference(shape, monkeypatch):
             assert float((kept != kept0).float().mean()) < 1e-3
 
 
+@pytest.mark.parametrize('shape', [(128, 512, 64), (1152, 512, 256), (256, 1024, 2048), (65536, 512, 1536)])
+@pytest.mark.parametrize('persist', ['0', '1'])
+def test_gemm_full_n_tile_matches_reference(shape, persist, monkeypatch):
+    # gemm_q512_kernel (emo_gemm_p256.hip, r05, opt-in EMO_GEMM_Q512=1): 128 x 512 tile — every A byte requested once, a lane's outputs complete
+    # 128-B lines; A ring 8 slabs deep, B ring 3.  One tile per block and (EMO_Q512_PERSIST=1) blocks walking several tiles with the two operand
+    # streams crossing tile boundaries at different times; K = 64 (first slab is also the last); N = 1024 (two column tiles per row panel).
+    ops = _ops()
+    monkeypatch.setenv('EMO_GEMM_EPI_SPLIT', '0')
+    monkeypatch.setenv('EMO_Q512_PERSIST', persist)
+    M, N, K = shape
+    A, W = _r(M, K, seed=1).to(torch.bfloat16).cuda(), _r(N, K, seed=2, scale=0.1).to(torch.bfloat16).cuda()
+    bias, res = _r(N, seed=3).cuda(), _r(M, N, seed=4).to(torch.bfloat16).cuda()
+    for kw in ({}, dict(bias=bias, residual=res), dict(bias=bias, p_drop=0.1, seed=5, offset=7, residual=res)):
+        monkeypatch.setenv('EMO_GEMM_Q512', '1')
+        y1 = ops.gemm(A, W, **kw)
+        assert ops.lib.emo_gemm_last_kernel() == 9
+        monkeypatch.setenv('EMO_GEMM_Q512', '0')
+        y0 = ops.gemm(A, W, **kw)
+        assert ops.lib.emo_gemm_last_kernel() != 9
+        if 'p_drop' not in kw:
+            rows = slice(0, M) if M <= 8192 else slice(M - 4096, M)
+            ref = A[rows].double() @ W.double().T + (bias.double() if 'bias' in kw else 0.0) + (res[rows].double() if 'residual' in kw else 0.0)
+            _close(y1[rows], ref, torch.bfloat16, mult=1.0)
+        assert float((y1.float() - y0.float()).abs().max()) <= 0.02 * float(y0.float().abs().max())
+        if 'p_drop' in kw:
+            base = ops.gemm(A, W, bias=bias).float()
+            kept = (y1.float() - res.float()).abs() > 1e-6 * (1 + base.abs())
+            kept0 = (y0.float() - res.float()).abs() > 1e-6 * (1 + base.abs())
+            assert float((kept != kept0).float().mean()) < 1e-3
+
+
 def test_gemm_persistent_256_tile_leaves_other_shapes_to_the_other_kernels(monkeypatch):
     # EMO_GEMM_P256=1 only takes M, N multiples of 256, K a multiple of 32 (>= 64), bf16 outputs, bias / dropout / residual epilogues: everything
     # else must run (and be right) on the kernels it ran on before

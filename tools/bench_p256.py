@@ -28,8 +28,12 @@ if os.environ.get('ONLY'):
     SHAPES = [s for s in SHAPES if os.environ['ONLY'] in s[0]]
 
 
+VARIANT = os.environ.get('VARIANT', 'p256')                    # p256: the 256 x 256 persistent kernel; q512: the 128 x 512 ("full N") tile
+
+
 def run(mode, a, w, o, kw):
-    os.environ['EMO_GEMM_P256'] = mode
+    os.environ['EMO_GEMM_P256'] = mode if VARIANT == 'p256' else '0'
+    os.environ['EMO_GEMM_Q512'] = mode if VARIANT == 'q512' else '0'
     return ops.gemm(a, w, out=o, **kw)
 
 
@@ -67,6 +71,7 @@ for name, n, k, spec in SHAPES:
             res.setdefault(mode, []).append(e0.elapsed_time(e1) / ITER * 1e3)
     fl = 2.0 * M * n * k
     t1, t0 = min(res['1']), min(res['0'])
-    print('%-38s p256 (kernel %d) %7.1f us = %6.1f TFLOP/s = %.3f of 2.5 PF | before (kernel %d) %7.1f us = %6.1f | max |diff| %.3g of %.3g %s' %
+    print('%-38s new  (kernel %d) %7.1f us = %6.1f TFLOP/s = %.3f of 2.5 PF | before (kernel %d) %7.1f us = %6.1f | max |diff| %.3g of %.3g %s' %
           (name, k1, t1, fl / t1 / 1e6, fl / t1 / 1e6 / 2500, k0, t0, fl / t0 / 1e6, diff, scale, '' if diff <= 0.02 * scale else '<-- MISMATCH'), flush=True)
 os.environ.pop('EMO_GEMM_P256', None)
+os.environ.pop('EMO_GEMM_Q512', None)
