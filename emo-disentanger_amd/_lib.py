@@ -79,6 +79,7 @@ _SIG = {
     'emo_cast': (c_i, [c_p, c_i, c_p, c_i, c_l, c_p]),
     'emo_add_bias2': (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_i, c_l, c_l, c_p]),
     'emo_transpose_batch': (c_i, [c_p, c_i, c_l, c_p]),
+    'emo_stream_wait': (c_i, [c_p, c_p]),
     'emo_comm_bind': (c_i, []),
     'emo_comm_unique_id': (c_i, [c_p]),
     'emo_comm_init': (c_i, [c_p, c_i, c_i]),
@@ -120,4 +121,7 @@ def ptr(t):
 
 
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t of torch's current stream on the current device.  (The raw getter: `torch.cuda.current_stream().cuda_stream` builds a Stream
+    object through four layers of Python per call — 8.5 us, ~200 calls per training step, a quarter of the host time that BOUNDS the step at the
+    reference YAML's batch size 4; tools/b4_host_profile.py, r05.)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())

@@ -1048,6 +1048,25 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(const int64_t* __r
     }
 }
 
+// `waiter` continues only after everything queued on `signaler` so far: one event record + one stream wait.  Events come from a small per-thread
+// ring (a wait holds the record it was issued behind, so re-recording an event 32 forks later cannot disturb it).
+extern "C" int emo_stream_wait(emo_stream_t waiter, emo_stream_t signaler) {
+    constexpr int RING = 32;
+    static thread_local hipEvent_t ev[RING] = {};
+    static thread_local int next = 0;
+    hipEvent_t& e = ev[next];
+    next = (next + 1) % RING;
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        emo_set_error("emo_stream_wait: hipEventCreate failed");
+        return EMO_ERR_LAUNCH;
+    }
+    if (hipEventRecord(e, (hipStream_t)signaler) != hipSuccess || hipStreamWaitEvent((hipStream_t)waiter, e, 0) != hipSuccess) {
+        emo_set_error("emo_stream_wait: %s", hipGetErrorString(hipGetLastError()));
+        return EMO_ERR_LAUNCH;
+    }
+    return EMO_OK;
+}
+
 extern "C" int emo_transpose_batch(const int64_t* desc, int n, int64_t total_tiles, emo_stream_t stream) {
     EMO_CHECK(desc && n > 0 && total_tiles > 0, "emo_transpose_batch: bad args");
     hipLaunchKernelGGL(transpose_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, desc, n);

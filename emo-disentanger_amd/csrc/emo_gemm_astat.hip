@@ -23,7 +23,7 @@
 
 namespace {
 constexpr int AS_K = 512, AS_BM = 128, AS_BN = 64, AS_KS = 128, AS_SLOT = AS_BN * AS_KS * 2, AS_RING = 4 * AS_SLOT;
-constexpr int AS_MIN_BLOCKS = 256;                             // = EMO_ASTAT_MIN_ROWS / 128 (ops.gemm_bitmask_ok mirrors it)
+constexpr int AS_MIN_BLOCKS = 32;                              // = ops.ASTAT_MIN_ROWS / 128 (ops.gemm_bitmask_ok mirrors it): below one panel per CU the columns are split
 constexpr int AS_MAXN = 2048;                                   // bias copy in LDS: 8 KB
 
 __device__ __forceinline__ int as_swz(int row) { return (row & 3) | ((row >> 1) & 12); }
@@ -220,7 +220,7 @@ __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ 
 // the end of the epilogue only, where one of the four B fragment sets is dead).
 template <typename OutT, int FL>
 __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
-                                                           OutT* __restrict__ C, int64_t M, int64_t N, EpiParams ep) {
+                                                           OutT* __restrict__ C, int64_t M, int64_t N, EpiParams ep, int tiles_per_block) {
     constexpr bool BITS = (FL & AF_BITS) != 0;
     // residual rows (AF_RES) or pre-activation rows (AF_DGELU) of the column tile prefetched like the mask word
     constexpr bool RESP = ((FL & AF_RES) != 0 || (FL & (AF_DGELU | AF_RES)) == AF_DGELU) && (FL & AF_GENERIC) == 0 && sizeof(OutT) == 2;
@@ -229,7 +229,9 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t m0 = (int64_t)blockIdx.x * AS_BM + wave * 32;
-    const int n_tiles = (int)(N / AS_BN), T = n_tiles * 4;
+    // column split (r05, token counts below one panel per CU — the reference YAML's batch size 4): blockIdx.y sweeps only the column tiles
+    // nt0 .. nt0 + n_tiles - 1 of its row panel, so that M / 128 panels still give every CU a block (the panel is re-read from the L2)
+    const int n_tiles_all = (int)(N / AS_BN), n_tiles = tiles_per_block, nt0 = (int)blockIdx.y * tiles_per_block;
 #ifdef EMO_DIAG
     const uint64_t t_entry = __builtin_readcyclecounter();
 #endif
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
     // bias -> registers first (oldest VMEM ops), -> LDS before the loop
     float bv[AS_MAXN / 256];
 #pragma unroll
-    for (int q = 0; q < AS_MAXN / 256; ++q) bv[q] = (ep.bias && tid + 256 * q < (int)N) ? ep.bias[tid + 256 * q] : 0.f;
+    for (int q = 0; q < AS_MAXN / 256; ++q) bv[q] = (ep.bias && tid + 256 * q < n_tiles * AS_BN) ? ep.bias[nt0 * AS_BN + tid + 256 * q] : 0.f;
 
     // ---- the wave's 32 x 512 slice of A, directly in MFMA operand layout (lane: row lane%16, 8 consecutive k at 8*(lane/16))
     bf16x8 a[2][16];
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
         const int row = as_nrow(f, lane & 15);
         rd[f] = (uint32_t)(row * 256 + (((lane >> 4) ^ as_swz(row)) << 4));
     }
-    const char* gB = (const char*)B;                              // wave-uniform: start of the NEXT stage to issue
+    const char* gB = (const char*)(B + (int64_t)nt0 * AS_BN * ldb);   // wave-uniform: start of the NEXT stage to issue
     const int64_t tile_step = (int64_t)AS_BN * ldb * 2 - 3 * AS_KS * 2;
     // LDS-DMA as inline asm with the SGPR-base addressing form (wave-uniform stage pointer + the lane's 32-bit offset): the builtin takes a
     // per-lane 64-bit pointer, which cost two v_lshl_add_u64 per piece and kept the four offsets zero-extended in eight VGPRs (r05: the first
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
     int issued = 3;                                               // stages issued so far; stage s lives in slot s & 3 (4 stages per column tile)
 #pragma unroll
     for (int q = 0; q < AS_MAXN / 256; ++q)
-        if (tid + 256 * q < (int)N) bias_lds[tid + 256 * q] = bv[q];
+        if (tid + 256 * q < n_tiles * AS_BN) bias_lds[tid + 256 * q] = bv[q];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     as_wait<8>();                                                 // A fragments + stage 0 landed (stages 1, 2 may be in flight)
     // (hipcc does not see the asm DMA or this wait: without the pin below it answers the FIRST use of every A fragment inside the unrolled
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
     // (r05; r03-r04: byte (2 i + h) * 64 + lane, four byte stores / loads of 64-byte runs per tile.  The r05 counters show the same write
     // traffic as before — 727 MB against 570 MB algorithmic — so the excess the r04 counters showed is NOT the byte stores: it comes with the
     // non-temporal output stores this instance uses, 1.31 x on the 537-MB output, see the launcher).  ops.bitmask_rows() converts to the row-major view for tests.
-    const int64_t mtile0 = (m0 >> 5) * (int64_t)n_tiles * 256;
+    const int64_t mtile0 = ((m0 >> 5) * (int64_t)n_tiles_all + nt0) * 256;
     // per-lane offsets of row (lane & 15) only: the 16-row step of the second row fragment goes into the wave-uniform (scalar) part of the
     // address — two loop-invariant VGPRs fewer (at 256 VGPRs a spilled one comes back as scratch_load + s_waitcnt vmcnt(0) = a drained DMA ring)
     const uint32_t eoff0 = (uint32_t)((lane & 15) * ep.ldc + ecol);                                                              // elements
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                         prew = as_load4(op, (uint32_t)lane * 4);
                         as_wait<5>();
                     } else if (RESP && kc == 2) {                 // the residual rows of this column tile (4 x 16 B per lane), 2.5 stages before their use
-                        const char* rp = (const char*)((FL & AF_RES) ? ep.residual : ep.mul_aux) + ((m0 * ep.ldc + (int64_t)nt * AS_BN) << 1);   // (wave-uniform).  In the epilogue each of
+                        const char* rp = (const char*)((FL & AF_RES) ? ep.residual : ep.mul_aux) + ((m0 * ep.ldc + (int64_t)(nt0 + nt) * AS_BN) << 1);   // (wave-uniform).  In the epilogue each of
                         const uint32_t vo = eoff0 * 2;            // the four plain loads was a full HBM round trip (tools/astat_cycles.py: 13.7 k cycles per
                         pres[0] = as_load16<0>(rp, vo);           // column tile against 2 k of MFMA issue).  vmcnt retires in order, so the lead cannot
                         pres[1] = as_load16<64>(rp, vo);          // exceed the ring: the stage issued behind these loads is needed 2 stages later
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
             for (int h = 0; h < 2; ++h) {
                 float v[8] = {acc[i][2 * h][0], acc[i][2 * h][1], acc[i][2 * h][2], acc[i][2 * h][3],
                               acc[i][2 * h + 1][0], acc[i][2 * h + 1][1], acc[i][2 * h + 1][2], acc[i][2 * h + 1][3]};
-                const int nb = nt * AS_BN + 32 * h;
+                const int nb = (nt0 + nt) * AS_BN + 32 * h;
                 uint32_t lo = eoff0;
                 asm volatile("" : "+v"(lo));                     // opaque per tile: keeps (base + lane offset) out of loop-invariant 64-bit VGPR pointers
                 as_epi8<OutT, FL>(ep, C, (m0 + 16 * i) * ep.ldc + nb, lo, nb, ecol, (m0 + 16 * i) * N + nb, doff0, mtile0 + nt * 256, (uint32_t)lane, v, bias_lds,
@@ -427,16 +429,29 @@ bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t l
                         const EpiParams& ep_in, hipStream_t st) {
     EpiParams ep = ep_in;
     const bool off = getenv("EMO_GEMM_NO_ASTAT") != nullptr;      // (read per call: the parity test toggles it in-process)
-    // one block owns a 128-row panel and sweeps all of N: the grid is M / 128 blocks, so small token counts (the reference's batch_size 4,
-    // stage 1) leave most CUs idle where the 128 x 128 tiling has N / 128 times more blocks -> A-stationary only from one block per CU up
-    if (off || K != AS_K || (M % AS_BM) != 0 || M < (int64_t)AS_BM * AS_MIN_BLOCKS || (N % AS_BN) != 0 || N > AS_MAXN || N < AS_BN) return false;
+    // one block owns a 128-row panel and sweeps all of N: the grid is M / 128 blocks.  Below one panel per CU (the reference's batch_size 4:
+    // 64 panels) the column tiles of a panel are split over blockIdx.y, every block keeping at least two column tiles (r05; until then these
+    // shapes ran on the 128 x 128 tiling at 0.15 of the MFMA peak)
+    int64_t min_rows = (int64_t)AS_BM * AS_MIN_BLOCKS;
+    { const char* e = getenv("EMO_ASTAT_MIN_ROWS"); if (e && atoll(e) > 0) min_rows = atoll(e); }      // (A/B of the column split; ops.py reads the same variable)
+    if (off || K != AS_K || (M % AS_BM) != 0 || M < min_rows || (N % AS_BN) != 0 || N > AS_MAXN || N < AS_BN) return false;
     if (ep.atomic || ep.accumulate || ep.ws_stride || ep.a_rowsum || ep.b_rowsum || ep.ln_c1 || ep.rln_x) return false;
     if ((ep.mask_out || ep.mul_mode == EMO_MUL_BITMASK) && dtype_out != EMO_BF16) return false;
     if (ep.act == EMO_ACT_GELU || ep.mul_mode == EMO_MUL_DGELU) return false;          // (exact erf GELU: the generic tiled epilogue only)
     if ((lda & 7) || (ldb & 7) || (ep.ldc & 7) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return false;
     if ((uint64_t)(AS_BN * ldb + AS_K) * 2 >= 0xFFFF0000ull) return false;
     const size_t lds = AS_RING + AS_MAXN * sizeof(float);
-    dim3 grid((unsigned)(M / AS_BM));
+    const int n_tiles_all = (int)(N / AS_BN);
+    int split = 1;
+    if (M / AS_BM < 256)                                           // the smallest split that gives every CU a block (measured at 8192 / 16384 rows,
+        for (int sp = 2; sp <= n_tiles_all / 2; ++sp)             // tools/bench_astat_split.py: 4 / 2 column blocks beat 8 / 4 and 16 / 8)
+            if (n_tiles_all % sp == 0) {
+                split = sp;
+                if ((M / AS_BM) * sp >= 256) break;
+            }
+    { const char* e = getenv("EMO_ASTAT_SPLIT"); if (e && atoi(e) > 0 && n_tiles_all % atoi(e) == 0) split = atoi(e); }      // (tests / experiments)
+    const int tiles_per_block = n_tiles_all / split;
+    dim3 grid((unsigned)(M / AS_BM), (unsigned)split);
     // Non-temporal output stores only for the FFN1 forward (the mask-out instance: 537 MB + the mask, read back once by the FFN2 forward).  r02
     // streamed every output beyond the 256-MB MALL; r03 per-instance sweep inside the step (EMO_ASTAT_NT_MASK, same box, 3 alternations):
     // all three large outputs 46.40 ms/step, FFN1 only 46.15, none 46.45 (the A-stationary kernels then run 0.9 ms faster and the kernels that
@@ -451,7 +466,7 @@ bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t l
         auto k = gemm_astat_kernel<OutT, FLv>;                                                                                            \
         static bool attr = false;                                                                                                         \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }      \
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, A, lda, B, ldb, (OutT*)C, M, N, ep);                                              \
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, A, lda, B, ldb, (OutT*)C, M, N, ep, tiles_per_block);                             \
     } while (0)
     // feature flags of this launch; the sets the Performer layer uses have their own straight-line instantiation, the rest runs the generic one
     const bool gelu_aux = ep.act == EMO_ACT_GELU_NEW && ep.aux_out;

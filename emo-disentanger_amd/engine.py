@@ -14,7 +14,7 @@ import math
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from ._lib import EmoError
 
 ALIGN = 8  # elements; keeps every parameter 16-B aligned in the bf16 mirror
@@ -69,6 +69,7 @@ class ParamStore:
                 p.data = view
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
         self._fused = fused
+        self._views = {}
         self._mirror_version, self._mirror_epoch, self._wT = -1, 0, {}
         self._first, self._last = named[0][1], named[-1][1]
         self._plist = [p for _, p in named]
@@ -150,11 +151,19 @@ class ParamStore:
 
     # -- views ------------------------------------------------------------------------------------
     def _view(self, buf, name, rows=None):
-        o, shp = self.offsets[name], self.shapes[name]
-        if name in self._fused and rows is not None:
-            n = sum(self.params[m].numel() for m in self._fused[name])
-            return buf[o:o + n].view(rows, -1) if len(shp) == 2 else buf[o:o + n]
-        return buf[o:o + self.params[name].numel()].view(shp)
+        # (views of the three flat buffers are cached: ~340 per training step, 2.7 us each to slice and reshape — a ninth of the host time that
+        # bounds the step at the reference YAML's batch size 4, r05.  The buffers live as long as the store; the cache is keyed by their address.)
+        key = (buf.data_ptr(), name, rows)
+        v = self._views.get(key)
+        if v is None:
+            o, shp = self.offsets[name], self.shapes[name]
+            if name in self._fused and rows is not None:
+                n = sum(self.params[m].numel() for m in self._fused[name])
+                v = buf[o:o + n].view(rows, -1) if len(shp) == 2 else buf[o:o + n]
+            else:
+                v = buf[o:o + self.params[name].numel()].view(shp)
+            self._views[key] = v
+        return v
 
     def w(self, name, fused_rows=None):
         """GEMM operand view (compute dtype)."""
@@ -246,7 +255,7 @@ def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save, act='rel
 # counts (the reference YAML's batch size 4: 8192 tokens, GEMM grids of 64-256 blocks on 256 CUs) the chip is underfilled and the second stream
 # wins (r03, same box: 9.08 -> 8.84 ms/step) -> EMO_WGRAD_STREAM unset = on below 32768 tokens; =1 always, =0 never.
 import os as _os
-_SIDE = {'stream': None, 'on': _os.environ.get('EMO_WGRAD_STREAM', '') == '1', 'auto': _os.environ.get('EMO_WGRAD_STREAM', '') == '', 'used': False}
+_SIDE = {'stream': None, 'raw': None, 'device': None, 'on': _os.environ.get('EMO_WGRAD_STREAM', '') == '1', 'auto': _os.environ.get('EMO_WGRAD_STREAM', '') == '', 'used': False}
 
 
 def _side_on(tensors):
@@ -259,52 +268,42 @@ def _side_on(tensors):
 _AUX = {'stream': None}     # auxiliary stream of the omega redraw (MusicLM forward)
 
 
-class _side_stream:
-    """with _side_stream(t1, t2, ...): launches go to the side stream after everything queued so far on the main stream;
-    the tensors are marked as used by the side stream so the caching allocator does not recycle them early."""
-
-    def __init__(self, *tensors):
-        self.tensors = tensors
-
-    def __enter__(self):
-        self.on = _side_on(self.tensors)
-        if not self.on:
-            return self
-        _SIDE['used'] = True
-        main = torch.cuda.current_stream()
-        if _SIDE['stream'] is None or _SIDE['stream'].device != main.device:
-            _SIDE['stream'] = torch.cuda.Stream(device=main.device)
-        side = _SIDE['stream']
-        side.wait_stream(main)
-        for t in self.tensors:
-            if t is not None:
-                t.record_stream(side)
-        self.ctx = torch.cuda.stream(side)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *a):
-        if self.on:
-            self.ctx.__exit__(*a)
-        return False
+def _side_fork(*tensors):
+    """Raw handle of the side stream, made to wait for everything queued on the main stream so far — or None when the weight gradients stay on
+    the main stream.  The tensors are marked as used by the side stream so the caching allocator does not recycle them early.
+    (r05: the launches take the handle explicitly.  The `with torch.cuda.stream(side)` form this replaces — current_stream(), wait_stream(),
+    the context manager's set_stream twice — cost 40-70 us of host time per weight gradient, 2-3 ms of the 8 ms in which the host queues a
+    training step at the reference YAML's batch size 4, a step the host bounds: tools/b4_cpu_probe.py, tools/b4_host_profile.py.)"""
+    if not _side_on(tensors):
+        return None
+    dev = torch._C._cuda_getDevice()
+    if _SIDE['stream'] is None or _SIDE['device'] != dev:
+        _SIDE['stream'], _SIDE['device'] = torch.cuda.Stream(device=dev), dev
+        _SIDE['raw'] = _SIDE['stream'].cuda_stream
+    _SIDE['used'] = True
+    _lib.check(_lib.lib.emo_stream_wait(_SIDE['raw'], _lib.stream()))
+    side = _SIDE['stream']
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    return _SIDE['raw']
 
 
 def join_side_stream():
     if _SIDE['used'] and _SIDE['stream'] is not None:
-        torch.cuda.current_stream().wait_stream(_SIDE['stream'])
+        _lib.check(_lib.lib.emo_stream_wait(_lib.stream(), _SIDE['raw']))
         _SIDE['used'] = False
 
 
-def _timed_wgrad(a, b, out, a_rowsum=None, b_rowsum=None):
+def _timed_wgrad(a, b, out, a_rowsum=None, b_rowsum=None, stream=None):
     """dW += a^T b.  a_rowsum / b_rowsum: the bias gradient (column sums of dY) taken inside the same GEMM from the operand fragments."""
-    ops.gemm(a, b, a_trans=True, b_trans=True, out=out, accumulate=True, a_rowsum=a_rowsum, b_rowsum=b_rowsum)
+    ops.gemm(a, b, a_trans=True, b_trans=True, out=out, accumulate=True, a_rowsum=a_rowsum, b_rowsum=b_rowsum, stream=stream)
 
 
 def _wgrad(ps, wname, bname, dy, xin, fused_rows=None, bias_done=False):
     """dW[N,K] += dy[M,N]^T xin[M,K] ; db[N] += colsum(dy)   (nn.Linear layout).  bias_done: the column sums were already
     accumulated by the LayerNorm-backward kernel that produced dy."""
-    with _side_stream(dy, xin):
-        _timed_wgrad(dy, xin, ps.g(wname, fused_rows), a_rowsum=None if bias_done else ps.g(bname, fused_rows))
+    _timed_wgrad(dy, xin, ps.g(wname, fused_rows), a_rowsum=None if bias_done else ps.g(bname, fused_rows), stream=_side_fork(dy, xin))
 
 
 def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
@@ -329,9 +328,9 @@ def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
         df = ops.gemm(dyd, ps.w(pfx + 'linear2.weight'), b_trans=True, mul_aux=s['f'], mul_mode=ops.MUL_NONZERO, mul_scale=inv)
     _wgrad(ps, pfx + 'linear1.weight', pfx + 'linear1.bias', df, s['h1'])
     # the long-reduction dgrads (K = 2048 / 1536) as NT products against transposed mirrors too: 256 x 256 tile kernel (emo_gemm_w128.hip).
-    # `bf` already requires >= ASTAT_MIN_ROWS = 32768 tokens, where M / 256 * N / 256 >= 256 tiles holds for N = 512: below that (the reference
-    # batch size 4) `nt_long` is False and the dgrads stay NN products on the 128 x 128 kernel, without mirror transposes.
-    nt_long = bf and dout.shape[0] % 256 == 0 and _os.environ.get('EMO_DGRAD_NT', '1') != '0'
+    # From 32768 tokens, where M / 256 * N / 256 >= 256 tiles holds for N = 512; below that (the reference batch size 4) the long-reduction
+    # dgrads stay NN products on the 128 x 128 kernel (the K = 512 ones above already run on the column-split A-stationary kernel from 4096 tokens).
+    nt_long = bf and dout.shape[0] >= 32768 and dout.shape[0] % 256 == 0 and _os.environ.get('EMO_DGRAD_NT', '1') != '0'
     dh1 = ops.gemm(df, ps.wT(pfx + 'linear1.weight'), residual=g2) if nt_long else ops.gemm(df, ps.w(pfx + 'linear1.weight'), b_trans=True, residual=g2)
     g1, da = ops.layernorm_bwd(dh1, s['x1'], ps.f32(pfx + 'norm1.weight'), s['m1'], s['r1'], ps.g(pfx + 'norm1.weight'), ps.g(pfx + 'norm1.bias'),
                                want_drop=p > 0, p_drop=p, seed=seed, offset=off + 1, dcol=ps.g(pfx + 'attention.out_projection.bias'))
@@ -378,8 +377,7 @@ def gpt2_block_fwd(ps, pfx, x, B, T, H, p, seed, off, save):
 
 def _wgrad_conv1d(ps, wname, bname, xin, dy):
     """dW[K,N] += xin[M,K]^T dy[M,N] ; db[N] += colsum(dy)   (HF Conv1D layout)."""
-    with _side_stream(dy, xin):
-        _timed_wgrad(xin, dy, ps.g(wname), b_rowsum=ps.g(bname))
+    _timed_wgrad(xin, dy, ps.g(wname), b_rowsum=ps.g(bname), stream=_side_fork(dy, xin))
 
 
 def gpt2_block_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
@@ -541,8 +539,7 @@ class LogitsFn(torch.autograd.Function):
             ops.cast(padded, p16)
             padded = p16
         g = padded[:, :V]
-        with _side_stream(padded, ctx.h2):
-            _timed_wgrad(g, ctx.h2, ps.g('dec_out_proj.weight'), a_rowsum=ps.g('dec_out_proj.bias'))
+        _timed_wgrad(g, ctx.h2, ps.g('dec_out_proj.weight'), a_rowsum=ps.g('dec_out_proj.bias'), stream=_side_fork(padded, ctx.h2))
         dh = ops.gemm(g, ps.w('dec_out_proj.weight'), b_trans=True)
         join_side_stream()
         return None, dh.view(ctx.shp)

@@ -5,6 +5,8 @@ Every function takes GPU tensors, validates layout, and launches on torch's curr
 projection."""
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
@@ -31,7 +33,9 @@ def _rows(t):
     return t.stride(0)
 
 
+_stream = stream   # (gemm() has a keyword argument of that name)
 _ws_cache = {}
+_ws_need = {}      # emo_gemm_workspace_bytes by problem (a pure function of the shape: one library call per shape, not per launch)
 GEMM_TIMING = None   # bench.py sets this to a list: every GEMM launch is then bracketed by HIP events on its launch stream (in situ)
 KERNEL_TIMING = None  # bench.py sets this to a dict kind -> list of (event0, event1, algorithmic flops, algorithmic bytes) for the attention kernels
 
@@ -55,14 +59,14 @@ class _timed:
         return False
 
 
-def _workspace(kind, device, need):
+def _workspace(kind, device, need, st=None):
     """Caller-owned kernel scratch (the library never allocates): one buffer per (kind, device, stream), grown on demand.  Consumers on one
     stream run in launch order, so consecutive launches can share it.  The size REPORTED to the kernel is the size it asked for, not the
     (possibly larger) cached buffer: the GEMM's split-K count depends on the workspace it is offered, and a result must not depend on which
     shapes the process happened to run before (r03: a trace test passed alone and failed after other tests by 1e-4 of a parameter sum)."""
     if need == 0:
         return None, 0
-    key = (kind, device, stream())
+    key = (kind, device, st if st is not None else stream())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < need:
         buf = torch.empty(need, device=device, dtype=torch.uint8)
@@ -72,9 +76,11 @@ def _workspace(kind, device, need):
 
 def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumulate=False, bias=None, act=ACT_NONE,
          aux_out=None, mul_aux=None, mul_mode=MUL_NONE, mul_scale=1.0, p_drop=0.0, seed=0, offset=0, residual=None,
-         ln_c1=None, ln_eps=1e-5, ln_stats_out=None, rln=None, a_rowsum=None, b_rowsum=None, mask_out=None):
+         ln_c1=None, ln_eps=1e-5, ln_stats_out=None, rln=None, a_rowsum=None, b_rowsum=None, mask_out=None, stream=None):
     """C[M,N] = epilogue(op(A) @ op(B));  a_trans: A stored [K,M];  b_trans=False: B stored [N,K] (nn.Linear),
-    b_trans=True: B stored [K,N] (HF Conv1D).  ln_c1 / ln_stats_out / rln: LayerNorm folded around a decode-step GEMM (include/emo_hip.h)."""
+    b_trans=True: B stored [K,N] (HF Conv1D).  ln_c1 / ln_stats_out / rln: LayerNorm folded around a decode-step GEMM (include/emo_hip.h).
+    stream: raw hipStream_t to launch on (default: torch's current stream)."""
+    st = stream if stream is not None else _stream()
     K, M = (A.shape if a_trans else A.shape[::-1])
     Kb, N = (B.shape if b_trans else B.shape[::-1])
     assert K == Kb, 'inner dims differ: %s vs %s' % (tuple(A.shape), tuple(B.shape))
@@ -85,21 +91,26 @@ def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumu
     plain = bias is None and residual is None and aux_out is None and mul_aux is None and act == ACT_NONE and p_drop == 0.0
     if (out.dtype == torch.float32 and plain) or (out.dtype == torch.bfloat16 and not accumulate and M > 32):
         # fp32 plain outputs (wgrad): split-K partial sums; bf16 outputs on a small tile grid with a long reduction: split-K + reduce-with-epilogue
-        ws, ws_bytes = _workspace('gemm', A.device, lib.emo_gemm_workspace_bytes(M, N, K, dtype_code(A.dtype), dtype_code(out.dtype)))
+        wkey = (M, N, K, A.dtype, out.dtype)
+        need = _ws_need.get(wkey)
+        if need is None:
+            need = _ws_need[wkey] = lib.emo_gemm_workspace_bytes(M, N, K, dtype_code(A.dtype), dtype_code(out.dtype))
+        ws, ws_bytes = _workspace('gemm', A.device, need, st)
     rx, rstats, rgamma, rbeta = rln if rln is not None else (None, None, None, None)     # residual = LayerNorm(rx) from exported statistics
     assert rx is None or (rx.dtype == out.dtype and _rows(rx) == _rows(out))
     epi = Epilogue(ptr(bias), act, ptr(aux_out), ptr(mul_aux), mul_mode, mul_scale, p_drop, seed, offset, ptr(residual),
                    ptr(ln_c1), ln_eps, ptr(ln_stats_out), ptr(rx), ptr(rstats), ptr(rgamma), ptr(rbeta), ptr(a_rowsum), ptr(b_rowsum), ptr(mask_out), ptr(ws), ws_bytes)
-    for t in (aux_out, residual) + (() if mul_mode == MUL_BITMASK else (mul_aux,)):
-        assert t is None or (t.dtype == out.dtype and _rows(t) == _rows(out))
-    for t in (mask_out,) + ((mul_aux,) if mul_mode == MUL_BITMASK else ()):
-        assert t is None or (t.dtype == torch.uint8 and t.is_contiguous() and t.shape == (M, N // 8) and gemm_bitmask_ok(M, N, K, A.dtype, out.dtype))
-    assert bias is None or bias.dtype == torch.float32
+    if not plain or mask_out is not None:
+        for t in (aux_out, residual) + (() if mul_mode == MUL_BITMASK else (mul_aux,)):
+            assert t is None or (t.dtype == out.dtype and _rows(t) == _rows(out))
+        for t in (mask_out,) + ((mul_aux,) if mul_mode == MUL_BITMASK else ()):
+            assert t is None or (t.dtype == torch.uint8 and t.is_contiguous() and t.shape == (M, N // 8) and gemm_bitmask_ok(M, N, K, A.dtype, out.dtype))
+        assert bias is None or bias.dtype == torch.float32
     if GEMM_TIMING is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     check(lib.emo_gemm(ptr(A), int(a_trans), _rows(A), ptr(B), int(b_trans), _rows(B), ptr(out), _rows(out), M, N, K,
-                       dtype_code(A.dtype), dtype_code(out.dtype), int(accumulate), ctypes.byref(epi), stream()))
+                       dtype_code(A.dtype), dtype_code(out.dtype), int(accumulate), ctypes.byref(epi), st))
     if GEMM_TIMING is not None:
         e1.record()
         kind = ('T' if a_trans else 'N') + ('N' if b_trans else 'T')
@@ -121,7 +132,7 @@ def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumu
     return out
 
 
-ASTAT_MIN_ROWS = 128 * 256      # emo_gemm_astat.hip: one 128-row panel per block, at least one block per CU
+ASTAT_MIN_ROWS = int(os.environ.get('EMO_ASTAT_MIN_ROWS', 0)) or 128 * 32       # emo_gemm_astat.hip (AS_MIN_BLOCKS): 128-row panels; below one panel per CU the kernel splits the columns over the grid
 
 
 def gemm_bitmask_ok(M, N, K, in_dtype, out_dtype):

@@ -363,6 +363,10 @@ int emo_add_bias2(const void* x, int64_t ld, const float* b1, const float* b2, v
  * the record's first 64 x 64 tile, tiles per row = ceil(cols / 64)}; src is [rows, cols] row-major, dst [cols, rows]; total_tiles = sum over
  * records of ceil(rows / 64) * ceil(cols / 64); rows and the pointers must allow 16-B accesses (rows % 8 == 0, cols % 8 == 0 fast path). */
 int emo_transpose_batch(const int64_t* desc, int n, int64_t total_tiles, emo_stream_t stream);
+/* Stream fork / join without a host round trip through torch's Stream objects (no reference counterpart: the weight-gradient products of
+ * a layer run on a second stream beside the dgrad chain at small token counts): `waiter` continues only after everything queued on `signaler`
+ * so far.  Asynchronous; events are owned by the library (per calling thread). */
+int emo_stream_wait(emo_stream_t waiter, emo_stream_t signaler);
 
 /* ------------------------------------------------------------------ data-parallel exchange (RCCL over xGMI)
  * The reference trains on one GPU; the build shards the batch over one process per GPU and adds ONE exchange per optimizer

@@ -1027,7 +1027,10 @@ def test_gemm_skinny_decode_shapes(M):
 
 
 # ------------------------------------------------------------------------------------------- A-stationary K = 512 GEMM
-@pytest.mark.parametrize('M,N', [(32768, 64), (32768 + 384, 512), (32768 + 1024, 1536), (32768 + 2048, 2048)])
+# (the shapes below 32768 rows: fewer 128-row panels than CUs — the reference YAML's batch size 4 is 8192 tokens — where the kernel splits the
+# column tiles of a panel over blockIdx.y, r05: 4, 8 and 8 column blocks, 33 panels x 8)
+@pytest.mark.parametrize('M,N', [(32768, 64), (32768 + 384, 512), (32768 + 1024, 1536), (32768 + 2048, 2048), (8192, 512), (8192, 1536), (8192, 2048),
+                                 (4096 + 128, 2048)])
 @pytest.mark.parametrize('out_dt', [torch.bfloat16, torch.float32])
 def test_gemm_astat_k512_matches_reference_and_the_tiled_kernel(M, N, out_dt, monkeypatch):
     """emo_gemm_astat.hip (A stationary in registers, weights streamed through the LDS ring) against an fp64 product, and BIT-FOR-BIT
@@ -1079,12 +1082,14 @@ def test_gemm_astat_k512_matches_reference_and_the_tiled_kernel(M, N, out_dt, mo
     assert float(outb[:, :N].abs().max()) == 0.0
 
 
-def test_gemm_astat_bitmask_epilogue_equals_the_activation_mask():
+@pytest.mark.parametrize('M', [32768 + 640, 8192])
+def test_gemm_astat_bitmask_epilogue_equals_the_activation_mask(M):
     """mask_out packs (value after ReLU + dropout != 0) into 1 bit per output; EMO_MUL_BITMASK multiplies by it: the FFN2 dgrad through the
-    bit mask equals, bit for bit, the dgrad through the [M, N] activation itself (EMO_MUL_NONZERO); elsewhere the two are refused loudly."""
+    bit mask equals, bit for bit, the dgrad through the [M, N] activation itself (EMO_MUL_NONZERO); elsewhere the two are refused loudly.
+    (8192 rows: the column-split grid, every block writes / reads its own tiles of the mask.)"""
     ops = _ops()
     from emo_disentanger_amd._lib import EmoError
-    M, N, K = 32768 + 640, 2048, 512
+    N, K = 2048, 512
     h, W1, b1 = _r(M, K, seed=1, dt=torch.bfloat16).cuda(), _r(N, K, seed=2, dt=torch.bfloat16, scale=0.05).cuda(), _r(N, seed=3).cuda()
     fmask = torch.zeros(M, N // 8, device='cuda', dtype=torch.uint8)
     f = ops.gemm(h, W1, bias=b1, act=ops.ACT_RELU, p_drop=0.1, seed=5, offset=2, mask_out=fmask)

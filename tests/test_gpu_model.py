@@ -222,7 +222,11 @@ def test_bf16_error_budget_by_site(scale, monkeypatch):
     def run(dtype, sites):
         def gemm(A, B, **kw):
             if 'gemm_in' in sites and A.dtype == torch.float32:
-                A, B = A.to(torch.bfloat16).float(), B.to(torch.bfloat16).float()
+                # (weight-gradient products are launched on the engine's side stream through an explicit handle: the rounded copies the product
+                # reads must be made on that stream too, behind the fork the engine issued)
+                st = kw.get('stream')
+                with torch.cuda.stream(torch.cuda.ExternalStream(st) if st is not None else torch.cuda.current_stream()):
+                    A, B = A.to(torch.bfloat16).float(), B.to(torch.bfloat16).float()
             out = real['gemm'](A, B, **kw)
             if 'acts' in sites and out.dtype == torch.float32 and not kw.get('accumulate') and kw.get('out') is None:
                 _round_bf16_(out)
