@@ -133,10 +133,10 @@ def _txl_layer_bwd(ps, p, dout, pe_d, B, T, H, pd, seed, off, s, acc, dyd=None, 
     D = dout.shape[1]
     a, f = p + 'dec_attn.', p + 'pos_ff.'
     inv = 1.0 / (1.0 - pd) if pd > 0 else 1.0
+    # weight gradients on the engine's side stream, as the Performer does below 32768 rows (r03 measured no gain, 7.98 against 8.02 ms/step: the
+    # host then queued a step no faster than the GPU ran it; r05, with the host at 4.5 ms per step, the GPU bounds the step and the overlap counts)
     wg = lambda dy, xin, wname, bname=None: ops.gemm(dy, xin, a_trans=True, b_trans=True, out=ps.g(wname), accumulate=True,
-                                                     a_rowsum=None if bname is None else ps.g(bname))
-    # (weight gradients on the engine's side stream, as the Performer does below 32768 rows: measured late r03 on one box, 7.98 ms/step with
-    # against 8.02 without — the stage-1 step is paced by its ~500 dependent launches, not by CU occupancy — so they stay on the main stream)
+                                                     a_rowsum=None if bname is None else ps.g(bname), stream=engine._side_fork(dy, xin))
     if dyd is None:
         dyd = ops.dropout_apply(dout, pd, seed, off + 4) if pd > 0 else dout
     wg(dyd, s['g'], f + 'CoreNet.3.weight', None if bias3_done else f + 'CoreNet.3.bias')
@@ -162,7 +162,7 @@ def _txl_layer_bwd(ps, p, dout, pe_d, B, T, H, pd, seed, off, s, acc, dyd=None, 
     if dR_out is None:
         wg(dR.to(ps.compute_dtype), pe_d, a + 'r_net.weight')                 # R = r_net(dropout(pos_emb)): dW_r += dR^T pos_emb
     # (colsum(dq) = the first D entries of the column sums of dqkv, which the weight-gradient GEMM takes from its operand fragments: acc[:3D])
-    ops.gemm(dqkv, s['n'], a_trans=True, b_trans=True, out=ps.g(a + 'qkv_net.weight'), accumulate=True, a_rowsum=acc[:3 * D])
+    ops.gemm(dqkv, s['n'], a_trans=True, b_trans=True, out=ps.g(a + 'qkv_net.weight'), accumulate=True, a_rowsum=acc[:3 * D], stream=engine._side_fork(dqkv, s['n']))
     dn = ops.gemm(dqkv, ps.w(a + 'qkv_net.weight'), b_trans=True)
     if below is not None and not mlen:                           # the layer below wants dx * its output dropout and colsum of that (its CoreNet.3 bias)
         dx, dxd = ops.layernorm_bwd(dn, s['x'], ps.f32(a + 'layer_norm.weight'), s['m1'], s['r1'], ps.g(a + 'layer_norm.weight'), ps.g(a + 'layer_norm.bias'),
@@ -235,6 +235,7 @@ class TXLStackFn(torch.autograd.Function):
             ctx.saves[l] = None
         if stacked:
             ops.colsum(dq_rel_all.view(L * B * T, D), out=acc[3 * D:], accumulate=True)
+        engine.join_side_stream()                                             # acc[:3 D] and the weight gradients are complete
         # R_l = r_net_l(dropout(pos_emb)): dW_r[l] += dR_l^T pos_emb, all layers in one product (the weights are adjacent in the store)
         ops.gemm(dR_all.to(ps.compute_dtype), ctx.pe_d, a_trans=True, b_trans=True, out=ps.g('decoder.layers.0.dec_attn.r_net.weight', L * D), accumulate=True)
         ps.g('decoder.r_r_bias').add_(acc[3 * D:].view(H, D // H))             # d r_r_bias = colsum(dq_relative)
