@@ -120,6 +120,12 @@ __device__ __forceinline__ void as_unpack8(const u32x4& r, float (&t)[8]) {
 //   ub = m0 * ldc + n_tile0 (+32 h)   lo = row_in_wave * ldc + ecol           (C / aux_out / mul_aux / residual, elements)
 //   nb = n_tile0 + 32 h               (bias / columns)                           db = m0 * N + nb, dl = row_in_wave * N + ecol (dropout index)
 // pre_bits: the mask byte already in a register (inline-asm prefetch)
+// Timing ablations of a -DEMO_DIAG build (EMO_GEMM_ABLATE; results are wrong): 1 no output stores, 2 no weight DMA, 3 no barrier, 4 no fragment
+// reads, 5 no MFMAs, 6 no epilogue, 7 every block stores to the same 256 rows (output stays in the L2).  r05, 131072 rows, isolated launches:
+// FFN2 dgrad (bit mask, N = 2048) 330 us; no MFMAs 316; no epilogue 220; no stores 223; stores kept in the L2 268 — the kernel is paced by
+// its epilogue and by draining 537 MB of output (1.6 TB/s while it runs), not by the MFMA pipe: without a single MFMA it is 4 % faster.
+// The same with the two groups of a CU made one 8-wave workgroup that alternates stages and epilogue quarters at shared barriers
+// ("ping-pong", built and measured in r05): 294 -> 314 us (FFN1 forward), 324 -> 349 (FFN2 dgrad): dropped.
 // The epilogue is specialised at COMPILE time (FL = feature flags): with run-time `ep.*` tests the column-tile epilogue was ~650 lines of
 // branchy code per tile (dead mul / residual / aux paths with their own `s_waitcnt vmcnt(0)`, per-lane parity branches of the dropout
 // hash) and took 35-52 % of a wave's cycles (s_memtime, tools/astat_cycles.py); the flag sets the Performer step uses are straight-line.
@@ -276,6 +282,9 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(src[jj]), "s"(gB), "s"(ring_lds + slot * AS_SLOT + jj * 1024) : "memory");
     };
     auto frags = [&](int slot, int ks, bf16x8 (&bf)[4]) {
+#ifdef EMO_DIAG
+        if (ep.ablate == 4) return;                               // diagnostics: no fragment reads (timing only)
+#endif
 #pragma unroll
         for (int f = 0; f < 4; ++f) bf[f] = *(const bf16x8*)(smem + slot * AS_SLOT + (rd[f] ^ (uint32_t)(ks << 6)));
     };
@@ -380,6 +389,9 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                     const int g2 = kc * 4 + ks + 2;              // step to prefetch (compile-time after unrolling); steps 16, 17 = the next column tile's 0, 1
                     frags((g2 >> 2) & 3, g2 & 3, bq[g2 & 3]);
                 }
+#ifdef EMO_DIAG
+                if (ep.ablate != 5)                               // diagnostics: no MFMAs
+#endif
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -389,6 +401,9 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
         // ---- the wave's 32 x 64 outputs of this column tile, straight from the accumulators
 #ifdef EMO_DIAG
         const uint64_t te0 = __builtin_readcyclecounter();
+#endif
+#ifdef EMO_DIAG
+        if (ep.ablate == 6) continue;                             // diagnostics: no epilogue at all
 #endif
         if (BITS) as_pinw<4>(prew);                               // one refill (4 DMA ops) was issued after the mask word
         if (RESP) as_pin<4>(pres);
@@ -402,7 +417,12 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                 const int nb = (nt0 + nt) * AS_BN + 32 * h;
                 uint32_t lo = eoff0;
                 asm volatile("" : "+v"(lo));                     // opaque per tile: keeps (base + lane offset) out of loop-invariant 64-bit VGPR pointers
-                as_epi8<OutT, FL>(ep, C, (m0 + 16 * i) * ep.ldc + nb, lo, nb, ecol, (m0 + 16 * i) * N + nb, doff0, mtile0 + nt * 256, (uint32_t)lane, v, bias_lds,
+#ifdef EMO_DIAG
+                const int64_t m0s = ep.ablate == 7 ? (m0 & 255) : m0;       // diagnostics: every block writes the same 256 rows (the output stays in the L2)
+#else
+                const int64_t m0s = m0;
+#endif
+                as_epi8<OutT, FL>(ep, C, (m0s + 16 * i) * ep.ldc + nb, lo, nb, ecol, (m0 + 16 * i) * N + nb, doff0, mtile0 + nt * 256, (uint32_t)lane, v, bias_lds,
                                     (prew >> (8 * (i * 2 + h))) & 0xFFu, mask_word, i * 2 + h, pres[i * 2 + h]);
                 __builtin_amdgcn_sched_barrier(0);               // one 8-column group at a time: keeps the epilogue's temporaries out of the register peak
             }
