@@ -124,4 +124,12 @@ def stream():
     """hipStream_t of torch's current stream on the current device.  (The raw getter: `torch.cuda.current_stream().cuda_stream` builds a Stream
     object through four layers of Python per call — 8.5 us, ~200 calls per training step, a quarter of the host time that BOUNDS the step at the
     reference YAML's batch size 4; tools/b4_host_profile.py, r05.)"""
-    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    return _raw_stream(_cur_device())
+
+
+# (private torch entry points, present in every torch with a CUDA / ROCm build this package supports; the public form is the fall-back)
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_cur_device = getattr(torch._C, '_cuda_getDevice', None)
+if _raw_stream is None or _cur_device is None:
+    def stream():                                                  # noqa: F811
+        return torch.cuda.current_stream().cuda_stream

@@ -276,7 +276,7 @@ def _side_fork(*tensors):
     training step at the reference YAML's batch size 4, a step the host bounds: tools/b4_cpu_probe.py, tools/b4_host_profile.py.)"""
     if not _side_on(tensors):
         return None
-    dev = torch._C._cuda_getDevice()
+    dev = torch.cuda.current_device()
     if _SIDE['stream'] is None or _SIDE['device'] != dev:
         _SIDE['stream'], _SIDE['device'] = torch.cuda.Stream(device=dev), dev
         _SIDE['raw'] = _SIDE['stream'].cuda_stream

@@ -108,11 +108,12 @@ def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumu
         assert bias is None or bias.dtype == torch.float32
     if GEMM_TIMING is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        tstream = torch.cuda.ExternalStream(st) if stream is not None else torch.cuda.current_stream()     # the events go where the launch goes
+        e0.record(tstream)
     check(lib.emo_gemm(ptr(A), int(a_trans), _rows(A), ptr(B), int(b_trans), _rows(B), ptr(out), _rows(out), M, N, K,
                        dtype_code(A.dtype), dtype_code(out.dtype), int(accumulate), ctypes.byref(epi), st))
     if GEMM_TIMING is not None:
-        e1.record()
+        e1.record(tstream)
         kind = ('T' if a_trans else 'N') + ('N' if b_trans else 'T')
         fam = lib.emo_gemm_last_kernel() & 15          # the kernel family that RAN (emo_hip.h), not the one the shape suggests
         if fam == 4:

@@ -1117,6 +1117,33 @@ def test_add_bias2_matches_torch(dt):
     assert torch.equal(o1, (q.float() + b1.view(1, D)).to(dt)) and torch.equal(o2, (q.float() + b2.view(1, D)).to(dt))
 
 
+def test_stream_wait_orders_a_side_stream_launch_behind_the_main_stream():
+    # emo_stream_wait (fork / join of the weight-gradient stream without torch Stream contexts) + ops.gemm(stream=raw handle): a product launched
+    # on a second stream must see operands that the main stream is still producing when the launch is queued, and the main stream must see its
+    # result after the join.  The producer is made slow (a long chain of large copies) so that an unordered launch would read stale data.
+    ops = _ops()
+    from emo_disentanger_amd import _lib
+    M, N, K = 4096, 512, 512
+    side = torch.cuda.Stream()
+    A_final = _r(M, K, seed=1).to(torch.bfloat16).cuda()
+    W = _r(N, K, seed=2, scale=0.1).to(torch.bfloat16).cuda()
+    big = torch.zeros(64 << 20, device='cuda', dtype=torch.float32)
+    for rep in range(3):
+        A = torch.zeros_like(A_final)
+        out = torch.full((M, N), -7.0, device='cuda', dtype=torch.bfloat16)
+        torch.cuda.synchronize()
+        for _ in range(8):
+            big.add_(1.0)                                            # ~2 ms of main-stream work queued in front of the producer
+        A.copy_(A_final)                                            # the producer (main stream)
+        _lib.check(_lib.lib.emo_stream_wait(side.cuda_stream, _lib.stream()))        # fork: side waits for everything queued on main so far
+        A.record_stream(side)
+        ops.gemm(A, W, out=out, stream=side.cuda_stream)
+        _lib.check(_lib.lib.emo_stream_wait(_lib.stream(), side.cuda_stream))        # join: main continues behind the product
+        res = out.float().clone()                                   # main stream
+        torch.cuda.synchronize()
+        _close(res, A_final.double() @ W.double().T, torch.bfloat16, mult=1.0)
+
+
 def test_transpose_batch_matches_torch():
     # emo_transpose_batch: the transposed weight mirrors of one optimizer step in ONE launch (fast 16-B path and ragged shapes)
     ops = _ops()

@@ -4,5 +4,5 @@ F="--steps 10 --warmup 3 --no-cpu-baseline --no-gen --no-stage1 --no-gpt2 --no-s
 N=$1; A=$2; B=$3
 for v in "$A" "$B" "$A" "$B"; do
   if [ "$v" = "-" ]; then unset $N; else export $N="$v"; fi
-  python bench.py $F 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$N=$v', d['ms_per_step'], d['median_ms_per_step'], [(r['kernel'][:28], round(r['achieved'],1), r['total_ms_per_step']) for r in d['roofline']['roofline_others'][:6] if 'astat' in r['kernel']])"
+  python bench.py $F 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$N=$v', d['ms_per_step'], d['median_ms_per_step'], {k: (round(v['achieved_tflops']), v['total_ms_per_step']) for k, v in d['roofline']['gemm_families'].items()})"
 done
