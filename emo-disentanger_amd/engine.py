@@ -70,6 +70,7 @@ class ParamStore:
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
         self._fused = fused
         self._views = {}
+        self._pad = {}
         self._mirror_version, self._mirror_epoch, self._wT = -1, 0, {}
         self._first, self._last = named[0][1], named[-1][1]
         self._plist = [p for _, p in named]
@@ -113,6 +114,20 @@ class ParamStore:
             self._wT_desc = None                                  # table rebuilt with the new record
         if ent[1] != self._mirror_epoch:
             self._refresh_wT()
+        return ent[0]
+
+    def padded(self, name, n, fill=0.0, master=False):
+        """Copy of parameter `name` with its first dimension padded to n entries of `fill` (compute dtype; master=True: fp32), refreshed when the
+        mirror changes.  The output projection's vocabulary (327) padded to 512: engine.LogitsFn."""
+        key = (name, n, master)
+        ent = self._pad.get(key)
+        if ent is None:
+            shp = self.shapes[name]
+            ent = self._pad[key] = [torch.full((n,) + tuple(shp[1:]), fill, device=self.device, dtype=torch.float32 if master else self.compute_dtype), -1]
+        if ent[1] != self._mirror_epoch:
+            src = self.f32(name) if master else self.w(name)
+            ent[0][:src.shape[0]].copy_(src)
+            ent[1] = self._mirror_epoch
         return ent[0]
 
     def _refresh_wT(self):
@@ -509,6 +524,20 @@ class DecoderStackFn(torch.autograd.Function):
         return None, None, None, None, None, None
 
 
+LOGIT_PAD_FILL = -1e30         # logit of a pad column: exp(pad - lse) == 0 exactly in fp32, never the row maximum
+
+
+def logit_pad(M, V, dtype):
+    """Padded vocabulary size of the output projection (0 = none).  From 32768 rows in the bf16 mode the three products around the logits
+    (forward, d hidden, dW: 45 GFLOP each at the benchmark batch) ran on the generic kernels that take N, K or M = 327 — 314 + 109 + 388 us,
+    r05 — where the tiled kernels need 90 / 77 / ~100: the projection is computed for 512 columns (zero weight rows, bias LOGIT_PAD_FILL), the
+    loss kernels see a 512-column problem whose pad columns contribute exactly nothing, and the caller gets the [.., :V] view."""
+    mode = _os.environ.get('EMO_LOGIT_PAD', '')                    # '0' never / '1' always (tests, A/B)
+    if dtype != torch.bfloat16 or V % 128 == 0 or mode == '0' or (mode != '1' and M < 32768):
+        return 0
+    return (V + 511) // 512 * 512 if V <= 512 else (V + 127) // 128 * 128
+
+
 class LogitsFn(torch.autograd.Function):
     """dec_out_proj: fp32 logits = h W^T + b (untied nn.Linear, music_performer.py:27,65)."""
 
@@ -517,8 +546,13 @@ class LogitsFn(torch.autograd.Function):
         ps = model._store
         shp = h.shape
         h2 = h.reshape(-1, shp[-1])
-        logits = ops.gemm(h2, ps.w('dec_out_proj.weight'), bias=ps.f32('dec_out_proj.bias'), out_dtype=torch.float32)
+        V = ps.shapes['dec_out_proj.weight'][0]
+        Vp = logit_pad(h2.shape[0], V, ps.compute_dtype)
         ctx.model, ctx.h2, ctx.shp = model, h2, shp
+        if Vp:
+            buf = ops.gemm(h2, ps.padded('dec_out_proj.weight', Vp), bias=ps.padded('dec_out_proj.bias', Vp, LOGIT_PAD_FILL, master=True), out_dtype=torch.float32)
+            return buf[:, :V].view(*shp[:-1], V)                  # strided view: XentFn / accuracy find the padded buffer behind it
+        logits = ops.gemm(h2, ps.w('dec_out_proj.weight'), bias=ps.f32('dec_out_proj.bias'), out_dtype=torch.float32)
         return logits.view(*shp[:-1], -1)
 
     @staticmethod
@@ -529,8 +563,9 @@ class LogitsFn(torch.autograd.Function):
         dl = dlogits.reshape(M, V)
         Vp = (V + 7) // 8 * 8
         base = dl._base
-        if base is not None and base.dim() == 2 and base.shape == (M, Vp) and base.dtype == torch.float32 and dl.data_ptr() == base.data_ptr():
-            padded = base                                         # produced by XentFn: already padded, pad columns are zero
+        if (base is not None and base.dim() == 2 and base.shape[0] == M and base.shape[1] >= Vp and base.shape[1] % 8 == 0 and base.is_contiguous()
+                and base.dtype == torch.float32 and dl.data_ptr() == base.data_ptr() and dl.stride() == (base.shape[1], 1)):
+            padded, Vp = base, base.shape[1]                      # produced by XentFn: already padded (to 8, or to logit_pad), pad columns are zero
         else:
             padded = torch.zeros(M, Vp, device=dl.device, dtype=torch.float32)
             padded[:, :V].copy_(dl)
@@ -538,6 +573,16 @@ class LogitsFn(torch.autograd.Function):
             p16 = torch.empty(M, Vp, device=dl.device, dtype=torch.bfloat16)
             ops.cast(padded, p16)
             padded = p16
+        if Vp % 128 == 0 and Vp != V and Vp == logit_pad(M, V, ps.compute_dtype):
+            # the padded problem: d hidden against the zero-padded weight, dW / db of all Vp rows into a scratch whose first V rows are added
+            dWp = torch.zeros(Vp, ctx.h2.shape[1], device=dl.device, dtype=torch.float32)
+            dbp = torch.zeros(Vp, device=dl.device, dtype=torch.float32)
+            _timed_wgrad(padded, ctx.h2, dWp, a_rowsum=dbp, stream=_side_fork(padded, ctx.h2))
+            dh = ops.gemm(padded, ps.padded('dec_out_proj.weight', Vp), b_trans=True)
+            join_side_stream()
+            ps.g('dec_out_proj.weight').add_(dWp[:V])
+            ps.g('dec_out_proj.bias').add_(dbp[:V])
+            return None, dh.view(ctx.shp)
         g = padded[:, :V]
         _timed_wgrad(g, ctx.h2, ps.g('dec_out_proj.weight'), a_rowsum=ps.g('dec_out_proj.bias'), stream=_side_fork(padded, ctx.h2))
         dh = ops.gemm(g, ps.w('dec_out_proj.weight'), b_trans=True)
@@ -551,9 +596,11 @@ class XentFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, tgt, ignore_index):
         V = logits.shape[-1]
-        l2 = logits.reshape(-1, V)
-        if not l2.is_contiguous():
-            l2 = l2.contiguous()
+        l2 = padded_logits(logits)                                # LogitsFn's padded buffer [M, Vp] behind the view, if there is one
+        if l2 is None:
+            l2 = logits.reshape(-1, V)
+            if not l2.is_contiguous():
+                l2 = l2.contiguous()
         t = tgt.reshape(-1)
         check_ids(t, V, 'cross-entropy targets', also=ignore_index)
         lse, acc = ops.xent_fwd(l2, t, ignore_index)
@@ -565,10 +612,22 @@ class XentFn(torch.autograd.Function):
     def backward(ctx, gout):
         l2, t, lse, acc = ctx.saved_tensors
         gscale = (gout.float() / acc[1]).reshape(1)
-        V = l2.shape[1]
+        V = ctx.shape[-1]
         dl = ops.xent_bwd(l2, t, lse, gscale, ctx.ignore, torch.float32)
         g = dl.view(ctx.shape) if dl.shape[1] == V else _as_view(dl, V, ctx.shape)
         return g, None, None
+
+
+def padded_logits(logits):
+    """The contiguous [M, Vp] buffer of LogitsFn's padded projection when `logits` is its [.., :V] view (pad columns = LOGIT_PAD_FILL), else None."""
+    base = logits._base
+    V = logits.shape[-1]
+    if base is None or base.dim() != 2 or not base.is_contiguous() or base.dtype != torch.float32 or base.shape[1] <= V or base.shape[1] % 128:
+        return None
+    M = logits.numel() // V
+    if base.shape[0] != M or logits.data_ptr() != base.data_ptr() or logits.reshape(-1, V).stride() != (base.shape[1], 1):
+        return None
+    return base
 
 
 def _as_view(dl, V, shape):

@@ -76,7 +76,9 @@ def compute_accuracy(dec_logits, dec_target, inp_chord, inp_melody, pad_token):
     """train.py:184-193 on the device: argmax + masked compares in one kernel, 6 counters to the host.
     Returns (total_acc, chord_acc, melody_acc, others_acc); empty classes give nan like np.mean([])."""
     V = dec_logits.shape[-1]
-    c = ops.accuracy_counts(dec_logits.detach().reshape(-1, V).float().contiguous(), dec_target.reshape(-1), inp_chord.reshape(-1),
+    from .engine import padded_logits
+    lp = padded_logits(dec_logits.detach()) if dec_logits.dtype == torch.float32 else None     # the padded projection's buffer: pad columns never win the argmax
+    c = ops.accuracy_counts(lp if lp is not None else dec_logits.detach().reshape(-1, V).float().contiguous(), dec_target.reshape(-1), inp_chord.reshape(-1),
                             inp_melody.reshape(-1), pad_token).cpu().numpy().astype(np.float64)
     with np.errstate(invalid='ignore', divide='ignore'):
         total, chord, melody = c[1] / c[0], c[3] / c[2], c[5] / c[4]

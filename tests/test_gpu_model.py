@@ -299,6 +299,37 @@ def test_bf16_error_budget_by_site(scale, monkeypatch):
     assert res['bf16'][2] <= 0.11 and res['bf16'][3] <= 0.153
 
 
+def test_padded_output_projection_equals_the_unpadded_one(monkeypatch):
+    """From 32768 rows (bf16 mode) the output projection is computed for 512 columns — zero weight rows, bias -1e30 — so that its three products
+    run on the tiled kernels (engine.logit_pad); the loss kernels see a 512-column problem whose pad columns contribute exactly nothing.  Same
+    logits (the caller's [.., :V] view), loss, accuracy counters and gradients as the unpadded path, up to the summation order of other kernels."""
+    c = PERF_CASES[1]
+    from oracle.weights import synthetic_batch
+    from emo_disentanger_amd import train as tr
+    b = synthetic_batch(c['V'], 2, 512, seed=31)
+    x, seg, tgt = b['dec_input'].cuda(), b['track_mask'].cuda(), b['dec_target'].cuda()
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('EMO_LOGIT_PAD', mode)
+        m, _ = _performer(c, 'bf16')
+        m.train()                                                 # (dropout 0, fixed omega: the two runs differ in the padding only)
+        m.zero_grad()
+        logits = m(x, seg_inp=seg)
+        assert logits.shape[-1] == c['V'] and (logits._base is not None and logits._base.shape[-1] == 512) == (mode == '1')
+        loss = m.compute_loss(logits, tgt)['total_loss']
+        loss.backward()
+        acc = tr.compute_accuracy(logits, tgt, b['chord_idx'].cuda(), b['melody_idx'].cuda(), c['V'] - 1)
+        res[mode] = (logits.detach().float().clone(), float(loss), acc, {k: p.grad.detach().float().clone() for k, p in m.named_parameters()})
+    l0, loss0, acc0, g0 = res['0']
+    l1, loss1, acc1, g1 = res['1']
+    assert float((l0 - l1).abs().max()) <= 2e-3 * float(l0.abs().max()) and abs(loss0 - loss1) <= 1e-5
+    assert all((a == b_) or (a != a and b_ != b_) for a, b_ in zip(acc0, acc1))
+    for k in g0:
+        assert float((g0[k] - g1[k]).abs().max()) <= 2e-2 * max(float(g0[k].abs().max()), 1e-12), k
+    wk = 'dec_out_proj.weight'
+    assert float((g0[wk] - g1[wk]).abs().max()) <= 2e-3 * float(g0[wk].abs().max())
+
+
 def test_bf16_mirror_follows_torch_side_weight_writes():
     """The bf16 copy of the weights that the MFMA GEMMs read must follow EVERY write to the fp32 parameters, not only the fused
     optimizer's: load_state_dict after a forward, and a stock torch.optim.Adam step on a GEMM weight (the reference's optimizer)."""
