@@ -841,13 +841,22 @@ static void dispatch_glds(bool akc, bool bkc, dim3 grid, hipStream_t st, const b
     else dispatch_glds2<OutT, 32, 2>(akc, bkc, grid, st, A, lda, B, ldb, C, M, N, K, kps, ep);
 }
 
-static int g_gemm_variant = -1;   // EMO_GEMM_VARIANT: 1 = register-staged v1, 2 = LDS-DMA ring (default when eligible)
+static int g_gemm_variant = -1;   // EMO_GEMM_VARIANT: 1 = register-staged v1, 2 = LDS-DMA ring for k-contiguous A, 3 = also for the TN (wgrad) layout; unset = per call
+static bool g_gemm_variant_auto = true;
 static int gemm_variant() {
     if (g_gemm_variant < 0) {
         const char* e = getenv("EMO_GEMM_VARIANT");
-        g_gemm_variant = (e && e[0] >= '1' && e[0] <= '3') ? (e[0] - '0') : 2;
+        g_gemm_variant_auto = !(e && e[0] >= '1' && e[0] <= '3');
+        g_gemm_variant = g_gemm_variant_auto ? 2 : (e[0] - '0');
     }
     return g_gemm_variant;
+}
+// Per call (r05): the weight-gradient layout (A stored [K, M]) on the LDS-DMA kernel when the reduction is short — stage 1 (2048 tokens per step:
+// 48 weight gradients on the register-staged kernel) 6.35 -> 6.13 ms per step; at 8192 tokens it measures the same, at 131072 it loses 1.5 ms
+// (those shapes have the 256 x 256 wgrad kernel; what reaches this point then is better off with the in-kernel bias gradient of v1).
+static int gemm_variant_for(int a_trans, int64_t K) {
+    const int v = gemm_variant();
+    return (g_gemm_variant_auto && a_trans && K <= 4096) ? 3 : v;
 }
 
 template <bool SAFE, typename OutT>
@@ -1051,7 +1060,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     EMO_CHECK(!(ep.a_rowsum && ep.b_rowsum), "emo_gemm: a_rowsum and b_rowsum are exclusive");
     if (ep.b_rowsum) {
         EMO_CHECK(a_trans && b_trans, "emo_gemm: b_rowsum needs a_trans and b_trans (B stored [K, N]: the Conv1D wgrad layout)");
-        const bool in_kernel = dtype_in == EMO_BF16 && dtype_out == EMO_F32 && gemm_variant() < 3 && !use_safe_tr();
+        const bool in_kernel = dtype_in == EMO_BF16 && dtype_out == EMO_F32 && gemm_variant_for(a_trans, K) < 3 && !use_safe_tr();
         if (!in_kernel) {
             const int rc = emo_colsum(B, dtype_in, K, N, ldb, ep.b_rowsum, 1, stream);
             if (rc) return rc;
@@ -1060,7 +1069,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     }
     if (ep.a_rowsum) {
         EMO_CHECK(a_trans, "emo_gemm: a_rowsum needs a_trans (A stored [K, M]: the wgrad layout)");
-        const bool in_kernel = dtype_in == EMO_BF16 && dtype_out == EMO_F32 && b_trans && gemm_variant() < 3 && !use_safe_tr();
+        const bool in_kernel = dtype_in == EMO_BF16 && dtype_out == EMO_F32 && b_trans && gemm_variant_for(a_trans, K) < 3 && !use_safe_tr();
         if (!in_kernel) {                                   // other kernels: the plain column-sum launch over A [K, M]
             const int rc = emo_colsum(A, dtype_in, K, M, lda, ep.a_rowsum, 1, stream);
             if (rc) return rc;
@@ -1068,7 +1077,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         }
     }
     const bool big = dtype_in == EMO_BF16;
-    const int variant = big ? gemm_variant() : 0;
+    const int variant = big ? gemm_variant_for(a_trans, K) : 0;
     if (big && M <= 32 && !a_trans && !b_trans && (K % 32) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0 &&
         !accumulate) {
         dim3 g((unsigned)cdiv64(N, 16));

@@ -14,14 +14,28 @@ from emo_disentanger_amd.model.music_performer import MusicPerformer  # noqa: E4
 from emo_disentanger_amd.optim import FusedAdam  # noqa: E402
 
 B, T = int(os.environ.get('B', 4)), 2048
-m = MusicPerformer(327, 12, 8, 512, 2048, 512, use_segment_emb=True, n_segment_types=2, favor_feature_dims=128, compute_dtype='bf16').cuda().train()
+MODEL = os.environ.get('MODEL', 'performer')                      # performer | gpt2 | stage1
+if MODEL == 'stage1':
+    from emo_disentanger_amd.model.plain_transformer import PlainTransformer
+    T, V = 512, 200
+    m = PlainTransformer(512, V, 12, 8, 512, 2048, 0, T, dec_dropout=0.1, pre_lnorm=True, compute_dtype='bf16').cuda().train()
+    g = torch.Generator().manual_seed(1)
+    x, tgt = torch.randint(0, V - 1, (T, B), generator=g).cuda(), torch.randint(0, V - 1, (T, B), generator=g).cuda()
+    fwd = lambda: m.compute_loss(m(x, tuple())[0], tgt)['total_loss']
+else:
+    if MODEL == 'gpt2':
+        from emo_disentanger_amd.model.music_gpt2 import MusicGPT2
+        m = MusicGPT2(327, 12, 8, 512, 2048, 512, use_segment_emb=True, n_segment_types=2, dropout=0.1, compute_dtype='bf16').cuda().train()
+    else:
+        m = MusicPerformer(327, 12, 8, 512, 2048, 512, use_segment_emb=True, n_segment_types=2, favor_feature_dims=128, compute_dtype='bf16').cuda().train()
+    b = synthetic_batch(327, B, T, device='cuda')
+    fwd = lambda: m.compute_loss(m(b['dec_input'], seg_inp=b['track_mask']), b['dec_target'])['total_loss']
 opt = FusedAdam(m, lr=1e-5, max_grad_norm=0.5)
-b = synthetic_batch(327, B, T, device='cuda')
 
 
 def step():
     opt.zero_grad()
-    l = m.compute_loss(m(b['dec_input'], seg_inp=b['track_mask']), b['dec_target'])['total_loss']
+    l = fwd()
     l.backward()
     opt.step()
 
@@ -48,9 +62,7 @@ def gemm(A, Bm, **kw):
     return out
 
 
-ops.gemm = gemm
-from emo_disentanger_amd import engine  # noqa: E402
-engine.ops.gemm = gemm
+ops.gemm = gemm                                                  # (engine / plain_transformer call ops.gemm through the module attribute)
 step()
 torch.cuda.synchronize()
 for k, n in sorted(seen.items(), key=lambda t: (-t[1], t[0])):
