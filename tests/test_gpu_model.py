@@ -330,10 +330,13 @@ def test_padded_output_projection_equals_the_unpadded_one(monkeypatch):
     assert float((g0[wk] - g1[wk]).abs().max()) <= 2e-3 * float(g0[wk].abs().max())
 
 
-def test_bf16_mirror_follows_torch_side_weight_writes():
+@pytest.mark.parametrize('pad', ['0', '1'])
+def test_bf16_mirror_follows_torch_side_weight_writes(pad, monkeypatch):
     """The bf16 copy of the weights that the MFMA GEMMs read must follow EVERY write to the fp32 parameters, not only the fused
-    optimizer's: load_state_dict after a forward, and a stock torch.optim.Adam step on a GEMM weight (the reference's optimizer)."""
-    c = PERF_CASES[0]
+    optimizer's: load_state_dict after a forward, and a stock torch.optim.Adam step on a GEMM weight (the reference's optimizer).
+    pad = 1: with the padded output projection, whose zero-padded weight / bias copies are a second mirror (ParamStore.padded)."""
+    monkeypatch.setenv('EMO_LOGIT_PAD', pad)
+    c = PERF_CASES[1] if pad == '1' else PERF_CASES[0]
     from oracle.weights import make_state_dict, synthetic_batch
     b = synthetic_batch(c['V'], c['B'], c['T'], seed=79)
     x, seg, tgt = b['dec_input'].cuda(), b['track_mask'].cuda(), b['dec_target'].cuda()
@@ -362,6 +365,12 @@ def test_bf16_mirror_follows_torch_side_weight_writes():
     with torch.no_grad():
         c2 = m(x, seg_inp=seg)
     assert not torch.equal(c2, b2)
+    # ... and a torch-side write to the output projection (weight and bias) must reach the logits too
+    with torch.no_grad():
+        m.dec_out_proj.bias.add_(0.5)
+        m.dec_out_proj.weight.mul_(1.5)
+        c3 = m(x, seg_inp=seg)
+    assert float((c3 - c2).abs().mean()) > 0.1                    # (+0.5 on every bias, x 1.5 on every weight)
 
 
 @pytest.mark.parametrize('kind', ['performer', 'gpt2'])
