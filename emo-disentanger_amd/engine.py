@@ -509,7 +509,25 @@ class DecoderStackFn(torch.autograd.Function):
         else:
             dE = ps.g('token_emb.emb_lookup.weight')
             dS = ps.g('segemb.emb_lookup.weight') if ctx.seg is not None else None
-        if ctx.chord is None:
+        n_seg = model.n_segment_types if ctx.seg is not None else 0
+        eg = _os.environ.get('EMO_EMBED_GEMM', '')                 # '0' never / '1' always (tests, A/B); default: from 32768 tokens
+        if (ctx.chord is None and not proj and ps.compute_dtype == torch.bfloat16 and (eg == '1' or (eg != '0' and dx.shape[0] >= 32768))
+                and model.n_token + n_seg <= 512 and D % 256 == 0 and dx.shape[0] % 64 == 0):
+            # The scatter-add of the embedding gradient as ONE weight-gradient product against a 0 / 1 indicator matrix [M, 512] (column = token
+            # id, n_token + segment id): bf16 x 1.0 is exact and the sums are fp32 in a fixed order, without float atomics.  r05, benchmark batch:
+            # emo_embed_bwd 375 us (its LDS float atomics and 128-B row loads) -> dropout pass + indicator + the 256 x 256 wgrad kernel,
+            # same-box -0.32 ms per step.  Rounding: the dropped / rescaled gradient passes through bf16 once before the sum.
+            dxm = ops.dropout_apply(dx.contiguous(), p, seed, base) if p > 0.0 else dx.contiguous()
+            ind = torch.zeros(dx.shape[0], 512, device=dx.device, dtype=torch.bfloat16)
+            ind.scatter_(1, ctx.tok.reshape(-1, 1), 1.0)
+            if n_seg:
+                ind.scatter_(1, ctx.seg.reshape(-1, 1) + model.n_token, 1.0)
+            dEp = ops.gemm(ind, dxm, a_trans=True, b_trans=True, out_dtype=torch.float32)
+            sc = float(model.token_emb.emb_scale)
+            dE.add_(dEp[:model.n_token], alpha=sc)
+            if n_seg:
+                dS.add_(dEp[model.n_token:model.n_token + n_seg], alpha=sc)
+        elif ctx.chord is None:
             ops.embed_bwd(ctx.tok, ctx.seg, dx, dE, dS, float(model.token_emb.emb_scale), p_drop=p, seed=seed, offset=base)
         else:
             dxm = ops.dropout_apply(dx.contiguous(), p, seed, base) if p > 0.0 else dx.contiguous()

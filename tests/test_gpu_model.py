@@ -330,6 +330,33 @@ def test_padded_output_projection_equals_the_unpadded_one(monkeypatch):
     assert float((g0[wk] - g1[wk]).abs().max()) <= 2e-3 * float(g0[wk].abs().max())
 
 
+@pytest.mark.parametrize('p_drop', [0.0, 0.1])
+def test_embedding_gradient_as_a_product_equals_the_scatter_kernel(p_drop, monkeypatch):
+    """From 32768 tokens (bf16 mode) the embedding tables' gradient is ONE weight-gradient product against a 0 / 1 indicator matrix instead of
+    emo_embed_bwd's LDS float atomics (engine.DecoderStackFn.backward): same token and segment table gradients — the dropout mask is the same
+    (seed, offset, index) stream, the dropped gradient passes through bf16 once — and every other gradient unchanged."""
+    c = PERF_CASES[1]
+    from oracle.weights import synthetic_batch
+    b = synthetic_batch(c['V'], 2, 512, seed=33)
+    x, seg, tgt = b['dec_input'].cuda(), b['track_mask'].cuda(), b['dec_target'].cuda()
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('EMO_EMBED_GEMM', mode)
+        torch.manual_seed(5)
+        m, _ = _performer(c, 'bf16', dropout=p_drop)
+        m.train()
+        m.zero_grad()
+        m.compute_loss(m(x, seg_inp=seg), tgt)['total_loss'].backward()
+        res[mode] = {k: p.grad.detach().float().clone() for k, p in m.named_parameters()}
+    for k in res['0']:
+        a, bb = res['0'][k], res['1'][k]
+        if 'emb_lookup' in k:
+            assert float((a - bb).abs().max()) <= 1e-2 * float(a.abs().max()), k          # one bf16 rounding of each dropped element, summed over the tokens of an id
+            assert float((a - bb).norm()) <= 3e-3 * float(a.norm()), k
+        else:                                                     # (not touched by the change; bias gradients of small shapes are atomic column sums)
+            assert float((a - bb).abs().max()) <= 1e-6 * max(float(a.abs().max()), 1e-30), (k, float((a - bb).abs().max()), float(a.abs().max()))
+
+
 @pytest.mark.parametrize('pad', ['0', '1'])
 def test_bf16_mirror_follows_torch_side_weight_writes(pad, monkeypatch):
     """The bf16 copy of the weights that the MFMA GEMMs read must follow EVERY write to the fp32 parameters, not only the fused
