@@ -395,16 +395,24 @@ def _wgrad_conv1d(ps, wname, bname, xin, dy):
     _timed_wgrad(xin, dy, ps.g(wname), b_rowsum=ps.g(bname), stream=_side_fork(dy, xin))
 
 
-def gpt2_block_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
+def gpt2_block_bwd(ps, pfx, dout, B, T, H, p, seed, off, save, doutd=None, below_off=None):
+    """doutd: dout already multiplied with this block's MLP-output dropout mask (by the LayerNorm backward of the block above).  below_off: dropout
+    offset whose mask the returned gradient is ALSO wanted with — the block below's MLP-output dropout (off_below + 3) or the embedding dropout —
+    produced by this block's last LayerNorm backward instead of a separate pass (r05: 24 dropout_apply launches per step).  Returns (dx, dx masked)."""
     s = save.t
     D = dout.shape[1]
-    dyd = ops.dropout_apply(dout, p, seed, off + 3) if p > 0 else dout
+    dyd = doutd if doutd is not None else (ops.dropout_apply(dout, p, seed, off + 3) if p > 0 else dout)
     _wgrad_conv1d(ps, pfx + 'mlp.c_proj.weight', pfx + 'mlp.c_proj.bias', s['f'], dyd)
     dz = ops.gemm(dyd, ps.w(pfx + 'mlp.c_proj.weight'), mul_aux=s['z'], mul_mode=ops.MUL_DGELU_NEW)
     _wgrad_conv1d(ps, pfx + 'mlp.c_fc.weight', pfx + 'mlp.c_fc.bias', s['n2'], dz)
     dn2 = ops.gemm(dz, ps.w(pfx + 'mlp.c_fc.weight'))
-    dh, _ = ops.layernorm_bwd(dn2, s['h'], ps.f32(pfx + 'ln_2.weight'), s['m2'], s['r2'], ps.g(pfx + 'ln_2.weight'), ps.g(pfx + 'ln_2.bias'), dres=dout)
-    dad = ops.dropout_apply(dh, p, seed, off + 2) if p > 0 else dh
+    fuse = _os.environ.get('EMO_GPT2_FUSE_MASK', '1') != '0'       # (0: the separate dropout_apply passes, same-box A/B)
+    dh, dad = ops.layernorm_bwd(dn2, s['h'], ps.f32(pfx + 'ln_2.weight'), s['m2'], s['r2'], ps.g(pfx + 'ln_2.weight'), ps.g(pfx + 'ln_2.bias'), dres=dout,
+                                want_drop=p > 0 and fuse, p_drop=p, seed=seed, offset=off + 2)       # dad = dh with the attention-output dropout's mask
+    if dad is None:
+        dad = ops.dropout_apply(dh, p, seed, off + 2) if p > 0 else dh
+    if not fuse:
+        below_off = None
     _wgrad_conv1d(ps, pfx + 'attn.c_proj.weight', pfx + 'attn.c_proj.bias', s['a'], dad)
     da = ops.gemm(dad, ps.w(pfx + 'attn.c_proj.weight'))
     qkv = s['qkv']
@@ -412,8 +420,9 @@ def gpt2_block_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
     dqkv = dq._base
     _wgrad_conv1d(ps, pfx + 'attn.c_attn.weight', pfx + 'attn.c_attn.bias', s['n1'], dqkv)
     dn1 = ops.gemm(dqkv, ps.w(pfx + 'attn.c_attn.weight'))
-    dx, _ = ops.layernorm_bwd(dn1, s['x'], ps.f32(pfx + 'ln_1.weight'), s['m1'], s['r1'], ps.g(pfx + 'ln_1.weight'), ps.g(pfx + 'ln_1.bias'), dres=dh)
-    return dx
+    dx, dxd = ops.layernorm_bwd(dn1, s['x'], ps.f32(pfx + 'ln_1.weight'), s['m1'], s['r1'], ps.g(pfx + 'ln_1.weight'), ps.g(pfx + 'ln_1.bias'), dres=dh,
+                                want_drop=p > 0 and below_off is not None, p_drop=p, seed=seed, offset=below_off if below_off is not None else 0)
+    return dx, dxd
 
 
 # =================================================================================================== autograd nodes
@@ -493,11 +502,17 @@ class DecoderStackFn(torch.autograd.Function):
         dx = dout.reshape(B * T, D)
         if dx.dtype != ps.compute_dtype or not dx.is_contiguous():
             dx = dx.to(ps.compute_dtype).contiguous()
+        dxd = None                                                # GPT-2: dx with the dropout mask its consumer wants (the block below / the embedding)
+        n_seg = model.n_segment_types if ctx.seg is not None else 0
+        eg = _os.environ.get('EMO_EMBED_GEMM', '')                 # '0' never / '1' always (tests, A/B); default: from 32768 tokens
+        emb_gemm = (ctx.chord is None and model.d_embed == D and ps.compute_dtype == torch.bfloat16 and (eg == '1' or (eg != '0' and dx.shape[0] >= 32768))
+                    and model.n_token + n_seg <= 512 and D % 256 == 0 and dx.shape[0] % 64 == 0)
         for l in reversed(range(L)):
             if model.kind == 'performer':
                 dx = performer_layer_bwd(ps, model._layer_prefix(l), dx, B, T, H, p, seed, base + 8 * (l + 1), ctx.saves[l])
             else:
-                dx = gpt2_block_bwd(ps, model._layer_prefix(l), dx, B, T, H, p, seed, base + 8 * (l + 1), ctx.saves[l])
+                dx, dxd = gpt2_block_bwd(ps, model._layer_prefix(l), dx, B, T, H, p, seed, base + 8 * (l + 1), ctx.saves[l], doutd=dxd,
+                                         below_off=(base + 8 * l + 3) if l > 0 else (base if emb_gemm else None))
             ctx.saves[l] = None
             hook = getattr(model, '_bwd_hook', None)                 # data parallel: dp.GradExchange starts the late layers' all-reduce here
             if hook is not None:
@@ -509,15 +524,12 @@ class DecoderStackFn(torch.autograd.Function):
         else:
             dE = ps.g('token_emb.emb_lookup.weight')
             dS = ps.g('segemb.emb_lookup.weight') if ctx.seg is not None else None
-        n_seg = model.n_segment_types if ctx.seg is not None else 0
-        eg = _os.environ.get('EMO_EMBED_GEMM', '')                 # '0' never / '1' always (tests, A/B); default: from 32768 tokens
-        if (ctx.chord is None and not proj and ps.compute_dtype == torch.bfloat16 and (eg == '1' or (eg != '0' and dx.shape[0] >= 32768))
-                and model.n_token + n_seg <= 512 and D % 256 == 0 and dx.shape[0] % 64 == 0):
+        if emb_gemm:
             # The scatter-add of the embedding gradient as ONE weight-gradient product against a 0 / 1 indicator matrix [M, 512] (column = token
             # id, n_token + segment id): bf16 x 1.0 is exact and the sums are fp32 in a fixed order, without float atomics.  r05, benchmark batch:
             # emo_embed_bwd 375 us (its LDS float atomics and 128-B row loads) -> dropout pass + indicator + the 256 x 256 wgrad kernel,
             # same-box -0.32 ms per step.  Rounding: the dropped / rescaled gradient passes through bf16 once before the sum.
-            dxm = ops.dropout_apply(dx.contiguous(), p, seed, base) if p > 0.0 else dx.contiguous()
+            dxm = dxd if dxd is not None else (ops.dropout_apply(dx.contiguous(), p, seed, base) if p > 0.0 else dx.contiguous())
             ind = torch.zeros(dx.shape[0], 512, device=dx.device, dtype=torch.bfloat16)
             ind.scatter_(1, ctx.tok.reshape(-1, 1), 1.0)
             if n_seg:
