@@ -26,7 +26,8 @@ class Epilogue(ctypes.Structure):
     _fields_ = [('bias', c_p), ('act', c_i), ('aux_out', c_p), ('mul_aux', c_p), ('mul_mode', c_i), ('mul_scale', c_f),
                 ('p_drop', c_f), ('seed', c_u64), ('offset', c_u64), ('residual', c_p),
                 ('ln_c1', c_p), ('ln_eps', c_f), ('ln_stats_out', c_p), ('rln_x', c_p), ('rln_stats', c_p), ('rln_gamma', c_p), ('rln_beta', c_p), ('a_rowsum', c_p), ('b_rowsum', c_p),
-                ('mask_out', c_p), ('workspace', c_p), ('workspace_bytes', c_l)]
+                ('mask_out', c_p), ('workspace', c_p), ('workspace_bytes', c_l),
+                ('lna_gamma', c_p), ('lna_beta', c_p), ('lna_out', c_p), ('lna_mean', c_p), ('lna_rstd', c_p)]
 
 
 _SIG = {

@@ -1052,6 +1052,11 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         ep.a_rowsum = e->a_rowsum; ep.b_rowsum = e->b_rowsum; ep.mask_out = e->mask_out;
         ep.ln_c1 = e->ln_c1; ep.ln_stats_out = e->ln_stats_out; ep.ln_eps = e->ln_eps;
         ep.rln_x = e->rln_x; ep.rln_stats = e->rln_stats; ep.rln_gamma = e->rln_gamma; ep.rln_beta = e->rln_beta;
+        ep.lna_gamma = e->lna_gamma; ep.lna_beta = e->lna_beta; ep.lna_out = e->lna_out; ep.lna_mean = e->lna_mean; ep.lna_rstd = e->lna_rstd;
+        EMO_CHECK(!e->lna_gamma || (e->lna_beta && e->lna_out && e->lna_mean && e->lna_rstd && !a_trans && !b_trans && dtype_in == EMO_BF16 && !e->ln_c1 && !e->rln_x),
+                  "emo_gemm: lna_gamma needs lna_beta / lna_out / lna_mean / lna_rstd, bf16, NT, and no ln_c1 / rln_x");
+        EMO_CHECK(!e->lna_gamma || (K == 512 && (M % 128) == 0 && M >= 4096 && (N % 64) == 0 && N <= 2048 && !accumulate && (((uintptr_t)e->lna_out) & 15) == 0),
+                  "emo_gemm: lna_* (LayerNorm of the A operand) exists only on the A-stationary kernel: K = 512, M %% 128 == 0, M >= 4096, N %% 64 == 0, N <= 2048");
         EMO_CHECK(!e->rln_x || (e->rln_stats && e->rln_gamma && e->rln_beta && !e->act && !ep.drop.thr16 && !ep.mul_mode),
                   "emo_gemm: rln_x needs rln_stats/gamma/beta and no activation / dropout / mul epilogue");
         EMO_CHECK(!e->ln_stats_out || e->ln_c1, "emo_gemm: ln_stats_out needs ln_c1");
@@ -1097,7 +1102,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         g_last_gemm_kernel = 1;
         return EMO_OK;
     }
-    if (big && !a_trans && !b_trans && !ln_fused && !accumulate && !use_safe_tr()) {
+    if (big && !a_trans && !b_trans && !ln_fused && !accumulate && !use_safe_tr() && !ep.lna_gamma) {
         const int pk = emo_gemm_p256_try((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, dtype_out, M, N, K, ep, st);   // opt-in persistent tile walks (r05)
         if (pk) {
             EMO_LAUNCH_CHECK();
@@ -1118,6 +1123,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         g_last_gemm_kernel = 3;
         return EMO_OK;
     }
+    EMO_CHECK(!ep.lna_gamma, "emo_gemm: lna_* (LayerNorm of the A operand) exists only on the A-stationary kernel: bf16, NT, K = 512, M %% 128 == 0, M >= 4096, N %% 64 == 0, N <= 2048");
     if (big && !a_trans && !b_trans && !ln_fused && !accumulate &&
         emo_gemm_w128_try((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, dtype_out, M, N, K, ep, st)) {    // long-K NT products on 256 x 256 tiles (opt-in)
         EMO_LAUNCH_CHECK();

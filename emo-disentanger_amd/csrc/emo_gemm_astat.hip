@@ -26,6 +26,15 @@ constexpr int AS_K = 512, AS_BM = 128, AS_BN = 64, AS_KS = 128, AS_SLOT = AS_BN 
 constexpr int AS_MIN_BLOCKS = 32;                              // = ops.ASTAT_MIN_ROWS / 128 (ops.gemm_bitmask_ok mirrors it): below one panel per CU the columns are split
 constexpr int AS_MAXN = 2048;                                   // bias copy in LDS: 8 KB
 
+// sum over the four 16-lane rows of a wave (lanes l % 16 + 16 j), result in every lane: two VALU lane swaps (permlane32_swap / permlane16_swap)
+__device__ __forceinline__ float as_sum_lane_rows(float x) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, x);
+    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float y = __builtin_bit_cast(float, (uint32_t)a[0]) + __builtin_bit_cast(float, (uint32_t)a[1]);
+    const uint32_t w = __builtin_bit_cast(uint32_t, y);
+    const auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+    return __builtin_bit_cast(float, (uint32_t)b[0]) + __builtin_bit_cast(float, (uint32_t)b[1]);
+}
 __device__ __forceinline__ int as_swz(int row) { return (row & 3) | ((row >> 1) & 12); }
 // tile row (= output column inside the 64-column tile) that MFMA fragment f reads for its N-index i:
 // the lane with N-indices 4g..4g+3 of fragments 2h and 2h+1 then owns columns 32h + 8g .. +7
@@ -298,6 +307,11 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
 #pragma unroll
     for (int q = 0; q < AS_MAXN / 256; ++q)
         if (tid + 256 * q < n_tiles * AS_BN) bias_lds[tid + 256 * q] = bv[q];
+    float* lna_gb = (float*)(smem + 3 * AS_SLOT);                 // gamma [512] | beta [512]: the ring's last slot is not filled before the loop's first barrier
+    if (ep.lna_gamma) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { lna_gb[tid + 256 * q] = ep.lna_gamma[tid + 256 * q]; lna_gb[AS_K + tid + 256 * q] = ep.lna_beta[tid + 256 * q]; }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     as_wait<8>();                                                 // A fragments + stage 0 landed (stages 1, 2 may be in flight)
     // (hipcc does not see the asm DMA or this wait: without the pin below it answers the FIRST use of every A fragment inside the unrolled
@@ -308,6 +322,54 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                      "+v"(a[i][9]), "+v"(a[i][10]), "+v"(a[i][11]), "+v"(a[i][12]), "+v"(a[i][13]), "+v"(a[i][14]), "+v"(a[i][15]));
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (ep.lna_gamma) {
+        // LayerNorm of the A rows in place (emo_hip.h: lna_*): the wave's two row fragments hold complete 512-wide rows — row lane % 16 (+ 16 i), its
+        // 512 elements in the four lanes lane % 16 + 16 j.  The normalised rows and the statistics leave from column block 0 only.
+        // Statistics on the MFMA pipe (the VALU form — unpack + add, unpack + centre + square over 256 values per lane — was two thirds of this block's
+        // 10 k cycles): row sums = ones . A^T (every lane of column `row` gets the sum), sums of squares = the diagonal of the Gram matrix A A^T
+        // (lane group row / 4, register row % 4).  bf16 x bf16 products are exact in fp32; variance = E[x^2] - mean^2, clamped at 0.
+        float mean_[2], rstd_[2];
+        {
+            const bf16_t one_b = (bf16_t)1.f;
+            bf16x8 ones = {one_b, one_b, one_b, one_b, one_b, one_b, one_b, one_b};
+            asm volatile("" : "+v"(ones));
+            const int dr = lane & 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, gacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i][ks], sacc, 0, 0, 0);
+                    gacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], a[i][ks], gacc, 0, 0, 0);
+                }
+                const float dg = dr == 0 ? gacc[0] : dr == 1 ? gacc[1] : dr == 2 ? gacc[2] : gacc[3];
+                const float sq = as_sum_lane_rows((lane >> 4) == ((lane & 15) >> 2) ? dg : 0.f);
+                mean_[i] = sacc[0] * (1.f / AS_K);
+                rstd_[i] = rsqrtf(fmaxf(sq * (1.f / AS_K) - mean_[i] * mean_[i], 0.f) + ep.ln_eps);
+            }
+        }
+        const bool writer = blockIdx.y == 0;
+        bf16_t* lo = (bf16_t*)ep.lna_out + (m0 + (lane & 15)) * AS_K + (lane >> 4) * 8;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const f32x4 g0 = *(const f32x4*)(lna_gb + ks * 32 + (lane >> 4) * 8), g1 = *(const f32x4*)(lna_gb + ks * 32 + (lane >> 4) * 8 + 4);
+            const f32x4 b0 = *(const f32x4*)(lna_gb + AS_K + ks * 32 + (lane >> 4) * 8), b1 = *(const f32x4*)(lna_gb + AS_K + ks * 32 + (lane >> 4) * 8 + 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                bf16x8 y;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    y[e] = (bf16_t)(((float)a[i][ks][e] - mean_[i]) * rstd_[i] * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]));
+                a[i][ks] = y;
+                if (writer) *(bf16x8*)(lo + (int64_t)i * 16 * AS_K + ks * 32) = y;
+            }
+            __builtin_amdgcn_sched_barrier(0);                    // one k step at a time: the gamma / beta reads of later steps are not hoisted into the register peak
+        }
+        if (writer && lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { ep.lna_mean[m0 + 16 * i + lane] = mean_[i]; ep.lna_rstd[m0 + 16 * i + lane] = rstd_[i]; }
+        }
+    }
     // B fragments: 4 rotating register sets (step g of a column tile computes with set g & 3 and prefetches step g + 2 into set (g + 2) & 3,
     // so three sets are live: the LDS round trip is covered by 16 MFMAs of the wave itself, not only by the partner wave)
     bf16x8 bq[4][4];

@@ -30,6 +30,12 @@ struct EpiParams {
     int nt_store;        // A-stationary kernel: non-temporal output stores (set by its launcher for outputs too large to stay cached)
     int a_nt;            // streaming (non-temporal) hint on the A operand loads (A-stationary panel loads / 256 x 256 tile A tiles)
     int ablate;   // diagnostics only (EMO_GEMM_ABLATE): 1 = skip tile loads, 2 = skip MFMAs
+    // LayerNorm of the A operand inside the A-stationary kernel (emo_hip.h: lna_*)
+    const float* lna_gamma;
+    const float* lna_beta;
+    void* lna_out;
+    float* lna_mean;
+    float* lna_rstd;
 };
 
 // ------------------------------------------------------------------------------------------------

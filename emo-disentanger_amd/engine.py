@@ -231,12 +231,20 @@ class LayerCtx:
         self.t = {}
 
 
-def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save, act='relu'):
+def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save, act='relu', ln_in=None, defer_norm2=False):
     """Post-LN encoder layer with FAVOR+ causal attention.  x: [M, D].  act: 'relu' (every YAML of the reference) or 'gelu'
-    (upstream's F.gelu, passed through at fast_transformer_decoder.py:50: exact erf form on the generic epilogue, pre-activation saved)."""
+    (upstream's F.gelu, passed through at fast_transformer_decoder.py:50: exact erf form on the generic epilogue, pre-activation saved).
+    LayerNorm inside the product that consumes it (emo_hip.h lna_*, r05): norm1 runs inside the linear1 product; with defer_norm2 the layer returns
+    its un-normalised x2 and the NEXT layer passes ln_in = (gamma2, beta2, this layer's save) to run norm2 inside its QKV product (the statistics land
+    in this layer's save for the backward)."""
     D = x.shape[1]
     q = pfx + 'attention.query_projection.'
-    qkv = ops.gemm(x, ps.w(q + 'weight', 3 * D), bias=ps.f32(q + 'bias', 3 * D))
+    if ln_in is not None:                                          # x is the previous layer's raw x2
+        qkv, x, m_prev, r_prev = ops.gemm(x, ps.w(q + 'weight', 3 * D), bias=ps.f32(q + 'bias', 3 * D), lna=(ln_in[0], ln_in[1], 1e-5))
+        if ln_in[2] is not None:
+            ln_in[2].t['m2'], ln_in[2].t['r2'] = m_prev, r_prev
+    else:
+        qkv = ops.gemm(x, ps.w(q + 'weight', 3 * D), bias=ps.f32(q + 'bias', 3 * D))
     # (training with a time-segmented scan — B*H < 256: the call's workspace stays with the layer, its K-state increments serve the backward)
     fws = None
     if save is not None:
@@ -245,19 +253,27 @@ def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save, act='rel
         attn, den = ops.favor_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], omega, B, T, H)
     x1 = ops.gemm(attn, ps.w(pfx + 'attention.out_projection.weight'), bias=ps.f32(pfx + 'attention.out_projection.bias'),
                   p_drop=p, seed=seed, offset=off + 1, residual=x)
-    h1, m1, r1 = ops.layernorm_fwd(x1, ps.f32(pfx + 'norm1.weight'), ps.f32(pfx + 'norm1.bias'))
     W1 = ps.w(pfx + 'linear1.weight')
+    ln1_in = act == 'relu' and ops.gemm_lna_ok(x.shape[0], W1.shape[0], D, x1.dtype)
+    if not ln1_in:
+        h1, m1, r1 = ops.layernorm_fwd(x1, ps.f32(pfx + 'norm1.weight'), ps.f32(pfx + 'norm1.bias'))
     # 1-bit relu.dropout mask for the FFN2 dgrad (1/16 of the bytes of re-reading f), when the shape runs on the A-stationary kernel
     fmask = torch.empty(x.shape[0], W1.shape[0] // 8, device=x.device, dtype=torch.uint8) \
-        if (act == 'relu' and save is not None and ops.gemm_bitmask_ok(x.shape[0], W1.shape[0], D, h1.dtype, h1.dtype)) else None
+        if (act == 'relu' and save is not None and ops.gemm_bitmask_ok(x.shape[0], W1.shape[0], D, x1.dtype, x1.dtype)) else None
     z = None
-    if act == 'relu':
+    if ln1_in:
+        f, h1, m1, r1 = ops.gemm(x1, W1, bias=ps.f32(pfx + 'linear1.bias'), act=ops.ACT_RELU, p_drop=p, seed=seed, offset=off + 2, mask_out=fmask,
+                                 lna=(ps.f32(pfx + 'norm1.weight'), ps.f32(pfx + 'norm1.bias'), 1e-5))
+    elif act == 'relu':
         f = ops.gemm(h1, W1, bias=ps.f32(pfx + 'linear1.bias'), act=ops.ACT_RELU, p_drop=p, seed=seed, offset=off + 2, mask_out=fmask)
     else:
         z = torch.empty(x.shape[0], W1.shape[0], device=x.device, dtype=h1.dtype) if save is not None else None      # pre-activation for gelu'
         f = ops.gemm(h1, W1, bias=ps.f32(pfx + 'linear1.bias'), act=ops.ACT_GELU, aux_out=z, p_drop=p, seed=seed, offset=off + 2)
     x2 = ops.gemm(f, ps.w(pfx + 'linear2.weight'), bias=ps.f32(pfx + 'linear2.bias'), p_drop=p, seed=seed, offset=off + 3, residual=h1)
-    out, m2, r2 = ops.layernorm_fwd(x2, ps.f32(pfx + 'norm2.weight'), ps.f32(pfx + 'norm2.bias'))
+    if defer_norm2:
+        out, m2, r2 = x2, None, None                              # norm2 runs inside the next layer's QKV product, which fills m2 / r2 of this save
+    else:
+        out, m2, r2 = ops.layernorm_fwd(x2, ps.f32(pfx + 'norm2.weight'), ps.f32(pfx + 'norm2.bias'))
     if save is not None:
         save.t = dict(x=x, qkv=qkv, attn=attn, den=den, x1=x1, m1=m1, r1=r1, h1=h1, f=f, fmask=fmask, z=z, x2=x2, m2=m2, r2=r2, omega=omega, fws=fws)
     return out
@@ -375,15 +391,21 @@ def gpt2_block_fwd(ps, pfx, x, B, T, H, p, seed, off, save):
             return ops.gemm(inp, ps.wT(wname), **kw)
         return ops.gemm(inp, ps.w(wname), b_trans=True, **kw)
 
-    n1, m1, r1 = ops.layernorm_fwd(x, ps.f32(pfx + 'ln_1.weight'), ps.f32(pfx + 'ln_1.bias'))
-    qkv = lin(n1, pfx + 'attn.c_attn.weight', bias=ps.f32(pfx + 'attn.c_attn.bias'))
+    # LayerNorm inside the product that consumes it (emo_hip.h lna_*, r05): the A-stationary kernel holds complete rows of its A panel in registers
+    def ln_lin(inp, ln, wname, **kw):
+        g, b = ps.f32(pfx + ln + '.weight'), ps.f32(pfx + ln + '.bias')
+        if nt and ops.gemm_lna_ok(inp.shape[0], ps.shapes[wname][1], D, inp.dtype):
+            return ops.gemm(inp, ps.wT(wname), lna=(g, b, 1e-5), **kw)          # -> (product, LN(inp), mean, rstd)
+        n, m, r = ops.layernorm_fwd(inp, g, b)
+        return lin(n, wname, **kw), n, m, r
+
+    qkv, n1, m1, r1 = ln_lin(x, 'ln_1', pfx + 'attn.c_attn.weight', bias=ps.f32(pfx + 'attn.c_attn.bias'))
     # (training: the forward leaves the attention-dropout keep bits for the backward's dK/dV pass — one hash evaluation per score instead of two)
     a, lse, keep = ops.softmax_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, T, H, p_drop=p, seed=seed, offset=off + 1, want_keep=True) \
         if (save is not None and p > 0) else ops.softmax_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, T, H, p_drop=p, seed=seed, offset=off + 1) + (None,)
     h = lin(a, pfx + 'attn.c_proj.weight', bias=ps.f32(pfx + 'attn.c_proj.bias'), p_drop=p, seed=seed, offset=off + 2, residual=x)
-    n2, m2, r2 = ops.layernorm_fwd(h, ps.f32(pfx + 'ln_2.weight'), ps.f32(pfx + 'ln_2.bias'))
     z = torch.empty(x.shape[0], ps.shapes[pfx + 'mlp.c_fc.weight'][1], device=x.device, dtype=x.dtype) if save is not None else None
-    f = lin(n2, pfx + 'mlp.c_fc.weight', bias=ps.f32(pfx + 'mlp.c_fc.bias'), act=ops.ACT_GELU_NEW, aux_out=z)
+    f, n2, m2, r2 = ln_lin(h, 'ln_2', pfx + 'mlp.c_fc.weight', bias=ps.f32(pfx + 'mlp.c_fc.bias'), act=ops.ACT_GELU_NEW, aux_out=z)
     out = lin(f, pfx + 'mlp.c_proj.weight', bias=ps.f32(pfx + 'mlp.c_proj.bias'), p_drop=p, seed=seed, offset=off + 3, residual=h)
     if save is not None:
         save.t = dict(x=x, m1=m1, r1=r1, n1=n1, qkv=qkv, a=a, lse=lse, keep=keep, h=h, m2=m2, r2=r2, n2=n2, z=z, f=f)
@@ -483,10 +505,16 @@ class DecoderStackFn(torch.autograd.Function):
             torch.cuda.current_stream().wait_event(omega_ev)
             for t in omegas:
                 t.record_stream(torch.cuda.current_stream())
+        # norm2 of layer l inside layer l + 1's QKV product (performer_layer_fwd): possible when that product runs on the A-stationary kernel
+        chain = model.kind == 'performer' and ops.gemm_lna_ok(B * T, 3 * D, D, ps.compute_dtype) and _os.environ.get('EMO_LN2_IN_GEMM', '1') != '0'
+        ln_in = None
         for l in range(L):
             sv = LayerCtx() if need_bwd else None
             if model.kind == 'performer':
-                x = performer_layer_fwd(ps, model._layer_prefix(l), x, omegas[l], B, T, H, p, seed, base + 8 * (l + 1), sv, act=model.activation)
+                pfx = model._layer_prefix(l)
+                defer = chain and l + 1 < L
+                x = performer_layer_fwd(ps, pfx, x, omegas[l], B, T, H, p, seed, base + 8 * (l + 1), sv, act=model.activation, ln_in=ln_in, defer_norm2=defer)
+                ln_in = (ps.f32(pfx + 'norm2.weight'), ps.f32(pfx + 'norm2.bias'), sv) if defer else None
             else:
                 x = gpt2_block_fwd(ps, model._layer_prefix(l), x, B, T, H, p, seed, base + 8 * (l + 1), sv)
             saves.append(sv)

@@ -16,7 +16,7 @@ from ._lib import (ACT_GELU, ACT_GELU_NEW, ACT_NONE, ACT_RELU, BF16, F32, MUL_BI
 __all__ = ['gemm', 'colsum', 'embed_fwd', 'embed_bwd', 'layernorm_fwd', 'layernorm_bwd', 'dropout_apply', 'favor_attn_fwd',
            'favor_attn_bwd', 'favor_decode_step', 'performer_decode_step', 'performer_decode_step_sampled', 'favor_draw_omega', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'relpos_attn_fwd', 'relpos_attn_bwd', 'relpos_attn_decode', 'xent_fwd',
            'xent_bwd', 'argmax', 'sample_nucleus', 'sample_nucleus_step', 'accuracy_counts', 'sumsq', 'clip_coef', 'adam_step', 'cast', 'add_bias2',
-           'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'ACT_GELU', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW', 'MUL_DGELU', 'MUL_BITMASK', 'gemm_bitmask_ok', 'bitmask_rows']
+           'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'ACT_GELU', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW', 'MUL_DGELU', 'MUL_BITMASK', 'gemm_bitmask_ok', 'gemm_lna_ok', 'bitmask_rows']
 
 
 def _c(t):
@@ -76,10 +76,12 @@ def _workspace(kind, device, need, st=None):
 
 def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumulate=False, bias=None, act=ACT_NONE,
          aux_out=None, mul_aux=None, mul_mode=MUL_NONE, mul_scale=1.0, p_drop=0.0, seed=0, offset=0, residual=None,
-         ln_c1=None, ln_eps=1e-5, ln_stats_out=None, rln=None, a_rowsum=None, b_rowsum=None, mask_out=None, stream=None):
+         ln_c1=None, ln_eps=1e-5, ln_stats_out=None, rln=None, a_rowsum=None, b_rowsum=None, mask_out=None, stream=None, lna=None):
     """C[M,N] = epilogue(op(A) @ op(B));  a_trans: A stored [K,M];  b_trans=False: B stored [N,K] (nn.Linear),
     b_trans=True: B stored [K,N] (HF Conv1D).  ln_c1 / ln_stats_out / rln: LayerNorm folded around a decode-step GEMM (include/emo_hip.h).
-    stream: raw hipStream_t to launch on (default: torch's current stream)."""
+    stream: raw hipStream_t to launch on (default: torch's current stream).
+    lna = (gamma, beta, eps): A is the RAW input of a LayerNorm whose output is the operand — the A-stationary kernel normalises its row panel in
+    registers (gemm_lna_ok shapes only); returns (C, LN(A), mean, rstd) instead of C."""
     st = stream if stream is not None else _stream()
     K, M = (A.shape if a_trans else A.shape[::-1])
     Kb, N = (B.shape if b_trans else B.shape[::-1])
@@ -98,8 +100,16 @@ def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumu
         ws, ws_bytes = _workspace('gemm', A.device, need, st)
     rx, rstats, rgamma, rbeta = rln if rln is not None else (None, None, None, None)     # residual = LayerNorm(rx) from exported statistics
     assert rx is None or (rx.dtype == out.dtype and _rows(rx) == _rows(out))
+    ln_out = ln_mean = ln_rstd = None
+    if lna is not None:
+        assert gemm_lna_ok(M, N, K, A.dtype) and not a_trans and not b_trans and lna[0].dtype == torch.float32 and lna[1].dtype == torch.float32
+        ln_eps = lna[2]
+        ln_out = torch.empty(M, K, device=A.device, dtype=A.dtype)
+        ln_mean = torch.empty(M, device=A.device, dtype=torch.float32)
+        ln_rstd = torch.empty(M, device=A.device, dtype=torch.float32)
     epi = Epilogue(ptr(bias), act, ptr(aux_out), ptr(mul_aux), mul_mode, mul_scale, p_drop, seed, offset, ptr(residual),
-                   ptr(ln_c1), ln_eps, ptr(ln_stats_out), ptr(rx), ptr(rstats), ptr(rgamma), ptr(rbeta), ptr(a_rowsum), ptr(b_rowsum), ptr(mask_out), ptr(ws), ws_bytes)
+                   ptr(ln_c1), ln_eps, ptr(ln_stats_out), ptr(rx), ptr(rstats), ptr(rgamma), ptr(rbeta), ptr(a_rowsum), ptr(b_rowsum), ptr(mask_out), ptr(ws), ws_bytes,
+                   ptr(lna[0]) if lna is not None else None, ptr(lna[1]) if lna is not None else None, ptr(ln_out), ptr(ln_mean), ptr(ln_rstd))
     if not plain or mask_out is not None:
         for t in (aux_out, residual) + (() if mul_mode == MUL_BITMASK else (mul_aux,)):
             assert t is None or (t.dtype == out.dtype and _rows(t) == _rows(out))
@@ -130,6 +140,8 @@ def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumu
             kind += '/skinny'
         GEMM_TIMING.append((kind, e0, e1, 2.0 * M * N * K,
                             (M * K + N * K) * A.element_size() + M * N * out.element_size(), (M, N, K)))
+    if lna is not None:
+        return out, ln_out, ln_mean, ln_rstd
     return out
 
 
@@ -139,6 +151,12 @@ ASTAT_MIN_ROWS = int(os.environ.get('EMO_ASTAT_MIN_ROWS', 0)) or 128 * 32       
 def gemm_bitmask_ok(M, N, K, in_dtype, out_dtype):
     """Shape class in which emo_gemm writes / reads the 1-bit epilogue mask (mask_out / MUL_BITMASK): the A-stationary K = 512 kernel."""
     return in_dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and K == 512 and M % 128 == 0 and M >= ASTAT_MIN_ROWS and N % 64 == 0 and 64 <= N <= 2048
+
+
+def gemm_lna_ok(M, N, K, in_dtype):
+    """Shape class in which emo_gemm can take the LayerNorm of its A operand (lna=): the A-stationary K = 512 kernel (emo_hip.h: lna_*)."""
+    return (in_dtype == torch.bfloat16 and K == 512 and M % 128 == 0 and M >= ASTAT_MIN_ROWS and N % 64 == 0 and 64 <= N <= 2048
+            and os.environ.get('EMO_GEMM_NO_ASTAT') is None and os.environ.get('EMO_LN_IN_GEMM', '1') != '0')
 
 
 def bitmask_rows(mask, M, N):

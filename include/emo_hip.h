@@ -87,6 +87,17 @@ typedef struct {
     void* workspace;      /* NULL or caller scratch for split-K partial sums (plain fp32-output GEMMs = weight gradients): */
     int64_t workspace_bytes; /* with it the splits are summed in a fixed order by a reduce kernel (deterministic, no atomics);
                               * without it they are fp32 atomics into C.  Size: emo_gemm_workspace_bytes(). */
+    /* LayerNorm of the A operand inside the product (r05; replaces the standalone norm launch in front of a Linear — norm1 -> linear1 of
+     * fast-transformers' TransformerEncoderLayer via fast_transformer_decoder.py:45-51, ln_1 -> c_attn / ln_2 -> c_fc of HF GPT2Block via
+     * music_gpt2.py:42-51): A is the RAW tensor; the A-stationary kernel, which holds complete 512-wide rows in registers, computes
+     * mean / rstd per row (biased variance, ln_eps inside the sqrt), normalises in place with lna_gamma / lna_beta [K] and, besides the product,
+     * writes the normalised rows to lna_out [M, K] (dtype_in, contiguous: residual of the next Linear, operand of the weight gradient) and the
+     * statistics to lna_mean / lna_rstd [M].  Only in the A-stationary shape class (bf16, NT, K = 512, M % 128 == 0, M >= 4096); refused elsewhere. */
+    const float* lna_gamma;
+    const float* lna_beta;
+    void* lna_out;
+    float* lna_mean;
+    float* lna_rstd;
 } emo_epilogue_t;
 
 /* scratch that lets emo_gemm() run its split-K without atomics (0 = this problem is not split) */

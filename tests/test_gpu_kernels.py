@@ -1117,6 +1117,30 @@ def test_add_bias2_matches_torch(dt):
     assert torch.equal(o1, (q.float() + b1.view(1, D)).to(dt)) and torch.equal(o2, (q.float() + b2.view(1, D)).to(dt))
 
 
+@pytest.mark.parametrize('M,N', [(4096, 512), (8192, 2048), (32768 + 256, 1536)])
+def test_gemm_layernorm_of_the_a_operand_matches_the_separate_kernels(M, N):
+    # lna= (emo_hip.h lna_*, r05): the A-stationary kernel normalises its row panel in registers.  Against the standalone LayerNorm kernel + the same
+    # product: the normalised rows agree to one bf16 rounding (another summation order for mean / variance), the statistics to 1e-6, and the
+    # product of the kernel's OWN normalised rows is bit-identical to what it returns (the product reads exactly the rows it wrote).
+    ops = _ops()
+    K = 512
+    x = (_r(M, K, seed=1) * 1.7 + 0.3).to(torch.bfloat16).cuda()
+    W = _r(N, K, seed=2, scale=0.05).to(torch.bfloat16).cuda()
+    bias, g, b = _r(N, seed=3).cuda(), (1.0 + 0.1 * _r(K, seed=4)).cuda(), (0.1 * _r(K, seed=5)).cuda()
+    assert ops.gemm_lna_ok(M, N, K, torch.bfloat16)
+    for kw in (dict(bias=bias), dict(bias=bias, act=ops.ACT_RELU, p_drop=0.1, seed=7, offset=3)):
+        y, h, mean, rstd = ops.gemm(x, W, lna=(g, b, 1e-5), **kw)
+        h_ref, m_ref, r_ref = ops.layernorm_fwd(x, g, b)
+        xd = x.double()
+        mu = xd.mean(1)
+        var = ((xd - mu[:, None]) ** 2).mean(1)
+        assert float((mean.double() - mu).abs().max()) <= 1e-5 and float((rstd.double() * (var + 1e-5).sqrt() - 1).abs().max()) <= 1e-5
+        assert float((mean - m_ref).abs().max()) <= 1e-6 * max(1.0, float(m_ref.abs().max())) and float((rstd / r_ref - 1).abs().max()) <= 1e-5
+        d = (h.float() - h_ref.float()).abs()
+        assert float((d / h_ref.float().abs().clamp_min(0.25)).max()) <= 2 ** -7 and float((d > 0).float().mean()) < 0.01
+        assert torch.equal(y, ops.gemm(h, W, **kw))
+
+
 def test_stream_wait_orders_a_side_stream_launch_behind_the_main_stream():
     # emo_stream_wait (fork / join of the weight-gradient stream without torch Stream contexts) + ops.gemm(stream=raw handle): a product launched
     # on a second stream must see operands that the main stream is still producing when the launch is queued, and the main stream must see its
