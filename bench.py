@@ -174,7 +174,10 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
     roof['gemm_families'] = {k_: {'achieved_tflops': round(f_['flops'] / f_['ms'] / 1e9, 1), 'frac': round(f_['flops'] / f_['ms'] / 1e9 / PEAK_BF16_TFLOPS, 4),
                                   'total_ms_per_step': round(f_['ms'] / n_steps, 2)} for k_, f_ in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])}
     roof['timing'] = 'HIP events on the launch stream around every GEMM launch in %d real training steps (kernels serialized on one stream)' % n_steps
-    roof['rocprof_summary'] = ('profiles/r04_bench_train_rocprof_stats.txt = rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3 --no-cpu-baseline '
+    import glob
+    summaries = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_bench_train_rocprof_stats.txt')))
+    roof['rocprof_summary'] = ('profiles/%s = rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3 --no-cpu-baseline '
+                               % (os.path.basename(summaries[-1]) if summaries else '(none committed)') +
                                '--no-gen --no-stage1 --no-gpt2 --no-step0-check --no-b4` (training kernels only); PMC (traffic, mfma_busy, effective clock): ' + pmc_note)
     roof['roofline_others'] = [entry(k) for k in order[1:]] + [attn_entry(k, v, n_steps, pmc_all if B * T == 131072 else {}) for k, v in sorted(extra.items())]
     return roof
