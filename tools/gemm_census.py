@@ -47,11 +47,12 @@ real = ops.gemm
 
 
 def gemm(A, Bm, **kw):
-    out = real(A, Bm, **kw)
+    res = real(A, Bm, **kw)
+    out = res[0] if isinstance(res, tuple) else res               # (lna=: the product comes with LN(A), mean, rstd)
     a_t, b_t = kw.get('a_trans', False), kw.get('b_trans', False)
     K, M = (A.shape if a_t else A.shape[::-1])
     N = Bm.shape[1] if b_t else Bm.shape[0]
-    epi = '+'.join(k for k in ('bias', 'residual', 'mul_aux', 'mask_out', 'aux_out', 'a_rowsum', 'b_rowsum') if kw.get(k) is not None)
+    epi = '+'.join(k for k in ('lna', 'bias', 'residual', 'mul_aux', 'mask_out', 'aux_out', 'a_rowsum', 'b_rowsum') if kw.get(k) is not None)
     if kw.get('p_drop', 0.0) > 0:
         epi += '+drop'
     if kw.get('act', 0):
@@ -59,7 +60,7 @@ def gemm(A, Bm, **kw):
     if kw.get('accumulate'):
         epi += '+acc'
     seen[(('T' if a_t else 'N') + ('N' if b_t else 'T'), M, N, K, str(A.dtype)[6:], str(out.dtype)[6:], epi, ops.lib.emo_gemm_last_kernel())] += 1
-    return out
+    return res
 
 
 ops.gemm = gemm                                                  # (engine / plain_transformer call ops.gemm through the module attribute)
