@@ -99,3 +99,35 @@ def test_full_size_generation_is_consistent_with_teacher_forcing(dtype):
         eager = inf.generate_streams(m, ptok[:4], pseg[:4], 256, greedy=True, use_graph=False)
         graph = inf.generate_streams(m, ptok[:4], pseg[:4], 256, greedy=True)
         assert torch.equal(eager, graph)
+
+def test_large_batch_fast_paths_train_like_the_plain_paths(monkeypatch):
+    """End to end through forward, backward, clip and FusedAdam at 32 x 2048 tokens: the large-batch fast paths (output projection on 512 padded
+    columns, embedding gradient as a product, LayerNorm inside the consuming K = 512 products) and the same steps with them switched off follow
+    the same loss curve on a learnable batch (next token = a fixed function of the current one), and the loss falls."""
+    from emo_disentanger_amd.data import synthetic_batch
+    from emo_disentanger_amd.model.music_performer import MusicPerformer
+    from emo_disentanger_amd.optim import FusedAdam
+    c = SHAPE
+    curves = {}
+    for name, env in (('fast', {}), ('off', {'EMO_LOGIT_PAD': '0', 'EMO_EMBED_GEMM': '0', 'EMO_LN_IN_GEMM': '0'})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        torch.manual_seed(0)
+        m = MusicPerformer(c['V'], c['L'], c['H'], c['d'], c['dff'], c['d'], favor_feature_dims=c['nf'], use_segment_emb=True, n_segment_types=2,
+                           compute_dtype='bf16', dropout=0.0, redraw='fixed').cuda().train()
+        opt = FusedAdam(m, lr=3e-4, max_grad_norm=0.5)
+        b = synthetic_batch(c['V'], 32, c['T'], device='cuda', seed=11)
+        tgt = (b['dec_input'] * 7 + 3) % (c['V'] - 1)
+        ls = []
+        for _ in range(10):
+            opt.zero_grad()
+            loss = m.compute_loss(m(b['dec_input'], seg_inp=b['track_mask']), tgt)['total_loss']
+            loss.backward()
+            opt.step()
+            ls.append(float(loss.detach()))
+        curves[name] = ls
+        for k in env:
+            monkeypatch.delenv(k)
+        del m, opt
+    assert curves['fast'][-1] < 0.8 * curves['fast'][0] and curves['off'][-1] < 0.8 * curves['off'][0], curves
+    assert max(abs(a - b_) for a, b_ in zip(curves['fast'], curves['off'])) < 0.03, curves
