@@ -36,6 +36,7 @@ _SIG = {
     'emo_device_cus': (c_i, []),
     'emo_gemm': (c_i, [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, ctypes.POINTER(Epilogue), c_p]),
     'emo_gemm_last_kernel': (c_i, []),
+    'emo_epilogue_size': (c_i, []),
     'emo_gemm_workspace_bytes': (c_l, [c_l, c_l, c_l, c_i, c_i]),
     'emo_colsum': (c_i, [c_p, c_i, c_l, c_l, c_l, c_p, c_i, c_p]),
     'emo_embed_fwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_l, c_l, c_l, c_l, c_l, c_p, c_f, c_f, c_u64, c_u64, c_p]),
@@ -93,6 +94,9 @@ _SIG = {
 for _name, (_res, _args) in _SIG.items():
     _fn = getattr(lib, _name)          # AttributeError here = header/library mismatch
     _fn.restype, _fn.argtypes = _res, _args
+if lib.emo_epilogue_size() != ctypes.sizeof(Epilogue):      # a stale libemo_hip.so (or a stale mirror above) would read garbage pointers
+    raise ImportError('libemo_hip.so was built with an emo_epilogue_t of %d bytes, this binding has %d: rebuild (python -c "import __graft_entry__ as g; g.build()")'
+                      % (lib.emo_epilogue_size(), ctypes.sizeof(Epilogue)))
 
 
 class EmoError(RuntimeError):

@@ -1003,6 +1003,7 @@ static int64_t choose_splits(int64_t M, int64_t N, int64_t K, bool big, bool has
 // one its shape suggests): 1 skinny (M <= 32), 2 A-stationary K = 512, 3 256 x 256 tile wgrad, 4 256 x 256 tile NT, 5 128 x 128 LDS-DMA ring,
 // 6 128 x 128 register-staged, 7 exact-fp32; + 16 split-K through the workspace, + 32 split-K with the reduce-and-epilogue pass
 static thread_local int g_last_gemm_kernel = 0;
+extern "C" int emo_epilogue_size(void) { return (int)sizeof(emo_epilogue_t); }
 extern "C" int emo_gemm_last_kernel(void) { return g_last_gemm_kernel; }
 
 #define EMO_GEMM_MAX_SPLITS 32

@@ -104,6 +104,8 @@ typedef struct {
 /* diagnostics: kernel family of the calling thread's last emo_gemm (1 skinny, 2 A-stationary K = 512, 3 / 4 256 x 256 tile wgrad / NT,
  * 5 / 6 128 x 128 LDS-DMA / register-staged, 7 exact-fp32, 8 persistent 256 x 256 tile walk (EMO_GEMM_P256=1), 9 128 x 512 tile (EMO_GEMM_Q512=1); + 16 split-K via the workspace, + 32 with the reduce-and-epilogue pass) */
 int emo_gemm_last_kernel(void);
+/* sizeof(emo_epilogue_t) as the library was built — a binding checks its own mirror of the struct against it before the first call */
+int emo_epilogue_size(void);
 int64_t emo_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype_in, int dtype_out);
 
 int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, int b_trans, int64_t ldb,

@@ -37,3 +37,11 @@ def test_invalid_arguments_raise_without_a_gpu():
         _lib.ptr(torch.zeros(3))           # CPU tensor: the product path has no CPU fallback
     with pytest.raises(_lib.EmoError):
         _lib.dtype_code(torch.float16)
+
+
+def test_epilogue_struct_mirror_has_the_library_size():
+    # the ctypes mirror of emo_epilogue_t (fields are appended as epilogue features are added) must match the struct the library was built with
+    import ctypes
+    from emo_disentanger_amd import _lib
+    assert _lib.lib.emo_epilogue_size() == ctypes.sizeof(_lib.Epilogue)
+
