@@ -583,9 +583,10 @@ def test_layernorm_fwd_bf16_d512_fast_path(M):
     assert float(((rstd.cpu().double() - want_rstd) / want_rstd).abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize('M,V', [(301, 327), (2049, 327), (1027, 200), (1500, 450), (1100, 700)])
+@pytest.mark.parametrize('M,V', [(301, 327), (2049, 327), (1027, 200), (1500, 450), (1100, 700), (1027, 512), (4099, 512)])
 def test_xent_fwd_bwd_and_accuracy(M, V):
-    # M >= 1024 and V <= 512 take the register-row kernels (two rows per wave step; odd M exercises the tail), V = 700 the generic ones
+    # M >= 1024 and V <= 512 take the register-row kernels (two rows per wave step; odd M exercises the tail), V = 700 the generic ones,
+    # V = 512 = the padded output projection
     ops = _ops()
     from oracle import host_ref
     logits = (_r(M, V, seed=1) * 3).requires_grad_(True)
