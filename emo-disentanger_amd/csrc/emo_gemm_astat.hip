@@ -525,11 +525,15 @@ bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t l
     const size_t lds = AS_RING + AS_MAXN * sizeof(float);
     const int n_tiles_all = (int)(N / AS_BN);
     int split = 1;
-    if (M / AS_BM < 256)                                           // the smallest split that gives every CU a block (measured at 8192 / 16384 rows,
-        for (int sp = 2; sp <= n_tiles_all / 2; ++sp)             // tools/bench_astat_split.py: 4 / 2 column blocks beat 8 / 4 and 16 / 8)
+    // the smallest split that gives every CU one block — two for the long column sweeps (N >= 2048), where a lone block per CU leaves the MFMA pipe
+    // without a partner wave for 32 column tiles (tools/bench_astat_split.py at 8192 / 16384 / 32768 rows; GPT-2 step at 32768 tokens, whose
+    // products ran one block per CU: 19.0 -> 18.4 ms with two)
+    const int64_t want_blocks = N >= 2048 ? 512 : 256;
+    if (M / AS_BM < want_blocks)
+        for (int sp = 2; sp <= n_tiles_all / 2; ++sp)
             if (n_tiles_all % sp == 0) {
                 split = sp;
-                if ((M / AS_BM) * sp >= 256) break;
+                if ((M / AS_BM) * sp >= want_blocks) break;
             }
     { const char* e = getenv("EMO_ASTAT_SPLIT"); if (e && atoi(e) > 0 && n_tiles_all % atoi(e) == 0) split = atoi(e); }      // (tests / experiments)
     const int tiles_per_block = n_tiles_all / split;
