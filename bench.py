@@ -178,7 +178,7 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
     summaries = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_bench_train_rocprof_stats.txt')))
     roof['rocprof_summary'] = ('profiles/%s = rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3 --no-cpu-baseline '
                                % (os.path.basename(summaries[-1]) if summaries else '(none committed)') +
-                               '--no-gen --no-stage1 --no-gpt2 --no-step0-check --no-b4` (training kernels only); PMC (traffic, mfma_busy, effective clock): ' + pmc_note)
+                               '--no-gen --no-stage1 --no-gpt2 --no-step0-check --no-b4 --no-fp32` (training kernels only); PMC (traffic, mfma_busy, effective clock): ' + pmc_note)
     roof['roofline_others'] = [entry(k) for k in order[1:]] + [attn_entry(k, v, n_steps, pmc_all if B * T == 131072 else {}) for k, v in sorted(extra.items())]
     return roof
 
@@ -381,7 +381,10 @@ def step0_check(model, batch):
     out['abs_err_fp32'] = abs(out['loss_hip_fp32'] - out['loss_oracle'])
     out['abs_err_bf16'] = abs(out['loss_hip_bf16'] - out['loss_oracle'])
     out['abs_err'] = out['abs_err_bf16']
-    out['ok'] = bool(out['abs_err_fp32'] <= 1e-4 and out['abs_err_bf16'] <= 5e-3)
+    # north_star's bound (1e-4) is asserted for the fp32 parity mode; the timed bf16 mode is held to 3e-4 (the mean of 2048 signed per-token
+    # errors of ~1e-2: its size moves with the summation order) and the line says whether it ALSO met 1e-4 on this sample
+    out['bf16_meets_1e-4'] = bool(out['abs_err_bf16'] <= 1e-4)
+    out['ok'] = bool(out['abs_err_fp32'] <= 1e-4 and out['abs_err_bf16'] <= 3e-4)
     out['sample'] = 'first sequence (B=1 x T=%d) of the timed batch, the timed weights, omega fixed, dropout 0' % x.shape[1]
     return out
 
@@ -508,6 +511,52 @@ def b4_bench(model, opt_cls, tr, steps=30, warm=5):
             'mean_loss': round(loss, 4)}
 
 
+PEAK_F32_TFLOPS = 157.3        # exact-f32 MFMA peak (v_mfma_f32_*_f32), /opt/skills/guides/cdna_hip_programming.md
+
+
+def fp32_parity_bench(tr, opt_cls, B, T, steps=5, warm=3):
+    """The mode in which north_star's tolerances are asserted (loss within 1e-4 of the CPU oracle, exact greedy ids: tests/test_gpu_model.py, step0_check)
+    on the clock (r05 verdict): the SAME product loop (train.train_model, dropout 0.1, omega redrawn every forward, fused clip + Adam) with
+    compute_dtype='fp32' — fp32 storage, exact-f32 MFMA products (v_mfma_f32_16x16x4_f32 = an fp32 FMA chain), fp32 FAVOR+ / LayerNorm / loss.
+    B = the benchmark's batch when it fits, halved on an out-of-memory error.  Roofline: the model's GEMM flops per step against the 157.3-TFLOP/s
+    exact-f32 MFMA peak (the fp32 kernels are the parity yardstick, not tuned: 64 x 64 x 16 tiles, register-staged)."""
+    import contextlib
+    import tempfile
+    from emo_disentanger_amd.data import synthetic_batch
+    from emo_disentanger_amd.model.music_performer import MusicPerformer
+    while B >= 1:
+        try:
+            with contextlib.redirect_stdout(sys.stderr):
+                m = MusicPerformer(CFG['n_token'], CFG['n_layer'], CFG['n_head'], CFG['d_model'], CFG['d_ff'], CFG['d_model'], favor_feature_dims=CFG['n_feat'],
+                                   use_segment_emb=True, n_segment_types=2, dropout=0.1, compute_dtype='fp32', redraw='every_forward').cuda().train()
+            bs = [synthetic_batch(CFG['n_token'], B, T, seed=777 + i, device='cuda') for i in range(2)]
+            cfg = tr.TrainConfig(warmup_steps=200, max_lr=1e-4, min_lr=1e-5, lr_decay_steps=500000, redraw_prob=1.0, log_interval=10 ** 9,
+                                 ckpt_dir=tempfile.mkdtemp(prefix='emo_bench_fp32_'), verbose=False)
+            opt = opt_cls(m, lr=1e-4, max_grad_norm=0.5)
+            tr.train_model(1, m, [bs[i % 2] for i in range(warm)], opt, None, CFG['n_token'] - 1, cfg=cfg)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loss = tr.train_model(1, m, [bs[i % 2] for i in range(steps)], opt, None, CFG['n_token'] - 1, cfg=cfg)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            break
+        except torch.OutOfMemoryError:
+            m = opt = bs = None
+            torch.cuda.empty_cache()
+            B //= 2
+    else:
+        return {'error': 'out of memory at B = 1'}
+    tf = B * T * gemm_flops_per_token() / dt / 1e12
+    return {'metric': 'train tokens/sec in the fp32 parity mode', 'value': round(B * T / dt, 1), 'unit': 'tokens/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': steps, 'warmup': warm,
+            'dtype': 'f32', 'config': {'workload': 'stage2 Performer d512 L12 H8 F128 seq=%d, B=%d, compute_dtype=fp32 (exact-f32 MFMA), dropout 0.1, omega redraw every forward, '
+                                                   'fwd+bwd+clip+Adam through train.train_model' % (T, B)},
+            'mean_loss': round(loss, 4),
+            'roofline': {'bound': 'mfma', 'achieved': round(tf, 1), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_F32_TFLOPS, 4),
+                         'note': 'GEMM flops of the model per step (227.5 MFLOP per token) / whole step time, against the exact-f32 MFMA peak'},
+            'tolerances': 'this is the mode whose loss is within 1e-4 of the CPU oracle and whose greedy ids are exact (step0_check.abs_err_fp32, '
+                          'tests/test_gpu_model.py::test_performer_at_benchmark_shape_matches_oracle[fp32-*])'}
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) through torch.distributed.run and exit with its
     status.  Fails instead of shrinking the job when the node has fewer than N GPUs."""
@@ -539,6 +588,7 @@ def main():
     ap.add_argument('--no-gpt2', action='store_true')
     ap.add_argument('--no-step0-check', action='store_true')
     ap.add_argument('--no-b4', action='store_true')
+    ap.add_argument('--no-fp32', action='store_true', help='skip the fp32 parity-mode leg')
     ap.add_argument('--dp-selftest', action='store_true', help='N > 1: run only the gradient-exchange self-test and exit')
     args = ap.parse_args()
 
@@ -675,6 +725,9 @@ def main():
                 out['gen']['cpu_baseline'] = cpu_generation_baseline()
         if world == 1 and not args.no_b4:
             out['b4'] = b4_bench(model, FusedAdam, tr)
+        if world == 1 and not args.no_fp32:
+            out['fp32_parity'] = fp32_parity_bench(tr, FusedAdam, B, T)
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_stage1:
             out['stage1'] = stage1_bench()
         if world == 1 and not args.no_gpt2:

@@ -32,6 +32,7 @@ class Epilogue(ctypes.Structure):
 
 _SIG = {
     'emo_version': (c_i, []),
+    'emo_build_flags': (c_i, []),
     'emo_last_error': (ctypes.c_char_p, []),
     'emo_device_cus': (c_i, []),
     'emo_gemm': (c_i, [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, ctypes.POINTER(Epilogue), c_p]),

@@ -17,6 +17,13 @@ void emo_set_error(const char* fmt, ...) {
 }
 extern "C" const char* emo_last_error(void) { return g_err; }
 extern "C" int emo_version(void) { return 100; }
+extern "C" int emo_build_flags(void) {
+#ifdef EMO_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" int emo_device_cus(void) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -1049,13 +1056,20 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(const int64_t* __r
 }
 
 // `waiter` continues only after everything queued on `signaler` so far: one event record + one stream wait.  Events come from a small per-thread
-// ring (a wait holds the record it was issued behind, so re-recording an event 32 forks later cannot disturb it).
+// ring per device (a wait holds the record it was issued behind, so re-recording an event 32 forks later cannot disturb it).
 extern "C" int emo_stream_wait(emo_stream_t waiter, emo_stream_t signaler) {
-    constexpr int RING = 32;
-    static thread_local hipEvent_t ev[RING] = {};
-    static thread_local int next = 0;
-    hipEvent_t& e = ev[next];
-    next = (next + 1) % RING;
+    constexpr int RING = 32, MAXDEV = 16;
+    // (one ring per device: an event belongs to the device that was current when it was created, and recording it on another device's stream fails —
+    // a thread that switches devices gets that device's own ring)
+    static thread_local hipEvent_t ev[MAXDEV][RING] = {};
+    static thread_local int next[MAXDEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) {
+        emo_set_error("emo_stream_wait: device index %d outside [0, %d)", dev, MAXDEV);
+        return EMO_ERR_INVALID;
+    }
+    hipEvent_t& e = ev[dev][next[dev]];
+    next[dev] = (next[dev] + 1) % RING;
     if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
         emo_set_error("emo_stream_wait: hipEventCreate failed");
         return EMO_ERR_LAUNCH;

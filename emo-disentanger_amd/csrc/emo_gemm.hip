@@ -1103,6 +1103,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         g_last_gemm_kernel = 1;
         return EMO_OK;
     }
+#ifdef EMO_EXPERIMENTAL
     if (big && !a_trans && !b_trans && !ln_fused && !accumulate && !use_safe_tr() && !ep.lna_gamma) {
         const int pk = emo_gemm_p256_try((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, dtype_out, M, N, K, ep, st);   // opt-in persistent tile walks (r05)
         if (pk) {
@@ -1111,6 +1112,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
             return EMO_OK;
         }
     }
+#endif
     if (big && !a_trans && !b_trans && !ln_fused && !use_safe_tr() &&
         emo_gemm_astat_try((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, dtype_out, M, N, K, ep, st)) {   // K = 512, A stationary in registers
         EMO_LAUNCH_CHECK();
@@ -1131,7 +1133,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         g_last_gemm_kernel = 4;
         return EMO_OK;
     }
-    EMO_CHECK(!ep.mask_out && ep.mul_mode != EMO_MUL_BITMASK, "emo_gemm: mask_out / EMO_MUL_BITMASK need bf16 in/out, NT, K = 512, M %% 128 == 0, M >= 32768, N %% 64 == 0, N <= 2048");
+    EMO_CHECK(!ep.mask_out && ep.mul_mode != EMO_MUL_BITMASK, "emo_gemm: mask_out / EMO_MUL_BITMASK need bf16 in/out, NT, K = 512, M %% 128 == 0, M >= 4096, N %% 64 == 0, N <= 2048");
     EMO_CHECK(!ln_fused, "emo_gemm: the LayerNorm-folded epilogue (ln_c1 / rln_x) exists only on the skinny path (bf16, M <= 32, NT, K %% 32 == 0)");
     const int64_t BMt = big ? GB_M : 64, BNt = big ? GB_N : 64;
     const int64_t BKt = big ? (variant >= 2 ? G2_BK : GB_K) : 16;

@@ -29,6 +29,9 @@
 // other CUs' K loops.  What would have to change for the persistent walk to win: CUs out of phase without idle time (a stream-K split of each
 // CU's first tile costs 128 MB of fp32 partials per launch on a product that is already bound by its HBM stream), or output tiles staged in
 // registers and stored during the next tile's K loop (needs 128 more VGPRs per wave than the 256-register accumulator leaves).
+// Built only with -DEMO_EXPERIMENTAL (`make EXTRA=-DEMO_EXPERIMENTAL`, r06): both kernels of this file lose inside the training step and are
+// measured negatives, not product; emo_build_flags() & 1 tells a binding whether they are in the library.
+#ifdef EMO_EXPERIMENTAL
 #include "emo_gemm_epi.h"
 
 namespace {
@@ -682,3 +685,5 @@ int emo_gemm_p256_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb
 #undef P_LAUNCH
     return 8;
 }
+
+#endif  // EMO_EXPERIMENTAL

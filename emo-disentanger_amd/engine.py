@@ -11,6 +11,7 @@ Activations are [B*T, D] row-major in the compute dtype; LayerNorm statistics, s
 normalisers, logits and all gradients of parameters are fp32.
 """
 import math
+import weakref
 
 import torch
 
@@ -261,6 +262,24 @@ def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save, act='rel
     fmask = torch.empty(x.shape[0], W1.shape[0] // 8, device=x.device, dtype=torch.uint8) \
         if (act == 'relu' and save is not None and ops.gemm_bitmask_ok(x.shape[0], W1.shape[0], D, x1.dtype, x1.dtype)) else None
     z = None
+    chf = int(_os.environ.get('EMO_FFN_CHUNK_F', 0))
+    if ln1_in and chf and x.shape[0] > chf and x.shape[0] % chf == 0:      # PROBE: FFN1 -> FFN2 per row chunk (the hidden chunk stays in the Infinity Cache)
+        M_ = x.shape[0]
+        f = torch.empty(M_, W1.shape[0], device=x.device, dtype=x1.dtype)
+        h1, x2 = torch.empty_like(x1), torch.empty_like(x1)
+        m1, r1 = torch.empty(M_, device=x.device, dtype=torch.float32), torch.empty(M_, device=x.device, dtype=torch.float32)
+        for r0 in range(0, M_, chf):
+            sl = slice(r0, r0 + chf)
+            ops.gemm(x1[sl], W1, bias=ps.f32(pfx + 'linear1.bias'), act=ops.ACT_RELU, p_drop=p, seed=seed, offset=off + 2, mask_out=None if fmask is None else fmask[sl],
+                     lna=(ps.f32(pfx + 'norm1.weight'), ps.f32(pfx + 'norm1.bias'), 1e-5), lna_out=(h1[sl], m1[sl], r1[sl]), out=f[sl])
+            ops.gemm(f[sl], ps.w(pfx + 'linear2.weight'), bias=ps.f32(pfx + 'linear2.bias'), p_drop=p, seed=seed, offset=off + 3, residual=h1[sl], out=x2[sl])
+        if defer_norm2:
+            out, m2, r2 = x2, None, None
+        else:
+            out, m2, r2 = ops.layernorm_fwd(x2, ps.f32(pfx + 'norm2.weight'), ps.f32(pfx + 'norm2.bias'))
+        if save is not None:
+            save.t = dict(x=x, qkv=qkv, attn=attn, den=den, x1=x1, m1=m1, r1=r1, h1=h1, f=f, fmask=fmask, z=z, x2=x2, m2=m2, r2=r2, omega=omega, fws=fws)
+        return out
     if ln1_in:
         f, h1, m1, r1 = ops.gemm(x1, W1, bias=ps.f32(pfx + 'linear1.bias'), act=ops.ACT_RELU, p_drop=p, seed=seed, offset=off + 2, mask_out=fmask,
                                  lna=(ps.f32(pfx + 'norm1.weight'), ps.f32(pfx + 'norm1.bias'), 1e-5))
@@ -345,9 +364,23 @@ def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
                                 want_drop=p > 0, p_drop=p, seed=seed, offset=off + 3, dcol=ps.g(pfx + 'linear2.bias'))
     if dyd is None:
         dyd = g2
-    _wgrad(ps, pfx + 'linear2.weight', pfx + 'linear2.bias', dyd, s['f'], bias_done=True)
+    bf = ps.flat16 is not None and D == 512 and dout.shape[0] % 128 == 0 and dout.shape[0] >= ops.ASTAT_MIN_ROWS
+    chb = int(_os.environ.get('EMO_FFN_CHUNK_B', 0))
+    chunked = bool(bf and chb and s['fmask'] is not None and s.get('z') is None and dout.shape[0] > chb and dout.shape[0] % chb == 0)
+    if chunked:                                                     # PROBE: the FFN backward per row chunk (df stays in the Infinity Cache for its two readers)
+        dh1 = torch.empty_like(dyd)
+        for r0 in range(0, dout.shape[0], chb):
+            sl = slice(r0, r0 + chb)
+            _wgrad(ps, pfx + 'linear2.weight', pfx + 'linear2.bias', dyd[sl], s['f'][sl], bias_done=True)
+            dfc = ops.gemm(dyd[sl], ps.wT(pfx + 'linear2.weight'), mul_aux=s['fmask'][sl], mul_mode=ops.MUL_BITMASK, mul_scale=inv)
+            _wgrad(ps, pfx + 'linear1.weight', pfx + 'linear1.bias', dfc, s['h1'][sl])
+            ops.gemm(dfc, ps.wT(pfx + 'linear1.weight'), residual=g2[sl], out=dh1[sl])
+    else:
+        _wgrad(ps, pfx + 'linear2.weight', pfx + 'linear2.bias', dyd, s['f'], bias_done=True)
     bf = ps.flat16 is not None and D == 512 and dout.shape[0] % 128 == 0 and dout.shape[0] >= ops.ASTAT_MIN_ROWS     # the A-stationary K = 512 class
-    if s.get('z') is not None:                       # activation = 'gelu': df = (dyd W2) * gelu'(z), then the hidden dropout's multipliers again
+    if chunked:
+        pass
+    elif s.get('z') is not None:                       # activation = 'gelu': df = (dyd W2) * gelu'(z), then the hidden dropout's multipliers again
         df = ops.gemm(dyd, ps.w(pfx + 'linear2.weight'), b_trans=True, mul_aux=s['z'], mul_mode=ops.MUL_DGELU)
         if p > 0:
             df = ops.dropout_apply(df, p, seed, off + 2)
@@ -357,12 +390,14 @@ def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
         df = ops.gemm(dyd, ps.wT(pfx + 'linear2.weight'), mul_aux=s['f'], mul_mode=ops.MUL_NONZERO, mul_scale=inv)
     else:
         df = ops.gemm(dyd, ps.w(pfx + 'linear2.weight'), b_trans=True, mul_aux=s['f'], mul_mode=ops.MUL_NONZERO, mul_scale=inv)
-    _wgrad(ps, pfx + 'linear1.weight', pfx + 'linear1.bias', df, s['h1'])
+    if not chunked:
+        _wgrad(ps, pfx + 'linear1.weight', pfx + 'linear1.bias', df, s['h1'])
     # the long-reduction dgrads (K = 2048 / 1536) as NT products against transposed mirrors too: 256 x 256 tile kernel (emo_gemm_w128.hip).
     # From 32768 tokens, where M / 256 * N / 256 >= 256 tiles holds for N = 512; below that (the reference batch size 4) the long-reduction
     # dgrads stay NN products on the 128 x 128 kernel (the K = 512 ones above already run on the column-split A-stationary kernel from 4096 tokens).
     nt_long = bf and dout.shape[0] >= 32768 and dout.shape[0] % 256 == 0 and _os.environ.get('EMO_DGRAD_NT', '1') != '0'
-    dh1 = ops.gemm(df, ps.wT(pfx + 'linear1.weight'), residual=g2) if nt_long else ops.gemm(df, ps.w(pfx + 'linear1.weight'), b_trans=True, residual=g2)
+    if not chunked:
+        dh1 = ops.gemm(df, ps.wT(pfx + 'linear1.weight'), residual=g2) if nt_long else ops.gemm(df, ps.w(pfx + 'linear1.weight'), b_trans=True, residual=g2)
     g1, da = ops.layernorm_bwd(dh1, s['x1'], ps.f32(pfx + 'norm1.weight'), s['m1'], s['r1'], ps.g(pfx + 'norm1.weight'), ps.g(pfx + 'norm1.bias'),
                                want_drop=p > 0, p_drop=p, seed=seed, offset=off + 1, dcol=ps.g(pfx + 'attention.out_projection.bias'))
     if da is None:
@@ -609,6 +644,7 @@ class LogitsFn(torch.autograd.Function):
         ctx.model, ctx.h2, ctx.shp = model, h2, shp
         if Vp:
             buf = ops.gemm(h2, ps.padded('dec_out_proj.weight', Vp), bias=ps.padded('dec_out_proj.bias', Vp, LOGIT_PAD_FILL, master=True), out_dtype=torch.float32)
+            _tag_padded(buf)
             return buf[:, :V].view(*shp[:-1], V)                  # strided view: XentFn / accuracy find the padded buffer behind it
         logits = ops.gemm(h2, ps.w('dec_out_proj.weight'), bias=ps.f32('dec_out_proj.bias'), out_dtype=torch.float32)
         return logits.view(*shp[:-1], -1)
@@ -676,11 +712,29 @@ class XentFn(torch.autograd.Function):
         return g, None, None
 
 
+_PADDED = {}                   # data_ptr -> weakref of a buffer LogitsFn.forward produced (pad columns = LOGIT_PAD_FILL)
+
+
+def _tag_padded(buf):
+    key = buf.data_ptr()
+
+    def drop(ref, key=key):
+        if _PADDED.get(key) is ref:
+            del _PADDED[key]
+    _PADDED[key] = weakref.ref(buf, drop)
+
+
 def padded_logits(logits):
-    """The contiguous [M, Vp] buffer of LogitsFn's padded projection when `logits` is its [.., :V] view (pad columns = LOGIT_PAD_FILL), else None."""
+    """The contiguous [M, Vp] buffer of LogitsFn's padded projection when `logits` is its [.., :V] view (pad columns = LOGIT_PAD_FILL), else None.
+    Only buffers that LogitsFn.forward itself produced and that are still alive qualify (r05 advisor finding: geometry alone also matched a
+    user's [.., :V] slice of any wider fp32 tensor, whose extra columns are real logits)."""
     base = logits._base
     V = logits.shape[-1]
     if base is None or base.dim() != 2 or not base.is_contiguous() or base.dtype != torch.float32 or base.shape[1] <= V or base.shape[1] % 128:
+        return None
+    ref = _PADDED.get(base.data_ptr())
+    tagged = ref() if ref is not None else None
+    if tagged is None or tagged.shape != base.shape:
         return None
     M = logits.numel() // V
     if base.shape[0] != M or logits.data_ptr() != base.data_ptr() or logits.reshape(-1, V).stride() != (base.shape[1], 1):

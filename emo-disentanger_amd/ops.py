@@ -69,6 +69,11 @@ def _workspace(kind, device, need, st=None):
     key = (kind, device, st if st is not None else stream())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < need:
+        if buf is not None and st is not None and st != stream():
+            # (r05 advisor finding) the scratch of a side-stream launch is allocated from the CURRENT stream's pool: the buffer that is being
+            # replaced may still be in use by an earlier launch on `st`, and without this mark the caching allocator would hand its block to the
+            # next main-stream allocation as soon as the reference drops
+            buf.record_stream(torch.cuda.ExternalStream(st))
         buf = torch.empty(need, device=device, dtype=torch.uint8)
         _ws_cache[key] = buf
     return buf, need
@@ -76,7 +81,7 @@ def _workspace(kind, device, need, st=None):
 
 def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumulate=False, bias=None, act=ACT_NONE,
          aux_out=None, mul_aux=None, mul_mode=MUL_NONE, mul_scale=1.0, p_drop=0.0, seed=0, offset=0, residual=None,
-         ln_c1=None, ln_eps=1e-5, ln_stats_out=None, rln=None, a_rowsum=None, b_rowsum=None, mask_out=None, stream=None, lna=None):
+         ln_c1=None, ln_eps=1e-5, ln_stats_out=None, rln=None, a_rowsum=None, b_rowsum=None, mask_out=None, stream=None, lna=None, lna_out=None):
     """C[M,N] = epilogue(op(A) @ op(B));  a_trans: A stored [K,M];  b_trans=False: B stored [N,K] (nn.Linear),
     b_trans=True: B stored [K,N] (HF Conv1D).  ln_c1 / ln_stats_out / rln: LayerNorm folded around a decode-step GEMM (include/emo_hip.h).
     stream: raw hipStream_t to launch on (default: torch's current stream).
@@ -103,10 +108,16 @@ def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumu
     ln_out = ln_mean = ln_rstd = None
     if lna is not None:
         assert gemm_lna_ok(M, N, K, A.dtype) and not a_trans and not b_trans and lna[0].dtype == torch.float32 and lna[1].dtype == torch.float32
+        assert _rows(A) % 8 == 0 and _rows(B) % 8 == 0 and _rows(out) % 8 == 0 and (A.data_ptr() | B.data_ptr() | out.data_ptr()) % 16 == 0, \
+            'lna=: the A-stationary kernel needs 16-B aligned operands and row strides that are multiples of 8 elements'
         ln_eps = lna[2]
-        ln_out = torch.empty(M, K, device=A.device, dtype=A.dtype)
-        ln_mean = torch.empty(M, device=A.device, dtype=torch.float32)
-        ln_rstd = torch.empty(M, device=A.device, dtype=torch.float32)
+        if lna_out is not None:                                    # caller's (rows, mean, rstd) buffers: row chunks of one tensor
+            ln_out, ln_mean, ln_rstd = lna_out
+            assert ln_out.shape == (M, K) and ln_out.is_contiguous() and ln_out.dtype == A.dtype and ln_mean.numel() == M and ln_rstd.numel() == M
+        else:
+            ln_out = torch.empty(M, K, device=A.device, dtype=A.dtype)
+            ln_mean = torch.empty(M, device=A.device, dtype=torch.float32)
+            ln_rstd = torch.empty(M, device=A.device, dtype=torch.float32)
     epi = Epilogue(ptr(bias), act, ptr(aux_out), ptr(mul_aux), mul_mode, mul_scale, p_drop, seed, offset, ptr(residual),
                    ptr(ln_c1), ln_eps, ptr(ln_stats_out), ptr(rx), ptr(rstats), ptr(rgamma), ptr(rbeta), ptr(a_rowsum), ptr(b_rowsum), ptr(mask_out), ptr(ws), ws_bytes,
                    ptr(lna[0]) if lna is not None else None, ptr(lna[1]) if lna is not None else None, ptr(ln_out), ptr(ln_mean), ptr(ln_rstd))
@@ -155,8 +166,11 @@ def gemm_bitmask_ok(M, N, K, in_dtype, out_dtype):
 
 def gemm_lna_ok(M, N, K, in_dtype):
     """Shape class in which emo_gemm can take the LayerNorm of its A operand (lna=): the A-stationary K = 512 kernel (emo_hip.h: lna_*)."""
+    # (mirrors every refusal of emo_gemm_astat_try that does not depend on the tensors: shape class, EMO_GEMM_NO_ASTAT, the safe-transpose
+    # diagnostics mode; strides / alignment are asserted by gemm() itself, which owns the tensors — lna_* has no other kernel to fall back to)
     return (in_dtype == torch.bfloat16 and K == 512 and M % 128 == 0 and M >= ASTAT_MIN_ROWS and N % 64 == 0 and 64 <= N <= 2048
-            and os.environ.get('EMO_GEMM_NO_ASTAT') is None and os.environ.get('EMO_LN_IN_GEMM', '1') != '0')
+            and os.environ.get('EMO_GEMM_NO_ASTAT') is None and os.environ.get('EMO_LN_IN_GEMM', '1') != '0'
+            and os.environ.get('EMO_GEMM_SAFE_TR', '0') in ('', '0'))
 
 
 def bitmask_rows(mask, M, N):

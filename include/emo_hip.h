@@ -37,6 +37,9 @@ enum { EMO_ACT_NONE = 0, EMO_ACT_RELU = 1, EMO_ACT_GELU_NEW = 2, EMO_ACT_GELU = 
 enum { EMO_MUL_NONE = 0, EMO_MUL_NONZERO = 1, EMO_MUL_DGELU_NEW = 2, EMO_MUL_BITMASK = 3, EMO_MUL_DGELU = 4 };   /* DGELU: *= d/dx of the erf form at mul_aux */
 
 int emo_version(void);
+/* build options of the library: bit 0 = the opt-in experimental GEMM kernels (emo_gemm_p256.hip: persistent 256 x 256 tile walk, 128 x 512 tile — measured
+ * negatives inside the training step, built only with `make EXTRA=-DEMO_EXPERIMENTAL`; without them EMO_GEMM_P256 / EMO_GEMM_Q512 have no effect) */
+int emo_build_flags(void);
 const char* emo_last_error(void);
 /* number of CUs of the current device (for grid sizing on the host side) */
 int emo_device_cus(void);
@@ -83,7 +86,7 @@ typedef struct {
                            * bytes of a 32-row x 64-column tile are contiguous at ((m/32)*(N/64) + n/64)*256; inside, byte
                            * ((n%32)/8*16 + m%16)*4 + (m%32)/16*2 + (n%64)/32 holds columns 8*(n/8) .. +7 of row m, bit j = column 8*(n/8)+j
                            * (a lane's four bytes of a tile are one dword: ONE 256-byte store / load per wave of the A-stationary kernel).  Only with EMO_MUL_BITMASK's
-                           * shape class: bf16 in/out, NT, K = 512, M % 128 == 0, M >= 32768, N % 64 == 0, N <= 2048 (the A-stationary kernel); refused elsewhere. */
+                           * shape class: bf16 in/out, NT, K = 512, M % 128 == 0, M >= 4096, N % 64 == 0, N <= 2048 (the A-stationary kernel); refused elsewhere. */
     void* workspace;      /* NULL or caller scratch for split-K partial sums (plain fp32-output GEMMs = weight gradients): */
     int64_t workspace_bytes; /* with it the splits are summed in a fixed order by a reduce kernel (deterministic, no atomics);
                               * without it they are fp32 atomics into C.  Size: emo_gemm_workspace_bytes(). */

@@ -231,8 +231,15 @@ def test_gemm_256_tile_nt_matches_reference_and_128_tile(shape, monkeypatch):
             _close(y1, ref, torch.bfloat16, mult=1.0)
 
 
+def _need_experimental():
+    # the opt-in kernels of emo_gemm_p256.hip are only in a library built with `make EXTRA=-DEMO_EXPERIMENTAL` (emo_build_flags() & 1)
+    if not (_ops().lib.emo_build_flags() & 1):
+        pytest.skip('libemo_hip.so built without -DEMO_EXPERIMENTAL')
+
+
 @pytest.mark.parametrize('shape', [(512, 256, 320), (1024, 512, 2048), (2048, 768, 1024), (256, 1024, 4096), (8192, 512, 64), (2304, 256, 96), (131072, 512, 1536)])
 def test_gemm_persistent_256_tile_matches_reference(shape, monkeypatch):
+    _need_experimental()
     # emo_gemm_p256.hip (r05, opt-in EMO_GEMM_P256=1): persistent tile walk, 32 x 32 x 16 MFMA, 32-deep slabs in a 5 + 5 ring.  Shapes cover
     # one tile per block (no walk), fewer blocks than CUs, several tiles per block with the operand stream crossing tile boundaries (2304 x 256 =
     # 9 tiles on 8 blocks; the last shape = the QKV dgrad of the benchmark: 4 tiles per CU), K = 64 (first slab is also the last), every
@@ -267,6 +274,7 @@ def test_gemm_persistent_256_tile_matches_reference(shape, monkeypatch):
 @pytest.mark.parametrize('shape', [(128, 512, 64), (1152, 512, 256), (256, 1024, 2048), (65536, 512, 1536)])
 @pytest.mark.parametrize('persist', ['0', '1'])
 def test_gemm_full_n_tile_matches_reference(shape, persist, monkeypatch):
+    _need_experimental()
     # gemm_q512_kernel (emo_gemm_p256.hip, r05, opt-in EMO_GEMM_Q512=1): 128 x 512 tile — every A byte requested once, a lane's outputs complete
     # 128-B lines; A ring 8 slabs deep, B ring 3.  One tile per block and (EMO_Q512_PERSIST=1) blocks walking several tiles with the two operand
     # streams crossing tile boundaries at different times; K = 64 (first slab is also the last); N = 1024 (two column tiles per row panel).
@@ -296,6 +304,7 @@ def test_gemm_full_n_tile_matches_reference(shape, persist, monkeypatch):
 
 
 def test_gemm_persistent_256_tile_leaves_other_shapes_to_the_other_kernels(monkeypatch):
+    _need_experimental()
     # EMO_GEMM_P256=1 only takes M, N multiples of 256, K a multiple of 32 (>= 64), bf16 outputs, bias / dropout / residual epilogues: everything
     # else must run (and be right) on the kernels it ran on before
     ops = _ops()

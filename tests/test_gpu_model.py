@@ -163,8 +163,8 @@ def test_performer_at_benchmark_shape_matches_oracle(dtype, scale):
     MI355X (r02): |dloss| 1.7e-5 / 8.3e-5, max |dlogit| 0.014 / 0.031, largest gradient-element error 3.7 % / 7.8 % of the largest
     gradient at weight scale 1.0 / 2.5 (the loss error is the MEAN of ~2048 per-token errors of either sign, each ~1e-2 at scale 2.5: its
     expected size is 1e-2 / sqrt(2048) = 2e-4 and it moves with any change of summation order — 2.7e-4 after the FAVOR+ forward went to
-    transposed LDS reads with unchanged logit / gradient errors); asserted at loss 6e-4, logits 5e-2, gradient elements 12 %, per-parameter
-    relative L2 15 %."""
+    transposed LDS reads with unchanged logit / gradient errors); asserted at loss 1e-4 (scale 1.0) / 4.5e-4 (scale 2.5), logits 5e-2, gradient
+    elements 5.6 % / 11 %, per-parameter relative L2 15.3 %."""
     from emo_disentanger_amd.model.music_performer import MusicPerformer
     c = BENCH_SHAPE
     sd, b, rloss, rlogits, rgrads = _bench_oracle(scale)
@@ -191,7 +191,11 @@ def test_performer_at_benchmark_shape_matches_oracle(dtype, scale):
     else:
         # measured + 50 % (r03: gradient elements 3.7 % / 7.3 % at scale 1.0 / 2.5, per-parameter relative L2 10.2 % at 2.5; the site-by-site
         # attribution is test_bf16_error_budget_by_site: inter-kernel bf16 activations 7.6 %, GEMM operand rounding 5.2 %, FAVOR+ in bf16 2.3 %)
-        assert loss_err <= 6e-4 and logit_err <= 5e-2 and gerr <= (0.056 if scale == 1.0 else 0.11) and gl2 <= 0.153, (loss_err, logit_err, gerr, gl2)
+        # loss (r06, r05 verdict "the timed mode's asserted bounds are looser than north_star's"): at the init-scale weights bench.py times the bf16 mode
+        # is held to north_star's own 1e-4 (measured 1.1e-5 .. 1.7e-5 over rounds 2-6); at the trained-like scale 2.5 — a mean of ~2048 signed
+        # per-token errors of ~1e-2 each — measured 8.3e-5 .. 2.8e-4 depending on the summation order, asserted at 4.5e-4 (r02-r05: 6e-4 for both)
+        assert loss_err <= (1e-4 if scale == 1.0 else 4.5e-4), loss_err
+        assert logit_err <= 5e-2 and gerr <= (0.056 if scale == 1.0 else 0.11) and gl2 <= 0.153, (loss_err, logit_err, gerr, gl2)
 
 
 def _round_bf16_(t):
@@ -316,6 +320,12 @@ def test_padded_output_projection_equals_the_unpadded_one(monkeypatch):
         m.zero_grad()
         logits = m(x, seg_inp=seg)
         assert logits.shape[-1] == c['V'] and (logits._base is not None and logits._base.shape[-1] == 512) == (mode == '1')
+        # the loss / accuracy kernels recognise the padded buffer by a tag LogitsFn.forward leaves, not by geometry (r05 advisor finding):
+        # a user's [.., :V] slice of some other 512-wide fp32 tensor has real values in its extra columns and must not be taken for one
+        from emo_disentanger_amd.engine import padded_logits
+        assert (padded_logits(logits) is not None) == (mode == '1')
+        other = torch.randn(logits.numel() // c['V'], 512, device='cuda')
+        assert padded_logits(other[:, :c['V']].view(*logits.shape)) is None
         loss = m.compute_loss(logits, tgt)['total_loss']
         loss.backward()
         acc = tr.compute_accuracy(logits, tgt, b['chord_idx'].cuda(), b['melody_idx'].cuda(), c['V'] - 1)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box A/B of one environment setting inside the product training step: tools/ab_env.sh NAME VALUE_A VALUE_B  (VALUE "-" = unset)
-F="--steps 10 --warmup 3 --no-cpu-baseline --no-gen --no-stage1 --no-gpt2 --no-step0-check --no-b4"
+F="--steps 10 --warmup 3 --no-cpu-baseline --no-gen --no-stage1 --no-gpt2 --no-step0-check --no-b4 --no-fp32"
 N=$1; A=$2; B=$3
 for v in "$A" "$B" "$A" "$B"; do
   if [ "$v" = "-" ]; then unset $N; else export $N="$v"; fi

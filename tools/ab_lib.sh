@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box A/B of two builds of the library: emo-disentanger_amd/_ab_old.so vs _ab_new.so (both built here, git-ignored), product bench loop
-F="--steps 10 --warmup 3 --no-cpu-baseline --no-gen --no-stage1 --no-gpt2 --no-step0-check --no-b4"
+F="--steps 10 --warmup 3 --no-cpu-baseline --no-gen --no-stage1 --no-gpt2 --no-step0-check --no-b4 --no-fp32"
 P=emo-disentanger_amd
 for v in old new old new; do
   cp $P/_ab_$v.so $P/libemo_hip.so

@@ -6,7 +6,7 @@ set -u
 R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-rocprofv3 --kernel-trace --stats -d gpurun_out/${R}_stats -o x -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-gen --no-stage1 --no-gpt2 --no-step0-check --no-b4 > gpurun_out/${R}_stats_bench.json 2> gpurun_out/${R}_stats.log
+rocprofv3 --kernel-trace --stats -d gpurun_out/${R}_stats -o x -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-gen --no-stage1 --no-gpt2 --no-step0-check --no-b4 --no-fp32 > gpurun_out/${R}_stats_bench.json 2> gpurun_out/${R}_stats.log
 python tools/rocprof_summary.py gpurun_out/${R}_stats/x_results.db gpurun_out/${R}_bench_train_rocprof_stats.txt 13 > /dev/null
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"; do
