@@ -55,6 +55,7 @@ GEMM_KERNELS = {   # class of ops.gemm (one per kernel INSTANCE of the rocprofv3
     'NT': ('gemm_bf16_glds_kernel<true,true,bf16,32,3>', 'forward Y = X W^T + fused epilogue, K = 512 (shapes outside the A-stationary class)'),
     'NT/K=512/plain': ('gemm_astat_kernel<bf16,0> (A stationary in registers, weights through the LDS ring)', 'K = 512, bias-only epilogue: QKV forward, out-projection dgrad'),
     'NT/K=512/relu+drop+mask': ('gemm_astat_kernel<bf16,19>', 'K = 512: FFN1 forward with ReLU + dropout + 1-bit mask output'),
+    'NT/K=512/hdiv': ('gemm_astat_kernel<bf16,256>', 'K = 512, N = 512: out-projection dgrad leaving dN = dout / den (per-row, per-head divisor in the epilogue)'),
     'NT/K=512/bits': ('gemm_astat_kernel<bf16,8>', 'K = 512: FFN2 dgrad through the 1-bit relu.dropout mask'),
     'NT/K=512/drop+res': ('gemm_astat_kernel<bf16,6>', 'K = 512, N = 512: out-projection forward with dropout + residual (HBM-bound)'),
     'NT/K=512': ('gemm_astat_kernel<bf16,FL> (other epilogue instances)', 'K = 512 products'),

@@ -27,7 +27,7 @@ class Epilogue(ctypes.Structure):
                 ('p_drop', c_f), ('seed', c_u64), ('offset', c_u64), ('residual', c_p),
                 ('ln_c1', c_p), ('ln_eps', c_f), ('ln_stats_out', c_p), ('rln_x', c_p), ('rln_stats', c_p), ('rln_gamma', c_p), ('rln_beta', c_p), ('a_rowsum', c_p), ('b_rowsum', c_p),
                 ('mask_out', c_p), ('workspace', c_p), ('workspace_bytes', c_l),
-                ('lna_gamma', c_p), ('lna_beta', c_p), ('lna_out', c_p), ('lna_mean', c_p), ('lna_rstd', c_p)]
+                ('lna_gamma', c_p), ('lna_beta', c_p), ('lna_out', c_p), ('lna_mean', c_p), ('lna_rstd', c_p), ('hdiv', c_p), ('hdiv_T', c_l)]
 
 
 _SIG = {
@@ -51,6 +51,8 @@ _SIG = {
     'emo_favor_attn_fwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_l, c_l, c_l, c_l, c_l, c_f, c_p, c_l, c_p]),
     'emo_favor_attn_bwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_l, c_f, c_p, c_l, c_p]),
     'emo_favor_attn_bwd_kstate': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_l, c_f, c_p, c_l, c_i, c_p]),
+    'emo_favor_attn_bwd_dn_supported': (c_i, [c_i, c_l, c_l, c_l, c_l, c_l]),
+    'emo_favor_attn_bwd_dn': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_l, c_f, c_p]),
     'emo_favor_decode_step': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_f, c_p]),
     'emo_performer_decode_step_workspace_bytes': (c_l, []),
     'emo_performer_decode_step_supported': (c_i, []),

@@ -1348,6 +1348,16 @@ static int run_favor(int which, const void* q, const void* k, const void* v, int
             (void)hipFuncSetAttribute((const void*)k2s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
             attr = true;
         }
+        if (den == nullptr) {
+            // emo_favor_attn_bwd_dn: `dout` is dN = dout / den already — only the slice kernels' single-segment instances take that form
+            EMO_CHECK(FS && P == 1, "emo_favor_attn_bwd_dn: needs bf16, d_head 64, 128 features and a single-segment scan (B * H >= 256): emo_favor_attn_bwd_dn_supported()");
+            if (!fs_try(1) || !fs_try(2)) {
+                emo_set_error("emo_favor_attn_bwd_dn: the slice kernels refused this call (T %% 32, 16-B alignment, EMO_FAVOR_FS / EMO_FAVOR_FS_BWD = 0)");
+                return EMO_ERR_UNSUPPORTED;
+            }
+            EMO_LAUNCH_CHECK();
+            return EMO_OK;
+        }
         // P > 1: the K-state increments are recomputed (state-only forward pass), then the workspace is reused for the R-state increments
         // (kstate_valid: the caller kept the forward's workspace — the same increments — for this call: emo_favor_attn_bwd_kstate)
         if (P > 1 && !kstate_valid)
@@ -1425,6 +1435,28 @@ extern "C" int emo_favor_attn_bwd_kstate(const void* q, const void* k, const voi
     EMO_CHECK((((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)out | (uintptr_t)dout) & 15) == 0, "emo_favor_attn_bwd: pointers must be 16-B aligned");
     return dispatch_favor(1, dtype, dh, n_feat / 2, q, k, v, ld, omega, (void*)out, ld_out, (float*)den, nullptr, nullptr, dout, dq, dk, dv, ld_d, B, T, H,
                           eps, workspace, workspace_bytes, (hipStream_t)stream, kstate_valid != 0 && workspace != nullptr);
+}
+// 1 when emo_favor_attn_bwd_dn serves this problem (the single-segment slice kernels), else 0
+extern "C" int emo_favor_attn_bwd_dn_supported(int dtype, int64_t B, int64_t T, int64_t H, int64_t dh, int64_t n_feat) {
+    if (dtype != EMO_BF16 || dh != 64 || n_feat != 128 || T < 32 || (T % 32) != 0 || B * H <= 0) return 0;
+    const char* e = getenv("EMO_FAVOR_FS");
+    const char* e2 = getenv("EMO_FAVOR_FS_BWD");
+    if ((e && atoi(e) == 0) || (e2 && atoi(e2) == 0)) return 0;
+    int P; int64_t Ts;
+    favor_segments(B, T, H, &P, &Ts);
+    return P <= 1 ? 1 : 0;
+}
+extern "C" int emo_favor_attn_bwd_dn(const void* q, const void* k, const void* v, int64_t ld, const float* omega, const void* out, const void* dn,
+                                     int64_t ld_out, void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H,
+                                     int64_t dh, int64_t n_feat, float eps, emo_stream_t stream) {
+    int rc = favor_check(q, k, v, ld, ld_out, dtype, dh, n_feat);
+    if (rc) return rc;
+    EMO_CHECK(omega && out && dn && dq && dk && dv, "emo_favor_attn_bwd_dn: null pointer");
+    EMO_CHECK(emo_favor_attn_bwd_dn_supported(dtype, B, T, H, dh, n_feat), "emo_favor_attn_bwd_dn: problem not in the supported class (emo_favor_attn_bwd_dn_supported)");
+    EMO_CHECK(ld_d % 4 == 0, "emo_favor_attn_bwd_dn: ld_d must be a multiple of 4");
+    EMO_CHECK((((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)out | (uintptr_t)dn) & 15) == 0, "emo_favor_attn_bwd_dn: pointers must be 16-B aligned");
+    return dispatch_favor(1, dtype, dh, n_feat / 2, q, k, v, ld, omega, (void*)out, ld_out, (float*)nullptr, nullptr, nullptr, dn, dq, dk, dv, ld_d, B, T, H,
+                          eps, nullptr, 0, (hipStream_t)stream, false);
 }
 extern "C" int emo_favor_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const float* omega, const void* out, const void* dout,
                                   int64_t ld_out, const float* den, void* dq, void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H,

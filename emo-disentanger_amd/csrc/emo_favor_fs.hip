@@ -450,6 +450,10 @@ __device__ __forceinline__ bf16x8 fs_scale8(const bf16x8& x, float a) {
     return r;
 }
 
+// PRE (r06): `dout` already holds dN = dout / den (the out-projection dgrad divided it in its epilogue, emo_hip.h: hdiv / emo_favor_attn_bwd_dn): no
+// normaliser stream (5 DMA instructions per chunk instead of 6), no reciprocal, no rescaled operand copies — dD = -(dN . out) comes straight from
+// the Gram diagonal.  r05 measured the same arithmetic removal with a timing-only build: -10 % / -17 % VALU in dq / dk-dv, -4.4 % time.
+template <bool PRE>
 __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                int64_t ld, const float* __restrict__ omega, const bf16_t* __restrict__ out,
                                                                const bf16_t* __restrict__ dout, int64_t ld_out, const float* __restrict__ den_g,
@@ -528,11 +532,12 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
         else if (part == 2) fs_dma16(vb + t0n * ld + so_qkv, dst + 2 * FS_TILEB);
         else if (part == 3) fs_dma16(gb + t0n * ld_out + so_o, dst + 3 * FS_TILEB);
         else if (part == 4) fs_dma16(ob + t0n * ld_out + so_o, dst + 4 * FS_TILEB);
-        else {
+        else if (!PRE) {
             const int64_t tl = t0n + lane;
             fs_dma4(dnb + (tl < T ? tl : T - 1), den_lds + (n % 3) * 256);  // (every wave writes the same 256 B: keeps the DMA count uniform)
         }
     };
+    constexpr int NPART = PRE ? 5 : 6;                 // DMA instructions per wave and chunk
     auto issue = [&](int n) {
 #pragma unroll
         for (int part = 0; part < 6; ++part) issue_part(n, part);
@@ -540,7 +545,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
     issue(0);
     if (nch > 1) issue(1);
     if (nch > 2) issue(2);
-    if (nch > 2) fs_wait<12>(); else if (nch > 1) fs_wait<6>(); else fs_wait<0>();
+    if (nch > 2) fs_wait<2 * NPART>(); else if (nch > 1) fs_wait<NPART>(); else fs_wait<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     char* KPw = KP + w * 2048;
@@ -600,10 +605,16 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
         float dD[2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            const float inv = 1.f / dens[16 * tt + c];
-            dD[tt] = -fs_diag_sum_rows(gmm[tt], g, c) * inv;
-            gop[tt][0] = fs_scale8(dfr[tt][0], inv);
-            gop[tt][1] = fs_scale8(dfr[tt][1], inv);
+            if constexpr (PRE) {
+                dD[tt] = -fs_diag_sum_rows(gmm[tt], g, c);
+                gop[tt][0] = dfr[tt][0];
+                gop[tt][1] = dfr[tt][1];
+            } else {
+                const float inv = 1.f / dens[16 * tt + c];
+                dD[tt] = -fs_diag_sum_rows(gmm[tt], g, c) * inv;
+                gop[tt][0] = fs_scale8(dfr[tt][0], inv);
+                gop[tt][1] = fs_scale8(dfr[tt][1], inv);
+            }
         }
         FSD(1);
         if (i > 0) issue_part(i + 2, 4);
@@ -691,7 +702,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
         ST[4][0] = mma32(oneop, kfT[0], ST[4][0]);
         ST[4][1] = mma32(oneop, kfT[1], ST[4][1]);
         FSD(4);
-        if (i + 2 < nch) fs_wait<6>(); else fs_wait<0>();
+        if (i + 2 < nch) fs_wait<NPART>(); else fs_wait<0>();
         FSD(5);
         if (i > 0) {
 #pragma unroll
@@ -734,6 +745,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
 // row sums were published (dk columns need every m).  1 / den is folded into the OPERAND that is indexed by t (Qf^T for RT, the wave's own
 // dN^T fragment for RD / dV), so the dout rows are used raw from the ring (transpose reads) and no scaled dN image is built.
 // q, k, v, dout, out, den: 2-slot LDS-DMA ring (an iteration is long enough to cover the HBM round trip of the next-but-one chunk).
+template <bool PRE>                                    // PRE: dout = dN already (see favor_fs_dq_kernel)
 __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                 int64_t ld, const float* __restrict__ omega, const bf16_t* __restrict__ out,
                                                                 const bf16_t* __restrict__ dout, int64_t ld_out, const float* __restrict__ den_g,
@@ -820,12 +832,14 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
         fs_dma16(vb + t0n * ld + so_qkv, dst + 2 * FS_TILEB);
         fs_dma16(gb + t0n * ld_out + so_o, dst + 3 * FS_TILEB);
         fs_dma16(ob + t0n * ld_out + so_o, dst + 4 * FS_TILEB);
-        const int64_t tl = t0n + lane;
-        fs_dma4(dnb + (tl < T ? tl : T - 1), den_lds + (n & 1) * 256);
+        if constexpr (!PRE) {
+            const int64_t tl = t0n + lane;
+            fs_dma4(dnb + (tl < T ? tl : T - 1), den_lds + (n & 1) * 256);
+        }
     };
     issue(0);
     if (nch > 1) issue(1);
-    if (nch > 1) fs_wait<6>(); else fs_wait<0>();
+    if (nch > 1) fs_wait<PRE ? 5 : 6>(); else fs_wait<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     float* PVw = PV + w * 96;
@@ -869,11 +883,17 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
             const bf16x8 o0 = fs_ring_perm(Xo, 16 * tt, 0, g, c), o1 = fs_ring_perm(Xo, 16 * tt, 1, g, c);
             f32x4 gm = mma32(o0, d0, zero4());
             gm = mma32(o1, d1, gm);
-            const float inv = 1.f / dens[16 * tt + c];
             const float dot = fs_diag_sum_rows(gm, g, c);
-            if (g == 0) { PVw[16 * tt + c] = -dot * inv; PVw[32 + 16 * tt + c] = -dot; PVw[64 + 16 * tt + c] = inv; }
-            gA[tt][0] = fs_scale8(d0, inv);
-            gA[tt][1] = fs_scale8(d1, inv);
+            if constexpr (PRE) {
+                if (g == 0) PVw[16 * tt + c] = -dot;   // dD_t = -(dN_t . out_t)
+                gA[tt][0] = d0;
+                gA[tt][1] = d1;
+            } else {
+                const float inv = 1.f / dens[16 * tt + c];
+                if (g == 0) { PVw[16 * tt + c] = -dot * inv; PVw[32 + 16 * tt + c] = -dot; PVw[64 + 16 * tt + c] = inv; }
+                gA[tt][0] = fs_scale8(d0, inv);
+                gA[tt][1] = fs_scale8(d1, inv);
+            }
         }
         FSD(1);
         bf16x8 pb[2];                                  // P[t][j] = dN_t.v_j + dD_t, t >= j: rows t = 16 tt + 4 g + r, column j
@@ -935,9 +955,11 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
         }
         FSD(4);
         // 1 / den of the lane's eight t positions (permuted k = t), the slice's Qf^T plain and scaled
-        const f32x4 iv0 = *(const f32x4*)(PVw + 64 + 4 * g), iv1 = *(const f32x4*)(PVw + 64 + 16 + 4 * g);
+        f32x4 iv0 = {}, iv1 = {};
+        if constexpr (!PRE) { iv0 = *(const f32x4*)(PVw + 64 + 4 * g); iv1 = *(const f32x4*)(PVw + 64 + 16 + 4 * g); }
         auto scale_t = [&](const bf16x8& x) {
-            return (bf16x8){(bf16_t)((float)x[0] * iv0[0]), (bf16_t)((float)x[1] * iv0[1]), (bf16_t)((float)x[2] * iv0[2]), (bf16_t)((float)x[3] * iv0[3]),
+            if constexpr (PRE) return x;               // dN carries 1 / den already
+            else return (bf16x8){(bf16_t)((float)x[0] * iv0[0]), (bf16_t)((float)x[1] * iv0[1]), (bf16_t)((float)x[2] * iv0[2]), (bf16_t)((float)x[3] * iv0[3]),
                             (bf16_t)((float)x[4] * iv1[0]), (bf16_t)((float)x[5] * iv1[1]), (bf16_t)((float)x[6] * iv1[2]), (bf16_t)((float)x[7] * iv1[3])};
         };
         bf16x8 qfTs[2];
@@ -1011,7 +1033,8 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
             RT[dl][1] = mma32(gT, qfTs[1], RT[dl][1]);
         }
         {
-            const f32x4 nd0 = *(const f32x4*)(PVw + 32 + 4 * g), nd1 = *(const f32x4*)(PVw + 32 + 16 + 4 * g);
+            // (PRE: the dD row itself — the 1 / den that the other form keeps in qfTs is already inside dN and dD)
+            const f32x4 nd0 = *(const f32x4*)(PVw + (PRE ? 0 : 32) + 4 * g), nd1 = *(const f32x4*)(PVw + (PRE ? 0 : 32) + 16 + 4 * g);
             bf16x8 ndop = pack8(nd0, nd1);
 #pragma unroll
             for (int e = 0; e < 8; ++e) ndop[e] = c == 0 ? ndop[e] : (bf16_t)0.f;  // row d' = 64 of G'^T: dD_t = -dot_t / den_t, 1 / den again in qfTs
@@ -1056,6 +1079,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
 // which: 0 forward, 1 backward main passes (P > 1: the caller has run the generic state-only pass into S_ws / z_ws — for the backward the
 // K-state increments before `stage` 1 (dq) and the R-state increments before `stage` 2 (dk, dv)).  stage: 0 = whole call (P == 1 only),
 // 1 = dq, 2 = dk / dv.  Returns 0 when the shape / mode is not covered (the caller then runs the generic kernels), 1 when it was served.
+// den == nullptr in a backward call: `dout` is dN = dout / den (emo_favor_attn_bwd_dn) — the PRE instances.
 int emo_favor_fs_try(int which, int stage, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld, const float* omega, bf16_t* out, int64_t ld_out,
                      float* den, float* sS, float* sz, const bf16_t* dout, bf16_t* dq, bf16_t* dk, bf16_t* dv, int64_t ld_d, int64_t B, int64_t T, int64_t H,
                      float eps, const float* ws_S, const float* ws_z, int P, int64_t Ts, hipStream_t st) {
@@ -1079,19 +1103,36 @@ int emo_favor_fs_try(int which, int stage, const bf16_t* q, const bf16_t* k, con
     }
     const char* e2 = getenv("EMO_FAVOR_FS_BWD");               // "0": generic backward kernels
     if (e2 && atoi(e2) == 0) return 0;
+    const bool pre = den == nullptr;
     if (stage == 0 || stage == 1) {
         const size_t lds = (size_t)3 * FS_SLOTB + 3 * 256 + 4 * 2048 + 2 * FS_TILEB + 2 * 4 * 32 * sizeof(float);
         static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)favor_fs_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-        hipLaunchKernelGGL(favor_fs_dq_kernel, grid, dim3(FS_NT), lds, st, q, k, v, ld, omega, (const bf16_t*)out, dout, ld_out, (const float*)den, dq, ld_d, T, H,
-                           ws_S, ws_z, P, Ts);
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)favor_fs_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)favor_fs_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        if (pre)
+            hipLaunchKernelGGL(favor_fs_dq_kernel<true>, grid, dim3(FS_NT), lds, st, q, k, v, ld, omega, (const bf16_t*)out, dout, ld_out, (const float*)nullptr, dq, ld_d, T, H,
+                               ws_S, ws_z, P, Ts);
+        else
+            hipLaunchKernelGGL(favor_fs_dq_kernel<false>, grid, dim3(FS_NT), lds, st, q, k, v, ld, omega, (const bf16_t*)out, dout, ld_out, (const float*)den, dq, ld_d, T, H,
+                               ws_S, ws_z, P, Ts);
     }
     if (stage == 0 || stage == 2) {
         const size_t lds2 = (size_t)2 * FS_SLOTB + 2 * 256 + sizeof(bf16_t) * (size_t)(2 * FS_C * FS_LDF) + FS_TILEB + sizeof(float) * (128 + 4 * 96);
         static bool attr2 = false;
-        if (!attr2) { (void)hipFuncSetAttribute((const void*)favor_fs_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr2 = true; }
-        hipLaunchKernelGGL(favor_fs_dkv_kernel, grid, dim3(FS_NT), lds2, st, q, k, v, ld, omega, (const bf16_t*)out, dout, ld_out, (const float*)den, dk, dv, ld_d, T, H,
-                           ws_S, ws_z, P, Ts);
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void*)favor_fs_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            (void)hipFuncSetAttribute((const void*)favor_fs_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            attr2 = true;
+        }
+        if (pre)
+            hipLaunchKernelGGL(favor_fs_dkv_kernel<true>, grid, dim3(FS_NT), lds2, st, q, k, v, ld, omega, (const bf16_t*)out, dout, ld_out, (const float*)nullptr, dk, dv, ld_d, T, H,
+                               ws_S, ws_z, P, Ts);
+        else
+            hipLaunchKernelGGL(favor_fs_dkv_kernel<false>, grid, dim3(FS_NT), lds2, st, q, k, v, ld, omega, (const bf16_t*)out, dout, ld_out, (const float*)den, dk, dv, ld_d, T, H,
+                               ws_S, ws_z, P, Ts);
     }
     return 1;
 }

@@ -1058,6 +1058,13 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
                   "emo_gemm: lna_gamma needs lna_beta / lna_out / lna_mean / lna_rstd, bf16, NT, and no ln_c1 / rln_x");
         EMO_CHECK(!e->lna_gamma || (K == 512 && (M % 128) == 0 && M >= 4096 && (N % 64) == 0 && N <= 2048 && !accumulate && (((uintptr_t)e->lna_out) & 15) == 0),
                   "emo_gemm: lna_* (LayerNorm of the A operand) exists only on the A-stationary kernel: K = 512, M %% 128 == 0, M >= 4096, N %% 64 == 0, N <= 2048");
+        ep.hdiv = e->hdiv; ep.hdiv_T = e->hdiv_T;
+        EMO_CHECK(!e->hdiv || (!has_epi && !e->lna_gamma && !e->mask_out && !e->a_rowsum && !e->b_rowsum && !e->ln_c1 && !e->rln_x && !a_trans && !b_trans && !accumulate &&
+                               dtype_in == EMO_BF16 && dtype_out == EMO_BF16),
+                  "emo_gemm: hdiv needs a plain epilogue, bf16 in / out, NT");
+        EMO_CHECK(!e->hdiv || (K == 512 && (M % 128) == 0 && M >= 4096 && (N % 64) == 0 && N <= 2048 && e->hdiv_T > 0 && (e->hdiv_T % 32) == 0 && (M % e->hdiv_T) == 0 &&
+                               (((uintptr_t)e->hdiv) & 3) == 0),
+                  "emo_gemm: hdiv exists only on the A-stationary kernel (K = 512, M %% 128 == 0, M >= 4096, N %% 64 == 0, N <= 2048) with hdiv_T %% 32 == 0 and M %% hdiv_T == 0");
         EMO_CHECK(!e->rln_x || (e->rln_stats && e->rln_gamma && e->rln_beta && !e->act && !ep.drop.thr16 && !ep.mul_mode),
                   "emo_gemm: rln_x needs rln_stats/gamma/beta and no activation / dropout / mul epilogue");
         EMO_CHECK(!e->ln_stats_out || e->ln_c1, "emo_gemm: ln_stats_out needs ln_c1");
@@ -1104,7 +1111,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         return EMO_OK;
     }
 #ifdef EMO_EXPERIMENTAL
-    if (big && !a_trans && !b_trans && !ln_fused && !accumulate && !use_safe_tr() && !ep.lna_gamma) {
+    if (big && !a_trans && !b_trans && !ln_fused && !accumulate && !use_safe_tr() && !ep.lna_gamma && !ep.hdiv) {
         const int pk = emo_gemm_p256_try((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, dtype_out, M, N, K, ep, st);   // opt-in persistent tile walks (r05)
         if (pk) {
             EMO_LAUNCH_CHECK();
@@ -1127,6 +1134,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         return EMO_OK;
     }
     EMO_CHECK(!ep.lna_gamma, "emo_gemm: lna_* (LayerNorm of the A operand) exists only on the A-stationary kernel: bf16, NT, K = 512, M %% 128 == 0, M >= 4096, N %% 64 == 0, N <= 2048");
+    EMO_CHECK(!ep.hdiv, "emo_gemm: hdiv exists only on the A-stationary kernel and this call was refused by it (alignment / strides / EMO_GEMM_NO_ASTAT)");
     if (big && !a_trans && !b_trans && !ln_fused && !accumulate &&
         emo_gemm_w128_try((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, dtype_out, M, N, K, ep, st)) {    // long-K NT products on 256 x 256 tiles (opt-in)
         EMO_LAUNCH_CHECK();

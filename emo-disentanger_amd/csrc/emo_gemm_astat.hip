@@ -44,6 +44,7 @@ template <int N> __device__ __forceinline__ void as_wait();
 template <> __device__ __forceinline__ void as_wait<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <> __device__ __forceinline__ void as_wait<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
 template <> __device__ __forceinline__ void as_wait<5>() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+template <> __device__ __forceinline__ void as_wait<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 template <> __device__ __forceinline__ void as_wait<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 template <> __device__ __forceinline__ void as_wait<12>() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
 template <> __device__ __forceinline__ void as_wait<16>() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
@@ -138,7 +139,7 @@ __device__ __forceinline__ void as_unpack8(const u32x4& r, float (&t)[8]) {
 // The epilogue is specialised at COMPILE time (FL = feature flags): with run-time `ep.*` tests the column-tile epilogue was ~650 lines of
 // branchy code per tile (dead mul / residual / aux paths with their own `s_waitcnt vmcnt(0)`, per-lane parity branches of the dropout
 // hash) and took 35-52 % of a wave's cycles (s_memtime, tools/astat_cycles.py); the flag sets the Performer step uses are straight-line.
-enum { AF_RELU = 1, AF_DROP = 2, AF_RES = 4, AF_BITS = 8, AF_MASKOUT = 16, AF_GENERIC = 32, AF_DGELU = 64, AF_GELUAUX = 128 };   // (the last two: GPT-2's MLP)
+enum { AF_RELU = 1, AF_DROP = 2, AF_RES = 4, AF_BITS = 8, AF_MASKOUT = 16, AF_GENERIC = 32, AF_DGELU = 64, AF_GELUAUX = 128, AF_HDIV = 256 };   // (DGELU, GELUAUX: GPT-2's MLP; HDIV: emo_hip.h hdiv)
 
 // 8 consecutive elements starting at a multiple of 8 of a 32-bit linear index: two hashes + two xorshifts, no parity branch, no 64-bit
 // arithmetic (bit-identical to drop_mult(); the launcher sends outputs of 2^32 elements or more to the generic epilogue)
@@ -169,6 +170,11 @@ __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ 
     } else if (G && ep.act == EMO_ACT_GELU_NEW) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = gelu_new_o<OutT>(v[i]);
+    }
+    if (FL & AF_HDIV) {                                           // pre_bits = the row's divisor for this 64-column block (prefetched like the mask word)
+        const float inv = 1.f / __builtin_bit_cast(float, pre_bits);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= inv;
     }
     if (FL & AF_BITS) {
 #pragma unroll
@@ -237,6 +243,7 @@ template <typename OutT, int FL>
 __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
                                                            OutT* __restrict__ C, int64_t M, int64_t N, EpiParams ep, int tiles_per_block) {
     constexpr bool BITS = (FL & AF_BITS) != 0;
+    constexpr bool HDIV = (FL & AF_HDIV) != 0;                    // two divisor words per lane and column tile (rows lane % 16 and + 16), fetched like the mask word
     // residual rows (AF_RES) or pre-activation rows (AF_DGELU) of the column tile prefetched like the mask word
     constexpr bool RESP = ((FL & AF_RES) != 0 || (FL & (AF_DGELU | AF_RES)) == AF_DGELU) && (FL & AF_GENERIC) == 0 && sizeof(OutT) == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [4 slots x 16 KB ring][bias: N floats]
@@ -392,6 +399,8 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
     // address — two loop-invariant VGPRs fewer (at 256 VGPRs a spilled one comes back as scratch_load + s_waitcnt vmcnt(0) = a drained DMA ring)
     const uint32_t eoff0 = (uint32_t)((lane & 15) * ep.ldc + ecol);                                                              // elements
     const uint32_t doff0 = (uint32_t)((lane & 15) * N + ecol);
+    // hdiv (emo_hip.h): divisor of row m and column block j at ((m / T) * (N / 64) + j) * T + m % T; a wave's 32 rows share m / T (T % 32 == 0)
+    const int64_t hbase = HDIV ? ((m0 / ep.hdiv_T) * n_tiles_all + nt0) * ep.hdiv_T + (m0 % ep.hdiv_T) : 0;
 #ifdef EMO_DIAG
     uint64_t t_wait = 0, t_epi = 0, t_loop0 = __builtin_readcyclecounter();
 #endif
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
             acc[0][f] = b4;
             acc[1][f] = b4;
         }
-        uint32_t prew = 0;
+        uint32_t prew = 0, preh[2] = {0, 0};
         u32x4 pres[4] = {};
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
@@ -413,7 +422,12 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
 #ifdef EMO_DIAG
                     const uint64_t tw0 = __builtin_readcyclecounter();
 #endif
-                    if (BITS && kc == 3) {                        // the mask word of this column tile: youngest VMEM op at the wait below
+                    if (HDIV && kc == 3) {                        // the two divisors of this column tile (= head nt0 + nt): youngest VMEM ops at the wait below
+                        const char* hp = (const char*)(ep.hdiv + hbase + (int64_t)nt * ep.hdiv_T);   // wave-uniform: the 32 rows' divisors of block (m / T, head nt0 + nt)
+                        preh[0] = as_load4(hp, (uint32_t)(lane & 15) * 4);
+                        preh[1] = as_load4(hp + 64, (uint32_t)(lane & 15) * 4);
+                        as_wait<6>();
+                    } else if (BITS && kc == 3) {                        // the mask word of this column tile: youngest VMEM op at the wait below
                         const char* op = (const char*)ep.mul_aux + mtile0 + nt * 256;                          // wave-uniform
                         prew = as_load4(op, (uint32_t)lane * 4);
                         as_wait<5>();
@@ -468,6 +482,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
         if (ep.ablate == 6) continue;                             // diagnostics: no epilogue at all
 #endif
         if (BITS) as_pinw<4>(prew);                               // one refill (4 DMA ops) was issued after the mask word
+        if (HDIV) { as_pinw<4>(preh[0]); as_pinw<4>(preh[1]); }
         if (RESP) as_pin<4>(pres);
         uint32_t mask_word = 0;
 #pragma unroll
@@ -485,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                 const int64_t m0s = m0;
 #endif
                 as_epi8<OutT, FL>(ep, C, (m0s + 16 * i) * ep.ldc + nb, lo, nb, ecol, (m0 + 16 * i) * N + nb, doff0, mtile0 + nt * 256, (uint32_t)lane, v, bias_lds,
-                                    (prew >> (8 * (i * 2 + h))) & 0xFFu, mask_word, i * 2 + h, pres[i * 2 + h]);
+                                    HDIV ? preh[i] : (prew >> (8 * (i * 2 + h))) & 0xFFu, mask_word, i * 2 + h, pres[i * 2 + h]);
                 __builtin_amdgcn_sched_barrier(0);               // one 8-column group at a time: keeps the epilogue's temporaries out of the register peak
             }
         if ((FL & AF_MASKOUT) || ((FL & AF_GENERIC) && ep.mask_out)) as_store4(ep.mask_out + mtile0 + nt * 256, (uint32_t)lane * 4, mask_word);
@@ -518,6 +533,7 @@ bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t l
     { const char* e = getenv("EMO_ASTAT_MIN_ROWS"); if (e && atoll(e) > 0) min_rows = atoll(e); }      // (A/B of the column split; ops.py reads the same variable)
     if (off || K != AS_K || (M % AS_BM) != 0 || M < min_rows || (N % AS_BN) != 0 || N > AS_MAXN || N < AS_BN) return false;
     if (ep.atomic || ep.accumulate || ep.ws_stride || ep.a_rowsum || ep.b_rowsum || ep.ln_c1 || ep.rln_x) return false;
+    if (ep.hdiv && dtype_out != EMO_BF16) return false;
     if ((ep.mask_out || ep.mul_mode == EMO_MUL_BITMASK) && dtype_out != EMO_BF16) return false;
     if (ep.act == EMO_ACT_GELU || ep.mul_mode == EMO_MUL_DGELU) return false;          // (exact erf GELU: the generic tiled epilogue only)
     if ((lda & 7) || (ldb & 7) || (ep.ldc & 7) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return false;
@@ -560,7 +576,8 @@ bool emo_gemm_astat_try(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t l
              (ep.mask_out ? AF_MASKOUT : 0) | (ep.mul_mode == EMO_MUL_DGELU_NEW ? AF_DGELU : 0) | (gelu_aux ? AF_GELUAUX : 0);
     const bool other = (!gelu_aux && (ep.aux_out || ep.act == EMO_ACT_GELU_NEW)) || ep.mul_mode == EMO_MUL_NONZERO ||
                        (ep.drop.thr16 && (uint64_t)M * (uint64_t)N >= (1ull << 32));
-    if (dtype_out == EMO_F32) AS_LAUNCH(float, AF_GENERIC);
+    if (ep.hdiv) AS_LAUNCH(bf16_t, AF_HDIV);                       // (emo_gemm admits hdiv only with a plain epilogue)
+    else if (dtype_out == EMO_F32) AS_LAUNCH(float, AF_GENERIC);
     else if (other) AS_LAUNCH(bf16_t, AF_GENERIC);
     else if (fl == 0) AS_LAUNCH(bf16_t, 0);
     else if (fl == AF_RELU) AS_LAUNCH(bf16_t, AF_RELU);

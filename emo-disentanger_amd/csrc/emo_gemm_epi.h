@@ -36,6 +36,9 @@ struct EpiParams {
     void* lna_out;
     float* lna_mean;
     float* lna_rstd;
+    // per-row, per-64-column-block divisor (emo_hip.h: hdiv), A-stationary kernel only
+    const float* hdiv;
+    int64_t hdiv_T;
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -403,9 +403,16 @@ def performer_layer_bwd(ps, pfx, dout, B, T, H, p, seed, off, save):
     if da is None:
         da = g1
     _wgrad(ps, pfx + 'attention.out_projection.weight', pfx + 'attention.out_projection.bias', da, s['attn'], bias_done=True)
-    dattn = ops.gemm(da, ps.wT(pfx + 'attention.out_projection.weight')) if bf else ops.gemm(da, ps.w(pfx + 'attention.out_projection.weight'), b_trans=True)
     qkv = s['qkv']
-    dq, dk, dv = ops.favor_attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], s['omega'], s['attn'], dattn, s['den'], B, T, H, ws_saved=s.get('fws'))
+    # d(attention output) leaves the out-projection dgrad already divided by the FAVOR+ normaliser (emo_hip.h: hdiv, emo_favor_attn_bwd_dn; r06):
+    # one rounding from the fp32 accumulators, and the two backward sweeps lose their normaliser stream, reciprocals and rescaled operand copies
+    dn = bool(bf and D // H == 64 and s.get('fws') is None and _os.environ.get('EMO_FAVOR_DN', '1') != '0'
+              and ops.favor_bwd_dn_ok(qkv.dtype, B, T, H, D // H, 2 * s['omega'].shape[1]))
+    if dn:
+        dattn = ops.gemm(da, ps.wT(pfx + 'attention.out_projection.weight'), hdiv=(s['den'], T))
+    else:
+        dattn = ops.gemm(da, ps.wT(pfx + 'attention.out_projection.weight')) if bf else ops.gemm(da, ps.w(pfx + 'attention.out_projection.weight'), b_trans=True)
+    dq, dk, dv = ops.favor_attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], s['omega'], s['attn'], dattn, s['den'], B, T, H, ws_saved=s.get('fws'), dn=dn)
     dqkv = dq._base if dq._base is not None else torch.cat([dq, dk, dv], 1)
     q = pfx + 'attention.query_projection.'
     _wgrad(ps, q + 'weight', q + 'bias', dqkv, s['x'], fused_rows=3 * D)

@@ -16,7 +16,7 @@ from ._lib import (ACT_GELU, ACT_GELU_NEW, ACT_NONE, ACT_RELU, BF16, F32, MUL_BI
 __all__ = ['gemm', 'colsum', 'embed_fwd', 'embed_bwd', 'layernorm_fwd', 'layernorm_bwd', 'dropout_apply', 'favor_attn_fwd',
            'favor_attn_bwd', 'favor_decode_step', 'performer_decode_step', 'performer_decode_step_sampled', 'favor_draw_omega', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'relpos_attn_fwd', 'relpos_attn_bwd', 'relpos_attn_decode', 'xent_fwd',
            'xent_bwd', 'argmax', 'sample_nucleus', 'sample_nucleus_step', 'accuracy_counts', 'sumsq', 'clip_coef', 'adam_step', 'cast', 'add_bias2',
-           'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'ACT_GELU', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW', 'MUL_DGELU', 'MUL_BITMASK', 'gemm_bitmask_ok', 'gemm_lna_ok', 'bitmask_rows']
+           'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'ACT_GELU', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW', 'MUL_DGELU', 'MUL_BITMASK', 'gemm_bitmask_ok', 'gemm_lna_ok', 'bitmask_rows', 'favor_bwd_dn_ok']
 
 
 def _c(t):
@@ -81,7 +81,7 @@ def _workspace(kind, device, need, st=None):
 
 def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumulate=False, bias=None, act=ACT_NONE,
          aux_out=None, mul_aux=None, mul_mode=MUL_NONE, mul_scale=1.0, p_drop=0.0, seed=0, offset=0, residual=None,
-         ln_c1=None, ln_eps=1e-5, ln_stats_out=None, rln=None, a_rowsum=None, b_rowsum=None, mask_out=None, stream=None, lna=None, lna_out=None):
+         ln_c1=None, ln_eps=1e-5, ln_stats_out=None, rln=None, a_rowsum=None, b_rowsum=None, mask_out=None, stream=None, lna=None, lna_out=None, hdiv=None):
     """C[M,N] = epilogue(op(A) @ op(B));  a_trans: A stored [K,M];  b_trans=False: B stored [N,K] (nn.Linear),
     b_trans=True: B stored [K,N] (HF Conv1D).  ln_c1 / ln_stats_out / rln: LayerNorm folded around a decode-step GEMM (include/emo_hip.h).
     stream: raw hipStream_t to launch on (default: torch's current stream).
@@ -120,7 +120,10 @@ def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumu
             ln_rstd = torch.empty(M, device=A.device, dtype=torch.float32)
     epi = Epilogue(ptr(bias), act, ptr(aux_out), ptr(mul_aux), mul_mode, mul_scale, p_drop, seed, offset, ptr(residual),
                    ptr(ln_c1), ln_eps, ptr(ln_stats_out), ptr(rx), ptr(rstats), ptr(rgamma), ptr(rbeta), ptr(a_rowsum), ptr(b_rowsum), ptr(mask_out), ptr(ws), ws_bytes,
-                   ptr(lna[0]) if lna is not None else None, ptr(lna[1]) if lna is not None else None, ptr(ln_out), ptr(ln_mean), ptr(ln_rstd))
+                   ptr(lna[0]) if lna is not None else None, ptr(lna[1]) if lna is not None else None, ptr(ln_out), ptr(ln_mean), ptr(ln_rstd),
+                   ptr(hdiv[0]) if hdiv is not None else None, int(hdiv[1]) if hdiv is not None else 0)
+    if hdiv is not None:      # (den, T): C[m][n] /= den[m / T, n / 64, m % T]  (emo_hip.h: hdiv — the out-projection dgrad leaves dN = dout / den)
+        assert hdiv[0].dtype == torch.float32 and hdiv[0].is_contiguous() and hdiv[0].numel() == M * (N // 64) and plain and mask_out is None and lna is None
     if not plain or mask_out is not None:
         for t in (aux_out, residual) + (() if mul_mode == MUL_BITMASK else (mul_aux,)):
             assert t is None or (t.dtype == out.dtype and _rows(t) == _rows(out))
@@ -141,7 +144,8 @@ def gemm(A, B, *, a_trans=False, b_trans=False, out=None, out_dtype=None, accumu
             kind += '/K>1024'
         elif fam == 2:       # one class per kernel INSTANCE (template argument = epilogue flags), as the rocprofv3 summary lists them
             tag = [t for t, on in (('relu', act == ACT_RELU), ('gelu', act == ACT_GELU_NEW), ('drop', p_drop > 0), ('res', residual is not None),
-                                   ('bits', mul_mode == MUL_BITMASK), ('mul', mul_aux is not None and mul_mode != MUL_BITMASK), ('mask', mask_out is not None)) if on]
+                                   ('bits', mul_mode == MUL_BITMASK), ('mul', mul_aux is not None and mul_mode != MUL_BITMASK), ('mask', mask_out is not None),
+                                   ('hdiv', hdiv is not None)) if on]
             kind += '/K=512/' + ('+'.join(tag) if tag else 'plain')
         elif fam == 3:       # 256 x 256 tile wgrad (with / without the bias gradient)
             kind += '/rs' if (a_rowsum is not None or b_rowsum is not None) else '/plain'
@@ -270,8 +274,14 @@ def favor_attn_fwd(q, k, v, omega, B, T, H, eps=1e-6, want_state=False, keep_ws=
     return (out, den, S, z) if want_state else (out, den)
 
 
-def favor_attn_bwd(q, k, v, omega, out, dout, den, B, T, H, dqkv=None, eps=1e-6, ws_saved=None):
-    """Returns (dq, dk, dv) views of one fused [B*T, 3*H*dh] buffer (ready for the fused-QKV dgrad/wgrad)."""
+def favor_bwd_dn_ok(dtype, B, T, H, dh, n_feat):
+    """True when favor_attn_bwd(dn=True) serves the problem (emo_hip.h: emo_favor_attn_bwd_dn — the single-segment slice kernels)."""
+    return dtype == torch.bfloat16 and bool(lib.emo_favor_attn_bwd_dn_supported(dtype_code(dtype), B, T, H, dh, n_feat))
+
+
+def favor_attn_bwd(q, k, v, omega, out, dout, den, B, T, H, dqkv=None, eps=1e-6, ws_saved=None, dn=False):
+    """Returns (dq, dk, dv) views of one fused [B*T, 3*H*dh] buffer (ready for the fused-QKV dgrad/wgrad).
+    dn=True: `dout` is already dN = dout / den (gemm(hdiv=(den, T)) produced it); den is not read."""
     M, HD = q.shape
     dh = HD // H
     n_feat = 2 * omega.shape[1]
@@ -279,6 +289,11 @@ def favor_attn_bwd(q, k, v, omega, out, dout, den, B, T, H, dqkv=None, eps=1e-6,
     if dqkv is None:
         dqkv = torch.empty(M, 3 * HD, device=q.device, dtype=q.dtype)
     dq, dk, dv = dqkv[:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:]
+    if dn:
+        with _timed('favor_bwd', 0.0, 7.0 * M * HD * q.element_size()):
+            check(lib.emo_favor_attn_bwd_dn(ptr(q), ptr(k), ptr(v), _rows(q), ptr(omega), ptr(out), ptr(dout), HD, ptr(dq), ptr(dk), ptr(dv), 3 * HD,
+                                            dtype_code(q.dtype), B, T, H, dh, n_feat, eps, stream()))
+        return dq, dk, dv
     if ws_saved is not None:                                      # the forward's private workspace: its K-state increments are still there
         ws, ws_bytes, kvalid = ws_saved, ws_saved.numel(), 1
         assert ws_bytes == lib.emo_favor_attn_workspace_bytes(B, T, H, dh, n_feat)

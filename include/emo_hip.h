@@ -101,6 +101,14 @@ typedef struct {
     void* lna_out;
     float* lna_mean;
     float* lna_rstd;
+    /* Per-row, per-64-column-block divisor (r06): C[m][n] /= hdiv[((m / hdiv_T) * (N / 64) + n / 64) * hdiv_T + m % hdiv_T] — with hdiv = the FAVOR+
+     * normaliser den [B, H, T] (emo_favor_attn_fwd) and C = d(attention output) = the out-projection's dgrad, the product leaves as dN = dout / den
+     * (the first thing both backward sweeps of causal_product form), in ONE rounding from the fp32 accumulators, and
+     * emo_favor_attn_bwd_dn takes it without the normaliser.  Replaces the d(out)/den scalings inside the causal_product backward reached from
+     * fast_transformer_decoder.py:33-40.  Only with a plain epilogue in the A-stationary class (bf16 in / out, NT, K = 512, M % 128 == 0, M >= 4096,
+     * N % 64 == 0) and hdiv_T % 32 == 0, M % hdiv_T == 0; refused elsewhere. */
+    const float* hdiv;
+    int64_t hdiv_T;
 } emo_epilogue_t;
 
 /* scratch that lets emo_gemm() run its split-K without atomics (0 = this problem is not split) */
@@ -193,6 +201,16 @@ int emo_favor_attn_bwd_kstate(const void* q, const void* k, const void* v, int64
                               void* dk, void* dv, int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H,
                               int64_t dh, int64_t n_feat, float eps, void* workspace, int64_t workspace_bytes,
                               int kstate_valid, emo_stream_t stream);
+/* The backward with the incoming gradient already divided by the normaliser (r06): `dn` = dN = dout / den, as the out-projection's dgrad leaves it
+ * when its epilogue carries emo_epilogue_t.hdiv = den (one rounding from the fp32 accumulators instead of bf16(dout) then bf16(dout / den)); the kernels
+ * then need neither den nor the rescaled operand copies (dD_t = -(dN_t . out_t)).  Same reference lines as emo_favor_attn_bwd (the native
+ * causal_product backward reached from fast_transformer_decoder.py:33-40).  Served by the single-segment slice kernels only — bf16, d_head 64,
+ * 128 features, T % 32 == 0, B * H >= 256 (emo_favor_attn_bwd_dn_supported() = 1); EMO_ERR_UNSUPPORTED elsewhere, the caller then keeps the plain form. */
+int emo_favor_attn_bwd_dn_supported(int dtype, int64_t B, int64_t T, int64_t H, int64_t dh, int64_t n_feat);
+int emo_favor_attn_bwd_dn(const void* q, const void* k, const void* v, int64_t ld, const float* omega,
+                          const void* out, const void* dn, int64_t ld_out, void* dq, void* dk, void* dv,
+                          int64_t ld_d, int dtype, int64_t B, int64_t T, int64_t H, int64_t dh, int64_t n_feat,
+                          float eps, emo_stream_t stream);
 /* one recurrent step per stream: state += phi(k) (x) v ; out = phi(q)^T S / (phi(q).z + eps) */
 int emo_favor_decode_step(const void* q, const void* k, const void* v, int64_t ld, const float* omega,
                           float* state_S, float* state_z, void* out, int64_t ld_out, int dtype,

@@ -685,6 +685,61 @@ def test_favor_slice_kernels_vs_oracle_and_generic(B, T, H, segs, monkeypatch):
         assert float((a - b_).abs().max()) <= 3e-2 * max(float(b_.abs().max()), 1e-6)
 
 
+# r06: the backward from a gradient that is already dN = dout / den (emo_favor_attn_bwd_dn; the out-projection dgrad divides in its epilogue:
+# emo_epilogue_t.hdiv) against the fp64 quadratic form and against the plain form of the same kernels
+@pytest.mark.parametrize('B,T,H', [(2, 256, 2), (1, 32, 1), (3, 96, 3), (2, 2048, 1), (32, 512, 8)])
+def test_favor_backward_from_the_predivided_gradient(B, T, H, monkeypatch):
+    ops = _ops()
+    from oracle import model_ref
+    from oracle.weights import orthogonal_omega
+    dt, dh, nf = torch.bfloat16, 64, 128
+    if B * H < 256:
+        monkeypatch.setenv('EMO_FAVOR_SEGMENTS', '1')        # single-segment scan (what B*H >= 256 gets by itself)
+    assert ops.favor_bwd_dn_ok(dt, B, T, H, dh, nf)
+    om = orthogonal_omega(dh, nf, np.random.default_rng(5))
+    qkv = _r(B * T, 3 * H * dh, seed=21, dt=dt, scale=0.8)
+    dout = _r(B, T, H, dh, seed=22, dt=dt)
+    qc, HD = qkv.cuda(), H * dh
+    out, den = ops.favor_attn_fwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], om.cuda(), B, T, H)
+    dq0, dk0, dv0 = [x.float().clone() for x in ops.favor_attn_bwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], om.cuda(), out, dout.view(B * T, HD).cuda(), den, B, T, H)]
+    # dN exactly as the GEMM epilogue forms it: fp32 quotient, one rounding to bf16
+    dn = (dout.view(B, T, H, dh).cuda().float() / den.permute(0, 2, 1).unsqueeze(-1)).to(dt).view(B * T, HD).contiguous()
+    dq1, dk1, dv1 = [x.float() for x in ops.favor_attn_bwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], om.cuda(), out, dn, None, B, T, H, dn=True)]
+    for a, b_ in ((dq1, dq0), (dk1, dk0), (dv1, dv0)):       # same arithmetic up to where the bf16 roundings of the operands sit
+        assert float((a - b_).abs().max()) <= 2e-2 * float(b_.abs().max())
+    if B * T * H <= 4096:                                    # fp64 autograd of the O(T^2) form
+        q, k, v = [qkv[:, i * HD:(i + 1) * HD].double().view(B, T, H, dh).requires_grad_(True) for i in range(3)]
+        model_ref.causal_linear_attention(q, k, v, om.double(), form='quadratic').backward(dout.double())
+        gscale = max(float(q.grad.abs().max()), float(k.grad.abs().max()), float(v.grad.abs().max()))
+        _close(dv1.reshape(B, T, H, dh), v.grad, dt, scale=gscale, mult=4)
+        _close(dq1.reshape(B, T, H, dh), q.grad, dt, scale=gscale, mult=4)
+        _close(dk1.reshape(B, T, H, dh), k.grad, dt, scale=gscale, mult=4)
+    # outside the class (segmented scan) the entry point refuses instead of computing something else
+    monkeypatch.setenv('EMO_FAVOR_SEGMENTS', '4')
+    if T >= 512:
+        assert not ops.favor_bwd_dn_ok(dt, B, T, H, dh, nf)
+        with pytest.raises(Exception):
+            ops.favor_attn_bwd(qc[:, :HD], qc[:, HD:2 * HD], qc[:, 2 * HD:], om.cuda(), out, dn, None, B, T, H, dn=True)
+
+
+@pytest.mark.parametrize('M,T,N', [(4096, 512, 512), (32768, 2048, 512), (8192, 1024, 256)])
+def test_gemm_row_block_divisor_epilogue(M, T, N):
+    """emo_epilogue_t.hdiv: C[m][n] /= hdiv[m / T][n / 64][m % T] — the out-projection dgrad leaving dN = dout / den for emo_favor_attn_bwd_dn."""
+    ops = _ops()
+    A, W = _r(M, 512, seed=1).to(torch.bfloat16).cuda(), _r(N, 512, seed=2, scale=0.1).to(torch.bfloat16).cuda()
+    den = (torch.rand(M // T, N // 64, T, generator=torch.Generator().manual_seed(3)) * 4 + 0.25).cuda()
+    y = ops.gemm(A, W, hdiv=(den, T))
+    assert ops.lib.emo_gemm_last_kernel() == 2
+    ref = (A.double() @ W.double().T).view(M // T, T, N // 64, 64) / den.double().permute(0, 2, 1).unsqueeze(-1)
+    _close(y.view(M // T, T, N // 64, 64), ref, torch.bfloat16, mult=1.0)
+    y0 = ops.gemm(A, W).float().view(M // T, T, N // 64, 64) / den.permute(0, 2, 1).unsqueeze(-1)       # two roundings instead of one
+    assert float((y.float().view_as(y0) - y0).abs().max()) <= 1e-2 * float(y0.abs().max())
+    with pytest.raises(Exception):                              # not a plain epilogue / not the A-stationary class: refused
+        ops.gemm(A, W, hdiv=(den, T), bias=torch.zeros(N, device='cuda'))
+    with pytest.raises(Exception):
+        ops.gemm(A[:1024], W, hdiv=(den[:1024 // T] if 1024 >= T else den[:1], T))
+
+
 # segment-parallel scan (B*H < 256 workgroups): automatic segment count, forced counts, ragged last segment, empty tail segments
 @pytest.mark.parametrize('dt', DT)
 @pytest.mark.parametrize('B,T,H,dh,nf,segs', [(1, 700, 2, 64, 128, None), (1, 512, 2, 32, 64, 4), (2, 330, 1, 16, 32, 3), (1, 1000, 1, 32, 128, 16),
