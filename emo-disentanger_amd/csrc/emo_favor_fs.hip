@@ -182,6 +182,49 @@ __device__ __forceinline__ bf16x8 fs_ring_perm_tr(const char* tile, int col0, in
 }
 __device__ __forceinline__ uint32_t fs_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
 
+// ---- 8-byte LDS reads as INLINE ASM with a literal offset (r06; r05 verdict item 2 (i)).  fs_load_perm / fs_ring_perm above keep hipcc from fusing
+// neighbouring reads into ds_read2_b64 by routing every offset through an opaque register — one v_add per read: 218 of the dk / dv loop's 672 VALU
+// instructions were 32-bit address arithmetic (profiles/r05_isa_census.txt).  A literal `offset:` can neither be fused nor does it need an add: the
+// per-lane part of an address pattern lives in ONE register per XOR class of the swizzle and every read of the pattern is that register + a constant.
+// hipcc does not see these reads: their results are only used behind fs_pin<N>, a counted `s_waitcnt lgkmcnt(N)` that takes the registers as "+v"
+// operands (N = asm reads issued after the last one the pin covers; LDS operations retire in order, so reads / writes the compiler issues in between
+// only make the wait stricter).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 fs_rd8(uint32_t addr, int off) {
+    u32x2 r;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(off));
+    return r;
+}
+__device__ __forceinline__ bf16x8 fs_join(u32x2 lo, u32x2 hi) { return __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]}); }
+template <int N> __device__ __forceinline__ void fs_pin(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) {
+    static_assert(N == 0 || N == 4 || N == 8 || N == 12 || N >= 15, "");
+    if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    else if constexpr (N == 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    else if constexpr (N == 12) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    else asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));      // (4-bit counter: a smaller count than the true one only waits longer)
+}
+// feature image [32][FS_LDF] (fs_load_perm's fragment): lane part of the address = (c * FS_LDF + 4 g) * 2 + image base; row0 / k-step in the literal
+__device__ __forceinline__ uint32_t fs_lp_lane(int g, int c) { return (uint32_t)((c * FS_LDF + 4 * g) * 2); }
+__device__ __forceinline__ bf16x8 fs_lp_asm(uint32_t base, int img_off, int row0, int step) {
+    const int o = img_off + (row0 * FS_LDF + 32 * step) * 2;
+    return fs_join(fs_rd8(base, o), fs_rd8(base, o + 32));
+}
+// swizzled ring tile (fs_ring_perm's fragment): piece index (4 s + (g >> 1) (+ 2)) ^ fs_sw(row) — row0 is a multiple of 16 and fs_sw only looks at row
+// bits 1-3, so with P = (g >> 1) ^ fs_sw(c) the four (k-step, half) combinations are the XOR classes P ^ {0, 2, 4, 6} of ONE lane constant:
+// rp[s][h] = slot base + c * 128 + (g & 1) * 8 + ((P ^ (4 s + 2 h)) << 4); tensor and row block go into the literal
+__device__ __forceinline__ void fs_rp_lane(int g, int c, uint32_t (&l)[2][2]) {
+    const int P = (g >> 1) ^ fs_sw(c);
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) l[s_][h] = (uint32_t)(c * FS_ROWB + (g & 1) * 8 + ((P ^ (4 * s_ + 2 * h)) << 4));
+}
+__device__ __forceinline__ bf16x8 fs_rp_asm(const uint32_t (&rp)[2][2], int tensor, int row0, int s_) {
+    const int o = tensor * FS_TILEB + row0 * FS_ROWB;
+    return fs_join(fs_rd8(rp[s_][0], o), fs_rd8(rp[s_][1], o));
+}
+
 __global__ __launch_bounds__(FS_NT, 2) void favor_fs_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                 int64_t ld, const float* __restrict__ omega, bf16_t* __restrict__ out, int64_t ld_out,
                                                                 float* __restrict__ den_g, float* __restrict__ state_S, float* __restrict__ state_z,
@@ -258,6 +301,8 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_fwd_kernel(const bf16_t* __
     asm volatile("" ::: "memory");
     bf16x4 o_prev[2] = {};                             // chunk i - 1's output rows, stored during iteration i
     float d_prev[2] = {0.f, 0.f};
+    const uint32_t lpb0 = fs_lds_addr(QFb) + fs_lp_lane(g, c);       // lane part of the asm feature-image reads (fs_lp_asm)
+    constexpr int KFO = 2 * FS_C * FS_LDF * 2;         // KF images behind the two QF images
 #ifdef EMO_DIAG
     uint64_t tc[8] = {}, ts = __builtin_readcyclecounter(), tstart = ts;
 #define FS_STAMP(k) do { const uint64_t tn_ = __builtin_readcyclecounter(); tc[k] += tn_ - ts; ts = tn_; } while (0)
@@ -306,11 +351,16 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_fwd_kernel(const bf16_t* __
 #endif
         // ---------------- phase B
         bf16x8 qf[2][4], kf[2][4];
+        const uint32_t lpb = lpb0 + (i & 1) * (FS_C * FS_LDF * 2);
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+        for (int hs = 0; hs < 2; ++hs)                 // k-steps 0, 1 of every fragment first (16 reads), then 2, 3
 #pragma unroll
-            for (int s = 0; s < 4; ++s) { qf[tt][s] = fs_load_perm(QF, 16 * tt, s, lane); kf[tt][s] = fs_load_perm(KF, 16 * tt, s, lane); }
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) { qf[tt][2 * hs + u] = fs_lp_asm(lpb, 0, 16 * tt, 2 * hs + u); kf[tt][2 * hs + u] = fs_lp_asm(lpb, KFO, 16 * tt, 2 * hs + u); }
         const bf16x8 vop = fs_ring_perm_tr(VB, 16 * w, lane);
+        fs_pin<24>(qf[0][0], kf[0][0], qf[1][0], kf[1][0]);
+        fs_pin<16>(qf[0][1], kf[0][1], qf[1][1], kf[1][1]);
 #ifdef EMO_DIAG
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         asm volatile("" :: "v"(vop), "v"(qf[0][0]), "v"(qf[1][3]), "v"(kf[0][0]), "v"(kf[1][3]));
@@ -324,6 +374,8 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_fwd_kernel(const bf16_t* __
             aa[1][u] = mma32(kf[0][u], qf[1][u], zero4());
             aa[2][u] = mma32(kf[1][u], qf[1][u], zero4());
         }
+        fs_pin<8>(qf[0][2], kf[0][2], qf[1][2], kf[1][2]);
+        fs_pin<0>(qf[0][3], kf[0][3], qf[1][3], kf[1][3]);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             aa[0][u] = mma32(kf[0][2 + u], qf[0][2 + u], aa[0][u]);
@@ -550,6 +602,8 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
     asm volatile("" ::: "memory");
     char* KPw = KP + w * 2048;
     bf16x4 o_prev[2] = {};
+    uint32_t rpl[2][2];                                // lane parts of the asm ring reads (fs_rp_asm)
+    fs_rp_lane(g, c, rpl);
     FSD_BEGIN
     for (int i = 0; i < nch; ++i) {
         const int64_t t0 = (int64_t)i * FS_C;
@@ -562,14 +616,30 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
         char* DUb = DU + (i & 1) * FS_TILEB;
         float* SAb = SA + (i & 1) * 128;
         // dN / dD operands first (ring reads + the Gram MFMAs), so that their latency runs under the feature phase's exponentials
-        bf16x8 dfr[2][2];
+        bf16x8 dfr[2][2], ofr[2][2], vr[2][2];
         f32x4 gmm[2];
+        uint32_t rp[2][2];
+        {
+            const uint32_t slot = ring_lds + (i % 3) * FS_SLOTB;
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+                for (int h_ = 0; h_ < 2; ++h_) rp[s_][h_] = rpl[s_][h_] + slot;
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) { dfr[tt][s_] = fs_rp_asm(rp, 3, 16 * tt, s_); ofr[tt][s_] = fs_rp_asm(rp, 4, 16 * tt, s_); }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)                 // the V rows of the P product: landed long before they are used
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) vr[jt][s_] = fs_rp_asm(rp, 2, 16 * jt, s_);
+        fs_pin<16>(dfr[0][0], ofr[0][0], dfr[0][1], ofr[0][1]);
+        fs_pin<8>(dfr[1][0], ofr[1][0], dfr[1][1], ofr[1][1]);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            dfr[tt][0] = fs_ring_perm(Xg, 16 * tt, 0, g, c); dfr[tt][1] = fs_ring_perm(Xg, 16 * tt, 1, g, c);
-            const bf16x8 o0 = fs_ring_perm(Xo, 16 * tt, 0, g, c), o1 = fs_ring_perm(Xo, 16 * tt, 1, g, c);
-            gmm[tt] = mma32(o0, dfr[tt][0], zero4());
-            gmm[tt] = mma32(o1, dfr[tt][1], gmm[tt]);
+            gmm[tt] = mma32(ofr[tt][0], dfr[tt][0], zero4());
+            gmm[tt] = mma32(ofr[tt][1], dfr[tt][1], gmm[tt]);
         }
         // ---------------- phase A: features of the slice
         float pq[2][4], nq[2][4];
@@ -621,11 +691,7 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dq_kernel(const bf16_t* __r
         // P^T(jt, tt) = V G^T + dD, masked j <= t
         bf16x8 at[2];
         {
-            bf16x8 vr[2][2];
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) vr[jt][s] = fs_ring_perm(Xv, 16 * jt, s, g, c);
+            fs_pin<0>(vr[0][0], vr[0][1], vr[1][0], vr[1][1]);
             f32x4 p00 = mma32(vr[0][0], gop[0][0], zero4()), p01 = mma32(vr[0][0], gop[1][0], zero4()), p11 = mma32(vr[1][0], gop[1][0], zero4());
             p00 = mma32(vr[0][1], gop[0][1], p00);
             p01 = mma32(vr[0][1], gop[1][1], p01);
@@ -844,6 +910,10 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
     asm volatile("" ::: "memory");
     float* PVw = PV + w * 96;
     bf16x4 dk_prev[2] = {}, dv_prev[2] = {};
+    uint32_t rpl[2][2];                                // lane parts of the asm LDS reads (fs_rp_asm / fs_lp_asm)
+    fs_rp_lane(g, c, rpl);
+    const uint32_t lpb = fs_lds_addr(QF) + fs_lp_lane(g, c);
+    constexpr int KFO = FS_C * FS_LDF * 2;             // KF image behind QF
     FSD_BEGIN
     for (int n = 0; n < nch; ++n) {
         const int64_t t0 = (int64_t)(nch - 1 - n) * FS_C;
@@ -877,10 +947,29 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
             xown[jt] = *(const bf16x4*)(Xk + row * FS_ROWB + (((2 * w + (g >> 1)) ^ fs_sw(row)) << 4) + (g & 1) * 8);
         }
         bf16x8 gA[2][2];                               // dN rows t as A operand (permuted k = d)
+        uint32_t rp[2][2];
+        {
+            const uint32_t slot = ring_lds + (n & 1) * FS_SLOTB;
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+                for (int h_ = 0; h_ < 2; ++h_) rp[s_][h_] = rpl[s_][h_] + slot;
+        }
+        bf16x8 dfr[2][2], ofr[2][2], vB1[2][2];       // 24 asm reads in flight: dout / out rows of both tiles, then the V rows of the P product
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) { dfr[tt][s_] = fs_rp_asm(rp, 3, 16 * tt, s_); ofr[tt][s_] = fs_rp_asm(rp, 4, 16 * tt, s_); }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) vB1[jt][s_] = fs_rp_asm(rp, 2, 16 * jt, s_);
+        fs_pin<16>(dfr[0][0], ofr[0][0], dfr[0][1], ofr[0][1]);
+        fs_pin<8>(dfr[1][0], ofr[1][0], dfr[1][1], ofr[1][1]);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            const bf16x8 d0 = fs_ring_perm(Xg, 16 * tt, 0, g, c), d1 = fs_ring_perm(Xg, 16 * tt, 1, g, c);
-            const bf16x8 o0 = fs_ring_perm(Xo, 16 * tt, 0, g, c), o1 = fs_ring_perm(Xo, 16 * tt, 1, g, c);
+            const bf16x8 d0 = dfr[tt][0], d1 = dfr[tt][1];
+            const bf16x8 o0 = ofr[tt][0], o1 = ofr[tt][1];
             f32x4 gm = mma32(o0, d0, zero4());
             gm = mma32(o1, d1, gm);
             const float dot = fs_diag_sum_rows(gm, g, c);
@@ -898,11 +987,8 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
         FSD(1);
         bf16x8 pb[2];                                  // P[t][j] = dN_t.v_j + dD_t, t >= j: rows t = 16 tt + 4 g + r, column j
         {
-            bf16x8 vB[2][2];                           // V rows j as B operand (permuted k = d)
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) vB[jt][s] = fs_ring_perm(Xv, 16 * jt, s, g, c);
+            fs_pin<0>(vB1[0][0], vB1[0][1], vB1[1][0], vB1[1][1]);
+            bf16x8 (&vB)[2][2] = vB1;                  // V rows j as B operand (permuted k = d)
             f32x4 p00 = mma32(gA[0][0], vB[0][0], zero4()), p10 = mma32(gA[1][0], vB[0][0], zero4()), p11 = mma32(gA[1][0], vB[1][0], zero4());
             p00 = mma32(gA[0][1], vB[0][1], p00);
             p10 = mma32(gA[1][1], vB[0][1], p10);
@@ -926,9 +1012,13 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
         {
             bf16x8 qfA[2][4], kfB[2][4];
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
+            for (int hs = 0; hs < 2; ++hs)             // k-steps 0, 1 of every fragment first (16 reads), then 2, 3
 #pragma unroll
-                for (int s = 0; s < 4; ++s) { qfA[tt][s] = fs_load_perm(QF, 16 * tt, s, lane); kfB[tt][s] = fs_load_perm(KF, 16 * tt, s, lane); }
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) { qfA[tt][2 * hs + u] = fs_lp_asm(lpb, 0, 16 * tt, 2 * hs + u); kfB[tt][2 * hs + u] = fs_lp_asm(lpb, KFO, 16 * tt, 2 * hs + u); }
+            fs_pin<24>(qfA[0][0], kfB[0][0], qfA[1][0], kfB[1][0]);
+            fs_pin<16>(qfA[0][1], kfB[0][1], qfA[1][1], kfB[1][1]);
             f32x4 aa[3][2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -936,6 +1026,8 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
                 aa[1][u] = mma32(qfA[1][u], kfB[0][u], zero4());
                 aa[2][u] = mma32(qfA[1][u], kfB[1][u], zero4());
             }
+            fs_pin<8>(qfA[0][2], kfB[0][2], qfA[1][2], kfB[1][2]);
+            fs_pin<0>(qfA[0][3], kfB[0][3], qfA[1][3], kfB[1][3]);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 aa[0][u] = mma32(qfA[0][2 + u], kfB[0][2 + u], aa[0][u]);
@@ -974,12 +1066,13 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) vB[jt][s] = fs_ring_perm(Xv, 16 * jt, s, g, c);
+                for (int s = 0; s < 2; ++s) vB[jt][s] = fs_rp_asm(rp, 2, 16 * jt, s);
             f32x4 dph[2][2];
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
                 for (int ph = 0; ph < 2; ++ph) dph[jt][ph] = mma32(qfT[ph], pb[jt], zero4());
+            fs_pin<0>(vB[0][0], vB[0][1], vB[1][0], vB[1][1]);
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -1014,12 +1107,17 @@ __global__ __launch_bounds__(FS_NT, 2) void favor_fs_dkv_kernel(const bf16_t* __
         // dV^T for the wave's columns: dN^T A + R^T Kf^T  (two independent chains)
         const bf16x8 gTs = scale_t(fs_ring_perm_tr(Xg, 16 * w, lane));       // dN^T rows d = 16 w + i, permuted k = t
         {
+            bf16x8 kp0[4], kp1[4];                     // K features of both tiles, permuted k = f (16 asm reads)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { kp0[s] = fs_lp_asm(lpb, KFO, 0, s); kp1[s] = fs_lp_asm(lpb, KFO, 16, s); }
             f32x4 a0 = mma32(gTs, ab[0], zero4()), a1 = mma32(gTs, ab[1], zero4());
+            fs_pin<8>(kp0[0], kp1[0], kp0[1], kp1[1]);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
+                if (s == 2) fs_pin<0>(kp0[2], kp1[2], kp0[3], kp1[3]);
                 const bf16x8 rd = pack8(RD[2 * s], RD[2 * s + 1]);
-                a0 = mma32(rd, fs_load_perm(KF, 0, s, lane), a0);
-                a1 = mma32(rd, fs_load_perm(KF, 16, s, lane), a1);
+                a0 = mma32(rd, kp0[s], a0);
+                a1 = mma32(rd, kp1[s], a1);
             }
             dv_prev[0] = (bf16x4){(bf16_t)a0[0], (bf16_t)a0[1], (bf16_t)a0[2], (bf16_t)a0[3]};
             dv_prev[1] = (bf16x4){(bf16_t)a1[0], (bf16_t)a1[1], (bf16_t)a1[2], (bf16_t)a1[3]};
