@@ -72,6 +72,7 @@ _SIG = {
     'emo_relpos_attn_bwd_r_workspace_bytes': (c_l, [c_l, c_l, c_l, c_l]),
     'emo_relpos_attn_decode': (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_p]),
     'emo_softmax_attn_decode': (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_l, c_l, c_l, c_p]),
+    'emo_softmax_attn_decode_layout': (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_l, c_l, c_l, c_i, c_p]),
     'emo_xent_fwd': (c_i, [c_p, c_p, c_l, c_l, c_l, c_p, c_p, c_p]),
     'emo_xent_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_p]),
     'emo_argmax': (c_i, [c_p, c_l, c_l, c_p, c_p]),

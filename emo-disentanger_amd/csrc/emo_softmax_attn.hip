@@ -395,7 +395,7 @@ template <typename CT, int NT>
 __global__ __launch_bounds__(NT) void sattn_decode_kernel(const CT* __restrict__ q, int64_t ld_q, CT* __restrict__ kc, CT* __restrict__ vc,
                                                            int64_t T_max, const int64_t* __restrict__ lens, int64_t lens_off,
                                                            const CT* __restrict__ k_new, const CT* __restrict__ v_new, int64_t ld_new,
-                                                           CT* __restrict__ out, int64_t ld_out, int64_t H, int dh) {
+                                                           CT* __restrict__ out, int64_t ld_out, int64_t H, int dh, int head_major) {
     constexpr int VE = 16 / sizeof(CT);
     extern __shared__ float sc[];            // [T_max] scores
     __shared__ float qs[128], red[NT / 64];
@@ -404,11 +404,16 @@ __global__ __launch_bounds__(NT) void sattn_decode_kernel(const CT* __restrict__
     const int64_t sh = blockIdx.x, s = sh / H, h = sh % H;
     const int64_t len = lens[s] + lens_off;
     const int64_t HD = H * dh;
+    // cache layout: [n, T_max, H * dh] (row stride H * dh: the layout of the projections) or, head_major, [n, H, T_max, dh] — a (stream, head)'s
+    // keys are then ONE contiguous run of len * dh elements instead of dh-element pieces H * dh apart
+    const int64_t rstride = head_major ? dh : HD;
+    kc += head_major ? (s * H + h) * T_max * dh : s * T_max * HD + h * dh;
+    vc += head_major ? (s * H + h) * T_max * dh : s * T_max * HD + h * dh;
     if (tid < dh) {
         qs[tid] = to_f32<CT>(q[s * ld_q + h * dh + tid]);
         if (k_new) {
-            kc[(s * T_max + len - 1) * HD + h * dh + tid] = k_new[s * ld_new + h * dh + tid];
-            vc[(s * T_max + len - 1) * HD + h * dh + tid] = v_new[s * ld_new + h * dh + tid];
+            kc[(len - 1) * rstride + tid] = k_new[s * ld_new + h * dh + tid];
+            vc[(len - 1) * rstride + tid] = v_new[s * ld_new + h * dh + tid];
         }
     }
     __syncthreads();
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(NT) void sattn_decode_kernel(const CT* __restrict__
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
             const int64_t j = j0 + (int64_t)u * RPB + rl;
-            kv[u] = *(const RowV*)(kc + (s * T_max + (j < len ? j : len - 1)) * HD + h * dh + cl);
+            kv[u] = *(const RowV*)(kc + (j < len ? j : len - 1) * rstride + cl);
         }
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(NT) void sattn_decode_kernel(const CT* __restrict__
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
             const int64_t j = j0 + (int64_t)u * RPB + rl;
-            vv[u] = *(const RowV*)(vc + (s * T_max + (j < len ? j : len - 1)) * HD + h * dh + cl);
+            vv[u] = *(const RowV*)(vc + (j < len ? j : len - 1) * rstride + cl);
             pw[u] = j < len ? sc[j] : 0.f;
         }
 #pragma unroll
@@ -617,9 +622,17 @@ extern "C" int emo_softmax_attn_bwd(const void* q, const void* k, const void* v,
     return emo_softmax_attn_bwd_keep(q, k, v, ld, out, dout, ld_out, lse, delta_ws, dq, dk, dv, ld_d, dtype, B, T, H, dh, p_drop, seed, offset, nullptr, 0, stream);
 }
 
+extern "C" int emo_softmax_attn_decode_layout(const void* q, int64_t ld_q, void* kcache, void* vcache, int64_t T_max, const int64_t* lens, int64_t lens_off,
+                                              const void* k_new, const void* v_new, int64_t ld_new, void* out, int64_t ld_out, int dtype, int64_t n_streams,
+                                              int64_t H, int64_t dh, int head_major, emo_stream_t stream);
 extern "C" int emo_softmax_attn_decode(const void* q, int64_t ld_q, void* kcache, void* vcache, int64_t T_max, const int64_t* lens, int64_t lens_off,
                                        const void* k_new, const void* v_new, int64_t ld_new, void* out, int64_t ld_out, int dtype, int64_t n_streams,
                                        int64_t H, int64_t dh, emo_stream_t stream) {
+    return emo_softmax_attn_decode_layout(q, ld_q, kcache, vcache, T_max, lens, lens_off, k_new, v_new, ld_new, out, ld_out, dtype, n_streams, H, dh, 0, stream);
+}
+extern "C" int emo_softmax_attn_decode_layout(const void* q, int64_t ld_q, void* kcache, void* vcache, int64_t T_max, const int64_t* lens, int64_t lens_off,
+                                              const void* k_new, const void* v_new, int64_t ld_new, void* out, int64_t ld_out, int dtype, int64_t n_streams,
+                                              int64_t H, int64_t dh, int head_major, emo_stream_t stream) {
     EMO_CHECK(q && kcache && vcache && lens && out, "emo_softmax_attn_decode: null pointer");
     EMO_CHECK(dh == 16 || dh == 32 || dh == 64 || dh == 128, "emo_softmax_attn_decode: d_head must be 16, 32, 64 or 128");
     EMO_CHECK(!k_new == !v_new, "emo_softmax_attn_decode: k_new and v_new go together");
@@ -633,6 +646,10 @@ extern "C" int emo_softmax_attn_decode(const void* q, int64_t ld_q, void* kcache
     // times the requests in flight (r05; EMO_SATTN_DECODE_NT=256 keeps the 4-wave instance).  GPT-2 generation, 32 streams x 2048: 25 us per
     // layer with 8 rows per thread in flight, 20 us with 16 waves (the CU's own ~10 B/clk HBM rate gives 12 us for its 270 KB at the mean
     // context); a single-sweep online-softmax variant (K and V rows in flight together, no score buffer) measured the same 20 us and was dropped.
+    // (r06: a single-sweep form — lens, q, the new rows and the first 1024 key AND value rows requested speculatively in the first round trip,
+    // thread-local online softmax, one merge at the end — measured 0.675 against 0.558 ms per token step of the 32 x 2048 generation: it moves
+    // 1.5 x the bytes (every step fetches 1024 rows per (stream, head) whatever its context) and the kernel is bound by the CU's fetch rate, not
+    // by its chain of round trips; removed, tools/ab_gen_gpt2.sh kept)
     int nt = 1024;
     { const char* e = getenv("EMO_SATTN_DECODE_NT"); if (e && atoi(e) == 256) nt = 256; }
     if (T_max * 4 > 96 * 1024) nt = 256;                             // (two-pass kernel: score buffer + the 1024-thread instance's partial sums must fit the LDS)
@@ -641,7 +658,7 @@ extern "C" int emo_softmax_attn_decode(const void* q, int64_t ld_q, void* kcache
         static bool a = false;                                                                                                             \
         if (!a) { (void)hipFuncSetAttribute((const void*)sattn_decode_kernel<CTv, NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, (NTv == 1024 ? 96 : 128) * 1024); a = true; } \
         hipLaunchKernelGGL((sattn_decode_kernel<CTv, NTv>), grid, dim3(NTv), lds, st, (const CTv*)q, ld_q, (CTv*)kcache, (CTv*)vcache, T_max, lens, lens_off, \
-                           (const CTv*)k_new, (const CTv*)v_new, ld_new, (CTv*)out, ld_out, H, (int)dh);                                  \
+                           (const CTv*)k_new, (const CTv*)v_new, ld_new, (CTv*)out, ld_out, H, (int)dh, head_major);                      \
     } while (0)
     if (dtype == EMO_F32) { if (nt == 1024) SD_LAUNCH(float, 1024); else SD_LAUNCH(float, 256); }
     else { if (nt == 1024) SD_LAUNCH(bf16_t, 1024); else SD_LAUNCH(bf16_t, 256); }

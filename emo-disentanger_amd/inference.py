@@ -346,8 +346,12 @@ class GPT2DecodeEngine(_EngineBase):
     def __init__(self, model, n_streams, max_len=max_dec_inp_len):
         super().__init__(model, n_streams, max_len)
         D = model.d_model
-        self.kc = [torch.zeros(n_streams, max_len, D, device=self.dev, dtype=self.dt) for _ in range(model.n_layer)]
-        self.vc = [torch.zeros(n_streams, max_len, D, device=self.dev, dtype=self.dt) for _ in range(model.n_layer)]
+        # head-major cache [n, H, max_len, dh] (r06; HF's own past_key_values layout): the decode attention gives one workgroup to a (stream, head),
+        # whose keys are then one contiguous run instead of 128-byte pieces 1 KB apart.  EMO_KV_HEAD_MAJOR=0: [n, max_len, D] (r05, same-box A/B)
+        self.head_major = os.environ.get('EMO_KV_HEAD_MAJOR', '1') != '0'
+        shp = (n_streams, model.n_head, max_len, D // model.n_head) if self.head_major else (n_streams, max_len, D)
+        self.kc = [torch.zeros(*shp, device=self.dev, dtype=self.dt) for _ in range(model.n_layer)]
+        self.vc = [torch.zeros(*shp, device=self.dev, dtype=self.dt) for _ in range(model.n_layer)]
         self.lens = torch.zeros(n_streams, device=self.dev, dtype=torch.int64)
         # bf16 one-token steps: the Conv1D weights ([in, out]) are transposed ONCE to the k-contiguous layout of the skinny decode GEMM,
         # ln_1 / ln_2 are folded into c_attn / c_fc (emo_hip.h: ln_c1) and the new k / v rows are appended by the attention kernel:
@@ -407,8 +411,12 @@ class GPT2DecodeEngine(_EngineBase):
             pfx = m._layer_prefix(l)
             n1, _, _ = ops.layernorm_fwd(x, ps.f32(pfx + 'ln_1.weight'), ps.f32(pfx + 'ln_1.bias'))
             qkv = ops.gemm(n1, ps.w(pfx + 'attn.c_attn.weight'), b_trans=True, bias=ps.f32(pfx + 'attn.c_attn.bias'))
-            self.kc[l][:, :T].copy_(qkv[:, D:2 * D].view(B, T, D))
-            self.vc[l][:, :T].copy_(qkv[:, 2 * D:].view(B, T, D))
+            if self.head_major:
+                self.kc[l][:, :, :T].copy_(qkv[:, D:2 * D].view(B, T, H, D // H).permute(0, 2, 1, 3))
+                self.vc[l][:, :, :T].copy_(qkv[:, 2 * D:].view(B, T, H, D // H).permute(0, 2, 1, 3))
+            else:
+                self.kc[l][:, :T].copy_(qkv[:, D:2 * D].view(B, T, D))
+                self.vc[l][:, :T].copy_(qkv[:, 2 * D:].view(B, T, D))
             a, _ = ops.softmax_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, T, H)
             x = self._block_tail(pfx, x, a)
         self.pos = T
@@ -431,20 +439,15 @@ class GPT2DecodeEngine(_EngineBase):
             else:
                 self.pos += 1
             return out
-        if dev_pos:
-            slot = torch.arange(self.n, device=self.dev) * self.max_len + self.pos_dev      # flat cache row of each stream's new token
         self.lens.add_(1)
+        ext = dev_pos and not self.pos_auto                       # positions AND key counts come from the sampler's step counter (as in the folded path)
         for l in range(m.n_layer):
             pfx = m._layer_prefix(l)
             n1, _, _ = ops.layernorm_fwd(x, ps.f32(pfx + 'ln_1.weight'), ps.f32(pfx + 'ln_1.bias'))
             qkv = ops.gemm(n1, ps.w(pfx + 'attn.c_attn.weight'), b_trans=True, bias=ps.f32(pfx + 'attn.c_attn.bias'))
-            if dev_pos:
-                self.kc[l].view(-1, D).index_copy_(0, slot, qkv[:, D:2 * D])
-                self.vc[l].view(-1, D).index_copy_(0, slot, qkv[:, 2 * D:])
-            else:
-                self.kc[l][:, self.pos].copy_(qkv[:, D:2 * D])
-                self.vc[l][:, self.pos].copy_(qkv[:, 2 * D:])
-            a = ops.softmax_attn_decode(qkv[:, :D], self.kc[l], self.vc[l], self.lens, H)
+            # (the general-shape path — fp32 parity mode, more than 32 streams — lets the attention kernel append the rows as the folded path does)
+            a = ops.softmax_attn_decode(qkv[:, :D], self.kc[l], self.vc[l], self.pos_dev if ext else self.lens, H, lens_off=self.dev_pos0 + 1 if ext else 0,
+                                        k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:])
             x = self._block_tail(pfx, x, a)
         if dev_pos:
             self.pos_dev.add_(1)

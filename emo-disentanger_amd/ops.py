@@ -383,14 +383,17 @@ def softmax_attn_bwd(q, k, v, out, dout, lse, B, T, H, p_drop=0.0, seed=0, offse
 
 
 def softmax_attn_decode(q, kcache, vcache, lens, H, lens_off=0, k_new=None, v_new=None):
-    """One query row per stream against the KV caches; k_new / v_new: the new token's rows, appended in-kernel at position lens + lens_off - 1."""
+    """One query row per stream against the KV caches; k_new / v_new: the new token's rows, appended in-kernel at position lens + lens_off - 1.
+    Caches: [n, T_max, H * dh], or head-major [n, H, T_max, dh] (4-D tensors)."""
     n, HD = q.shape
-    T_max = kcache.shape[1]
-    assert kcache.is_contiguous() and vcache.is_contiguous() and lens.dtype == torch.int64
+    head_major = kcache.dim() == 4
+    T_max = kcache.shape[2] if head_major else kcache.shape[1]
+    assert kcache.is_contiguous() and vcache.is_contiguous() and lens.dtype == torch.int64 and kcache.shape == vcache.shape
+    assert not head_major or (kcache.shape[1] == H and kcache.shape[3] == HD // H)
     assert (k_new is None) == (v_new is None) and (k_new is None or _rows(k_new) == _rows(v_new))
     out = torch.empty(n, HD, device=q.device, dtype=q.dtype)
-    check(lib.emo_softmax_attn_decode(ptr(q), _rows(q), ptr(kcache), ptr(vcache), T_max, ptr(lens), lens_off, ptr(k_new), ptr(v_new),
-                                      0 if k_new is None else _rows(k_new), ptr(out), HD, dtype_code(q.dtype), n, H, HD // H, stream()))
+    check(lib.emo_softmax_attn_decode_layout(ptr(q), _rows(q), ptr(kcache), ptr(vcache), T_max, ptr(lens), lens_off, ptr(k_new), ptr(v_new),
+                                             0 if k_new is None else _rows(k_new), ptr(out), HD, dtype_code(q.dtype), n, H, HD // H, int(head_major), stream()))
     return out
 
 

@@ -291,6 +291,13 @@ int emo_softmax_attn_decode(const void* q, int64_t ld_q, void* kcache, void* vca
                             const int64_t* lens, int64_t lens_off, const void* k_new, const void* v_new,
                             int64_t ld_new, void* out, int64_t ld_out, int dtype, int64_t n_streams,
                             int64_t H, int64_t dh, emo_stream_t stream);
+/* The same with the cache layout chosen by the caller (r06): head_major = 0: [n_streams, T_max, H*dh] as above; head_major = 1:
+ * [n_streams, H, T_max, dh] — the keys / values of one (stream, head) are one contiguous run, which is what the one workgroup per (stream, head)
+ * streams (the layout HF's `past_key_values` itself uses: [batch, head, seq, head_dim]). */
+int emo_softmax_attn_decode_layout(const void* q, int64_t ld_q, void* kcache, void* vcache, int64_t T_max,
+                                   const int64_t* lens, int64_t lens_off, const void* k_new, const void* v_new,
+                                   int64_t ld_new, void* out, int64_t ld_out, int dtype, int64_t n_streams,
+                                   int64_t H, int64_t dh, int head_major, emo_stream_t stream);
 
 /* ------------------------------------------------------------------ K5r: relative-position causal attention (stage-1 Transformer-XL)
  * SURVEY §8 f-1.  Replaces RelPartialLearnableMultiHeadAttn's score / softmax / value product

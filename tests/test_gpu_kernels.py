@@ -849,6 +849,16 @@ def test_softmax_attention_fwd_bwd(dt, B, T, H, dh):
     ql = qc[:, :HD].reshape(B, T, HD)[:, -1].contiguous()
     od = ops.softmax_attn_decode(ql, kc, vc, torch.full((B,), T, dtype=torch.int64, device='cuda'), H)
     _close(od, ref.view(B, T, HD)[:, -1], dt)
+    # head-major cache [B, H, T_max, dh] (r06, emo_softmax_attn_decode_layout) with the last key / value row appended by the kernel itself
+    T_max = T + 5
+    kh = torch.zeros(B, H, T_max, dh, device='cuda', dtype=dt)
+    vh = torch.zeros(B, H, T_max, dh, device='cuda', dtype=dt)
+    kh[:, :, :T - 1] = kc.view(B, T, H, dh)[:, :T - 1].permute(0, 2, 1, 3)
+    vh[:, :, :T - 1] = vc.view(B, T, H, dh)[:, :T - 1].permute(0, 2, 1, 3)
+    oh = ops.softmax_attn_decode(ql, kh, vh, torch.full((B,), T - 1, dtype=torch.int64, device='cuda'), H, lens_off=1,
+                                 k_new=kc[:, -1].contiguous(), v_new=vc[:, -1].contiguous())
+    assert torch.equal(oh, od)
+    assert torch.equal(kh[:, :, T - 1], kc.view(B, T, H, dh)[:, -1]) and torch.equal(vh[:, :, T - 1], vc.view(B, T, H, dh)[:, -1])
 
 
 @pytest.mark.parametrize('B,T,H,p', [(2, 256, 2, 0.0), (1, 128, 1, 0.0), (1, 640, 3, 0.0), (2, 384, 2, 0.2)])
