@@ -649,7 +649,8 @@ extern "C" int emo_softmax_attn_decode_layout(const void* q, int64_t ld_q, void*
     // (r06: a single-sweep form — lens, q, the new rows and the first 1024 key AND value rows requested speculatively in the first round trip,
     // thread-local online softmax, one merge at the end — measured 0.675 against 0.558 ms per token step of the 32 x 2048 generation: it moves
     // 1.5 x the bytes (every step fetches 1024 rows per (stream, head) whatever its context) and the kernel is bound by the CU's fetch rate, not
-    // by its chain of round trips; removed, tools/ab_gen_gpt2.sh kept)
+    // by its chain of round trips; removed, tools/ab_gen_gpt2.sh kept.  Requesting the next iteration's rows before the current ones are used
+    // (software-pipelined sweeps) measured 0.585 against 0.566: more requests in flight per CU do not help either)
     int nt = 1024;
     { const char* e = getenv("EMO_SATTN_DECODE_NT"); if (e && atoi(e) == 256) nt = 256; }
     if (T_max * 4 > 96 * 1024) nt = 256;                             // (two-pass kernel: score buffer + the 1024-thread instance's partial sums must fit the LDS)
