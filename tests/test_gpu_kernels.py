@@ -1216,6 +1216,28 @@ def test_gemm_layernorm_of_the_a_operand_matches_the_separate_kernels(M, N):
         assert torch.equal(y, ops.gemm(h, W, **kw))
 
 
+def test_gemm_layernorm_of_the_a_operand_rows_with_a_large_mean():
+    # r05 advisor finding: the in-product LayerNorm takes the variance as E[x^2] - mean^2 from MFMA row sums (fp32), where the standalone kernel
+    # centres first — rows whose |mean| is far above their spread lose variance digits to cancellation.  Bound measured and asserted here for
+    # |mean| = 50 x std (E[x^2] ~ 2500 against a variance of ~1: the fp32 sum of 512 exact products carries ~1e-7 relative error, i.e. ~3e-4 of
+    # the variance): rstd within 2e-3 of the fp64 value — below the bf16 rounding (2^-8) of the normalised rows it scales; the post-LN / pre-LN
+    # streams of the two backbones have |mean| / std < 1 (test above).  Rows with |mean| > ~1000 x std would need the centred form.
+    ops = _ops()
+    M, N, K = 4096, 512, 512
+    x = (_r(M, K, seed=11) + 50.0).to(torch.bfloat16).cuda()
+    W = _r(N, K, seed=2, scale=0.05).to(torch.bfloat16).cuda()
+    g, b = torch.ones(K, device='cuda'), torch.zeros(K, device='cuda')
+    y, h, mean, rstd = ops.gemm(x, W, lna=(g, b, 1e-5))
+    xd = x.double()
+    mu = xd.mean(1)
+    var = ((xd - mu[:, None]) ** 2).mean(1)
+    rel = float((rstd.double() * (var + 1e-5).sqrt() - 1).abs().max())
+    print('[lna large mean] max relative rstd error %.3g (mean / std = 50)' % rel)
+    assert float((mean.double() - mu).abs().max()) <= 1e-4 and rel <= 2e-3
+    h_ref, _, r_ref = ops.layernorm_fwd(x, g, b)
+    assert float((h.float() - h_ref.float()).abs().max()) <= 2 ** -6 * float(h_ref.float().abs().max())
+
+
 def test_stream_wait_orders_a_side_stream_launch_behind_the_main_stream():
     # emo_stream_wait (fork / join of the weight-gradient stream without torch Stream contexts) + ops.gemm(stream=raw handle): a product launched
     # on a second stream must see operands that the main stream is still producing when the launch is queued, and the main stream must see its

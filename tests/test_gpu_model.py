@@ -363,8 +363,10 @@ def test_embedding_gradient_as_a_product_equals_the_scatter_kernel(p_drop, monke
         if 'emb_lookup' in k:
             assert float((a - bb).abs().max()) <= 1e-2 * float(a.abs().max()), k          # one bf16 rounding of each dropped element, summed over the tokens of an id
             assert float((a - bb).norm()) <= 3e-3 * float(a.norm()), k
-        else:                                                     # (not touched by the change; bias gradients of small shapes are atomic column sums)
-            assert float((a - bb).abs().max()) <= 1e-6 * max(float(a.abs().max()), 1e-30), (k, float((a - bb).abs().max()), float(a.abs().max()))
+        else:                                                     # (not touched by the change; LayerNorm weight / bias gradients of small shapes are float-atomic column sums:
+            # tools/stress_determinism.py measures up to 8.9e-7 of the largest element between two identical runs over 40 repeats — the 1e-6 this
+            # asserted until r06 failed once in five full-suite runs)
+            assert float((a - bb).abs().max()) <= 4e-6 * max(float(a.abs().max()), 1e-30), (k, float((a - bb).abs().max()), float(a.abs().max()))
 
 
 @pytest.mark.parametrize('pad', ['0', '1'])
