@@ -174,6 +174,129 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// f32 parity kernel, 128 x 128 x 16 tile (r06).  The 64 x 64 kernel above loads element-wise with arbitrary strides, single-buffered, two workgroup
+// barriers per 16-deep tile, four MFMAs per wave and k-step: 25 TFLOP/s = 0.16 of the 157-TFLOP/s exact-f32 MFMA peak, and 93 % of the fp32 parity
+// mode's training step (profiles/r06_fp32_step_rocprof_stats.txt).  Same instruction (v_mfma_f32_16x16x4_f32: an fp32 FMA chain over k in ascending
+// order — a dot product sums in the SAME order as in the kernel above, so unsplit results are bit-identical), but: a wave owns 64 x 64 outputs (16
+// MFMAs per two times four 4-byte operand reads), operand tiles arrive by 16-byte loads along whichever dimension is contiguous (KC: k-contiguous
+// rows -> LDS image [row][20]; otherwise m/n-contiguous -> [k][132]; both 16-B aligned row pitches), staged through registers so that the next
+// tile's loads are in flight during the MFMAs, two LDS buffers, ONE barrier per tile.  Edges (rows beyond M / N, a K range that is not a multiple
+// of 4, unaligned bases or strides) take element-wise predicated loads.  Shapes: the launcher sends M >= 128 and N >= 128 here.
+constexpr int F3_BM = 128, F3_BN = 128, F3_BK = 16, F3_LDK = 20, F3_LDM = 132, F3_TILE = 128 * F3_LDK;   // 2560 floats >= 16 * 132 = 2112
+template <bool KC>
+__device__ __forceinline__ void f3_gload(const float* __restrict__ P, int64_t s_row, int64_t s_k, int64_t row0, int64_t nrows, int64_t k0, int64_t kend,
+                                         bool vec_ok, int tid, f32x4 (&r)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (KC) {                                   // chunk = 4 consecutive k of one row: row = idx / 4, chunk = idx % 4
+            const int64_t gr = row0 + (idx >> 2), gk = k0 + (idx & 3) * 4;
+            if (gr < nrows && gk < kend) {
+                const float* q = P + gr * s_row + gk;
+                if (vec_ok && gk + 3 < kend) v = *(const f32x4*)q;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (gk + e < kend) v[e] = q[e];
+                }
+            }
+        } else {                                              // chunk = 4 consecutive rows at one k: k = idx / 32, chunk = idx % 32
+            const int64_t gk = k0 + (idx >> 5), gr = row0 + (idx & 31) * 4;
+            if (gk < kend && gr < nrows) {
+                const float* q = P + gk * s_k + gr;
+                if (vec_ok && gr + 3 < nrows) v = *(const f32x4*)q;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (gr + e < nrows) v[e] = q[e];
+                }
+            }
+        }
+        r[i] = v;
+    }
+}
+template <bool KC>
+__device__ __forceinline__ void f3_lstore(float* lds, int tid, const f32x4 (&r)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i;
+        if constexpr (KC) *(f32x4*)(lds + (idx >> 2) * F3_LDK + (idx & 3) * 4) = r[i];
+        else *(f32x4*)(lds + (idx >> 5) * F3_LDM + (idx & 31) * 4) = r[i];
+    }
+}
+template <bool KC>
+__device__ __forceinline__ float f3_frag(const float* lds, int row, int k) { return KC ? lds[row * F3_LDK + k] : lds[k * F3_LDM + row]; }
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_t128_kernel(const float* __restrict__ A, int64_t sam, int64_t sak, const float* __restrict__ B, int64_t sbn,
+                                                               int64_t sbk, float* __restrict__ C, int64_t M, int64_t N, int64_t K, int64_t k_per_split,
+                                                               EpiParams ep, int a_vec, int b_vec) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][F3_TILE];           // [buffer][A | B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t tiles_n = (N + F3_BN - 1) / F3_BN, tiles_m = (M + F3_BM - 1) / F3_BM;
+    int64_t tm, tn, split = 0;
+    if (ep.atomic) {
+        splitk_coords(tiles_m, tiles_n, ep.atomic, tm, tn, split);
+        if (ep.ws_stride) { C += split * ep.ws_stride; ep.atomic = 0; }
+    } else tile_coords(tiles_m, tiles_n, tm, tn);
+    if (tm >= tiles_m) return;
+    const int64_t m0 = tm * F3_BM, n0 = tn * F3_BN;
+    const int64_t kbeg = split * k_per_split;
+    const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+    if (kbeg >= kend) return;
+    const int wm = wave >> 1, wn = wave & 1;                  // 2 x 2 waves, 64 x 64 each
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[2], rb[2];
+    f3_gload<A_KC>(A, sam, sak, m0, M, kbeg, kend, a_vec != 0, tid, ra);
+    f3_gload<B_KC>(B, sbn, sbk, n0, N, kbeg, kend, b_vec != 0, tid, rb);
+    f3_lstore<A_KC>(lds[0][0], tid, ra);
+    f3_lstore<B_KC>(lds[0][1], tid, rb);
+    __syncthreads();
+    const int nk = (int)((kend - kbeg + F3_BK - 1) / F3_BK);
+    const int r16 = lane & 15, kq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {                                           // next tile's loads in flight during this tile's MFMAs
+            const int64_t k0 = kbeg + (int64_t)(kt + 1) * F3_BK;
+            f3_gload<A_KC>(A, sam, sak, m0, M, k0, kend, a_vec != 0, tid, ra);
+            f3_gload<B_KC>(B, sbn, sbk, n0, N, k0, kend, b_vec != 0, tid, rb);
+        }
+        const float* As = lds[cur][0];
+        const float* Bs = lds[cur][1];
+#pragma unroll
+        for (int ks = 0; ks < F3_BK; ks += 4) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = f3_frag<A_KC>(As, wm * 64 + i * 16 + r16, ks + kq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = f3_frag<B_KC>(Bs, wn * 64 + j * 16 + r16, ks + kq);
+            // swapped operands: D'[n][m] so that a lane owns 4 consecutive n
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            f3_lstore<A_KC>(lds[cur ^ 1][0], tid, ra);
+            f3_lstore<B_KC>(lds[cur ^ 1][1], tid, rb);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t m = m0 + wm * 64 + i * 16 + r16;
+            const int64_t n = n0 + wn * 64 + j * 16 + kq * 4;
+            if (m < M && n < N) epi_store4_call<float>(ep, C, m, n, acc[i][j], N);
+        }
+}
+
 // ================================================================================================
 // bf16 MFMA kernel
 constexpr int GB_M = 128, GB_N = 128, GB_K = 64;
@@ -1006,6 +1129,14 @@ static thread_local int g_last_gemm_kernel = 0;
 extern "C" int emo_epilogue_size(void) { return (int)sizeof(emo_epilogue_t); }
 extern "C" int emo_gemm_last_kernel(void) { return g_last_gemm_kernel; }
 
+// fp32 products: tile edge of the kernel that serves the shape (a pure function of the shape: the split-K plan and the workspace size follow it).
+// EMO_GEMM_F32_TILE=64 keeps every shape on the 64 x 64 kernel (A/B, tests).
+static int64_t f32_tile(int64_t M, int64_t N) {
+    const char* e = getenv("EMO_GEMM_F32_TILE");                 // (read per call: tests toggle it in-process)
+    const bool small_only = e != nullptr && atoi(e) == 64;
+    return (!small_only && M >= 128 && N >= 128) ? 128 : 64;
+}
+
 #define EMO_GEMM_MAX_SPLITS 32
 extern "C" int64_t emo_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype_in, int dtype_out) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -1015,7 +1146,7 @@ extern "C" int64_t emo_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int
     }
     if (dtype_out != EMO_F32) return 0;
     const bool big = dtype_in == EMO_BF16;
-    const int64_t BMt = big ? GB_M : 64, BNt = big ? GB_N : 64, BKt = big ? (gemm_variant() >= 2 ? G2_BK : GB_K) : 16;
+    const int64_t BMt = big ? GB_M : f32_tile(M, N), BNt = big ? GB_N : f32_tile(M, N), BKt = big ? (gemm_variant() >= 2 ? G2_BK : GB_K) : 16;
     int64_t splits = choose_splits(M, N, K, big, false, dtype_out, BMt, BNt, BKt, EMO_GEMM_MAX_SPLITS);
     int64_t rs_floats = 0;
     if (big) {                                                  // (layout unknown here: sized for the wgrad kernel too, with its bias-gradient partials)
@@ -1143,7 +1274,7 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
     }
     EMO_CHECK(!ep.mask_out && ep.mul_mode != EMO_MUL_BITMASK, "emo_gemm: mask_out / EMO_MUL_BITMASK need bf16 in/out, NT, K = 512, M %% 128 == 0, M >= 4096, N %% 64 == 0, N <= 2048");
     EMO_CHECK(!ln_fused, "emo_gemm: the LayerNorm-folded epilogue (ln_c1 / rln_x) exists only on the skinny path (bf16, M <= 32, NT, K %% 32 == 0)");
-    const int64_t BMt = big ? GB_M : 64, BNt = big ? GB_N : 64;
+    const int64_t BMt = big ? GB_M : f32_tile(M, N), BNt = big ? GB_N : f32_tile(M, N);
     const int64_t BKt = big ? (variant >= 2 ? G2_BK : GB_K) : 16;
     const int64_t tiles_m = cdiv64(M, BMt), tiles_n = cdiv64(N, BNt);
     const int64_t tiles_m8 = cdiv64(tiles_m, 8) * 8;
@@ -1193,8 +1324,19 @@ extern "C" int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, 
         const float* b = (const float*)B;
         const int64_t sam = a_trans ? 1 : lda, sak = a_trans ? lda : 1;
         const int64_t sbn = b_trans ? 1 : ldb, sbk = b_trans ? ldb : 1;
-        hipLaunchKernelGGL(gemm_f32_kernel<float>, grid, dim3(256), 0, st, a, sam, sak, b, sbn, sbk, (float*)C, M, N, K,
-                           kps, ep);
+        // 128 x 128 tile kernel when one of each operand's two strides is 1 (always, for the layouts emo_gemm takes); vector loads need 16-B aligned
+        // bases and non-unit strides that are multiples of 4 elements
+        const bool akc = sak == 1, bkc = sbk == 1;
+        if (BMt == 128 && (akc || sam == 1) && (bkc || sbn == 1)) {
+            const int av = (((uintptr_t)a & 15) == 0 && ((akc ? sam : sak) & 3) == 0 && (kps & 3) == 0) ? 1 : 0;
+            const int bv = (((uintptr_t)b & 15) == 0 && ((bkc ? sbn : sbk) & 3) == 0 && (kps & 3) == 0) ? 1 : 0;
+#define F3_LAUNCH(AKv, BKv) hipLaunchKernelGGL((gemm_f32_t128_kernel<AKv, BKv>), grid, dim3(256), 0, st, a, sam, sak, b, sbn, sbk, (float*)C, M, N, K, kps, ep, av, bv)
+            if (akc && bkc) F3_LAUNCH(true, true); else if (akc) F3_LAUNCH(true, false); else if (bkc) F3_LAUNCH(false, true); else F3_LAUNCH(false, false);
+#undef F3_LAUNCH
+        } else {
+            EMO_CHECK(BMt == 64, "emo_gemm(fp32): operand with two non-unit strides on the 128-tile plan");
+            hipLaunchKernelGGL(gemm_f32_kernel<float>, grid, dim3(256), 0, st, a, sam, sak, b, sbn, sbk, (float*)C, M, N, K, kps, ep);
+        }
     } else {
         EMO_CHECK((lda & 7) == 0 && (ldb & 7) == 0, "emo_gemm(bf16): lda/ldb must be multiples of 8 (16-B rows)");
         EMO_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "emo_gemm(bf16): A/B must be 16-B aligned");

@@ -56,6 +56,44 @@ def test_gemm_layouts(dt, a_trans, b_trans, M, N, K):
     _close(out, ref, dt, mult=1.0 if dt == torch.float32 else 0.3)
 
 
+@pytest.mark.parametrize('a_trans,b_trans', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 16), (200, 136, 264), (129, 327, 509), (1024, 512, 512), (384, 2048, 96), (4096, 327, 512)])
+def test_gemm_f32_128_tile_equals_the_64_tile_kernel(a_trans, b_trans, M, N, K, monkeypatch):
+    """r06: fp32 products with M, N >= 128 run on a 128 x 128 x 16 tile kernel (16-byte operand loads, register-staged double buffer) instead of the
+    64 x 64 element-wise one.  Same MFMA instruction, same k order inside a dot product => unsplit results are BIT-identical; every layout, odd sizes
+    (scalar edge loads, K tails), unaligned row strides (views of padded tensors: vector loads off), epilogue."""
+    ops = _ops()
+    for pad in (0, 3):                                           # 3: row stride not a multiple of 4 -> the element-wise loader of the new kernel
+        A = _r(*((K, M + pad) if a_trans else (M, K + pad)), seed=1).cuda()
+        Bm = _r(*((K, N + pad) if b_trans else (N, K + pad)), seed=2).cuda()
+        Ag = A[:, :M] if a_trans else A[:, :K]
+        Bg = Bm[:, :N] if b_trans else Bm[:, :K]
+        bias = _r(N, seed=3).cuda()
+        kw = dict(a_trans=bool(a_trans), b_trans=bool(b_trans), bias=bias, act=ops.ACT_RELU)
+        monkeypatch.setenv('EMO_GEMM_F32_TILE', '64')
+        y64 = ops.gemm(Ag, Bg, **kw)
+        monkeypatch.delenv('EMO_GEMM_F32_TILE')
+        y = ops.gemm(Ag, Bg, **kw)
+        assert torch.equal(y, y64), (pad, float((y - y64).abs().max()))
+        ref = torch.relu((Ag.double().T if a_trans else Ag.double()) @ (Bg.double() if b_trans else Bg.double().T) + bias.double())
+        _close(y, ref, torch.float32)
+
+
+def test_gemm_f32_128_tile_split_k_weight_gradient():
+    # the wgrad layout with a long reduction (split-K through the workspace, accumulate into C) on the 128-tile plan
+    ops = _ops()
+    Mtok, N, K = 8192, 512, 256
+    dY, X = _r(Mtok, N, seed=5).cuda(), _r(Mtok, K, seed=6).cuda()
+    C = _r(N, K, seed=7).cuda()
+    C0 = C.clone()
+    ops.gemm(dY, X, a_trans=True, b_trans=True, out=C, accumulate=True)
+    ref = C0.double() + dY.double().T @ X.double()
+    assert float((C.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    C2 = C0.clone()
+    ops.gemm(dY, X, a_trans=True, b_trans=True, out=C2, accumulate=True)
+    assert torch.equal(C, C2)                                    # workspace split-K: fixed summation order
+
+
 @pytest.mark.parametrize('dt', DT)
 def test_gemm_epilogue_bias_act_residual_aux(dt):
     ops = _ops()
