@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, KB ? 3 : 2) void sattn32_dq_kernel(const bf16_
             p0 = mma3216(*(const bf16x8*)(Vt + oa), gf[s], p0);
             p1 = mma3216(*(const bf16x8*)(Vt + oc), gf[s], p1);
         }
-        const bool diag = k0 + 63 > wq_min;
+        const int qrel = (int)(qrow - k0) - 4 * hi;                    // key 8 a4 + r (+ 32) of this lane lies above the row when it exceeds qrel
 #pragma unroll
         for (int a4 = 0; a4 < 4; ++a4) {
             float d0[4] = {1.f, 1.f, 1.f, 1.f}, d1[4] = {1.f, 1.f, 1.f, 1.f};
@@ -293,12 +293,12 @@ __global__ __launch_bounds__(256, KB ? 3 : 2) void sattn32_dq_kernel(const bf16_
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = 4 * a4 + r, kl = r + 8 * a4 + 4 * hi;
+                const int i = 4 * a4 + r;
                 float e0 = __builtin_amdgcn_exp2f(fmaf(s0[i], c2, nl)), e1 = __builtin_amdgcn_exp2f(fmaf(s1[i], c2, nl));
-                if (diag) {
-                    if (k0 + kl > qrow) e0 = 0.f;
-                    if (k0 + 32 + kl > qrow) e1 = 0.f;
-                }
+                // causal mask as ONE 32-bit compare of a compile-time key index with a per-tile lane value (r06; `if (diag) if (k0 + kl > qrow)`
+                // compiled into 64-bit compares + mask ANDs for every score of every tile): away from the diagonal qrel >= 63 and nothing is masked
+                if (r + 8 * a4 > qrel) e0 = 0.f;
+                if (32 + r + 8 * a4 > qrel) e1 = 0.f;
                 s0[i] = e0 * fmaf(p0[i], d0[r], -dl);                 // dS (in units of the scaled scores)
                 s1[i] = e1 * fmaf(p1[i], d1[r], -dl);
             }
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void sattn32_dkv_kernel(const bf16_t* __res
         const char* Gt = Qt + A32_TILEB;
         const float* lse_l = (const float*)(Gt + A32_TILEB);
         const float* del_l = lse_l + 64;
-        const bool diag = q0 < kw0 + 31;                              // some row of the tile lies before some key of the wave
+        const int krel = (int)(key - q0) - 4 * hi;                     // row 32 hq + 8 a4 + r of the tile lies before this lane's key when it is below krel
 #pragma unroll
         for (int hq = 0; hq < 2; ++hq) {
             f32x16 sa, pa;
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void sattn32_dkv_kernel(const bf16_t* __res
                 for (int r = 0; r < 4; ++r) {
                     const int i = 4 * a4 + r;
                     float p = __builtin_amdgcn_exp2f(fmaf(sa[i], c2, -ls[r] * A32_LOG2E));
-                    if (diag && q0 + rl + r < key) p = 0.f;
+                    if (32 * hq + 8 * a4 + r < krel) p = 0.f;            // (one 32-bit compare; r06 — was a 64-bit compare + mask AND per score)
                     sa[i] = p * dm[r];                                // Pd
                     pa[i] = p * (pa[i] * dm[r] - dl[r]);              // dS
                 }
