@@ -39,6 +39,8 @@ _SIG = {
     'emo_gemm_last_kernel': (c_i, []),
     'emo_epilogue_size': (c_i, []),
     'emo_gemm_workspace_bytes': (c_l, [c_l, c_l, c_l, c_i, c_i]),
+    'emo_ffn_fwd_supported': (c_i, [c_i, c_l, c_l, c_l]),
+    'emo_ffn_fwd': (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_i, c_f, c_u64, c_u64, c_u64, c_p]),
     'emo_colsum': (c_i, [c_p, c_i, c_l, c_l, c_l, c_p, c_i, c_p]),
     'emo_embed_fwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_l, c_l, c_l, c_l, c_l, c_p, c_f, c_f, c_u64, c_u64, c_p]),
     'emo_embed_bwd': (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_l, c_l, c_l, c_l, c_f, c_f, c_u64, c_u64, c_p]),

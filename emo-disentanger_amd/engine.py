@@ -262,6 +262,18 @@ def performer_layer_fwd(ps, pfx, x, omega, B, T, H, p, seed, off, save, act='rel
     fmask = torch.empty(x.shape[0], W1.shape[0] // 8, device=x.device, dtype=torch.uint8) \
         if (act == 'relu' and save is not None and ops.gemm_bitmask_ok(x.shape[0], W1.shape[0], D, x1.dtype, x1.dtype)) else None
     z = None
+    # the feed-forward block in ONE launch (emo_hip.h: emo_ffn_fwd, r06): LayerNorm1 in registers, the hidden chunk handed from the FFN1 accumulators
+    # straight into the FFN2 product, residual from the registers; f / mask / h1 / statistics are written for the backward as before
+    if (ln1_in and fmask is not None and save is not None and _os.environ.get('EMO_FFN_FUSED', '1') != '0'
+            and ops.ffn_fwd_ok(x.shape[0], D, W1.shape[0], x1.dtype)):
+        f, h1, m1, r1, fmask, x2 = ops.ffn_fwd(x1, ps.f32(pfx + 'norm1.weight'), ps.f32(pfx + 'norm1.bias'), W1, ps.f32(pfx + 'linear1.bias'),
+                                               ps.w(pfx + 'linear2.weight'), ps.f32(pfx + 'linear2.bias'), p_drop=p, seed=seed, offset_f=off + 2, offset_y=off + 3)
+        if defer_norm2:
+            out, m2, r2 = x2, None, None
+        else:
+            out, m2, r2 = ops.layernorm_fwd(x2, ps.f32(pfx + 'norm2.weight'), ps.f32(pfx + 'norm2.bias'))
+        save.t = dict(x=x, qkv=qkv, attn=attn, den=den, x1=x1, m1=m1, r1=r1, h1=h1, f=f, fmask=fmask, z=z, x2=x2, m2=m2, r2=r2, omega=omega, fws=fws)
+        return out
     chf = int(_os.environ.get('EMO_FFN_CHUNK_F', 0))
     if ln1_in and chf and x.shape[0] > chf and x.shape[0] % chf == 0:      # PROBE: FFN1 -> FFN2 per row chunk (the hidden chunk stays in the Infinity Cache)
         M_ = x.shape[0]

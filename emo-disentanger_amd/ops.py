@@ -16,7 +16,7 @@ from ._lib import (ACT_GELU, ACT_GELU_NEW, ACT_NONE, ACT_RELU, BF16, F32, MUL_BI
 __all__ = ['gemm', 'colsum', 'embed_fwd', 'embed_bwd', 'layernorm_fwd', 'layernorm_bwd', 'dropout_apply', 'favor_attn_fwd',
            'favor_attn_bwd', 'favor_decode_step', 'performer_decode_step', 'performer_decode_step_sampled', 'favor_draw_omega', 'softmax_attn_fwd', 'softmax_attn_bwd', 'softmax_attn_decode', 'relpos_attn_fwd', 'relpos_attn_bwd', 'relpos_attn_decode', 'xent_fwd',
            'xent_bwd', 'argmax', 'sample_nucleus', 'sample_nucleus_step', 'accuracy_counts', 'sumsq', 'clip_coef', 'adam_step', 'cast', 'add_bias2',
-           'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'ACT_GELU', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW', 'MUL_DGELU', 'MUL_BITMASK', 'gemm_bitmask_ok', 'gemm_lna_ok', 'bitmask_rows', 'favor_bwd_dn_ok']
+           'ACT_NONE', 'ACT_RELU', 'ACT_GELU_NEW', 'ACT_GELU', 'MUL_NONE', 'MUL_NONZERO', 'MUL_DGELU_NEW', 'MUL_DGELU', 'MUL_BITMASK', 'gemm_bitmask_ok', 'gemm_lna_ok', 'bitmask_rows', 'favor_bwd_dn_ok', 'ffn_fwd', 'ffn_fwd_ok']
 
 
 def _c(t):
@@ -181,6 +181,29 @@ def bitmask_rows(mask, M, N):
     """Row-major view [M, N/8] (byte (m, n/8), bit j = column 8 (n/8) + j) of a mask in emo_gemm's tiled layout (emo_hip.h: mask_out) — tests / diagnostics."""
     t = mask.reshape(M // 32, N // 64, 4, 16, 2, 2)           # [row panel, column tile, g = column group, r = row % 16, i = row / 16, h = column / 32]
     return t.permute(0, 4, 3, 1, 5, 2).reshape(M, N // 8)
+
+
+def ffn_fwd_ok(M, d_model, d_ff, dtype):
+    """True when ffn_fwd serves the problem (emo_hip.h: emo_ffn_fwd — the feed-forward block in one launch)."""
+    return dtype == torch.bfloat16 and bool(lib.emo_ffn_fwd_supported(dtype_code(dtype), M, d_model, d_ff))
+
+
+def ffn_fwd(x1, gamma, beta, W1, b1, W2, b2, p_drop=0.0, seed=0, offset_f=0, offset_y=0, eps=1e-5):
+    """(f, h1, mean, rstd, mask, x2) of the fused feed-forward block: h1 = LN(x1), f = drop(relu(h1 W1^T + b1)), x2 = h1 + drop(f W2^T + b2)."""
+    M, D = x1.shape
+    Hd = W1.shape[0]
+    assert x1.is_contiguous() and W1.is_contiguous() and W2.is_contiguous() and W1.shape == (Hd, D) and W2.shape == (D, Hd)
+    assert b1.dtype == torch.float32 and b2.dtype == torch.float32 and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    dev, dt = x1.device, x1.dtype
+    h1, x2 = torch.empty_like(x1), torch.empty_like(x1)
+    f = torch.empty(M, Hd, device=dev, dtype=dt)
+    mean, rstd = torch.empty(M, device=dev, dtype=torch.float32), torch.empty(M, device=dev, dtype=torch.float32)
+    mask = torch.empty(M, Hd // 8, device=dev, dtype=torch.uint8)
+    flops, nbytes = 2.0 * 2.0 * M * D * Hd, (3.0 * M * D + M * Hd) * x1.element_size() + M * Hd / 8
+    with _timed('ffn_fused_fwd', flops, nbytes):
+        check(lib.emo_ffn_fwd(ptr(x1), ptr(gamma), ptr(beta), eps, ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(h1), ptr(mean), ptr(rstd), ptr(f), ptr(mask),
+                              ptr(x2), M, D, Hd, dtype_code(dt), p_drop, seed, offset_f, offset_y, stream()))
+    return f, h1, mean, rstd, mask, x2
 
 
 def colsum(X, out=None, accumulate=False):

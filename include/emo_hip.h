@@ -124,6 +124,23 @@ int emo_gemm(const void* A, int a_trans, int64_t lda, const void* B, int b_trans
              int dtype_in, int dtype_out, int accumulate /* C += result; fp32 out only */,
              const emo_epilogue_t* epi /* may be NULL */, emo_stream_t stream);
 
+/* ------------------------------------------------------------------ K7f: the feed-forward block in one launch (r06)
+ *   h1 = LayerNorm(x1) * gamma + beta;  f = dropout(relu(h1 W1^T + b1));  x2 = h1 + dropout(f W2^T + b2)
+ * Replaces `norm1 -> linear1 -> activation -> dropout -> linear2 -> dropout -> + residual` of fast-transformers' TransformerEncoderLayer.forward
+ * as called from model/fast_transformer_decoder.py:45-51 (two emo_gemm launches until r05).  W1 [d_ff, d_model], W2 [d_model, d_ff] are the
+ * nn.Linear weights (bf16 mirrors, k-contiguous rows), b1 / b2 fp32.  Outputs: h1_out [M, d_model] (the residual; operand of the FFN1 weight gradient),
+ * mean_out / rstd_out [M] (LayerNorm backward), f_out [M, d_ff] (operand of the FFN2 weight gradient), mask_out (M * d_ff / 8 bytes: the 1-bit
+ * relu.dropout mask in emo_epilogue_t.mask_out's tiled layout, read back by EMO_MUL_BITMASK in the FFN2 dgrad), x2_out [M, d_model].  The hidden
+ * activation is written once and never re-read in the forward; the residual never leaves the registers.  Dropout element indices as in emo_gemm:
+ * (seed, offset_f, m * d_ff + n) for f and (seed, offset_y, m * d_model + n) for the FFN2 output — results are bit-identical to the two-launch
+ * form.  Served for bf16, d_model 512, d_ff 2048, M % 128 == 0, M >= 32768 (emo_ffn_fwd_supported() = 1); EMO_ERR_INVALID elsewhere. */
+int emo_ffn_fwd_supported(int dtype, int64_t M, int64_t d_model, int64_t d_ff);
+int emo_ffn_fwd(const void* x1, const float* gamma, const float* beta, float ln_eps, const void* W1,
+                const float* b1, const void* W2, const float* b2, void* h1_out, float* mean_out,
+                float* rstd_out, void* f_out, uint8_t* mask_out, void* x2_out, int64_t M, int64_t d_model,
+                int64_t d_ff, int dtype, float p_drop, uint64_t seed, uint64_t offset_f, uint64_t offset_y,
+                emo_stream_t stream);
+
 /* out[n] (+)= sum_m X[m,n] — bias gradients */
 int emo_colsum(const void* X, int dtype, int64_t M, int64_t N, int64_t ld, float* out,
                int accumulate, emo_stream_t stream);

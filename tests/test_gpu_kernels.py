@@ -1276,6 +1276,34 @@ def test_gemm_layernorm_of_the_a_operand_rows_with_a_large_mean():
     assert float((h.float() - h_ref.float()).abs().max()) <= 2 ** -6 * float(h_ref.float().abs().max())
 
 
+@pytest.mark.parametrize('M,p', [(32768, 0.0), (32768, 0.1), (65536, 0.1)])
+def test_fused_feed_forward_block_equals_the_two_launch_form(M, p):
+    # emo_ffn_fwd (r06): LN1 -> FFN1 -> relu -> dropout -> FFN2 -> dropout -> + residual in one launch.  Every output — normalised rows, statistics,
+    # hidden activation, 1-bit mask, x2 — against the two emo_gemm launches it replaces (same products in the same order, same dropout hashes:
+    # bit-identical), and x2 against fp64 at p = 0.
+    ops = _ops()
+    D, Hd = 512, 2048
+    assert ops.ffn_fwd_ok(M, D, Hd, torch.bfloat16)
+    x1 = (_r(M, D, seed=1) * 1.3 + 0.2).to(torch.bfloat16).cuda()
+    W1, W2 = _r(Hd, D, seed=2, scale=0.05).to(torch.bfloat16).cuda(), _r(D, Hd, seed=3, scale=0.03).to(torch.bfloat16).cuda()
+    b1, b2 = _r(Hd, seed=4, scale=0.1).cuda(), _r(D, seed=5, scale=0.1).cuda()
+    g, b = (1.0 + 0.1 * _r(D, seed=6)).cuda(), (0.1 * _r(D, seed=7)).cuda()
+    f, h1, mean, rstd, mask, x2 = ops.ffn_fwd(x1, g, b, W1, b1, W2, b2, p_drop=p, seed=11, offset_f=5, offset_y=6)
+    mask0 = torch.empty(M, Hd // 8, device='cuda', dtype=torch.uint8)
+    f0, h0, m0, r0 = ops.gemm(x1, W1, bias=b1, act=ops.ACT_RELU, p_drop=p, seed=11, offset=5, mask_out=mask0, lna=(g, b, 1e-5))
+    x20 = ops.gemm(f0, W2, bias=b2, p_drop=p, seed=11, offset=6, residual=h0)
+    assert torch.equal(h1, h0) and torch.equal(mean, m0) and torch.equal(rstd, r0)
+    assert torch.equal(f, f0) and torch.equal(mask, mask0)
+    assert torch.equal(x2, x20), float((x2.float() - x20.float()).abs().max())
+    if p == 0.0:
+        rows = slice(M - 2048, M)
+        hd = h1[rows].double()
+        ref = hd + (torch.relu(hd @ W1.double().T + b1.double()).to(torch.bfloat16).double() @ W2.double().T + b2.double())
+        _close(x2[rows], ref, torch.bfloat16, mult=1.0)
+    f2, _, _, _, _, x22 = ops.ffn_fwd(x1, g, b, W1, b1, W2, b2, p_drop=p, seed=11, offset_f=5, offset_y=6)
+    assert torch.equal(f, f2) and torch.equal(x2, x22)
+
+
 def test_stream_wait_orders_a_side_stream_launch_behind_the_main_stream():
     # emo_stream_wait (fork / join of the weight-gradient stream without torch Stream contexts) + ops.gemm(stream=raw handle): a product launched
     # on a second stream must see operands that the main stream is still producing when the launch is queued, and the main stream must see its
