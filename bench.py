@@ -184,7 +184,8 @@ def dominant_kernel_roofline(step_fn, B, T, n_steps=2):
     return roof
 
 
-ATTN_KERNELS = {'favor_fwd': ('favor_fs_fwd_kernel (bf16 slice kernel; generic: favor_fwd_kernel)', 'hbm', 'FAVOR+ causal linear attention forward: features + chunked prefix-sum scan; bytes = q, k, v read + out written (4*512*e per token*layer)'),
+ATTN_KERNELS = {'ffn_fused_fwd': ('ffn_fused_fwd_kernel (LayerNorm1 -> FFN1 -> ReLU -> dropout -> FFN2 -> dropout -> + residual in one launch; one workgroup per CU, hidden chunk handed from the FFN1 accumulators into the FFN2 MFMAs)', 'mfma', 'the feed-forward block of a layer, forward: 2 x 2 M 512 2048 flop; bytes = x1 read + h1, f, mask, x2 written'),
+                'favor_fwd': ('favor_fs_fwd_kernel (bf16 slice kernel; generic: favor_fwd_kernel)', 'hbm', 'FAVOR+ causal linear attention forward: features + chunked prefix-sum scan; bytes = q, k, v read + out written (4*512*e per token*layer)'),
                 'favor_bwd': ('favor_fs_dq_kernel + favor_fs_dkv_kernel (bf16 slice kernels; generic: favor_bwd_dq_kernel / favor_bwd_dkv_kernel)', 'hbm', 'FAVOR+ backward (forward sweep dq, reverse sweep dk/dv); bytes = 7*512*e per token*layer'),
                 'sattn_fwd': ('sattn32_fwd_kernel (32x32x16 tiles; generic: sattn_fwd_kernel)', 'mfma', 'GPT-2 causal softmax attention forward (flash tiles): 2 matmuls, causal half'),
                 'sattn_bwd': ('sattn32_dq_kernel + sattn32_dkv_kernel (32x32x16 tiles, dropout keep bits from the forward; generic: sattn_bwd_dq_kernel + sattn_bwd_dkv_kernel)', 'mfma', 'GPT-2 attention backward: 7 matmuls, causal half')}

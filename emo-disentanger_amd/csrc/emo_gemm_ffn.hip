@@ -26,6 +26,12 @@
 namespace {
 constexpr int FF_D = 512, FF_H = 2048, FF_BM = 128, FF_STAGE = 16384, FF_SLOTS = 8, FF_RING = FF_SLOTS * FF_STAGE;
 constexpr int FF_NCH = FF_H / 64;                              // 32 hidden chunks
+#ifndef FF_ABL
+#define FF_ABL 0                                               // timing ablations (wrong results): 1 no chunk-epilogue math / stores, 2 no phase-2 MFMAs, 3 no MFMAs, 4 no f / mask stores
+#endif
+#ifndef FF_PF
+#define FF_PF 2                                                // fragment prefetch distance in sub-steps
+#endif
 
 __device__ __forceinline__ int ff_swz1(int row) { return (row & 3) | ((row >> 1) & 12); }          // phase-1 image (256-B rows): gemm_astat_kernel's map
 __device__ __forceinline__ int ff_nrow(int f, int i) { return 32 * (f >> 1) + 8 * (i >> 2) + 4 * (f & 1) + (i & 3); }
@@ -65,6 +71,13 @@ __device__ __forceinline__ void ff_drop8(const DropCtx& d, uint32_t idx0, float 
     }
 }
 
+#ifdef EMO_DIAG
+__device__ unsigned long long emo_ffn_diag[16];            // diagnostics build only (tools/ffn_cycles.py): cycle sums over all waves
+#define FFD(k) do { const uint64_t tn_ = __builtin_readcyclecounter(); tc_[k] += tn_ - ts_; ts_ = tn_; } while (0)
+#else
+#define FFD(k) do {} while (0)
+#endif
+
 struct FfnArgs {
     const bf16_t* x1; const float* gamma; const float* beta; float ln_eps;
     const bf16_t* W1; const float* b1; const bf16_t* W2; const float* b2;
@@ -80,6 +93,9 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_fwd_kernel(FfnArgs a_) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t m0 = (int64_t)blockIdx.x * FF_BM + wave * 32;
     const int g = lane >> 4, r16 = lane & 15;
+#ifdef EMO_DIAG
+    uint64_t tc_[8] = {}, ts_ = __builtin_readcyclecounter(), tstart_ = ts_;
+#endif
 
     // ---- the wave's 32 x 512 slice of x1 in MFMA operand layout (lane: row lane % 16 (+ 16 i), 8 consecutive k at 32 ks + 8 (lane / 16))
     bf16x8 a[2][16];
@@ -202,6 +218,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_fwd_kernel(FfnArgs a_) {
         }
     }
     // (gamma / beta in slot 7 are dead from here; the first refill of slot 7 comes behind the first barrier of the loop)
+    FFD(0);                                                       // prologue: A panel, LayerNorm, first stages
     f32x4 acc2[2][32];                                            // the 32 x 512 output tile: column tile t = j / 4 ... see the final epilogue
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -211,6 +228,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_fwd_kernel(FfnArgs a_) {
     bf16x8 hcb[2][2];                                             // the chunk's 32 x 64 hidden tile as phase-2 operand: [row fragment][k-step]
     frags(0, 0, bq[0]);
     frags(0, 1, bq[1]);
+    if (FF_PF == 3) frags(0, 2, bq[2]);
     const int ecol = 8 * g;
     const uint32_t foff0 = (uint32_t)(r16 * FF_H + ecol);          // element offset of (row lane % 16, column 8 g) in an [.., 2048] row-major tensor
     for (int c = 0; c < FF_NCH; ++c) {
@@ -224,6 +242,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_fwd_kernel(FfnArgs a_) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (j == 4) {
+                FFD(1);                                           // phase 1 of the chunk (incl. its waits)
                 // ---- the chunk's hidden tile: ReLU, dropout, mask bits, one rounding to bf16, store — and hand-over to phase 2
                 ff_drain();
                 uint32_t mask_word = 0;
@@ -234,6 +253,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_fwd_kernel(FfnArgs a_) {
                     for (int h = 0; h < 2; ++h) {
                         float v[8] = {acc1[i][2 * h][0], acc1[i][2 * h][1], acc1[i][2 * h][2], acc1[i][2 * h][3],
                                       acc1[i][2 * h + 1][0], acc1[i][2 * h + 1][1], acc1[i][2 * h + 1][2], acc1[i][2 * h + 1][3]};
+                        if (FF_ABL != 1) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v[e]), 0));
                         if (a_.drop_f.thr16) ff_drop8(a_.drop_f, (uint32_t)((m0 + 16 * i) * FF_H + c * 64 + 32 * h) + foff0, v);
@@ -241,44 +261,64 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_fwd_kernel(FfnArgs a_) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) bits |= (v[e] != 0.f ? 1u : 0u) << e;
                         mask_word |= bits << (8 * (2 * i + h));
+                        }
                         bf16x8 o;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
                         hcb[i][h] = o;
                         const uint32_t bo = (foff0 + (uint32_t)(16 * i * FF_H + 32 * h)) * 2;
+                        if (FF_ABL != 1 && FF_ABL != 4) {
                         if (a_.nt_store) ff_store16_nt(fb, bo, __builtin_bit_cast(u32x4, o));
                         else ff_store16(fb, bo, __builtin_bit_cast(u32x4, o));
+                        }
                     }
-                ff_store4(a_.mask + ((m0 >> 5) * (int64_t)FF_NCH + c) * 256, (uint32_t)lane * 4, mask_word);
+                if (FF_ABL != 1 && FF_ABL != 4) ff_store4(a_.mask + ((m0 >> 5) * (int64_t)FF_NCH + c) * 256, (uint32_t)lane * 4, mask_word);
                 frags(4, 0, bq[0]);
                 frags(4, 1, bq[1]);
+                if (FF_PF == 3) frags(4, 2, bq[2]);
                 asm volatile("s_nop 4" ::: "memory");             // VALU-written operands ahead of an MFMA the hazard recogniser cannot see
+                FFD(2);                                           // chunk epilogue
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (u == 2) {
+#ifdef EMO_DIAG
+                    const uint64_t tw0_ = __builtin_readcyclecounter();
+#endif
                     ff_wait<20>();                                // stage s + 1 landed; stages s + 2 .. s + 6 (20 DMA operations) may stay in flight
+#ifdef EMO_DIAG
+                    const uint64_t tw1_ = __builtin_readcyclecounter();
+                    tc_[4] += tw1_ - tw0_;
+#endif
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
+#ifdef EMO_DIAG
+                    tc_[5] += __builtin_readcyclecounter() - tw1_;
+#endif
                     if (j == 0) issue(c, 7); else issue(c + 1, j - 1);   // refill the slot of stage s - 1 with stage s + 7
                 }
-                if (!(j == 3 && u >= 2)) {                        // (nothing is prefetched across the chunk epilogue: register peak)
-                    const int g2 = j * 4 + u + 2;                 // sub-step to prefetch (32, 33 = the next chunk's 0, 1)
+                if (!(j == 3 && u + FF_PF >= 4)) {                // (nothing is prefetched across the chunk epilogue: register peak)
+                    const int g2 = j * 4 + u + FF_PF;             // sub-step to prefetch (32 .. = the next chunk's 0 ..)
                     frags((g2 >> 2) & 7, g2 & 3, bq[g2 & 3]);
                 }
                 if (j < 4) {
+                    if (FF_ABL != 3) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int f = 0; f < 4; ++f) ff_mma_v(acc1[i][f], bq[u][f], a[i][j * 4 + u]);
+                    } else asm volatile("" :: "v"(bq[u][0]), "v"(bq[u][1]), "v"(bq[u][2]), "v"(bq[u][3]));
                 } else {
+                    if (FF_ABL != 2 && FF_ABL != 3) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int f = 0; f < 4; ++f) ff_mma_a(acc2[i][(j - 4) * 8 + (u >> 1) * 4 + f], bq[u][f], hcb[i][u & 1]);
+                    } else asm volatile("" :: "v"(bq[u][0]), "v"(bq[u][1]), "v"(bq[u][2]), "v"(bq[u][3]), "v"(hcb[0][0]), "v"(hcb[0][1]), "v"(hcb[1][0]), "v"(hcb[1][1]));
                 }
             }
         }
+        FFD(3);                                                   // phase 2 of the chunk
     }
     ff_drain();
     ff_wait<0>();                                                 // the run-ahead refills past the last stage must land before the LDS is released
@@ -303,8 +343,24 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_fwd_kernel(FfnArgs a_) {
                 for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(v[e] + (float)res[e]);
                 ff_store16(xb, (xoff0 + (uint32_t)(16 * i * FF_D + 64 * T + 32 * h)) * 2, __builtin_bit_cast(u32x4, o));
             }
+#ifdef EMO_DIAG
+    FFD(6);                                                       // final epilogue
+    if (lane == 0) {
+        for (int k_ = 0; k_ < 7; ++k_) atomicAdd(&emo_ffn_diag[k_], (unsigned long long)tc_[k_]);
+        atomicAdd(&emo_ffn_diag[14], (unsigned long long)(__builtin_readcyclecounter() - tstart_));
+        atomicAdd(&emo_ffn_diag[15], 1ull);
+    }
+#endif
 }
 }  // namespace
+
+#ifdef EMO_DIAG
+extern "C" int emo_ffn_diag_fetch(unsigned long long* host, int reset) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(emo_ffn_diag), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(emo_ffn_diag), z, sizeof(z)); }
+    return 0;
+}
+#endif
 
 extern "C" int emo_ffn_fwd_supported(int dtype, int64_t M, int64_t d_model, int64_t d_ff) {
     const char* e = getenv("EMO_FFN_FUSED");
