@@ -61,6 +61,10 @@ _SIG = {
     'emo_performer_decode_step': (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_f, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_l, c_p, c_l, c_f, c_f, c_p, c_p]),
     'emo_performer_decode_step_sampled': (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_f, c_l, c_p, c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_l, c_l, c_p, c_l, c_f, c_f,
                                                 c_f, c_f, c_p, c_p, c_p, c_l, c_l, c_p, c_p]),
+    'emo_gpt2_decode_step_supported': (c_i, []),
+    'emo_gpt2_decode_step': (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_f, c_l, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_p, c_l, c_f, c_p, c_p]),
+    'emo_gpt2_decode_step_sampled': (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_f, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_l, c_p, c_l, c_f,
+                                           c_f, c_f, c_p, c_p, c_p, c_l, c_l, c_p, c_p]),
     'emo_favor_draw_omega': (c_i, [c_p, c_p, c_l, c_l, c_l, c_p]),
     'emo_softmax_attn_fwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p]),
     'emo_softmax_attn_bwd': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_f, c_u64, c_u64, c_p]),

@@ -78,6 +78,8 @@ struct PdArgs {
     // logits) exactly as emo_sample_nucleus_step does, writes it to tok_out / seq and hands it to the group through 4 granules; tok is ignored
     int samp_mode; float temp, top_p; const float* u_steps; int64_t* step; int64_t* seq; int64_t ld_seq, col0; int64_t* tok_out; const float* logits_in; int n_real;
     int flags;      // bit 0: non-temporal weight loads
+    // GPT-2 form (pd_step_kernel<true>): [gamma | beta] of layer 0's ln_1, rows per (stream, head) of the head-major KV caches the table's S / z slots point to
+    const float* ln0; int64_t kv_tmax;
     u64* diag;      // optional [32 members][16 layers][8 phases][4]: {t_start, t_gathered, t_published, failed poll passes} of GROUP 0, 10-ns ticks (tools/pd_diag.py)
 };
 // t = thread index INSIDE the role (0..255), hw = wave inside the role (0..3)
@@ -88,7 +90,9 @@ struct PdCtx { int t, lane, hw; long long t0; gu64* err; bool local; };
 constexpr int LDS_XIN = 0, LDS_XA = LDS_XIN + PD_GS * PD_XS * 2, LDS_X1 = LDS_XA + PD_GS * PD_XS * 2, LDS_FH = LDS_X1 + PD_GS * PD_XS * 2,
               LDS_PART = LDS_FH + PD_GS * PD_FS * 2, LDS_ATT = LDS_PART + PD_HW * 4 * 64 * 4,
               LDS_LN = LDS_ATT + (3 * PD_DH + 2 * PD_F + 8 + PD_HW * PD_DH + 2 * 2 * 64 + 8) * 4, LDS_MISC = LDS_LN + 2 * 2 * PD_D * 4, LDS_OM = LDS_MISC + 64,
-              LDS_SAMP = LDS_OM + PD_DH * PD_MF * 4, LDS_TOTAL = LDS_SAMP + EMO_NUCLEUS_LDS;
+              LDS_SAMP = LDS_OM + PD_DH * PD_MF * 4, LDS_TOTAL = LDS_SAMP + EMO_NUCLEUS_LDS,
+              LDS_XRAW = LDS_SAMP, LDS_HRAW = LDS_XRAW + PD_GS * PD_XS * 2;      // GPT-2 form: pre-LN rows (the residuals); the draw's scratch is free after barrier Bt
+static_assert(LDS_HRAW + PD_GS * PD_XS * 2 <= LDS_TOTAL, "LDS carve");
 extern __shared__ __attribute__((aligned(16))) char pd_smem[];
 #define PD_SERR (*(int*)(pd_smem + LDS_MISC))
 
@@ -257,12 +261,12 @@ __device__ __forceinline__ float pd_wave_sum(float v) {
     v = pd_dpp_add(v, 3);
     return rows4_sum(v);
 }
-// POLLERS: LayerNorm of LDS row `hw` (the row this poller wave gathered itself), in place, gamma / beta from LDS (ln = [gamma 512 | beta 512]);
+// POLLERS: LayerNorm of LDS row `hw` of src (the row this poller wave gathered itself) into row `hw` of xs (Performer: in place), gamma / beta from LDS (ln = [gamma 512 | beta 512]);
 // the arithmetic of layernorm_fwd_bf16_d512_kernel
-__device__ __forceinline__ void pd_ln_row(bf16_t* xs, const float* ln, float eps, const PdCtx& c) {
+__device__ __forceinline__ void pd_ln_row(const bf16_t* src, bf16_t* xs, const float* ln, float eps, const PdCtx& c) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // the wave's own row is in LDS
     bf16_t* row = xs + c.hw * PD_XS + c.lane * 8;
-    const bf16x8 a = *(const bf16x8*)row;
+    const bf16x8 a = *(const bf16x8*)(src + c.hw * PD_XS + c.lane * 8);
     float v[8], s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { v[i] = (float)a[i]; s += v[i]; }
@@ -309,6 +313,8 @@ __device__ __noinline__ int64_t pd_draw(const float* l, int n_token, float temp,
     return emo_nucleus_draw(l, n_token, temp, top_p, u, pd_smem + LDS_SAMP, tid, [] { PD_BARRIER(); });
 }
 
+// G2 = false: the Performer layer described above.  G2 = true: the GPT-2 block on the same skeleton (see the GPT-2 notes before the entry points).
+template <bool G2>
 __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
     bf16_t* xin = (bf16_t*)(pd_smem + LDS_XIN);        // layer input (post-LN2 / embedding), kept for the out-projection's residual
     bf16_t* xa = (bf16_t*)(pd_smem + LDS_XA);          // attention output rows
@@ -327,7 +333,9 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
     float* ln1 = (float*)(pd_smem + LDS_LN);           // [gamma | beta] of norm1 of the layer (written by half A before P2, read by the pollers in P4)
     float* ln2 = ln1 + 2 * PD_D;                       // norm2 (written by half A in P4, read by the pollers in the next P1 / before the logits)
     int* s_misc = (int*)(pd_smem + LDS_MISC);          // [0] error flag, [1] launch counter, [2] census: group on one XCD, [4..7] the group's tokens
-    float* oml = (float*)(pd_smem + LDS_OM);           // omega of the layer [64][64]
+    float* oml = (float*)(pd_smem + LDS_OM);           // omega of the layer [64][64]   (GPT-2: scores [<= 2048] | V partial sums [32][64])
+    bf16_t* xraw = (bf16_t*)(pd_smem + LDS_XRAW);      // GPT-2: block input before ln_1 (the attention residual)
+    bf16_t* hraw = (bf16_t*)(pd_smem + LDS_HRAW);      // GPT-2: attention output + residual before ln_2 (the MLP residual)
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), role = wave >> 2;      // 0 = A, 1 = B, 2 = pollers
     PdCtx c;
@@ -419,7 +427,11 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
                     o[4 * h2 + i] = (bf16_t)v;
                 }
             }
-            *(bf16x8*)(xin + s * PD_XS + c8) = o;
+            *(bf16x8*)((G2 ? xraw : xin) + s * PD_XS + c8) = o;
+            if constexpr (G2) {
+                if (c.lane == 0) s_misc[8 + s] = (int)pos;            // keys of the stream before this token (the row it appends)
+                pd_ln_row(xraw, xin, a.ln0, a.ln_eps, c);
+            }
         }
         if (c.hw == 0) {                                              // census: is the whole group on one XCD?
             u64 v = 0;
@@ -443,8 +455,8 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
             // ---- P1
             PD_DIAG(l, 1, 0, PD_NOW());
             if (l > 0) {
-                const unsigned sp = pd_gather_rows<PD_D>(gs + OFF_E1, ep - 8u + 5u, xin, PD_XS, c, 0x100u + l);
-                if (!PD_SERR) pd_ln_row(xin, ln2, a.ln_eps, c);
+                const unsigned sp = pd_gather_rows<PD_D>(gs + OFF_E1, ep - 8u + 5u, G2 ? xraw : xin, PD_XS, c, 0x100u + l);
+                if (!PD_SERR) pd_ln_row(G2 ? xraw : xin, xin, ln2, a.ln_eps, c);
                 PD_DIAG(l, 1, 3, sp);
             }
             PD_SYNC_OR_LEAVE();                                       // 1a: xin ready
@@ -492,9 +504,9 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
             PD_DIAG(l, 4, 0, PD_NOW());
             {
                 u64 fp = 0;
-                const unsigned sp = pd_gather_rows<PD_D>(gs + OFF_E4, ep + 3u, x1, PD_XS, c, 0x400u + l, a.diag ? &fp : nullptr);
+                const unsigned sp = pd_gather_rows<PD_D>(gs + OFF_E4, ep + 3u, G2 ? hraw : x1, PD_XS, c, 0x400u + l, a.diag ? &fp : nullptr);
                 PD_DIAG(l, 6, 1, fp);
-                if (!PD_SERR) pd_ln_row(x1, ln1, a.ln_eps, c);
+                if (!PD_SERR) pd_ln_row(G2 ? hraw : x1, x1, ln1, a.ln_eps, c);
                 PD_DIAG(l, 4, 3, sp);
             }
             PD_SYNC_OR_LEAVE();                                       // 4a
@@ -514,7 +526,9 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
         }
         if (!has_logits) return;
         pd_gather_rows<PD_D>(gs + OFF_E1, ep0 + (unsigned)(L_ - 1) * 8u + 5u, xin, PD_XS, c, 0x600u);
-        if (!PD_SERR) pd_ln_row(xin, ln2, a.ln_eps, c);
+        if constexpr (!G2) {                                          // (this GPT-2 has no ln_f: the logits take the last block's output)
+            if (!PD_SERR) pd_ln_row(xin, xin, ln2, a.ln_eps, c);
+        }
         PD_SYNC_OR_LEAVE();                                           // Fa
         PD_BARRIER();                                                 // Fb
         PD_DIAG(15, 0, 2, PD_NOW());
@@ -526,7 +540,7 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
         // ========================================================================================== HALF A (waves 0-3): P1 and P4 products
         bf16x8 wq[3][4], w1[4][4];
         float bq[3], b1[4];
-        f32x4 lnv, ln1v, om[4];
+        f32x4 lnv, ln1v, om[4] = {};
         // operand set of P1 (+ what half A hands to the others through LDS before P2: omega for half B, LayerNorm1's parameters for the pollers)
 #define PD_LOAD_A0(Lp)                                                                                     \
     do {                                                                                                   \
@@ -536,7 +550,7 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
 #define PD_LOAD_A1(Lp)                                                                                     \
     do {                                                                                                   \
         pd_load_w_part<3, 4, 4, 8>(wq, (Lp).wqkv + (size_t)m * (PD_HW * 3 * 4 * 512), cc, nt);               \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) om[i] = *(const f32x4*)((Lp).omega + cc.t * 16 + 4 * i); \
+        if constexpr (!G2) { _Pragma("unroll") for (int i = 0; i < 4; ++i) om[i] = *(const f32x4*)((Lp).omega + cc.t * 16 + 4 * i); } \
     } while (0)
 #define PD_LOAD_A2(Lp)                                                                                     \
     do {                                                                                                   \
@@ -573,8 +587,10 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
                 pd_publish_pair(gs + OFF_E2, ((hm * PD_GS + s) * 3 + t) * 32 + ((jm * 16 + col) >> 1), ep + 1u, pd_part_sum<3>(part, t, s, col), col, cc);
             }
             PD_DIAG(l, 1, 2, PD_NOW());
+            if constexpr (!G2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *(f32x4*)(oml + cc.t * 16 + 4 * i) = om[i];       // omega [64 d][64 m] of the layer for half B
+                for (int i = 0; i < 4; ++i) *(f32x4*)(oml + cc.t * 16 + 4 * i) = om[i];   // omega [64 d][64 m] of the layer for half B
+            }
             *(f32x4*)(ln1 + cc.t * 4) = ln1v;                          // [gamma | beta]: threads 0..127 gamma, 128..255 beta
             PD_SCHED_FENCE();
             // (requested AFTER the publish: a 64-KB burst in front of it held the partial sums back by ~2 us — the issue itself stalls on the full queue)
@@ -605,7 +621,8 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
             PD_BARRIER();                                             // 4b
             {
                 const int t = cc.t >> 6, s = (cc.t >> 4) & 3, col = cc.t & 15, gc = m * 64 + t * 16 + col;
-                pd_publish_pair(gs + OFF_E5, s * (PD_FF / 2) + (gc >> 1), ep + 4u, fmaxf(pd_part_sum<4>(part, t, s, col), 0.f), col, cc);
+                const float hv = pd_part_sum<4>(part, t, s, col);
+                pd_publish_pair(gs + OFF_E5, s * (PD_FF / 2) + (gc >> 1), ep + 4u, G2 ? gelu_new_fast(hv) : fmaxf(hv, 0.f), col, cc);
             }
             PD_DIAG(l, 4, 2, PD_NOW());
             PD_SCHED_FENCE();
@@ -661,16 +678,18 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
     {
         bf16x8 wo[1][4], w2[1][16];
         float bo[1], b2[1];
-        f32x4 st[8];
+        f32x4 st[8] = {};
         float zold = 0.f;
         const int64_t sh = ((int64_t)g * PD_GS + jm) * PD_H + hm;     // (stream, head) of this member
 #define PD_LOAD_B(Lp)                                                                                      \
     do {                                                                                                   \
         pd_load_w<1, 4>(wo, (Lp).wo + (size_t)m * (PD_HW * 1 * 4 * 512), cc, nt);                           \
         bo[0] = (Lp).bo[m * 16 + lc16];                                                                    \
-        const float* Sb_ = (Lp).S + sh * (PD_F * PD_DH);                                                   \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) st[i] = *(const f32x4*)(Sb_ + (fg + 16 * i) * PD_DH + d4); \
-        if (cc.t < PD_F) zold = (Lp).z[sh * PD_F + cc.t];                                                  \
+        if constexpr (!G2) {                                                                               \
+            const float* Sb_ = (Lp).S + sh * (PD_F * PD_DH);                                               \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) st[i] = *(const f32x4*)(Sb_ + (fg + 16 * i) * PD_DH + d4); \
+            if (cc.t < PD_F) zold = (Lp).z[sh * PD_F + cc.t];                                              \
+        }                                                                                                  \
     } while (0)
         {
             const PdCtx cc = c;
@@ -686,73 +705,162 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
             const bool last = l + 1 == L_;
             const unsigned ep = ep0 + (unsigned)l * 8u;
             float* Sb = L.S + sh * (PD_F * PD_DH);
+            const int64_t sh_kv = sh;
             PdCtx cc = pd_fresh(c);
             cc.local = c.local;
             const int lc16 = cc.lane & 15, d4 = (cc.t & 15) * 4, fg = cc.t >> 4;      // state mapping: 16 threads per state row, 16 rows per pass, 8 passes
             PD_SYNC_OR_LEAVE();                                       // 1a
-            if (l > 0) {                                              // (layer 0's slice was requested before the loop)
+            if (!G2 && l > 0) {                                       // (layer 0's slice was requested before the loop)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) st[i] = *(const f32x4*)(Sb + (fg + 16 * i) * PD_DH + d4);
             }
             PD_BARRIER();                                             // 1b
-            if (l > 0) {
+            if (!G2 && l > 0) {
 #pragma unroll
                 for (int i = 4; i < 8; ++i) st[i] = *(const f32x4*)(Sb + (fg + 16 * i) * PD_DH + d4);
                 if (cc.t < PD_F) zold = L.z[sh * PD_F + cc.t];
             }
             // ---- P2: the recurrent step
             PD_SYNC_OR_LEAVE();                                       // 2a: q | k | v rows (poller wave 0) and omega (half A) staged
-            {   // projections: thread = (d-half, q | k, projection): 32 of the 64 terms each
-                const int col = cc.t & 63, which = (cc.t >> 6) & 1, hd = cc.t >> 7;
-                const float* xx = which ? xk : xq;
-                float u = 0.f, nn = 0.f;
+            if constexpr (G2) {
+                // softmax attention of (head hm, stream jm) over the stream's cached keys + the row this token appends (the arithmetic of
+                // sattn_decode_kernel): thread = (key row of a 32-row pass, 8 of the 64 dims); scores and the 32 partial V sums live in the omega region
+                const int kprev = s_misc[8 + jm];                     // cached rows; the new row has index kprev
+                bf16_t* Kc = (bf16_t*)L.S + (sh_kv * a.kv_tmax) * PD_DH;
+                bf16_t* Vc = (bf16_t*)L.z + (sh_kv * a.kv_tmax) * PD_DH;
+                float* sc = oml;
+                float* vp = oml + 2048;
+                const int rl = cc.t >> 3, c8 = (cc.t & 7) * 8;
+                bf16x8 kn, vn;
+                float qv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { qv[e] = xq[c8 + e]; kn[e] = (bf16_t)xk[c8 + e]; vn[e] = (bf16_t)xv[c8 + e]; }
+                if (cc.t < 8) {
+                    *(bf16x8*)(Kc + (int64_t)kprev * PD_DH + c8) = kn;
+                    *(bf16x8*)(Vc + (int64_t)kprev * PD_DH + c8) = vn;
+                }
+                const int last_c = kprev > 0 ? kprev - 1 : 0;         // rows past the cache: any valid address, the value is replaced / masked
+                float mx = -3.0e38f;
+                for (int j0 = 0; j0 <= kprev; j0 += 32 * 8) {
+                    bf16x8 kr[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = j0 + u * 32 + rl;
+                        kr[u] = *(const bf16x8*)(Kc + (int64_t)(j < kprev ? j : last_c) * PD_DH + c8);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = j0 + u * 32 + rl;
+                        const bf16x8 kk = j == kprev ? kn : kr[u];
+                        float d = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) d += qv[e] * (float)kk[e];
+                        d = pd_dpp_add(d, 0);
+                        d = pd_dpp_add(d, 1);
+                        d = pd_dpp_add(d, 2);
+                        d *= 0.125f;
+                        if (j <= kprev) {
+                            mx = fmaxf(mx, d);
+                            if ((cc.t & 7) == 0) sc[j] = d;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                if (cc.lane == 0) dpart[cc.hw] = mx;
+                PD_BARRIER();                                         // 2b
+                mx = fmaxf(fmaxf(dpart[0], dpart[1]), fmaxf(dpart[2], dpart[3]));
+                float sum = 0.f;
+                for (int j = cc.t; j <= kprev; j += PD_HT) {
+                    const float pj = __expf(sc[j] - mx);
+                    sc[j] = pj;
+                    sum += pj;
+                }
+                sum = pd_wave_sum(sum);
+                if (cc.lane == 0) npart[cc.hw] = sum;
+                PD_BARRIER();                                         // 2c
+                float acc[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+                for (int j0 = 0; j0 <= kprev; j0 += 32 * 8) {
+                    bf16x8 vr[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = j0 + u * 32 + rl;
+                        vr[u] = *(const bf16x8*)(Vc + (int64_t)(j < kprev ? j : last_c) * PD_DH + c8);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = j0 + u * 32 + rl;
+                        const bf16x8 vv = j == kprev ? vn : vr[u];
+                        const float pj = j <= kprev ? sc[j] : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[e] += pj * (float)vv[e];
+                    }
+                }
+                *(f32x4*)(vp + rl * PD_DH + c8) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+                *(f32x4*)(vp + rl * PD_DH + c8 + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+                PD_BARRIER();                                         // 2d
+                if (cc.t < PD_DH) {
+                    float o = 0.f;
 #pragma unroll 8
-                for (int d = 0; d < 32; ++d) {
-                    const float xv_ = xx[hd * 32 + d];
-                    u += xv_ * oml[(hd * 32 + d) * PD_MF + col];
-                    nn += xv_ * xv_;
+                    for (int r = 0; r < 32; ++r) o += vp[r * PD_DH + cc.t];
+                    o = o / ((npart[0] + npart[1]) + (npart[2] + npart[3]));
+                    pd_publish_pair(gs + OFF_E3, jm * (PD_D / 2) + ((hm * PD_DH + cc.t) >> 1), ep + 2u, o, c.t, cc);
                 }
-                upart[(hd * 2 + which) * 64 + col] = u;
-                if (col == 0) npart[hd * 2 + which] = nn;
-            }
-            PD_BARRIER();                                             // 2b
-            const float cs = rsqrtf(sqrtf((float)PD_DH)), half_ln_f = 0.5f * logf((float)PD_F);
-            float dn = 0.f;
-            if (cc.t < PD_F) {
-                const int col = cc.t & (PD_MF - 1);
-                const float sgn = cc.t < PD_MF ? 1.f : -1.f;
-                const float uq = upart[col] + upart[128 + col], uk = upart[64 + col] + upart[192 + col];
-                const float nq = npart[0] + npart[2], nk = npart[1] + npart[3];
-                const float pq = __expf(sgn * cs * uq - (0.5f * cs * cs * nq + half_ln_f));
-                const float pk = __expf(sgn * cs * uk - (0.5f * cs * cs * nk + half_ln_f));
-                fq[cc.t] = pq;
-                fk[cc.t] = pk;
-                const float z = zold + pk;
-                L.z[sh * PD_F + cc.t] = z;
-                dn = pq * z;
-            }
-            dn = pd_wave_sum(dn);
-            if (cc.lane == 0) dpart[cc.hw] = dn;
-            PD_BARRIER();                                             // 2c
-            {
-                const f32x4 vd = {xv[d4], xv[d4 + 1], xv[d4 + 2], xv[d4 + 3]};
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int f = fg + 16 * i;
-                    const f32x4 sv = st[i] + fk[f] * vd;
-                    *(f32x4*)(Sb + f * PD_DH + d4) = sv;
-                    acc += fq[f] * sv;
+            } else {
+                {   // projections: thread = (d-half, q | k, projection): 32 of the 64 terms each
+                    const int col = cc.t & 63, which = (cc.t >> 6) & 1, hd = cc.t >> 7;
+                    const float* xx = which ? xk : xq;
+                    float u = 0.f, nn = 0.f;
+#pragma unroll 8
+                    for (int d = 0; d < 32; ++d) {
+                        const float xv_ = xx[hd * 32 + d];
+                        u += xv_ * oml[(hd * 32 + d) * PD_MF + col];
+                        nn += xv_ * xv_;
+                    }
+                    upart[(hd * 2 + which) * 64 + col] = u;
+                    if (col == 0) npart[hd * 2 + which] = nn;
                 }
+                PD_BARRIER();                                             // 2b
+                const float cs = rsqrtf(sqrtf((float)PD_DH)), half_ln_f = 0.5f * logf((float)PD_F);
+                float dn = 0.f;
+                if (cc.t < PD_F) {
+                    const int col = cc.t & (PD_MF - 1);
+                    const float sgn = cc.t < PD_MF ? 1.f : -1.f;
+                    const float uq = upart[col] + upart[128 + col], uk = upart[64 + col] + upart[192 + col];
+                    const float nq = npart[0] + npart[2], nk = npart[1] + npart[3];
+                    const float pq = __expf(sgn * cs * uq - (0.5f * cs * cs * nq + half_ln_f));
+                    const float pk = __expf(sgn * cs * uk - (0.5f * cs * cs * nk + half_ln_f));
+                    fq[cc.t] = pq;
+                    fk[cc.t] = pk;
+                    const float z = zold + pk;
+                    L.z[sh * PD_F + cc.t] = z;
+                    dn = pq * z;
+                }
+                dn = pd_wave_sum(dn);
+                if (cc.lane == 0) dpart[cc.hw] = dn;
+                PD_BARRIER();                                             // 2c
+                {
+                    const f32x4 vd = {xv[d4], xv[d4 + 1], xv[d4 + 2], xv[d4 + 3]};
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = rows4_sum(acc[i]);   // the wave's 4 rows per pass sit in lanes l, l^16, l^32, l^48
-                if (cc.lane < 16) *(f32x4*)(num + cc.hw * PD_DH + d4) = acc;
-            }
-            PD_BARRIER();                                             // 2d
-            if (cc.t < PD_DH) {
-                float o = (num[cc.t] + num[PD_DH + cc.t]) + (num[2 * PD_DH + cc.t] + num[3 * PD_DH + cc.t]);
-                o = o / (dpart[0] + dpart[1] + a.eps);                // (waves 2, 3 of the half hold no features)
-                pd_publish_pair(gs + OFF_E3, jm * (PD_D / 2) + ((hm * PD_DH + cc.t) >> 1), ep + 2u, o, c.t, cc);
+                    for (int i = 0; i < 8; ++i) {
+                        const int f = fg + 16 * i;
+                        const f32x4 sv = st[i] + fk[f] * vd;
+                        *(f32x4*)(Sb + f * PD_DH + d4) = sv;
+                        acc += fq[f] * sv;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = rows4_sum(acc[i]);   // the wave's 4 rows per pass sit in lanes l, l^16, l^32, l^48
+                    if (cc.lane < 16) *(f32x4*)(num + cc.hw * PD_DH + d4) = acc;
+                }
+                PD_BARRIER();                                             // 2d
+                if (cc.t < PD_DH) {
+                    float o = (num[cc.t] + num[PD_DH + cc.t]) + (num[2 * PD_DH + cc.t] + num[3 * PD_DH + cc.t]);
+                    o = o / (dpart[0] + dpart[1] + a.eps);                // (waves 2, 3 of the half hold no features)
+                    pd_publish_pair(gs + OFF_E3, jm * (PD_D / 2) + ((hm * PD_DH + cc.t) >> 1), ep + 2u, o, c.t, cc);
+                }
             }
             // ---- P3
             PD_SYNC_OR_LEAVE();                                       // 3a
@@ -763,7 +871,7 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
             PD_BARRIER();                                             // 3b
             if (cc.t < 64) {
                 const int s = cc.t >> 4, col = cc.t & 15, gc = m * 16 + col;
-                pd_publish_pair(gs + OFF_E4, s * (PD_D / 2) + (gc >> 1), ep + 3u, pd_part_sum<1>(part, 0, s, col) + (float)xin[s * PD_XS + gc], col, cc);
+                pd_publish_pair(gs + OFF_E4, s * (PD_D / 2) + (gc >> 1), ep + 3u, pd_part_sum<1>(part, 0, s, col) + (float)(G2 ? xraw : xin)[s * PD_XS + gc], col, cc);
             }
             PD_DIAG(l, 3, 2, PD_NOW());
             PD_SCHED_FENCE();
@@ -783,7 +891,7 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
             PD_BARRIER();                                             // 5b
             if (cc.t < 64) {
                 const int s = cc.t >> 4, col = cc.t & 15, gc = m * 16 + col;
-                pd_publish_pair(gs + OFF_E1, s * (PD_D / 2) + (gc >> 1), ep + 5u, pd_part_sum<1>(part, 0, s, col) + (float)x1[s * PD_XS + gc], col, cc);
+                pd_publish_pair(gs + OFF_E1, s * (PD_D / 2) + (gc >> 1), ep + 5u, pd_part_sum<1>(part, 0, s, col) + (float)(G2 ? hraw : x1)[s * PD_XS + gc], col, cc);
             }
             PD_DIAG(l, 5, 2, PD_NOW());
             PD_SCHED_FENCE();
@@ -811,8 +919,10 @@ static int pd_supported() {
     const size_t lds = 96 * 1024;
     int dev = 0, cus = 0, per_cu = 0;
     bool ok = hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= PD_NG * PD_GM;
-    ok = ok && hipFuncSetAttribute((const void*)pd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-    ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)pd_step_kernel, PD_NT, lds) == hipSuccess && per_cu >= 1;
+    ok = ok && hipFuncSetAttribute((const void*)pd_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)pd_step_kernel<false>, PD_NT, lds) == hipSuccess && per_cu >= 1;
+    ok = ok && hipFuncSetAttribute((const void*)pd_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)pd_step_kernel<true>, PD_NT, lds) == hipSuccess && per_cu >= 1;
     (void)hipGetLastError();
     cached = ok ? 1 : 0;
     return cached;
@@ -823,8 +933,10 @@ static int pd_launch(const void* layer_table, int64_t n_layers, const int64_t* t
                      float emb_scale, int64_t pos0, const int64_t* pos_ids, const void* wout_packed, const float* bout, int64_t n_token, float* logits,
                      int64_t n_streams, int64_t d_model, int64_t n_head, int64_t n_feat, int64_t d_ff, void* sync_ws, int64_t sync_ws_bytes, float eps,
                      float ln_eps, int64_t* diag, int samp_mode, float temperature, float top_p, const float* u_steps, int64_t* step, int64_t* seq,
-                     int64_t ld_seq, int64_t col0, int64_t* tok_out, const float* logits_in, int64_t n_real, emo_stream_t stream) {
+                     int64_t ld_seq, int64_t col0, int64_t* tok_out, const float* logits_in, int64_t n_real, emo_stream_t stream, bool g2 = false,
+                     const float* ln0 = nullptr, int64_t kv_tmax = 0) {
     EMO_CHECK(layer_table && E && pe && wout_packed && bout && logits && sync_ws, "emo_performer_decode_step: null pointer");
+    if (g2) EMO_CHECK(ln0 && kv_tmax >= 1 && kv_tmax <= 2048, "emo_gpt2_decode_step: needs layer 0's ln_1 parameters and a KV cache of <= 2048 rows per (stream, head)");
     EMO_CHECK(d_model == PD_D && n_head == PD_H && n_feat == PD_F && d_ff == PD_FF,
               "emo_performer_decode_step: built for d_model 512 / 8 heads / 128 features / d_ff 2048 (got %lld / %lld / %lld / %lld)", (long long)d_model,
               (long long)n_head, (long long)n_feat, (long long)d_ff);
@@ -846,12 +958,14 @@ static int pd_launch(const void* layer_table, int64_t n_layers, const int64_t* t
     a.sync = (u64*)sync_ws; a.eps = eps; a.ln_eps = ln_eps; a.diag = (u64*)diag;
     a.samp_mode = samp_mode; a.temp = temperature; a.top_p = top_p; a.u_steps = u_steps; a.step = step; a.seq = seq; a.ld_seq = ld_seq; a.col0 = col0;
     a.tok_out = tok_out; a.logits_in = logits_in; a.n_real = (int)n_real;
+    a.ln0 = ln0; a.kv_tmax = kv_tmax;
     { const char* e = getenv("EMO_PD_NT"); a.flags = e ? (atoi(e) & 3) : 0; }
     static_assert(LDS_TOTAL <= 96 * 1024, "LDS carve");
     const size_t lds = 96 * 1024;                                         // > half of the CU's LDS: one workgroup per CU
     EMO_CHECK(pd_supported(), "emo_performer_decode_step: this device / partition cannot hold the launch's %d workgroups at once (needs >= %d CUs with 96 KB "
               "of LDS each): use the chain of launches", PD_NG * PD_GM, PD_NG * PD_GM);
-    hipLaunchKernelGGL(pd_step_kernel, dim3(PD_NG * PD_GM), dim3(PD_NT), lds, (hipStream_t)stream, a);
+    if (g2) hipLaunchKernelGGL(pd_step_kernel<true>, dim3(PD_NG * PD_GM), dim3(PD_NT), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(pd_step_kernel<false>, dim3(PD_NG * PD_GM), dim3(PD_NT), lds, (hipStream_t)stream, a);
     EMO_LAUNCH_CHECK();
     return EMO_OK;
 }
@@ -874,4 +988,35 @@ extern "C" int emo_performer_decode_step_sampled(const void* layer_table, int64_
     return pd_launch(layer_table, n_layers, nullptr, seg, E, Sg, pe, emb_scale, pos0, nullptr, wout_packed, bout, n_token, logits, n_streams, d_model, n_head,
                      n_feat, d_ff, sync_ws, sync_ws_bytes, eps, ln_eps, nullptr, 1, temperature, top_p, u_steps, step, seq, ld_seq, col0, tok_out, logits,
                      n_real, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- GPT-2 form (r06)
+// The same launch for the GPT-2 backbone of BASELINE configs[3] (reference: stage2_accompaniment/model/music_gpt2.py -> HF GPT2Block, pre-LN,
+// gelu_new, no ln_f; the loop of stage2_accompaniment/inference.py:250-277): pd_step_kernel<true>.  Differences to the Performer layer, all inside the
+// same five edges and the same barrier sequence:
+//   * the gathered rows are the RAW residual stream; the pollers normalise them out of place (E1 -> ln_1 of the next block, E4 -> ln_2), half B adds
+//     the raw rows as residuals; layer 0's ln_1 parameters come from `ln0`, and the logits take the last block's output as it is;
+//   * P2 is softmax attention of (head, stream) over the stream's head-major KV cache [n, H, kv_tmax, 64] (bf16): the member appends the token's key /
+//     value row at index pos (= keys already cached; pos = pos0 + pos_ids[stream], or the sampler's counter) and reads the rows before it — the
+//     table's S / z slots hold the K / V cache of the layer, the omega slot is unused;
+//   * the table's g1 / be1 are ln_2 of the block, g2 / be2 are ln_1 of the NEXT block (any valid pointer for the last one); FFN activation gelu_new.
+extern "C" int emo_gpt2_decode_step_supported(void) { return pd_supported(); }
+
+extern "C" int emo_gpt2_decode_step(const void* layer_table, int64_t n_layers, const int64_t* tok, const int64_t* seg, const float* E, const float* Sg,
+                                    const float* pe, float emb_scale, int64_t pos0, const int64_t* pos_ids, const float* ln0, int64_t kv_tmax,
+                                    const void* wout_packed, const float* bout, int64_t n_token, float* logits, int64_t n_streams, int64_t d_model,
+                                    int64_t n_head, int64_t d_ff, void* sync_ws, int64_t sync_ws_bytes, float ln_eps, int64_t* diag, emo_stream_t stream) {
+    return pd_launch(layer_table, n_layers, tok, seg, E, Sg, pe, emb_scale, pos0, pos_ids, wout_packed, bout, n_token, logits, n_streams, d_model, n_head,
+                     PD_F, d_ff, sync_ws, sync_ws_bytes, 0.f, ln_eps, diag, 0, 1.f, 1.f, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, stream, true, ln0,
+                     kv_tmax);
+}
+
+extern "C" int emo_gpt2_decode_step_sampled(const void* layer_table, int64_t n_layers, const int64_t* seg, const float* E, const float* Sg, const float* pe,
+                                            float emb_scale, int64_t pos0, const float* ln0, int64_t kv_tmax, const void* wout_packed, const float* bout,
+                                            int64_t n_token, float* logits, int64_t n_streams, int64_t n_real, int64_t d_model, int64_t n_head, int64_t d_ff,
+                                            void* sync_ws, int64_t sync_ws_bytes, float ln_eps, float temperature, float top_p, const float* u_steps,
+                                            int64_t* step, int64_t* seq, int64_t ld_seq, int64_t col0, int64_t* tok_out, emo_stream_t stream) {
+    return pd_launch(layer_table, n_layers, nullptr, seg, E, Sg, pe, emb_scale, pos0, nullptr, wout_packed, bout, n_token, logits, n_streams, d_model, n_head,
+                     PD_F, d_ff, sync_ws, sync_ws_bytes, 0.f, ln_eps, nullptr, 1, temperature, top_p, u_steps, step, seq, ld_seq, col0, tok_out, logits, n_real,
+                     stream, true, ln0, kv_tmax);
 }

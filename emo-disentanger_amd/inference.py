@@ -343,15 +343,28 @@ class PerformerDecodeEngine(_EngineBase):
 class GPT2DecodeEngine(_EngineBase):
     """KV cache in HBM: per layer k,v [n, max_len, D] in the compute dtype (1.6 GB for 32 streams x 2048 x 12 layers, bf16)."""
 
-    def __init__(self, model, n_streams, max_len=max_dec_inp_len):
+    def __init__(self, model, n_streams, max_len=max_dec_inp_len, persistent=True):
         super().__init__(model, n_streams, max_len)
         D = model.d_model
+        self.n_pad = (n_streams + 3) // 4 * 4
         # head-major cache [n, H, max_len, dh] (r06; HF's own past_key_values layout): the decode attention gives one workgroup to a (stream, head),
         # whose keys are then one contiguous run instead of 128-byte pieces 1 KB apart.  EMO_KV_HEAD_MAJOR=0: [n, max_len, D] (r05, same-box A/B)
         self.head_major = os.environ.get('EMO_KV_HEAD_MAJOR', '1') != '0'
-        shp = (n_streams, model.n_head, max_len, D // model.n_head) if self.head_major else (n_streams, max_len, D)
-        self.kc = [torch.zeros(*shp, device=self.dev, dtype=self.dt) for _ in range(model.n_layer)]
-        self.vc = [torch.zeros(*shp, device=self.dev, dtype=self.dt) for _ in range(model.n_layer)]
+        # the whole token step as ONE persistent launch (emo_gpt2_decode_step; r06), under the conditions of the Performer engine's: bf16, d_model 512,
+        # 8 heads, d_ff 2048, <= 32 streams (padded to a multiple of 4 with idle streams), head-major cache of <= 2048 rows.  EMO_DECODE_PERSISTENT=0 /
+        # EMO_GPT2_PERSISTENT=0 keep the chain of launches (tests compare the two).
+        ff = self.ps.f32(model._layer_prefix(0) + 'mlp.c_fc.bias').numel()
+        want_persist = (self.dt == torch.bfloat16 and 1 <= n_streams <= 32 and D == 512 and model.n_head == 8 and ff == 2048 and model.n_layer <= 15
+                        and model.n_token <= 512 and max_len <= 2048 and self.head_major and persistent
+                        and os.environ.get('EMO_DECODE_PERSISTENT', '1') != '0' and os.environ.get('EMO_GPT2_PERSISTENT', '1') != '0'
+                        and ops.lib.emo_gpt2_decode_step_supported() == 1)
+        rows = self.n_pad if want_persist else n_streams
+        shp = (rows, model.n_head, max_len, D // model.n_head) if self.head_major else (rows, max_len, D)
+        self.kc_all = [torch.zeros(*shp, device=self.dev, dtype=self.dt) for _ in range(model.n_layer)]
+        self.vc_all = [torch.zeros(*shp, device=self.dev, dtype=self.dt) for _ in range(model.n_layer)]
+        self.kc = [t[:n_streams] for t in self.kc_all]             # (rows n .. n_pad: the idle padding streams of the one-launch step)
+        self.vc = [t[:n_streams] for t in self.vc_all]
+        self.persist = None
         self.lens = torch.zeros(n_streams, device=self.dev, dtype=torch.int64)
         # bf16 one-token steps: the Conv1D weights ([in, out]) are transposed ONCE to the k-contiguous layout of the skinny decode GEMM,
         # ln_1 / ln_2 are folded into c_attn / c_fc (emo_hip.h: ln_c1) and the new k / v rows are appended by the attention kernel:
@@ -359,6 +372,117 @@ class GPT2DecodeEngine(_EngineBase):
         self.fold = None
         if self.dt == torch.bfloat16 and n_streams <= 32 and os.environ.get('EMO_DECODE_LN_FOLD', '1') != '0':
             self._prepare_folds()
+        if want_persist:
+            self._prepare_persist()
+
+    # ------------------------------------------------------------------------------------------ one-launch step
+    def _prepare_persist(self):
+        m, ps, dev = self.model, self.ps, self.dev
+        L = m.n_layer
+        mem = torch.arange(32, device=dev)
+        t_qkv = torch.stack([mem, 32 + mem, 64 + mem], 1)            # member (h, j) = 4 h + j: columns 64 h + 16 j .. of q, of k (+ 512), of v (+ 1024)
+        t_one = mem.view(32, 1)
+        t_ffn = (4 * mem).view(32, 1) + torch.arange(4, device=dev).view(1, 4)
+        pk = PerformerDecodeEngine._pack_fragments
+
+        def lin(name):                                               # Conv1D [in, out] -> nn.Linear layout [out, in]
+            return ps.w(name).t().contiguous()
+
+        pf = [m._layer_prefix(l) for l in range(L)]
+        self.persist = {'w': [], 'table': None}
+        for l in range(L):
+            nx = pf[l + 1] if l + 1 < L else pf[0]                   # (the last block's slot is loaded and never applied: this GPT-2 has no ln_f)
+            self.persist['w'].append(dict(
+                wqkv=pk(lin(pf[l] + 'attn.c_attn.weight'), t_qkv, 4), bqkv=ps.f32(pf[l] + 'attn.c_attn.bias'),
+                wo=pk(lin(pf[l] + 'attn.c_proj.weight'), t_one, 4), bo=ps.f32(pf[l] + 'attn.c_proj.bias'),
+                g1=ps.f32(pf[l] + 'ln_2.weight'), be1=ps.f32(pf[l] + 'ln_2.bias'),
+                w1=pk(lin(pf[l] + 'mlp.c_fc.weight'), t_ffn, 4), b1=ps.f32(pf[l] + 'mlp.c_fc.bias'),
+                w2=pk(lin(pf[l] + 'mlp.c_proj.weight'), t_one, 16), b2=ps.f32(pf[l] + 'mlp.c_proj.bias'),
+                g2=ps.f32(nx + 'ln_1.weight'), be2=ps.f32(nx + 'ln_1.bias')))
+        self.persist['ln0'] = torch.cat([ps.f32(pf[0] + 'ln_1.weight'), ps.f32(pf[0] + 'ln_1.bias')]).contiguous()
+        V = m.n_token
+        Vp = (V + 15) // 16 * 16
+        wout = torch.zeros(Vp, m.d_model, device=dev, dtype=torch.bfloat16)
+        wout[:V] = ps.w('dec_out_proj.weight')
+        self.persist['wout'] = pk(wout, torch.arange(Vp // 16, device=dev).view(-1, 1), 4)
+        self.persist['bout'] = ps.f32('dec_out_proj.bias')
+        self.persist['sync'] = torch.zeros(ops.lib.emo_performer_decode_step_workspace_bytes() // 8, device=dev, dtype=torch.int64)   # zeroed ONCE
+        self.persist['logits'] = torch.zeros(self.n_pad, V, device=dev, dtype=torch.float32)
+        if self.n_pad != self.n:                                     # padded inputs of the idle streams: token 0, segment 0, position 0
+            self.persist['tok'] = torch.zeros(self.n_pad, dtype=torch.int64, device=dev)
+            self.persist['seg'] = torch.zeros(self.n_pad, dtype=torch.int64, device=dev)
+            self.persist['pos'] = torch.zeros(self.n_pad, dtype=torch.int64, device=dev)
+
+    def _persist_table(self):
+        """[L][16] device pointers (emo_hip.h: emo_gpt2_decode_step); the caches live as long as the engine."""
+        pp = self.persist
+        if pp['table'] is None:
+            rows = []
+            for l, w in enumerate(pp['w']):
+                rows.append([w['wqkv'].data_ptr(), w['bqkv'].data_ptr(), w['wo'].data_ptr(), w['bo'].data_ptr(), w['g1'].data_ptr(), w['be1'].data_ptr(),
+                             w['w1'].data_ptr(), w['b1'].data_ptr(), w['w2'].data_ptr(), w['b2'].data_ptr(), w['g2'].data_ptr(), w['be2'].data_ptr(),
+                             0, self.kc_all[l].data_ptr(), self.vc_all[l].data_ptr(), 0])
+            pp['table'] = torch.tensor(rows, dtype=torch.int64, device=self.dev)
+        return pp['table']
+
+    def _persist_inputs(self):
+        m = self.model
+        if self._tables is None:
+            self._tables = (engine.embedding_table(self.ps, 'token_emb.'), engine.embedding_table(self.ps, 'segemb.') if m.use_segment_emb else None)
+        E, Sg = self._tables
+        pe = m.pe.pe if m.use_pe else m._zero_pe(self.max_len, m.d_model)
+        return E, Sg, pe
+
+    def _step_persistent(self, tok, seg, dev_pos, logits_out):
+        """Returns `logits_out` when given, else the engine's STATIC logits buffer (or a view of its first n rows), like the Performer engine's."""
+        m, pp = self.model, self.persist
+        E, Sg, pe = self._persist_inputs()
+        seg = seg if (Sg is not None and seg is not None) else None
+        if not dev_pos and self.pos >= min(pe.shape[0], self.max_len):
+            raise EmoError('decode position %d is past the positional-encoding table / the KV cache (%d rows)' % (self.pos, min(pe.shape[0], self.max_len)))
+        pos_ids = self.pos_dev if dev_pos else None
+        padded = self.n_pad != self.n
+        if padded:
+            pp['tok'][:self.n].copy_(tok)
+            tok = pp['tok']
+            if seg is not None:
+                pp['seg'][:self.n].copy_(seg)
+                seg = pp['seg']
+            if pos_ids is not None:
+                pp['pos'][:self.n].copy_(pos_ids)
+                pos_ids = pp['pos']
+        out = logits_out if (logits_out is not None and not padded) else pp['logits']
+        ops.gpt2_decode_step(self._persist_table(), m.n_layer, tok, seg, E, Sg if seg is not None else None, pe, float(m.token_emb.emb_scale),
+                             self.dev_pos0 if dev_pos else self.pos, pos_ids, pp['ln0'], self.max_len, pp['wout'], pp['bout'], m.n_token, out,
+                             self.n_pad, m.d_model, m.n_head, 2048, pp['sync'], diag=pp.get('diag'))
+        if padded:
+            if logits_out is not None:
+                logits_out.copy_(out[:self.n])
+                return logits_out
+            return out[:self.n]
+        return out
+
+    def step_sampled(self, seg_padded, temp, top_p, U, step_ctr, seq, col0, tok_out, pos0):
+        """One token step with the nucleus draw INSIDE the launch (emo_gpt2_decode_step_sampled); see PerformerDecodeEngine.step_sampled."""
+        m, pp = self.model, self.persist
+        E, Sg, pe = self._persist_inputs()
+        seg = seg_padded if Sg is not None else None
+        ops.gpt2_decode_step_sampled(self._persist_table(), m.n_layer, seg, E, Sg if seg is not None else None, pe, float(m.token_emb.emb_scale), pos0,
+                                     pp['ln0'], self.max_len, pp['wout'], pp['bout'], m.n_token, pp['logits'], self.n_pad, self.n, m.d_model, m.n_head,
+                                     2048, pp['sync'], temp, top_p, U, step_ctr, seq, col0, tok_out)
+        return pp['logits'][:self.n]
+
+    def load_logits(self, logits):
+        """Put externally produced logits (the prefill's) where step_sampled draws from."""
+        self.persist['logits'][:self.n].copy_(logits)
+
+    def check_persistent(self):
+        """Raises if a one-launch step gave up (synchronises; call it where the caller reads results anyway)."""
+        if self.persist is not None:
+            code = int(self.persist['sync'][-8].item())
+            if code != 0:
+                raise EmoError('emo_gpt2_decode_step gave up (code 0x%x): a workgroup of the persistent launch did not get a compute unit next to the '
+                               'others within 50 ms (is another process using the GPU?); set EMO_DECODE_PERSISTENT=0 for the chain of launches' % code)
 
     def _prepare_folds(self):
         m, ps = self.model, self.ps
@@ -428,6 +552,15 @@ class GPT2DecodeEngine(_EngineBase):
     def step(self, tok, seg, dev_pos=False, logits_out=None):
         m, ps = self.model, self.ps
         D, H = m.d_model, m.n_head
+        if self.persist is not None:
+            out = self._step_persistent(tok.reshape(-1), None if seg is None else seg.reshape(-1), dev_pos, logits_out)
+            self.lens.add_(1)
+            if dev_pos:
+                if self.pos_auto:
+                    self.pos_dev.add_(1)
+            else:
+                self.pos += 1
+            return out
         x = self._embed(tok.view(-1, 1), None if seg is None else seg.view(-1, 1), self.pos, dev_pos)
         if self.fold is not None:
             if dev_pos and not self.pos_auto:            # positions AND key counts come from the sampler's step counter
@@ -502,7 +635,7 @@ def generate_conditional(model, event2idx, idx2event, lead_sheet_events, primer,
                         # the one-launch step gave up (its workgroups were not all resident within 50 ms): logits and recurrent state of this
                         # engine are void.  Re-run the piece so far through the chain of launches and continue there.
                         note('[gen] %s -> falling back to the chain of launches' % e)
-                        eng = make_engine(model, 1, redraw=False, persistent=False) if model.kind == 'performer' else make_engine(model, 1)
+                        eng = make_engine(model, 1, redraw=False, persistent=False) if model.kind == 'performer' else make_engine(model, 1, persistent=False)
                         s.consumed, cached = 0, None
                         continue
                 probs = temperature(logits_np, temp, inadmissibles=inadmissibles)
@@ -664,7 +797,7 @@ class _Chain:
     def __init__(self, model, ptok, pseg, n_new, U, temp, top_p, greedy, seg_value, redraw, persistent=True):
         self.n, self.T0 = ptok.shape
         n, T0, dev = self.n, self.T0, ptok.device
-        self.eng = make_engine(model, n, redraw=redraw, persistent=persistent) if model.kind == 'performer' else make_engine(model, n)
+        self.eng = make_engine(model, n, redraw=redraw, persistent=persistent) if model.kind == 'performer' else make_engine(model, n, persistent=persistent)
         eng = self.eng
         self.out = torch.empty(n, T0 + n_new, dtype=torch.long, device=dev)
         self.out[:, :T0] = ptok

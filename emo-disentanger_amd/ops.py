@@ -363,6 +363,33 @@ def performer_decode_step_sampled(layer_table, n_layers, seg, E, Sg, pe, emb_sca
     return logits
 
 
+def gpt2_decode_step(layer_table, n_layers, tok, seg, E, Sg, pe, emb_scale, pos0, pos_ids, ln0, kv_tmax, wout_packed, bout, n_token, logits, n_streams,
+                     d_model, n_head, d_ff, sync_ws, ln_eps=1e-5, diag=None):
+    """One GPT-2 token step of every stream in ONE persistent launch (emo_hip.h: emo_gpt2_decode_step)."""
+    tok, seg, pos_ids = _c(tok), _c(seg), _c(pos_ids)
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.shape == (n_streams, n_token)
+    assert ln0.dtype == torch.float32 and ln0.is_contiguous() and ln0.numel() == 2 * d_model
+    check(lib.emo_gpt2_decode_step(ptr(layer_table), n_layers, ptr(tok), ptr(seg), ptr(E), ptr(Sg), ptr(pe), emb_scale, pos0, ptr(pos_ids), ptr(ln0), kv_tmax,
+                                   ptr(wout_packed), ptr(bout), n_token, ptr(logits), n_streams, d_model, n_head, d_ff,
+                                   ptr(sync_ws), sync_ws.numel() * sync_ws.element_size(), ln_eps, ptr(diag), stream()))
+    return logits
+
+
+def gpt2_decode_step_sampled(layer_table, n_layers, seg, E, Sg, pe, emb_scale, pos0, ln0, kv_tmax, wout_packed, bout, n_token, logits, n_streams, n_real,
+                             d_model, n_head, d_ff, sync_ws, temperature, top_p, u_steps, step, seq, col0, tok_out, ln_eps=1e-5):
+    """emo_gpt2_decode_step with the next token drawn inside the launch (emo_hip.h)."""
+    seg = _c(seg)
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.shape == (n_streams, n_token)
+    assert ln0.dtype == torch.float32 and ln0.is_contiguous() and ln0.numel() == 2 * d_model
+    assert u_steps.dtype == torch.float32 and u_steps.is_contiguous() and u_steps.shape[1] == n_real and step.dtype == torch.int64 and tok_out.dtype == torch.int64
+    assert seq is None or (seq.dtype == torch.int64 and seq.stride(1) == 1)
+    check(lib.emo_gpt2_decode_step_sampled(ptr(layer_table), n_layers, ptr(seg), ptr(E), ptr(Sg), ptr(pe), emb_scale, pos0, ptr(ln0), kv_tmax, ptr(wout_packed),
+                                           ptr(bout), n_token, ptr(logits), n_streams, n_real, d_model, n_head, d_ff, ptr(sync_ws),
+                                           sync_ws.numel() * sync_ws.element_size(), ln_eps, temperature, top_p, ptr(u_steps), ptr(step), ptr(seq),
+                                           0 if seq is None else seq.stride(0), col0, ptr(tok_out), stream()))
+    return logits
+
+
 def favor_draw_omega(gauss, omega):
     """gauss [L, nb, dh, dh] ~ N(0,1) -> omega [L, dh, n_feat/2] (orthogonal blocks scaled by row norms)."""
     L, nb, dh, _ = gauss.shape

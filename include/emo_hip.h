@@ -269,6 +269,27 @@ int emo_performer_decode_step_sampled(const void* layer_table, int64_t n_layers,
                                       float temperature, float top_p, const float* u_steps, int64_t* step, int64_t* seq, int64_t ld_seq,
                                       int64_t col0, int64_t* tok_out, emo_stream_t stream);
 
+/* ONE-LAUNCH GPT-2 decode step (r06): the same persistent launch for the GPT-2 backbone (stage2_accompaniment/model/music_gpt2.py -> HF GPT2Block:
+ * pre-LN, gelu_new, no ln_f; token loop of inference.py:250-277 with the KV cache BASELINE configs[3] names).  d_model 512 / 8 heads / d_ff 2048,
+ * n_layers <= 15, n_token <= 512, n_streams <= 32 (a multiple of 4), bf16.  Arguments as emo_performer_decode_step, except:
+ *   layer_table : [n_layers][16] pointers: c_attn packed, bias (f32 [3 d]), attn.c_proj packed, bias, ln_2 gamma, beta, c_fc packed, bias, mlp.c_proj
+ *                 packed, bias, ln_1 gamma, beta OF THE NEXT BLOCK (any valid pointer for the last block), unused, K cache, V cache, unused.
+ *                 Packed = the TRANSPOSED Conv1D weight ([out][in]) in the fragment order of emo_performer_decode_step.
+ *                 K / V cache: bf16 [n_streams][8][kv_tmax][64] (head-major, kv_tmax <= 2048); the step appends the token's key / value row at index
+ *                 pos = pos0 + pos_ids[s] (= the number of rows already cached) and attends over rows 0 .. pos.
+ *   ln0         : f32 [2][512]: gamma | beta of block 0's ln_1. */
+int emo_gpt2_decode_step_supported(void);
+int emo_gpt2_decode_step(const void* layer_table, int64_t n_layers, const int64_t* tok, const int64_t* seg, const float* E, const float* Sg,
+                         const float* pe, float emb_scale, int64_t pos0, const int64_t* pos_ids, const float* ln0, int64_t kv_tmax,
+                         const void* wout_packed, const float* bout, int64_t n_token, float* logits, int64_t n_streams, int64_t d_model,
+                         int64_t n_head, int64_t d_ff, void* sync_ws, int64_t sync_ws_bytes, float ln_eps, int64_t* diag, emo_stream_t stream);
+/* with the next token drawn inside the launch, as emo_performer_decode_step_sampled (row index of the appended key = pos0 + step[r] + 1) */
+int emo_gpt2_decode_step_sampled(const void* layer_table, int64_t n_layers, const int64_t* seg, const float* E, const float* Sg, const float* pe,
+                                 float emb_scale, int64_t pos0, const float* ln0, int64_t kv_tmax, const void* wout_packed, const float* bout,
+                                 int64_t n_token, float* logits, int64_t n_streams, int64_t n_real, int64_t d_model, int64_t n_head, int64_t d_ff,
+                                 void* sync_ws, int64_t sync_ws_bytes, float ln_eps, float temperature, float top_p, const float* u_steps,
+                                 int64_t* step, int64_t* seq, int64_t ld_seq, int64_t col0, int64_t* tok_out, emo_stream_t stream);
+
 /* FAVOR+ omega draw (fast-transformers orthogonal_random_matrix_, called from new_feature_map() on every
  * forward — SURVEY F8): gauss [n_layers, ceil((n_feat/2)/dh), dh, dh] ~ N(0,1) from the caller's RNG ->
  * omega [n_layers, dh, n_feat/2] with orthogonal columns per block scaled by the row norms of the block. */
