@@ -66,9 +66,16 @@ constexpr int PD_WS_WORDS = PD_NG * PD_GSTRIDE + 8;             // last 8 words:
 constexpr int PD_MAX_LAYERS = 15;                               // epoch = launch * 128 + layer * 8 + phase (census: + 127)
 constexpr long long PD_TIMEOUT = 5000000;                       // wall_clock64 ticks (100 MHz): 50 ms for the whole launch
 
+// Everything the table points to is addressed as GLOBAL memory (address space 1), never through flat pointers: a flat load counts on lgkmcnt as well
+// as vmcnt, so every LDS barrier (lgkmcnt(0)) of the wave would wait for its outstanding weight / state / cache loads (r06: found in the ISA — the
+// table's pointers are loaded from memory and hipcc does not infer their address space).
+typedef __attribute__((address_space(1))) bf16_t gbf16_t;
+typedef __attribute__((address_space(1))) bf16x8 gbf16x8;
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) f32x4 gf32x4;
 struct PdLayer {            // one row of the caller's device table: 16 pointers
-    const bf16_t* wqkv; const float* bqkv; const bf16_t* wo; const float* bo; const float* g1; const float* be1; const bf16_t* w1; const float* b1;
-    const bf16_t* w2; const float* b2; const float* g2; const float* be2; const float* omega; float* S; float* z; void* pad;
+    const gbf16_t* wqkv; const gfloat* bqkv; const gbf16_t* wo; const gfloat* bo; const gfloat* g1; const gfloat* be1; const gbf16_t* w1; const gfloat* b1;
+    const gbf16_t* w2; const gfloat* b2; const gfloat* g2; const gfloat* be2; const gfloat* omega; gfloat* S; gfloat* z; void* pad;
 };
 struct PdArgs {
     const PdLayer* layers; int n_layers;
@@ -176,14 +183,14 @@ __device__ __forceinline__ unsigned pd_gather_rows(const gu64* buf, unsigned ep,
 
 // COMPUTE: the wave's share of a member's packed weights: T column tiles x KPW k-steps, one KB (64 lanes x 8 bf16) per fragment, into registers.
 template <int T, int KPW>
-__device__ __forceinline__ void pd_load_w(bf16x8 (&w)[T][KPW], const bf16_t* member_base, const PdCtx& c, int nt) {
-    const bf16_t* p = member_base + (size_t)c.hw * (T * KPW * 512) + c.lane * 8;
+__device__ __forceinline__ void pd_load_w(bf16x8 (&w)[T][KPW], const gbf16_t* member_base, const PdCtx& c, int nt) {
+    const gbf16_t* p = member_base + (size_t)c.hw * (T * KPW * 512) + c.lane * 8;
     if (nt == 2) p = member_base + c.lane * 8;              // TIMING ABLATION ONLY (EMO_PD_NT=2): every fragment from one hot KB — no weight stream, wrong results
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int ks = 0; ks < KPW; ++ks) {
-            const bf16x8* q = (const bf16x8*)(p + (nt == 2 ? 0 : (t * KPW + ks) * 512));
+            const gbf16x8* q = (const gbf16x8*)(p + (nt == 2 ? 0 : (t * KPW + ks) * 512));
             w[t][ks] = nt == 1 ? __builtin_nontemporal_load(q) : *q;
         }
 }
@@ -191,11 +198,11 @@ __device__ __forceinline__ void pd_load_w(bf16x8 (&w)[T][KPW], const bf16_t* mem
 // so that no 48-64 KB burst sits in the CU's memory queue in front of the pollers' loads (r04 diagnostics: first poll 2.0 us behind a burst, 0.2 us
 // without one; the burst's issue itself stalled its wave for ~2 us)
 template <int T, int KPW, int I0, int I1>
-__device__ __forceinline__ void pd_load_w_part(bf16x8 (&w)[T][KPW], const bf16_t* member_base, const PdCtx& c, int nt) {
-    const bf16_t* p = member_base + (size_t)c.hw * (T * KPW * 512) + c.lane * 8;
+__device__ __forceinline__ void pd_load_w_part(bf16x8 (&w)[T][KPW], const gbf16_t* member_base, const PdCtx& c, int nt) {
+    const gbf16_t* p = member_base + (size_t)c.hw * (T * KPW * 512) + c.lane * 8;
 #pragma unroll
     for (int i = I0; i < I1; ++i) {
-        const bf16x8* q = (const bf16x8*)(p + (nt == 2 ? 0 : i * 512));
+        const gbf16x8* q = (const gbf16x8*)(p + (nt == 2 ? 0 : i * 512));
         w[i / KPW][i % KPW] = nt == 1 ? __builtin_nontemporal_load(q) : *q;
     }
 }
@@ -550,12 +557,12 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
 #define PD_LOAD_A1(Lp)                                                                                     \
     do {                                                                                                   \
         pd_load_w_part<3, 4, 4, 8>(wq, (Lp).wqkv + (size_t)m * (PD_HW * 3 * 4 * 512), cc, nt);               \
-        if constexpr (!G2) { _Pragma("unroll") for (int i = 0; i < 4; ++i) om[i] = *(const f32x4*)((Lp).omega + cc.t * 16 + 4 * i); } \
+        if constexpr (!G2) { _Pragma("unroll") for (int i = 0; i < 4; ++i) om[i] = *(const gf32x4*)((Lp).omega + cc.t * 16 + 4 * i); } \
     } while (0)
 #define PD_LOAD_A2(Lp)                                                                                     \
     do {                                                                                                   \
         pd_load_w_part<3, 4, 8, 12>(wq, (Lp).wqkv + (size_t)m * (PD_HW * 3 * 4 * 512), cc, nt);              \
-        ln1v = *(const f32x4*)((cc.t < 128 ? (Lp).g1 : (Lp).be1) + (cc.t & 127) * 4);                      \
+        ln1v = *(const gf32x4*)((cc.t < 128 ? (Lp).g1 : (Lp).be1) + (cc.t & 127) * 4);                     \
     } while (0)
 #define PD_LOAD_A(Lp) do { PD_LOAD_A0(Lp); PD_LOAD_A1(Lp); PD_LOAD_A2(Lp); } while (0)
         {
@@ -595,11 +602,11 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
             PD_SCHED_FENCE();
             // (requested AFTER the publish: a 64-KB burst in front of it held the partial sums back by ~2 us — the issue itself stalls on the full queue)
             // next operand set: P4's FFN1 fragments + bias, and LayerNorm2's parameters for the pollers (handed over through LDS in P4)
-            const bf16_t* w1p = L.w1 + (size_t)m * (PD_HW * 4 * 4 * 512);
+            const gbf16_t* w1p = L.w1 + (size_t)m * (PD_HW * 4 * 4 * 512);
             pd_load_w_part<4, 4, 0, 2>(w1, w1p, cc, nt);
 #pragma unroll
             for (int t = 0; t < 4; ++t) b1[t] = L.b1[m * 64 + t * 16 + lc16];
-            lnv = *(const f32x4*)((cc.t < 128 ? L.g2 : L.be2) + (cc.t & 127) * 4);
+            lnv = *(const gf32x4*)((cc.t < 128 ? L.g2 : L.be2) + (cc.t & 127) * 4);
             PD_SYNC_OR_LEAVE();                                       // 2a
             pd_load_w_part<4, 4, 2, 4>(w1, w1p, cc, nt);
             PD_BARRIER();                                             // 2b
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
                 ln1v = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (has_logits) {                                     // the logits tile reuses the first q/k/v fragment set
                     bf16x8 wl[1][4];
-                    pd_load_w<1, 4>(wl, a.wout + (size_t)m * (PD_HW * 1 * 4 * 512), cc, nt);
+                    pd_load_w<1, 4>(wl, (const gbf16_t*)a.wout + (size_t)m * (PD_HW * 1 * 4 * 512), cc, nt);
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) wq[0][ks] = wl[0][ks];
                     bq[0] = (m * 16 + lc16) < a.n_token ? a.bout[m * 16 + lc16] : 0.f;
@@ -683,11 +690,11 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
         const int64_t sh = ((int64_t)g * PD_GS + jm) * PD_H + hm;     // (stream, head) of this member
 #define PD_LOAD_B(Lp)                                                                                      \
     do {                                                                                                   \
-        pd_load_w<1, 4>(wo, (Lp).wo + (size_t)m * (PD_HW * 1 * 4 * 512), cc, nt);                           \
-        bo[0] = (Lp).bo[m * 16 + lc16];                                                                    \
         if constexpr (!G2) {                                                                               \
-            const float* Sb_ = (Lp).S + sh * (PD_F * PD_DH);                                               \
-            _Pragma("unroll") for (int i = 0; i < 8; ++i) st[i] = *(const f32x4*)(Sb_ + (fg + 16 * i) * PD_DH + d4); \
+            pd_load_w<1, 4>(wo, (Lp).wo + (size_t)m * (PD_HW * 1 * 4 * 512), cc, nt);                       \
+            bo[0] = (Lp).bo[m * 16 + lc16];                                                                \
+            const gfloat* Sb_ = (Lp).S + sh * (PD_F * PD_DH);                                              \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) st[i] = *(const gf32x4*)(Sb_ + (fg + 16 * i) * PD_DH + d4); \
             if (cc.t < PD_F) zold = (Lp).z[sh * PD_F + cc.t];                                              \
         }                                                                                                  \
     } while (0)
@@ -704,67 +711,82 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
             const PdLayer L = LY[l];
             const bool last = l + 1 == L_;
             const unsigned ep = ep0 + (unsigned)l * 8u;
-            float* Sb = L.S + sh * (PD_F * PD_DH);
-            const int64_t sh_kv = sh;
+            gfloat* Sb = L.S + sh * (PD_F * PD_DH);
             PdCtx cc = pd_fresh(c);
             cc.local = c.local;
             const int lc16 = cc.lane & 15, d4 = (cc.t & 15) * 4, fg = cc.t >> 4;      // state mapping: 16 threads per state row, 16 rows per pass, 8 passes
             PD_SYNC_OR_LEAVE();                                       // 1a
             if (!G2 && l > 0) {                                       // (layer 0's slice was requested before the loop)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) st[i] = *(const f32x4*)(Sb + (fg + 16 * i) * PD_DH + d4);
+                for (int i = 0; i < 4; ++i) st[i] = *(const gf32x4*)(Sb + (fg + 16 * i) * PD_DH + d4);
             }
             PD_BARRIER();                                             // 1b
             if (!G2 && l > 0) {
 #pragma unroll
-                for (int i = 4; i < 8; ++i) st[i] = *(const f32x4*)(Sb + (fg + 16 * i) * PD_DH + d4);
+                for (int i = 4; i < 8; ++i) st[i] = *(const gf32x4*)(Sb + (fg + 16 * i) * PD_DH + d4);
                 if (cc.t < PD_F) zold = L.z[sh * PD_F + cc.t];
             }
-            // ---- P2: the recurrent step
+            // ---- P2: the recurrent step  (GPT-2: attention over the KV cache)
+            // GPT-2: thread = (key row rl of a 32-row pass, dims c8 .. c8 + 7); a SWEEP = 8 passes = 256 rows = 8 x 16-B loads per thread, two sweeps (A, B)
+            // in flight.  The first two key sweeps are requested BEFORE the q row arrives (they do not depend on it), the first two value sweeps before the
+            // softmax's two barriers.
+            const int kprev = G2 ? min(s_misc[8 + jm], (int)a.kv_tmax - 1) : 0;      // cached rows; this token's row gets index kprev
+            const int last_c = kprev > 0 ? kprev - 1 : 0;             // rows past the cache: any valid address, the value is replaced / masked
+            const int rl = cc.t >> 3, c8 = (cc.t & 7) * 8;
+            gbf16_t* Kc = (gbf16_t*)L.S + (sh * a.kv_tmax) * PD_DH + c8;
+            gbf16_t* Vc = (gbf16_t*)L.z + (sh * a.kv_tmax) * PD_DH + c8;
+            bf16x8 kA[8], kB[8];
+#define PD_KV_LOAD(dst, base, J0)                                                                          \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                        \
+        const int j_ = (J0) + u * 32 + rl;                                                                 \
+        dst[u] = *(const gbf16x8*)((base) + (int64_t)(j_ < kprev ? j_ : last_c) * PD_DH);                  \
+    }
+            if constexpr (G2) {
+                PD_KV_LOAD(kA, Kc, 0);
+                PD_KV_LOAD(kB, Kc, 256);      // (unconditional: rows past the cache read one hot row — a conditionally defined array stays live across the layer loop)
+            }
             PD_SYNC_OR_LEAVE();                                       // 2a: q | k | v rows (poller wave 0) and omega (half A) staged
             if constexpr (G2) {
                 // softmax attention of (head hm, stream jm) over the stream's cached keys + the row this token appends (the arithmetic of
-                // sattn_decode_kernel): thread = (key row of a 32-row pass, 8 of the 64 dims); scores and the 32 partial V sums live in the omega region
-                const int kprev = s_misc[8 + jm];                     // cached rows; the new row has index kprev
-                bf16_t* Kc = (bf16_t*)L.S + (sh_kv * a.kv_tmax) * PD_DH;
-                bf16_t* Vc = (bf16_t*)L.z + (sh_kv * a.kv_tmax) * PD_DH;
+                // sattn_decode_kernel); scores and the 32 partial V sums live in the omega region
                 float* sc = oml;
                 float* vp = oml + 2048;
-                const int rl = cc.t >> 3, c8 = (cc.t & 7) * 8;
                 bf16x8 kn, vn;
                 float qv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { qv[e] = xq[c8 + e]; kn[e] = (bf16_t)xk[c8 + e]; vn[e] = (bf16_t)xv[c8 + e]; }
                 if (cc.t < 8) {
-                    *(bf16x8*)(Kc + (int64_t)kprev * PD_DH + c8) = kn;
-                    *(bf16x8*)(Vc + (int64_t)kprev * PD_DH + c8) = vn;
+                    *(gbf16x8*)(Kc + (int64_t)kprev * PD_DH) = kn;
+                    *(gbf16x8*)(Vc + (int64_t)kprev * PD_DH) = vn;
                 }
-                const int last_c = kprev > 0 ? kprev - 1 : 0;         // rows past the cache: any valid address, the value is replaced / masked
                 float mx = -3.0e38f;
-                for (int j0 = 0; j0 <= kprev; j0 += 32 * 8) {
-                    bf16x8 kr[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int j = j0 + u * 32 + rl;
-                        kr[u] = *(const bf16x8*)(Kc + (int64_t)(j < kprev ? j : last_c) * PD_DH + c8);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int j = j0 + u * 32 + rl;
-                        const bf16x8 kk = j == kprev ? kn : kr[u];
-                        float d = 0.f;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) d += qv[e] * (float)kk[e];
-                        d = pd_dpp_add(d, 0);
-                        d = pd_dpp_add(d, 1);
-                        d = pd_dpp_add(d, 2);
-                        d *= 0.125f;
-                        if (j <= kprev) {
-                            mx = fmaxf(mx, d);
-                            if ((cc.t & 7) == 0) sc[j] = d;
-                        }
+#define PD_KV_SCORE(src, J0)                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                        \
+        const int j_ = (J0) + u * 32 + rl;                                                                 \
+        const bf16x8 kk = j_ == kprev ? kn : src[u];                                                       \
+        float d = 0.f;                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) d += qv[e] * (float)kk[e];                           \
+        d = pd_dpp_add(d, 0);                                                                              \
+        d = pd_dpp_add(d, 1);                                                                              \
+        d = pd_dpp_add(d, 2);                                                                              \
+        d *= 0.125f;                                                                                       \
+        if (j_ <= kprev) {                                                                                 \
+            mx = fmaxf(mx, d);                                                                             \
+            if ((cc.t & 7) == 0) sc[j_] = d;                                                               \
+        }                                                                                                  \
+    }
+                for (int j0 = 0; j0 <= kprev; j0 += 512) {
+                    PD_KV_SCORE(kA, j0);
+                    if (j0 + 512 <= kprev) { PD_KV_LOAD(kA, Kc, j0 + 512); }
+                    if (j0 + 256 <= kprev) {
+                        PD_KV_SCORE(kB, j0 + 256);
+                        if (j0 + 768 <= kprev) { PD_KV_LOAD(kB, Kc, j0 + 768); }
                     }
                 }
+                PD_SCHED_FENCE();
+                bf16x8 vA[8], vB[8];
+                PD_KV_LOAD(vA, Vc, 0);
+                PD_KV_LOAD(vB, Vc, 256);
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
                 if (cc.lane == 0) dpart[cc.hw] = mx;
@@ -782,20 +804,19 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
                 float acc[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-                for (int j0 = 0; j0 <= kprev; j0 += 32 * 8) {
-                    bf16x8 vr[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int j = j0 + u * 32 + rl;
-                        vr[u] = *(const bf16x8*)(Vc + (int64_t)(j < kprev ? j : last_c) * PD_DH + c8);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int j = j0 + u * 32 + rl;
-                        const bf16x8 vv = j == kprev ? vn : vr[u];
-                        const float pj = j <= kprev ? sc[j] : 0.f;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[e] += pj * (float)vv[e];
+#define PD_KV_ACC(src, J0)                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                        \
+        const int j_ = (J0) + u * 32 + rl;                                                                 \
+        const bf16x8 vv = j_ == kprev ? vn : src[u];                                                       \
+        const float pj = j_ <= kprev ? sc[j_] : 0.f;                                                       \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) acc[e] += pj * (float)vv[e];                         \
+    }
+                for (int j0 = 0; j0 <= kprev; j0 += 512) {
+                    PD_KV_ACC(vA, j0);
+                    if (j0 + 512 <= kprev) { PD_KV_LOAD(vA, Vc, j0 + 512); }
+                    if (j0 + 256 <= kprev) {
+                        PD_KV_ACC(vB, j0 + 256);
+                        if (j0 + 768 <= kprev) { PD_KV_LOAD(vB, Vc, j0 + 768); }
                     }
                 }
                 *(f32x4*)(vp + rl * PD_DH + c8) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
@@ -808,6 +829,11 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
                     o = o / ((npart[0] + npart[1]) + (npart[2] + npart[3]));
                     pd_publish_pair(gs + OFF_E3, jm * (PD_D / 2) + ((hm * PD_DH + cc.t) >> 1), ep + 2u, o, c.t, cc);
                 }
+                // P3's operand set is requested HERE and lands behind the E3 edge (held from the end of the previous layer, or requested between the
+                // sweeps, hipcc spilled it: each spill is a vmcnt(0) in the middle of the sweeps)
+                PD_SCHED_FENCE();
+                pd_load_w<1, 4>(wo, L.wo + (size_t)m * (PD_HW * 1 * 4 * 512), cc, nt);
+                bo[0] = L.bo[m * 16 + lc16];
             } else {
                 {   // projections: thread = (d-half, q | k, projection): 32 of the 64 terms each
                     const int col = cc.t & 63, which = (cc.t >> 6) & 1, hd = cc.t >> 7;
@@ -848,7 +874,7 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
                     for (int i = 0; i < 8; ++i) {
                         const int f = fg + 16 * i;
                         const f32x4 sv = st[i] + fk[f] * vd;
-                        *(f32x4*)(Sb + f * PD_DH + d4) = sv;
+                        *(gf32x4*)(Sb + f * PD_DH + d4) = sv;
                         acc += fq[f] * sv;
                     }
 #pragma unroll
@@ -875,7 +901,7 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
             }
             PD_DIAG(l, 3, 2, PD_NOW());
             PD_SCHED_FENCE();
-            const bf16_t* w2p = L.w2 + (size_t)m * (PD_HW * 1 * 16 * 512);                // next operand set: P5, in three slices
+            const gbf16_t* w2p = L.w2 + (size_t)m * (PD_HW * 1 * 16 * 512);                // next operand set: P5, in three slices
             pd_load_w_part<1, 16, 0, 5>(w2, w2p, cc, nt);
             b2[0] = L.b2[m * 16 + lc16];
             PD_SYNC_OR_LEAVE();                                       // 4a
@@ -895,7 +921,7 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
             }
             PD_DIAG(l, 5, 2, PD_NOW());
             PD_SCHED_FENCE();
-            if (!last) {                                              // next operand set: the next layer's P3 fragments now, its state slice after 1a / 1b
+            if (!G2 && !last) {                                       // next operand set: the next layer's P3 fragments now, its state slice after 1a / 1b
                 pd_load_w<1, 4>(wo, LY[l + 1].wo + (size_t)m * (PD_HW * 1 * 4 * 512), cc, nt);
                 bo[0] = LY[l + 1].bo[m * 16 + lc16];
             }
