@@ -296,10 +296,11 @@ def generation_bench(model, n_streams=32, prompt=64, n_new=2048 - 64, top_p=0.9,
 
 
 def gpt2_generation_bench(n_streams=32, prompt=64, n_new=2048 - 64, top_p=0.9, temp=1.1):
-    """BASELINE configs[3] names a KV cache: the same 32 x 2048 nucleus generation on the GPT-2 backbone (d512 / L12 / H8) — KV cache
-    [n, 2048, 512] x 2 per layer in HBM (bf16), token step = hipGraph-replayed chain of launches (skinny GEMMs with the LayerNorms folded in,
-    sattn_decode over the cache, nucleus sampler).  Roofline: HBM bytes a token step must move = the bf16 weights once + every stream's keys and
-    values of all layers at the step's context length (12 x 2 x ctx x 512 x 2 B), averaged over the generated positions."""
+    """BASELINE configs[3] names a KV cache: the same 32 x 2048 nucleus generation on the GPT-2 backbone (d512 / L12 / H8) — head-major KV cache
+    [n, 8, 2048, 64] x 2 per layer in HBM (bf16), token step = ONE persistent launch (emo_gpt2_decode_step_sampled, r06: nucleus draw, embedding,
+    12 blocks with the softmax attention over the cache, logits), hipGraph-replayed; r05 and EMO_GPT2_PERSISTENT=0: a chain of launches (skinny
+    GEMMs with the LayerNorms folded in, sattn_decode, nucleus sampler).  Roofline: HBM bytes a token step must move = the bf16 weights once +
+    every stream's keys and values of all layers at the step's context length (12 x 2 x ctx x 512 x 2 B), averaged over the generated positions."""
     import contextlib
     from emo_disentanger_amd import inference as inf
     from emo_disentanger_amd.model.music_gpt2 import MusicGPT2
@@ -325,7 +326,10 @@ def gpt2_generation_bench(n_streams=32, prompt=64, n_new=2048 - 64, top_p=0.9, t
             'ms_per_token_step': round(1000 * step_s, 3),
             'roofline': {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4),
                          'algorithmic_bytes_per_step': int(wbytes + kv), 'note': 'weights %.1f MB + KV cache %.1f MB at the mean context of %d tokens' % (wbytes / 1e6, kv / 1e6, ctx)},
-            'engine': 'KV cache [n, 2048, 512] x 2 x 12 layers (bf16) in HBM; token step = hipGraph replay of the launch chain (skinny GEMMs with folded LayerNorms, sattn_decode, nucleus sampler)'}
+            'engine': 'head-major KV cache [n, 8, 2048, 64] x 2 x 12 layers (bf16) in HBM; token step = ' +
+                      ('one persistent launch (emo_gpt2_decode_step_sampled: draw + embedding + 12 blocks + logits), hipGraph-replayed'
+                       if os.environ.get('EMO_GPT2_PERSISTENT', '1') != '0' and os.environ.get('EMO_DECODE_PERSISTENT', '1') != '0'
+                       else 'hipGraph replay of the launch chain (skinny GEMMs with folded LayerNorms, sattn_decode, nucleus sampler)')}
 
 
 def stage1_bench(n_steps=30, B=4, T=512, V=200):

@@ -220,3 +220,30 @@ def test_gpt2_one_launch_step_matches_oracle_full_forward(n, monkeypatch):
     assert e_max <= 0.05 * rng
     assert float(safe.float().mean()) > 0.05
     assert torch.equal(got.argmax(-1)[safe], ref.argmax(-1)[safe])
+
+
+def test_gpt2_one_launch_step_fills_the_cache_to_its_last_row(monkeypatch):
+    """Context up to the 2048-row window (the reference's max_dec_inp_len): the last step appends row 2047 and attends over all 2048 rows (4 full
+    256-row sweeps); one more token does not fit and must be refused, not written past the cache."""
+    from emo_disentanger_amd import inference as inf
+    from emo_disentanger_amd._lib import EmoError
+    g = torch.Generator().manual_seed(31)
+    V, n, L, T0, K = 327, 4, 2, 2042, 6
+    ptok = torch.randint(0, V - 1, (n, T0), generator=g).cuda()
+    pseg = torch.randint(0, 2, (n, T0), generator=g).cuda()
+    toks = torch.randint(0, V - 1, (n, K), generator=g).cuda()
+    segs = torch.randint(0, 2, (n, K), generator=g).cuda()
+    mb, _ = _gpt2(L, 'bf16')
+    one, K1, V1 = _run_gpt2(mb, ptok, pseg, toks, segs, True, monkeypatch)
+    chain, K0, V0 = _run_gpt2(mb, ptok, pseg, toks, segs, False, monkeypatch)
+    rng = float(chain.max() - chain.min())
+    assert float((one - chain).abs().max()) <= 0.02 * rng
+    for a, b in zip(K1 + V1, K0 + V0):
+        assert a.shape[2] == 2048 and float((a.float() - b.float()).norm() / b.float().norm()) <= 1e-2
+    monkeypatch.setenv('EMO_DECODE_PERSISTENT', '1')
+    eng = inf.make_engine(mb, n)
+    eng.prefill(ptok, pseg)
+    for t in range(K):
+        eng.step(toks[:, t], segs[:, t])
+    with pytest.raises(EmoError, match='past the positional-encoding table / the KV cache'):
+        eng.step(toks[:, 0], segs[:, 0])
