@@ -147,6 +147,10 @@ template <> __device__ __forceinline__ void pd_poll<2>(u32x4 (&v)[2], const gu64
     asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(v[0]), "=&v"(v[1]) : "v"(p) : "memory");
 }
+template <> __device__ __forceinline__ void pd_poll<3>(u32x4 (&v)[3], const gu64* p) {
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %3, off offset:16 sc1\n\tglobal_load_dwordx4 %2, %3, off offset:32 sc1\n\t"
+                 "s_waitcnt vmcnt(0)" : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(p) : "memory");
+}
 template <> __device__ __forceinline__ void pd_poll<6>(u32x4 (&v)[6], const gu64* p) {
     asm volatile("global_load_dwordx4 %0, %6, off sc1\n\tglobal_load_dwordx4 %1, %6, off offset:16 sc1\n\t"
                  "global_load_dwordx4 %2, %6, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %6, off offset:48 sc1\n\t"
@@ -190,7 +194,7 @@ __device__ __forceinline__ unsigned pd_gather_rows(const gu64* buf, unsigned ep,
 // E5 (the FFN hidden rows: 4 streams x 2048 values, the one edge whose PAYLOAD matters — r06 diagnostics: first poll pass 3.2 us for 32 KB of
 // {epoch, 2 bf16} granules, ~10 KB / us into a CU) uses DENSE granules {3 bf16 | 16-bit epoch}: a producer wave's 16 columns of a stream are 6
 // granules (5 triples + a single), a member's 64 columns 24, the edge 4 x 32 x 24 = 3072 granules = 24 KB = exactly 6 pairs per poller thread,
-// whose 12 granules are 32 CONSECUTIVE hidden values of one stream (two producer waves' tiles).  The 16-bit epoch wraps every 512 launches; a
+// (pairs of 16-byte loads; see pd_gather_e5).  The 16-bit epoch wraps every 512 launches; a
 // granule is rewritten in every layer of every launch, so a stale value can never carry the expected tag.
 constexpr int PD_E5_GPT = 6;                                  // granules per (member, stream, column tile); 24 per (member, stream)
 __device__ __forceinline__ void pd_publish_triple(gu64* buf, unsigned ep, float v, int col, const PdCtx& c) {
@@ -200,34 +204,33 @@ __device__ __forceinline__ void pd_publish_triple(gu64* buf, unsigned ep, float 
     const unsigned n2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x102, 0xF, 0xF, true);      // same 16-lane row (0 past column 15)
     if (col % 3 == 0) PD_PUBLISH(buf + col / 3, ((u64)(((ep & 0xffffu) << 16) | n2) << 32) | (u64)(mine | (n1 << 16)));
 }
-__device__ __forceinline__ unsigned pd_gather_e5(const gu64* buf, unsigned ep, bf16_t* fh, const PdCtx& c, unsigned code, u64* first_poll = nullptr) {
-    u32x4 g[6];
+// The gather is shared by the pollers AND half A (512 threads, u = 0 .. 511; half A has published its product and requests its next operand set only
+// after this gather, so nothing of its own is in flight in front of the polls): thread u takes the 6 granules of (stream u / 128, member (u % 128) / 4,
+// column tile u % 4) = 16 consecutive hidden values.  The time of a poll pass grows with the loads per thread (8 -> 6 -> 3: 3.2 -> 2.4 -> .. us).
+__device__ __forceinline__ unsigned pd_gather_e5(const gu64* buf, unsigned ep, bf16_t* fh, int u, const PdCtx& c, unsigned code, u64* first_poll = nullptr) {
+    u32x4 g[3];
     const unsigned tag = ep & 0xffffu;
     unsigned spins = 0;
     for (;;) {
         const u64 tp0 = first_poll && spins == 0 ? (u64)wall_clock64() : 0;
-        pd_poll<6>(g, buf + 12 * c.t);
+        pd_poll<3>(g, buf + 6 * u);
         if (first_poll && spins == 0) *first_poll = (u64)wall_clock64() - tp0;
         bool ok = true;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) ok = ok && (g[i][1] >> 16) == tag && (g[i][3] >> 16) == tag;
+        for (int i = 0; i < 3; ++i) ok = ok && (g[i][1] >> 16) == tag && (g[i][3] >> 16) == tag;
         if (__all(ok)) break;
         if (pd_spin_fail(spins, c, code)) return spins;
     }
-    // thread t: stream t / 64, member (t % 64) / 2, column tiles 2 (t & 1), 2 (t & 1) + 1: 32 consecutive hidden values
-    unsigned short h[32];
+    unsigned short h[16];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+    for (int k = 0; k < 6; ++k) {
+        const unsigned lo = g[k >> 1][(k & 1) * 2], hi = g[k >> 1][(k & 1) * 2 + 1];
+        h[3 * k] = (unsigned short)(lo & 0xffffu);
+        if (k < 5) { h[3 * k + 1] = (unsigned short)(lo >> 16); h[3 * k + 2] = (unsigned short)(hi & 0xffffu); }
+    }
+    bf16_t* dst = fh + (u >> 7) * PD_FS + ((u & 127) >> 2) * 64 + (u & 3) * 16;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int gi = 6 * tt + k;
-            const unsigned lo = g[gi >> 1][(gi & 1) * 2], hi = g[gi >> 1][(gi & 1) * 2 + 1];
-            h[16 * tt + 3 * k] = (unsigned short)(lo & 0xffffu);
-            if (k < 5) { h[16 * tt + 3 * k + 1] = (unsigned short)(lo >> 16); h[16 * tt + 3 * k + 2] = (unsigned short)(hi & 0xffffu); }
-        }
-    bf16_t* dst = fh + (c.t >> 6) * PD_FS + ((c.t & 63) >> 1) * 64 + (c.t & 1) * 32;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 2; ++q) {
         u32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (unsigned)h[8 * q + 2 * e] | ((unsigned)h[8 * q + 2 * e + 1] << 16);
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
             PD_DIAG(l, 5, 0, PD_NOW());
             {
                 u64 fp = 0;
-                const unsigned sp = pd_gather_e5(gs + OFF_E5, ep + 4u, fh, c, 0x500u + l, a.diag ? &fp : nullptr);
+                const unsigned sp = pd_gather_e5(gs + OFF_E5, ep + 4u, fh, c.t, c, 0x500u + l, a.diag ? &fp : nullptr);
                 PD_DIAG(l, 6, 0, fp);
                 PD_DIAG(l, 5, 3, sp);
             }
@@ -687,6 +690,8 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
                 pd_publish_triple(gs + OFF_E5 + ((s * PD_GM + m) * 4 + t) * PD_E5_GPT, ep + 4u, G2 ? gelu_new_fast(hv) : fmaxf(hv, 0.f), col, cc);
             }
             PD_DIAG(l, 4, 2, PD_NOW());
+            PD_SCHED_FENCE();
+            pd_gather_e5(gs + OFF_E5, ep + 4u, fh, PD_HT + cc.t, cc, 0x580u + l);      // half A's share of the E5 gather (see pd_gather_e5)
             PD_SCHED_FENCE();
             if (!last) {
                 PD_LOAD_A0(LY[l + 1]);
