@@ -661,22 +661,22 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
             // (requested AFTER the publish: a 64-KB burst in front of it held the partial sums back by ~2 us — the issue itself stalls on the full queue)
             // next operand set: P4's FFN1 fragments + bias, and LayerNorm2's parameters for the pollers (handed over through LDS in P4)
             const gbf16_t* w1p = L.w1 + (size_t)m * (PD_HW * 4 * 4 * 512);
-            pd_load_w_part<4, 4, 0, 2>(w1, w1p, cc, nt);
+            pd_load_w_part<4, 4, 0, 3>(w1, w1p, cc, nt);
 #pragma unroll
             for (int t = 0; t < 4; ++t) b1[t] = L.b1[m * 64 + t * 16 + lc16];
             lnv = *(const gf32x4*)((cc.t < 128 ? L.g2 : L.be2) + (cc.t & 127) * 4);
             PD_SYNC_OR_LEAVE();                                       // 2a
-            pd_load_w_part<4, 4, 2, 4>(w1, w1p, cc, nt);
+            pd_load_w_part<4, 4, 3, 6>(w1, w1p, cc, nt);
             PD_BARRIER();                                             // 2b
-            pd_load_w_part<4, 4, 4, 6>(w1, w1p, cc, nt);
+            pd_load_w_part<4, 4, 6, 9>(w1, w1p, cc, nt);
             PD_BARRIER();                                             // 2c
-            pd_load_w_part<4, 4, 6, 8>(w1, w1p, cc, nt);
+            pd_load_w_part<4, 4, 9, 12>(w1, w1p, cc, nt);
             PD_BARRIER();                                             // 2d
-            pd_load_w_part<4, 4, 8, 10>(w1, w1p, cc, nt);
+            pd_load_w_part<4, 4, 12, 14>(w1, w1p, cc, nt);
             PD_SYNC_OR_LEAVE();                                       // 3a
-            pd_load_w_part<4, 4, 10, 13>(w1, w1p, cc, nt);
+            pd_load_w_part<4, 4, 14, 16>(w1, w1p, cc, nt);
             PD_BARRIER();                                             // 3b
-            pd_load_w_part<4, 4, 13, 16>(w1, w1p, cc, nt);
+            // (no slice behind 3b: the E4 polls start there)
             *(f32x4*)(ln2 + cc.t * 4) = lnv;                           // [gamma | beta]: threads 0..127 gamma, 128..255 beta
             PD_SYNC_OR_LEAVE();                                       // 4a
             const u64 tg4 = a.diag ? PD_NOW() : 0;
@@ -962,12 +962,13 @@ __global__ __launch_bounds__(PD_NT, 3) void pd_step_kernel(PdArgs a) {
             PD_DIAG(l, 3, 2, PD_NOW());
             PD_SCHED_FENCE();
             const gbf16_t* w2p = L.w2 + (size_t)m * (PD_HW * 1 * 16 * 512);                // next operand set: P5, in three slices
-            pd_load_w_part<1, 16, 0, 5>(w2, w2p, cc, nt);
-            b2[0] = L.b2[m * 16 + lc16];
+            // (nothing is requested between the E4 publish and barrier 4a: the pollers' E4 polls queued behind a slice issued here — r06 diagnostics:
+            // first E4 poll pass 1.3 us against 0.4 us for E3, same payload)
             PD_SYNC_OR_LEAVE();                                       // 4a
-            pd_load_w_part<1, 16, 5, 10>(w2, w2p, cc, nt);
+            pd_load_w_part<1, 16, 0, 8>(w2, w2p, cc, nt);
+            b2[0] = L.b2[m * 16 + lc16];
             PD_BARRIER();                                             // 4b
-            pd_load_w_part<1, 16, 10, 16>(w2, w2p, cc, nt);
+            pd_load_w_part<1, 16, 8, 16>(w2, w2p, cc, nt);
             // ---- P5
             PD_SYNC_OR_LEAVE();                                       // 5a
             const u64 tg5 = a.diag ? PD_NOW() : 0;
