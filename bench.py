@@ -290,9 +290,19 @@ def generation_bench(model, n_streams=32, prompt=64, n_new=2048 - 64, top_p=0.9,
     torch.cuda.synchronize()
     single_ms = 1000 * (time.perf_counter() - t1) / 512
     model.train()
+    # roofline: a token step streams the bf16 matrices once for all streams and reads + writes every stream's FAVOR+ state
+    # (12 layers x 8 heads x (128 x 64 + 128) fp32, read and written)
+    wbytes = 2 * sum(p.numel() for n_, p in model.named_parameters() if p.dim() == 2 and 'emb' not in n_)
+    sbytes = n_streams * CFG['n_layer'] * CFG['n_head'] * (CFG['n_feat'] * (CFG['d_model'] // CFG['n_head']) + CFG['n_feat']) * 4 * 2
+    step_s = dt / n_new
+    ach = (wbytes + sbytes) / step_s / 1e9
     return {'metric': 'AR gen tokens/sec, stage2 Performer d512 L12, %d streams, nucleus p=%.2f' % (n_streams, top_p),
             'value': round(n_streams * n_new / dt, 1), 'unit': 'tokens/s', 'streams': n_streams, 'prompt': prompt, 'new_tokens': n_new,
-            'ms_per_token_step': round(1000 * dt / n_new, 3), 'single_stream_ms_per_token': round(single_ms, 3), 'engine': 'FAVOR+ recurrent state in HBM; token step = ONE persistent launch (emo_performer_decode_step_sampled: nucleus draw + embedding + 12 layers + logits), hipGraph replay'}
+            'ms_per_token_step': round(1000 * dt / n_new, 3), 'single_stream_ms_per_token': round(single_ms, 3),
+            'roofline': {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4),
+                         'algorithmic_bytes_per_step': int(wbytes + sbytes),
+                         'note': 'weights %.1f MB + recurrent state read and written %.1f MB per token step; the step is 60 dependent all-gather edges (latency), not bytes' % (wbytes / 1e6, sbytes / 1e6)},
+            'engine': 'FAVOR+ recurrent state in HBM; token step = ONE persistent launch (emo_performer_decode_step_sampled: nucleus draw + embedding + 12 layers + logits), hipGraph replay'}
 
 
 def gpt2_generation_bench(n_streams=32, prompt=64, n_new=2048 - 64, top_p=0.9, temp=1.1):
