@@ -208,17 +208,26 @@ __device__ __forceinline__ void pd_publish_triple(gu64* buf, unsigned ep, float 
 // after this gather, so nothing of its own is in flight in front of the polls): thread u takes the 6 granules of (stream u / 128, member (u % 128) / 4,
 // column tile u % 4) = 16 consecutive hidden values.  The time of a poll pass grows with the loads per thread (8 -> 6 -> 3: 3.2 -> 2.4 -> .. us).
 __device__ __forceinline__ unsigned pd_gather_e5(const gu64* buf, unsigned ep, bf16_t* fh, int u, const PdCtx& c, unsigned code, u64* first_poll = nullptr) {
+    // A thread's 6 granules were written by ONE store instruction of one producer wave: the first pair is polled alone (a pass costs time in
+    // proportion to its loads) and the other two are fetched once it carries the epoch — and re-polled in the rare case they do not yet.
     u32x4 g[3];
     const unsigned tag = ep & 0xffffu;
     unsigned spins = 0;
     for (;;) {
         const u64 tp0 = first_poll && spins == 0 ? (u64)wall_clock64() : 0;
-        pd_poll<3>(g, buf + 6 * u);
+        u32x4 g0[1];
+        pd_poll<1>(g0, buf + 6 * u);
         if (first_poll && spins == 0) *first_poll = (u64)wall_clock64() - tp0;
-        bool ok = true;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) ok = ok && (g[i][1] >> 16) == tag && (g[i][3] >> 16) == tag;
-        if (__all(ok)) break;
+        g[0] = g0[0];
+        if (__all((g[0][1] >> 16) == tag && (g[0][3] >> 16) == tag)) break;
+        if (pd_spin_fail(spins, c, code)) return spins;
+    }
+    for (;;) {
+        u32x4 g12[2];
+        pd_poll<2>(g12, buf + 6 * u + 2);
+        g[1] = g12[0];
+        g[2] = g12[1];
+        if (__all((g[1][1] >> 16) == tag && (g[1][3] >> 16) == tag && (g[2][1] >> 16) == tag && (g[2][3] >> 16) == tag)) break;
         if (pd_spin_fail(spins, c, code)) return spins;
     }
     unsigned short h[16];
