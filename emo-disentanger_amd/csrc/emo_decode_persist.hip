@@ -14,7 +14,8 @@
 //   P3 out-projection + bias + residual (pre-LN row)                                        -> E4
 //   P4 LayerNorm1 (every member normalises the gathered rows itself) + FFN1 + ReLU         -> E5
 //   P5 FFN2 + bias + residual (pre-LN row)                                                  -> E1 (next layer's P1 applies LayerNorm2)
-// An edge is a buffer of 8-byte GRANULES {tag = epoch, value = 2 bf16} written by single agent-scope (sc1) stores and polled with agent-scope
+// An edge is a buffer of 8-byte GRANULES {tag = epoch, value = 2 bf16} (E5, the one large edge, since r06: {3 bf16 | 16-bit epoch}, see
+// pd_publish_triple) written by single agent-scope (sc1) stores and polled with agent-scope
 // loads: the data is the flag, no fences, correct for any workgroup -> XCD placement (MI355X guide, Guideline 16 form R2).  Epochs count
 // launches (a per-group counter the group's member 0 bumps when it is done) x phases, so nothing is zeroed per launch and hipGraph replay
 // works.  A buffer is rewritten one layer later; between two uses lies at least one all-to-all edge, so every reader of the old contents has
@@ -47,6 +48,11 @@
 // gather stays at 2.4-2.8 us whatever precedes it: it is the CU's own L2 -> CU rate); wave roles with evenly sliced loads 0.221 (kernel 181 us = 60 phases x 3.0 us: 0.5-0.9 us of work each, the
 // rest is the wait for the edge behind the CU's weight stream: every XCD streams ALL weights for its 4 streams, 0.8 GB per token step).
 // Workgroup barriers are raw s_barrier + lgkmcnt(0): __syncthreads() carries a vmcnt(0) fence and would drain the HBM loads at every barrier.
+//
+// r06 (tools/pd_diag.py again, profiles/r06_pd_diag.txt, profiles/r06_gpt2_persistent.txt): a poll pass costs time in proportion to its 16-byte sc1
+// loads per thread and queues behind any weight slice requested just before it -> dense E5 granules, the E5 gather shared between the pollers and
+// half A (first granule pair polled alone), no slice between a publish and the barrier behind the next gather: kernel 197.6 -> 164 us per token step;
+// with the weight stream ablated 130 us.  The same kernel as a template also runs the GPT-2 block (KV-cache attention in P2): see the end of the file.
 //
 // Arithmetic mirrors the launch path's bf16 mode (emo_gemm skinny kernel, favor_decode_fast_kernel, layernorm_fwd_bf16_d512_kernel): bf16
 // activations between products, fp32 accumulation, fp32 FAVOR+ state, LayerNorm statistics in fp32 from the bf16 row.
