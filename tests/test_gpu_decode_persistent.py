@@ -257,7 +257,7 @@ def test_gpt2_one_launch_step_refuses_what_it_was_not_built_for():
     ws = torch.zeros(ops.lib.emo_performer_decode_step_workspace_bytes() // 8, dtype=torch.int64, device='cuda')
     lg = torch.zeros(4, 327, device='cuda')
     with pytest.raises(EmoError, match='built for d_model 512'):
-        ops.gpt2_decode_step(zi, 1, zi, None, z, None, z, 1.0, 0, None, z, 2048, z, z, 327, lg, 4, 256, 8, 2048, ws)
+        ops.gpt2_decode_step(zi, 1, zi, None, z, None, z, 1.0, 0, None, z[:512], 2048, z, z, 327, lg, 4, 256, 8, 2048, ws)
     with pytest.raises(EmoError, match='KV cache of <= 2048 rows'):
         ops.gpt2_decode_step(zi, 1, zi, None, z, None, z, 1.0, 0, None, z, 4096, z, z, 327, lg, 4, 512, 8, 2048, ws)
     lg6 = torch.zeros(6, 327, device='cuda')
