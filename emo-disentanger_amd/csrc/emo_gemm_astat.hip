@@ -157,7 +157,7 @@ __device__ __forceinline__ void as_drop8(const DropCtx& d, uint32_t idx0, float 
 template <typename OutT, int FL>
 __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ C, int64_t ub, uint32_t lo, int nb, int ecol, int64_t db, uint32_t dl,
                                         int64_t mb, uint32_t ml, float (&v)[8], const float* bias_lds, uint32_t pre_bits, uint32_t& mask_word, int mask_byte,
-                                        const u32x4& pre_res) {
+                                        const u32x4& pre_res, u32x4* defer = nullptr) {
     // (the bias is already in the accumulators: they START from it)
     constexpr bool G = (FL & AF_GENERIC) != 0;
     if ((FL & AF_GELUAUX) || (G && ep.aux_out)) as_store_row8<OutT>((const OutT*)ep.aux_out + ub, lo, v);      // the pre-activation (gelu backward)
@@ -233,7 +233,16 @@ __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ 
 #ifdef EMO_DIAG
     if (ep.ablate == 1) return;                                   // diagnostics: no output stores
 #endif
-    as_store_row8<OutT>(C + ub, lo, v, ep.nt_store != 0);
+    if constexpr (sizeof(OutT) == 2) {
+        if (defer) {                                              // full-line mode: the caller stores the two halves of a row pair-wise (see the tile epilogue)
+            bf16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+            *defer = __builtin_bit_cast(u32x4, o);
+            return;
+        }
+    }
+    as_store_row8<OutT>(C + ub, lo, v, (ep.nt_store & 1) != 0);
 }
 
 // BITS: the 1-bit mask operand (EMO_MUL_BITMASK, 1 byte per 8 columns) is prefetched by inline-asm loads half a stage before the epilogue.
@@ -399,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
     // address — two loop-invariant VGPRs fewer (at 256 VGPRs a spilled one comes back as scratch_load + s_waitcnt vmcnt(0) = a drained DMA ring)
     const uint32_t eoff0 = (uint32_t)((lane & 15) * ep.ldc + ecol);                                                              // elements
     const uint32_t doff0 = (uint32_t)((lane & 15) * N + ecol);
+    const uint32_t floff0 = (uint32_t)((lane & 7) * ep.ldc + ecol + ((lane >> 3) & 1) * 32);      // full-line mode: row lane % 8 (+ 8), half (lane / 8) % 2
     // hdiv (emo_hip.h): divisor of row m and column block j at ((m / T) * (N / 64) + j) * T + m % T; a wave's 32 rows share m / T (T % 32 == 0)
     const int64_t hbase = HDIV ? ((m0 / ep.hdiv_T) * n_tiles_all + nt0) * ep.hdiv_T + (m0 % ep.hdiv_T) : 0;
 #ifdef EMO_DIAG
@@ -485,8 +495,10 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
         if (HDIV) { as_pinw<4>(preh[0]); as_pinw<4>(preh[1]); }
         if (RESP) as_pin<4>(pres);
         uint32_t mask_word = 0;
+        constexpr bool full_line = sizeof(OutT) == 2 && !(FL & AF_GENERIC);      // bf16 straight-line instances: full-line output stores (below)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+            u32x4 piece[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 float v[8] = {acc[i][2 * h][0], acc[i][2 * h][1], acc[i][2 * h][2], acc[i][2 * h][3],
@@ -500,9 +512,33 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                 const int64_t m0s = m0;
 #endif
                 as_epi8<OutT, FL>(ep, C, (m0s + 16 * i) * ep.ldc + nb, lo, nb, ecol, (m0 + 16 * i) * N + nb, doff0, mtile0 + nt * 256, (uint32_t)lane, v, bias_lds,
-                                    HDIV ? preh[i] : (prew >> (8 * (i * 2 + h))) & 0xFFu, mask_word, i * 2 + h, pres[i * 2 + h]);
+                                    HDIV ? preh[i] : (prew >> (8 * (i * 2 + h))) & 0xFFu, mask_word, i * 2 + h, pres[i * 2 + h], full_line ? &piece[h] : nullptr);
                 __builtin_amdgcn_sched_barrier(0);               // one 8-column group at a time: keeps the epilogue's temporaries out of the register peak
             }
+            if constexpr (sizeof(OutT) == 2) {
+                if constexpr (full_line) {
+                    // FULL-LINE stores (r06): a lane's two 16-B pieces of a row (columns 8 g .. and 32 + 8 g ..) sit 64 B apart, so each of the two store
+                    // instructions of a row tile wrote 16 HALF lines.  Lanes r and r + 8 of a 16-lane row (rows r, r + 8 of the tile) swap one piece (DPP
+                    // row_ror:8): the first instruction then writes rows 0-7 complete (8 lanes x 16 B = the 128-B line of the tile row), the second rows
+                    // 8-15.  Same-box in the training step (EMO_ASTAT_FULL 0 / 1 of the run-time-switched build): K = 512 class 13.78 -> 13.32 ms,
+                    // step 44.67 -> 44.38 ms.
+                    const bool lowr = (lane & 8) == 0;
+                    u32x4 X, R, SA, SB;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        X[e] = lowr ? piece[1][e] : piece[0][e];
+                        R[e] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[e], 0x128, 0xF, 0xF, true);
+                        SA[e] = lowr ? piece[0][e] : R[e];
+                        SB[e] = lowr ? R[e] : piece[1][e];
+                    }
+                    uint32_t la = floff0;
+                    asm volatile("" : "+v"(la));
+                    const OutT* cb = C + (m0 + 16 * i) * ep.ldc + (int64_t)(nt0 + nt) * AS_BN;
+                    if (ep.nt_store & 1) { as_store16_nt(cb, la * 2, SA); as_store16_nt(cb, (la + 8 * (uint32_t)ep.ldc) * 2, SB); }
+                    else { as_store16(cb, la * 2, SA); as_store16(cb, (la + 8 * (uint32_t)ep.ldc) * 2, SB); }
+                }
+            }
+        }
         if ((FL & AF_MASKOUT) || ((FL & AF_GENERIC) && ep.mask_out)) as_store4(ep.mask_out + mtile0 + nt * 256, (uint32_t)lane * 4, mask_word);
 #ifdef EMO_DIAG
         t_epi += __builtin_readcyclecounter() - te0;
