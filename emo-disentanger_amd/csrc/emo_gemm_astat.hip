@@ -157,10 +157,22 @@ __device__ __forceinline__ void as_drop8(const DropCtx& d, uint32_t idx0, float 
 template <typename OutT, int FL>
 __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ C, int64_t ub, uint32_t lo, int nb, int ecol, int64_t db, uint32_t dl,
                                         int64_t mb, uint32_t ml, float (&v)[8], const float* bias_lds, uint32_t pre_bits, uint32_t& mask_word, int mask_byte,
-                                        const u32x4& pre_res, u32x4* defer = nullptr) {
+                                        const u32x4& pre_res, u32x4* defer = nullptr, u32x4* defer_aux = nullptr) {
     // (the bias is already in the accumulators: they START from it)
     constexpr bool G = (FL & AF_GENERIC) != 0;
-    if ((FL & AF_GELUAUX) || (G && ep.aux_out)) as_store_row8<OutT>((const OutT*)ep.aux_out + ub, lo, v);      // the pre-activation (gelu backward)
+    if ((FL & AF_GELUAUX) || (G && ep.aux_out)) {                // the pre-activation (gelu backward)
+        bool stored = false;
+        if constexpr (sizeof(OutT) == 2) {
+            if (defer_aux) {
+                bf16x8 o;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+                *defer_aux = __builtin_bit_cast(u32x4, o);
+                stored = true;
+            }
+        }
+        if (!stored) as_store_row8<OutT>((const OutT*)ep.aux_out + ub, lo, v);
+    }
     if ((FL & AF_RELU) || (G && ep.act == EMO_ACT_RELU)) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v[i]), 0));   // one v_max_i32: same bits as fmaxf(v, 0) for every non-NaN v (fmaxf = canonicalise + v_max_f32)
@@ -498,7 +510,8 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
         constexpr bool full_line = sizeof(OutT) == 2 && !(FL & AF_GENERIC);      // bf16 straight-line instances: full-line output stores (below)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            u32x4 piece[2];
+            u32x4 piece[2], piece_aux[2];
+            constexpr bool full_aux = full_line && (FL & AF_GELUAUX) != 0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 float v[8] = {acc[i][2 * h][0], acc[i][2 * h][1], acc[i][2 * h][2], acc[i][2 * h][3],
@@ -512,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                 const int64_t m0s = m0;
 #endif
                 as_epi8<OutT, FL>(ep, C, (m0s + 16 * i) * ep.ldc + nb, lo, nb, ecol, (m0 + 16 * i) * N + nb, doff0, mtile0 + nt * 256, (uint32_t)lane, v, bias_lds,
-                                    HDIV ? preh[i] : (prew >> (8 * (i * 2 + h))) & 0xFFu, mask_word, i * 2 + h, pres[i * 2 + h], full_line ? &piece[h] : nullptr);
+                                    HDIV ? preh[i] : (prew >> (8 * (i * 2 + h))) & 0xFFu, mask_word, i * 2 + h, pres[i * 2 + h], full_line ? &piece[h] : nullptr, full_aux ? &piece_aux[h] : nullptr);
                 __builtin_amdgcn_sched_barrier(0);               // one 8-column group at a time: keeps the epilogue's temporaries out of the register peak
             }
             if constexpr (sizeof(OutT) == 2) {
@@ -536,6 +549,18 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                     const OutT* cb = C + (m0 + 16 * i) * ep.ldc + (int64_t)(nt0 + nt) * AS_BN;
                     if (ep.nt_store & 1) { as_store16_nt(cb, la * 2, SA); as_store16_nt(cb, (la + 8 * (uint32_t)ep.ldc) * 2, SB); }
                     else { as_store16(cb, la * 2, SA); as_store16(cb, (la + 8 * (uint32_t)ep.ldc) * 2, SB); }
+                    if constexpr (full_aux) {                     // the pre-activation rows of the GPT-2 MLP likewise
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            X[e] = lowr ? piece_aux[1][e] : piece_aux[0][e];
+                            R[e] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[e], 0x128, 0xF, 0xF, true);
+                            SA[e] = lowr ? piece_aux[0][e] : R[e];
+                            SB[e] = lowr ? R[e] : piece_aux[1][e];
+                        }
+                        const OutT* ab = (const OutT*)ep.aux_out + (m0 + 16 * i) * ep.ldc + (int64_t)(nt0 + nt) * AS_BN;
+                        as_store16(ab, la * 2, SA);
+                        as_store16(ab, (la + 8 * (uint32_t)ep.ldc) * 2, SB);
+                    }
                 }
             }
         }
