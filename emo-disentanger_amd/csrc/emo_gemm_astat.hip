@@ -48,6 +48,8 @@ template <> __device__ __forceinline__ void as_wait<6>() { asm volatile("s_waitc
 template <> __device__ __forceinline__ void as_wait<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 template <> __device__ __forceinline__ void as_wait<12>() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
 template <> __device__ __forceinline__ void as_wait<16>() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+template <> __device__ __forceinline__ void as_wait<9>() { asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }
+template <> __device__ __forceinline__ void as_wait<13>() { asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); }
 
 // Epilogue operands (residual / mask rows) are fetched by inline-asm loads half a stage before the epilogue: hipcc does not see
 // them, so it cannot answer them with the `s_waitcnt vmcnt(0)` that would drain the DMA ring at every column tile; the counted
@@ -134,6 +136,10 @@ __device__ __forceinline__ void as_unpack8(const u32x4& r, float (&t)[8]) {
 // reads, 5 no MFMAs, 6 no epilogue, 7 every block stores to the same 256 rows (output stays in the L2).  r05, 131072 rows, isolated launches:
 // FFN2 dgrad (bit mask, N = 2048) 330 us; no MFMAs 316; no epilogue 220; no stores 223; stores kept in the L2 268 — the kernel is paced by
 // its epilogue and by draining 537 MB of output (1.6 TB/s while it runs), not by the MFMA pipe: without a single MFMA it is 4 % faster.
+// r06 (tools/astat_ablate.py, tools/astat_cycles.py on the full-line-store build; FFN1 forward with ReLU + dropout + mask, isolated launches of the
+// diagnostics build): 431 us; no MFMAs 297; no epilogue 275 — the MFMA stages and the epilogues of the two waves of a SIMD hardly overlap (the column tile
+// takes a wave 15.3 k cycles, 8.2 k of them in the epilogue whose VALU content is ~1.7 k); starting the second workgroup of a CU 2-12 k cycles out of
+// phase changes nothing (362-370 us in the product build).
 // The same with the two groups of a CU made one 8-wave workgroup that alternates stages and epilogue quarters at shared barriers
 // ("ping-pong", built and measured in r05): 294 -> 314 us (FFN1 forward), 324 -> 349 (FFN2 dgrad): dropped.
 // The epilogue is specialised at COMPILE time (FL = feature flags): with run-time `ep.*` tests the column-tile epilogue was ~650 lines of
@@ -267,6 +273,10 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
     constexpr bool HDIV = (FL & AF_HDIV) != 0;                    // two divisor words per lane and column tile (rows lane % 16 and + 16), fetched like the mask word
     // residual rows (AF_RES) or pre-activation rows (AF_DGELU) of the column tile prefetched like the mask word
     constexpr bool RESP = ((FL & AF_RES) != 0 || (FL & (AF_DGELU | AF_RES)) == AF_DGELU) && (FL & AF_GENERIC) == 0 && sizeof(OutT) == 2;
+    // VMEM operations of a column tile's epilogue when they are all inline-asm stores (no load the compiler would wait for): 4 output stores, the mask
+    // word, 4 pre-activation stores
+    constexpr bool RELAX = sizeof(OutT) == 2 && (FL & AF_GENERIC) == 0 && (FL & (AF_DGELU | AF_RES)) != (AF_DGELU | AF_RES);
+    constexpr int NE = 4 + ((FL & AF_MASKOUT) ? 1 : 0) + ((FL & AF_GELUAUX) ? 4 : 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [4 slots x 16 KB ring][bias: N floats]
     float* bias_lds = (float*)(smem + AS_RING);                   // bias (or zeros): the accumulators of every column tile start from it
     const int tid = threadIdx.x, lane = tid & 63;
@@ -463,6 +473,12 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                         as_wait<8>();
                     } else if (RESP && kc == 3) {
                         as_wait<8>();                             // stage s+1 landed; behind it: the residual rows and stage s+2
+                    } else if (RELAX && kc < 2 && nt > 0) {
+                        // the two waits behind an epilogue: its NE output stores are YOUNGER than the stage these waits are for and may stay in flight too.
+                        // (vmcnt retires in order: with vmcnt(4) here the first wait behind an epilogue also waited for the stage issued half a stage
+                        // before it and — with a mask or second output — for the first stores, the second one for every store: the stores had half a
+                        // stage to one stage to be acknowledged; now two and a half)
+                        as_wait<4 + NE>();
                     } else {
 #ifdef EMO_DIAG
                         if (ep.ablate != 2)
@@ -529,6 +545,9 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                 __builtin_amdgcn_sched_barrier(0);               // one 8-column group at a time: keeps the epilogue's temporaries out of the register peak
             }
             if constexpr (sizeof(OutT) == 2) {
+#ifdef EMO_DIAG
+                if (ep.ablate == 1) continue;                     // diagnostics: no output stores
+#endif
                 if constexpr (full_line) {
                     // FULL-LINE stores (r06): a lane's two 16-B pieces of a row (columns 8 g .. and 32 + 8 g ..) sit 64 B apart, so each of the two store
                     // instructions of a row tile wrote 16 HALF lines.  Lanes r and r + 8 of a 16-lane row (rows r, r + 8 of the tile) swap one piece (DPP
