@@ -179,7 +179,33 @@ __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ 
         }
         if (!stored) as_store_row8<OutT>((const OutT*)ep.aux_out + ub, lo, v);
     }
-    if ((FL & AF_RELU) || (G && ep.act == EMO_ACT_RELU)) {
+    // ReLU + dropout (+ the 1-bit mask) of the FFN1 forward in ONE select per element (r06): keep = (v > 0) & (dropout field >= threshold) as a 64-bit lane
+    // mask (two v_cmp + one SALU and), out = keep ? v * scale : 0 (v_mul + v_cndmask on the mask), mask bit shifted into the tile's word by ONE
+    // v_addc_co_u32 (acc = 2 acc + keep): 5 VALU per element where max / cmp / cndmask / mul and cmp / cndmask / or took 7 — an epilogue instruction
+    // costs a wave ~20 cycles next to the other wave's MFMA stages (tools/astat_cycles.py, profiles/r06_valu_mfma_overlap.txt).  Same bits as the
+    // separate steps for every non-NaN v (v > 0 and kept <=> max(v, 0) * mult != 0).
+    constexpr bool FUSED_RD = (FL & (AF_RELU | AF_DROP)) == (AF_RELU | AF_DROP) && !G && !(FL & (AF_HDIV | AF_BITS | AF_DGELU | AF_GELUAUX));      // (dropout alone keeps as_drop8: its packed multiplies are fewer instructions — 331 against 363 for the out-projection forward)
+    if constexpr (FUSED_RD) {
+        const DropCtx& d = ep.drop;
+        const uint32_t idx0 = (uint32_t)db + dl;
+        // the two 16-bit fields of a hash word are compared IN PLACE: high field >= thr <=> word >= thr << 16; low field by an SDWA compare of WORD_0
+        uint32_t hw[4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { hw[2 * q] = emo_drop_hash(d, (idx0 >> 2) + q); hw[2 * q + 1] = emo_xs32(hw[2 * q]); }
+        const uint32_t thr_hi = d.thr16 << 16;
+        uint32_t thr_v = d.thr16;
+        asm volatile("" : "+v"(thr_v));                               // (SDWA takes its second source from a VGPR)
+#pragma unroll
+        for (int i = 7; i >= 0; --i) {                               // (descending: the first element of the group ends in the byte's bit 0)
+            uint64_t kd;
+            if (i & 1) kd = __builtin_amdgcn_uicmp(hw[i >> 1], thr_hi, 35 /* uge */);
+            else asm volatile("v_cmp_ge_u32_sdwa %0, %1, %2 src0_sel:WORD_0 src1_sel:DWORD" : "=s"(kd) : "v"(hw[i >> 1]), "v"(thr_v));
+            const uint64_t k = __builtin_amdgcn_fcmpf(v[i], 0.f, 2 /* ogt */) & kd;      // two v_cmp into SGPR pairs + s_and_b64
+            const float sv = v[i] * d.scale;
+            asm volatile("v_cndmask_b32 %0, 0, %1, %2" : "=v"(v[i]) : "v"(sv), "s"(k));
+            if constexpr ((FL & AF_MASKOUT) != 0) asm volatile("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(mask_word) : "s"(k) : "vcc");
+        }
+    } else if ((FL & AF_RELU) || (G && ep.act == EMO_ACT_RELU)) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v[i]), 0));   // one v_max_i32: same bits as fmaxf(v, 0) for every non-NaN v (fmaxf = canonicalise + v_max_f32)
     } else if (FL & AF_GELUAUX) {
@@ -222,7 +248,8 @@ __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ 
             v[4 + i] *= (ep.mul_mode == EMO_MUL_NONZERO) ? (t1[i] != 0.f ? ep.mul_scale : 0.f) : dgelu_new_o<OutT>(t1[i]);
         }
     }
-    if (FL & AF_DROP) as_drop8(ep.drop, (uint32_t)db + dl, v);
+    if constexpr (FUSED_RD) {
+    } else if (FL & AF_DROP) as_drop8(ep.drop, (uint32_t)db + dl, v);
     else if (G && ep.drop.thr16) {
         float d0[4], d1[4];
         drop_mult4(ep.drop, (uint64_t)db + dl, d0);
@@ -230,7 +257,8 @@ __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[i] *= d0[i]; v[4 + i] *= d1[i]; }
     }
-    if ((FL & AF_MASKOUT) || (G && ep.mask_out)) {               // 1 bit per output: (value after act / dropout) != 0
+    if constexpr (FUSED_RD) {                                     // (mask bits already shifted into mask_word: the caller reverses the four bytes)
+    } else if ((FL & AF_MASKOUT) || (G && ep.mask_out)) {               // 1 bit per output: (value after act / dropout) != 0
         uint32_t bits = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) bits |= (v[i] != 0.f ? 1u : 0u) << i;
@@ -583,6 +611,8 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
                 }
             }
         }
+        if constexpr ((FL & (AF_RELU | AF_DROP | AF_MASKOUT)) == (AF_RELU | AF_DROP | AF_MASKOUT) && !(FL & (AF_GENERIC | AF_HDIV | AF_BITS | AF_DGELU | AF_GELUAUX)))
+            mask_word = __builtin_bswap32(mask_word);           // the fused ReLU + dropout path shifted the groups in: group 0 sits in the top byte
         if ((FL & AF_MASKOUT) || ((FL & AF_GENERIC) && ep.mask_out)) as_store4(ep.mask_out + mtile0 + nt * 256, (uint32_t)lane * 4, mask_word);
 #ifdef EMO_DIAG
         t_epi += __builtin_readcyclecounter() - te0;
