@@ -200,7 +200,7 @@ __device__ __forceinline__ void as_epi8(const EpiParams& ep, OutT* __restrict__ 
             uint64_t kd;
             if (i & 1) kd = __builtin_amdgcn_uicmp(hw[i >> 1], thr_hi, 35 /* uge */);
             else asm volatile("v_cmp_ge_u32_sdwa %0, %1, %2 src0_sel:WORD_0 src1_sel:DWORD" : "=s"(kd) : "v"(hw[i >> 1]), "v"(thr_v));
-            const uint64_t k = __builtin_amdgcn_fcmpf(v[i], 0.f, 2 /* ogt */) & kd;      // two v_cmp into SGPR pairs + s_and_b64
+            const uint64_t k = __builtin_amdgcn_fcmpf(v[i], 0.f, 10 /* ugt: a NaN stays a NaN where it is kept */) & kd;      // two v_cmp into SGPR pairs + s_and_b64
             const float sv = v[i] * d.scale;
             asm volatile("v_cndmask_b32 %0, 0, %1, %2" : "=v"(v[i]) : "v"(sv), "s"(k));
             if constexpr ((FL & AF_MASKOUT) != 0) asm volatile("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(mask_word) : "s"(k) : "vcc");
